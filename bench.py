@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of AGCN forward+backward at (N,C,T,V,M) = (64,3,300,25,2) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one train-mode forward + backward (CrossEntropy, gradients for all 3.47 M parameters) of the
+10-block AGCN (fusion_gcn_amd.models.mmargcn.agcn.Model, NTU-RGB-D graph, 60 classes) over the GLOBAL batch of
+64 synthetic clips, already resident in HBM; with N > 1 the batch is sharded over the ranks (8 clips per GPU at
+N = 8: strong scaling, per-replica BatchNorm) and the step includes the single RCCL all-reduce of the flat
+gradient buffer.  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline      the dominant kernel (9x1 temporal-conv row GEMM on the f32 MFMA), timed live with HIP events on
+                the stream it runs on, against the f32 matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  cpu_baseline  the CPU oracle (oracle/agcn_oracle.py = stock-torch restatement of the reference model) timed on
+                this box's host cores on a bounded sample of the same workload (N = 4 clips).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
+SHAPE = dict(N=64, M=2, T=300, V=25, C=3, classes=60)
+
+
+def block_table():
+    plan, cin = [], SHAPE["C"]
+    for i, cout in enumerate([64] * 4 + [128] * 3 + [256] * 3):
+        plan.append((cin, cout, 2 if i in (4, 7) else 1, i != 0))
+        cin = cout
+    return plan
+
+
+def algorithmic_costs(n_clips: int):
+    """FLOPs and HBM bytes of fwd+bwd for n_clips clips (SURVEY.md §8d formulas; bwd = 2x fwd)."""
+    B, T, V = n_clips * SHAPE["M"], SHAPE["T"], SHAPE["V"]
+    flops = byts = 0.0
+    for cin, cout, s, res in block_table():
+        ic, Tp = cout // 4, (T - 1) // s + 1
+        down = cin != cout
+        conv_res = res and (down or s != 1)
+        f = B * T * V * (12 * cin * ic + 6 * V * cin + 6 * cin * cout + (2 * cin * cout if down else 0))
+        f += 6 * V * V * ic * T * B
+        f += B * Tp * V * (18 * cout * cout + (2 * cin * cout if conv_res else 0))
+        flops += 3 * f
+        byts += 4 * B * V * (3 * cin * T + 5 * cout * T + 2 * cout * Tp)
+        T = Tp
+    return flops, byts
+
+
+def build_model(device):
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    torch.manual_seed(1)
+    model = Model((SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"]), SHAPE["classes"],
+                  Graph(ntu.skeleton_edges, center_joint=ntu.center_joint))
+    # the reference initialises the gcn BatchNorm scale and adj_b at 1e-6 (blocks start as near-identities); use O(1)
+    # values so every kernel sees realistic magnitudes (timing does not depend on them, ReLU sparsity does slightly)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("gcn1.bn.weight"):
+                p.fill_(1.0)
+    return model.to(device).train()
+
+
+def time_dominant_kernel(device, b_local: int, reps: int = 10):
+    """Live HIP-event timing of the temporal-conv row GEMM (the kernel with the largest share of the step) at the
+    three channel widths of the model; returns per-launch algorithmic FLOPs and mean duration of the heaviest one."""
+    from fusion_gcn_amd import ops
+    out = []
+    T = SHAPE["T"]
+    for c, t in ((64, T), (128, (T - 1) // 2 + 1), (256, ((T - 1) // 2) // 2 + 1)):
+        x = torch.randn(b_local, t, SHAPE["V"], c, device=device)
+        w = torch.randn(9, c, c, device=device) * (9 * c) ** -0.5
+        y = torch.empty_like(x)
+        tm = ops.conv_tmap(9, 1)
+        for _ in range(2):
+            ops.rows_gemm(x, w, y, K=c, N=c, tmap=tm, stats=True)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()                      # our launches go to torch's current stream: the events see them
+        for _ in range(reps):
+            ops.rows_gemm(x, w, y, K=c, N=c, tmap=tm, stats=True)
+        end.record()
+        end.synchronize()
+        ms = start.elapsed_time(end) / reps
+        flops = 2.0 * b_local * t * SHAPE["V"] * 9 * c * c
+        byts = 4.0 * b_local * t * SHAPE["V"] * 2 * c
+        out.append(dict(channels=c, ms=ms, flops=flops, bytes=byts, tflops=flops / ms / 1e9))
+    return out
+
+
+def cpu_baseline(n_clips: int = 4, iters: int = 2):
+    """Reported baseline, not the target: the oracle model, fwd+bwd, on the host cores of this box."""
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from oracle import agcn_oracle as O
+    from oracle import filler, graph_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    adj = graph_oracle.spatial_partition_stack(ntu.skeleton_edges)
+    sd = O.new_state_dict((SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"]), SHAPE["classes"], adj)
+    for k in list(sd):
+        if not k.endswith("adj_a"):
+            sd[k] = torch.from_numpy(filler.fill_value_for(k, tuple(sd[k].shape))).reshape(sd[k].shape).to(sd[k].dtype)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n_clips, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"], generator=g)
+    y = torch.randint(0, SHAPE["classes"], (n_clips,), generator=g)
+    O.loss_and_grads(x, y, sd)              # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        O.loss_and_grads(x, y, sd)
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=n_clips / dt, unit="clips/s", cores=cores, kind="port",
+                sample=f"oracle (stock-torch restatement of the reference model) fwd+bwd, {n_clips} clips of the same "
+                       f"(C,T,V,M)=(3,300,25,2) workload, 1 warm-up + {iters} timed iterations, {dt:.2f} s/iter")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=SHAPE["N"], help="GLOBAL clip batch (sharded over ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
+    model = build_model(device)
+    broadcast_parameters(model)
+    grads = FlatGradients(model.parameters())
+
+    n_global = args.batch
+    shard = shard_batch(n_global, rank, world)
+    g = torch.Generator().manual_seed(1)
+    x_all = torch.randn(n_global, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"], generator=g)
+    y_all = torch.randint(0, SHAPE["classes"], (n_global,), generator=g)
+    x = x_all[shard].to(device).contiguous()      # resident in HBM before the timed region
+    y = y_all[shard].to(device)
+    del x_all
+
+    def step():
+        grads.zero()
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        grads.all_reduce_mean()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+
+    kern = None if args.no_kernel_timing else time_dominant_kernel(device, (shard.stop - shard.start) * SHAPE["M"])
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        clips_per_s = n_global * args.steps / elapsed
+        flops, byts = algorithmic_costs(n_global)
+        out = {
+            "metric": "clips/sec (N,C,T,V,M)=(64,3,300,25,2) fwd+bwd",
+            "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
+                                   "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
+                                   % n_global,
+                       "global_batch": n_global, "per_gpu_batch": shard.stop - shard.start,
+                       "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+            "step_fractions": {
+                "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                "hbm": round(byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4),
+                "algorithmic_gflop_per_clip": round(flops / n_global / 1e9, 2),
+                "algorithmic_mb_per_clip": round(byts / n_global / 1e6, 2)},
+        }
+        if kern:
+            dom = max(kern, key=lambda k: k["ms"])
+            out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                               "traffic": None,
+                               "kernel": f"rows_gemm_kernel (9x1 temporal conv, {dom['channels']} channels)",
+                               "ms_per_launch": round(dom["ms"], 4),
+                               "flop_per_launch": dom["flops"],
+                               "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
+                                              for d in kern]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

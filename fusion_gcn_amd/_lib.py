@@ -1,0 +1,87 @@
+"""ctypes binding of libfgcn.so (the C ABI declared in include/fgcn.h).
+
+No fallback: if the library is missing or the device is not gfx950 every entry point raises.  Build it with
+``python -m fusion_gcn_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfgcn.so")
+
+c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class TMap(C.Structure):
+    """fgcn_tmap: ti = (to*ta + j*tb + tc) / td."""
+    _fields_ = [("taps", C.c_int), ("ta", C.c_int), ("tb", C.c_int), ("tc", C.c_int), ("td", C.c_int)]
+
+
+class MixTerm(C.Structure):
+    _fields_ = [("mat", C.c_short), ("transpose", C.c_short), ("in_c_lo", C.c_short), ("in_c_hi", C.c_short),
+                ("mask", C.c_short)]
+
+
+class MixItem(C.Structure):
+    _fields_ = [("out_c", C.c_short), ("width", C.c_short), ("nterms", C.c_short), ("term", MixTerm * 3)]
+
+
+class GramItem(C.Structure):
+    _fields_ = [("c1", C.c_short), ("c2", C.c_short), ("width", C.c_short), ("mat", C.c_short)]
+
+
+_I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/fgcn.h one to one
+SIGNATURES = {
+    "fgcn_version": (_I, []),
+    "fgcn_last_error": (C.c_char_p, []),
+    "fgcn_check_device": (_I, []),
+    "fgcn_rows_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
+    "fgcn_rows_gemm_tiles": (_I, [_LL]),
+    "fgcn_rows_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
+    "fgcn_reduce_sum": (_I, [_P, _P, _I, _LL, _I, _P]),
+    "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
+    "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
+    "fgcn_joint_gram": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(GramItem), _I, _P]),
+    "fgcn_adj_softmax_fwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fgcn_adj_softmax_bwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "fgcn_bn_finalize": (_I, [_P, _I, _LL, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
+    "fgcn_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _P, _I, _P]),
+    "fgcn_bn_act": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "fgcn_elem_tiles": (_I, [_LL]),
+    "fgcn_col_sum": (_I, [_P, _P, _LL, _I, _I, _P]),
+    "fgcn_spatial_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_spatial_tiles": (_I, [_I, _I]),
+}
+
+_lib = None
+
+
+class FgcnError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libfgcn.so once; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FgcnError(f"{LIB_PATH} not found: build the HIP extension first (python -m fusion_gcn_amd.build). "
+                            "There is no CPU / eager fallback for the AGCN block.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fgcn_last_error()
+        raise FgcnError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else ''}")

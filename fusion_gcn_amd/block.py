@@ -1,0 +1,354 @@
+"""One AGCN / ST-GCN block (SpatialTemporalConv) on the HIP kernels: forward, backward, autograd glue.
+
+Reference semantics: torch_src/models/mmargcn/agcn.py:96-115 (SpatialGraphConv.forward), :49-51 (TemporalConv),
+:134-136 (SpatialTemporalConv.forward) and the autograd backward of that graph (formulas: SURVEY.md Appendix A).
+
+Internal layout is channels-last (B, T, V, C) with C padded to a multiple of 4 (only the 3-channel network input
+needs padding).  Every arithmetic step is a libfgcn kernel (fusion_gcn_amd/ops.py); torch is used for buffers,
+the stream and trivial weight re-layout (cat / permute of the small parameter tensors, cached per parameter version).
+
+Kernel schedule of one block, train mode (B = N*M samples):
+  forward   rows_gemm(theta|phi 1x1)  -> joint_gram (V x V affinity) -> adj_softmax (A^ = A + B + C)
+            spatial_fwd  [fused x.A^_k + conv_d, BN partial sums]   (or joint_mix + rows_gemm when fused_spatial=False)
+            bn_finalize -> [rows_gemm(down) -> bn_finalize] -> bn_act (BN + down/identity + ReLU = G)
+            rows_gemm(9x1 temporal conv, stride s, BN partial sums) -> bn_finalize
+            [rows_gemm(residual 1x1 stride s) -> bn_finalize] -> bn_act (BN + residual + ReLU = O)
+  backward  bn_act_bwd (O)  -> rows_gemm(dgrad 9x1) / rows_wgrad(9x1) -> bn_act_bwd (G)
+            rows_gemm(dY.Wd) -> joint_mix(agg recompute) -> rows_wgrad(conv_d) -> joint_mix(dx) -> joint_gram(dA^)
+            adj_softmax_bwd -> joint_mix(dtheta, dphi) -> rows_gemm(dx) / rows_wgrad(theta|phi)
+            + down / residual conv dgrad & wgrad, bias gradients by col_sum.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+NUM_SUBSETS = 3
+
+
+def _r4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+@dataclass(frozen=True)
+class BlockConfig:
+    cin: int
+    cout: int
+    stride: int = 1
+    residual: str = "identity"      # "none" | "identity" | "conv"
+    has_down: bool = False
+    static_adjacency: bool = False  # ST-GCN special case: A^ = A + B, no data-dependent C_k
+    fused_spatial: bool = True      # north-star fused kernel vs. joint_mix + rows_gemm
+
+    @property
+    def ic(self) -> int:
+        return self.cout // 4
+
+    @property
+    def cx(self) -> int:            # padded input channels
+        return _r4(self.cin)
+
+    def validate(self) -> None:
+        if self.cout % 64 != 0:
+            raise ValueError(f"HIP AGCN block needs out_channels % 64 == 0 (got {self.cout}): the embedding "
+                             "channels (out_channels/4 per subset) are tiled in groups of 16")
+        if self.residual == "identity" and not (self.cin == self.cout and self.stride == 1):
+            raise ValueError("identity residual needs cin == cout and stride 1")
+        if not self.has_down and self.cin != self.cout:
+            raise ValueError("cin != cout needs the down branch")
+
+
+# parameter order of a block (autograd.Function inputs); bn buffers travel separately
+def param_names(cfg: BlockConfig) -> List[str]:
+    names = ["gcn1.adj_b"]
+    for grp in ("conv_a", "conv_b", "conv_d"):
+        for k in range(NUM_SUBSETS):
+            names += [f"gcn1.{grp}.{k}.weight", f"gcn1.{grp}.{k}.bias"]
+    names += ["gcn1.bn.weight", "gcn1.bn.bias"]
+    if cfg.has_down:
+        names += ["gcn1.down.0.weight", "gcn1.down.0.bias", "gcn1.down.1.weight", "gcn1.down.1.bias"]
+    names += ["tcn1.conv.weight", "tcn1.conv.bias", "tcn1.bn.weight", "tcn1.bn.bias"]
+    if cfg.residual == "conv":
+        names += ["residual.conv.weight", "residual.conv.bias", "residual.bn.weight", "residual.bn.bias"]
+    return names
+
+
+def bn_names(cfg: BlockConfig) -> List[str]:
+    out = ["gcn1.bn"]
+    if cfg.has_down:
+        out.append("gcn1.down.1")
+    out.append("tcn1.bn")
+    if cfg.residual == "conv":
+        out.append("residual.bn")
+    return out
+
+
+# ---- weight re-layout (tiny tensors; torch plumbing) ---------------------------------------------------------------
+def _pad_last(t: torch.Tensor, n: int) -> torch.Tensor:
+    return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
+
+
+def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torch.Tensor]:
+    """Reference-layout parameters -> packed (taps, K, N) matrices for rows_gemm / spatial_fwd.
+    The input-channel dimension is zero-padded from cin to cx (= cin rounded up to 4): the kernels then see a
+    cx-channel block whose extra input channel is identically zero (only the 3-channel network input pads)."""
+    cin, cout, ic, cx = cfg.cin, cfg.cout, cfg.ic, cfg.cx
+    W: Dict[str, torch.Tensor] = {}
+    with torch.no_grad():
+        if not cfg.static_adjacency:
+            rows = []
+            for k in range(NUM_SUBSETS):                       # embedding channel order [th0 ph0 th1 ph1 th2 ph2]
+                rows += [P[f"gcn1.conv_a.{k}.weight"].view(ic, cin), P[f"gcn1.conv_b.{k}.weight"].view(ic, cin)]
+            emb_t = _pad_last(torch.cat(rows, 0), cx)          # (6ic, cx)
+            W["emb"] = emb_t.t().contiguous().unsqueeze(0)     # (1, cx, 6ic)
+            W["emb_t"] = emb_t.contiguous().unsqueeze(0)       # (1, 6ic, cx)  data-gradient form
+            W["emb_b"] = torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
+        d = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
+        W["d"] = torch.cat([w.t() for w in d], 0).contiguous()                    # (3cx, cout)
+        W["d_t"] = torch.cat(d, 1).contiguous().unsqueeze(0)                      # (1, cout, 3cx)
+        W["d_b"] = (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()
+        if cfg.has_down:
+            w = _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx)
+            W["down"] = w.t().contiguous().unsqueeze(0)                           # (1, cx, cout)
+            W["down_t"] = w.contiguous().unsqueeze(0)                             # (1, cout, cx)
+        wt = P["tcn1.conv.weight"].view(cout, cout, -1)                           # (o, c, kt)
+        W["t"] = wt.permute(2, 1, 0).contiguous()                                 # (kt, c, o)
+        W["t_t"] = wt.permute(2, 0, 1).contiguous()                               # (kt, o, c)
+        if cfg.residual == "conv":
+            w = _pad_last(P["residual.conv.weight"].view(cout, cin), cx)
+            W["res"] = w.t().contiguous().unsqueeze(0)
+            W["res_t"] = w.contiguous().unsqueeze(0)
+    return W
+
+
+# ---- joint-mix item tables -----------------------------------------------------------------------------------------
+def spec_agg(cin: int) -> List[dict]:
+    """agg[(k, c)] = sum_v x[v, c] A^_k[v, w]: out joint = column index of A^_k -> transpose = 1."""
+    out = []
+    for k in range(NUM_SUBSETS):
+        for c0 in range(0, cin, 32):
+            out.append(dict(out_c=k * cin + c0, width=min(32, cin - c0), terms=[(k, 1, c0, c0 + 16, 3)]))
+    return out
+
+
+def spec_dx(cin: int) -> List[dict]:
+    """dx[v, c] = sum_k sum_w dagg[(k, c), w] A^_k[v, w]."""
+    return [dict(out_c=c0, width=min(32, cin - c0),
+                 terms=[(k, 0, k * cin + c0, k * cin + c0 + 16, 3) for k in range(NUM_SUBSETS)])
+            for c0 in range(0, cin, 32)]
+
+
+def spec_demb(ic: int) -> List[dict]:
+    """dtheta_k = dS_k . phi_k (transpose 0), dphi_k = dS_k^T . theta_k (transpose 1); embedding channels are
+    [th0 ph0 th1 ph1 th2 ph2], each ``ic`` (a multiple of 16) wide, so a 32-lane tile may straddle two groups."""
+    def source(c):                       # 16-channel group starting at c -> (mat, transpose, source channel)
+        grp, off = divmod(c, ic)
+        k, is_phi = divmod(grp, 2)
+        return (k, 1, 2 * k * ic + off) if is_phi else (k, 0, (2 * k + 1) * ic + off)
+    out = []
+    for c0 in range(0, 6 * ic, 32):
+        lo, hi = source(c0), source(c0 + 16)
+        if lo[:2] == hi[:2]:
+            terms = [(lo[0], lo[1], lo[2], hi[2], 3)]
+        else:
+            terms = [(lo[0], lo[1], lo[2], lo[2], 1), (hi[0], hi[1], hi[2], hi[2], 2)]
+        out.append(dict(out_c=c0, width=32, terms=terms))
+    return out
+
+
+# ---- forward ---------------------------------------------------------------------------------------------------------
+def _bn_vec(part, count, P, bufs, name, train):
+    g, b = P[f"{name}.weight"], P[f"{name}.bias"]
+    rm, rv = bufs[f"{name}.running_mean"], bufs[f"{name}.running_var"]
+    if train:
+        return ops.bn_finalize(part, count, g, b, rm, rv)
+    return ops.bn_eval_coeffs(g, b, rm, rv)
+
+
+def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
+                  cfg: BlockConfig, train: bool):
+    """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict)."""
+    B, T, V, cx = x.shape
+    cout, ic, s = cfg.cout, cfg.ic, cfg.stride
+    assert cx == cfg.cx, (cx, cfg.cx)
+    cin = cx                     # kernels work on the padded channel count; the pad channel is identically zero
+    Tp = (T - 1) // s + 1
+    dev = x.device
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    S: Dict[str, Optional[torch.Tensor]] = {"x": x}
+
+    # -- data-dependent adjacency ------------------------------------------------------------------------------------
+    adj_ab = (bufs["gcn1.adj_a"] + P["gcn1.adj_b"].detach()).contiguous()
+    if cfg.static_adjacency:
+        emb, c_mat = None, None
+        _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_ab, 1, use_softmax=False)
+    else:
+        emb = new(B, T, V, 6 * ic)
+        ops.rows_gemm(x, W["emb"], emb, K=cin, N=6 * ic, bias=W["emb_b"])
+        part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
+        c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_ab, B)
+    S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
+
+    # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
+    if cfg.fused_spatial:
+        y, part = ops.spatial_fwd(x, a_hat, W["d"], W["d_b"], Cin=cin, Cout=cout, stats=train)
+    else:
+        agg = new(B, T, V, 3 * cin)
+        ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+        y = new(B, T, V, cout)
+        part = ops.rows_gemm(agg, W["d"].unsqueeze(0), y, K=3 * cin, N=cout, bias=W["d_b"], stats=train)
+    vec_y = _bn_vec(part, B * T * V, P, bufs, "gcn1.bn", train)
+    if cfg.has_down:
+        d = new(B, T, V, cout)
+        part = ops.rows_gemm(x, W["down"], d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
+        vec_d = _bn_vec(part, B * T * V, P, bufs, "gcn1.down.1", train)
+        g = ops.bn_act(y, vec_y, d, vec_d, relu=True)
+    else:
+        d, vec_d = None, None
+        g = ops.bn_act(y, vec_y, x, None, relu=True)
+    S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g)
+
+    # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
+    kt = W["t"].shape[0]
+    u = new(B, Tp, V, cout)
+    part = ops.rows_gemm(g, W["t"], u, K=cout, N=cout, tmap=ops.conv_tmap(kt, s), bias=P["tcn1.conv.bias"], stats=train)
+    vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
+    r, vec_r = None, None
+    if cfg.residual == "none":
+        o = ops.bn_act(u, vec_u, None, None, relu=True)
+    elif cfg.residual == "identity":
+        o = ops.bn_act(u, vec_u, x, None, relu=True)
+    else:
+        r = new(B, Tp, V, cout)
+        part = ops.rows_gemm(x, W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
+        vec_r = _bn_vec(part, B * Tp * V, P, bufs, "residual.bn", train)
+        o = ops.bn_act(u, vec_u, r, vec_r, relu=True)
+    S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=o)
+    return o, S
+
+
+# ---- backward --------------------------------------------------------------------------------------------------------
+def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
+                   W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True):
+    """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape})."""
+    x = S["x"]
+    B, T, V, cx = x.shape
+    cout, ic, s = cfg.cout, cfg.ic, cfg.stride
+    cin, cin_true = cx, cfg.cin  # kernels work on the padded channel count; gradients are cut back to cin_true
+    Tp = d_o.shape[1]
+    dev = x.device
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    G: Dict[str, torch.Tensor] = {}
+    d_o = d_o.contiguous()
+    kt = W["t"].shape[0]
+
+    dx = new(B, T, V, cx)
+    dx_live = False      # becomes True once dx holds a valid partial sum
+
+    # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
+    if cfg.residual == "none":
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train)
+    elif cfg.residual == "identity":
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx)
+        dx_live = True
+    else:
+        du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train)
+        G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0]
+        ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
+        dx_live = True
+        gw = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1))
+        G["residual.conv.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
+        G["residual.conv.bias"] = ops.col_sum(dr, cout)
+    G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
+
+    # -- temporal conv -------------------------------------------------------------------------------------------------------
+    dg = new(B, T, V, cout)
+    ops.rows_gemm(du, W["t_t"], dg, K=cout, N=cout, tmap=ops.conv_dgrad_tmap(kt, s))
+    gw = ops.rows_wgrad(S["g"], du, K=cout, N=cout, tmap=ops.conv_tmap(kt, s))    # (kt, c, o)
+    G["tcn1.conv.weight"] = gw.permute(2, 1, 0).unsqueeze(-1)
+    G["tcn1.conv.bias"] = ops.col_sum(du, cout)
+
+    # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
+    if cfg.has_down:
+        dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train)
+        G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0]
+        ops.rows_gemm(dd, W["down_t"], dx, K=cout, N=cx, accumulate=dx_live)
+        dx_live = True
+        gw = ops.rows_wgrad(x, dd, K=cin, N=cout)
+        G["gcn1.down.0.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
+        G["gcn1.down.0.bias"] = ops.col_sum(dd, cout)
+    else:
+        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
+                                     db_accumulate=dx_live)
+        dx_live = True
+    G["gcn1.bn.weight"], G["gcn1.bn.bias"] = sums[1], sums[0]
+
+    # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
+    a_hat = S["a_hat"]
+    c3 = 3 * cin
+    dagg = new(B, T, V, c3)
+    ops.rows_gemm(dy, W["d_t"], dagg, K=cout, N=c3)
+    agg = new(B, T, V, c3)
+    ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+    gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)[0]                              # (3cin, cout)
+    dbias = ops.col_sum(dy, cout)
+    for k in range(NUM_SUBSETS):
+        G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
+        G[f"gcn1.conv_d.{k}.bias"] = dbias
+    ops.joint_mix(dagg, dx, a_hat, spec_dx(cin), in_channels=3 * cin, out_channels=cin, accumulate=dx_live)
+    dx_live = True
+    part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
+    d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
+    db = torch.empty_like(P["gcn1.adj_b"])
+    ops.reduce_sum(d_a_hat.view(B, -1), db.view(-1))
+    G["gcn1.adj_b"] = db
+
+    # -- attention embeddings -----------------------------------------------------------------------------------------------------
+    if not cfg.static_adjacency:
+        emb = S["emb"]
+        demb = new(B, T, V, 6 * ic)
+        ops.joint_mix(emb, demb, d_s, spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+        ops.rows_gemm(demb, W["emb_t"], dx, K=6 * ic, N=cx, accumulate=dx_live)
+        gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic)[0].t()                        # (6ic, cin)
+        gb = ops.col_sum(demb, 6 * ic)
+        for k in range(NUM_SUBSETS):
+            for j, grp in enumerate(("conv_a", "conv_b")):
+                lo = (2 * k + j) * ic
+                G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic, :cin_true].reshape(ic, cin_true, 1, 1)
+                G[f"gcn1.{grp}.{k}.bias"] = gb[lo:lo + ic]
+    return (dx if need_dx else None), G
+
+
+# ---- autograd ----------------------------------------------------------------------------------------------------------
+class STBlockFunction(torch.autograd.Function):
+    """y = SpatialTemporalConv(x); inputs: x, then the block's parameters in ``param_names(cfg)`` order."""
+
+    @staticmethod
+    def forward(ctx, x, cfg: BlockConfig, train: bool, bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
+                holder: Optional[dict], *params):
+        names = param_names(cfg)
+        P = dict(zip(names, params))
+        o, S = block_forward(x, P, bufs, W, cfg, train)
+        ctx.cfg, ctx.train, ctx.names, ctx.W, ctx.S = cfg, train, names, W, S
+        ctx.save_for_backward(*params)
+        if holder is not None:
+            holder["adj_c"] = S["c_mat"]
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        P = dict(zip(ctx.names, ctx.saved_tensors))
+        dx, G = block_backward(d_o, ctx.S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0])
+        ctx.S = None
+        grads = []
+        for i, n in enumerate(ctx.names):
+            g = G.get(n) if ctx.needs_input_grad[6 + i] else None
+            if g is None and ctx.needs_input_grad[6 + i]:
+                g = torch.zeros_like(P[n])          # static-adjacency: embedding convs get no gradient
+            grads.append(g)
+        return (dx, None, None, None, None, None, *grads)

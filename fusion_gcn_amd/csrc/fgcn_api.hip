@@ -1,0 +1,28 @@
+// libfgcn: version, error text, device check.
+#include <cstring>
+
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace fgcn
+
+extern "C" int fgcn_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* fgcn_last_error(void) { return fgcn::error_buffer(); }
+
+extern "C" int fgcn_check_device(void) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fgcn::fail(FGCN_E_ARCH, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fgcn::fail(FGCN_E_ARCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fgcn::fail(FGCN_E_ARCH, "libfgcn is built for gfx950 (MI355X) only; device %d is %s", dev,
+                          prop.gcnArchName);
+    return FGCN_OK;
+}

@@ -1,0 +1,327 @@
+// BatchNorm statistics / apply / backward and the residual + ReLU epilogues of the AGCN block, channels-last.
+// All of these are pure HBM streams: 16-byte loads, channel = (flat index * 4) % C, per-channel vectors
+// (mean, rstd, scale, shift) read through L1/L2.  Reductions produce per-tile partials that a second tiny
+// kernel (fgcn_reduce_sum / bn_finalize) sums in a fixed order: results are bitwise reproducible.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+constexpr int ELEM_ROWS_PER_TILE = 512;
+constexpr int ELEM_MAX_TILES = 4096;
+
+// ---- BatchNorm finalize ------------------------------------------------------------------------------------
+// block = 32 channels x 8 partial-groups; double accumulation of the float tile sums.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int P, long long count,
+                                                          const float* gamma, const float* beta, float* rmean,
+                                                          float* rvar, float momentum, float eps, float* out, int C) {
+    __shared__ double s1[8][32], s2[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int i = g; i < P; i += 8) {
+            a += (double)partials[((long long)i * 2 + 0) * C + c];
+            b += (double)partials[((long long)i * 2 + 1) * C + c];
+        }
+    }
+    s1[g][cl] = a;
+    s2[g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int i = 1; i < 8; ++i) {
+            a += s1[i][cl];
+            b += s2[i][cl];
+        }
+        const double mean = a / (double)count;
+        double var = b / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * rstd;
+        out[0 * C + c] = (float)mean;
+        out[1 * C + c] = rstd;
+        out[2 * C + c] = scale;
+        out[3 * C + c] = beta[c] - (float)mean * scale;
+        if (rmean && rvar) {
+            const double unbiased = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, float* out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(rvar[c] + eps);
+    const float scale = gamma[c] * rstd;
+    out[0 * C + c] = rmean[c];
+    out[1 * C + c] = rstd;
+    out[2 * C + c] = scale;
+    out[3 * C + c] = beta[c] - rmean[c] * scale;
+}
+
+// ---- forward epilogue ----------------------------------------------------------------------------------------
+template <int RES>
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
+                                                     float* out, long long n4, int C, int relu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(va + 3 * C + c);
+        f32x4 y = x * sc + sh;
+        if (RES == 1) {
+            y += *reinterpret_cast<const f32x4*>(b + i * 4);
+        } else if (RES == 2) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(b + i * 4);
+            y += r * *reinterpret_cast<const f32x4*>(vb + 2 * C + c) + *reinterpret_cast<const f32x4*>(vb + 3 * C + c);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = y;
+    }
+}
+
+// ---- backward pass 1: per-channel reductions ---------------------------------------------------------------
+// blockDim = (C/4, ny): thread (x, y) owns channels 4x..4x+3 and rows y, y+ny, ... of its tile.
+template <int RES>
+__global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const float* a, const float* va,
+                                         const float* b, const float* vb, float* partials, long long rows,
+                                         long long rows_per_tile, int C, int relu) {
+    extern __shared__ float red[];  // [ny][3][C]
+    const int c = threadIdx.x * 4;
+    const long long r0 = (long long)blockIdx.x * rows_per_tile;
+    const long long r1 = min(r0 + rows_per_tile, rows);
+    const f32x4 mean_a = *reinterpret_cast<const f32x4*>(va + c);
+    const f32x4 rstd_a = *reinterpret_cast<const f32x4*>(va + C + c);
+    f32x4 mean_b = {0.f, 0.f, 0.f, 0.f}, rstd_b = {0.f, 0.f, 0.f, 0.f};
+    if (RES == 2) {
+        mean_b = *reinterpret_cast<const f32x4*>(vb + c);
+        rstd_b = *reinterpret_cast<const f32x4*>(vb + C + c);
+    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+    for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
+        const long long o = r * C + c;
+        f32x4 dp = *reinterpret_cast<const f32x4*>(dout + o);
+        if (relu) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(out + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[e] = y[e] > 0.f ? dp[e] : 0.f;
+        }
+        const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
+        s1 += dp;
+        s2 += dp * ah;
+        if (RES == 2) s3 += dp * ((*reinterpret_cast<const f32x4*>(b + o) - mean_b) * rstd_b);
+    }
+    float* mine = red + (long long)threadIdx.y * 3 * C;
+    *reinterpret_cast<f32x4*>(mine + c) = s1;
+    *reinterpret_cast<f32x4*>(mine + C + c) = s2;
+    *reinterpret_cast<f32x4*>(mine + 2 * C + c) = s3;
+    __syncthreads();
+    const int nthreads = blockDim.x * blockDim.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < 3 * C; i += nthreads) {
+        float s = 0.f;
+        for (int y = 0; y < (int)blockDim.y; ++y) s += red[y * 3 * C + i];
+        partials[(long long)blockIdx.x * 3 * C + i] = s;
+    }
+}
+
+// ---- backward pass 2: apply -----------------------------------------------------------------------------------
+template <int RES>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* out, const float* a,
+                                                               const float* va, const float* b, const float* vb,
+                                                               const float* sums, float* da, float* db, long long n4,
+                                                               int C, int relu, int train, float inv_m,
+                                                               int db_accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        f32x4 dp = *reinterpret_cast<const f32x4*>(dout + i * 4);
+        if (relu) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(out + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[e] = y[e] > 0.f ? dp[e] : 0.f;
+        }
+        const f32x4 sc_a = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
+        f32x4 ga = dp;
+        if (train) {
+            const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + i * 4) - *reinterpret_cast<const f32x4*>(va + c)) *
+                             *reinterpret_cast<const f32x4*>(va + C + c);
+            ga = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
+                 ah * (*reinterpret_cast<const f32x4*>(sums + C + c) * inv_m);
+        }
+        *reinterpret_cast<f32x4*>(da + i * 4) = ga * sc_a;
+        if (RES != 0 && db) {
+            f32x4 gb = dp;
+            if (RES == 2) {
+                const f32x4 sc_b = *reinterpret_cast<const f32x4*>(vb + 2 * C + c);
+                if (train) {
+                    const f32x4 bh =
+                        (*reinterpret_cast<const f32x4*>(b + i * 4) - *reinterpret_cast<const f32x4*>(vb + c)) *
+                        *reinterpret_cast<const f32x4*>(vb + C + c);
+                    gb = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
+                         bh * (*reinterpret_cast<const f32x4*>(sums + 2 * C + c) * inv_m);
+                }
+                gb = gb * sc_b;
+            }
+            if (db_accumulate) gb += *reinterpret_cast<const f32x4*>(db + i * 4);
+            *reinterpret_cast<f32x4*>(db + i * 4) = gb;
+        }
+    }
+}
+
+// ---- column sums ------------------------------------------------------------------------------------------------
+__global__ void col_sum_kernel(const float* x, float* partials, long long rows, long long rows_per_tile, int C, int ld) {
+    extern __shared__ float red[];  // [ny][C4*4]
+    const int c = threadIdx.x * 4;
+    const int CP = blockDim.x * 4;
+    const long long r0 = (long long)blockIdx.x * rows_per_tile;
+    const long long r1 = min(r0 + rows_per_tile, rows);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) s += *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    *reinterpret_cast<f32x4*>(red + (long long)threadIdx.y * CP + c) = s;
+    __syncthreads();
+    const int nthreads = blockDim.x * blockDim.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < C; i += nthreads) {
+        float acc = 0.f;
+        for (int y = 0; y < (int)blockDim.y; ++y) acc += red[y * CP + i];
+        partials[(long long)blockIdx.x * C + i] = acc;
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+extern "C" int fgcn_elem_tiles(long long rows) {
+    long long t = cdiv(rows, ELEM_ROWS_PER_TILE);
+    return (int)(t < ELEM_MAX_TILES ? t : ELEM_MAX_TILES);
+}
+
+static long long rows_per_tile_for(long long rows) { return cdiv(rows, fgcn_elem_tiles(rows)); }
+
+static unsigned stream_blocks(long long n4) {
+    const long long b = cdiv(n4, 256);
+    return (unsigned)(b < 8192 ? b : 8192);
+}
+
+extern "C" int fgcn_bn_finalize(const float* partials, int n_partials, long long count, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* out_vec, int C, void* stream) {
+    FGCN_REQUIRE(partials && gamma && beta && out_vec && n_partials > 0 && count > 0 && C > 0, FGCN_E_BADARG,
+                 "bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partials,
+                       n_partials, count, gamma, beta, running_mean, running_var, momentum, eps, out_vec, C);
+    return launch_status("bn_finalize");
+}
+
+extern "C" int fgcn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* out_vec, int C, void* stream) {
+    FGCN_REQUIRE(gamma && beta && running_mean && running_var && out_vec && C > 0, FGCN_E_BADARG,
+                 "bn_eval_coeffs: bad argument");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma,
+                       beta, running_mean, running_var, eps, out_vec, C);
+    return launch_status("bn_eval_coeffs");
+}
+
+static int check_elem(const char* what, long long rows, int C, int res_mode, const void* b, const void* vb) {
+    FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, FGCN_E_BADARG, "%s: rows=%lld C=%d (C must be a multiple of 4)", what,
+                 rows, C);
+    FGCN_REQUIRE(res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG, "%s: res_mode=%d", what, res_mode);
+    FGCN_REQUIRE(res_mode == 0 || b, FGCN_E_BADARG, "%s: residual operand missing", what);
+    FGCN_REQUIRE(res_mode != 2 || vb, FGCN_E_BADARG, "%s: residual BatchNorm vector missing", what);
+    return FGCN_OK;
+}
+
+extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
+                           long long rows, int C, int res_mode, int relu, void* stream) {
+    FGCN_REQUIRE(a && vec_a && out, FGCN_E_BADARG, "bn_act: null pointer");
+    if (int e = check_elem("bn_act", rows, C, res_mode, b, vec_b)) return e;
+    FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
+                 "bn_act: 16-byte alignment");
+    const long long n4 = rows * C / 4;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(stream_blocks(n4)), blk(256);
+    if (res_mode == 0) hipLaunchKernelGGL(bn_act_kernel<0>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
+    else if (res_mode == 1) hipLaunchKernelGGL(bn_act_kernel<1>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
+    else hipLaunchKernelGGL(bn_act_kernel<2>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
+    return launch_status("bn_act");
+}
+
+static int reduce_block(int C, dim3* blk) {
+    const int cx = C / 4;
+    if (cx < 1 || cx > 256) return -1;
+    int ny = 256 / cx;
+    if (ny > 32) ny = 32;
+    *blk = dim3((unsigned)cx, (unsigned)ny);
+    return 0;
+}
+
+extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const float* a, const float* vec_a,
+                                      const float* b, const float* vec_b, float* partials, int n_tiles, long long rows,
+                                      int C, int res_mode, int relu, void* stream) {
+    FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out), FGCN_E_BADARG, "bn_act_bwd_reduce: null pointer");
+    if (int e = check_elem("bn_act_bwd_reduce", rows, C, res_mode, b, vec_b)) return e;
+    FGCN_REQUIRE(n_tiles == fgcn_elem_tiles(rows), FGCN_E_BADARG, "bn_act_bwd_reduce: n_tiles must be %d",
+                 fgcn_elem_tiles(rows));
+    dim3 blk;
+    FGCN_REQUIRE(reduce_block(C, &blk) == 0, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d unsupported (4..1024)", C);
+    const size_t lds = (size_t)blk.y * 3 * C * sizeof(float);
+    FGCN_REQUIRE(lds <= 64 * 1024, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d needs too much LDS", C);
+    const long long rpt = rows_per_tile_for(rows);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((unsigned)n_tiles);
+    if (res_mode == 2)
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, g, blk, lds, s, dout, out, a, vec_a, b, vec_b, partials, rows,
+                           rpt, C, relu);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, g, blk, lds, s, dout, out, a, vec_a, b, vec_b, partials, rows,
+                           rpt, C, relu);
+    return launch_status("bn_act_bwd_reduce");
+}
+
+extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const float* a, const float* vec_a,
+                                     const float* b, const float* vec_b, const float* sums, float* da, float* db,
+                                     long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
+                                     void* stream) {
+    FGCN_REQUIRE(dout && vec_a && da && (!relu || out) && (!train || (a && sums)), FGCN_E_BADARG,
+                 "bn_act_bwd_apply: null pointer");
+    FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG,
+                 "bn_act_bwd_apply: bad shape/res_mode");
+    FGCN_REQUIRE(res_mode != 2 || !db || (vec_b && (!train || b)), FGCN_E_BADARG,
+                 "bn_act_bwd_apply: residual BatchNorm inputs missing");
+    const long long n4 = rows * C / 4;
+    const float inv_m = 1.f / (float)rows;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(stream_blocks(n4)), blk(256);
+    if (res_mode == 0 || !db)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<0>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
+                           relu, train, inv_m, db_accumulate);
+    else if (res_mode == 1)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
+                           relu, train, inv_m, db_accumulate);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<2>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
+                           relu, train, inv_m, db_accumulate);
+    return launch_status("bn_act_bwd_apply");
+}
+
+extern "C" int fgcn_col_sum(const float* x, float* partials, long long rows, int C, int ld, void* stream) {
+    FGCN_REQUIRE(x && partials && rows > 0 && C > 0 && ld % 4 == 0 && ld >= ((C + 3) & ~3) && aligned16(x), FGCN_E_BADARG,
+                 "col_sum: bad argument (rows=%lld C=%d ld=%d)", rows, C, ld);
+    const int cx = (C + 3) / 4;
+    FGCN_REQUIRE(cx <= 256, FGCN_E_BADARG, "col_sum: C=%d too wide", C);
+    int ny = 256 / cx;
+    if (ny > 32) ny = 32;
+    dim3 blk((unsigned)cx, (unsigned)ny);
+    const size_t lds = (size_t)ny * cx * 4 * sizeof(float);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)fgcn_elem_tiles(rows)), blk, lds, (hipStream_t)stream, x, partials,
+                       rows, rows_per_tile_for(rows), C, ld);
+    return launch_status("col_sum");
+}

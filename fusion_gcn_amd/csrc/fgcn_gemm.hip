@@ -1,0 +1,388 @@
+// Row GEMMs on the f32 MFMA (v_mfma_f32_32x32x2_f32): every 1x1 / (kt x 1) convolution of the AGCN block,
+// forward, data gradient and weight gradient, as an implicit GEMM over the flattened (n, t, v) rows of a
+// channels-last activation.  See include/fgcn.h for the contracts and the reference lines replaced.
+//
+// rows_gemm : M = rows (B*T_out*V), N = out channels, K = taps * in channels.
+//   workgroup = 4 waves, tile 128 rows x (32*NT) channels; wave w owns rows [32w, 32w+32) x all tile channels
+//   (NT accumulators of 32x32).  K is walked in 32-wide chunks staged through LDS; the next chunk's global
+//   loads are issued before the current chunk's MFMAs (register double buffer).  f32 MFMA issues one
+//   32x32x2 per 64 cycles per SIMD, so LDS/L2 bandwidth needs are tiny; what matters is keeping the four
+//   SIMDs issuing: several workgroups per CU (<= 36 KiB LDS, ~100 VGPRs) overlap each other's staging.
+//   The temporal taps shift the source row by (tap offset)*V rows inside the same sample, zero outside [0,T).
+//
+// rows_wgrad: dW[tap][k][n] = sum_rows a[src(row,tap)][k] * g[row][n]: both operands are K(=row)-major, so
+//   A/B fragments are single LDS dwords with the channel on the lane.  64x64 output tile per workgroup
+//   (one 32x32 accumulator per wave), rows split across blockIdx.z into deterministic partial slabs.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct RowsGemmP {
+    const float* in;
+    float* out;
+    const float* w;
+    const float* bias;
+    float* stats;
+    long long M;
+    int T_in, T_out, V, K, N, ld_in, ld_out;
+    int taps, ta, tb, tc, td;
+    int accumulate;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
+    constexpr int BM = 128, BK = 32, BN = 32 * NT, AS = BK + 4;
+    __shared__ __attribute__((aligned(16))) float As[BM * AS];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int k4 = (tid & 7) * 4;
+
+    // the four A-tile rows this thread stages: r = (tid >> 3) + 32*i
+    long long rbase[4];
+    int rto[4];
+    const int TV = p.T_out * p.V;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = m0 + (tid >> 3) + 32 * i;
+        if (m < p.M) {
+            const int n = (int)(m / TV);
+            const int rem = (int)(m - (long long)n * TV);
+            const int to = rem / p.V;
+            const int v = rem - to * p.V;
+            rbase[i] = ((long long)n * p.T_in * p.V + v) * p.ld_in;
+            rto[i] = to;
+        } else {
+            rbase[i] = 0;
+            rto[i] = -1;
+        }
+    }
+
+    const int KC = (p.K + BK - 1) / BK;
+    const int S = p.taps * KC;
+    f32x4 areg[4], breg[NT];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = zero16();
+
+    auto load_stage = [&](int s) {
+        const int tap = s / KC;
+        const int kc = (s - tap * KC) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int ti = rto[i] >= 0 ? tmap_src(rto[i], tap, p.ta, p.tb, p.tc, p.td, p.T_in) : -1;
+            const int k = kc + k4;
+            if (ti >= 0 && k < p.K) {
+                const float* src = p.in + rbase[i] + (long long)ti * p.V * p.ld_in + k;
+                if (k + 3 < p.K) {
+                    v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < p.K) v[e] = src[e];
+                }
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+            const int k = kc + kk, n = n0 + 4 * n4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < p.K && n < p.N) v = *reinterpret_cast<const f32x4*>(p.w + ((long long)tap * p.K + k) * p.N + n);
+            breg[i] = v;
+        }
+    };
+
+    load_stage(0);
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();  // previous chunk's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(&As[((tid >> 3) + 32 * i) * AS + k4]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int idx = tid + 256 * i;
+            const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+            *reinterpret_cast<f32x4*>(&Bs[kk * BN + 4 * n4]) = breg[i];
+        }
+        __syncthreads();
+        const int kc = (s % KC) * BK;
+        if (s + 1 < S) load_stage(s + 1);  // in flight while this chunk's MFMAs run
+        const int kleft = p.K - kc;
+        const int nq = kleft >= BK ? BK / 8 : (kleft + 7) / 8;
+        const float* arow = &As[(wave * 32 + (lane & 31)) * AS + 4 * (lane >> 5)];
+        const float* bcol = &Bs[(4 * (lane >> 5)) * BN + (lane & 31)];
+        for (int q = 0; q < nq; ++q) {
+            // lane half h holds k = 8q + 4h + e (e = 0..3): any k permutation is fine as long as A and B agree
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma32(av[e], bcol[(8 * q + e) * BN + nt * 32], acc[nt]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, optional accumulate, store, optional BatchNorm partial statistics -----------------
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.f;
+        ssq[nt] = 0.f;
+        const int col = n0 + nt * 32 + (lane & 31);
+        const bool cok = col < p.N;
+        const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = m0 + wave * 32 + acc_row(r, lane);
+            if (cok && m < p.M) {
+                float* dst = p.out + m * p.ld_out + col;
+                float val = acc[nt][r] + bv;
+                if (p.accumulate) val += *dst;
+                *dst = val;
+                ssum[nt] += val;
+                ssq[nt] += val * val;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();  // As is free now: reuse as [2][4 waves][BN]
+        float* red = As;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float a = ssum[nt] + __shfl_xor(ssum[nt], 32);
+            const float b = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (lane < 32) {
+                red[(0 * 4 + wave) * BN + nt * 32 + lane] = a;
+                red[(1 * 4 + wave) * BN + nt * 32 + lane] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            const int col = n0 + c;
+            if (col < p.N) {
+                const float t = red[(which * 4 + 0) * BN + c] + red[(which * 4 + 1) * BN + c] +
+                                red[(which * 4 + 2) * BN + c] + red[(which * 4 + 3) * BN + c];
+                p.stats[((long long)blockIdx.x * 2 + which) * p.N + col] = t;
+            }
+        }
+    }
+}
+
+struct WgradP {
+    const float* a;
+    const float* g;
+    float* partial;
+    long long M, rows_per_split;
+    int T_a, T_g, V, K, N, ld_a, ld_g;
+    int taps, ta, tb, tc, td;
+    int tilesN;
+};
+
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
+    constexpr int BR = 64, TK = 64, TN = 64;
+    __shared__ __attribute__((aligned(16))) float As[BR * TK];
+    __shared__ __attribute__((aligned(16))) float Gs[BR * TN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int tk = blockIdx.x / p.tilesN, tn = blockIdx.x - tk * p.tilesN;
+    const int tap = blockIdx.y;
+    const int split = blockIdx.z;
+    const long long mbeg = (long long)split * p.rows_per_split;
+    long long mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+    const int k0 = tk * TK, n0 = tn * TN;
+    const int c4 = (tid & 15) * 4;
+    const int TVg = p.T_g * p.V;
+
+    f32x4 areg[4], greg[4];
+    f32x16 acc = zero16();
+
+    auto load_stage = [&](long long mb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long m = mb + (tid >> 4) + 16 * j;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vg = {0.f, 0.f, 0.f, 0.f};
+            if (m < mend) {
+                const int n = (int)(m / TVg);
+                const int rem = (int)(m - (long long)n * TVg);
+                const int tg = rem / p.V;
+                const int v = rem - tg * p.V;
+                const int ti = tmap_src(tg, tap, p.ta, p.tb, p.tc, p.td, p.T_a);
+                if (ti >= 0) {
+                    const int k = k0 + c4;
+                    const float* src = p.a + (((long long)n * p.T_a + ti) * p.V + v) * p.ld_a + k;
+                    if (k + 3 < p.K) {
+                        va = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k + e < p.K) va[e] = src[e];
+                    }
+                    const int nn = n0 + c4;
+                    const float* gsrc = p.g + m * p.ld_g + nn;
+                    if (nn + 3 < p.N) {
+                        vg = *reinterpret_cast<const f32x4*>(gsrc);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nn + e < p.N) vg[e] = gsrc[e];
+                    }
+                }
+            }
+            areg[j] = va;
+            greg[j] = vg;
+        }
+    };
+
+    if (mbeg < mend) load_stage(mbeg);
+    for (long long mb = mbeg; mb < mend; mb += BR) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (tid >> 4) + 16 * j;
+            *reinterpret_cast<f32x4*>(&As[row * TK + c4]) = areg[j];
+            *reinterpret_cast<f32x4*>(&Gs[row * TN + c4]) = greg[j];
+        }
+        __syncthreads();
+        if (mb + BR < mend) load_stage(mb + BR);
+        const float* ap = &As[(lane >> 5) * TK + wk * 32 + (lane & 31)];
+        const float* gp = &Gs[(lane >> 5) * TN + wn * 32 + (lane & 31)];
+#pragma unroll 8
+        for (int s = 0; s < BR / 2; ++s) acc = mfma32(ap[2 * s * TK], gp[2 * s * TN], acc);
+    }
+
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + wk * 32 + acc_row(r, lane);
+            if (k < p.K)
+                p.partial[(((long long)split * p.taps + tap) * p.K + k) * p.N + n] = acc[r];
+        }
+    }
+}
+
+__global__ void reduce_sum_kernel(float* dst, const float* src, int S, long long count, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (long long)gridDim.x * blockDim.x) {
+        float t = 0.f;
+        for (int s = 0; s < S; ++s) t += src[(long long)s * count + i];
+        dst[i] = accumulate ? dst[i] + t : t;
+    }
+}
+
+__global__ void pack_weight_kernel(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
+                                   long long st_tap, long long st_k, long long st_n, int flip) {
+    const long long total = (long long)taps * K * N_dst;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N_dst);
+        const long long jk = i / N_dst;
+        const int k = (int)(jk % K);
+        const int j = (int)(jk / K);
+        const int jj = flip ? taps - 1 - j : j;
+        dst[i] = n < N_src ? src[(long long)n * st_n + (long long)k * st_k + (long long)jj * st_tap] : 0.f;
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+extern "C" int fgcn_rows_gemm_tiles(long long M) { return (int)cdiv(M, 128); }
+
+static int check_tmap(const fgcn_tmap& m) {
+    FGCN_REQUIRE(m.taps >= 1 && m.taps <= 16 && m.td >= 1 && m.ta >= 0, FGCN_E_BADARG,
+                 "bad temporal map (taps=%d ta=%d td=%d)", m.taps, m.ta, m.td);
+    return FGCN_OK;
+}
+
+extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
+                              int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                              fgcn_tmap map, int accumulate, void* stream) {
+    FGCN_REQUIRE(in && out && w, FGCN_E_BADARG, "rows_gemm: null pointer");
+    FGCN_REQUIRE(B > 0 && T_in > 0 && T_out > 0 && V > 0 && K > 0 && N > 0, FGCN_E_BADARG,
+                 "rows_gemm: non-positive size B=%d T_in=%d T_out=%d V=%d K=%d N=%d", B, T_in, T_out, V, K, N);
+    FGCN_REQUIRE(N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, FGCN_E_ALIGN,
+                 "rows_gemm: N, ld_in, ld_out must be multiples of 4 (N=%d ld_in=%d ld_out=%d)", N, ld_in, ld_out);
+    FGCN_REQUIRE(ld_in >= ((K + 3) & ~3) && ld_out >= N, FGCN_E_BADARG,
+                 "rows_gemm: row strides too small (K=%d ld_in=%d N=%d ld_out=%d)", K, ld_in, N, ld_out);
+    FGCN_REQUIRE(aligned16(in) && aligned16(out) && aligned16(w), FGCN_E_ALIGN, "rows_gemm: 16-byte alignment");
+    if (int e = check_tmap(map)) return e;
+    RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
+                map.taps, map.ta, map.tb, map.tc, map.td, accumulate};
+    const long long tiles_m = cdiv(p.M, 128);
+    FGCN_REQUIRE(tiles_m < (1ll << 31), FGCN_E_BADARG, "rows_gemm: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
+    int nt = 4;
+    long long best = -1;
+    for (int c = 4; c >= 1; --c) {
+        const long long padded = cdiv(N, 32 * c) * 32 * c;
+        if (best < 0 || padded < best) {
+            best = padded;
+            nt = c;
+        }
+    }
+    const int bn = 32 * nt;
+    dim3 grid((unsigned)tiles_m, (unsigned)cdiv(N, bn));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(rows_gemm_kernel<1>, grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(rows_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(rows_gemm_kernel<3>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(rows_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
+    }
+    return launch_status("rows_gemm");
+}
+
+extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
+                               int B, int T_a, int T_g, int V, int K, int N, int ld_a, int ld_g,
+                               fgcn_tmap map, int nsplit, void* stream) {
+    FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "rows_wgrad: null pointer");
+    FGCN_REQUIRE(B > 0 && T_a > 0 && T_g > 0 && V > 0 && K > 0 && N > 0 && nsplit > 0, FGCN_E_BADARG,
+                 "rows_wgrad: non-positive size");
+    FGCN_REQUIRE(ld_a % 4 == 0 && ld_g % 4 == 0 && ld_a >= ((K + 3) & ~3) && ld_g >= ((N + 3) & ~3), FGCN_E_ALIGN,
+                 "rows_wgrad: row strides must be multiples of 4 and cover the channels (K=%d ld_a=%d N=%d ld_g=%d)",
+                 K, ld_a, N, ld_g);
+    FGCN_REQUIRE(aligned16(a) && aligned16(g), FGCN_E_ALIGN, "rows_wgrad: 16-byte alignment");
+    if (int e = check_tmap(map)) return e;
+    FGCN_REQUIRE(nsplit <= 65535, FGCN_E_BADARG, "rows_wgrad: nsplit too large");
+    WgradP p;
+    p.a = a; p.g = g; p.partial = partial;
+    p.M = (long long)B * T_g * V;
+    p.rows_per_split = cdiv(cdiv(p.M, nsplit), 64) * 64;
+    p.T_a = T_a; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
+    p.taps = map.taps; p.ta = map.ta; p.tb = map.tb; p.tc = map.tc; p.td = map.td;
+    p.tilesN = (int)cdiv(N, 64);
+    dim3 grid((unsigned)(cdiv(K, 64) * p.tilesN), (unsigned)map.taps, (unsigned)nsplit);
+    hipLaunchKernelGGL(rows_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("rows_wgrad");
+}
+
+extern "C" int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream) {
+    FGCN_REQUIRE(dst && src && S > 0 && count > 0, FGCN_E_BADARG, "reduce_sum: bad argument");
+    const unsigned blocks = (unsigned)(cdiv(count, 256) < 4096 ? cdiv(count, 256) : 4096);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, S, count,
+                       accumulate);
+    return launch_status("reduce_sum");
+}
+
+extern "C" int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
+                                long long st_tap, long long st_k, long long st_n, int flip, void* stream) {
+    FGCN_REQUIRE(dst && src && taps > 0 && K > 0 && N_src > 0 && N_dst >= N_src && N_dst % 4 == 0, FGCN_E_BADARG,
+                 "pack_weight: bad argument (taps=%d K=%d N_src=%d N_dst=%d)", taps, K, N_src, N_dst);
+    const long long total = (long long)taps * K * N_dst;
+    const unsigned blocks = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, taps, K, N_src,
+                       N_dst, st_tap, st_k, st_n, flip);
+    return launch_status("pack_weight");
+}

@@ -1,0 +1,289 @@
+// Joint-mixing kernels: everything in the AGCN block that contracts over the skeleton's joints (V <= 32).
+//   joint_mix  : out_t (V x ch) (+)= M (V x V) . in_t (V x ch)      per sample n and frame t   (MFMA 32x32x2 f32)
+//   joint_gram : G (V x V) += in1_t (V x ch) . in2_t^T (ch x V)      summed over frames and channels
+//   adj_softmax_{fwd,bwd}: the column softmax that turns the joint affinity into the data-dependent adjacency.
+// The per-sample V x V matrices live in LDS (zero-padded to 32 x 32, row stride 33); one wave owns one frame
+// at a time, the joint index sits on the MFMA row/K dimension and 32 channels on the lanes, so global loads and
+// stores are 128-byte contiguous per half-wave.  These ops are HBM-bound (each activation element feeds one
+// 32x32x2 step); the fused spatial kernel (fgcn_spatial.hip) removes them from the forward pass.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+constexpr int MS = 33;  // LDS row stride of a padded 32 x 32 joint matrix
+constexpr int MIX_MAX_MATS = 3;
+
+struct MixP {
+    const float* in;
+    float* out;
+    const float* mats;
+    int B, T, V, ld_in, ld_out, in_ch, out_ch, n_mats, mats_batched, n_items, accumulate, t_chunk;
+    fgcn_mix_item items[FGCN_MIX_MAX_ITEMS];
+};
+
+__global__ __launch_bounds__(256) void joint_mix_kernel(MixP p) {
+    __shared__ float mat[MIX_MAX_MATS * 32 * MS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V;
+
+    const float* msrc = p.mats + (p.mats_batched ? (long long)n * p.n_mats * V * V : 0);
+    for (int i = tid; i < p.n_mats * 32 * 32; i += 256) {
+        const int mi = i >> 10, u = (i >> 5) & 31, w = i & 31;
+        mat[(mi * 32 + u) * MS + w] = (u < V && w < V) ? msrc[(mi * V + u) * V + w] : 0.f;
+    }
+    __syncthreads();
+
+    const int ksteps = (V + 1) >> 1;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const long long row0 = ((long long)n * p.T + t) * V;
+        for (int it = 0; it < p.n_items; ++it) {
+            const fgcn_mix_item& item = p.items[it];
+            f32x16 acc = zero16();
+            for (int tr = 0; tr < item.nterms; ++tr) {
+                const fgcn_mix_term& term = item.term[tr];
+                const int c_in = l31 < 16 ? term.in_c_lo + l31 : term.in_c_hi + (l31 - 16);
+                const bool take = ((term.mask >> (l31 >> 4)) & 1) && c_in < p.in_ch && l31 < item.width;
+                const float* src = p.in + row0 * p.ld_in + c_in;
+                const float* mrow = &mat[term.mat * 32 * MS];
+                // A[i = out joint][k = in joint] = M[i][k] (or M[k][i]); B[k = in joint][j = channel]
+                const int a_i = term.transpose ? 1 : MS, a_k = term.transpose ? MS : 1;
+#pragma unroll 4
+                for (int s = 0; s < ksteps; ++s) {
+                    const int k = 2 * s + h;
+                    const float a = mrow[l31 * a_i + k * a_k];
+                    const float b = (take && k < V) ? src[(long long)k * p.ld_in] : 0.f;
+                    acc = mfma32(a, b, acc);
+                }
+            }
+            const int c_out = item.out_c + l31;
+            if (c_out < p.out_ch && l31 < item.width) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = acc_row(r, lane);
+                    if (u < V) {
+                        float* dst = p.out + (row0 + u) * p.ld_out + c_out;
+                        *dst = p.accumulate ? *dst + acc[r] : acc[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct GramP {
+    const float* in1;
+    const float* in2;
+    float* partial;
+    int B, T, V, ld1, ld2, t_chunk, n_items;
+    fgcn_gram_item items[FGCN_GRAM_MAX_ITEMS];
+};
+
+__device__ __forceinline__ f32x4 load4_masked(const float* p, int c, int width, bool row_ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row_ok && c < width) {
+        if (c + 3 < width) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < width) v[e] = p[e];
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
+    __shared__ float red[4 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V;
+    const bool row_ok = l31 < V;
+    const int vv = row_ok ? l31 : 0;
+
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const long long row = ((long long)n * p.T + t) * V + vv;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            if (it < p.n_items) {
+                const fgcn_gram_item item = p.items[it];
+                const float* s1 = p.in1 + row * p.ld1 + item.c1 + 4 * h;
+                const float* s2 = p.in2 + row * p.ld2 + item.c2 + 4 * h;
+                const int nq = (item.width + 7) >> 3;
+                for (int q = 0; q < nq; ++q) {
+                    // lane half h contracts channels 8q + 4h + e on both operands
+                    const f32x4 a = load4_masked(s1 + 8 * q, 8 * q + 4 * h, item.width, row_ok);
+                    const f32x4 b = load4_masked(s2 + 8 * q, 8 * q + 4 * h, item.width, row_ok);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[it] = mfma32(a[e], b[e], acc[it]);
+                }
+            }
+        }
+    }
+    // deterministic cross-wave sum, one matrix at a time
+    const int nchunk = gridDim.x;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        if (it < p.n_items) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[it][r];
+            __syncthreads();
+            float* dst = p.partial + (((long long)n * nchunk + chunk) * p.n_items + p.items[it].mat) * 1024;
+            for (int e = tid; e < 1024; e += 256) {
+                const float s = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+                const int r = e >> 6, l = e & 63;
+                dst[acc_row(r, l) * 32 + (l & 31)] = s;
+            }
+        }
+    }
+}
+
+// one thread per (n, k, w): column softmax over v (dim -2 of the (V, V) affinity)
+__global__ void adj_softmax_fwd_kernel(const float* partial, int nchunk, float scale, const float* adj_ab,
+                                       float* c_out, float* a_hat, int B, int K, int V, int use_softmax) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K * V) return;
+    const int w = idx % V, k = (idx / V) % K, n = idx / (V * K);
+    float* crow = c_out + ((long long)(n * K + k) * V) * V + w;
+    float* arow = a_hat + ((long long)(n * K + k) * V) * V + w;
+    const float* ab = adj_ab + (long long)k * V * V + w;
+    if (!use_softmax) {
+        for (int v = 0; v < V; ++v) arow[v * V] = ab[v * V];
+        return;
+    }
+    float mx = -INFINITY;
+    for (int v = 0; v < V; ++v) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += partial[(((long long)n * nchunk + c) * K + k) * 1024 + v * 32 + w];
+        s *= scale;
+        crow[v * V] = s;  // staged; overwritten below
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int v = 0; v < V; ++v) {
+        const float e = expf(crow[v * V] - mx);
+        crow[v * V] = e;
+        den += e;
+    }
+    const float inv = 1.f / den;
+    for (int v = 0; v < V; ++v) {
+        const float c = crow[v * V] * inv;
+        crow[v * V] = c;
+        arow[v * V] = c + ab[v * V];
+    }
+}
+
+__global__ void adj_softmax_bwd_kernel(const float* partial, int nchunk, float scale, const float* c_in,
+                                       float* d_a_hat, float* d_s, int B, int K, int V) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K * V) return;
+    const int w = idx % V, k = (idx / V) % K, n = idx / (V * K);
+    const long long base = ((long long)(n * K + k) * V) * V + w;
+    float dot = 0.f;
+    for (int v = 0; v < V; ++v) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += partial[(((long long)n * nchunk + c) * K + k) * 1024 + v * 32 + w];
+        d_a_hat[base + v * V] = s;
+        if (c_in) dot += c_in[base + v * V] * s;
+    }
+    if (c_in && d_s) {
+        for (int v = 0; v < V; ++v) {
+            const float c = c_in[base + v * V];
+            d_s[base + v * V] = scale * c * (d_a_hat[base + v * V] - dot);
+        }
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+static int pick_t_chunk(int B, int T) {
+    // enough workgroups to fill 256 CUs a few times over, at least 4 frames (one per wave) per workgroup
+    int chunk = 32;
+    while (chunk > 4 && (long long)B * cdiv(T, chunk) < 1024) chunk >>= 1;
+    return chunk;
+}
+
+extern "C" int fgcn_joint_mix(const float* in, float* out, const float* mats, int B, int T, int V,
+                              int ld_in, int ld_out, int in_channels, int out_channels, int n_mats, int mats_batched,
+                              const fgcn_mix_item* items, int n_items, int accumulate, void* stream) {
+    FGCN_REQUIRE(in && out && mats && items, FGCN_E_BADARG, "joint_mix: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG, "joint_mix: bad B/T/V (%d,%d,%d)", B, T, V);
+    FGCN_REQUIRE(n_mats >= 1 && n_mats <= MIX_MAX_MATS && n_items >= 1 && n_items <= FGCN_MIX_MAX_ITEMS,
+                 FGCN_E_BADARG, "joint_mix: n_mats=%d n_items=%d out of range", n_mats, n_items);
+    FGCN_REQUIRE(in_channels > 0 && out_channels > 0 && ld_in >= in_channels && ld_out >= out_channels, FGCN_E_BADARG,
+                 "joint_mix: channel counts exceed row strides");
+    FGCN_REQUIRE(B <= 65535, FGCN_E_BADARG, "joint_mix: B too large for grid.y");
+    MixP p;
+    p.in = in; p.out = out; p.mats = mats;
+    p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out; p.in_ch = in_channels; p.out_ch = out_channels;
+    p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items; p.accumulate = accumulate;
+    p.t_chunk = pick_t_chunk(B, T);
+    for (int i = 0; i < n_items; ++i) {
+        const fgcn_mix_item& it = items[i];
+        FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.out_c >= 0 && it.width >= 1 && it.width <= 32, FGCN_E_BADARG,
+                     "joint_mix: item %d malformed", i);
+        for (int t = 0; t < it.nterms; ++t)
+            FGCN_REQUIRE(it.term[t].mat >= 0 && it.term[t].mat < n_mats && it.term[t].in_c_lo >= 0 &&
+                             it.term[t].in_c_hi >= 0,
+                         FGCN_E_BADARG, "joint_mix: item %d term %d malformed", i, t);
+        p.items[i] = it;
+    }
+    dim3 grid((unsigned)cdiv(T, p.t_chunk), (unsigned)B);
+    hipLaunchKernelGGL(joint_mix_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("joint_mix");
+}
+
+extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partial, int B, int T, int V,
+                               int ld1, int ld2, int t_chunk, int n_mats, const fgcn_gram_item* items, int n_items,
+                               void* stream) {
+    FGCN_REQUIRE(in1 && in2 && partial && items, FGCN_E_BADARG, "joint_gram: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0 && V > 0 && V <= FGCN_MAX_V && t_chunk > 0, FGCN_E_BADARG, "joint_gram: bad sizes");
+    FGCN_REQUIRE(n_items >= 1 && n_items <= 3 && n_mats == n_items, FGCN_E_BADARG,
+                 "joint_gram: needs 1..3 items, one per output matrix (n_items=%d n_mats=%d)", n_items, n_mats);
+    FGCN_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && aligned16(in1) && aligned16(in2), FGCN_E_ALIGN,
+                 "joint_gram: strides/pointers must be 16-byte aligned");
+    FGCN_REQUIRE(B <= 65535, FGCN_E_BADARG, "joint_gram: B too large for grid.y");
+    GramP p;
+    p.in1 = in1; p.in2 = in2; p.partial = partial;
+    p.B = B; p.T = T; p.V = V; p.ld1 = ld1; p.ld2 = ld2; p.t_chunk = t_chunk; p.n_items = n_items;
+    for (int i = 0; i < n_items; ++i) {
+        FGCN_REQUIRE(items[i].mat == i && items[i].width > 0 && items[i].c1 % 4 == 0 && items[i].c2 % 4 == 0 &&
+                         items[i].c1 + items[i].width <= ld1 + 3 && items[i].c2 + items[i].width <= ld2 + 3,
+                     FGCN_E_BADARG, "joint_gram: item %d malformed", i);
+        p.items[i] = items[i];
+    }
+    dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
+    hipLaunchKernelGGL(joint_gram_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("joint_gram");
+}
+
+extern "C" int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_ab,
+                                    float* c_out, float* a_hat, int B, int K, int V, int use_softmax, void* stream) {
+    FGCN_REQUIRE(adj_ab && a_hat && B > 0 && K > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
+                 "adj_softmax_fwd: bad argument");
+    FGCN_REQUIRE(!use_softmax || (partial && c_out && nchunk > 0), FGCN_E_BADARG, "adj_softmax_fwd: missing partials");
+    const int total = B * K * V;
+    hipLaunchKernelGGL(adj_softmax_fwd_kernel, dim3((unsigned)cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream,
+                       partial, nchunk, scale, adj_ab, c_out, a_hat, B, K, V, use_softmax);
+    return launch_status("adj_softmax_fwd");
+}
+
+extern "C" int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scale, const float* c_in,
+                                    float* d_a_hat, float* d_s, int B, int K, int V, void* stream) {
+    FGCN_REQUIRE(partial && d_a_hat && nchunk > 0 && B > 0 && K > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
+                 "adj_softmax_bwd: bad argument");
+    const int total = B * K * V;
+    hipLaunchKernelGGL(adj_softmax_bwd_kernel, dim3((unsigned)cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream,
+                       partial, nchunk, scale, c_in, d_a_hat, d_s, B, K, V);
+    return launch_status("adj_softmax_bwd");
+}

@@ -1,0 +1,243 @@
+// Fused spatial graph convolution, forward (north-star kernel 1):
+//
+//     y[(n,t,w), o] = bias[o] + sum_k sum_c Wd_k[o][c] * ( sum_v x[(n,t,v), c] * A^_k[n][v][w] )
+//
+// i.e. the K=3 joint aggregations x.A^_k and the three 1x1 convolutions conv_d[k] of the reference's
+// SpatialGraphConv.forward (torch_src/models/mmargcn/agcn.py:103-111) in ONE kernel, with no agg tensor in HBM.
+//
+// Mapping (one wave = one frame t of one sample n at a time; a workgroup = 4 waves = 4 frames of the same sample):
+//   step 1  agg_k^T (32 c x 32 w) = X_t^T (c x v) . A^_k (v x w)     13 x v_mfma_f32_32x32x2_f32 for V = 25
+//           A operand: x[(n,t,v)][c0 + lane]  -> 128-byte contiguous global reads per half-wave, read ONCE per
+//           channel tile and reused for the three subsets;  B operand: A^_k[v][w] from LDS (per-sample, zero-padded
+//           32 x 32, row stride 33: conflict-free).
+//   step 2  y^T (32 o x 32 w) += Wd_k (o x c) . agg_k^T (c x w)      16 MFMAs per (o tile, c tile, k)
+//           the step-1 accumulator IS the B operand of step 2 (register r of lane half h holds row
+//           (r&3)+8(r>>2)+4h of agg^T, exactly the k index a 32x32x2 B operand needs), so agg never leaves
+//           registers; the A operand Wd_k[o][c] comes from a 32-row weight chunk staged in LDS and shared by the 4
+//           waves (double buffered, one barrier per chunk, next chunk's global loads in flight during the MFMAs).
+//   epilogue: + sum_k bd_k, 16-byte stores of 4 consecutive channels per lane, BatchNorm partial sums
+//           (sum, sum of squares per channel) reduced across the joint lanes with wave shuffles.
+// The joint axis sits on 25 of the 32 MFMA columns (78 % of the f32 MFMA rate is the ceiling of this mapping);
+// A^_k's zero padding makes the 7 idle columns exact zeros, so they drop out of stores and statistics.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+constexpr int AHS = 33;
+
+struct SpatialP {
+    const float* x;
+    const float* a_hat;
+    const float* wd;
+    const float* bias;
+    float* y;
+    float* stats;
+    int B, T, V, Cin, Cout, ld_x, ld_y, ns, a_batched, t_chunk;
+};
+
+template <int CT_IN, int CT_OUT>
+__global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
+    constexpr int WROW = CT_OUT * 32;                 // floats per staged weight row (padded Cout)
+    constexpr int WCHUNK = 32 * WROW;                 // one (k, c-tile) chunk: 32 input channels x Cout
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ah = smem;                                 // [3][32][33]
+    float* wl = smem + ((3 * 32 * AHS + 3) & ~3);     // 2 x WCHUNK, 16-byte aligned for the float4 commits
+    float* st = wl + 2 * WCHUNK;                      // [4 waves][2][WROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int V = p.V, NS = p.ns;
+    const int t0 = blockIdx.x * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+
+    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * NS * V * V : 0);
+    for (int i = tid; i < 3 * 32 * 32; i += 256) {
+        const int k = i >> 10, v = (i >> 5) & 31, w = i & 31;
+        ah[(k * 32 + v) * AHS + w] = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+    }
+    for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
+
+    const int ksteps = (V + 1) >> 1;
+    const int nchunks = CT_IN * NS;                   // weight chunks per frame group
+    f32x4 wreg[CT_OUT];
+
+    // weight chunk q = ci*NS + k covers rows k*Cin + ci*32 .. +31 of the packed [NS*Cin][Cout] matrix
+    auto prefetch_w = [&](int q) {
+        const int ci = q / NS, k = q - ci * NS;
+#pragma unroll
+        for (int i = 0; i < CT_OUT; ++i) {
+            const int idx = tid + 256 * i;             // float4 index inside the chunk
+            const int row = idx / (WROW / 4), c4 = (idx - row * (WROW / 4)) * 4;
+            const int c = ci * 32 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < p.Cin && c4 < p.Cout) v = *reinterpret_cast<const f32x4*>(p.wd + ((long long)k * p.Cin + c) * p.Cout + c4);
+            wreg[i] = v;
+        }
+    };
+    auto commit_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CT_OUT; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(wl + buf * WCHUNK + idx * 4) = wreg[i];
+        }
+    };
+
+    prefetch_w(0);
+    int qg = 0;  // global chunk counter (selects the LDS buffer)
+    for (int tg = t0; tg < t1; tg += 4) {
+        const int t = tg + wave;
+        const bool tv = t < t1;
+        const long long row0 = ((long long)n * p.T + (tv ? t : t0)) * V;
+        f32x16 acc[CT_OUT];
+#pragma unroll
+        for (int i = 0; i < CT_OUT; ++i) acc[i] = zero16();
+
+#pragma unroll 1
+        for (int ci = 0; ci < CT_IN; ++ci) {
+            // this frame's x for channel tile ci: A operand of step 1, reused by the NS subsets
+            float xv[16];
+            const int c = ci * 32 + l31;
+            const bool cok = tv && c < p.Cin;
+            const float* xs = p.x + row0 * p.ld_x + c;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int v = 2 * s + h;
+                xv[s] = (cok && s < ksteps && v < V) ? xs[(long long)v * p.ld_x] : 0.f;
+            }
+#pragma unroll 1
+            for (int k = 0; k < NS; ++k, ++qg) {
+                const int buf = qg & 1;
+                commit_w(buf);
+                __syncthreads();                        // chunk visible; everyone is done with buffer buf^1
+                {
+                    int qn = ci * NS + k + 1;           // next chunk in the (ci, k) cycle
+                    if (qn == nchunks) qn = 0;
+                    prefetch_w(qn);
+                }
+                // step 1: agg^T tile
+                f32x16 agg = zero16();
+                const float* ak = ah + (k * 32) * AHS + l31;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    if (s < ksteps) agg = mfma32(xv[s], ak[(2 * s + h) * AHS], agg);
+                // step 2: y^T tiles; register r of agg is the k-pair {rho(r), rho(r)+4} of the contraction
+                const float* wb = wl + buf * WCHUNK + (4 * h) * WROW + l31;
+                const int cleft = p.Cin - ci * 32;      // valid input channels in this tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rho = (r & 3) + 8 * (r >> 2);
+                    if (rho < cleft) {                  // wave-uniform: skips all-zero weight rows (Cin = 3)
+#pragma unroll
+                        for (int ot = 0; ot < CT_OUT; ++ot)
+                            acc[ot] = mfma32(wb[rho * WROW + ot * 32], agg[r], acc[ot]);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue for this frame -------------------------------------------------------------------------
+        const bool wok = tv && l31 < V;
+        float* yrow = p.y + (row0 + l31) * p.ld_y;
+#pragma unroll
+        for (int ot = 0; ot < CT_OUT; ++ot) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o = ot * 32 + 8 * g + 4 * h;
+                if (o < p.Cout) {                       // Cout % 4 == 0: the quad is all-in or all-out
+                    f32x4 val = {acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]};
+                    if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + o);
+                    if (wok) *reinterpret_cast<f32x4*>(yrow + o) = val;
+                    if (p.stats) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float s1 = wok ? val[e] : 0.f;
+                            float s2 = s1 * s1;
+#pragma unroll
+                            for (int m = 16; m >= 1; m >>= 1) {
+                                s1 += __shfl_xor(s1, m);
+                                s2 += __shfl_xor(s2, m);
+                            }
+                            if (l31 == 0) {
+                                st[(wave * 2 + 0) * WROW + o + e] += s1;
+                                st[(wave * 2 + 1) * WROW + o + e] += s2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * WROW; i += 256) {
+            const int which = i / WROW, o = i - which * WROW;
+            if (o < p.Cout)
+                p.stats[(wg * 2 + which) * p.Cout + o] = st[(0 * 2 + which) * WROW + o] + st[(1 * 2 + which) * WROW + o] +
+                                                          st[(2 * 2 + which) * WROW + o] + st[(3 * 2 + which) * WROW + o];
+        }
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+static int spatial_t_chunk(int B, int T) {
+    int chunk = 32;
+    while (chunk > 4 && (long long)B * cdiv(T, chunk) < 1024) chunk >>= 1;
+    return chunk;
+}
+
+extern "C" int fgcn_spatial_tiles(int B, int T) { return (int)(B * cdiv(T, spatial_t_chunk(B, T))); }
+
+template <int CI, int CO>
+static void launch_spatial(const SpatialP& p, hipStream_t s) {
+    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 2 * 32 * CO * 32 + 4 * 2 * CO * 32) * sizeof(float);
+    dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
+    if (lds > 48 * 1024)  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO>), grid, dim3(256), lds, s, p);
+}
+
+template <int CI>
+static int dispatch_out(int co, const SpatialP& p, hipStream_t s) {
+    switch (co) {
+        case 1: launch_spatial<CI, 1>(p, s); return 0;
+        case 2: launch_spatial<CI, 2>(p, s); return 0;
+        case 4: launch_spatial<CI, 4>(p, s); return 0;
+        case 8: launch_spatial<CI, 8>(p, s); return 0;
+    }
+    return -1;
+}
+
+extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float* wd, const float* bias_sum, float* y,
+                                float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                                int n_subsets, int a_hat_batched, void* stream) {
+    FGCN_REQUIRE(x && a_hat && wd && y, FGCN_E_BADARG, "spatial_fwd: null pointer");
+    FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V && Cin > 0 && Cout > 0, FGCN_E_BADARG,
+                 "spatial_fwd: bad sizes B=%d T=%d V=%d Cin=%d Cout=%d", B, T, V, Cin, Cout);
+    FGCN_REQUIRE(n_subsets >= 1 && n_subsets <= 3, FGCN_E_BADARG, "spatial_fwd: n_subsets=%d (1..3)", n_subsets);
+    FGCN_REQUIRE(Cout % 4 == 0 && ld_y % 4 == 0 && ld_y >= Cout && ld_x >= Cin, FGCN_E_ALIGN,
+                 "spatial_fwd: Cout and ld_y must be multiples of 4, strides must cover the channels");
+    FGCN_REQUIRE(aligned16(y) && aligned16(wd) && (!bias_sum || aligned16(bias_sum)), FGCN_E_ALIGN,
+                 "spatial_fwd: 16-byte alignment");
+    auto tiles = [](int c) { int t = (c + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 8 ? 8 : -1; };
+    const int ci = tiles(Cin), co = tiles(Cout);
+    FGCN_REQUIRE(ci > 0 && co > 0, FGCN_E_BADARG, "spatial_fwd: at most 256 channels (Cin=%d Cout=%d)", Cin, Cout);
+    SpatialP p{x, a_hat, wd, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, n_subsets, a_hat_batched,
+               spatial_t_chunk(B, T)};
+    hipStream_t s = (hipStream_t)stream;
+    int rc = -1;
+    switch (ci) {
+        case 1: rc = dispatch_out<1>(co, p, s); break;
+        case 2: rc = dispatch_out<2>(co, p, s); break;
+        case 4: rc = dispatch_out<4>(co, p, s); break;
+        case 8: rc = dispatch_out<8>(co, p, s); break;
+    }
+    FGCN_REQUIRE(rc == 0, FGCN_E_BADARG, "spatial_fwd: unsupported tile combination");
+    return launch_status("spatial_fwd");
+}

@@ -1,0 +1,304 @@
+"""Thin, checked Python wrappers over the C ABI (include/fgcn.h).
+
+Every function takes torch CUDA tensors (float32, channels-last activations of shape (B, T, V, ld)), validates
+what the kernels assume (device, dtype, contiguity, sizes) and enqueues on torch's current HIP stream.  Nothing
+here computes anything in torch: a missing library or a non-gfx950 device raises ``FgcnError``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GramItem, MixItem, MixTerm, TMap, check
+
+TMAP_POINTWISE = (1, 1, 0, 0, 1)
+
+
+def conv_tmap(kt: int, stride: int) -> Tuple[int, int, int, int, int]:
+    """Temporal map of a (kt x 1) convolution with padding (kt-1)//2 and the given stride."""
+    return (kt, stride, 1, -((kt - 1) // 2), 1)
+
+
+def conv_dgrad_tmap(kt: int, stride: int) -> Tuple[int, int, int, int, int]:
+    """Map of that convolution's data gradient (output frames = the conv's input frames)."""
+    return (kt, 1, -1, (kt - 1) // 2, stride)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.FgcnError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} {t.device} "
+                             f"contiguous={t.is_contiguous()}")
+
+
+def _p(t: Optional[torch.Tensor], coff: int = 0) -> Optional[int]:
+    return None if t is None else t.data_ptr() + 4 * coff
+
+
+_device_ok = False
+
+
+def ensure_device() -> None:
+    global _device_ok
+    if not _device_ok:
+        check(_lib.load().fgcn_check_device(), "fgcn_check_device")
+        _device_ok = True
+
+
+# ---- row GEMMs ---------------------------------------------------------------------------------------------------
+def rows_gemm(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, K: int, N: int, tmap=TMAP_POINTWISE,
+              bias: Optional[torch.Tensor] = None, stats: bool = False, accumulate: bool = False,
+              in_coff: int = 0, out_coff: int = 0) -> Optional[torch.Tensor]:
+    """out[..., out_coff:out_coff+N] (+)= conv(inp[..., in_coff:in_coff+K]); w packed (taps, K, N).
+    Returns the (tiles, 2, N) statistics partials when ``stats``."""
+    ensure_device()
+    _chk(inp, "rows_gemm.in"), _chk(out, "rows_gemm.out"), _chk(w, "rows_gemm.w")
+    B, T_in, V, ld_in = inp.shape
+    Bo, T_out, Vo, ld_out = out.shape
+    taps = tmap[0]
+    if (Bo, Vo) != (B, V) or tuple(w.shape) != (taps, K, N):
+        raise _lib.FgcnError(f"rows_gemm: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} "
+                             f"w={tuple(w.shape)} expected w=({taps},{K},{N})")
+    if in_coff + K > ld_in or out_coff + N > ld_out or in_coff % 4 or out_coff % 4:
+        raise _lib.FgcnError("rows_gemm: channel window outside the tensor or not 4-aligned")
+    if bias is not None:
+        _chk(bias, "rows_gemm.bias")
+        if bias.numel() != N:
+            raise _lib.FgcnError("rows_gemm: bias size")
+    lib = _lib.load()
+    part = None
+    if stats:
+        part = torch.empty((lib.fgcn_rows_gemm_tiles(B * T_out * V), 2, N), device=inp.device, dtype=torch.float32)
+    check(lib.fgcn_rows_gemm(_p(inp, in_coff), _p(out, out_coff), _p(w), _p(bias), _p(part), B, T_in, T_out, V, K, N,
+                             ld_in, ld_out, TMap(*tmap), int(accumulate), _stream()), "fgcn_rows_gemm")
+    return part
+
+
+def _pick_nsplit(M: int, K: int, N: int, taps: int) -> int:
+    tiles = ((K + 63) // 64) * ((N + 63) // 64) * taps
+    want = max(1, 2048 // tiles)
+    return int(max(1, min(want, (M + 511) // 512)))
+
+
+def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_POINTWISE, a_coff: int = 0,
+               g_coff: int = 0, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """(taps, K, N) weight gradient: sum over rows of a[src(row, tap), k] * g[row, n]."""
+    ensure_device()
+    _chk(a, "rows_wgrad.a"), _chk(g, "rows_wgrad.g")
+    B, T_a, V, ld_a = a.shape
+    Bg, T_g, Vg, ld_g = g.shape
+    if (Bg, Vg) != (B, V) or a_coff + K > ld_a + 3 or g_coff + N > ld_g + 3 or a_coff % 4 or g_coff % 4:
+        raise _lib.FgcnError(f"rows_wgrad: shape mismatch a={tuple(a.shape)} g={tuple(g.shape)} K={K} N={N}")
+    taps = tmap[0]
+    lib = _lib.load()
+    nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
+    partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
+    check(lib.fgcn_rows_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_a, T_g, V, K, N, ld_a, ld_g,
+                              TMap(*tmap), nsplit, _stream()), "fgcn_rows_wgrad")
+    if out is None:
+        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
+    reduce_sum(partial.view(nsplit, -1), out.view(-1), accumulate=accumulate)
+    return out
+
+
+def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """dst[i] (+)= sum_s src[s, i]."""
+    ensure_device()
+    _chk(src, "reduce_sum.src"), _chk(dst, "reduce_sum.dst")
+    S, count = src.shape[0], src[0].numel()
+    if dst.numel() != count:
+        raise _lib.FgcnError("reduce_sum: size mismatch")
+    check(_lib.load().fgcn_reduce_sum(_p(dst), _p(src), S, count, int(accumulate), _stream()), "fgcn_reduce_sum")
+    return dst
+
+
+def pack_weight(src: torch.Tensor, taps: int, K: int, N: int, st_tap: int, st_k: int, st_n: int,
+                n_pad: Optional[int] = None, flip: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gather a conv weight into the packed (taps, K, N_pad) layout the row GEMM consumes."""
+    ensure_device()
+    _chk(src, "pack_weight.src")
+    n_dst = N if n_pad is None else n_pad
+    if out is None:
+        out = torch.empty((taps, K, n_dst), device=src.device, dtype=torch.float32)
+    check(_lib.load().fgcn_pack_weight(_p(out), _p(src), taps, K, N, n_dst, st_tap, st_k, st_n, int(flip), _stream()),
+          "fgcn_pack_weight")
+    return out
+
+
+# ---- joint mixing --------------------------------------------------------------------------------------------------
+def mix_items(spec: Sequence[dict]):
+    """spec: [{out_c, width, terms: [(mat, transpose, in_c_lo, in_c_hi, mask), ...]}, ...] -> ctypes array."""
+    arr = (MixItem * len(spec))()
+    for i, it in enumerate(spec):
+        arr[i].out_c, arr[i].width, arr[i].nterms = it["out_c"], it.get("width", 32), len(it["terms"])
+        for j, (mat, tr, lo, hi, mask) in enumerate(it["terms"]):
+            arr[i].term[j] = MixTerm(mat, tr, lo, hi, mask)
+    return arr
+
+
+def joint_mix(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec: Sequence[dict], *, in_channels: int,
+              out_channels: int, accumulate: bool = False) -> torch.Tensor:
+    """out[(n,t,u), oc] (+)= sum_terms sum_v M[u, v] in[(n,t,v), ic]; mats (B|1, n_mats, V, V)."""
+    ensure_device()
+    _chk(inp, "joint_mix.in"), _chk(out, "joint_mix.out"), _chk(mats, "joint_mix.mats")
+    B, T, V, ld_in = inp.shape
+    if out.shape[:3] != inp.shape[:3] or mats.shape[-1] != V or mats.shape[-2] != V or mats.shape[0] not in (1, B):
+        raise _lib.FgcnError(f"joint_mix: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} "
+                             f"mats={tuple(mats.shape)}")
+    items = mix_items(spec)
+    check(_lib.load().fgcn_joint_mix(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], in_channels,
+                                     out_channels, mats.shape[1], int(mats.shape[0] != 1),
+                                     items, len(spec), int(accumulate), _stream()), "fgcn_joint_mix")
+    return out
+
+
+def gram_t_chunk(B: int, T: int) -> int:
+    chunk = 32
+    while chunk > 4 and B * ((T + chunk - 1) // chunk) < 1024:
+        chunk //= 2
+    return chunk
+
+
+def joint_gram(in1: torch.Tensor, in2: torch.Tensor, items: Sequence[Tuple[int, int, int]]) -> torch.Tensor:
+    """items: [(c1, c2, width)] (matrix i from item i) -> partial (B, nchunk, n, 32, 32)."""
+    ensure_device()
+    _chk(in1, "joint_gram.in1"), _chk(in2, "joint_gram.in2")
+    B, T, V, ld1 = in1.shape
+    if in2.shape[:3] != in1.shape[:3]:
+        raise _lib.FgcnError("joint_gram: shape mismatch")
+    n = len(items)
+    arr = (GramItem * n)()
+    for i, (c1, c2, width) in enumerate(items):
+        arr[i] = GramItem(c1, c2, width, i)
+    chunk = gram_t_chunk(B, T)
+    nchunk = (T + chunk - 1) // chunk
+    partial = torch.empty((B, nchunk, n, 32, 32), device=in1.device, dtype=torch.float32)
+    check(_lib.load().fgcn_joint_gram(_p(in1), _p(in2), _p(partial), B, T, V, ld1, in2.shape[3], chunk, n, arr, n,
+                                      _stream()), "fgcn_joint_gram")
+    return partial
+
+
+def adj_softmax_fwd(partial: Optional[torch.Tensor], scale: float, adj_ab: torch.Tensor, B: int,
+                    use_softmax: bool = True):
+    """-> (C (B,K,V,V) or None, a_hat (B,K,V,V))."""
+    ensure_device()
+    _chk(adj_ab, "adj_softmax_fwd.adj_ab")
+    K, V, _ = adj_ab.shape
+    a_hat = torch.empty((B, K, V, V), device=adj_ab.device, dtype=torch.float32)
+    c_out = torch.empty_like(a_hat) if use_softmax else None
+    nchunk = partial.shape[1] if partial is not None else 0
+    check(_lib.load().fgcn_adj_softmax_fwd(_p(partial), nchunk, float(scale), _p(adj_ab), _p(c_out), _p(a_hat), B, K, V,
+                                           int(use_softmax), _stream()), "fgcn_adj_softmax_fwd")
+    return c_out, a_hat
+
+
+def adj_softmax_bwd(partial: torch.Tensor, scale: float, c_in: Optional[torch.Tensor], V: int):
+    """-> (d_a_hat (B,K,V,V), dS (B,K,V,V) or None)."""
+    ensure_device()
+    _chk(partial, "adj_softmax_bwd.partial")
+    B, nchunk, K = partial.shape[:3]
+    d_a_hat = torch.empty((B, K, V, V), device=partial.device, dtype=torch.float32)
+    d_s = torch.empty_like(d_a_hat) if c_in is not None else None
+    check(_lib.load().fgcn_adj_softmax_bwd(_p(partial), nchunk, float(scale), _p(c_in), _p(d_a_hat), _p(d_s), B, K, V,
+                                           _stream()), "fgcn_adj_softmax_bwd")
+    return d_a_hat, d_s
+
+
+# ---- BatchNorm / epilogues -------------------------------------------------------------------------------------------
+def bn_finalize(partials: torch.Tensor, count: int, gamma, beta, running_mean=None, running_var=None,
+                momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+    """-> vec (4, C) = mean, rstd, scale, shift; updates running stats in place when given."""
+    ensure_device()
+    _chk(partials, "bn_finalize.partials")
+    C = partials.shape[-1]
+    vec = torch.empty((4, C), device=partials.device, dtype=torch.float32)
+    check(_lib.load().fgcn_bn_finalize(_p(partials), partials.shape[0], count, _p(gamma), _p(beta), _p(running_mean),
+                                       _p(running_var), momentum, eps, _p(vec), C, _stream()), "fgcn_bn_finalize")
+    return vec
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float = 1e-5) -> torch.Tensor:
+    ensure_device()
+    C = gamma.numel()
+    vec = torch.empty((4, C), device=gamma.device, dtype=torch.float32)
+    check(_lib.load().fgcn_bn_eval_coeffs(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(vec), C,
+                                          _stream()), "fgcn_bn_eval_coeffs")
+    return vec
+
+
+def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = None, vec_b: Optional[torch.Tensor] = None,
+           relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(a*scale_a + shift_a + [b | b*scale_b + shift_b])."""
+    ensure_device()
+    _chk(a, "bn_act.a")
+    C = a.shape[-1]
+    rows = a.numel() // C
+    res_mode = 0 if b is None else (1 if vec_b is None else 2)
+    if b is not None and b.shape != a.shape:
+        raise _lib.FgcnError(f"bn_act: residual shape {tuple(b.shape)} != {tuple(a.shape)}")
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.load().fgcn_bn_act(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(out), rows, C, res_mode, int(relu), _stream()),
+          "fgcn_bn_act")
+    return out
+
+
+def bn_act_bwd(dout: torch.Tensor, out: torch.Tensor, a: torch.Tensor, vec_a: torch.Tensor,
+               b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
+               res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False):
+    """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b."""
+    ensure_device()
+    _chk(dout, "bn_act_bwd.dout"), _chk(a, "bn_act_bwd.a")
+    C = a.shape[-1]
+    rows = a.numel() // C
+    lib = _lib.load()
+    tiles = lib.fgcn_elem_tiles(rows)
+    partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
+    check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials), tiles, rows, C,
+                                     res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
+    sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
+    reduce_sum(partials.view(tiles, -1), sums.view(-1))
+    da = torch.empty_like(a)
+    if res_mode != 0 and db is None:
+        db = torch.empty_like(a)
+    check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da), _p(db), rows,
+                                    C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
+          "fgcn_bn_act_bwd_apply")
+    return da, db, sums
+
+
+def col_sum(x: torch.Tensor, C: int, coff: int = 0) -> torch.Tensor:
+    """Per-channel sum over all rows of x[..., coff:coff+C] -> (C,)."""
+    ensure_device()
+    _chk(x, "col_sum.x")
+    ld = x.shape[-1]
+    rows = x.numel() // ld
+    lib = _lib.load()
+    tiles = lib.fgcn_elem_tiles(rows)
+    partials = torch.empty((tiles, C), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_col_sum(_p(x, coff), _p(partials), rows, C, ld, _stream()), "fgcn_col_sum")
+    out = torch.empty((C,), device=x.device, dtype=torch.float32)
+    return reduce_sum(partials, out)
+
+
+# ---- fused spatial forward -----------------------------------------------------------------------------------------
+def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
+                Cout: int, stats: bool = True):
+    """y = sum_k conv_d[k](x . A^_k) fused; wd packed (K*Cin, Cout).  -> (y (B,T,V,Cout), stats partials or None)."""
+    ensure_device()
+    _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat"), _chk(wd, "spatial_fwd.wd")
+    B, T, V, ld_x = x.shape
+    ns = a_hat.shape[1]
+    if tuple(wd.shape) != (ns * Cin, Cout) or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
+        raise _lib.FgcnError(f"spatial_fwd: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} wd={tuple(wd.shape)}")
+    lib = _lib.load()
+    y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
+    part = torch.empty((lib.fgcn_spatial_tiles(B, T), 2, Cout), device=x.device, dtype=torch.float32) if stats else None
+    check(lib.fgcn_spatial_fwd(_p(x), _p(a_hat), _p(wd), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout, ns,
+                               int(a_hat.shape[0] == B), _stream()), "fgcn_spatial_fwd")
+    return y, part

@@ -1,0 +1,172 @@
+/*
+ * fgcn.h — C ABI of libfgcn.so: the MI355X (gfx950) kernels behind fusion-gcn's AGCN / ST-GCN block.
+ *
+ * The reference (mduhme/fusion-gcn) has no FFI of its own: its hot path is the op sequence of
+ * torch_src/models/mmargcn/agcn.py (SpatialGraphConv :96-115, TemporalConv :49-51, SpatialTemporalConv
+ * :134-136), dispatched to ATen.  Each entry point below names the reference lines whose arithmetic it
+ * replaces.  The Python host (fusion_gcn_amd/ops.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*.
+ *   - activations are float32, channels-last: element (n, t, v, c) of a tensor with row stride `ld`
+ *     lives at base[((n*T + t)*V + v)*ld + c].  `ld` and every channel offset are multiples of 4 floats
+ *     and every base pointer is 16-byte aligned.
+ *   - the caller owns every buffer (outputs, workspaces, partial-sum scratch); the library allocates nothing,
+ *     never synchronises and only enqueues work on `stream`.
+ *   - return value: 0 = ok, <0 = error (FGCN_E_*); text via fgcn_last_error() (thread-local).  Never throws
+ *     or exits.  Shapes are validated on the host before any launch.
+ */
+#ifndef FGCN_H
+#define FGCN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGCN_OK 0
+#define FGCN_E_BADARG (-1)   /* null pointer / inconsistent or unsupported shape */
+#define FGCN_E_ALIGN (-2)    /* pointer or stride not aligned as required */
+#define FGCN_E_LAUNCH (-3)   /* hipLaunchKernel reported an error */
+#define FGCN_E_ARCH (-4)     /* device is not gfx950 */
+
+#define FGCN_MAX_V 32        /* joints per skeleton graph (reference graphs: 18..27) */
+#define FGCN_MIX_MAX_ITEMS 24
+#define FGCN_GRAM_MAX_ITEMS 4
+
+int fgcn_version(void);
+const char* fgcn_last_error(void);
+/* 0 if the current HIP device is gfx950, FGCN_E_ARCH otherwise (message names the arch found). */
+int fgcn_check_device(void);
+
+/* Temporal index map shared by the row GEMMs: for output frame `to` and tap `j`
+ *     num = to*ta + j*tb + tc ;  valid iff num >= 0, num % td == 0 and num/td < T_in ;  ti = num/td.
+ * forward conv (kernel kt, stride s, pad p): ta=s tb=1 tc=-p td=1 ; its data gradient: ta=1 tb=-1 tc=p td=s. */
+typedef struct {
+    int taps, ta, tb, tc, td;
+} fgcn_tmap;
+
+/* out[(n,to,v), 0:N] (+)= bias + sum_j sum_k in[(n,ti(to,j),v), k] * w[j][k][n]      (implicit GEMM over rows)
+ *   replaces nn.Conv2d 1x1 / (kt,1) forward and data-gradient: agcn.py:41-42 (tcn conv), :71-73 (conv_a/b/d),
+ *   :77 (down), :125-132 (residual conv) and their autograd backward w.r.t. the input.
+ *   w is packed [taps][K][N] (N contiguous, N % 4 == 0).  bias may be NULL.
+ *   stat_partials (may be NULL): float[ceil(M/128)][2][N] receives per-row-tile sum and sum of squares of the
+ *   values written (the BatchNorm batch statistics of agcn.py:44,78,83 come from these).  accumulate: out += . */
+int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
+                   int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                   fgcn_tmap map, int accumulate, void* stream);
+/* number of row tiles = leading dimension of stat_partials for M = B*T_out*V rows */
+int fgcn_rows_gemm_tiles(long long M);
+
+/* partial[s][j][k][n] = sum over the s-th slice of rows m=(n,tg,v) of a[(n,ti(tg,j),v), k] * g[m, n]
+ *   (weight gradient of the same convolutions; autograd backward of agcn.py:41-42,71-73,77).
+ *   partial: float[nsplit][taps][K][N]; reduce with fgcn_reduce_sum.  nsplit >= 1. */
+int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
+                    int B, int T_a, int T_g, int V, int K, int N, int ld_a, int ld_g,
+                    fgcn_tmap map, int nsplit, void* stream);
+
+/* dst[i] (+)= sum_s src[s*count + i]   (deterministic tree-free column sum; also bias / adj_b gradients) */
+int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream);
+
+/* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
+ * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */
+int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
+                     long long st_tap, long long st_k, long long st_n, int flip, void* stream);
+
+/* ---- joint-mixing kernels (the "graph" part: A.X over the K=3 partition adjacencies) ------------------ */
+typedef struct {
+    short mat;        /* which V x V matrix of the sample (0..n_mats-1) */
+    short transpose;  /* 0: out_joint = row index of mat;  1: out_joint = column index */
+    short in_c_lo;    /* input channel of lane 0  (lanes 0..15 read in_c_lo + lane) */
+    short in_c_hi;    /* input channel of lane 16 (lanes 16..31 read in_c_hi + lane-16) */
+    short mask;       /* bit0: lanes 0..15 take this term, bit1: lanes 16..31 take it */
+} fgcn_mix_term;
+typedef struct {
+    short out_c;      /* first of the (up to 32) output channels of this tile */
+    short width;      /* lanes (channels) of the tile that exist: 1..32 */
+    short nterms;     /* 1..3 */
+    fgcn_mix_term term[3];
+} fgcn_mix_item;
+
+/* For every sample n, frame t and item: out[(n,t,u), out_c + l] (+)= sum_terms sum_v M[u][v] * in[(n,t,v), in_c(l)]
+ *   with M = mats[n][term.mat] (or its transpose).  One kernel serves
+ *     agg_k = x . A^_k                (agcn.py:109-110, torch.matmul(A2, A1))        and the two backward mixes
+ *     dx += sum_k dagg_k . A^_k^T ,   dtheta_k = dS_k . phi_k ,  dphi_k = dS_k^T . theta_k.
+ *   mats: float[B or 1][n_mats][V][V]; mats_batched = 0 shares one set across the batch (static-adjacency ST-GCN).
+ *   Channels >= in_channels / out_channels are treated as absent. */
+int fgcn_joint_mix(const float* in, float* out, const float* mats, int B, int T, int V,
+                   int ld_in, int ld_out, int in_channels, int out_channels, int n_mats, int mats_batched,
+                   const fgcn_mix_item* items, int n_items, int accumulate, void* stream);
+
+typedef struct {
+    short c1;     /* first channel of in1 */
+    short c2;     /* first channel of in2 */
+    short width;  /* channels contracted */
+    short mat;    /* output matrix index */
+} fgcn_gram_item;
+
+/* partial[n][chunk][mat][u][w] = sum_{t in chunk} sum_c in1[(n,t,u), c1+c] * in2[(n,t,w), c2+c]   (32x32 padded)
+ *   joint affinity  theta^T phi  (agcn.py:104-106, torch.matmul(A1, A2)) and dA^_k = x^T dagg_k in backward.
+ *   partial: float[B][nchunk][n_mats][32][32], nchunk = ceil(T / t_chunk). */
+int fgcn_joint_gram(const float* in1, const float* in2, float* partial, int B, int T, int V,
+                    int ld1, int ld2, int t_chunk, int n_mats, const fgcn_gram_item* items, int n_items,
+                    void* stream);
+
+/* S = scale * sum_chunks partial ; C[n,k,:,w] = softmax over v ; a_hat = C + adj_ab[k]      (agcn.py:84,106-108)
+ *   c_out, a_hat: float[B][K][V][V]; adj_ab: float[K][V][V] (= adj_a + adj_b, agcn.py:100).
+ *   use_softmax = 0 gives the static-adjacency case a_hat = adj_ab (c_out untouched). */
+int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_ab,
+                         float* c_out, float* a_hat, int B, int K, int V, int use_softmax, void* stream);
+/* d_a_hat[n,k] = sum_chunks partial ; dS = scale * C .* (dC - colsum(C .* dC))  with dC = d_a_hat (softmax backward) */
+int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scale, const float* c_in,
+                         float* d_a_hat, float* d_s, int B, int K, int V, void* stream);
+
+/* ---- BatchNorm / activation epilogues ------------------------------------------------------------------ */
+/* mean/var from row-tile partials -> scale = gamma*rstd, shift = beta - mean*scale, and the running-stat update
+ * (momentum, unbiased variance) of nn.BatchNorm2d in train mode (agcn.py:44,78,83; torch defaults eps 1e-5, 0.1).
+ * out_vec: float[4][C] = {mean, rstd, scale, shift}.  running_* may be NULL. */
+int fgcn_bn_finalize(const float* partials, int n_partials, long long count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     float* out_vec, int C, void* stream);
+/* eval mode: scale/shift from running statistics; out_vec as above (mean = running_mean, rstd = 1/sqrt(var+eps)) */
+int fgcn_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* out_vec, int C, void* stream);
+
+/* out = act( a*scale_a + shift_a + r ),  r = 0 | b | b*scale_b + shift_b          (agcn.py:113-115, :135-136)
+ *   res_mode: 0 none, 1 identity, 2 batch-normalised.  vec_a / vec_b: the float[4][C] of fgcn_bn_finalize.
+ *   rows x C elements, all tensors share row stride ld (== C). relu: 0/1. */
+int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
+                long long rows, int C, int res_mode, int relu, void* stream);
+
+/* Backward of the above, pass 1 (reductions): with dP = dout .* [out > 0] (or dout when relu = 0)
+ *   partials[tile][0][c] = sum dP, [1] = sum dP * a_hat, [2] = sum dP * b_hat   (a_hat = (a-mean_a)*rstd_a). */
+int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const float* a, const float* vec_a,
+                           const float* b, const float* vec_b, float* partials, int n_tiles,
+                           long long rows, int C, int res_mode, int relu, void* stream);
+/* pass 2: da = scale_a * (dP - s1/m - a_hat*s2a/m) (train) or scale_a*dP (eval);
+ *         db = dP (identity) or scale_b*(dP - s1/m - b_hat*s2b/m);  sums: float[3][C] reduced partials.
+ *   db may be NULL (res_mode 0); db_accumulate adds into db instead of storing. */
+int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const float* a, const float* vec_a,
+                          const float* b, const float* vec_b, const float* sums, float* da, float* db,
+                          long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
+                          void* stream);
+/* number of row tiles the reduce kernel uses for `rows` rows (leading dim of its partials) */
+int fgcn_elem_tiles(long long rows);
+
+/* partials[tile][c] = sum over the tile's rows of x[row][c]   (bias gradients); n_tiles = fgcn_elem_tiles(rows) */
+int fgcn_col_sum(const float* x, float* partials, long long rows, int C, int ld, void* stream);
+
+/* ---- fused spatial block forward (north-star kernel 1) -------------------------------------------------- */
+/* y[(n,t,w), o] = sum_k bd_k[o] + sum_c Wd_k[o][c] * sum_v x[(n,t,v), c] * a_hat[n][k][v][w]
+ *   = conv_d[k](x . A^_k) summed over the K subsets (agcn.py:103-111) in ONE kernel: A^ staged in LDS, the joint
+ *   aggregation and the Cin x Cout contraction chained on MFMA without materialising agg.
+ *   wd: packed float[K*Cin][Cout] (row k*Cin + c); bias_sum: float[Cout] (= sum_k bd_k) or NULL.
+ *   stat_partials: float[fgcn_spatial_tiles(B,T)][2][Cout] or NULL. */
+int fgcn_spatial_fwd(const float* x, const float* a_hat, const float* wd, const float* bias_sum, float* y,
+                     float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                     int n_subsets, int a_hat_batched, void* stream);
+int fgcn_spatial_tiles(int B, int T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGCN_H */

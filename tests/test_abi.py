@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads, exports every symbol include/fgcn.h
+declares, and rejects malformed calls on the host before any launch (no GPU needed: validation precedes HIP)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from fusion_gcn_amd import _lib, build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fgcn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fgcn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libfgcn.so does not export {n}"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+
+
+def test_version_and_error_text(lib):
+    assert lib.fgcn_version() >= 100
+    rc = lib.fgcn_rows_gemm(None, None, None, None, None, 1, 1, 1, 1, 1, 4, 4, 4, _lib.TMap(1, 1, 0, 0, 1), 0, None)
+    assert rc == -1 and b"null pointer" in lib.fgcn_last_error()
+    with pytest.raises(_lib.FgcnError, match="null pointer"):
+        _lib.check(rc, "fgcn_rows_gemm")
+
+
+def test_host_side_validation(lib):
+    buf = (C.c_float * 64)()
+    p = C.addressof(buf)
+    p16 = (p + 15) // 16 * 16
+    ident = _lib.TMap(1, 1, 0, 0, 1)
+    # N not a multiple of 4
+    assert lib.fgcn_rows_gemm(p16, p16, p16, None, None, 1, 1, 1, 1, 4, 3, 4, 4, ident, 0, None) == -2
+    # row stride smaller than the channel window
+    assert lib.fgcn_rows_gemm(p16, p16, p16, None, None, 1, 1, 1, 1, 8, 4, 4, 4, ident, 0, None) == -1
+    # misaligned base pointer
+    assert lib.fgcn_rows_gemm(p16 + 4, p16, p16, None, None, 1, 1, 1, 1, 4, 4, 4, 4, ident, 0, None) == -2
+    # bad temporal map
+    assert lib.fgcn_rows_gemm(p16, p16, p16, None, None, 1, 1, 1, 1, 4, 4, 4, 4, _lib.TMap(0, 1, 0, 0, 1), 0, None) == -1
+    # more joints than the kernels' 32-wide joint tile
+    item = (_lib.MixItem * 1)()
+    assert lib.fgcn_joint_mix(p16, p16, p16, 1, 1, 33, 4, 4, 4, 4, 1, 0, item, 1, 0, None) == -1
+    assert b"bad B/T/V" in lib.fgcn_last_error()
+    # spatial kernel: more than 256 channels
+    assert lib.fgcn_spatial_fwd(p16, p16, p16, None, p16, None, 1, 1, 25, 512, 64, 512, 64, 3, 1, None) == -1
+    # bn reduce with a wrong tile count
+    assert lib.fgcn_bn_act_bwd_reduce(p16, p16, p16, p16, None, None, p16, 7, 1000, 64, 0, 1, None) == -1
+    assert lib.fgcn_elem_tiles(1000) == 2 and lib.fgcn_rows_gemm_tiles(129) == 2
+    assert lib.fgcn_spatial_tiles(128, 300) == 128 * 10
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under fusion_gcn_amd/ may import it."""
+    pkg = os.path.join(ROOT, "fusion_gcn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from fusion_gcn_amd import ops
+    x = torch.zeros(1, 2, 5, 4)
+    with pytest.raises(_lib.FgcnError):
+        ops.rows_gemm(x, torch.zeros(1, 4, 4), torch.zeros(1, 2, 5, 4), K=4, N=4)

@@ -1,0 +1,323 @@
+"""Per-kernel parity on the MI355X: each libfgcn entry point (through the ctypes wrappers in fusion_gcn_amd.ops)
+against a float64 torch restatement of the same formula on identical seeded inputs.  Forward-type kernels must
+agree to 2e-6 relative L2 (f32 MFMA = exact f32 FMA chains), reductions over ~1e5 rows to 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 3e-6
+RED_TOL = 2e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def to_gpu(t):
+    return t.float().to(dev()).contiguous()
+
+
+def ref_rows_conv(x, w, tmap, T_out, bias=None):
+    """x (B,T_in,V,K) f64, w (taps,K,N): out[b,to,v,:] = sum_j x[b,ti(to,j),v,:] @ w[j]."""
+    taps, ta, tb, tc, td = tmap
+    B, T_in, V, K = x.shape
+    out = torch.zeros(B, T_out, V, w.shape[2], dtype=torch.float64)
+    for to in range(T_out):
+        for j in range(taps):
+            num = to * ta + j * tb + tc
+            if num < 0 or num % td:
+                continue
+            ti = num // td
+            if ti >= T_in:
+                continue
+            out[:, to] += x[:, ti] @ w[j]
+    if bias is not None:
+        out += bias
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,V,K,N,kt,s", [
+    (2, 20, 25, 64, 64, 9, 1),      # temporal conv, stride 1
+    (2, 21, 25, 64, 128, 9, 2),     # stride 2, odd T
+    (3, 10, 18, 128, 96, 1, 1),     # theta|phi embedding shape (N = 96)
+    (2, 12, 22, 256, 384, 1, 1),    # 6ic = 384
+    (2, 9, 27, 4, 64, 1, 1),        # network input (3 channels padded to 4)
+    (1, 30, 25, 192, 64, 1, 1),     # conv_d on stacked agg (K = 3*64)
+    (2, 16, 25, 64, 4, 1, 1),       # data gradient into the padded 4-channel input
+    (1, 7, 5, 40, 36, 3, 1),        # ragged K / N (not multiples of 32), 3 taps
+])
+def test_rows_gemm_forward_and_stats(B, T, V, K, N, kt, s):
+    from fusion_gcn_amd import ops
+    tmap = ops.conv_tmap(kt, s)
+    T_out = (T - 1) // s + 1
+    x, w, b = rnd(B, T, V, K, seed=1), rnd(kt, K, N, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    want = ref_rows_conv(x, w, tmap, T_out, b)
+    out = torch.empty(B, T_out, V, N, device=dev())
+    part = ops.rows_gemm(to_gpu(x), to_gpu(w), out, K=K, N=N, tmap=tmap, bias=to_gpu(b), stats=True)
+    assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
+    tot = part.double().sum(0).cpu()
+    flat = want.reshape(-1, N)
+    assert rel_l2(tot[0].numpy(), flat.sum(0).numpy()) < RED_TOL
+    assert rel_l2(tot[1].numpy(), (flat ** 2).sum(0).numpy()) < RED_TOL
+
+
+def test_rows_gemm_channel_windows_and_accumulate():
+    from fusion_gcn_amd import ops
+    B, T, V = 2, 6, 25
+    x = rnd(B, T, V, 96, seed=4)
+    w = rnd(1, 32, 64, seed=5, scale=0.2)
+    base = rnd(B, T, V, 128, seed=6)
+    out = to_gpu(base)
+    ops.rows_gemm(to_gpu(x), to_gpu(w), out, K=32, N=64, in_coff=64, out_coff=32, accumulate=True)
+    want = base.clone()
+    want[..., 32:96] += x[..., 64:96] @ w[0]
+    assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
+
+
+@pytest.mark.parametrize("kt,s,T", [(9, 1, 20), (9, 2, 21), (9, 2, 20), (1, 2, 11)])
+def test_rows_gemm_data_gradient_map(kt, s, T):
+    """conv_dgrad_tmap reproduces autograd's input gradient of the strided temporal conv."""
+    from fusion_gcn_amd import ops
+    B, V, C, O = 2, 5, 32, 64
+    T_out = (T - 1) // s + 1
+    w = rnd(kt, C, O, seed=7, scale=0.1)                       # forward packed (kt, c, o)
+    x = rnd(B, T, V, C, seed=8).requires_grad_(True)
+    y = ref_rows_conv(x, w, ops.conv_tmap(kt, s), T_out)
+    dy = rnd(B, T_out, V, O, seed=9)
+    (dx_want,) = torch.autograd.grad((y * dy).sum(), x)
+    dx = torch.empty(B, T, V, C, device=dev())
+    ops.rows_gemm(to_gpu(dy), to_gpu(w.permute(0, 2, 1)), dx, K=O, N=C, tmap=ops.conv_dgrad_tmap(kt, s))
+    assert rel_l2(dx.cpu().numpy(), dx_want.numpy()) < FWD_TOL
+
+
+@pytest.mark.parametrize("B,T,V,K,N,kt,s", [(2, 40, 25, 64, 64, 9, 1), (2, 41, 25, 64, 128, 9, 2),
+                                            (4, 64, 25, 128, 96, 1, 1), (2, 30, 22, 4, 64, 1, 1),
+                                            (1, 20, 18, 192, 64, 1, 1), (2, 33, 25, 64, 128, 1, 2)])
+def test_rows_wgrad(B, T, V, K, N, kt, s):
+    from fusion_gcn_amd import ops
+    tmap = ops.conv_tmap(kt, s)
+    T_out = (T - 1) // s + 1
+    a = rnd(B, T, V, K, seed=10)
+    g = rnd(B, T_out, V, N, seed=11)
+    w = torch.zeros(kt, K, N, dtype=torch.float64, requires_grad=True)
+    y = ref_rows_conv(a, w, tmap, T_out)
+    (want,) = torch.autograd.grad((y * g).sum(), w)
+    got = ops.rows_wgrad(to_gpu(a), to_gpu(g), K=K, N=N, tmap=tmap)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < RED_TOL
+
+
+def test_reduce_sum_and_col_sum_and_pack():
+    from fusion_gcn_amd import ops
+    src = rnd(37, 1000, seed=12)
+    dst = torch.ones(1000, device=dev())
+    ops.reduce_sum(to_gpu(src), dst, accumulate=True)
+    assert rel_l2(dst.cpu().numpy(), (src.sum(0) + 1).numpy()) < 1e-6
+    x = rnd(3, 50, 25, 96, seed=13)
+    assert rel_l2(ops.col_sum(to_gpu(x), 96).cpu().numpy(), x.reshape(-1, 96).sum(0).numpy()) < RED_TOL
+    assert rel_l2(ops.col_sum(to_gpu(x), 32, coff=64).cpu().numpy(), x.reshape(-1, 96)[:, 64:].sum(0).numpy()) < RED_TOL
+    w = rnd(64, 32, 9, 1, seed=14)                                         # conv weight (O, C, kt, 1)
+    packed = ops.pack_weight(to_gpu(w), taps=9, K=32, N=64, st_tap=1, st_k=9, st_n=32 * 9)
+    np.testing.assert_array_equal(packed.cpu().numpy(), w[..., 0].permute(2, 1, 0).float().numpy())
+    flipped = ops.pack_weight(to_gpu(w), taps=9, K=32, N=62, st_tap=1, st_k=9, st_n=32 * 9, n_pad=64, flip=True)
+    want = torch.zeros(9, 32, 64)
+    want[..., :62] = w[:62, :, :, 0].permute(2, 1, 0).flip(0).float()
+    np.testing.assert_array_equal(flipped.cpu().numpy(), want.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("V,cin", [(25, 64), (18, 128), (22, 4), (27, 256), (20, 64)])
+def test_joint_mix_aggregation_and_its_transpose(V, cin):
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.block import spec_agg, spec_dx
+    B, T = 3, 9
+    x = rnd(B, T, V, cin, seed=20)
+    a = rnd(B, 3, V, V, seed=21, scale=0.3)
+    want = torch.einsum("btvc,bkvw->btwkc", x, a).reshape(B, T, V, 3 * cin)
+    agg = torch.full((B, T, V, 3 * cin), 7.0, device=dev())
+    ops.joint_mix(to_gpu(x), agg, to_gpu(a), spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+    assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
+    # dx[v, c] = sum_k sum_w dagg[w, (k, c)] a[k, v, w], accumulated onto an existing tensor
+    dagg = rnd(B, T, V, 3 * cin, seed=22)
+    base = rnd(B, T, V, cin, seed=23)
+    want_dx = base + torch.einsum("btwkc,bkvw->btvc", dagg.reshape(B, T, V, 3, cin), a)
+    dx = to_gpu(base)
+    ops.joint_mix(to_gpu(dagg), dx, to_gpu(a), spec_dx(cin), in_channels=3 * cin, out_channels=cin, accumulate=True)
+    assert rel_l2(dx.cpu().numpy(), want_dx.numpy()) < FWD_TOL
+    # shared (static) adjacency
+    ops.joint_mix(to_gpu(x), agg, to_gpu(a[:1]), spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+    want = torch.einsum("btvc,kvw->btwkc", x, a[0]).reshape(B, T, V, 3 * cin)
+    assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
+
+
+@pytest.mark.parametrize("ic", [16, 32, 64])
+def test_joint_mix_embedding_gradient(ic):
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.block import spec_demb
+    B, T, V = 2, 7, 25
+    emb = rnd(B, T, V, 6 * ic, seed=24)
+    ds = rnd(B, 3, V, V, seed=25)
+    e = emb.reshape(B, T, V, 3, 2, ic)
+    theta, phi = e[..., 0, :], e[..., 1, :]                                  # (B,T,V,3,ic)
+    dtheta = torch.einsum("bkvw,btwke->btvke", ds, phi)
+    dphi = torch.einsum("bkvw,btvke->btwke", ds, theta)
+    want = torch.stack([dtheta, dphi], dim=4).reshape(B, T, V, 6 * ic)
+    out = torch.empty(B, T, V, 6 * ic, device=dev())
+    ops.joint_mix(to_gpu(emb), out, to_gpu(ds), spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+    assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
+
+
+@pytest.mark.parametrize("V,T,ic", [(25, 30, 16), (18, 33, 32), (27, 12, 64), (22, 300, 16)])
+def test_joint_gram_and_adjacency_softmax(V, T, ic):
+    from fusion_gcn_amd import ops
+    B = 3
+    emb = rnd(B, T, V, 6 * ic, seed=26)
+    e = emb.reshape(B, T, V, 3, 2, ic)
+    score = torch.einsum("btvke,btwke->bkvw", e[..., 0, :], e[..., 1, :]) / (ic * T)
+    adj_ab = rnd(3, V, V, seed=27, scale=0.2)
+    score.requires_grad_(True)
+    c_want = torch.softmax(score, dim=-2)
+    part = ops.joint_gram(to_gpu(emb), to_gpu(emb), [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(3)])
+    assert part.shape[2:] == (3, 32, 32)
+    got_s = part.double().sum(1)[..., :V, :V].cpu() / (ic * T)
+    assert rel_l2(got_s.numpy(), score.detach().numpy()) < RED_TOL
+    c, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), to_gpu(adj_ab), B)
+    assert rel_l2(c.cpu().numpy(), c_want.detach().numpy()) < 1e-5
+    assert rel_l2(a_hat.cpu().numpy(), (c_want.detach() + adj_ab).numpy()) < 1e-5
+    np.testing.assert_allclose(c.sum(-2).cpu().numpy(), 1.0, atol=1e-5)
+    # backward: partial sums of dA^ -> dA^ and dS through the column softmax
+    d_a = rnd(B, 3, V, V, seed=28)
+    (ds_want,) = torch.autograd.grad((c_want * d_a).sum(), score)
+    fake = torch.zeros(B, 2, 3, 32, 32, dtype=torch.float64)
+    fake[:, 0, :, :V, :V] = 0.25 * d_a
+    fake[:, 1, :, :V, :V] = 0.75 * d_a
+    d_a_hat, d_s = ops.adj_softmax_bwd(to_gpu(fake), 1.0 / (ic * T), c, V)
+    assert rel_l2(d_a_hat.cpu().numpy(), d_a.numpy()) < 1e-6
+    assert rel_l2(d_s.cpu().numpy(), (ds_want / (ic * T)).numpy()) < 2e-5
+    # static adjacency: a_hat is adj_ab, no softmax
+    _, a_static = ops.adj_softmax_fwd(None, 1.0, to_gpu(adj_ab), 1, use_softmax=False)
+    np.testing.assert_array_equal(a_static[0].cpu().numpy(), adj_ab.float().numpy())
+
+
+def test_joint_gram_general_operands():
+    """dA^_k[v, w] = sum_{t,c} x[t, v, c] dagg[t, w, (k, c)] (two different tensors, channel windows)."""
+    from fusion_gcn_amd import ops
+    B, T, V, cin = 2, 10, 25, 64
+    x, dagg = rnd(B, T, V, cin, seed=29), rnd(B, T, V, 3 * cin, seed=30)
+    want = torch.einsum("btvc,btwkc->bkvw", x, dagg.reshape(B, T, V, 3, cin))
+    part = ops.joint_gram(to_gpu(x), to_gpu(dagg), [(0, k * cin, cin) for k in range(3)])
+    assert rel_l2(part.double().sum(1)[..., :V, :V].cpu().numpy(), want.numpy()) < RED_TOL
+    x4, d4 = rnd(B, T, V, 4, seed=31), rnd(B, T, V, 12, seed=32)
+    x4[..., 3] = 0
+    want = torch.einsum("btvc,btwkc->bkvw", x4, d4.reshape(B, T, V, 3, 4))
+    part = ops.joint_gram(to_gpu(x4), to_gpu(d4), [(0, 4 * k, 4) for k in range(3)])
+    assert rel_l2(part.double().sum(1)[..., :V, :V].cpu().numpy(), want.numpy()) < RED_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,res_mode", [(64, 0), (64, 1), (128, 2), (256, 2), (16, 1)])
+def test_batchnorm_epilogue_forward_backward(C, res_mode):
+    from fusion_gcn_amd import ops
+    rows = 3 * 17 * 25
+    a = rnd(rows, C, seed=40) * 1.7 + 0.3
+    b = rnd(rows, C, seed=41) if res_mode else None
+    gam, bet = rnd(C, seed=42).abs() + 0.5, rnd(C, seed=43)
+    gam_b, bet_b = rnd(C, seed=44).abs() + 0.5, rnd(C, seed=45)
+    a_r = a.clone().requires_grad_(True)
+    b_r = b.clone().requires_grad_(True) if b is not None else None
+
+    def bn(t, g_, b_):
+        m, v = t.mean(0), t.var(0, unbiased=False)
+        return (t - m) / torch.sqrt(v + 1e-5) * g_ + b_
+    z = bn(a_r, gam, bet)
+    if res_mode == 1:
+        z = z + b_r
+    elif res_mode == 2:
+        z = z + bn(b_r, gam_b, bet_b)
+    out_want = torch.relu(z)
+
+    # statistics partials as a producer kernel would emit them (two tiles)
+    def partials(t):
+        h = rows // 2
+        p = torch.stack([torch.stack([t[:h].sum(0), (t[:h] ** 2).sum(0)]), torch.stack([t[h:].sum(0), (t[h:] ** 2).sum(0)])])
+        return to_gpu(p)
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    vec_a = ops.bn_finalize(partials(a), rows, to_gpu(gam), to_gpu(bet), rm, rv)
+    assert rel_l2(vec_a[0].cpu().numpy(), a.mean(0).numpy()) < 1e-6
+    assert rel_l2(rm.cpu().numpy(), (0.1 * a.mean(0)).numpy()) < 1e-6
+    assert rel_l2(rv.cpu().numpy(), (0.9 + 0.1 * a.var(0, unbiased=True)).numpy()) < 1e-6
+    vec_b = ops.bn_finalize(partials(b), rows, to_gpu(gam_b), to_gpu(bet_b)) if res_mode == 2 else None
+    ag, bg = to_gpu(a), (to_gpu(b) if b is not None else None)
+    out = ops.bn_act(ag, vec_a, bg, vec_b, relu=True)
+    assert rel_l2(out.cpu().numpy(), out_want.detach().numpy()) < FWD_TOL
+
+    dout = rnd(rows, C, seed=46)
+    ins = [a_r] + ([b_r] if b_r is not None else [])
+    grads = torch.autograd.grad((out_want * dout).sum(), ins + [])
+    # use the oracle's ReLU mask so a borderline activation cannot flip the comparison
+    out_mask = to_gpu(out_want.detach())
+    da, db, sums = ops.bn_act_bwd(to_gpu(dout), out_mask, ag, vec_a, bg, vec_b, res_mode=res_mode, relu=True, train=True)
+    assert rel_l2(da.cpu().numpy(), grads[0].numpy()) < 2e-5
+    if res_mode:
+        assert rel_l2(db.cpu().numpy(), grads[1].numpy()) < 2e-5
+    dp = dout * (out_want.detach() > 0)
+    a_hat = (a - a.mean(0)) / torch.sqrt(a.var(0, unbiased=False) + 1e-5)
+    assert rel_l2(sums[0].cpu().numpy(), dp.sum(0).numpy()) < RED_TOL
+    assert rel_l2(sums[1].cpu().numpy(), (dp * a_hat).sum(0).numpy()) < RED_TOL
+    # eval-mode coefficients
+    vec_e = ops.bn_eval_coeffs(to_gpu(gam), to_gpu(bet), rm, rv)
+    want_scale = gam / torch.sqrt(rv.cpu().double() + 1e-5)
+    assert rel_l2(vec_e[2].cpu().numpy(), want_scale.numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,V,cin,cout,batched", [
+    (2, 10, 25, 64, 64, True), (3, 9, 25, 4, 64, True), (2, 13, 18, 64, 128, True), (2, 6, 22, 128, 128, True),
+    (2, 5, 27, 128, 256, True), (1, 7, 25, 256, 256, True), (2, 10, 20, 64, 64, False)])
+def test_fused_spatial_forward(B, T, V, cin, cout, batched):
+    """y = sum_k conv_d[k](x . A^_k): fused kernel vs the einsum composition and vs the unfused kernel pair."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.block import spec_agg
+    x = rnd(B, T, V, cin, seed=50)
+    if cin == 4:
+        x[..., 3] = 0
+    a = rnd(B if batched else 1, 3, V, V, seed=51, scale=0.3)
+    wd = rnd(3 * cin, cout, seed=52, scale=(3 * cin) ** -0.5)
+    bias = rnd(cout, seed=53)
+    agg = torch.einsum("btvc,bkvw->btwkc", x, a.expand(B, 3, V, V)).reshape(B, T, V, 3 * cin)
+    want = agg @ wd + bias
+    y, part = ops.spatial_fwd(to_gpu(x), to_gpu(a), to_gpu(wd), to_gpu(bias), Cin=cin, Cout=cout, stats=True)
+    assert rel_l2(y.cpu().numpy(), want.numpy()) < FWD_TOL
+    tot = part.double().sum(0).cpu()
+    flat = want.reshape(-1, cout)
+    assert rel_l2(tot[0].numpy(), flat.sum(0).numpy()) < RED_TOL
+    assert rel_l2(tot[1].numpy(), (flat ** 2).sum(0).numpy()) < RED_TOL
+    # unfused pair gives the same tensor (different summation order)
+    agg_g = torch.empty(B, T, V, 3 * cin, device=dev())
+    ops.joint_mix(to_gpu(x), agg_g, to_gpu(a), spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+    y2 = torch.empty(B, T, V, cout, device=dev())
+    ops.rows_gemm(agg_g, to_gpu(wd).unsqueeze(0), y2, K=3 * cin, N=cout, bias=to_gpu(bias))
+    assert rel_l2(y2.cpu().numpy(), y.cpu().numpy()) < FWD_TOL
+
+
+def test_kernels_are_deterministic():
+    """Same inputs, same bits (no atomics anywhere in the path)."""
+    from fusion_gcn_amd import ops
+    x, w = to_gpu(rnd(4, 50, 25, 64, seed=60)), to_gpu(rnd(9, 64, 64, seed=61, scale=0.05))
+    outs = []
+    for _ in range(2):
+        out = torch.empty(4, 50, 25, 64, device=dev())
+        part = ops.rows_gemm(x, w, out, K=64, N=64, tmap=ops.conv_tmap(9, 1), stats=True)
+        g = ops.rows_wgrad(x, out, K=64, N=64, tmap=ops.conv_tmap(9, 1))
+        outs.append((out.clone(), part.clone(), g.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
