@@ -130,6 +130,11 @@ def cpu_baseline(n_clips: int = 4, iters: int = 2):
                        f"(C,T,V,M)=(3,300,25,2) workload, 1 warm-up + {iters} timed iterations, {dt:.2f} s/iter")
 
 
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,9 +185,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model + data resident on {device}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         step()
     fence()
+    log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -192,7 +199,8 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    log(f"{args.steps} steps in {elapsed:.3f} s; timing the dominant kernel")
 
     kern = None if args.no_kernel_timing else time_dominant_kernel(device, (shard.stop - shard.start) * SHAPE["M"])
     if rank == 0:
@@ -226,6 +234,7 @@ def main():
                                "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
                                               for d in kern]}
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle on the host cores")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -70,6 +70,9 @@ def load() -> C.CDLL:
     """Load libfgcn.so once; raises (never falls back) when it is absent."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already mapped when
+        # libfgcn.so resolves its HIP symbols, otherwise two runtimes coexist and ours sees no device.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise FgcnError(f"{LIB_PATH} not found: build the HIP extension first (python -m fusion_gcn_amd.build). "
                             "There is no CPU / eager fallback for the AGCN block.")

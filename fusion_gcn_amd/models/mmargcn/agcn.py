@@ -140,7 +140,7 @@ class SpatialTemporalConv(nn.Module):
     def _adj_a(self) -> torch.Tensor:
         return self.gcn1.adj_a
 
-    def _buffers(self) -> Dict[str, torch.Tensor]:
+    def _block_buffers(self) -> Dict[str, torch.Tensor]:
         bufs = {"gcn1.adj_a": self._adj_a()}
         for bn in bn_names(self.cfg):
             mod = self._tensor(bn)
@@ -159,7 +159,7 @@ class SpatialTemporalConv(nn.Module):
         params = [self._tensor(n) for n in names]
         W = self._packed(params)
         holder = {}
-        out = STBlockFunction.apply(x, self.cfg, self.training, self._buffers(), W, holder, *params)
+        out = STBlockFunction.apply(x, self.cfg, self.training, self._block_buffers(), W, holder, *params)
         if self.training:
             for bn in bn_names(self.cfg):
                 self._tensor(bn).num_batches_tracked += 1
