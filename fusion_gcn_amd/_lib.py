@@ -28,6 +28,14 @@ class MixItem(C.Structure):
     _fields_ = [("out_c", C.c_short), ("width", C.c_short), ("nterms", C.c_short), ("term", MixTerm * 3)]
 
 
+class MixVTerm(C.Structure):
+    _fields_ = [("mat", C.c_short), ("transpose", C.c_short), ("in_c", C.c_short)]
+
+
+class MixVItem(C.Structure):
+    _fields_ = [("out_c", C.c_short), ("nch", C.c_short), ("nterms", C.c_short), ("term", MixVTerm * 3)]
+
+
 class GramItem(C.Structure):
     _fields_ = [("c1", C.c_short), ("c2", C.c_short), ("width", C.c_short), ("mat", C.c_short)]
 
@@ -45,6 +53,7 @@ SIGNATURES = {
     "fgcn_reduce_sum": (_I, [_P, _P, _I, _LL, _I, _P]),
     "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
+    "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P]),
     "fgcn_joint_gram": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(GramItem), _I, _P]),
     "fgcn_adj_softmax_fwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_adj_softmax_bwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),

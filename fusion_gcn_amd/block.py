@@ -143,6 +143,35 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
+def _vec_width(cin: int) -> int:
+    """Channels per lane of the vectorised mix kernel (0: use the dword kernel, e.g. the 4-channel input)."""
+    return 4 if cin % 128 == 0 else (2 if cin % 64 == 0 else 0)
+
+
+def mix_agg(x: torch.Tensor, agg: torch.Tensor, a_hat: torch.Tensor, cin: int) -> None:
+    """agg[(k, c)] = x . A^_k for the three subsets."""
+    vw = _vec_width(cin)
+    if not vw:
+        ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+        return
+    g = 32 * vw
+    spec = [dict(out_c=k * cin + c0, nch=min(g, cin - c0), terms=[(k, 1, c0)])
+            for k in range(NUM_SUBSETS) for c0 in range(0, cin, g)]
+    ops.joint_mix_vec(x, agg, a_hat, spec, vw=vw)
+
+
+def mix_dx(dagg: torch.Tensor, dx: torch.Tensor, a_hat: torch.Tensor, cin: int, accumulate: bool) -> None:
+    """dx (+)= sum_k dagg_k . A^_k^T."""
+    vw = _vec_width(cin)
+    if not vw:
+        ops.joint_mix(dagg, dx, a_hat, spec_dx(cin), in_channels=3 * cin, out_channels=cin, accumulate=accumulate)
+        return
+    g = 32 * vw
+    spec = [dict(out_c=c0, nch=min(g, cin - c0), terms=[(k, 0, k * cin + c0) for k in range(NUM_SUBSETS)])
+            for c0 in range(0, cin, g)]
+    ops.joint_mix_vec(dagg, dx, a_hat, spec, vw=vw, accumulate=accumulate)
+
+
 def spec_demb(ic: int) -> List[dict]:
     """dtheta_k = dS_k . phi_k (transpose 0), dphi_k = dS_k^T . theta_k (transpose 1); embedding channels are
     [th0 ph0 th1 ph1 th2 ph2], each ``ic`` (a multiple of 16) wide, so a 32-lane tile may straddle two groups."""
@@ -199,7 +228,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         y, part = ops.spatial_fwd(x, a_hat, W["d"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     else:
         agg = new(B, T, V, 3 * cin)
-        ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+        mix_agg(x, agg, a_hat, cin)
         y = new(B, T, V, cout)
         part = ops.rows_gemm(agg, W["d"].unsqueeze(0), y, K=3 * cin, N=cout, bias=W["d_b"], stats=train)
     vec_y = _bn_vec(part, B * T * V, P, bufs, "gcn1.bn", train)
@@ -294,13 +323,13 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     dagg = new(B, T, V, c3)
     ops.rows_gemm(dy, W["d_t"], dagg, K=cout, N=c3)
     agg = new(B, T, V, c3)
-    ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
+    mix_agg(x, agg, a_hat, cin)
     gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)[0]                              # (3cin, cout)
     dbias = ops.col_sum(dy, cout)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
         G[f"gcn1.conv_d.{k}.bias"] = dbias
-    ops.joint_mix(dagg, dx, a_hat, spec_dx(cin), in_channels=3 * cin, out_channels=cin, accumulate=dx_live)
+    mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
     dx_live = True
     part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)

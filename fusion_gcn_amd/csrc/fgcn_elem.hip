@@ -10,16 +10,16 @@ constexpr int ELEM_ROWS_PER_TILE = 512;
 constexpr int ELEM_MAX_TILES = 4096;
 
 // ---- BatchNorm finalize ------------------------------------------------------------------------------------
-// block = 32 channels x 8 partial-groups; double accumulation of the float tile sums.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int P, long long count,
-                                                          const float* gamma, const float* beta, float* rmean,
-                                                          float* rvar, float momentum, float eps, float* out, int C) {
-    __shared__ double s1[8][32], s2[8][32];
+// block = 32 channels x 32 partial-groups; double accumulation of the float tile sums, fixed summation order.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials, int P, long long count,
+                                                           const float* gamma, const float* beta, float* rmean,
+                                                           float* rvar, float momentum, float eps, float* out, int C) {
+    __shared__ double s1[32][33], s2[32][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int i = g; i < P; i += 8) {
+        for (int i = g; i < P; i += 32) {
             a += (double)partials[((long long)i * 2 + 0) * C + c];
             b += (double)partials[((long long)i * 2 + 1) * C + c];
         }
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials,
     s2[g][cl] = b;
     __syncthreads();
     if (g == 0 && c < C) {
-        for (int i = 1; i < 8; ++i) {
+        for (int i = 1; i < 32; ++i) {
             a += s1[i][cl];
             b += s2[i][cl];
         }
@@ -216,7 +216,7 @@ extern "C" int fgcn_bn_finalize(const float* partials, int n_partials, long long
                                 float* out_vec, int C, void* stream) {
     FGCN_REQUIRE(partials && gamma && beta && out_vec && n_partials > 0 && count > 0 && C > 0, FGCN_E_BADARG,
                  "bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials,
                        n_partials, count, gamma, beta, running_mean, running_var, momentum, eps, out_vec, C);
     return launch_status("bn_finalize");
 }

@@ -271,12 +271,24 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
     }
 }
 
-__global__ void reduce_sum_kernel(float* dst, const float* src, int S, long long count, int accumulate) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-         i += (long long)gridDim.x * blockDim.x) {
-        float t = 0.f;
-        for (int s = 0; s < S; ++s) t += src[(long long)s * count + i];
-        dst[i] = accumulate ? dst[i] + t : t;
+// dst[i] (+)= sum_s src[s][i].  block = 64 outputs x 16 slice-lanes: lane y adds slices y, y+16, ... in order, then
+// the 16 partial sums are added in a fixed order -> deterministic, and S-way parallel (S reaches thousands for the
+// BatchNorm / bias partials, where one thread per output would serialise thousands of dependent loads).
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(float* dst, const float* src, int S, long long count,
+                                                          int accumulate) {
+    __shared__ float red[16][65];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const long long i = (long long)blockIdx.x * 64 + x;
+    float t = 0.f;
+    if (i < count)
+        for (int s = y; s < S; s += 16) t += src[(long long)s * count + i];
+    red[y][x] = t;
+    __syncthreads();
+    if (y == 0 && i < count) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][x];
+        dst[i] = accumulate ? dst[i] + a : a;
     }
 }
 
@@ -370,9 +382,9 @@ extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
 
 extern "C" int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream) {
     FGCN_REQUIRE(dst && src && S > 0 && count > 0, FGCN_E_BADARG, "reduce_sum: bad argument");
-    const unsigned blocks = (unsigned)(cdiv(count, 256) < 4096 ? cdiv(count, 256) : 4096);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, S, count,
-                       accumulate);
+    FGCN_REQUIRE(cdiv(count, 64) < (1ll << 31), FGCN_E_BADARG, "reduce_sum: count too large");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)cdiv(count, 64)), dim3(64, 16), 0, (hipStream_t)stream, dst, src,
+                       S, count, accumulate);
     return launch_status("reduce_sum");
 }
 

@@ -51,13 +51,16 @@ __global__ __launch_bounds__(256) void joint_mix_kernel(MixP p) {
                 const float* mrow = &mat[term.mat * 32 * MS];
                 // A[i = out joint][k = in joint] = M[i][k] (or M[k][i]); B[k = in joint][j = channel]
                 const int a_i = term.transpose ? 1 : MS, a_k = term.transpose ? MS : 1;
-#pragma unroll 4
-                for (int s = 0; s < ksteps; ++s) {
+                // all of the frame's loads for this term go out back to back, then the MFMA chain consumes them
+                float bv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
                     const int k = 2 * s + h;
-                    const float a = mrow[l31 * a_i + k * a_k];
-                    const float b = (take && k < V) ? src[(long long)k * p.ld_in] : 0.f;
-                    acc = mfma32(a, b, acc);
+                    bv[s] = (take && s < ksteps && k < V) ? src[(long long)k * p.ld_in] : 0.f;
                 }
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    if (s < ksteps) acc = mfma32(mrow[l31 * a_i + (2 * s + h) * a_k], bv[s], acc);
             }
             const int c_out = item.out_c + l31;
             if (c_out < p.out_ch && l31 < item.width) {
@@ -67,6 +70,85 @@ __global__ __launch_bounds__(256) void joint_mix_kernel(MixP p) {
                     if (u < V) {
                         float* dst = p.out + (row0 + u) * p.ld_out + c_out;
                         *dst = p.accumulate ? *dst + acc[r] : acc[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Vectorised form for the two big mixes of the backward pass (agg recompute, dx): lane j owns VW consecutive
+// channels (one 4/8/16-byte load per joint instead of VW dword loads), tile m of the group holds channel
+// base + VW*j + m, so loads and stores are fully contiguous (32*VW channels per half-wave access).
+struct MixVP {
+    const float* in;
+    float* out;
+    const float* mats;
+    int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, accumulate, t_chunk;
+    fgcn_mixv_item items[FGCN_MIX_MAX_ITEMS];
+};
+
+template <int VW>
+__global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
+    using vec = __attribute__((ext_vector_type(VW))) float;
+    __shared__ float mat[MIX_MAX_MATS * 32 * MS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V;
+
+    const float* msrc = p.mats + (p.mats_batched ? (long long)n * p.n_mats * V * V : 0);
+    for (int i = tid; i < p.n_mats * 32 * 32; i += 256) {
+        const int mi = i >> 10, u = (i >> 5) & 31, w = i & 31;
+        mat[(mi * 32 + u) * MS + w] = (u < V && w < V) ? msrc[(mi * V + u) * V + w] : 0.f;
+    }
+    __syncthreads();
+
+    const int ksteps = (V + 1) >> 1;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const long long row0 = ((long long)n * p.T + t) * V;
+        for (int it = 0; it < p.n_items; ++it) {
+            const fgcn_mixv_item& item = p.items[it];
+            const bool lane_ok = VW * l31 < item.nch;
+            f32x16 acc[VW];
+#pragma unroll
+            for (int m = 0; m < VW; ++m) acc[m] = zero16();
+            for (int tr = 0; tr < item.nterms; ++tr) {
+                const float* src = p.in + row0 * p.ld_in + item.term[tr].in_c + VW * l31;
+                const float* mrow = &mat[item.term[tr].mat * 32 * MS];
+                const int a_i = item.term[tr].transpose ? 1 : MS, a_k = item.term[tr].transpose ? MS : 1;
+                vec bv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = 2 * s + h;
+                    vec v;
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) v[m] = 0.f;
+                    if (lane_ok && s < ksteps && k < V) v = *reinterpret_cast<const vec*>(src + (long long)k * p.ld_in);
+                    bv[s] = v;
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if (s < ksteps) {
+                        const float a = mrow[l31 * a_i + (2 * s + h) * a_k];
+#pragma unroll
+                        for (int m = 0; m < VW; ++m) acc[m] = mfma32(a, bv[s][m], acc[m]);
+                    }
+                }
+            }
+            if (lane_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = acc_row(r, lane);
+                    if (u < V) {
+                        vec* dst = reinterpret_cast<vec*>(p.out + (row0 + u) * p.ld_out + item.out_c + VW * l31);
+                        vec v;
+#pragma unroll
+                        for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
                     }
                 }
             }
@@ -117,12 +199,22 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
                 const float* s1 = p.in1 + row * p.ld1 + item.c1 + 4 * h;
                 const float* s2 = p.in2 + row * p.ld2 + item.c2 + 4 * h;
                 const int nq = (item.width + 7) >> 3;
-                for (int q = 0; q < nq; ++q) {
-                    // lane half h contracts channels 8q + 4h + e on both operands
-                    const f32x4 a = load4_masked(s1 + 8 * q, 8 * q + 4 * h, item.width, row_ok);
-                    const f32x4 b = load4_masked(s2 + 8 * q, 8 * q + 4 * h, item.width, row_ok);
+                for (int q0 = 0; q0 < nq; q0 += 4) {
+                    // lane half h contracts channels 8q + 4h + e on both operands; 8 loads in flight, then 16 MFMAs
+                    f32x4 a[4], b[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[it] = mfma32(a[e], b[e], acc[it]);
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = q0 + j;
+                        a[j] = load4_masked(s1 + 8 * q, 8 * q + 4 * h, item.width, row_ok && q < nq);
+                        b[j] = load4_masked(s2 + 8 * q, 8 * q + 4 * h, item.width, row_ok && q < nq);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (q0 + j < nq) {   // wave-uniform
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[it] = mfma32(a[j][e], b[j][e], acc[it]);
+                        }
+                    }
                 }
             }
         }
@@ -286,4 +378,37 @@ extern "C" int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scal
     hipLaunchKernelGGL(adj_softmax_bwd_kernel, dim3((unsigned)cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream,
                        partial, nchunk, scale, c_in, d_a_hat, d_s, B, K, V);
     return launch_status("adj_softmax_bwd");
+}
+
+extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
+                                  int ld_in, int ld_out, int n_mats, int mats_batched,
+                                  const fgcn_mixv_item* items, int n_items, int vw, int accumulate, void* stream) {
+    FGCN_REQUIRE(in && out && mats && items, FGCN_E_BADARG, "joint_mix_vec: null pointer");
+    FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
+                 "joint_mix_vec: bad B/T/V (%d,%d,%d)", B, T, V);
+    FGCN_REQUIRE(n_mats >= 1 && n_mats <= MIX_MAX_MATS && n_items >= 1 && n_items <= FGCN_MIX_MAX_ITEMS,
+                 FGCN_E_BADARG, "joint_mix_vec: n_mats=%d n_items=%d out of range", n_mats, n_items);
+    FGCN_REQUIRE(vw == 2 || vw == 4, FGCN_E_BADARG, "joint_mix_vec: vw must be 2 or 4 (got %d)", vw);
+    FGCN_REQUIRE(ld_in % 4 == 0 && ld_out % 4 == 0 && aligned16(in) && aligned16(out), FGCN_E_ALIGN,
+                 "joint_mix_vec: 16-byte alignment");
+    MixVP p;
+    p.in = in; p.out = out; p.mats = mats;
+    p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out;
+    p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items; p.accumulate = accumulate;
+    p.t_chunk = pick_t_chunk(B, T);
+    for (int i = 0; i < n_items; ++i) {
+        const fgcn_mixv_item& it = items[i];
+        FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.nch >= vw && it.nch <= 32 * vw && it.nch % vw == 0 &&
+                         it.out_c >= 0 && it.out_c % vw == 0 && it.out_c + it.nch <= ld_out,
+                     FGCN_E_BADARG, "joint_mix_vec: item %d malformed", i);
+        for (int t = 0; t < it.nterms; ++t)
+            FGCN_REQUIRE(it.term[t].mat >= 0 && it.term[t].mat < n_mats && it.term[t].in_c >= 0 &&
+                             it.term[t].in_c % vw == 0 && it.term[t].in_c + it.nch <= ld_in,
+                         FGCN_E_BADARG, "joint_mix_vec: item %d term %d malformed", i, t);
+        p.items[i] = it;
+    }
+    dim3 grid((unsigned)cdiv(T, p.t_chunk), (unsigned)B);
+    if (vw == 4) hipLaunchKernelGGL(joint_mix_vec_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(joint_mix_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("joint_mix_vec");
 }

@@ -97,6 +97,24 @@ int fgcn_joint_mix(const float* in, float* out, const float* mats, int B, int T,
                    int ld_in, int ld_out, int in_channels, int out_channels, int n_mats, int mats_batched,
                    const fgcn_mix_item* items, int n_items, int accumulate, void* stream);
 
+/* Vectorised variant for whole channel groups (no 16-lane masks): lane j of a group owns `vw` (2 or 4) consecutive
+ * channels, so one item covers up to 32*vw channels with 8/16-byte loads and stores.  Same formula as
+ * fgcn_joint_mix; used for the two large mixes of the backward pass (agg recompute and dx). */
+typedef struct {
+    short mat;
+    short transpose;
+    short in_c;       /* first input channel of the group (multiple of vw) */
+} fgcn_mixv_term;
+typedef struct {
+    short out_c;      /* first output channel of the group (multiple of vw) */
+    short nch;        /* channels in the group: vw .. 32*vw, multiple of vw */
+    short nterms;     /* 1..3 */
+    fgcn_mixv_term term[3];
+} fgcn_mixv_item;
+int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
+                       int ld_in, int ld_out, int n_mats, int mats_batched,
+                       const fgcn_mixv_item* items, int n_items, int vw, int accumulate, void* stream);
+
 typedef struct {
     short c1;     /* first channel of in1 */
     short c2;     /* first channel of in2 */

@@ -159,6 +159,25 @@ def test_joint_mix_aggregation_and_its_transpose(V, cin):
     assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("V,cin", [(25, 64), (18, 128), (27, 256), (22, 192)])
+def test_joint_mix_vectorised_groups(V, cin):
+    """The 8/16-byte-per-lane variant used by the backward pass gives the same agg / dx as the einsum."""
+    from fusion_gcn_amd.block import mix_agg, mix_dx
+    B, T = 3, 9
+    x, a = rnd(B, T, V, cin, seed=70), rnd(B, 3, V, V, seed=71, scale=0.3)
+    want = torch.einsum("btvc,bkvw->btwkc", x, a).reshape(B, T, V, 3 * cin)
+    agg = torch.full((B, T, V, 3 * cin), 7.0, device=dev())
+    mix_agg(to_gpu(x), agg, to_gpu(a), cin)
+    assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
+    dagg, base = rnd(B, T, V, 3 * cin, seed=72), rnd(B, T, V, cin, seed=73)
+    want_dx = base + torch.einsum("btwkc,bkvw->btvc", dagg.reshape(B, T, V, 3, cin), a)
+    dx = to_gpu(base)
+    mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=True)
+    assert rel_l2(dx.cpu().numpy(), want_dx.numpy()) < FWD_TOL
+    mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=False)
+    assert rel_l2(dx.cpu().numpy(), (want_dx - base).numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("ic", [16, 32, 64])
 def test_joint_mix_embedding_gradient(ic):
     from fusion_gcn_amd import ops
