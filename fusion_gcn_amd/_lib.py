@@ -47,6 +47,7 @@ SIGNATURES = {
     "fgcn_version": (_I, []),
     "fgcn_last_error": (C.c_char_p, []),
     "fgcn_check_device": (_I, []),
+    "fgcn_set_tuning": (_I, [_I, _I]),
     "fgcn_rows_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_rows_gemm_tiles": (_I, [_LL]),
     "fgcn_rows_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),

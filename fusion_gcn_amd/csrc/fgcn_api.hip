@@ -8,7 +8,15 @@ char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
+static int g_tuning[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
 }  // namespace fgcn
+
+extern "C" int fgcn_set_tuning(int key, int value) {
+    if (key < 0 || key >= 8) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);
+    fgcn::g_tuning[key] = value;
+    return FGCN_OK;
+}
 
 extern "C" int fgcn_version(void) { return 100; }  // 0.1.0
 

@@ -39,6 +39,10 @@ inline int launch_status(const char* what) {
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// Kernel-variant selectors (fgcn_set_tuning): defaults are the measured-best variants; tests and tools/kbench.py
+// flip them to compare.  key 0: row-GEMM tile for <= 64 output channels, key 1: for wider outputs (see fgcn_gemm.hip).
+int tuning(int key);
+
 // ---- device: MFMA 32x32x2 f32 -----------------------------------------------------------------------------
 // A operand: lane l holds A[i = l & 31][k = l >> 5];  B operand: lane l holds B[k = l >> 5][j = l & 31];
 // C/D: lane l, register r holds D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31].

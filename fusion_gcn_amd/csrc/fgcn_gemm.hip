@@ -29,23 +29,26 @@ struct RowsGemmP {
     int accumulate;
 };
 
-template <int NT>
+// MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
+// DB = double-buffered LDS (one barrier per K chunk instead of two, at twice the LDS footprint).
+template <int MT, int NT, bool DB>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
-    constexpr int BM = 128, BK = 32, BN = 32 * NT, AS = BK + 4;
-    __shared__ __attribute__((aligned(16))) float As[BM * AS];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+    constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
+    constexpr int AR = 4 * MT;                         // A-tile rows staged per thread
+    __shared__ __attribute__((aligned(16))) float As[NBUF * BM * AS];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF * BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int k4 = (tid & 7) * 4;
 
-    // the four A-tile rows this thread stages: r = (tid >> 3) + 32*i
-    long long rbase[4];
-    int rto[4];
+    // the A-tile rows this thread stages: r = (tid >> 3) + 32*i
+    long long rbase[AR];
+    int rto[AR];
     const int TV = p.T_out * p.V;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AR; ++i) {
         const long long m = m0 + (tid >> 3) + 32 * i;
         if (m < p.M) {
             const int n = (int)(m / TV);
@@ -62,16 +65,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
 
     const int KC = (p.K + BK - 1) / BK;
     const int S = p.taps * KC;
-    f32x4 areg[4], breg[NT];
-    f32x16 acc[NT];
+    f32x4 areg[AR], breg[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = zero16();
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero16();
 
     auto load_stage = [&](int s) {
         const int tap = s / KC;
         const int kc = (s - tap * KC) * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AR; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int ti = rto[i] >= 0 ? tmap_src(rto[i], tap, p.ta, p.tb, p.tc, p.td, p.T_in) : -1;
             const int k = kc + k4;
@@ -100,31 +105,39 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
 
     load_stage(0);
     for (int s = 0; s < S; ++s) {
-        __syncthreads();  // previous chunk's LDS reads are done
+        float* Ab = As + (DB ? (s & 1) * BM * AS : 0);
+        float* Bb = Bs + (DB ? (s & 1) * BK * BN : 0);
+        if (!DB) __syncthreads();  // previous chunk's LDS reads are done (DB: the other buffer is being read)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(&As[((tid >> 3) + 32 * i) * AS + k4]) = areg[i];
+        for (int i = 0; i < AR; ++i)
+            *reinterpret_cast<f32x4*>(&Ab[((tid >> 3) + 32 * i) * AS + k4]) = areg[i];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int idx = tid + 256 * i;
             const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
-            *reinterpret_cast<f32x4*>(&Bs[kk * BN + 4 * n4]) = breg[i];
+            *reinterpret_cast<f32x4*>(&Bb[kk * BN + 4 * n4]) = breg[i];
         }
         __syncthreads();
         const int kc = (s % KC) * BK;
         if (s + 1 < S) load_stage(s + 1);  // in flight while this chunk's MFMAs run
         const int kleft = p.K - kc;
         const int nq = kleft >= BK ? BK / 8 : (kleft + 7) / 8;
-        const float* arow = &As[(wave * 32 + (lane & 31)) * AS + 4 * (lane >> 5)];
-        const float* bcol = &Bs[(4 * (lane >> 5)) * BN + (lane & 31)];
+        const float* arow = &Ab[(wave * 32 * MT + (lane & 31)) * AS + 4 * (lane >> 5)];
+        const float* bcol = &Bb[(4 * (lane >> 5)) * BN + (lane & 31)];
         for (int q = 0; q < nq; ++q) {
             // lane half h holds k = 8q + 4h + e (e = 0..3): any k permutation is fine as long as A and B agree
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * q);
+            f32x4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(arow + mt * 32 * AS + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                float bv[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = mfma32(av[e], bcol[(8 * q + e) * BN + nt * 32], acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bcol[(8 * q + e) * BN + nt * 32];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[mt][e], bv[nt], acc[mt][nt]);
             }
         }
     }
@@ -139,15 +152,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
         const bool cok = col < p.N;
         const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long m = m0 + wave * 32 + acc_row(r, lane);
-            if (cok && m < p.M) {
-                float* dst = p.out + m * p.ld_out + col;
-                float val = acc[nt][r] + bv;
-                if (p.accumulate) val += *dst;
-                *dst = val;
-                ssum[nt] += val;
-                ssq[nt] += val * val;
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wave * 32 * MT + mt * 32 + acc_row(r, lane);
+                if (cok && m < p.M) {
+                    float* dst = p.out + m * p.ld_out + col;
+                    float val = acc[mt][nt][r] + bv;
+                    if (p.accumulate) val += *dst;
+                    *dst = val;
+                    ssum[nt] += val;
+                    ssq[nt] += val * val;
+                }
             }
         }
     }
@@ -170,7 +186,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
             if (col < p.N) {
                 const float t = red[(which * 4 + 0) * BN + c] + red[(which * 4 + 1) * BN + c] +
                                 red[(which * 4 + 2) * BN + c] + red[(which * 4 + 3) * BN + c];
-                p.stats[((long long)blockIdx.x * 2 + which) * p.N + col] = t;
+                // the partials buffer has one row per 128 output rows: a 256-row tile fills the first of its two
+                // rows and zeroes the second
+                const long long prow = (long long)blockIdx.x * MT;
+                p.stats[(prow * 2 + which) * p.N + col] = t;
+                if (MT == 2 && (prow + 1) * 128 < p.M) p.stats[((prow + 1) * 2 + which) * p.N + col] = 0.f;
             }
         }
     }
@@ -332,8 +352,6 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     if (int e = check_tmap(map)) return e;
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
                 map.taps, map.ta, map.tb, map.tc, map.td, accumulate};
-    const long long tiles_m = cdiv(p.M, 128);
-    FGCN_REQUIRE(tiles_m < (1ll << 31), FGCN_E_BADARG, "rows_gemm: too many rows");
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;
@@ -345,14 +363,26 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
             nt = c;
         }
     }
-    const int bn = 32 * nt;
-    dim3 grid((unsigned)tiles_m, (unsigned)cdiv(N, bn));
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(rows_gemm_kernel<1>, grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(rows_gemm_kernel<2>, grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(rows_gemm_kernel<3>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(rows_gemm_kernel<4>, grid, dim3(256), 0, s, p); break;
+    // narrow outputs (<= 64 channels per tile) take two row tiles per wave so every A/B fragment feeds 2 MFMAs
+    const int tune_small = fgcn::tuning(0), tune_wide = fgcn::tuning(1);
+    const int mt = (nt <= 2 && tune_small != 0) ? 2 : 1;
+    const bool db = nt <= 2 ? tune_small == 2 : tune_wide == 1;
+    const long long tiles_m = cdiv(p.M, 128 * mt);
+    FGCN_REQUIRE(tiles_m < (1ll << 31), FGCN_E_BADARG, "rows_gemm: too many rows");
+    dim3 grid((unsigned)tiles_m, (unsigned)cdiv(N, 32 * nt));
+#define FGCN_LAUNCH(MT_, NT_, DB_) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_>), grid, dim3(256), 0, s, p)
+    if (mt == 2) {
+        if (nt == 1) { if (db) FGCN_LAUNCH(2, 1, true); else FGCN_LAUNCH(2, 1, false); }
+        else { if (db) FGCN_LAUNCH(2, 2, true); else FGCN_LAUNCH(2, 2, false); }
+    } else {
+        switch (nt) {
+            case 1: FGCN_LAUNCH(1, 1, false); break;
+            case 2: FGCN_LAUNCH(1, 2, false); break;
+            case 3: if (db) FGCN_LAUNCH(1, 3, true); else FGCN_LAUNCH(1, 3, false); break;
+            default: if (db) FGCN_LAUNCH(1, 4, true); else FGCN_LAUNCH(1, 4, false); break;
+        }
     }
+#undef FGCN_LAUNCH
     return launch_status("rows_gemm");
 }
 

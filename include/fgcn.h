@@ -38,6 +38,11 @@ const char* fgcn_last_error(void);
 /* 0 if the current HIP device is gfx950, FGCN_E_ARCH otherwise (message names the arch found). */
 int fgcn_check_device(void);
 
+/* Select a kernel variant (process-wide; for tuning tools and A/B tests — defaults are the measured-best ones).
+ * key 0: row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row,
+ *        double-buffered LDS.  key 1: wider N: 0 = two barriers per K chunk (default), 1 = double-buffered LDS. */
+int fgcn_set_tuning(int key, int value);
+
 /* Temporal index map shared by the row GEMMs: for output frame `to` and tap `j`
  *     num = to*ta + j*tb + tc ;  valid iff num >= 0, num % td == 0 and num/td < T_in ;  ti = num/td.
  * forward conv (kernel kt, stride s, pad p): ta=s tb=1 tc=-p td=1 ; its data gradient: ta=1 tb=-1 tc=p td=s. */

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmark at the headline model's shapes (B = 128 samples unless --b): times every libfgcn kernel
+family with HIP events on torch's current stream and prints ms, TFLOP/s (algorithmic) and GB/s (algorithmic).
+Used to A/B kernel variants (fgcn_set_tuning) in one process on one device.
+
+    python tools/kbench.py [--b 128] [--reps 10] [--only gemm,wgrad,spatial,joint,elem]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from fusion_gcn_amd import _lib, block, ops  # noqa: E402
+
+V = 25
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def report(name, ms, flops=0.0, byts=0.0):
+    print(f"{name:58s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TF/s  {byts / ms / 1e6:8.0f} GB/s", flush=True)
+
+
+def rnd(*shape):
+    return torch.randn(*shape, device=DEV)
+
+
+def bench_gemm(B, reps):
+    lib = _lib.load()
+    cases = [("tconv fwd", 300, 300, 64, 64, 9, 1), ("tconv fwd", 150, 150, 128, 128, 9, 1),
+             ("tconv fwd", 75, 75, 256, 256, 9, 1), ("tconv fwd s2", 300, 150, 128, 128, 9, 2),
+             ("emb 1x1", 300, 300, 64, 96, 1, 1), ("emb 1x1", 150, 150, 128, 192, 1, 1),
+             ("emb 1x1", 75, 75, 256, 384, 1, 1), ("dagg 1x1", 300, 300, 64, 192, 1, 1),
+             ("dagg 1x1", 75, 75, 256, 768, 1, 1), ("down 1x1", 300, 300, 64, 128, 1, 1)]
+    for k0, k1 in ((0, 0), (1, 0), (2, 1)):
+        lib.fgcn_set_tuning(0, k0)
+        lib.fgcn_set_tuning(1, k1)
+        print(f"-- rows_gemm, tuning small={k0} wide={k1}")
+        for name, tin, tout, K, N, kt, s in cases:
+            x, w, y = rnd(B, tin, V, K), rnd(kt, K, N) * (kt * K) ** -0.5, torch.empty(B, tout, V, N, device=DEV)
+            tm = ops.conv_tmap(kt, s)
+            ms = timeit(lambda: ops.rows_gemm(x, w, y, K=K, N=N, tmap=tm, stats=True), reps)
+            rows = B * tout * V
+            report(f"rows_gemm {name} T{tin}->{tout} K{kt}x{K} N{N}", ms, 2.0 * rows * kt * K * N,
+                   4.0 * (B * tin * V * K + rows * N))
+    lib.fgcn_set_tuning(0, 1)
+    lib.fgcn_set_tuning(1, 0)
+    # data gradient of the strided conv (half of the taps are empty for every output frame)
+    du, wt, dg = rnd(B, 150, V, 128), rnd(9, 128, 128) * 0.03, torch.empty(B, 300, V, 128, device=DEV)
+    ms = timeit(lambda: ops.rows_gemm(du, wt, dg, K=128, N=128, tmap=ops.conv_dgrad_tmap(9, 2)), reps)
+    report("rows_gemm tconv dgrad s2 T150->300 K9x128 N128", ms, 2.0 * B * 150 * V * 9 * 128 * 128, 4.0 * B * 450 * V * 128)
+
+
+def bench_wgrad(B, reps):
+    cases = [("tconv", 300, 300, 64, 64, 9, 1), ("tconv", 150, 150, 128, 128, 9, 1), ("tconv", 75, 75, 256, 256, 9, 1),
+             ("conv_d", 300, 300, 192, 64, 1, 1), ("conv_d", 75, 75, 768, 256, 1, 1), ("emb", 300, 300, 64, 96, 1, 1),
+             ("emb", 75, 75, 256, 384, 1, 1)]
+    for name, ta, tg, K, N, kt, s in cases:
+        a, g = rnd(B, ta, V, K), rnd(B, tg, V, N)
+        tm = ops.conv_tmap(kt, s)
+        ms = timeit(lambda: ops.rows_wgrad(a, g, K=K, N=N, tmap=tm), reps)
+        report(f"rows_wgrad {name} T{ta} K{kt}x{K} N{N}", ms, 2.0 * B * tg * V * kt * K * N, 4.0 * B * V * (ta * K + tg * N))
+
+
+def bench_spatial(B, reps):
+    for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
+        x, a = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2
+        wd, bias = rnd(3 * cin, cout) * (3 * cin) ** -0.5, rnd(cout)
+        ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
+        rows = B * T * V
+        report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
+
+
+def bench_joint(B, reps):
+    for T, c in ((300, 64), (150, 128), (75, 256)):
+        ic = c // 4
+        x, a = rnd(B, T, V, c), rnd(B, 3, V, V) * 0.2
+        agg, dx = torch.empty(B, T, V, 3 * c, device=DEV), torch.zeros(B, T, V, c, device=DEV)
+        rows = B * T * V
+        ms = timeit(lambda: block.mix_agg(x, agg, a, c), reps)
+        report(f"mix_agg T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+        ms = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=True), reps)
+        report(f"mix_dx  T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 5 * c)
+        emb, demb = rnd(B, T, V, 6 * ic), torch.empty(B, T, V, 6 * ic, device=DEV)
+        ms = timeit(lambda: ops.joint_mix(emb, demb, a, block.spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic), reps)
+        report(f"mix_demb T{T} ic{ic}", ms, 2.0 * rows * V * 6 * ic, 4.0 * rows * 12 * ic)
+        ms = timeit(lambda: ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(3)]), reps)
+        report(f"gram score T{T} ic{ic}", ms, 6.0 * rows * V * ic, 4.0 * rows * 6 * ic)
+        ms = timeit(lambda: ops.joint_gram(x, agg, [(0, k * c, c) for k in range(3)]), reps)
+        report(f"gram dA^ T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+
+
+def bench_elem(B, reps):
+    for T, c in ((300, 64), (75, 256)):
+        rows = B * T * V
+        a, b = rnd(B, T, V, c), rnd(B, T, V, c)
+        vec = torch.stack([torch.zeros(c), torch.ones(c), torch.ones(c), torch.zeros(c)]).to(DEV).contiguous()
+        out = torch.empty_like(a)
+        ms = timeit(lambda: ops.bn_act(a, vec, b, None, relu=True, out=out), reps)
+        report(f"bn_act identity T{T} C{c}", ms, 0, 4.0 * rows * 3 * c)
+        ms = timeit(lambda: ops.bn_act_bwd(a, out, b, vec, a, None, res_mode=1, db=torch.empty_like(a)), reps)
+        report(f"bn_act_bwd identity T{T} C{c} (reduce+apply)", ms, 0, 4.0 * rows * 8 * c)
+        ms = timeit(lambda: ops.col_sum(a, c), reps)
+        report(f"col_sum T{T} C{c}", ms, 0, 4.0 * rows * c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="gemm,wgrad,spatial,joint,elem")
+    args = ap.parse_args()
+    fns = dict(gemm=bench_gemm, wgrad=bench_wgrad, spatial=bench_spatial, joint=bench_joint, elem=bench_elem)
+    for k in args.only.split(","):
+        fns[k](args.b, args.reps)
+
+
+if __name__ == "__main__":
+    main()
