@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
                                                      float* out, long long n4, int C, int relu) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+        const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
         const f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(va + 3 * C + c);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                                                                int db_accumulate) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+        const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
         f32x4 dp = *reinterpret_cast<const f32x4*>(dout + i * 4);
         if (relu) {
             const f32x4 y = *reinterpret_cast<const f32x4*>(out + i * 4);
@@ -246,6 +246,7 @@ extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, c
     FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
                  "bn_act: 16-byte alignment");
     const long long n4 = rows * C / 4;
+    FGCN_REQUIRE(n4 < (1ll << 30), FGCN_E_BADARG, "elementwise kernel: tensor too large (>= 2^32 elements)");
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
     if (res_mode == 0) hipLaunchKernelGGL(bn_act_kernel<0>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
@@ -297,6 +298,7 @@ extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const 
     FGCN_REQUIRE(res_mode != 2 || !db || (vec_b && (!train || b)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: residual BatchNorm inputs missing");
     const long long n4 = rows * C / 4;
+    FGCN_REQUIRE(n4 < (1ll << 30), FGCN_E_BADARG, "elementwise kernel: tensor too large (>= 2^32 elements)");
     const float inv_m = 1.f / (float)rows;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);

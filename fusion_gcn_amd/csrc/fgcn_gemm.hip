@@ -51,9 +51,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
     for (int i = 0; i < AR; ++i) {
         const long long m = m0 + (tid >> 3) + 32 * i;
         if (m < p.M) {
-            const int n = (int)(m / TV);
-            const int rem = (int)(m - (long long)n * TV);
-            const int to = rem / p.V;
+            // 32-bit decode (host guarantees M < 2^31): a 64-bit division costs hundreds of instructions per row
+            const unsigned mu = (unsigned)m;
+            const int n = (int)(mu / (unsigned)TV);
+            const int rem = (int)(mu - (unsigned)n * (unsigned)TV);
+            const int to = (int)((unsigned)rem / (unsigned)p.V);
             const int v = rem - to * p.V;
             rbase[i] = ((long long)n * p.T_in * p.V + v) * p.ld_in;
             rto[i] = to;
@@ -201,6 +203,7 @@ struct WgradP {
     const float* g;
     float* partial;
     long long M, rows_per_split;
+    unsigned a_bytes, g_bytes;
     int T_a, T_g, V, K, N, ld_a, ld_g;
     int taps, ta, tb, tc, td;
     int tilesN;
@@ -223,47 +226,63 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
     const int c4 = (tid & 15) * 4;
     const int TVg = p.T_g * p.V;
 
+    // Row decode without divisions in the loop: each thread stages rows (tid >> 4) + 16*j of every 64-row stage;
+    // (n, tg, v) of those rows are decoded once (32-bit) and advanced by 64 rows per stage with carries.
+    // Loads are buffer loads: rows / channels that do not exist carry an out-of-range offset and read as zeros, so the
+    // eight loads of a stage issue back to back with no branches.
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const bool kcol_ok = k0 + c4 < p.K, ncol_ok = n0 + c4 < p.N;
+    const int dt = BR / p.V, dv = BR - dt * p.V;
+    unsigned rm[4];
+    int rn[4], rt[4], rv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rm[j] = (unsigned)mbeg + (tid >> 4) + 16 * j;
+        rn[j] = (int)(rm[j] / (unsigned)TVg);
+        const unsigned rem = rm[j] - (unsigned)rn[j] * (unsigned)TVg;
+        rt[j] = (int)(rem / (unsigned)p.V);
+        rv[j] = (int)rem - rt[j] * p.V;
+    }
+    const unsigned mend_u = (unsigned)mend;
+
     f32x4 areg[4], greg[4];
     f32x16 acc = zero16();
 
-    auto load_stage = [&](long long mb) {
+    auto load_stage = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long long m = mb + (tid >> 4) + 16 * j;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vg = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend) {
-                const int n = (int)(m / TVg);
-                const int rem = (int)(m - (long long)n * TVg);
-                const int tg = rem / p.V;
-                const int v = rem - tg * p.V;
-                const int ti = tmap_src(tg, tap, p.ta, p.tb, p.tc, p.td, p.T_a);
+            unsigned ao = OOB, go = OOB;
+            if (rm[j] < mend_u) {
+                const int ti = tmap_src(rt[j], tap, p.ta, p.tb, p.tc, p.td, p.T_a);
                 if (ti >= 0) {
-                    const int k = k0 + c4;
-                    const float* src = p.a + (((long long)n * p.T_a + ti) * p.V + v) * p.ld_a + k;
-                    if (k + 3 < p.K) {
-                        va = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (k + e < p.K) va[e] = src[e];
-                    }
-                    const int nn = n0 + c4;
-                    const float* gsrc = p.g + m * p.ld_g + nn;
-                    if (nn + 3 < p.N) {
-                        vg = *reinterpret_cast<const f32x4*>(gsrc);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nn + e < p.N) vg[e] = gsrc[e];
-                    }
+                    if (kcol_ok) ao = ((unsigned)((rn[j] * p.T_a + ti) * p.V + rv[j]) * (unsigned)p.ld_a + k0 + c4) * 4u;
+                    if (ncol_ok) go = (rm[j] * (unsigned)p.ld_g + n0 + c4) * 4u;
                 }
             }
-            areg[j] = va;
-            greg[j] = vg;
+            areg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ao, 0, 0));
+            greg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, go, 0, 0));
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rm[j] += BR;
+            rv[j] += dv;
+            rt[j] += dt;
+            if (rv[j] >= p.V) {
+                rv[j] -= p.V;
+                rt[j] += 1;
+            }
+            while (rt[j] >= p.T_g) {
+                rt[j] -= p.T_g;
+                rn[j] += 1;
+            }
         }
     };
 
-    if (mbeg < mend) load_stage(mbeg);
+    if (mbeg < mend) load_stage();
     for (long long mb = mbeg; mb < mend; mb += BR) {
         __syncthreads();
 #pragma unroll
@@ -273,7 +292,10 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
             *reinterpret_cast<f32x4*>(&Gs[row * TN + c4]) = greg[j];
         }
         __syncthreads();
-        if (mb + BR < mend) load_stage(mb + BR);
+        if (mb + BR < mend) {
+            advance();
+            load_stage();
+        }
         const float* ap = &As[(lane >> 5) * TK + wk * 32 + (lane & 31)];
         const float* gp = &Gs[(lane >> 5) * TN + wn * 32 + (lane & 31)];
 #pragma unroll 8
@@ -368,7 +390,7 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     const int mt = (nt <= 2 && tune_small != 0) ? 2 : 1;
     const bool db = nt <= 2 ? tune_small == 2 : tune_wide == 1;
     const long long tiles_m = cdiv(p.M, 128 * mt);
-    FGCN_REQUIRE(tiles_m < (1ll << 31), FGCN_E_BADARG, "rows_gemm: too many rows");
+    FGCN_REQUIRE(p.M < (1ll << 31) - 4096, FGCN_E_BADARG, "rows_gemm: too many rows (32-bit row indices)");
     dim3 grid((unsigned)tiles_m, (unsigned)cdiv(N, 32 * nt));
 #define FGCN_LAUNCH(MT_, NT_, DB_) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_>), grid, dim3(256), 0, s, p)
     if (mt == 2) {
@@ -401,6 +423,11 @@ extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
     WgradP p;
     p.a = a; p.g = g; p.partial = partial;
     p.M = (long long)B * T_g * V;
+    FGCN_REQUIRE(p.M < (1ll << 31) - 4096, FGCN_E_BADARG, "rows_wgrad: too many rows (32-bit row indices)");
+    const long long a_bytes = (long long)B * T_a * V * ld_a * 4, g_bytes = p.M * ld_g * 4;
+    FGCN_REQUIRE(a_bytes < 0x7FFF0000ll && g_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "rows_wgrad: operands must be smaller than 2 GiB (32-bit buffer offsets)");
+    p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes;
     p.rows_per_split = cdiv(cdiv(p.M, nsplit), 64) * 64;
     p.T_a = T_a; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
     p.taps = map.taps; p.ta = map.ta; p.tb = map.tb; p.tc = map.tc; p.td = map.td;

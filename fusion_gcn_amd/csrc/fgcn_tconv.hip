@@ -1,0 +1,286 @@
+// Temporal (kt x 1) convolution, forward and data gradient, as a halo-tile implicit GEMM (north-star kernel 2).
+//
+// rows_gemm (fgcn_gemm.hip) re-stages the row-shifted input tile and a weight tile for every tap, with two barriers
+// per 32-channel chunk.  Here the 128 output rows of a workgroup plus their temporal halo ((kt-1) frames =
+// (kt-1)*V rows) are staged ONCE per 32-channel chunk and all kt taps run from that LDS image: tap j of output row m
+// reads image row m + d_j*V (d_j = j*tb + tc).
+//   A operand : LDS halo image [row][32 + 4 pad] floats, one ds_read_b128 feeds 4 MFMA k-steps (k = 8q + 4h + e),
+//               read one (tap, q) step ahead of its MFMAs.
+//   B operand : weights streamed from L2 straight into registers with buffer_load_dwordx4 from a k-interleaved packing
+//               w4[tap][k/4][n][4] (lane = output channel -> 512 contiguous bytes per half-wave, 4 consecutive k per
+//               lane).  Buffer addressing = per-lane VGPR offset (fixed) + SGPR offset (per step): no per-step vector
+//               address arithmetic and no exec-masked branches, so hipcc keeps the next step's loads in flight behind a
+//               counted vmcnt instead of draining them (a plain guarded global_load made it emit vmcnt(0) before every
+//               MFMA group).  No weight staging: the only barriers are the pair around the halo fill.
+//   Halo fill : buffer loads again; rows outside the tensor / the frame view carry an out-of-range offset and the
+//               hardware returns zeros, so all fill loads issue back to back without branches.
+//   Frames outside [0, T) (and rows of a neighbouring sample that share the image) are masked to exact zeros per
+//   (row, tap) with a select on the A fragment.
+// Strided convolutions run as two stride-1 passes over the even / odd frames ("virtual frames" with a stride and
+// offset on the input or output side), so no tap is ever multiplied with a structurally-zero row.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct HaloP {
+    const float* in;
+    float* out;
+    const float* w4;
+    const float* bias;
+    float* stats;
+    long long Mv;                       // virtual rows = B * Tv * V
+    unsigned in_bytes, w_bytes;
+    int Tv, V, K, N, ld_in, ld_out;
+    int T_in_full, in_s, in_o, Th_in;   // input frame of virtual frame th: th*in_s + in_o (valid while th < Th_in)
+    int T_out_full, out_s, out_o, Th_out;  // output frame of virtual frame th: th*out_s + out_o (th < Th_out)
+    int taps, tb, tc;                   // d_j = j*tb + tc
+    int dmin, halo_rows;
+    int accumulate;
+};
+
+constexpr int HAS = 36;                 // LDS row stride of the halo image (32 channels + 4 pad: conflict-free b128)
+constexpr int HALO_MAX_STAGE = 13;      // ceil((128 + 8*32) / 32) + 1
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_halo_kernel(HaloP p) {
+    extern __shared__ __attribute__((aligned(16))) float Ah[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 32 * NT;
+    const int V = p.V, TvV = p.Tv * p.V;
+    const unsigned k4b = (tid & 7) * 16;            // byte offset of this thread's 4 channels inside a 32-chunk
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
+
+    // this lane's output row (for the per-tap frame mask)
+    const long long mrow = m0 + wave * 32 + l31;
+    const bool row_ok = mrow < p.Mv;
+    const int th_lane = row_ok ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;   // Mv < 2^31
+
+    // halo staging plan: image row r = (tid >> 3) + 32*i  <->  virtual row m0 + dmin*V + r.
+    // Rows that do not exist get an offset beyond the buffer: the load returns zeros.
+    unsigned src_off[HALO_MAX_STAGE];
+    const int nstage = (p.halo_rows + 31) >> 5;
+#pragma unroll
+    for (int i = 0; i < HALO_MAX_STAGE; ++i) {
+        src_off[i] = 0x80000000u;   // >= num_records: the hardware returns zeros
+        const int r = (tid >> 3) + 32 * i;
+        const long long hv = m0 + (long long)p.dmin * V + r;
+        if (i < nstage && hv >= 0 && hv < p.Mv) {
+            const unsigned hu = (unsigned)hv;                      // 32-bit decode: no 64-bit divisions
+            const int n = (int)(hu / (unsigned)TvV);
+            const int rem = (int)(hu - (unsigned)n * (unsigned)TvV);
+            const int th = (int)((unsigned)rem / (unsigned)V);
+            const int v = rem - th * V;
+            const int fr = th * p.in_s + p.in_o;
+            if (th < p.Th_in && fr < p.T_in_full)
+                src_off[i] = (unsigned)(((((long long)n * p.T_in_full + fr) * V + v) * p.ld_in) * 4) + k4b;
+        }
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = zero16();
+
+    const int IT = p.taps * 4;                      // (tap, q) steps per channel chunk, q = 8-channel group
+    const int K4 = p.K >> 2;
+    const int col = n0 + l31;                       // + nt*32
+    unsigned wvoff[NT];                             // per-lane byte offset into w4: ((h*N + col) * 4 floats)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wvoff[nt] = (unsigned)(((long long)h * p.N + col + nt * 32) * 16);
+    const float* arow = &Ah[(wave * 32 + l31) * HAS + 4 * h];
+
+    auto w_soff = [&](int it, int kc) -> unsigned {   // wave-uniform byte offset of step (tap j, group q)
+        const int j = it >> 2, q = it & 3;
+        return (unsigned)(((long long)(j * K4 + (kc >> 2) + 2 * q) * p.N) * 16);
+    };
+    auto a_read = [&](int it, bool& ok) -> f32x4 {
+        const int j = it >> 2, q = it & 3;
+        const int d = j * p.tb + p.tc;
+        const int ts = th_lane + d;
+        ok = row_ok && ts >= 0 && ts < p.Th_in;
+        return *reinterpret_cast<const f32x4*>(arow + (d - p.dmin) * V * HAS + 8 * q);
+    };
+
+    for (int kc = 0; kc < p.K; kc += 32) {
+        __syncthreads();                             // previous chunk's image reads are done
+        {
+            f32x4 stage[HALO_MAX_STAGE];
+#pragma unroll
+            for (int i = 0; i < HALO_MAX_STAGE; ++i)
+                if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+#pragma unroll
+            for (int i = 0; i < HALO_MAX_STAGE; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                if (i < nstage && r < p.halo_rows) *reinterpret_cast<f32x4*>(&Ah[r * HAS + (tid & 7) * 4]) = stage[i];
+            }
+        }
+        __syncthreads();
+
+        f32x4 b0[NT], b1[NT];
+        {
+            const unsigned so = w_soff(0, kc);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = buf_load4(rw, wvoff[nt], so);
+        }
+        bool ok0, ok1;
+        f32x4 a0 = a_read(0, ok0), a1;
+        for (int it = 0; it < IT; it += 2) {         // IT is even (4 steps per tap)
+            {
+                const unsigned so = w_soff(it + 1, kc);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b1[nt] = buf_load4(rw, wvoff[nt], so);
+            }
+            a1 = a_read(it + 1, ok1);
+            if (!ok0) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a0[e], b0[nt][e], acc[nt]);
+            if (it + 2 < IT) {
+                const unsigned so = w_soff(it + 2, kc);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b0[nt] = buf_load4(rw, wvoff[nt], so);
+                a0 = a_read(it + 2, ok0);
+            }
+            if (!ok1) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a1[e], b1[nt][e], acc[nt]);
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
+    float ssum[NT], ssq[NT], bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.f;
+        ssq[nt] = 0.f;
+        bv[nt] = (p.bias && col + nt * 32 < p.N) ? p.bias[col + nt * 32] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wave * 32 + acc_row(r, lane);
+        if (m < p.Mv) {
+            long long orow = m;
+            bool fok = true;
+            if (!plain_out) {
+                const unsigned mu = (unsigned)m;
+                const int n = (int)(mu / (unsigned)TvV);
+                const int rem = (int)(mu - (unsigned)n * (unsigned)TvV);
+                const int th = (int)((unsigned)rem / (unsigned)V);
+                const int v = rem - th * V;
+                fok = th < p.Th_out;
+                orow = ((long long)n * p.T_out_full + th * p.out_s + p.out_o) * V + v;
+            }
+            if (fok) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = col + nt * 32;
+                    if (c < p.N) {
+                        float* dst = p.out + orow * p.ld_out + c;
+                        float val = acc[nt][r] + bv[nt];
+                        if (p.accumulate) val += *dst;
+                        *dst = val;
+                        ssum[nt] += val;
+                        ssq[nt] += val * val;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        constexpr int BN = 32 * NT;
+        __syncthreads();
+        float* red = Ah;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float a = ssum[nt] + __shfl_xor(ssum[nt], 32);
+            const float b = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (lane < 32) {
+                red[(0 * 4 + wave) * BN + nt * 32 + lane] = a;
+                red[(1 * 4 + wave) * BN + nt * 32 + lane] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.N)
+                p.stats[((long long)blockIdx.x * 2 + which) * p.N + n0 + c] =
+                    red[(which * 4 + 0) * BN + c] + red[(which * 4 + 1) * BN + c] + red[(which * 4 + 2) * BN + c] +
+                    red[(which * 4 + 3) * BN + c];
+        }
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
+    const int Tv = Th_out > Th_in ? Th_out : Th_in;
+    return (int)cdiv((long long)B * Tv * V, 128);
+}
+
+extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
+                               int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                               int T_in_full, int in_s, int in_o, int Th_in,
+                               int T_out_full, int out_s, int out_o,
+                               int taps, int tb, int tc, int accumulate, void* stream) {
+    FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
+    FGCN_REQUIRE(B > 0 && Th > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0, FGCN_E_BADARG,
+                 "tconv_halo: bad sizes B=%d Th=%d V=%d K=%d N=%d", B, Th, V, K, N);
+    FGCN_REQUIRE(K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_in >= K && ld_out >= N, FGCN_E_ALIGN,
+                 "tconv_halo: K must be a multiple of 32, N and strides multiples of 4 (K=%d N=%d ld_in=%d ld_out=%d)", K,
+                 N, ld_in, ld_out);
+    FGCN_REQUIRE(aligned16(in) && aligned16(w4), FGCN_E_ALIGN, "tconv_halo: 16-byte alignment");
+    FGCN_REQUIRE(taps >= 1 && taps <= 16 && (tb == 1 || tb == -1), FGCN_E_BADARG, "tconv_halo: taps=%d tb=%d", taps, tb);
+    FGCN_REQUIRE(in_s >= 1 && out_s >= 1 && in_o >= 0 && out_o >= 0 && Th_in > 0, FGCN_E_BADARG,
+                 "tconv_halo: bad frame views");
+    FGCN_REQUIRE((long long)(Th_in - 1) * in_s + in_o < T_in_full && (long long)(Th - 1) * out_s + out_o < T_out_full,
+                 FGCN_E_BADARG, "tconv_halo: frame view exceeds the tensor (Th=%d Th_in=%d)", Th, Th_in);
+    const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4, w_bytes = (long long)taps * K * N * 4;
+    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    HaloP p;
+    p.in = in; p.out = out; p.w4 = w4; p.bias = bias; p.stats = stat_partials;
+    p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
+    p.Tv = Th > Th_in ? Th : Th_in;
+    p.Mv = (long long)B * p.Tv * V;
+    p.V = V; p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out;
+    p.T_in_full = T_in_full; p.in_s = in_s; p.in_o = in_o; p.Th_in = Th_in;
+    p.T_out_full = T_out_full; p.out_s = out_s; p.out_o = out_o; p.Th_out = Th;
+    p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
+    const int d0 = tc, d1 = (taps - 1) * tb + tc;
+    p.dmin = d0 < d1 ? d0 : d1;
+    const int dmax = d0 < d1 ? d1 : d0;
+    p.halo_rows = 128 + (dmax - p.dmin) * V;
+    FGCN_REQUIRE(p.halo_rows <= 32 * HALO_MAX_STAGE, FGCN_E_BADARG, "tconv_halo: halo of %d rows too large", p.halo_rows);
+    const size_t lds = (size_t)p.halo_rows * HAS * sizeof(float);
+    const long long tiles = cdiv(p.Mv, 128);
+    FGCN_REQUIRE(p.Mv < (1ll << 31) - 4096, FGCN_E_BADARG, "tconv_halo: too many rows (32-bit row indices)");
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 48 * 1024) {  // V > 25: opt in beyond the default dynamic-LDS limit (gfx950: 160 KiB per CU)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (N <= 64) {
+        dim3 grid((unsigned)tiles, (unsigned)cdiv(N, 64));
+        hipLaunchKernelGGL(conv_halo_kernel<2>, grid, dim3(256), lds, s, p);
+    } else {
+        dim3 grid((unsigned)tiles, (unsigned)cdiv(N, 128));
+        hipLaunchKernelGGL(conv_halo_kernel<4>, grid, dim3(256), lds, s, p);
+    }
+    return launch_status("tconv_halo");
+}

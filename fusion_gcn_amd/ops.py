@@ -79,6 +79,36 @@ def rows_gemm(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, K: int, 
     return part
 
 
+def pack_k4(w: torch.Tensor) -> torch.Tensor:
+    """(taps, K, N) packed weights -> k-interleaved (taps, K/4, N, 4) for tconv_halo (torch re-layout, tiny)."""
+    taps, K, N = w.shape
+    return w.view(taps, K // 4, 4, N).permute(0, 1, 3, 2).contiguous()
+
+
+def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
+               in_view=None, out_view=(1, 0), bias: Optional[torch.Tensor] = None, stats: bool = False,
+               accumulate: bool = False) -> Optional[torch.Tensor]:
+    """Halo-tile temporal conv over virtual frames [0, Th): input frame th*in_s + in_o (th < Th_in), output frame
+    th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked."""
+    ensure_device()
+    _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out"), _chk(w4, "tconv_halo.w4")
+    B, T_in, V, ld_in = inp.shape
+    Bo, T_out, Vo, ld_out = out.shape
+    K, N = w4.shape[1] * 4, w4.shape[2]
+    if (Bo, Vo) != (B, V) or w4.shape[0] != taps or w4.shape[3] != 4 or K > ld_in or N > ld_out:
+        raise _lib.FgcnError(f"tconv_halo: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} w4={tuple(w4.shape)}")
+    in_s, in_o, Th_in = in_view if in_view is not None else (1, 0, T_in)
+    out_s, out_o = out_view
+    lib = _lib.load()
+    part = None
+    if stats:
+        part = torch.empty((lib.fgcn_tconv_halo_tiles(B, Th, Th_in, V), 2, N), device=inp.device, dtype=torch.float32)
+    check(lib.fgcn_tconv_halo(_p(inp), _p(out), _p(w4), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
+                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), _stream()),
+          "fgcn_tconv_halo")
+    return part
+
+
 def _pick_nsplit(M: int, K: int, N: int, taps: int) -> int:
     tiles = ((K + 63) // 64) * ((N + 63) // 64) * taps
     want = max(1, 2048 // tiles)

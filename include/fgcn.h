@@ -62,6 +62,22 @@ int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bia
 /* number of row tiles = leading dimension of stat_partials for M = B*T_out*V rows */
 int fgcn_rows_gemm_tiles(long long M);
 
+/* Temporal (kt x 1) convolution / its data gradient as a halo-tile implicit GEMM (agcn.py:41-42 and its backward):
+ *   out[(n, fo(th), v), 0:N] (+)= bias + sum_j sum_k in[(n, fi(th + d_j), v), k] * W[j][k][n],   d_j = j*tb + tc,
+ * over "virtual" frames th in [0, Th): fi(t) = t*in_s + in_o (valid for t in [0, Th_in)), fo(t) = t*out_s + out_o.
+ * A stride-1 conv is one call with identity views; a stride-2 conv (or its data gradient) is two calls, one per frame
+ * parity of the strided side, so no tap meets a structurally empty row.  The input tile plus its temporal halo is
+ * staged in LDS once per 32 input channels and all taps run from it.
+ *   w4: k-interleaved packed weights float[taps][K/4][N][4]  (w4[j][k/4][n][k%4] = W[j][k][n]);  K % 32 == 0.
+ *   stat_partials: float[fgcn_tconv_halo_tiles(B, Th, Th_in, V)][2][N] or NULL (sums of the values written, after
+ *   accumulation).  Tensors must be smaller than 2 GiB (32-bit buffer offsets). */
+int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
+int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
+                    int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                    int T_in_full, int in_s, int in_o, int Th_in,
+                    int T_out_full, int out_s, int out_o,
+                    int taps, int tb, int tc, int accumulate, void* stream);
+
 /* partial[s][j][k][n] = sum over the s-th slice of rows m=(n,tg,v) of a[(n,ti(tg,j),v), k] * g[m, n]
  *   (weight gradient of the same convolutions; autograd backward of agcn.py:41-42,71-73,77).
  *   partial: float[nsplit][taps][K][N]; reduce with fgcn_reduce_sum.  nsplit >= 1. */

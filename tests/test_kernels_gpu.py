@@ -100,6 +100,42 @@ def test_rows_gemm_data_gradient_map(kt, s, T):
     assert rel_l2(dx.cpu().numpy(), dx_want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("B,T,V,C,O,s", [(3, 20, 25, 64, 64, 1), (2, 21, 25, 64, 128, 2), (2, 20, 27, 128, 128, 2),
+                                         (2, 13, 18, 128, 256, 1), (3, 7, 32, 32, 96, 1), (2, 1, 25, 64, 64, 2),
+                                         (1, 40, 25, 256, 256, 1), (2, 9, 20, 64, 64, 2)])
+def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
+    """The halo-tile kernel (input staged once per channel chunk, parity-split strides) vs the per-frame formula,
+    through the same helpers the block uses; tiles straddle sample boundaries (T*V is not a multiple of 128)."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.block import temporal_dgrad, temporal_fwd
+    kt = 9
+    Tp = (T - 1) // s + 1
+    wt = rnd(kt, C, O, seed=80, scale=(kt * C) ** -0.5)           # (kt, c, o)
+    bias = rnd(O, seed=81)
+    wg, wg_t = to_gpu(wt), to_gpu(wt.permute(0, 2, 1))
+    W = {"t": wg, "t_t": wg_t}
+    if s == 1:
+        W["t4"], W["t_t4"] = ops.pack_k4(wg), ops.pack_k4(wg_t)
+    else:
+        for par, tag in ((0, "e"), (1, "o")):
+            W[f"t4_{tag}"] = ops.pack_k4(wg[par::2].contiguous())
+            W[f"t_t4_{tag}"] = ops.pack_k4(wg_t[par::2].contiguous())
+    x = rnd(B, T, V, C, seed=82).requires_grad_(True)
+    want = ref_rows_conv(x, wt, ops.conv_tmap(kt, s), Tp, bias)
+    u = torch.full((B, Tp, V, O), 3.0, device=dev())
+    part = temporal_fwd(to_gpu(x.detach()), u, W, to_gpu(bias), kt, s, stats=True)
+    assert rel_l2(u.cpu().numpy(), want.detach().numpy()) < FWD_TOL
+    tot = part.double().sum(0).cpu()
+    flat = want.detach().reshape(-1, O)
+    assert rel_l2(tot[0].numpy(), flat.sum(0).numpy()) < RED_TOL
+    assert rel_l2(tot[1].numpy(), (flat ** 2).sum(0).numpy()) < RED_TOL
+    du = rnd(B, Tp, V, O, seed=83)
+    (dx_want,) = torch.autograd.grad((want * du).sum(), x)
+    dg = torch.full((B, T, V, C), 5.0, device=dev())
+    temporal_dgrad(to_gpu(du), dg, W, kt, s)
+    assert rel_l2(dg.cpu().numpy(), dx_want.numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("B,T,V,K,N,kt,s", [(2, 40, 25, 64, 64, 9, 1), (2, 41, 25, 64, 128, 9, 2),
                                             (4, 64, 25, 128, 96, 1, 1), (2, 30, 22, 4, 64, 1, 1),
                                             (1, 20, 18, 192, 64, 1, 1), (2, 33, 25, 64, 128, 1, 2)])

@@ -64,6 +64,27 @@ def bench_gemm(B, reps):
     report("rows_gemm tconv dgrad s2 T150->300 K9x128 N128", ms, 2.0 * B * 150 * V * 9 * 128 * 128, 4.0 * B * 450 * V * 128)
 
 
+def bench_tconv(B, reps):
+    """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2."""
+    for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
+        Tp = (T - 1) // s + 1
+        wt = rnd(9, c, c) * (9 * c) ** -0.5
+        W = {"t": wt, "t_t": wt.permute(0, 2, 1).contiguous()}
+        if s == 1:
+            W["t4"], W["t_t4"] = ops.pack_k4(wt), ops.pack_k4(wt.permute(0, 2, 1).contiguous())
+        else:
+            for par, tag in ((0, "e"), (1, "o")):
+                W[f"t4_{tag}"] = ops.pack_k4(wt[par::2].contiguous())
+                W[f"t_t4_{tag}"] = ops.pack_k4(wt.permute(0, 2, 1)[par::2].contiguous())
+        g, u, bias = rnd(B, T, V, c), torch.empty(B, Tp, V, c, device=DEV), rnd(c)
+        du, dg = rnd(B, Tp, V, c), torch.empty(B, T, V, c, device=DEV)
+        fl = 2.0 * B * Tp * V * 9 * c * c
+        ms = timeit(lambda: block.temporal_fwd(g, u, W, bias, 9, s, stats=True), reps)
+        report(f"tconv_halo fwd   T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
+        ms = timeit(lambda: block.temporal_dgrad(du, dg, W, 9, s), reps)
+        report(f"tconv_halo dgrad T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
+
+
 def bench_wgrad(B, reps):
     cases = [("tconv", 300, 300, 64, 64, 9, 1), ("tconv", 150, 150, 128, 128, 9, 1), ("tconv", 75, 75, 256, 256, 9, 1),
              ("conv_d", 300, 300, 192, 64, 1, 1), ("conv_d", 75, 75, 768, 256, 1, 1), ("emb", 300, 300, 64, 96, 1, 1),
@@ -121,9 +142,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,wgrad,spatial,joint,elem")
+    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,joint,elem")
     args = ap.parse_args()
-    fns = dict(gemm=bench_gemm, wgrad=bench_wgrad, spatial=bench_spatial, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
