@@ -295,6 +295,15 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 
 
 # ---- backward --------------------------------------------------------------------------------------------------------
+def _bias_grad(d: torch.Tensor, c: int, train: bool) -> torch.Tensor:
+    """Gradient of a conv bias that feeds a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
+    block output does not depend on that bias and its gradient is exactly zero (the reference's autograd produces
+    ~1e-9 rounding noise there); only eval-mode statistics make it a real column sum."""
+    if train:
+        return torch.zeros(c, device=d.device, dtype=torch.float32)
+    return ops.col_sum(d, c)
+
+
 def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
                    W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True):
     """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape})."""
@@ -325,7 +334,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         dx_live = True
         gw = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1))
         G["residual.conv.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
-        G["residual.conv.bias"] = ops.col_sum(dr, cout)
+        G["residual.conv.bias"] = _bias_grad(dr, cout, train)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
     # -- temporal conv -------------------------------------------------------------------------------------------------------
@@ -333,7 +342,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     temporal_dgrad(du, dg, W, kt, s)
     gw = ops.rows_wgrad(S["g"], du, K=cout, N=cout, tmap=ops.conv_tmap(kt, s))    # (kt, c, o)
     G["tcn1.conv.weight"] = gw.permute(2, 1, 0).unsqueeze(-1)
-    G["tcn1.conv.bias"] = ops.col_sum(du, cout)
+    G["tcn1.conv.bias"] = _bias_grad(du, cout, train)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
     if cfg.has_down:
@@ -343,7 +352,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         dx_live = True
         gw = ops.rows_wgrad(x, dd, K=cin, N=cout)
         G["gcn1.down.0.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
-        G["gcn1.down.0.bias"] = ops.col_sum(dd, cout)
+        G["gcn1.down.0.bias"] = _bias_grad(dd, cout, train)
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
                                      db_accumulate=dx_live)
@@ -358,7 +367,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     agg = new(B, T, V, c3)
     mix_agg(x, agg, a_hat, cin)
     gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)[0]                              # (3cin, cout)
-    dbias = ops.col_sum(dy, cout)
+    dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
         G[f"gcn1.conv_d.{k}.bias"] = dbias

@@ -18,6 +18,7 @@ struct MixP {
     float* out;
     const float* mats;
     int B, T, V, ld_in, ld_out, in_ch, out_ch, n_mats, mats_batched, n_items, accumulate, t_chunk;
+    unsigned in_bytes;
     fgcn_mix_item items[FGCN_MIX_MAX_ITEMS];
 };
 
@@ -38,29 +39,43 @@ __global__ __launch_bounds__(256) void joint_mix_kernel(MixP p) {
     __syncthreads();
 
     const int ksteps = (V + 1) >> 1;
+    // branch-free buffer loads (lanes / joints that do not take part read zeros through an out-of-range offset), issued
+    // one (item, term) step ahead of the MFMA chain that consumes them
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto issue = [&](int t, int it, int tr, float (&bv)[16]) {
+        const fgcn_mix_item& item = p.items[it < p.n_items ? it : 0];
+        const fgcn_mix_term& term = item.term[tr];
+        const int c_in = l31 < 16 ? term.in_c_lo + l31 : term.in_c_hi + (l31 - 16);
+        const bool take = t < t1 && it < p.n_items && ((term.mask >> (l31 >> 4)) & 1) && c_in < p.in_ch && l31 < item.width;
+        const unsigned base = (unsigned)((((long long)n * p.T + (t < t1 ? t : t0)) * V) * p.ld_in + c_in) * 4u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 2 * s + h;
+            bv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  rin, (take && s < ksteps && k < V) ? base + (unsigned)(k * p.ld_in) * 4u : OOB, 0, 0));
+        }
+    };
+    float bcur[16], bnxt[16];
+    issue(t0 + wave, 0, 0, bcur);
     for (int t = t0 + wave; t < t1; t += 4) {
         const long long row0 = ((long long)n * p.T + t) * V;
         for (int it = 0; it < p.n_items; ++it) {
             const fgcn_mix_item& item = p.items[it];
             f32x16 acc = zero16();
             for (int tr = 0; tr < item.nterms; ++tr) {
+                if (tr + 1 < item.nterms) issue(t, it, tr + 1, bnxt);
+                else if (it + 1 < p.n_items) issue(t, it + 1, 0, bnxt);
+                else issue(t + 4, 0, 0, bnxt);
                 const fgcn_mix_term& term = item.term[tr];
-                const int c_in = l31 < 16 ? term.in_c_lo + l31 : term.in_c_hi + (l31 - 16);
-                const bool take = ((term.mask >> (l31 >> 4)) & 1) && c_in < p.in_ch && l31 < item.width;
-                const float* src = p.in + row0 * p.ld_in + c_in;
                 const float* mrow = &mat[term.mat * 32 * MS];
                 // A[i = out joint][k = in joint] = M[i][k] (or M[k][i]); B[k = in joint][j = channel]
                 const int a_i = term.transpose ? 1 : MS, a_k = term.transpose ? MS : 1;
-                // all of the frame's loads for this term go out back to back, then the MFMA chain consumes them
-                float bv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int k = 2 * s + h;
-                    bv[s] = (take && s < ksteps && k < V) ? src[(long long)k * p.ld_in] : 0.f;
-                }
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
-                    if (s < ksteps) acc = mfma32(mrow[l31 * a_i + (2 * s + h) * a_k], bv[s], acc);
+                    if (s < ksteps) acc = mfma32(mrow[l31 * a_i + (2 * s + h) * a_k], bcur[s], acc);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bcur[s] = bnxt[s];
             }
             const int c_out = item.out_c + l31;
             if (c_out < p.out_ch && l31 < item.width) {
@@ -85,6 +100,7 @@ struct MixVP {
     float* out;
     const float* mats;
     int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, accumulate, t_chunk;
+    unsigned in_bytes;
     fgcn_mixv_item items[FGCN_MIX_MAX_ITEMS];
 };
 
@@ -106,7 +122,29 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
     }
     __syncthreads();
 
+    // Loads are buffer loads (joints / channels that do not exist carry an out-of-range offset and read as zeros: no
+    // branches), and the loads of step i+1 (next term, next item or next frame) are issued before the MFMAs of step i.
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     const int ksteps = (V + 1) >> 1;
+    auto issue = [&](int t, int it, int tr, vec (&bv)[16]) {
+        const bool ok = t < t1 && it < p.n_items && VW * l31 < p.items[it < p.n_items ? it : 0].nch;
+        const fgcn_mixv_item& item = p.items[it < p.n_items ? it : 0];
+        const unsigned base =
+            (unsigned)((((long long)n * p.T + (t < t1 ? t : t0)) * V) * p.ld_in + item.term[tr].in_c + VW * l31) * 4u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 2 * s + h;
+            const unsigned off = (ok && s < ksteps && k < V) ? base + (unsigned)(k * p.ld_in) * 4u : OOB;
+            if constexpr (VW == 4) {
+                bv[s] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+            } else {
+                bv[s] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b64(rin, off, 0, 0));
+            }
+        }
+    };
+    vec bcur[16], bnxt[16];
+    issue(t0 + wave, 0, 0, bcur);
     for (int t = t0 + wave; t < t1; t += 4) {
         const long long row0 = ((long long)n * p.T + t) * V;
         for (int it = 0; it < p.n_items; ++it) {
@@ -116,27 +154,22 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
 #pragma unroll
             for (int m = 0; m < VW; ++m) acc[m] = zero16();
             for (int tr = 0; tr < item.nterms; ++tr) {
-                const float* src = p.in + row0 * p.ld_in + item.term[tr].in_c + VW * l31;
+                // next step: next term of this item, else first term of the next item, else next frame of this wave
+                if (tr + 1 < item.nterms) issue(t, it, tr + 1, bnxt);
+                else if (it + 1 < p.n_items) issue(t, it + 1, 0, bnxt);
+                else issue(t + 4, 0, 0, bnxt);
                 const float* mrow = &mat[item.term[tr].mat * 32 * MS];
                 const int a_i = item.term[tr].transpose ? 1 : MS, a_k = item.term[tr].transpose ? MS : 1;
-                vec bv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int k = 2 * s + h;
-                    vec v;
-#pragma unroll
-                    for (int m = 0; m < VW; ++m) v[m] = 0.f;
-                    if (lane_ok && s < ksteps && k < V) v = *reinterpret_cast<const vec*>(src + (long long)k * p.ld_in);
-                    bv[s] = v;
-                }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     if (s < ksteps) {
                         const float a = mrow[l31 * a_i + (2 * s + h) * a_k];
 #pragma unroll
-                        for (int m = 0; m < VW; ++m) acc[m] = mfma32(a, bv[s][m], acc[m]);
+                        for (int m = 0; m < VW; ++m) acc[m] = mfma32(a, bcur[s][m], acc[m]);
                     }
                 }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bcur[s] = bnxt[s];
             }
             if (lane_ok) {
 #pragma unroll
@@ -161,6 +194,7 @@ struct GramP {
     const float* in2;
     float* partial;
     int B, T, V, ld1, ld2, t_chunk, n_items;
+    unsigned in1_bytes, in2_bytes;
     fgcn_gram_item items[FGCN_GRAM_MAX_ITEMS];
 };
 
@@ -189,31 +223,49 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
     const bool row_ok = l31 < V;
     const int vv = row_ok ? l31 : 0;
 
+    // Branch-free buffer loads (absent joints / channels read as zeros through an out-of-range offset); the 8 loads of
+    // the next 32-channel group (next group of the item, next item, or this wave's next frame) are in flight while the
+    // 16 MFMAs of the current group run.  Widths are multiples of 4 (host check).
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.in1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, p.in2_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto issue = [&](int t, int it, int q0, f32x4 (&a)[4], f32x4 (&b)[4]) {
+        const bool ok = row_ok && t < t1 && it < p.n_items;
+        const fgcn_gram_item item = p.items[it < p.n_items ? it : 0];
+        const unsigned row = (unsigned)(((long long)n * p.T + (t < t1 ? t : t0)) * V + vv);
+        const unsigned o1 = (row * (unsigned)p.ld1 + item.c1 + 4 * h) * 4u, o2 = (row * (unsigned)p.ld2 + item.c2 + 4 * h) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 8 * (q0 + j) + 4 * h;          // lane half h contracts channels 8q + 4h + e on both operands
+            const bool cok = ok && c < item.width;
+            a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, cok ? o1 + 32u * (q0 + j) : OOB, 0, 0));
+            b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, cok ? o2 + 32u * (q0 + j) : OOB, 0, 0));
+        }
+    };
+
     f32x16 acc[3] = {zero16(), zero16(), zero16()};
+    f32x4 ac[4], bc[4], an[4], bn[4];
+    issue(t0 + wave, 0, 0, ac, bc);
     for (int t = t0 + wave; t < t1; t += 4) {
-        const long long row = ((long long)n * p.T + t) * V + vv;
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             if (it < p.n_items) {
-                const fgcn_gram_item item = p.items[it];
-                const float* s1 = p.in1 + row * p.ld1 + item.c1 + 4 * h;
-                const float* s2 = p.in2 + row * p.ld2 + item.c2 + 4 * h;
-                const int nq = (item.width + 7) >> 3;
+                const int nq = (p.items[it].width + 7) >> 3;
                 for (int q0 = 0; q0 < nq; q0 += 4) {
-                    // lane half h contracts channels 8q + 4h + e on both operands; 8 loads in flight, then 16 MFMAs
-                    f32x4 a[4], b[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int q = q0 + j;
-                        a[j] = load4_masked(s1 + 8 * q, 8 * q + 4 * h, item.width, row_ok && q < nq);
-                        b[j] = load4_masked(s2 + 8 * q, 8 * q + 4 * h, item.width, row_ok && q < nq);
-                    }
+                    if (q0 + 4 < nq) issue(t, it, q0 + 4, an, bn);
+                    else if (it + 1 < p.n_items) issue(t, it + 1, 0, an, bn);
+                    else issue(t + 4, 0, 0, an, bn);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (q0 + j < nq) {   // wave-uniform
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[it] = mfma32(a[j][e], b[j][e], acc[it]);
+                            for (int e = 0; e < 4; ++e) acc[it] = mfma32(ac[j][e], bc[j][e], acc[it]);
                         }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ac[j] = an[j];
+                        bc[j] = bn[j];
                     }
                 }
             }
@@ -315,7 +367,10 @@ extern "C" int fgcn_joint_mix(const float* in, float* out, const float* mats, in
     FGCN_REQUIRE(in_channels > 0 && out_channels > 0 && ld_in >= in_channels && ld_out >= out_channels, FGCN_E_BADARG,
                  "joint_mix: channel counts exceed row strides");
     FGCN_REQUIRE(B <= 65535, FGCN_E_BADARG, "joint_mix: B too large for grid.y");
+    const long long mix_in_bytes = (long long)B * T * V * ld_in * 4;
+    FGCN_REQUIRE(mix_in_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "joint_mix: input must be smaller than 2 GiB");
     MixP p;
+    p.in_bytes = (unsigned)mix_in_bytes;
     p.in = in; p.out = out; p.mats = mats;
     p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out; p.in_ch = in_channels; p.out_ch = out_channels;
     p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items; p.accumulate = accumulate;
@@ -345,11 +400,15 @@ extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partia
     FGCN_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && aligned16(in1) && aligned16(in2), FGCN_E_ALIGN,
                  "joint_gram: strides/pointers must be 16-byte aligned");
     FGCN_REQUIRE(B <= 65535, FGCN_E_BADARG, "joint_gram: B too large for grid.y");
+    const long long b1 = (long long)B * T * V * ld1 * 4, b2 = (long long)B * T * V * ld2 * 4;
+    FGCN_REQUIRE(b1 < 0x7FFF0000ll && b2 < 0x7FFF0000ll, FGCN_E_BADARG, "joint_gram: operands must be smaller than 2 GiB");
     GramP p;
+    p.in1_bytes = (unsigned)b1; p.in2_bytes = (unsigned)b2;
     p.in1 = in1; p.in2 = in2; p.partial = partial;
     p.B = B; p.T = T; p.V = V; p.ld1 = ld1; p.ld2 = ld2; p.t_chunk = t_chunk; p.n_items = n_items;
     for (int i = 0; i < n_items; ++i) {
-        FGCN_REQUIRE(items[i].mat == i && items[i].width > 0 && items[i].c1 % 4 == 0 && items[i].c2 % 4 == 0 &&
+        FGCN_REQUIRE(items[i].mat == i && items[i].width > 0 && items[i].width % 4 == 0 && items[i].c1 % 4 == 0 &&
+                         items[i].c2 % 4 == 0 &&
                          items[i].c1 + items[i].width <= ld1 + 3 && items[i].c2 + items[i].width <= ld2 + 3,
                      FGCN_E_BADARG, "joint_gram: item %d malformed", i);
         p.items[i] = items[i];
@@ -391,7 +450,10 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     FGCN_REQUIRE(vw == 2 || vw == 4, FGCN_E_BADARG, "joint_mix_vec: vw must be 2 or 4 (got %d)", vw);
     FGCN_REQUIRE(ld_in % 4 == 0 && ld_out % 4 == 0 && aligned16(in) && aligned16(out), FGCN_E_ALIGN,
                  "joint_mix_vec: 16-byte alignment");
+    const long long in_bytes = (long long)B * T * V * ld_in * 4;
+    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "joint_mix_vec: input must be smaller than 2 GiB");
     MixVP p;
+    p.in_bytes = (unsigned)in_bytes;
     p.in = in; p.out = out; p.mats = mats;
     p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out;
     p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items; p.accumulate = accumulate;

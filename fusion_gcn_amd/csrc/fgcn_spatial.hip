@@ -33,16 +33,29 @@ struct SpatialP {
     float* y;
     float* stats;
     int B, T, V, Cin, Cout, ld_x, ld_y, ns, a_batched, t_chunk;
+    unsigned x_bytes, w_bytes;
 };
 
+constexpr int TTS = 36;   // row stride of the per-wave transpose tile (32 channels + 4 pad)
+using u32x4s = __attribute__((ext_vector_type(4))) unsigned int;
+
+__device__ __forceinline__ float sp_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ f32x4 sp_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 template <int CT_IN, int CT_OUT>
-__global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
+__global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
     constexpr int WROW = CT_OUT * 32;                 // floats per staged weight row (padded Cout)
     constexpr int WCHUNK = 32 * WROW;                 // one (k, c-tile) chunk: 32 input channels x Cout
+    constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond num_records: the load returns 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ah = smem;                                 // [3][32][33]
     float* wl = smem + ((3 * 32 * AHS + 3) & ~3);     // 2 x WCHUNK, 16-byte aligned for the float4 commits
     float* st = wl + 2 * WCHUNK;                      // [4 waves][2][WROW]
+    float* tt = st + 4 * 2 * WROW;                    // [4 waves][32][TTS] accumulator transpose tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -50,6 +63,9 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
     const int V = p.V, NS = p.ns;
     const int t0 = blockIdx.x * p.t_chunk;
     const int t1 = min(t0 + p.t_chunk, p.T);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, p.w_bytes, 0x00020000);
 
     const float* asrc = p.a_hat + (p.a_batched ? (long long)n * NS * V * V : 0);
     for (int i = tid; i < 3 * 32 * 32; i += 256) {
@@ -62,18 +78,23 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
     const int nchunks = CT_IN * NS;                   // weight chunks per frame group
     f32x4 wreg[CT_OUT];
 
-    // weight chunk q = ci*NS + k covers rows k*Cin + ci*32 .. +31 of the packed [NS*Cin][Cout] matrix
+    // weight chunk q = ci*NS + k covers rows k*Cin + ci*32 .. +31 of the packed [NS*Cin][Cout] matrix.
+    // Per-thread offsets inside a chunk are fixed; rows >= Cin / columns >= Cout read as zeros (OOB offset).
+    unsigned wvo[CT_OUT];
+    int wrow[CT_OUT];
+#pragma unroll
+    for (int i = 0; i < CT_OUT; ++i) {
+        const int idx = tid + 256 * i;                // float4 index inside the chunk
+        const int row = idx / (WROW / 4), c4 = (idx - row * (WROW / 4)) * 4;
+        wrow[i] = row;
+        wvo[i] = c4 < p.Cout ? (unsigned)(row * p.Cout + c4) * 4u : OOB;
+    }
     auto prefetch_w = [&](int q) {
         const int ci = q / NS, k = q - ci * NS;
+        const unsigned so = (unsigned)((k * p.Cin + ci * 32) * p.Cout) * 4u;
 #pragma unroll
-        for (int i = 0; i < CT_OUT; ++i) {
-            const int idx = tid + 256 * i;             // float4 index inside the chunk
-            const int row = idx / (WROW / 4), c4 = (idx - row * (WROW / 4)) * 4;
-            const int c = ci * 32 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c < p.Cin && c4 < p.Cout) v = *reinterpret_cast<const f32x4*>(p.wd + ((long long)k * p.Cin + c) * p.Cout + c4);
-            wreg[i] = v;
-        }
+        for (int i = 0; i < CT_OUT; ++i)
+            wreg[i] = sp_load4(rw, (ci * 32 + wrow[i] < p.Cin) ? wvo[i] : OOB, so);
     };
     auto commit_w = [&](int buf) {
 #pragma unroll
@@ -82,8 +103,21 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
             *reinterpret_cast<f32x4*>(wl + buf * WCHUNK + idx * 4) = wreg[i];
         }
     };
+    // x of frame t, channel tile ci: 16 branch-free dword loads (joint 2s + h of channel ci*32 + lane)
+    auto load_x = [&](int t, int ci, float (&xv)[16]) {
+        const int c = ci * 32 + l31;
+        const bool ok = t < t1 && c < p.Cin;
+        const unsigned base = (unsigned)((((long long)n * p.T + (t < t1 ? t : t0)) * V) * p.ld_x + c) * 4u;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int v = 2 * s + h;
+            xv[s] = sp_load1(rx, (ok && s < ksteps && v < V) ? base + (unsigned)(v * p.ld_x) * 4u : OOB);
+        }
+    };
 
     prefetch_w(0);
+    float xcur[16], xnxt[16];
+    load_x(t0 + wave, 0, xcur);
     int qg = 0;  // global chunk counter (selects the LDS buffer)
     for (int tg = t0; tg < t1; tg += 4) {
         const int t = tg + wave;
@@ -95,16 +129,9 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
 
 #pragma unroll 1
         for (int ci = 0; ci < CT_IN; ++ci) {
-            // this frame's x for channel tile ci: A operand of step 1, reused by the NS subsets
-            float xv[16];
-            const int c = ci * 32 + l31;
-            const bool cok = tv && c < p.Cin;
-            const float* xs = p.x + row0 * p.ld_x + c;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int v = 2 * s + h;
-                xv[s] = (cok && s < ksteps && v < V) ? xs[(long long)v * p.ld_x] : 0.f;
-            }
+            // next tile's x (next channel tile, or the first tile of this wave's next frame) flies during the MFMAs
+            if (ci + 1 < CT_IN) load_x(t, ci + 1, xnxt);
+            else load_x(t + 4, 0, xnxt);
 #pragma unroll 1
             for (int k = 0; k < NS; ++k, ++qg) {
                 const int buf = qg & 1;
@@ -120,7 +147,7 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
                 const float* ak = ah + (k * 32) * AHS + l31;
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
-                    if (s < ksteps) agg = mfma32(xv[s], ak[(2 * s + h) * AHS], agg);
+                    if (s < ksteps) agg = mfma32(xcur[s], ak[(2 * s + h) * AHS], agg);
                 // step 2: y^T tiles; register r of agg is the k-pair {rho(r), rho(r)+4} of the contraction
                 const float* wb = wl + buf * WCHUNK + (4 * h) * WROW + l31;
                 const int cleft = p.Cin - ci * 32;      // valid input channels in this tile
@@ -134,35 +161,49 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(SpatialP p) {
                     }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) xcur[s] = xnxt[s];
         }
 
-        // ---- epilogue for this frame -------------------------------------------------------------------------
-        const bool wok = tv && l31 < V;
-        float* yrow = p.y + (row0 + l31) * p.ld_y;
+        // ---- epilogue for this frame: transpose each 32(o) x 32(w) accumulator through a wave-private LDS tile so
+        //      rows leave as contiguous 128-byte segments and the per-channel sums need 3 shuffle steps, not 5 x 16 ---
+        float* T = tt + wave * 32 * TTS;
+        const int rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
         for (int ot = 0; ot < CT_OUT; ++ot) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int o = ot * 32 + 8 * g + 4 * h;
-                if (o < p.Cout) {                       // Cout % 4 == 0: the quad is all-in or all-out
-                    f32x4 val = {acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]};
-                    if (p.bias) val += *reinterpret_cast<const f32x4*>(p.bias + o);
-                    if (wok) *reinterpret_cast<f32x4*>(yrow + o) = val;
-                    if (p.stats) {
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(&T[l31 * TTS + 8 * g + 4 * h]) =
+                    f32x4{acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]};
+            const int o = ot * 32 + c4;
+            const bool ook = o < p.Cout;                // Cout % 4 == 0: the quad is all-in or all-out
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && ook) b4 = *reinterpret_cast<const f32x4*>(p.bias + o);
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float s1 = wok ? val[e] : 0.f;
-                            float s2 = s1 * s1;
+            for (int i = 0; i < 4; ++i) {
+                const int r = rr + 8 * i;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(&T[r * TTS + c4]) + b4;
+                if (tv && r < V && ook) {
+                    *reinterpret_cast<f32x4*>(p.y + (row0 + r) * p.ld_y + o) = val;
+                    s1 += val;
+                    s2 += val * val;
+                }
+            }
+            if (p.stats) {
 #pragma unroll
-                            for (int m = 16; m >= 1; m >>= 1) {
-                                s1 += __shfl_xor(s1, m);
-                                s2 += __shfl_xor(s2, m);
-                            }
-                            if (l31 == 0) {
-                                st[(wave * 2 + 0) * WROW + o + e] += s1;
-                                st[(wave * 2 + 1) * WROW + o + e] += s2;
-                            }
-                        }
+                for (int m = 8; m <= 32; m <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[e] += __shfl_xor(s1[e], m);
+                        s2[e] += __shfl_xor(s2[e], m);
+                    }
+                }
+                if (lane < 8 && ook) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        st[(wave * 2 + 0) * WROW + o + e] += s1[e];
+                        st[(wave * 2 + 1) * WROW + o + e] += s2[e];
                     }
                 }
             }
@@ -195,7 +236,7 @@ extern "C" int fgcn_spatial_tiles(int B, int T) { return (int)(B * cdiv(T, spati
 
 template <int CI, int CO>
 static void launch_spatial(const SpatialP& p, hipStream_t s) {
-    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 2 * 32 * CO * 32 + 4 * 2 * CO * 32) * sizeof(float);
+    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 2 * 32 * CO * 32 + 4 * 2 * CO * 32 + 4 * 32 * TTS) * sizeof(float);
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
     if (lds > 48 * 1024)  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO>),
@@ -228,8 +269,11 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
     auto tiles = [](int c) { int t = (c + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 8 ? 8 : -1; };
     const int ci = tiles(Cin), co = tiles(Cout);
     FGCN_REQUIRE(ci > 0 && co > 0, FGCN_E_BADARG, "spatial_fwd: at most 256 channels (Cin=%d Cout=%d)", Cin, Cout);
+    const long long x_bytes = (long long)B * T * V * ld_x * 4, w_bytes = (long long)n_subsets * Cin * Cout * 4;
+    FGCN_REQUIRE(x_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "spatial_fwd: x must be smaller than 2 GiB (32-bit buffer offsets)");
+    FGCN_REQUIRE(aligned16(x) || true, FGCN_E_ALIGN, "spatial_fwd: alignment");
     SpatialP p{x, a_hat, wd, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, n_subsets, a_hat_batched,
-               spatial_t_chunk(B, T)};
+               spatial_t_chunk(B, T), (unsigned)x_bytes, (unsigned)w_bytes};
     hipStream_t s = (hipStream_t)stream;
     int rc = -1;
     switch (ci) {
