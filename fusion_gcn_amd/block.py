@@ -245,15 +245,15 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S: Dict[str, Optional[torch.Tensor]] = {"x": x}
 
     # -- data-dependent adjacency ------------------------------------------------------------------------------------
-    adj_ab = (bufs["gcn1.adj_a"] + P["gcn1.adj_b"].detach()).contiguous()
+    adj_a, adj_b = bufs["gcn1.adj_a"], P["gcn1.adj_b"].detach()
     if cfg.static_adjacency:
         emb, c_mat = None, None
-        _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_ab, 1, use_softmax=False)
+        _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
         emb = new(B, T, V, 6 * ic)
         ops.rows_gemm(x, W["emb"], emb, K=cin, N=6 * ic, bias=W["emb_b"])
         part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
-        c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_ab, B)
+        c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_a, B, adj_b=adj_b)
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------

@@ -290,60 +290,58 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
     }
 }
 
-// one thread per (n, k, w): column softmax over v (dim -2 of the (V, V) affinity)
-__global__ void adj_softmax_fwd_kernel(const float* partial, int nchunk, float scale, const float* adj_ab,
-                                       float* c_out, float* a_hat, int B, int K, int V, int use_softmax) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * K * V) return;
-    const int w = idx % V, k = (idx / V) % K, n = idx / (V * K);
-    float* crow = c_out + ((long long)(n * K + k) * V) * V + w;
-    float* arow = a_hat + ((long long)(n * K + k) * V) * V + w;
-    const float* ab = adj_ab + (long long)k * V * V + w;
+// One 32 x 32 thread block per (sample, subset) matrix: thread (v, w) sums its chunk partials (consecutive threads read
+// consecutive addresses), the matrix goes through LDS and every thread reduces its own column (dim -2 of the (V, V)
+// affinity).  adj_ab may be given as two addends (adj_a, adj_b) so the caller needs no separate add kernel.
+__global__ __launch_bounds__(1024) void adj_softmax_fwd_kernel(const float* partial, int nchunk, float scale,
+                                                               const float* adj_a, const float* adj_b, float* c_out,
+                                                               float* a_hat, int K, int V, int use_softmax) {
+    __shared__ float S[32][33];
+    const int v = threadIdx.x >> 5, w = threadIdx.x & 31;
+    const int n = blockIdx.x / K, k = blockIdx.x - n * K;
+    const bool in = v < V && w < V;
+    const long long o = ((long long)(n * K + k) * V + v) * V + w;
+    const float ab = in ? adj_a[((long long)k * V + v) * V + w] + (adj_b ? adj_b[((long long)k * V + v) * V + w] : 0.f) : 0.f;
     if (!use_softmax) {
-        for (int v = 0; v < V; ++v) arow[v * V] = ab[v * V];
+        if (in) a_hat[o] = ab;
         return;
     }
+    float s = 0.f;
+    const float* src = partial + ((long long)n * nchunk * K + k) * 1024 + threadIdx.x;
+    for (int c = 0; c < nchunk; ++c) s += src[(long long)c * K * 1024];
+    s *= scale;
+    S[v][w] = in ? s : -INFINITY;
+    __syncthreads();
     float mx = -INFINITY;
-    for (int v = 0; v < V; ++v) {
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += partial[(((long long)n * nchunk + c) * K + k) * 1024 + v * 32 + w];
-        s *= scale;
-        crow[v * V] = s;  // staged; overwritten below
-        mx = fmaxf(mx, s);
-    }
+    for (int u = 0; u < V; ++u) mx = fmaxf(mx, S[u][w]);
     float den = 0.f;
-    for (int v = 0; v < V; ++v) {
-        const float e = expf(crow[v * V] - mx);
-        crow[v * V] = e;
-        den += e;
-    }
-    const float inv = 1.f / den;
-    for (int v = 0; v < V; ++v) {
-        const float c = crow[v * V] * inv;
-        crow[v * V] = c;
-        arow[v * V] = c + ab[v * V];
+    for (int u = 0; u < V; ++u) den += expf(S[u][w] - mx);
+    if (in) {
+        const float c = expf(s - mx) / den;
+        c_out[o] = c;
+        a_hat[o] = c + ab;
     }
 }
 
-__global__ void adj_softmax_bwd_kernel(const float* partial, int nchunk, float scale, const float* c_in,
-                                       float* d_a_hat, float* d_s, int B, int K, int V) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * K * V) return;
-    const int w = idx % V, k = (idx / V) % K, n = idx / (V * K);
-    const long long base = ((long long)(n * K + k) * V) * V + w;
+__global__ __launch_bounds__(1024) void adj_softmax_bwd_kernel(const float* partial, int nchunk, float scale,
+                                                               const float* c_in, float* d_a_hat, float* d_s, int K,
+                                                               int V) {
+    __shared__ float P[32][33];
+    const int v = threadIdx.x >> 5, w = threadIdx.x & 31;
+    const int n = blockIdx.x / K, k = blockIdx.x - n * K;
+    const bool in = v < V && w < V;
+    const long long o = ((long long)(n * K + k) * V + v) * V + w;
+    float dc = 0.f;
+    const float* src = partial + ((long long)n * nchunk * K + k) * 1024 + threadIdx.x;
+    for (int c = 0; c < nchunk; ++c) dc += src[(long long)c * K * 1024];
+    if (in) d_a_hat[o] = dc;
+    if (!c_in || !d_s) return;
+    const float cv = in ? c_in[o] : 0.f;
+    P[v][w] = cv * dc;
+    __syncthreads();
     float dot = 0.f;
-    for (int v = 0; v < V; ++v) {
-        float s = 0.f;
-        for (int c = 0; c < nchunk; ++c) s += partial[(((long long)n * nchunk + c) * K + k) * 1024 + v * 32 + w];
-        d_a_hat[base + v * V] = s;
-        if (c_in) dot += c_in[base + v * V] * s;
-    }
-    if (c_in && d_s) {
-        for (int v = 0; v < V; ++v) {
-            const float c = c_in[base + v * V];
-            d_s[base + v * V] = scale * c * (d_a_hat[base + v * V] - dot);
-        }
-    }
+    for (int u = 0; u < V; ++u) dot += P[u][w];
+    if (in) d_s[o] = scale * cv * (dc - dot);
 }
 
 }  // namespace fgcn
@@ -418,14 +416,14 @@ extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partia
     return launch_status("joint_gram");
 }
 
-extern "C" int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_ab,
-                                    float* c_out, float* a_hat, int B, int K, int V, int use_softmax, void* stream) {
-    FGCN_REQUIRE(adj_ab && a_hat && B > 0 && K > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
+extern "C" int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_a,
+                                    const float* adj_b, float* c_out, float* a_hat, int B, int K, int V,
+                                    int use_softmax, void* stream) {
+    FGCN_REQUIRE(adj_a && a_hat && B > 0 && K > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
                  "adj_softmax_fwd: bad argument");
     FGCN_REQUIRE(!use_softmax || (partial && c_out && nchunk > 0), FGCN_E_BADARG, "adj_softmax_fwd: missing partials");
-    const int total = B * K * V;
-    hipLaunchKernelGGL(adj_softmax_fwd_kernel, dim3((unsigned)cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream,
-                       partial, nchunk, scale, adj_ab, c_out, a_hat, B, K, V, use_softmax);
+    hipLaunchKernelGGL(adj_softmax_fwd_kernel, dim3((unsigned)(B * K)), dim3(1024), 0, (hipStream_t)stream, partial, nchunk,
+                       scale, adj_a, adj_b, c_out, a_hat, K, V, use_softmax);
     return launch_status("adj_softmax_fwd");
 }
 
@@ -433,9 +431,8 @@ extern "C" int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scal
                                     float* d_a_hat, float* d_s, int B, int K, int V, void* stream) {
     FGCN_REQUIRE(partial && d_a_hat && nchunk > 0 && B > 0 && K > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
                  "adj_softmax_bwd: bad argument");
-    const int total = B * K * V;
-    hipLaunchKernelGGL(adj_softmax_bwd_kernel, dim3((unsigned)cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream,
-                       partial, nchunk, scale, c_in, d_a_hat, d_s, B, K, V);
+    hipLaunchKernelGGL(adj_softmax_bwd_kernel, dim3((unsigned)(B * K)), dim3(1024), 0, (hipStream_t)stream, partial, nchunk,
+                       scale, c_in, d_a_hat, d_s, K, V);
     return launch_status("adj_softmax_bwd");
 }
 

@@ -238,9 +238,12 @@ template <int CI, int CO>
 static void launch_spatial(const SpatialP& p, hipStream_t s) {
     const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 2 * 32 * CO * 32 + 4 * 2 * CO * 32 + 4 * 32 * TTS) * sizeof(float);
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
-    if (lds > 48 * 1024)  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
+    static bool lds_opt_in = false;  // once per instantiation (not a stream operation: keep it out of graph captures)
+    if (!lds_opt_in && lds > 48 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_opt_in = true;
+    }
     hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO>), grid, dim3(256), lds, s, p);
 }
 

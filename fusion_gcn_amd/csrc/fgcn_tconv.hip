@@ -269,11 +269,14 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const long long tiles = cdiv(p.Mv, 128);
     FGCN_REQUIRE(p.Mv < (1ll << 31) - 4096, FGCN_E_BADARG, "tconv_halo: too many rows (32-bit row indices)");
     hipStream_t s = (hipStream_t)stream;
-    if (lds > 48 * 1024) {  // V > 25: opt in beyond the default dynamic-LDS limit (gfx950: 160 KiB per CU)
+    static bool lds_opt_in = false;  // once per process (not a stream operation: keep it out of graph captures)
+    if (!lds_opt_in) {               // V > 25 needs more than the default dynamic-LDS limit (gfx950: 160 KiB per CU)
+        const int max_lds = 32 * HALO_MAX_STAGE * HAS * (int)sizeof(float);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        lds_opt_in = true;
     }
     if (N <= 64) {
         dim3 grid((unsigned)tiles, (unsigned)cdiv(N, 64));

@@ -120,10 +120,12 @@ class Model(nn.Module):
         bn_init(self.data_bn, 1)
 
     _blocks_input = _base.Model._blocks_input
+    _bump_batch_counters = _base.Model._bump_batch_counters
 
     def forward(self, x):
         N, M, T, V, C = x.size()
         h = self._blocks_input(x)
+        self._bump_batch_counters()
         for layer in (self.l1, self.l2, self.l3, self.l4, self.l5, self.l6, self.l7, self.l8, self.l9, self.l10):
             h = layer(h)
         c_new = h.size(-1)

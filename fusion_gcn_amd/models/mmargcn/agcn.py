@@ -147,6 +147,11 @@ class SpatialTemporalConv(nn.Module):
             bufs[f"{bn}.running_mean"], bufs[f"{bn}.running_var"] = mod.running_mean, mod.running_var
         return bufs
 
+    _defer_nbt = False   # a Model bumps the num_batches_tracked counters of all its blocks with one multi-tensor add
+
+    def nbt_buffers(self):
+        return [self._tensor(bn).num_batches_tracked for bn in bn_names(self.cfg)]
+
     def _packed(self, params):
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._wcache is None or self._wcache[0] != key:
@@ -160,9 +165,8 @@ class SpatialTemporalConv(nn.Module):
         W = self._packed(params)
         holder = {}
         out = STBlockFunction.apply(x, self.cfg, self.training, self._block_buffers(), W, holder, *params)
-        if self.training:
-            for bn in bn_names(self.cfg):
-                self._tensor(bn).num_batches_tracked += 1
+        if self.training and not self._defer_nbt:
+            torch._foreach_add_(self.nbt_buffers(), 1)
         c = holder.get("adj_c")
         self.gcn1.adj_c = [c[:, k] for k in range(3)] if c is not None else [None] * 3
         return out
@@ -227,9 +231,18 @@ class Model(nn.Module):
             h = F.pad(h, (0, pad))
         return h.contiguous()
 
+    def _bump_batch_counters(self) -> None:
+        """num_batches_tracked += 1 for every block BatchNorm in one launch (26 scalar adds otherwise)."""
+        blocks = [m for m in self.modules() if isinstance(m, SpatialTemporalConv)]
+        for b in blocks:
+            b._defer_nbt = True
+        if self.training:
+            torch._foreach_add_([t for b in blocks for t in b.nbt_buffers()], 1)
+
     def forward(self, x):
         N, M, T, V, C = x.size()
         h = self._blocks_input(x)
+        self._bump_batch_counters()
         for layer in self.layers:
             h = layer(h)
         # (N*M, T', V, C') -> mean over (T', V) then over persons

@@ -233,17 +233,19 @@ def joint_gram(in1: torch.Tensor, in2: torch.Tensor, items: Sequence[Tuple[int, 
     return partial
 
 
-def adj_softmax_fwd(partial: Optional[torch.Tensor], scale: float, adj_ab: torch.Tensor, B: int,
-                    use_softmax: bool = True):
-    """-> (C (B,K,V,V) or None, a_hat (B,K,V,V))."""
+def adj_softmax_fwd(partial: Optional[torch.Tensor], scale: float, adj_a: torch.Tensor, B: int,
+                    use_softmax: bool = True, adj_b: Optional[torch.Tensor] = None):
+    """a_hat = softmax_v(scale * sum partial) + adj_a + adj_b  -> (C (B,K,V,V) or None, a_hat (B,K,V,V))."""
     ensure_device()
-    _chk(adj_ab, "adj_softmax_fwd.adj_ab")
-    K, V, _ = adj_ab.shape
-    a_hat = torch.empty((B, K, V, V), device=adj_ab.device, dtype=torch.float32)
+    _chk(adj_a, "adj_softmax_fwd.adj_a")
+    if adj_b is not None:
+        _chk(adj_b, "adj_softmax_fwd.adj_b")
+    K, V, _ = adj_a.shape
+    a_hat = torch.empty((B, K, V, V), device=adj_a.device, dtype=torch.float32)
     c_out = torch.empty_like(a_hat) if use_softmax else None
     nchunk = partial.shape[1] if partial is not None else 0
-    check(_lib.load().fgcn_adj_softmax_fwd(_p(partial), nchunk, float(scale), _p(adj_ab), _p(c_out), _p(a_hat), B, K, V,
-                                           int(use_softmax), _stream()), "fgcn_adj_softmax_fwd")
+    check(_lib.load().fgcn_adj_softmax_fwd(_p(partial), nchunk, float(scale), _p(adj_a), _p(adj_b), _p(c_out), _p(a_hat), B,
+                                           K, V, int(use_softmax), _stream()), "fgcn_adj_softmax_fwd")
     return c_out, a_hat
 
 

@@ -150,10 +150,10 @@ int fgcn_joint_gram(const float* in1, const float* in2, float* partial, int B, i
                     int ld1, int ld2, int t_chunk, int n_mats, const fgcn_gram_item* items, int n_items,
                     void* stream);
 
-/* S = scale * sum_chunks partial ; C[n,k,:,w] = softmax over v ; a_hat = C + adj_ab[k]      (agcn.py:84,106-108)
- *   c_out, a_hat: float[B][K][V][V]; adj_ab: float[K][V][V] (= adj_a + adj_b, agcn.py:100).
- *   use_softmax = 0 gives the static-adjacency case a_hat = adj_ab (c_out untouched). */
-int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_ab,
+/* S = scale * sum_chunks partial ; C[n,k,:,w] = softmax over v ; a_hat = C + adj_a[k] + adj_b[k]   (agcn.py:84,100,106-108)
+ *   c_out, a_hat: float[B][K][V][V]; adj_a (constant partition adjacency), adj_b (learned, may be NULL): float[K][V][V].
+ *   use_softmax = 0 gives the static-adjacency case a_hat = adj_a + adj_b (c_out untouched). */
+int fgcn_adj_softmax_fwd(const float* partial, int nchunk, float scale, const float* adj_a, const float* adj_b,
                          float* c_out, float* a_hat, int B, int K, int V, int use_softmax, void* stream);
 /* d_a_hat[n,k] = sum_chunks partial ; dS = scale * C .* (dC - colsum(C .* dC))  with dC = d_a_hat (softmax backward) */
 int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scale, const float* c_in,
