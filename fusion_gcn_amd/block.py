@@ -329,7 +329,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         dx_live = True
     else:
         du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train)
-        G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0]
+        G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
         gw = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1))
@@ -347,7 +347,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
     if cfg.has_down:
         dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train)
-        G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0]
+        G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         ops.rows_gemm(dd, W["down_t"], dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
         gw = ops.rows_wgrad(x, dd, K=cin, N=cout)
@@ -370,7 +370,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
-        G[f"gcn1.conv_d.{k}.bias"] = dbias
+        G[f"gcn1.conv_d.{k}.bias"] = dbias if k == 0 else dbias.clone()          # three parameters, three buffers
     mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
     dx_live = True
     part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])

@@ -6,8 +6,8 @@
 
 namespace fgcn {
 
-constexpr int ELEM_ROWS_PER_TILE = 512;
-constexpr int ELEM_MAX_TILES = 4096;
+constexpr int ELEM_ROWS_PER_TILE = 64;    // small tiles keep >= 8 workgroups per CU busy even at 8 clips per GPU
+constexpr int ELEM_MAX_TILES = 2048;
 
 // ---- BatchNorm finalize ------------------------------------------------------------------------------------
 // block = 32 channels x 32 partial-groups; double accumulation of the float tile sums, fixed summation order.
