@@ -44,6 +44,8 @@ class BlockConfig:
     has_down: bool = False
     static_adjacency: bool = False  # ST-GCN special case: A^ = A + B, no data-dependent C_k
     fused_spatial: bool = True      # north-star fused kernel vs. joint_mix + rows_gemm
+    fused_spatial_bwd: bool = False  # one-kernel dagg + dx + dA^ (fgcn_spatial_bwd): correct, but measured slower than the
+    #                                  row GEMM + joint_mix + joint_gram trio on MI355X (2.1 vs 1.7 ms at 256 ch), so off
 
     @property
     def ic(self) -> int:
@@ -110,7 +112,9 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torc
             W["emb_b"] = torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
         d = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
         W["d"] = torch.cat([w.t() for w in d], 0).contiguous()                    # (3cx, cout)
+        W["d4"] = ops.pack_k4(W["d"].unsqueeze(0))[0]                             # (3cx/4, cout, 4) for the fused kernel
         W["d_t"] = torch.cat(d, 1).contiguous().unsqueeze(0)                      # (1, cout, 3cx)
+        W["dt4"] = ops.pack_k4(torch.stack(d, 0).contiguous())                    # (3, cout/4, cx, 4) fused backward
         W["d_b"] = (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()
         if cfg.has_down:
             w = _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx)
@@ -258,7 +262,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
     if cfg.fused_spatial:
-        y, part = ops.spatial_fwd(x, a_hat, W["d"], W["d_b"], Cin=cin, Cout=cout, stats=train)
+        y, part = ops.spatial_fwd(x, a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     else:
         agg = new(B, T, V, 3 * cin)
         mix_agg(x, agg, a_hat, cin)
@@ -362,18 +366,24 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
     a_hat = S["a_hat"]
     c3 = 3 * cin
-    dagg = new(B, T, V, c3)
-    ops.rows_gemm(dy, W["d_t"], dagg, K=cout, N=c3)
+    # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     agg = new(B, T, V, c3)
     mix_agg(x, agg, a_hat, cin)
     gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)[0]                              # (3cin, cout)
+    del agg
     dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
         G[f"gcn1.conv_d.{k}.bias"] = dbias if k == 0 else dbias.clone()          # three parameters, three buffers
-    mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
+    if cfg.fused_spatial_bwd:
+        # dagg = dy . Wd, dx += dagg . A^^T and dA^ = x^T . dagg in one kernel; dagg never reaches HBM
+        part = ops.spatial_bwd(dy, x, a_hat, W["dt4"], dx, accumulate=dx_live)
+    else:
+        dagg = new(B, T, V, c3)
+        ops.rows_gemm(dy, W["d_t"], dagg, K=cout, N=c3)
+        mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
+        part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     dx_live = True
-    part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
     db = torch.empty_like(P["gcn1.adj_b"])
     ops.reduce_sum(d_a_hat.view(B, -1), db.view(-1))

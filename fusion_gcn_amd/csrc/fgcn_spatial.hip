@@ -48,13 +48,11 @@ __device__ __forceinline__ f32x4 sp_load4(__amdgpu_buffer_rsrc_t r, unsigned vof
 
 template <int CT_IN, int CT_OUT>
 __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
-    constexpr int WROW = CT_OUT * 32;                 // floats per staged weight row (padded Cout)
-    constexpr int WCHUNK = 32 * WROW;                 // one (k, c-tile) chunk: 32 input channels x Cout
+    constexpr int WROW = CT_OUT * 32;                 // padded Cout
     constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond num_records: the load returns 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ah = smem;                                 // [3][32][33]
-    float* wl = smem + ((3 * 32 * AHS + 3) & ~3);     // 2 x WCHUNK, 16-byte aligned for the float4 commits
-    float* st = wl + 2 * WCHUNK;                      // [4 waves][2][WROW]
+    float* st = smem + ((3 * 32 * AHS + 3) & ~3);     // [4 waves][2][WROW]
     float* tt = st + 4 * 2 * WROW;                    // [4 waves][32][TTS] accumulator transpose tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,36 +71,18 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
         ah[(k * 32 + v) * AHS + w] = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
     }
     for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
+    __syncthreads();                                  // the only workgroup barrier before the final statistics sum
 
     const int ksteps = (V + 1) >> 1;
-    const int nchunks = CT_IN * NS;                   // weight chunks per frame group
-    f32x4 wreg[CT_OUT];
-
-    // weight chunk q = ci*NS + k covers rows k*Cin + ci*32 .. +31 of the packed [NS*Cin][Cout] matrix.
-    // Per-thread offsets inside a chunk are fixed; rows >= Cin / columns >= Cout read as zeros (OOB offset).
+    // Weights stream from L2 straight into registers: wd4[(k*Cin + c)/4][o][4] (k-interleaved packing), lane = output
+    // channel o, one 16-byte buffer load = the 4 consecutive input channels c = 8g + 4h + e that registers 4g..4g+3 of
+    // the step-1 accumulator hold as the contraction index.  No LDS staging, no barriers: waves run independently.
     unsigned wvo[CT_OUT];
-    int wrow[CT_OUT];
 #pragma unroll
-    for (int i = 0; i < CT_OUT; ++i) {
-        const int idx = tid + 256 * i;                // float4 index inside the chunk
-        const int row = idx / (WROW / 4), c4 = (idx - row * (WROW / 4)) * 4;
-        wrow[i] = row;
-        wvo[i] = c4 < p.Cout ? (unsigned)(row * p.Cout + c4) * 4u : OOB;
+    for (int ot = 0; ot < CT_OUT; ++ot) {
+        const int o = ot * 32 + l31;
+        wvo[ot] = o < p.Cout ? (unsigned)(h * p.Cout + o) * 16u : OOB;
     }
-    auto prefetch_w = [&](int q) {
-        const int ci = q / NS, k = q - ci * NS;
-        const unsigned so = (unsigned)((k * p.Cin + ci * 32) * p.Cout) * 4u;
-#pragma unroll
-        for (int i = 0; i < CT_OUT; ++i)
-            wreg[i] = sp_load4(rw, (ci * 32 + wrow[i] < p.Cin) ? wvo[i] : OOB, so);
-    };
-    auto commit_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < CT_OUT; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(wl + buf * WCHUNK + idx * 4) = wreg[i];
-        }
-    };
     // x of frame t, channel tile ci: 16 branch-free dword loads (joint 2s + h of channel ci*32 + lane)
     auto load_x = [&](int t, int ci, float (&xv)[16]) {
         const int c = ci * 32 + l31;
@@ -115,10 +95,19 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
         }
     };
 
-    prefetch_w(0);
+    // weight fragment of step (ci, k, g): 4 consecutive input channels c = ci*32 + 8g + 4h + e for this lane's o
+    auto load_w = [&](int ci, int k, int g, auto& wv) {
+        const unsigned so = (unsigned)((((k * p.Cin + ci * 32) >> 2) + 2 * g) * p.Cout) * 16u;
+        const bool gok = ci * 32 + 8 * g + 4 * h < p.Cin;
+#pragma unroll
+        for (int ot = 0; ot < CT_OUT; ++ot) wv[ot] = sp_load4(rw, gok ? wvo[ot] : OOB, so);
+    };
+
     float xcur[16], xnxt[16];
+    constexpr bool PREFETCH_W = CT_OUT <= 4;
+    f32x4 wcur[CT_OUT], wnxt[PREFETCH_W ? CT_OUT : 1];
     load_x(t0 + wave, 0, xcur);
-    int qg = 0;  // global chunk counter (selects the LDS buffer)
+    if constexpr (PREFETCH_W) load_w(0, 0, 0, wcur);
     for (int tg = t0; tg < t1; tg += 4) {
         const int t = tg + wave;
         const bool tv = t < t1;
@@ -132,32 +121,38 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
             // next tile's x (next channel tile, or the first tile of this wave's next frame) flies during the MFMAs
             if (ci + 1 < CT_IN) load_x(t, ci + 1, xnxt);
             else load_x(t + 4, 0, xnxt);
+            const int cleft = p.Cin - ci * 32;          // valid input channels in this tile
 #pragma unroll 1
-            for (int k = 0; k < NS; ++k, ++qg) {
-                const int buf = qg & 1;
-                commit_w(buf);
-                __syncthreads();                        // chunk visible; everyone is done with buffer buf^1
-                {
-                    int qn = ci * NS + k + 1;           // next chunk in the (ci, k) cycle
-                    if (qn == nchunks) qn = 0;
-                    prefetch_w(qn);
-                }
-                // step 1: agg^T tile
+            for (int k = 0; k < NS; ++k) {
+                // step 1: agg^T tile (32 c x 32 w)
                 f32x16 agg = zero16();
                 const float* ak = ah + (k * 32) * AHS + l31;
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     if (s < ksteps) agg = mfma32(xcur[s], ak[(2 * s + h) * AHS], agg);
-                // step 2: y^T tiles; register r of agg is the k-pair {rho(r), rho(r)+4} of the contraction
-                const float* wb = wl + buf * WCHUNK + (4 * h) * WROW + l31;
-                const int cleft = p.Cin - ci * 32;      // valid input channels in this tile
+                // step 2: y^T tiles; registers 4g..4g+3 of agg are contraction rows c = 8g + 4h + (0..3).
+                // The weights of the NEXT step (next group, next subset, next channel tile, or the next frame's first
+                // step) are requested before this step's MFMAs.
+                const int nG = cleft >= 32 ? 4 : (cleft + 7) >> 3;   // channel groups that exist (Cin = 4: one)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rho = (r & 3) + 8 * (r >> 2);
-                    if (rho < cleft) {                  // wave-uniform: skips all-zero weight rows (Cin = 3)
+                for (int g = 0; g < 4; ++g) {
+                    if (g < nG) {                       // wave-uniform
+                        if constexpr (PREFETCH_W) {
+                            if (g + 1 < nG) load_w(ci, k, g + 1, wnxt);
+                            else if (k + 1 < NS) load_w(ci, k + 1, 0, wnxt);
+                            else if (ci + 1 < CT_IN) load_w(ci + 1, 0, 0, wnxt);
+                            else load_w(0, 0, 0, wnxt);
+                        } else {
+                            load_w(ci, k, g, wcur);     // 256 output channels: no registers left for a second set
+                        }
 #pragma unroll
-                        for (int ot = 0; ot < CT_OUT; ++ot)
-                            acc[ot] = mfma32(wb[rho * WROW + ot * 32], agg[r], acc[ot]);
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int ot = 0; ot < CT_OUT; ++ot) acc[ot] = mfma32(wcur[ot][e], agg[4 * g + e], acc[ot]);
+                        if constexpr (PREFETCH_W) {
+#pragma unroll
+                            for (int ot = 0; ot < CT_OUT; ++ot) wcur[ot] = wnxt[ot];
+                        }
                     }
                 }
             }
@@ -236,7 +231,7 @@ extern "C" int fgcn_spatial_tiles(int B, int T) { return (int)(B * cdiv(T, spati
 
 template <int CI, int CO>
 static void launch_spatial(const SpatialP& p, hipStream_t s) {
-    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 2 * 32 * CO * 32 + 4 * 2 * CO * 32 + 4 * 32 * TTS) * sizeof(float);
+    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 4 * 2 * CO * 32 + 4 * 32 * TTS) * sizeof(float);
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
     static bool lds_opt_in = false;  // once per instantiation (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in && lds > 48 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
@@ -265,6 +260,7 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
     FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V && Cin > 0 && Cout > 0, FGCN_E_BADARG,
                  "spatial_fwd: bad sizes B=%d T=%d V=%d Cin=%d Cout=%d", B, T, V, Cin, Cout);
     FGCN_REQUIRE(n_subsets >= 1 && n_subsets <= 3, FGCN_E_BADARG, "spatial_fwd: n_subsets=%d (1..3)", n_subsets);
+    FGCN_REQUIRE(Cin % 4 == 0, FGCN_E_ALIGN, "spatial_fwd: Cin must be a multiple of 4 (pad the 3-channel input), got %d", Cin);
     FGCN_REQUIRE(Cout % 4 == 0 && ld_y % 4 == 0 && ld_y >= Cout && ld_x >= Cin, FGCN_E_ALIGN,
                  "spatial_fwd: Cout and ld_y must be multiples of 4, strides must cover the channels");
     FGCN_REQUIRE(aligned16(y) && aligned16(wd) && (!bias_sum || aligned16(bias_sum)), FGCN_E_ALIGN,

@@ -341,12 +341,13 @@ def col_sum(x: torch.Tensor, C: int, coff: int = 0) -> torch.Tensor:
 # ---- fused spatial forward -----------------------------------------------------------------------------------------
 def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
                 Cout: int, stats: bool = True):
-    """y = sum_k conv_d[k](x . A^_k) fused; wd packed (K*Cin, Cout).  -> (y (B,T,V,Cout), stats partials or None)."""
+    """y = sum_k conv_d[k](x . A^_k) fused; wd = pack_k4 of the stacked (K*Cin, Cout) matrix, i.e. (K*Cin/4, Cout, 4).
+    -> (y (B,T,V,Cout), stats partials or None)."""
     ensure_device()
     _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat"), _chk(wd, "spatial_fwd.wd")
     B, T, V, ld_x = x.shape
     ns = a_hat.shape[1]
-    if tuple(wd.shape) != (ns * Cin, Cout) or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
+    if tuple(wd.shape) != (ns * Cin // 4, Cout, 4) or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
         raise _lib.FgcnError(f"spatial_fwd: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} wd={tuple(wd.shape)}")
     lib = _lib.load()
     y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
@@ -354,3 +355,24 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     check(lib.fgcn_spatial_fwd(_p(x), _p(a_hat), _p(wd), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout, ns,
                                int(a_hat.shape[0] == B), _stream()), "fgcn_spatial_fwd")
     return y, part
+
+
+def spatial_bwd(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, wdt4: torch.Tensor, dx: torch.Tensor, *,
+                accumulate: bool) -> torch.Tensor:
+    """Fused backward of the spatial aggregation: dx (+)= sum_k (dy . Wd_k) . A^_k^T and the per-chunk partials of
+    dA^_k = x^T . (dy . Wd_k).  wdt4 = pack_k4 of the (K, Cout, Cin) weight stack.  -> partial (B, nchunk, K, 32, 32)."""
+    ensure_device()
+    _chk(dy, "spatial_bwd.dy"), _chk(x, "spatial_bwd.x"), _chk(a_hat, "spatial_bwd.a_hat"), _chk(wdt4, "spatial_bwd.wdt4")
+    _chk(dx, "spatial_bwd.dx")
+    B, T, V, ld_dy = dy.shape
+    ns, Cout, Cin = wdt4.shape[0], wdt4.shape[1] * 4, wdt4.shape[2]
+    if x.shape[:3] != dy.shape[:3] or dx.shape != x.shape or a_hat.shape[1] != ns or a_hat.shape[0] not in (1, B) or \
+            a_hat.shape[2:] != (V, V) or wdt4.shape[3] != 4 or Cout > ld_dy or Cin > x.shape[3]:
+        raise _lib.FgcnError(f"spatial_bwd: shape mismatch dy={tuple(dy.shape)} x={tuple(x.shape)} "
+                             f"a_hat={tuple(a_hat.shape)} wdt4={tuple(wdt4.shape)}")
+    lib = _lib.load()
+    partial = torch.empty((B, lib.fgcn_spatial_bwd_chunks(B, T), ns, 32, 32), device=dy.device, dtype=torch.float32)
+    check(lib.fgcn_spatial_bwd(_p(dy), _p(x), _p(a_hat), _p(wdt4), _p(dx), _p(partial), B, T, V, Cin, Cout, ld_dy,
+                               x.shape[3], dx.shape[3], ns, int(a_hat.shape[0] != 1), int(accumulate), _stream()),
+          "fgcn_spatial_bwd")
+    return partial

@@ -198,12 +198,23 @@ int fgcn_col_sum(const float* x, float* partials, long long rows, int C, int ld,
 /* y[(n,t,w), o] = sum_k bd_k[o] + sum_c Wd_k[o][c] * sum_v x[(n,t,v), c] * a_hat[n][k][v][w]
  *   = conv_d[k](x . A^_k) summed over the K subsets (agcn.py:103-111) in ONE kernel: A^ staged in LDS, the joint
  *   aggregation and the Cin x Cout contraction chained on MFMA without materialising agg.
- *   wd: packed float[K*Cin][Cout] (row k*Cin + c); bias_sum: float[Cout] (= sum_k bd_k) or NULL.
+ *   wd: k-interleaved packed float[K*Cin/4][Cout][4] with wd[(k*Cin+c)/4][o][(k*Cin+c)%4] = Wd_k[o][c] (Cin % 4 == 0);
+ *   bias_sum: float[Cout] (= sum_k bd_k) or NULL.
  *   stat_partials: float[fgcn_spatial_tiles(B,T)][2][Cout] or NULL. */
 int fgcn_spatial_fwd(const float* x, const float* a_hat, const float* wd, const float* bias_sum, float* y,
                      float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
                      int n_subsets, int a_hat_batched, void* stream);
 int fgcn_spatial_tiles(int B, int T);
+
+/* ---- fused spatial block backward (input and adjacency gradients) ------------------------------------------ */
+/* dagg_k = dy . Wd_k (kept on chip);  dx (+)= sum_k dagg_k . A^_k^T;  partial[n][chunk][k] = sum_{t in chunk} x_t^T . dagg_k
+ *   = the autograd backward of agcn.py:103-111 w.r.t. x (through the aggregation) and w.r.t. A^_k, in one kernel.
+ *   wdt4: k-interleaved packed float[K][Cout/4][Cin][4] with wdt4[k][o/4][c][o%4] = Wd_k[o][c]; Cin % 4 == 0,
+ *   Cout % 16 == 0.  partial: float[B][fgcn_spatial_bwd_chunks(B,T)][K][32][32] (feed to fgcn_adj_softmax_bwd). */
+int fgcn_spatial_bwd(const float* dy, const float* x, const float* a_hat, const float* wdt4, float* dx, float* partial,
+                     int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx,
+                     int n_subsets, int a_hat_batched, int accumulate, void* stream);
+int fgcn_spatial_bwd_chunks(int B, int T);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,26 @@ def test_block_forward_backward_vs_oracle(name, cin, cout, stride, residual, V, 
     assert rel_l2(out_e.cpu().numpy(), want_e.numpy()) < 2e-5
 
 
+def test_fused_spatial_backward_block_matches_default_path():
+    """The opt-in one-kernel spatial backward gives the same block gradients as the default kernel trio."""
+    import dataclasses
+    from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv
+    adj = ntu_adj()
+    x = torch.from_numpy(filler.bellish("x.fsb", (2, 64, 10, 25))).float().to(dev())
+    probe = torch.from_numpy(filler.uniform("probe.fsb", (2, 128, 5, 25), -1, 1)).float().to(dev())
+    grads = []
+    for fused in (False, True):
+        blk = SpatialTemporalConv(64, 128, adj, stride=2)
+        fill_module(blk, "l0.")
+        blk.cfg = dataclasses.replace(blk.cfg, fused_spatial_bwd=fused)
+        blk = blk.to(dev()).train()
+        xg = x.clone().requires_grad_(True)
+        (blk.forward_nchw(xg) * probe).sum().backward()
+        grads.append([xg.grad] + [p.grad for p in blk.parameters()])
+    for a, b in zip(*grads):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5 or float(a.abs().max()) < 1e-6
+
+
 def test_static_adjacency_block_is_stgcn_special_case():
     """ST-GCN block = same kernels with the data-dependent C_k switched off."""
     from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv

@@ -99,10 +99,24 @@ def bench_wgrad(B, reps):
 def bench_spatial(B, reps):
     for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
         x, a = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2
-        wd, bias = rnd(3 * cin, cout) * (3 * cin) ** -0.5, rnd(cout)
+        wd, bias = ops.pack_k4((rnd(3 * cin, cout) * (3 * cin) ** -0.5).unsqueeze(0))[0], rnd(cout)
         ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
         rows = B * T * V
         report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
+
+
+def bench_spatial_bwd(B, reps):
+  for dbg in (0,):
+    _lib.load().fgcn_set_tuning(2, dbg)
+    print("-- spatial_bwd dbg", dbg)
+    for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
+        x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
+        wdt4 = ops.pack_k4(rnd(3, cout, cin) * (3 * cin) ** -0.5)
+        dx = torch.zeros(B, T, V, cin, device=DEV)
+        ms = timeit(lambda: ops.spatial_bwd(dy, x, a, wdt4, dx, accumulate=True), reps)
+        rows = B * T * V
+        report(f"spatial_bwd T{T} {cin}->{cout}", ms, rows * (12.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (3 * cin + cout))
+  _lib.load().fgcn_set_tuning(2, 0)
 
 
 def bench_joint(B, reps):
@@ -142,9 +156,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,joint,elem")
+    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_bwd,joint,elem")
     args = ap.parse_args()
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
