@@ -12,10 +12,10 @@ N = 8: strong scaling, per-replica BatchNorm) and the step includes the single R
 gradient buffer.  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
-  roofline      the dominant kernel (9x1 temporal-conv row GEMM on the f32 MFMA), timed live with HIP events on
+  roofline      the dominant kernel (halo-tile 9x1 temporal conv on the f32 MFMA), timed live with HIP events on
                 the stream it runs on, against the f32 matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
   cpu_baseline  the CPU oracle (oracle/agcn_oracle.py = stock-torch restatement of the reference model) timed on
-                this box's host cores on a bounded sample of the same workload (N = 4 clips).
+                this box's host cores on a bounded sample of the same workload (N = 16 clips).
 """
 from __future__ import annotations
 
@@ -80,28 +80,32 @@ def build_model(device):
 
 
 def time_dominant_kernel(device, b_local: int, reps: int = 10):
-    """Live HIP-event timing of the temporal-conv row GEMM (the kernel with the largest share of the step) at the
-    three channel widths of the model; returns per-launch algorithmic FLOPs and mean duration of the heaviest one."""
+    """Live HIP-event timing of the halo-tile temporal-conv kernel (conv_halo_kernel: with rows_wgrad_kernel the
+    largest share of the step) at the three channel widths of the model, forward form with bias and BatchNorm
+    partial sums exactly as the block launches it; returns per-launch algorithmic FLOPs and mean duration."""
     from fusion_gcn_amd import ops
     out = []
     T = SHAPE["T"]
     for c, t in ((64, T), (128, (T - 1) // 2 + 1), (256, ((T - 1) // 2) // 2 + 1)):
         x = torch.randn(b_local, t, SHAPE["V"], c, device=device)
-        w = torch.randn(9, c, c, device=device) * (9 * c) ** -0.5
+        w4 = ops.pack_k4(torch.randn(9, c, c, device=device) * (9 * c) ** -0.5)
+        bias = torch.randn(c, device=device)
         y = torch.empty_like(x)
-        tm = ops.conv_tmap(9, 1)
+
+        def launch():
+            ops.tconv_halo(x, w4, y, Th=t, taps=9, tb=1, tc=-4, bias=bias, stats=True)
         for _ in range(2):
-            ops.rows_gemm(x, w, y, K=c, N=c, tmap=tm, stats=True)
+            launch()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()                      # our launches go to torch's current stream: the events see them
         for _ in range(reps):
-            ops.rows_gemm(x, w, y, K=c, N=c, tmap=tm, stats=True)
+            launch()
         end.record()
         end.synchronize()
         ms = start.elapsed_time(end) / reps
         flops = 2.0 * b_local * t * SHAPE["V"] * 9 * c * c
         byts = 4.0 * b_local * t * SHAPE["V"] * 2 * c
-        out.append(dict(channels=c, ms=ms, flops=flops, bytes=byts, tflops=flops / ms / 1e9))
+        out.append(dict(channels=c, frames=t, ms=ms, flops=flops, bytes=byts, tflops=flops / ms / 1e9))
     return out
 
 
@@ -274,7 +278,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                                "traffic": None,
-                               "kernel": f"rows_gemm_kernel (9x1 temporal conv, {dom['channels']} channels)",
+                               "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4}> (9x1 temporal conv forward, "
+                                         f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),
                                "flop_per_launch": dom["flops"],
                                "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}

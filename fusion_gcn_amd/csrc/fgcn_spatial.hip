@@ -13,10 +13,13 @@
 //   step 2  y^T (32 o x 32 w) += Wd_k (o x c) . agg_k^T (c x w)      16 MFMAs per (o tile, c tile, k)
 //           the step-1 accumulator IS the B operand of step 2 (register r of lane half h holds row
 //           (r&3)+8(r>>2)+4h of agg^T, exactly the k index a 32x32x2 B operand needs), so agg never leaves
-//           registers; the A operand Wd_k[o][c] comes from a 32-row weight chunk staged in LDS and shared by the 4
-//           waves (double buffered, one barrier per chunk, next chunk's global loads in flight during the MFMAs).
-//   epilogue: + sum_k bd_k, 16-byte stores of 4 consecutive channels per lane, BatchNorm partial sums
-//           (sum, sum of squares per channel) reduced across the joint lanes with wave shuffles.
+//           registers; the A operand Wd_k[o][c] streams from L2 straight into registers as 16-byte buffer loads from
+//           a k-interleaved packing wd4[(k*Cin+c)/4][o][4] (lane = output channel, one load = the 4 consecutive c of
+//           registers 4g..4g+3), requested one step ahead.  No LDS staging of weights and no workgroup barrier in the
+//           frame loop: the four waves of a workgroup run independently.
+//   epilogue: each 32x32 accumulator goes through a wave-private LDS tile, so rows leave as contiguous 128-byte
+//           segments (+ sum_k bd_k) and the BatchNorm partial sums (sum, sum of squares per channel) need 3 shuffle
+//           steps per value instead of 5.
 // The joint axis sits on 25 of the 32 MFMA columns (78 % of the f32 MFMA rate is the ceiling of this mapping);
 // A^_k's zero padding makes the 7 idle columns exact zeros, so they drop out of stores and statistics.
 #include "fgcn_common.hpp"
