@@ -21,7 +21,7 @@ Kernel schedule of one block, train mode (B = N*M samples):
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -153,20 +153,30 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
-def _vec_width(cin: int) -> int:
-    """Channels per lane of the vectorised mix kernel (0: use the dword kernel, e.g. the 4-channel input)."""
-    return 4 if cin % 128 == 0 else (2 if cin % 64 == 0 else 0)
+MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
+
+
+def _vec_width(c: int, order: Sequence[int] = None) -> int:
+    """Channels per lane (1/2) for a group-of-``c``-channels mix: groups of 32*vw channels must tile ``c`` exactly
+    (first such vw in preference order), or ``c`` is a single narrower group (smallest such vw: most lanes busy).
+    0: no such tiling, use the dword kernel with 16-lane masks."""
+    order = order or MIX_VW_ORDER
+    for vw in order:
+        if c % (32 * vw) == 0:
+            return vw
+    narrow = [vw for vw in order if c % vw == 0 and c < 32 * vw]
+    return min(narrow) if narrow else 0
 
 
 def mix_agg(x: torch.Tensor, agg: torch.Tensor, a_hat: torch.Tensor, cin: int) -> None:
-    """agg[(k, c)] = x . A^_k for the three subsets."""
+    """agg[(k, c)] = x . A^_k for the three subsets (items of one channel group are adjacent: x is loaded once)."""
     vw = _vec_width(cin)
     if not vw:
         ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
         return
     g = 32 * vw
-    spec = [dict(out_c=k * cin + c0, nch=min(g, cin - c0), terms=[(k, 1, c0)])
-            for k in range(NUM_SUBSETS) for c0 in range(0, cin, g)]
+    spec = [dict(out_c=k * cin + c0, nch=min(g, cin), terms=[(k, 1, c0)])
+            for c0 in range(0, cin, g) for k in range(NUM_SUBSETS)]
     ops.joint_mix_vec(x, agg, a_hat, spec, vw=vw)
 
 
@@ -177,9 +187,25 @@ def mix_dx(dagg: torch.Tensor, dx: torch.Tensor, a_hat: torch.Tensor, cin: int, 
         ops.joint_mix(dagg, dx, a_hat, spec_dx(cin), in_channels=3 * cin, out_channels=cin, accumulate=accumulate)
         return
     g = 32 * vw
-    spec = [dict(out_c=c0, nch=min(g, cin - c0), terms=[(k, 0, k * cin + c0) for k in range(NUM_SUBSETS)])
+    spec = [dict(out_c=c0, nch=min(g, cin), terms=[(k, 0, k * cin + c0) for k in range(NUM_SUBSETS)])
             for c0 in range(0, cin, g)]
     ops.joint_mix_vec(dagg, dx, a_hat, spec, vw=vw, accumulate=accumulate)
+
+
+def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) -> None:
+    """dtheta_k = dS_k . phi_k, dphi_k = dS_k^T . theta_k over the embedding layout [th0 ph0 th1 ph1 th2 ph2]."""
+    vw = _vec_width(ic)
+    if not vw:
+        ops.joint_mix(emb, demb, d_s, spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+        return
+    g = 32 * vw
+    spec = []
+    for k in range(NUM_SUBSETS):
+        th, ph = 2 * k * ic, (2 * k + 1) * ic
+        for c0 in range(0, ic, g):
+            spec.append(dict(out_c=th + c0, nch=min(g, ic), terms=[(k, 0, ph + c0)]))
+            spec.append(dict(out_c=ph + c0, nch=min(g, ic), terms=[(k, 1, th + c0)]))
+    ops.joint_mix_vec(emb, demb, d_s, spec, vw=vw)
 
 
 def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], bias: torch.Tensor, kt: int, s: int,
@@ -393,7 +419,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     if not cfg.static_adjacency:
         emb = S["emb"]
         demb = new(B, T, V, 6 * ic)
-        ops.joint_mix(emb, demb, d_s, spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+        mix_demb(emb, demb, d_s, ic)
         ops.rows_gemm(demb, W["emb_t"], dx, K=6 * ic, N=cx, accumulate=dx_live)
         gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic)[0].t()                        # (6ic, cin)
         gb = ops.col_sum(demb, 6 * ic)

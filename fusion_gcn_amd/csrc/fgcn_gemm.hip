@@ -27,42 +27,50 @@ struct RowsGemmP {
     int T_in, T_out, V, K, N, ld_in, ld_out;
     int taps, ta, tb, tc, td;
     int accumulate;
+    long long in_elems;  // B * T_in * V * ld_in
+    unsigned w_bytes;
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
 // DB = double-buffered LDS (one barrier per K chunk instead of two, at twice the LDS footprint).
 template <int MT, int NT, bool DB>
-__global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
+__global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kernel(RowsGemmP p) {
     constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
     constexpr int AR = 4 * MT;                         // A-tile rows staged per thread
     __shared__ __attribute__((aligned(16))) float As[NBUF * BM * AS];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF * BK * BN];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int k4 = (tid & 7) * 4;
 
-    // the A-tile rows this thread stages: r = (tid >> 3) + 32*i
-    long long rbase[AR];
-    int rto[AR];
+    // All global accesses are buffer instructions with 32-bit offsets relative to a per-workgroup base (no tensor-size
+    // limit) and the out-of-range sentinel for absent rows / taps / channels: no exec-mask branches around memory
+    // instructions, so hipcc keeps counted vmcnt waits (guarded global loads / stores made it drain to vmcnt(0) after
+    // every store of the epilogue: 64 serialised store round trips per tile).
+    constexpr unsigned OOB = 0x80000000u;
     const int TV = p.T_out * p.V;
+    const int n_first = (int)((unsigned)m0 / (unsigned)TV);   // 32-bit decode: host guarantees M < 2^31
+    const long long in_base = (long long)n_first * p.T_in * p.V * p.ld_in;
+    const long long in_left = (p.in_elems - in_base) * 4;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.in + in_base), 0, (unsigned)(in_left < 0x7FFFFFFFll ? in_left : 0x7FFFFFFFll), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    // the A-tile rows this thread stages: r = (tid >> 3) + 32*i
+    unsigned roff[AR];
+    int rto[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const long long m = m0 + (tid >> 3) + 32 * i;
-        if (m < p.M) {
-            // 32-bit decode (host guarantees M < 2^31): a 64-bit division costs hundreds of instructions per row
-            const unsigned mu = (unsigned)m;
-            const int n = (int)(mu / (unsigned)TV);
-            const int rem = (int)(mu - (unsigned)n * (unsigned)TV);
-            const int to = (int)((unsigned)rem / (unsigned)p.V);
-            const int v = rem - to * p.V;
-            rbase[i] = ((long long)n * p.T_in * p.V + v) * p.ld_in;
-            rto[i] = to;
-        } else {
-            rbase[i] = 0;
-            rto[i] = -1;
-        }
+        const unsigned mu = (unsigned)(m < p.M ? m : m0);
+        const int n = (int)(mu / (unsigned)TV);
+        const int rem = (int)(mu - (unsigned)n * (unsigned)TV);
+        const int to = (int)((unsigned)rem / (unsigned)p.V);
+        const int v = rem - to * p.V;
+        roff[i] = (unsigned)(((n - n_first) * p.T_in * p.V + v) * p.ld_in) * 4u;
+        rto[i] = m < p.M ? to : -1;
     }
 
     const int KC = (p.K + BK - 1) / BK;
@@ -79,29 +87,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
         const int kc = (s - tap * KC) * BK;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int ti = rto[i] >= 0 ? tmap_src(rto[i], tap, p.ta, p.tb, p.tc, p.td, p.T_in) : -1;
-            const int k = kc + k4;
-            if (ti >= 0 && k < p.K) {
-                const float* src = p.in + rbase[i] + (long long)ti * p.V * p.ld_in + k;
-                if (k + 3 < p.K) {
-                    v = *reinterpret_cast<const f32x4*>(src);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k + e < p.K) v[e] = src[e];
-                }
-            }
-            areg[i] = v;
+            const int k = kc + k4;   // K % 4 == 0: a 16-byte group is either whole or absent
+            const unsigned off = (ti >= 0 && k < p.K) ? roff[i] + (unsigned)(ti * p.V * p.ld_in + k) * 4u : OOB;
+            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int idx = tid + 256 * i;
             const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
             const int k = kc + kk, n = n0 + 4 * n4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < p.K && n < p.N) v = *reinterpret_cast<const f32x4*>(p.w + ((long long)tap * p.K + k) * p.N + n);
-            breg[i] = v;
+            const unsigned off = (k < p.K && n < p.N) ? (unsigned)((tap * p.K + k) * p.N + n) * 4u : OOB;
+            breg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
         }
     };
 
@@ -145,6 +142,13 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
     }
 
     // ---- epilogue: bias, optional accumulate, store, optional BatchNorm partial statistics -----------------
+    // The output buffer covers exactly this tile's rows that exist (rows >= M fall outside and are dropped).
+    const long long rows_left = p.M - m0;
+    const unsigned tile_rows = (unsigned)(rows_left < BM ? rows_left : BM);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + m0 * p.ld_out), 0, tile_rows * (unsigned)p.ld_out * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias : p.w), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -152,20 +156,31 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemmP p) {
         ssq[nt] = 0.f;
         const int col = n0 + nt * 32 + (lane & 31);
         const bool cok = col < p.N;
-        const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+        const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, cok ? (unsigned)col * 4u : OOB, 0, 0));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            // register r holds row rel0 + (r & 3) + 8 (r >> 2); rows past the tile's last row are outside the buffer
+            const unsigned rel0 = (unsigned)(wave * 32 * MT + mt * 32 + 4 * (lane >> 5));
+            const unsigned off0 = cok ? (rel0 * (unsigned)p.ld_out + (unsigned)col) * 4u : OOB;
+            const unsigned rstep = (unsigned)p.ld_out * 4u;
+            float old[16];
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rout, off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wave * 32 * MT + mt * 32 + acc_row(r, lane);
-                if (cok && m < p.M) {
-                    float* dst = p.out + m * p.ld_out + col;
-                    float val = acc[mt][nt][r] + bv;
-                    if (p.accumulate) val += *dst;
-                    *dst = val;
-                    ssum[nt] += val;
-                    ssq[nt] += val * val;
-                }
+                const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
+                const float val = acc[mt][nt][r] + bv + old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off0 + dr * rstep, 0, 0);
+                const float kept = (cok && rel0 + dr < tile_rows) ? val : 0.f;
+                ssum[nt] += kept;
+                ssq[nt] += kept * kept;
             }
         }
     }
@@ -366,14 +381,17 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     FGCN_REQUIRE(in && out && w, FGCN_E_BADARG, "rows_gemm: null pointer");
     FGCN_REQUIRE(B > 0 && T_in > 0 && T_out > 0 && V > 0 && K > 0 && N > 0, FGCN_E_BADARG,
                  "rows_gemm: non-positive size B=%d T_in=%d T_out=%d V=%d K=%d N=%d", B, T_in, T_out, V, K, N);
-    FGCN_REQUIRE(N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, FGCN_E_ALIGN,
-                 "rows_gemm: N, ld_in, ld_out must be multiples of 4 (N=%d ld_in=%d ld_out=%d)", N, ld_in, ld_out);
+    FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, FGCN_E_ALIGN,
+                 "rows_gemm: K, N, ld_in, ld_out must be multiples of 4 (K=%d N=%d ld_in=%d ld_out=%d)", K, N, ld_in, ld_out);
+    FGCN_REQUIRE((long long)T_in * V * ld_in < (1ll << 27) && (long long)map.taps * K * N < (1ll << 28) && ld_out < (1 << 20),
+                 FGCN_E_BADARG, "rows_gemm: one sample / the weights exceed the 32-bit offset range");
     FGCN_REQUIRE(ld_in >= ((K + 3) & ~3) && ld_out >= N, FGCN_E_BADARG,
                  "rows_gemm: row strides too small (K=%d ld_in=%d N=%d ld_out=%d)", K, ld_in, N, ld_out);
     FGCN_REQUIRE(aligned16(in) && aligned16(out) && aligned16(w), FGCN_E_ALIGN, "rows_gemm: 16-byte alignment");
     if (int e = check_tmap(map)) return e;
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
-                map.taps, map.ta, map.tb, map.tc, map.td, accumulate};
+                map.taps, map.ta, map.tb, map.tc, map.td, accumulate,
+                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4)};
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;

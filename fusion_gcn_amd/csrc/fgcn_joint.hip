@@ -92,98 +92,120 @@ __global__ __launch_bounds__(256) void joint_mix_kernel(MixP p) {
     }
 }
 
-// Vectorised form for the two big mixes of the backward pass (agg recompute, dx): lane j owns VW consecutive
-// channels (one 4/8/16-byte load per joint instead of VW dword loads), tile m of the group holds channel
-// base + VW*j + m, so loads and stores are fully contiguous (32*VW channels per half-wave access).
+// Channel-group form (agg recompute, dx, embedding gradients): lane j of a group owns VW consecutive channels, one
+// item covers 32*VW channels, loads and stores are whole 128/256-byte rows (VW = 4 measured no faster and needs 216 VGPRs).  Built for a short instruction
+// stream and high occupancy rather than software pipelining (these mixes are HBM-bound; the first version spent its
+// time issuing ~1000 VALU instructions per frame with load, MFMA and store phases serialised at 1-2 waves/SIMD):
+//   * every load and store is a buffer instruction whose per-lane offset (joint row, lane channels, or the
+//     out-of-range sentinel for joints >= V / absent channels) is computed once per kernel; the frame / channel-group
+//     base goes in the scalar offset, so the inner loops carry no address arithmetic and no exec-mask branches;
+//   * the A operands (M or M^T, zero-padded) sit in LDS as [k][i] images: one ds_read with an immediate offset per step;
+//   * an item whose single term reads the same input as the previous item keeps that input in registers
+//     (agg_0..2 share x); the accumulate form fetches the old output before the MFMA chain, not after it.
 struct MixVP {
     const float* in;
     float* out;
     const float* mats;
-    int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, accumulate, t_chunk;
-    unsigned in_bytes;
-    fgcn_mixv_item items[FGCN_MIX_MAX_ITEMS];
+    int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, t_chunk, dbg;
+    unsigned in_bytes, out_bytes;
+    struct Item {  // dword fields only: the kernel reads them with scalar loads (16-bit fields went through vector memory)
+        int out_c, nterms, img[3], in_c[3];
+    } items[FGCN_MIX_MAX_ITEMS];
+    int nch;
 };
 
-template <int VW>
+template <int VW> struct MixVec;
+template <> struct MixVec<1> {
+    using raw = unsigned;
+    static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b32(r, v, so, 0); }
+    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b32(d, r, v, so, 0); }
+};
+template <> struct MixVec<2> {
+    using raw = __attribute__((ext_vector_type(2))) unsigned;
+    static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b64(r, v, so, 0); }
+    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b64(d, r, v, so, 0); }
+};
+constexpr int IMG = 32 * 32;  // one A-operand image, [k][i]
+
+// KS = MFMA k-steps (joint pairs) covered: ceil(V / 2) rounded up to even; the padding steps multiply zeros (the images
+// are zero-padded and absent joints load as zeros).  Compile-time so that the MFMA chains carry no branches: with a
+// runtime step count hipcc moved all accumulators between AGPRs and VGPRs around every conditional step.
+template <int VW, bool ACC, int KS>
 __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
     using vec = __attribute__((ext_vector_type(VW))) float;
-    __shared__ float mat[MIX_MAX_MATS * 32 * MS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    using raw = typename MixVec<VW>::raw;
+    __shared__ float img[2 * MIX_MAX_MATS * IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n = blockIdx.y;
     const int t0 = blockIdx.x * p.t_chunk;
     const int t1 = min(t0 + p.t_chunk, p.T);
     const int V = p.V;
 
+    // image 2m + tr holds A[i = out joint][k = in joint] = tr ? M_m[k][i] : M_m[i][k] at [k][i]
     const float* msrc = p.mats + (p.mats_batched ? (long long)n * p.n_mats * V * V : 0);
-    for (int i = tid; i < p.n_mats * 32 * 32; i += 256) {
-        const int mi = i >> 10, u = (i >> 5) & 31, w = i & 31;
-        mat[(mi * 32 + u) * MS + w] = (u < V && w < V) ? msrc[(mi * V + u) * V + w] : 0.f;
+    for (int e = tid; e < 2 * p.n_mats * IMG; e += 256) {
+        const int im = e >> 10, k = (e >> 5) & 31, i = e & 31;
+        const int r = (im & 1) ? k : i, c = (im & 1) ? i : k;
+        img[e] = (r < V && c < V) ? msrc[((im >> 1) * V + r) * V + c] : 0.f;
     }
     __syncthreads();
 
-    // Loads are buffer loads (joints / channels that do not exist carry an out-of-range offset and read as zeros: no
-    // branches), and the loads of step i+1 (next term, next item or next frame) are issued before the MFMAs of step i.
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    const int ksteps = (V + 1) >> 1;
-    auto issue = [&](int t, int it, int tr, vec (&bv)[16]) {
-        const bool ok = t < t1 && it < p.n_items && VW * l31 < p.items[it < p.n_items ? it : 0].nch;
-        const fgcn_mixv_item& item = p.items[it < p.n_items ? it : 0];
-        const unsigned base =
-            (unsigned)((((long long)n * p.T + (t < t1 ? t : t0)) * V) * p.ld_in + item.term[tr].in_c + VW * l31) * 4u;
+    const bool lane_ok = VW * l31 < p.nch;  // all items of a launch have the same width (checked on the host)
+    unsigned koff[16], uoff[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = 2 * s + h;
-            const unsigned off = (ok && s < ksteps && k < V) ? base + (unsigned)(k * p.ld_in) * 4u : OOB;
-            if constexpr (VW == 4) {
-                bv[s] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
-            } else {
-                bv[s] = __builtin_bit_cast(vec, __builtin_amdgcn_raw_buffer_load_b64(rin, off, 0, 0));
-            }
-        }
-    };
-    vec bcur[16], bnxt[16];
-    issue(t0 + wave, 0, 0, bcur);
+    for (int s = 0; s < 16; ++s) {
+        const int k = 2 * s + h, u = acc_row(s, lane);
+        koff[s] = (lane_ok && k < V && !(p.dbg & 4)) ? (unsigned)(k * p.ld_in + VW * l31) * 4u : OOB;
+        uoff[s] = (lane_ok && u < V && !(p.dbg & 1)) ? (unsigned)(u * p.ld_out + VW * l31) * 4u : OOB;
+    }
+    const float* arow = &img[h * 32 + l31];
+
     for (int t = t0 + wave; t < t1; t += 4) {
-        const long long row0 = ((long long)n * p.T + t) * V;
+        const unsigned frame = (unsigned)(n * p.T + t) * (unsigned)V;
+        const unsigned fin = frame * (unsigned)p.ld_in * 4u, fout = frame * (unsigned)p.ld_out * 4u;
+        raw bv[KS];
+        int loaded_c = -1;
         for (int it = 0; it < p.n_items; ++it) {
-            const fgcn_mixv_item& item = p.items[it];
-            const bool lane_ok = VW * l31 < item.nch;
+            const MixVP::Item& item = p.items[it];
+            const unsigned so_out = __builtin_amdgcn_readfirstlane(fout + (unsigned)item.out_c * 4u);
+            raw old[ACC ? 16 : 1];
+            if constexpr (ACC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((r & 3) + 8 * (r >> 2) < 2 * KS) old[r] = MixVec<VW>::load(rout, uoff[r], so_out);
+            }
             f32x16 acc[VW];
 #pragma unroll
             for (int m = 0; m < VW; ++m) acc[m] = zero16();
             for (int tr = 0; tr < item.nterms; ++tr) {
-                // next step: next term of this item, else first term of the next item, else next frame of this wave
-                if (tr + 1 < item.nterms) issue(t, it, tr + 1, bnxt);
-                else if (it + 1 < p.n_items) issue(t, it + 1, 0, bnxt);
-                else issue(t + 4, 0, 0, bnxt);
-                const float* mrow = &mat[item.term[tr].mat * 32 * MS];
-                const int a_i = item.term[tr].transpose ? 1 : MS, a_k = item.term[tr].transpose ? MS : 1;
+                const int in_c = item.in_c[tr];
+                if (!(item.nterms == 1 && in_c == loaded_c)) {
+                    const unsigned so_in = __builtin_amdgcn_readfirstlane(fin + (unsigned)in_c * 4u);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    if (s < ksteps) {
-                        const float a = mrow[l31 * a_i + (2 * s + h) * a_k];
-#pragma unroll
-                        for (int m = 0; m < VW; ++m) acc[m] = mfma32(a, bcur[s][m], acc[m]);
-                    }
+                    for (int s = 0; s < KS; ++s) bv[s] = MixVec<VW>::load(rin, koff[s], so_in);
                 }
+                loaded_c = item.nterms == 1 ? in_c : -1;
+                const float* a = arow + item.img[tr] * IMG;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) bcur[s] = bnxt[s];
+                for (int s = 0; s < KS; ++s) {
+                    const float av = a[s * 64];
+                    const vec b = __builtin_bit_cast(vec, bv[s]);
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) acc[m] = mfma32(av, b[m], acc[m]);
+                }
             }
-            if (lane_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int u = acc_row(r, lane);
-                    if (u < V) {
-                        vec* dst = reinterpret_cast<vec*>(p.out + (row0 + u) * p.ld_out + item.out_c + VW * l31);
-                        vec v;
+            for (int r = 0; r < 16; ++r) {
+                if ((r & 3) + 8 * (r >> 2) >= 2 * KS) continue;  // compile-time: register r only holds padding joints
+                vec v;
 #pragma unroll
-                        for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
-                    }
-                }
+                for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
+                if constexpr (ACC) v += __builtin_bit_cast(vec, old[r]);
+                MixVec<VW>::store(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
             }
         }
     }
@@ -195,7 +217,9 @@ struct GramP {
     float* partial;
     int B, T, V, ld1, ld2, t_chunk, n_items;
     unsigned in1_bytes, in2_bytes;
-    fgcn_gram_item items[FGCN_GRAM_MAX_ITEMS];
+    struct Item {  // dword fields: read with scalar loads (the 16-bit ABI fields went through vector memory + vmcnt(0))
+        int c1, c2, width, mat;
+    } items[FGCN_GRAM_MAX_ITEMS];
 };
 
 __device__ __forceinline__ f32x4 load4_masked(const float* p, int c, int width, bool row_ok) {
@@ -214,7 +238,7 @@ __device__ __forceinline__ f32x4 load4_masked(const float* p, int c, int width, 
 
 __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
     __shared__ float red[4 * 1024];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int t0 = chunk * p.t_chunk;
@@ -229,15 +253,27 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.in1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, p.in2_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    // item descriptors in scalar registers (dynamic indexing of the kernel-argument array went through vector memory
+    // and a full vmcnt(0) drain in front of every prefetch)
+    int ic1[3], ic2[3], iw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const bool have = i < p.n_items;
+        ic1[i] = __builtin_amdgcn_readfirstlane(have ? p.items[i].c1 : 0);
+        ic2[i] = __builtin_amdgcn_readfirstlane(have ? p.items[i].c2 : 0);
+        iw[i] = __builtin_amdgcn_readfirstlane(have ? p.items[i].width : 0);
+    }
     auto issue = [&](int t, int it, int q0, f32x4 (&a)[4], f32x4 (&b)[4]) {
         const bool ok = row_ok && t < t1 && it < p.n_items;
-        const fgcn_gram_item item = p.items[it < p.n_items ? it : 0];
-        const unsigned row = (unsigned)(((long long)n * p.T + (t < t1 ? t : t0)) * V + vv);
-        const unsigned o1 = (row * (unsigned)p.ld1 + item.c1 + 4 * h) * 4u, o2 = (row * (unsigned)p.ld2 + item.c2 + 4 * h) * 4u;
+        const int c1 = it == 0 ? ic1[0] : (it == 1 ? ic1[1] : ic1[2]);
+        const int c2 = it == 0 ? ic2[0] : (it == 1 ? ic2[1] : ic2[2]);
+        const int width = it == 0 ? iw[0] : (it == 1 ? iw[1] : iw[2]);
+        const unsigned row = (unsigned)((n * p.T + (t < t1 ? t : t0)) * V + vv);
+        const unsigned o1 = (row * (unsigned)p.ld1 + c1 + 4 * h) * 4u, o2 = (row * (unsigned)p.ld2 + c2 + 4 * h) * 4u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = 8 * (q0 + j) + 4 * h;          // lane half h contracts channels 8q + 4h + e on both operands
-            const bool cok = ok && c < item.width;
+            const bool cok = ok && c < width;
             a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, cok ? o1 + 32u * (q0 + j) : OOB, 0, 0));
             b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, cok ? o2 + 32u * (q0 + j) : OOB, 0, 0));
         }
@@ -250,7 +286,7 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
             if (it < p.n_items) {
-                const int nq = (p.items[it].width + 7) >> 3;
+                const int nq = (iw[it] + 7) >> 3;
                 for (int q0 = 0; q0 < nq; q0 += 4) {
                     if (q0 + 4 < nq) issue(t, it, q0 + 4, an, bn);
                     else if (it + 1 < p.n_items) issue(t, it + 1, 0, an, bn);
@@ -409,7 +445,8 @@ extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partia
                          items[i].c2 % 4 == 0 &&
                          items[i].c1 + items[i].width <= ld1 + 3 && items[i].c2 + items[i].width <= ld2 + 3,
                      FGCN_E_BADARG, "joint_gram: item %d malformed", i);
-        p.items[i] = items[i];
+        p.items[i].c1 = items[i].c1; p.items[i].c2 = items[i].c2;
+        p.items[i].width = items[i].width; p.items[i].mat = items[i].mat;
     }
     dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
     hipLaunchKernelGGL(joint_gram_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -444,30 +481,54 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
                  "joint_mix_vec: bad B/T/V (%d,%d,%d)", B, T, V);
     FGCN_REQUIRE(n_mats >= 1 && n_mats <= MIX_MAX_MATS && n_items >= 1 && n_items <= FGCN_MIX_MAX_ITEMS,
                  FGCN_E_BADARG, "joint_mix_vec: n_mats=%d n_items=%d out of range", n_mats, n_items);
-    FGCN_REQUIRE(vw == 2 || vw == 4, FGCN_E_BADARG, "joint_mix_vec: vw must be 2 or 4 (got %d)", vw);
+    FGCN_REQUIRE(vw == 1 || vw == 2, FGCN_E_BADARG, "joint_mix_vec: vw must be 1 or 2 (got %d)", vw);
     FGCN_REQUIRE(ld_in % 4 == 0 && ld_out % 4 == 0 && aligned16(in) && aligned16(out), FGCN_E_ALIGN,
                  "joint_mix_vec: 16-byte alignment");
-    const long long in_bytes = (long long)B * T * V * ld_in * 4;
-    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "joint_mix_vec: input must be smaller than 2 GiB");
+    const long long in_bytes = (long long)B * T * V * ld_in * 4, out_bytes = (long long)B * T * V * ld_out * 4;
+    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "joint_mix_vec: tensors must be smaller than 2 GiB");
     MixVP p;
-    p.in_bytes = (unsigned)in_bytes;
+    p.in_bytes = (unsigned)in_bytes; p.out_bytes = (unsigned)out_bytes;
     p.in = in; p.out = out; p.mats = mats;
     p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out;
-    p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items; p.accumulate = accumulate;
+    p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items;
     p.t_chunk = pick_t_chunk(B, T);
+    p.dbg = fgcn::tuning(3);
     for (int i = 0; i < n_items; ++i) {
         const fgcn_mixv_item& it = items[i];
         FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.nch >= vw && it.nch <= 32 * vw && it.nch % vw == 0 &&
-                         it.out_c >= 0 && it.out_c % vw == 0 && it.out_c + it.nch <= ld_out,
-                     FGCN_E_BADARG, "joint_mix_vec: item %d malformed", i);
+                         it.nch == items[0].nch && it.out_c >= 0 && it.out_c % vw == 0 && it.out_c + it.nch <= ld_out,
+                     FGCN_E_BADARG, "joint_mix_vec: item %d malformed (all items of a call share one width)", i);
         for (int t = 0; t < it.nterms; ++t)
             FGCN_REQUIRE(it.term[t].mat >= 0 && it.term[t].mat < n_mats && it.term[t].in_c >= 0 &&
                              it.term[t].in_c % vw == 0 && it.term[t].in_c + it.nch <= ld_in,
                          FGCN_E_BADARG, "joint_mix_vec: item %d term %d malformed", i, t);
-        p.items[i] = it;
+        p.items[i].out_c = it.out_c;
+        p.items[i].nterms = it.nterms;
+        for (int t = 0; t < 3; ++t) {
+            p.items[i].img[t] = t < it.nterms ? 2 * it.term[t].mat + (it.term[t].transpose ? 1 : 0) : 0;
+            p.items[i].in_c[t] = t < it.nterms ? it.term[t].in_c : 0;
+        }
     }
+    p.nch = items[0].nch;
     dim3 grid((unsigned)cdiv(T, p.t_chunk), (unsigned)B);
-    if (vw == 4) hipLaunchKernelGGL(joint_mix_vec_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(joint_mix_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const hipStream_t st = (hipStream_t)stream;
+    const int ks = (V + 3) / 4 * 2;  // k-steps, rounded up to even
+#define FGCN_MIXV_KS(VW_, ACC_)                                                                              \
+    do {                                                                                                     \
+        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10>), grid, dim3(256), 0, st, p);      \
+        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12>), grid, dim3(256), 0, st, p); \
+        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16>), grid, dim3(256), 0, st, p);               \
+    } while (0)
+#define FGCN_MIXV(VW_)                            \
+    do {                                          \
+        if (accumulate) FGCN_MIXV_KS(VW_, true);  \
+        else FGCN_MIXV_KS(VW_, false);            \
+    } while (0)
+    if (vw == 2) FGCN_MIXV(2);
+    else FGCN_MIXV(1);
+#undef FGCN_MIXV
+#undef FGCN_MIXV_KS
     return launch_status("joint_mix_vec");
 }

@@ -50,15 +50,16 @@ __device__ __forceinline__ f32x4 sp_load4(__amdgpu_buffer_rsrc_t r, unsigned vof
 }
 
 template <int CT_IN, int CT_OUT>
-__global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
+__global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
     constexpr int WROW = CT_OUT * 32;                 // padded Cout
     constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond num_records: the load returns 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ah = smem;                                 // [3][32][33]
     float* st = smem + ((3 * 32 * AHS + 3) & ~3);     // [4 waves][2][WROW]
     float* tt = st + 4 * 2 * WROW;                    // [4 waves][32][TTS] accumulator transpose tiles
+    float* bl = tt + 4 * 32 * TTS;                    // [WROW] bias (zeros where absent)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n = blockIdx.y;
     const int V = p.V, NS = p.ns;
@@ -67,6 +68,11 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, p.w_bytes, 0x00020000);
+    // output rows of this workgroup's frames [t0, t1): offsets relative to frame t0 (no tensor-size limit); stores are
+    // branch-free buffer stores (absent joints / channels carry the out-of-range offset and are dropped) -- guarded
+    // global stores made hipcc drain vmcnt(0), i.e. the next frame's x prefetch, in front of every row store
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y + ((long long)n * p.T + t0) * V * p.ld_y), 0, (unsigned)((t1 - t0) * V * p.ld_y) * 4u, 0x00020000);
 
     const float* asrc = p.a_hat + (p.a_batched ? (long long)n * NS * V * V : 0);
     for (int i = tid; i < 3 * 32 * 32; i += 256) {
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
         ah[(k * 32 + v) * AHS + w] = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
     }
     for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
+    for (int i = tid; i < WROW; i += 256) bl[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
     __syncthreads();                                  // the only workgroup barrier before the final statistics sum
 
     const int ksteps = (V + 1) >> 1;
@@ -114,7 +121,6 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
     for (int tg = t0; tg < t1; tg += 4) {
         const int t = tg + wave;
         const bool tv = t < t1;
-        const long long row0 = ((long long)n * p.T + (tv ? t : t0)) * V;
         f32x16 acc[CT_OUT];
 #pragma unroll
         for (int i = 0; i < CT_OUT; ++i) acc[i] = zero16();
@@ -175,18 +181,18 @@ __global__ __launch_bounds__(256, (CT_OUT <= 2 ? 2 : 1)) void spatial_fwd_kernel
                     f32x4{acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]};
             const int o = ot * 32 + c4;
             const bool ook = o < p.Cout;                // Cout % 4 == 0: the quad is all-in or all-out
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && ook) b4 = *reinterpret_cast<const f32x4*>(p.bias + o);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bl[o]);
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = rr + 8 * i;
                 const f32x4 val = *reinterpret_cast<const f32x4*>(&T[r * TTS + c4]) + b4;
-                if (tv && r < V && ook) {
-                    *reinterpret_cast<f32x4*>(p.y + (row0 + r) * p.ld_y + o) = val;
-                    s1 += val;
-                    s2 += val * val;
-                }
+                const bool keep = tv && r < V && ook;
+                const unsigned off = keep ? (unsigned)(((t - t0) * V + r) * p.ld_y + o) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, val), ry, off, 0, 0);
+                const f32x4 kept = keep ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+                s1 += kept;
+                s2 += kept * kept;
             }
             if (p.stats) {
 #pragma unroll
@@ -234,7 +240,7 @@ extern "C" int fgcn_spatial_tiles(int B, int T) { return (int)(B * cdiv(T, spati
 
 template <int CI, int CO>
 static void launch_spatial(const SpatialP& p, hipStream_t s) {
-    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 4 * 2 * CO * 32 + 4 * 32 * TTS) * sizeof(float);
+    const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 4 * 2 * CO * 32 + 4 * 32 * TTS + CO * 32) * sizeof(float);
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
     static bool lds_opt_in = false;  // once per instantiation (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in && lds > 48 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit

@@ -29,7 +29,7 @@ struct HaloP {
     const float* bias;
     float* stats;
     long long Mv;                       // virtual rows = B * Tv * V
-    unsigned in_bytes, w_bytes;
+    unsigned in_bytes, w_bytes, out_bytes;
     int Tv, V, K, N, ld_in, ld_out;
     int T_in_full, in_s, in_o, Th_in;   // input frame of virtual frame th: th*in_s + in_o (valid while th < Th_in)
     int T_out_full, out_s, out_o, Th_out;  // output frame of virtual frame th: th*out_s + out_o (th < Th_out)
@@ -46,8 +46,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void conv_halo_kernel(HaloP p) {
+// MINB = workgroups per CU the register allocation aims at (launch-bounds hint; fgcn_set_tuning key 4 picks 2 or 3)
+template <int NT, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -160,42 +161,58 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloP p) {
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
+    // Branch-free buffer stores (rows / channels / frames that do not exist carry the out-of-range offset and are
+    // dropped): guarded global stores made hipcc wait for vmcnt(0) after every single store.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NT], ssq[NT], bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         ssum[nt] = 0.f;
         ssq[nt] = 0.f;
-        bv[nt] = (p.bias && col + nt * 32 < p.N) ? p.bias[col + nt * 32] : 0.f;
+        bv[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rbias, col + nt * 32 < p.N ? (unsigned)(col + nt * 32) * 4u : OOB, 0, 0));
     }
+    unsigned rowoff[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long long m = m0 + wave * 32 + acc_row(r, lane);
-        if (m < p.Mv) {
-            long long orow = m;
-            bool fok = true;
-            if (!plain_out) {
-                const unsigned mu = (unsigned)m;
-                const int n = (int)(mu / (unsigned)TvV);
-                const int rem = (int)(mu - (unsigned)n * (unsigned)TvV);
-                const int th = (int)((unsigned)rem / (unsigned)V);
-                const int v = rem - th * V;
-                fok = th < p.Th_out;
-                orow = ((long long)n * p.T_out_full + th * p.out_s + p.out_o) * V + v;
-            }
-            if (fok) {
+        bool ok = m < p.Mv;
+        unsigned orow = (unsigned)(ok ? m : 0);
+        if (!plain_out) {                              // wave-uniform
+            const int n = (int)(orow / (unsigned)TvV);
+            const int rem = (int)(orow - (unsigned)n * (unsigned)TvV);
+            const int th = (int)((unsigned)rem / (unsigned)V);
+            const int v = rem - th * V;
+            ok = ok && th < p.Th_out;
+            orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
+        }
+        rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
+    }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int c = col + nt * 32;
-                    if (c < p.N) {
-                        float* dst = p.out + orow * p.ld_out + c;
-                        float val = acc[nt][r] + bv[nt];
-                        if (p.accumulate) val += *dst;
-                        *dst = val;
-                        ssum[nt] += val;
-                        ssq[nt] += val * val;
-                    }
-                }
-            }
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = col + nt * 32;
+        const unsigned coff = c < p.N ? (unsigned)c * 4u : OOB;
+        float old[16];
+        if (p.accumulate) {                            // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rout, (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff, 0, 0));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff;
+            const float val = acc[nt][r] + bv[nt] + old[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+            const float kept = off != OOB ? val : 0.f;
+            ssum[nt] += kept;
+            ssq[nt] += kept * kept;
         }
     }
     if (p.stats) {
@@ -239,7 +256,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
     FGCN_REQUIRE(B > 0 && Th > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0, FGCN_E_BADARG,
                  "tconv_halo: bad sizes B=%d Th=%d V=%d K=%d N=%d", B, Th, V, K, N);
-    FGCN_REQUIRE(K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_in >= K && ld_out >= N, FGCN_E_ALIGN,
+    FGCN_REQUIRE(K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N, FGCN_E_ALIGN,
                  "tconv_halo: K must be a multiple of 32, N and strides multiples of 4 (K=%d N=%d ld_in=%d ld_out=%d)", K,
                  N, ld_in, ld_out);
     FGCN_REQUIRE(aligned16(in) && aligned16(w4), FGCN_E_ALIGN, "tconv_halo: 16-byte alignment");
@@ -249,11 +266,12 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     FGCN_REQUIRE((long long)(Th_in - 1) * in_s + in_o < T_in_full && (long long)(Th - 1) * out_s + out_o < T_out_full,
                  FGCN_E_BADARG, "tconv_halo: frame view exceeds the tensor (Th=%d Th_in=%d)", Th, Th_in);
     const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4, w_bytes = (long long)taps * K * N * 4;
-    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
+    const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
+    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     HaloP p;
     p.in = in; p.out = out; p.w4 = w4; p.bias = bias; p.stats = stat_partials;
-    p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
+    p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
     p.Tv = Th > Th_in ? Th : Th_in;
     p.Mv = (long long)B * p.Tv * V;
     p.V = V; p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out;
@@ -272,18 +290,22 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     static bool lds_opt_in = false;  // once per process (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in) {               // V > 25 needs more than the default dynamic-LDS limit (gfx950: 160 KiB per CU)
         const int max_lds = 32 * HALO_MAX_STAGE * HAS * (int)sizeof(float);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define FGCN_HALO_ATTR(NT_, MB_)                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_>), \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
+        FGCN_HALO_ATTR(2, 2); FGCN_HALO_ATTR(2, 3); FGCN_HALO_ATTR(4, 2); FGCN_HALO_ATTR(4, 3);
+#undef FGCN_HALO_ATTR
         lds_opt_in = true;
     }
+    const bool three = fgcn::tuning(4) != 0;
     if (N <= 64) {
         dim3 grid((unsigned)tiles, (unsigned)cdiv(N, 64));
-        hipLaunchKernelGGL(conv_halo_kernel<2>, grid, dim3(256), lds, s, p);
+        if (three) hipLaunchKernelGGL((conv_halo_kernel<2, 3>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_halo_kernel<2, 2>), grid, dim3(256), lds, s, p);
     } else {
         dim3 grid((unsigned)tiles, (unsigned)cdiv(N, 128));
-        hipLaunchKernelGGL(conv_halo_kernel<4>, grid, dim3(256), lds, s, p);
+        if (three) hipLaunchKernelGGL((conv_halo_kernel<4, 3>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_halo_kernel<4, 2>), grid, dim3(256), lds, s, p);
     }
     return launch_status("tconv_halo");
 }

@@ -187,6 +187,9 @@ def joint_mix(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec: Se
     return out
 
 
+MIX_MAX_ITEMS = 24   # FGCN_MIX_MAX_ITEMS (include/fgcn.h)
+
+
 def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec: Sequence[dict], *, vw: int,
                   accumulate: bool = False) -> torch.Tensor:
     """Vectorised joint mix over whole channel groups; spec: [{out_c, nch, terms: [(mat, transpose, in_c)]}]."""
@@ -196,14 +199,16 @@ def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec
     if out.shape[:3] != inp.shape[:3] or mats.shape[-1] != V or mats.shape[-2] != V or mats.shape[0] not in (1, B):
         raise _lib.FgcnError(f"joint_mix_vec: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} "
                              f"mats={tuple(mats.shape)}")
-    arr = (_lib.MixVItem * len(spec))()
-    for i, it in enumerate(spec):
-        arr[i].out_c, arr[i].nch, arr[i].nterms = it["out_c"], it["nch"], len(it["terms"])
-        for j, (mat, tr, in_c) in enumerate(it["terms"]):
-            arr[i].term[j] = _lib.MixVTerm(mat, tr, in_c)
-    check(_lib.load().fgcn_joint_mix_vec(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], mats.shape[1],
-                                         int(mats.shape[0] != 1), arr, len(spec), vw, int(accumulate), _stream()),
-          "fgcn_joint_mix_vec")
+    for lo in range(0, len(spec), MIX_MAX_ITEMS):   # one launch per FGCN_MIX_MAX_ITEMS items
+        part = spec[lo:lo + MIX_MAX_ITEMS]
+        arr = (_lib.MixVItem * len(part))()
+        for i, it in enumerate(part):
+            arr[i].out_c, arr[i].nch, arr[i].nterms = it["out_c"], it["nch"], len(it["terms"])
+            for j, (mat, tr, in_c) in enumerate(it["terms"]):
+                arr[i].term[j] = _lib.MixVTerm(mat, tr, in_c)
+        check(_lib.load().fgcn_joint_mix_vec(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], mats.shape[1],
+                                             int(mats.shape[0] != 1), arr, len(part), vw, int(accumulate), _stream()),
+              "fgcn_joint_mix_vec")
     return out
 
 

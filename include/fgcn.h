@@ -118,9 +118,10 @@ int fgcn_joint_mix(const float* in, float* out, const float* mats, int B, int T,
                    int ld_in, int ld_out, int in_channels, int out_channels, int n_mats, int mats_batched,
                    const fgcn_mix_item* items, int n_items, int accumulate, void* stream);
 
-/* Vectorised variant for whole channel groups (no 16-lane masks): lane j of a group owns `vw` (2 or 4) consecutive
- * channels, so one item covers up to 32*vw channels with 8/16-byte loads and stores.  Same formula as
- * fgcn_joint_mix; used for the two large mixes of the backward pass (agg recompute and dx). */
+/* Channel-group variant (no 16-lane masks): lane j of a group owns `vw` (1 or 2) consecutive channels, one item
+ * covers up to 32*vw channels with 4/8-byte buffer loads and stores; all items of a call have the same `nch`.
+ * Same formula as fgcn_joint_mix; used for the agg recompute, dx and the embedding gradients of the backward pass.
+ * Both tensors must be smaller than 2 GiB. */
 typedef struct {
     short mat;
     short transpose;

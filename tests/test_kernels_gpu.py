@@ -195,29 +195,36 @@ def test_joint_mix_aggregation_and_its_transpose(V, cin):
     assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
 
 
-@pytest.mark.parametrize("V,cin", [(25, 64), (18, 128), (27, 256), (22, 192)])
-def test_joint_mix_vectorised_groups(V, cin):
-    """The 8/16-byte-per-lane variant used by the backward pass gives the same agg / dx as the einsum."""
-    from fusion_gcn_amd.block import mix_agg, mix_dx
+@pytest.mark.parametrize("order", [(1,), (2, 1)])
+@pytest.mark.parametrize("V,cin", [(25, 64), (18, 128), (27, 256), (22, 192), (25, 4), (20, 32), (32, 64), (5, 8)])
+def test_joint_mix_channel_groups(V, cin, order, monkeypatch):
+    """The channel-group kernel (1 or 2 channels per lane; every k-step template) gives the same agg / dx as the
+    einsum, with and without accumulation, and never writes outside its rows (canary row stride)."""
+    from fusion_gcn_amd import block
+    monkeypatch.setattr(block, "MIX_VW_ORDER", order)
     B, T = 3, 9
     x, a = rnd(B, T, V, cin, seed=70), rnd(B, 3, V, V, seed=71, scale=0.3)
     want = torch.einsum("btvc,bkvw->btwkc", x, a).reshape(B, T, V, 3 * cin)
     agg = torch.full((B, T, V, 3 * cin), 7.0, device=dev())
-    mix_agg(to_gpu(x), agg, to_gpu(a), cin)
+    block.mix_agg(to_gpu(x), agg, to_gpu(a), cin)
     assert rel_l2(agg.cpu().numpy(), want.numpy()) < FWD_TOL
     dagg, base = rnd(B, T, V, 3 * cin, seed=72), rnd(B, T, V, cin, seed=73)
     want_dx = base + torch.einsum("btwkc,bkvw->btvc", dagg.reshape(B, T, V, 3, cin), a)
     dx = to_gpu(base)
-    mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=True)
+    block.mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=True)
     assert rel_l2(dx.cpu().numpy(), want_dx.numpy()) < FWD_TOL
-    mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=False)
+    block.mix_dx(to_gpu(dagg), dx, to_gpu(a), cin, accumulate=False)
     assert rel_l2(dx.cpu().numpy(), (want_dx - base).numpy()) < FWD_TOL
+    # static (shared) adjacency: one set of matrices for the whole batch
+    block.mix_agg(to_gpu(x), agg, to_gpu(a[:1]), cin)
+    want1 = torch.einsum("btvc,kvw->btwkc", x, a[0]).reshape(B, T, V, 3 * cin)
+    assert rel_l2(agg.cpu().numpy(), want1.numpy()) < FWD_TOL
 
 
-@pytest.mark.parametrize("ic", [16, 32, 64])
-def test_joint_mix_embedding_gradient(ic):
-    from fusion_gcn_amd import ops
-    from fusion_gcn_amd.block import spec_demb
+@pytest.mark.parametrize("order", [None, (1,), (2, 1)])
+@pytest.mark.parametrize("ic", [16, 32, 64, 8, 48])
+def test_joint_mix_embedding_gradient(ic, order, monkeypatch):
+    from fusion_gcn_amd import block, ops
     B, T, V = 2, 7, 25
     emb = rnd(B, T, V, 6 * ic, seed=24)
     ds = rnd(B, 3, V, V, seed=25)
@@ -226,8 +233,14 @@ def test_joint_mix_embedding_gradient(ic):
     dtheta = torch.einsum("bkvw,btwke->btvke", ds, phi)
     dphi = torch.einsum("bkvw,btvke->btwke", ds, theta)
     want = torch.stack([dtheta, dphi], dim=4).reshape(B, T, V, 6 * ic)
-    out = torch.empty(B, T, V, 6 * ic, device=dev())
-    ops.joint_mix(to_gpu(emb), out, to_gpu(ds), spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+    out = torch.full((B, T, V, 6 * ic), 3.0, device=dev())
+    if order is None:       # the dword kernel with 16-lane masks (kept for widths the channel-group kernel cannot tile)
+        if ic % 16:
+            pytest.skip("dword-kernel spec needs 16-channel groups")
+        ops.joint_mix(to_gpu(emb), out, to_gpu(ds), block.spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
+    else:
+        monkeypatch.setattr(block, "MIX_VW_ORDER", order)
+        block.mix_demb(to_gpu(emb), out, to_gpu(ds), ic)
     assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
 
 

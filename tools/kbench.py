@@ -65,24 +65,30 @@ def bench_gemm(B, reps):
 
 
 def bench_tconv(B, reps):
-    """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2."""
-    for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
-        Tp = (T - 1) // s + 1
-        wt = rnd(9, c, c) * (9 * c) ** -0.5
-        W = {"t": wt, "t_t": wt.permute(0, 2, 1).contiguous()}
-        if s == 1:
-            W["t4"], W["t_t4"] = ops.pack_k4(wt), ops.pack_k4(wt.permute(0, 2, 1).contiguous())
-        else:
-            for par, tag in ((0, "e"), (1, "o")):
-                W[f"t4_{tag}"] = ops.pack_k4(wt[par::2].contiguous())
-                W[f"t_t4_{tag}"] = ops.pack_k4(wt.permute(0, 2, 1)[par::2].contiguous())
-        g, u, bias = rnd(B, T, V, c), torch.empty(B, Tp, V, c, device=DEV), rnd(c)
-        du, dg = rnd(B, Tp, V, c), torch.empty(B, T, V, c, device=DEV)
-        fl = 2.0 * B * Tp * V * 9 * c * c
-        ms = timeit(lambda: block.temporal_fwd(g, u, W, bias, 9, s, stats=True), reps)
-        report(f"tconv_halo fwd   T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
-        ms = timeit(lambda: block.temporal_dgrad(du, dg, W, 9, s), reps)
-        report(f"tconv_halo dgrad T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
+    """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2; tuning key 4 picks the
+    register budget (2 or 3 workgroups per CU)."""
+    lib = _lib.load()
+    for three in (0, 1):
+        lib.fgcn_set_tuning(4, three)
+        print(f"-- conv_halo, workgroups per CU hint = {2 + three}")
+        for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
+            Tp = (T - 1) // s + 1
+            wt = rnd(9, c, c) * (9 * c) ** -0.5
+            W = {"t": wt, "t_t": wt.permute(0, 2, 1).contiguous()}
+            if s == 1:
+                W["t4"], W["t_t4"] = ops.pack_k4(wt), ops.pack_k4(wt.permute(0, 2, 1).contiguous())
+            else:
+                for par, tag in ((0, "e"), (1, "o")):
+                    W[f"t4_{tag}"] = ops.pack_k4(wt[par::2].contiguous())
+                    W[f"t_t4_{tag}"] = ops.pack_k4(wt.permute(0, 2, 1)[par::2].contiguous())
+            g, u, bias = rnd(B, T, V, c), torch.empty(B, Tp, V, c, device=DEV), rnd(c)
+            du, dg = rnd(B, Tp, V, c), torch.empty(B, T, V, c, device=DEV)
+            fl = 2.0 * B * Tp * V * 9 * c * c
+            ms = timeit(lambda: block.temporal_fwd(g, u, W, bias, 9, s, stats=True), reps)
+            report(f"tconv_halo fwd   T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
+            ms = timeit(lambda: block.temporal_dgrad(du, dg, W, 9, s), reps)
+            report(f"tconv_halo dgrad T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
+    lib.fgcn_set_tuning(4, 0)
 
 
 def bench_wgrad(B, reps):
@@ -120,22 +126,47 @@ def bench_spatial_bwd(B, reps):
 
 
 def bench_joint(B, reps):
+    for order in ((1,), (2, 1)):
+        block.MIX_VW_ORDER = order
+        print(f"-- channel-group mix kernels, channels per lane preference {order}")
+        for T, c in ((300, 64), (150, 128), (75, 256)):
+            ic = c // 4
+            x, a = rnd(B, T, V, c), rnd(B, 3, V, V) * 0.2
+            agg, dx = torch.empty(B, T, V, 3 * c, device=DEV), torch.zeros(B, T, V, c, device=DEV)
+            rows = B * T * V
+            ms = timeit(lambda: block.mix_agg(x, agg, a, c), reps)
+            report(f"mix_agg T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+            ms = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=True), reps)
+            report(f"mix_dx (+=) T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 5 * c)
+            ms = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=False), reps)
+            report(f"mix_dx (=)  T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+            emb, demb = rnd(B, T, V, 6 * ic), torch.empty(B, T, V, 6 * ic, device=DEV)
+            ms = timeit(lambda: block.mix_demb(emb, demb, a, ic), reps)
+            report(f"mix_demb T{T} ic{ic}", ms, 2.0 * rows * V * 6 * ic, 4.0 * rows * 12 * ic)
+    block.MIX_VW_ORDER = (2, 1)
     for T, c in ((300, 64), (150, 128), (75, 256)):
         ic = c // 4
-        x, a = rnd(B, T, V, c), rnd(B, 3, V, V) * 0.2
-        agg, dx = torch.empty(B, T, V, 3 * c, device=DEV), torch.zeros(B, T, V, c, device=DEV)
         rows = B * T * V
-        ms = timeit(lambda: block.mix_agg(x, agg, a, c), reps)
-        report(f"mix_agg T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
-        ms = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=True), reps)
-        report(f"mix_dx  T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 5 * c)
-        emb, demb = rnd(B, T, V, 6 * ic), torch.empty(B, T, V, 6 * ic, device=DEV)
-        ms = timeit(lambda: ops.joint_mix(emb, demb, a, block.spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic), reps)
-        report(f"mix_demb T{T} ic{ic}", ms, 2.0 * rows * V * 6 * ic, 4.0 * rows * 12 * ic)
+        x, agg, emb = rnd(B, T, V, c), rnd(B, T, V, 3 * c), rnd(B, T, V, 6 * ic)
         ms = timeit(lambda: ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(3)]), reps)
         report(f"gram score T{T} ic{ic}", ms, 6.0 * rows * V * ic, 4.0 * rows * 6 * ic)
         ms = timeit(lambda: ops.joint_gram(x, agg, [(0, k * c, c) for k in range(3)]), reps)
         report(f"gram dA^ T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+
+
+def bench_jointdbg(B, reps):
+    """Ablation of the vectorised mix kernel (tuning 3: bit0 no stores, bit1 no MFMA, bit2 no loads)."""
+    lib = _lib.load()
+    T, c = 300, 64
+    x, a = rnd(B, T, V, c), rnd(B, 3, V, V) * 0.2
+    agg, dx = torch.empty(B, T, V, 3 * c, device=DEV), torch.zeros(B, T, V, c, device=DEV)
+    for dbg in (0, 1, 4, 5):
+        lib.fgcn_set_tuning(3, dbg)
+        ms1 = timeit(lambda: block.mix_agg(x, agg, a, c), reps)
+        ms2 = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=True), reps)
+        ms3 = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=False), reps)
+        print(f"dbg={dbg} mix_agg {ms1:.3f}  mix_dx(acc) {ms2:.3f}  mix_dx(noacc) {ms3:.3f}", flush=True)
+    lib.fgcn_set_tuning(3, 0)
 
 
 def bench_elem(B, reps):
@@ -158,7 +189,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_bwd,joint,elem")
     args = ap.parse_args()
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem, jointdbg=bench_jointdbg)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
