@@ -370,7 +370,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     # -- temporal conv -------------------------------------------------------------------------------------------------------
     dg = new(B, T, V, cout)
     temporal_dgrad(du, dg, W, kt, s)
-    gw = ops.rows_wgrad(S["g"], du, K=cout, N=cout, tmap=ops.conv_tmap(kt, s))    # (kt, c, o)
+    gw = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s)                            # (kt, c, o)
     G["tcn1.conv.weight"] = gw.permute(2, 1, 0).unsqueeze(-1)
     G["tcn1.conv.bias"] = _bias_grad(du, cout, train)
 

@@ -29,6 +29,7 @@ struct RowsGemmP {
     int accumulate;
     long long in_elems;  // B * T_in * V * ld_in
     unsigned w_bytes;
+    int tiles_m, tiles_n, per_xcd;  // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
@@ -41,8 +42,20 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     __shared__ __attribute__((aligned(16))) float Bs[NBUF * BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // Consecutive workgroup ids go round-robin over the 8 XCDs: id b takes virtual tile (b % 8) * per_xcd + b / 8, column
+    // tile fastest, so the workgroups that re-read one A row tile run on one XCD (one L2).  Speed only.
+    int bm, bn;
+    if (p.per_xcd > 0) {
+        const int vid = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+        if (vid >= p.tiles_m * p.tiles_n) return;
+        bm = vid / p.tiles_n;
+        bn = vid - bm * p.tiles_n;
+    } else {
+        bm = blockIdx.x;
+        bn = blockIdx.y;
+    }
+    const long long m0 = (long long)bm * BM;
+    const int n0 = bn * BN;
     const int k4 = (tid & 7) * 4;
 
     // All global accesses are buffer instructions with 32-bit offsets relative to a per-workgroup base (no tensor-size
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
                                 red[(which * 4 + 2) * BN + c] + red[(which * 4 + 3) * BN + c];
                 // the partials buffer has one row per 128 output rows: a 256-row tile fills the first of its two
                 // rows and zeroes the second
-                const long long prow = (long long)blockIdx.x * MT;
+                const long long prow = (long long)bm * MT;
                 p.stats[(prow * 2 + which) * p.N + col] = t;
                 if (MT == 2 && (prow + 1) * 128 < p.M) p.stats[((prow + 1) * 2 + which) * p.N + col] = 0.f;
             }
@@ -222,6 +235,7 @@ struct WgradP {
     int T_a, T_g, V, K, N, ld_a, ld_g;
     int taps, ta, tb, tc, td;
     int tilesN;
+    int tiles, nsplit, per_xcd;   // per_xcd > 0: 1-D grid, XCD-aware order (see the kernel)
 };
 
 __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
@@ -231,9 +245,24 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;
-    const int tk = blockIdx.x / p.tilesN, tn = blockIdx.x - tk * p.tilesN;
-    const int tap = blockIdx.y;
-    const int split = blockIdx.z;
+    // Workgroups that read the same rows (the taps and K/N tiles of one row split) should share an L2: consecutive
+    // workgroup ids go round-robin over the 8 XCDs, so id b works on virtual id (b % 8) * per_xcd + b / 8 and each XCD
+    // walks a contiguous range of (split, tap, tile) with the split slowest.  Speed only: any placement is correct.
+    int tile, tap, split;
+    if (p.per_xcd > 0) {
+        const int b = blockIdx.x;
+        const int vid = (b & 7) * p.per_xcd + (b >> 3);
+        if (vid >= p.tiles * p.taps * p.nsplit) return;
+        split = vid / (p.tiles * p.taps);
+        const int inner = vid - split * (p.tiles * p.taps);
+        tap = inner / p.tiles;
+        tile = inner - tap * p.tiles;
+    } else {
+        tile = blockIdx.x;
+        tap = blockIdx.y;
+        split = blockIdx.z;
+    }
+    const int tk = tile / p.tilesN, tn = tile - tk * p.tilesN;
     const long long mbeg = (long long)split * p.rows_per_split;
     long long mend = mbeg + p.rows_per_split;
     if (mend > p.M) mend = p.M;
@@ -391,7 +420,7 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     if (int e = check_tmap(map)) return e;
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
                 map.taps, map.ta, map.tb, map.tc, map.td, accumulate,
-                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4)};
+                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;
@@ -409,7 +438,14 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     const bool db = nt <= 2 ? tune_small == 2 : tune_wide == 1;
     const long long tiles_m = cdiv(p.M, 128 * mt);
     FGCN_REQUIRE(p.M < (1ll << 31) - 4096, FGCN_E_BADARG, "rows_gemm: too many rows (32-bit row indices)");
-    dim3 grid((unsigned)tiles_m, (unsigned)cdiv(N, 32 * nt));
+    p.tiles_m = (int)tiles_m;
+    p.tiles_n = (int)cdiv(N, 32 * nt);
+    const long long total = tiles_m * p.tiles_n;
+    dim3 grid((unsigned)tiles_m, (unsigned)p.tiles_n);
+    if ((fgcn::tuning(5) & 1) && p.tiles_n > 1 && total < (1ll << 30)) {   // measured slower than the plain 2-D grid: off
+        p.per_xcd = (int)cdiv(total, 8);
+        grid = dim3((unsigned)(p.per_xcd * 8));
+    }
 #define FGCN_LAUNCH(MT_, NT_, DB_) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_>), grid, dim3(256), 0, s, p)
     if (mt == 2) {
         if (nt == 1) { if (db) FGCN_LAUNCH(2, 1, true); else FGCN_LAUNCH(2, 1, false); }
@@ -450,8 +486,17 @@ extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
     p.T_a = T_a; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
     p.taps = map.taps; p.ta = map.ta; p.tb = map.tb; p.tc = map.tc; p.td = map.td;
     p.tilesN = (int)cdiv(N, 64);
-    dim3 grid((unsigned)(cdiv(K, 64) * p.tilesN), (unsigned)map.taps, (unsigned)nsplit);
-    hipLaunchKernelGGL(rows_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    p.tiles = (int)cdiv(K, 64) * p.tilesN;
+    p.nsplit = nsplit;
+    const long long total = (long long)p.tiles * map.taps * nsplit;
+    if (!(fgcn::tuning(5) & 4) && total < (1ll << 30)) {   // measured: -7 % at 64 channels, neutral above
+        p.per_xcd = (int)cdiv(total, 8);
+        hipLaunchKernelGGL(rows_wgrad_kernel, dim3((unsigned)(p.per_xcd * 8)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        p.per_xcd = 0;
+        dim3 grid((unsigned)p.tiles, (unsigned)map.taps, (unsigned)nsplit);
+        hipLaunchKernelGGL(rows_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     return launch_status("rows_wgrad");
 }
 

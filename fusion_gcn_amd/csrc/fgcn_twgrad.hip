@@ -1,0 +1,193 @@
+// Weight gradient of the (taps x 1) temporal convolution, all taps in one pass:
+//     dW[j][k][n] = sum_{sample, t, v} a[(t + shift_j, v), k] * g[(t, v), n]          (agcn.py:41-51, backward of conv)
+// The per-tap kernel (rows_wgrad) re-reads a and g once per tap and tile: 16 FLOP per byte fetched from L2, one
+// dependent MFMA chain per wave, two barriers per 32 MFMAs.  Here a workgroup owns a (32 in-channel x TN out-channel)
+// tile of ALL taps:
+//   * rows are walked in stages of 64 (TN = 128) or 128 (TN = 64) consecutive rows of ONE sample; the stage's rows of g
+//     and the window of a they touch over all taps (stage + (taps-1) V rows x 32 channels) are staged once in LDS (LDS-DMA); rows of the window
+//     outside the sample are zeros, so no per-(row, tap) masks are needed (a stage never straddles two samples);
+//   * every MFMA k-step (2 rows) reads ONE g fragment and one a fragment per tap: taps independent accumulators
+//     (9 x 16 registers), ~1.1 LDS dwords per MFMA, 288 MFMAs between barriers at 9 taps;
+//   * strided convolutions are two calls over the even / odd frames of a (`a_s`, `a_o`: frame view), each tap lands
+//     in its own slab (`tap0`, `tap_step`), so no structurally-zero taps are computed.
+// Output: deterministic partial slabs [nslab][taps_total][K][N], summed by reduce_sum.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+
+struct TWgradP {
+    const float* a;
+    const float* g;
+    float* partial;
+    int B, T_g, V, K, N, ld_a, ld_g;
+    int T_a_full, a_s, a_o, Th_a;
+    int shift0, tap0, tap_step, taps_total;
+    int stages_per_sample, total_stages, stages_per_split;
+    int tiles_n, win_rows, stage_rows;
+    unsigned a_bytes, g_bytes, p_bytes;
+};
+
+// TN = out-channel tile (64: waves = 2 column tiles x 2 row halves of the stage, 128: 4 column tiles).
+// Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`: one wave instruction drops 1 KiB = 8 window rows x 32 channels, or
+// 1024/TN g rows, straight into LDS; rows / channels that do not exist are out-of-range buffer reads = zeros): no
+// staging registers, which is what lets 9 x 16 accumulator registers and two workgroups per CU coexist.
+template <int NTAP, int TN>
+__global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
+    constexpr int TW_BR = 8192 / TN;                  // rows per stage: 64 (TN 128) or 128 (TN 64), 32 KiB of g
+    constexpr int NSUB = TN / 32, NPART = 4 / NSUB;   // column tiles, row parts of a stage
+    constexpr int STEPS = TW_BR / 2 / NPART;          // MFMA k-steps per wave and stage
+    constexpr int GROWS = 256 / TN;                   // g rows per LDS-DMA piece (64 lanes x 4 floats)
+    constexpr int GPIECES = TW_BR / GROWS;
+    constexpr unsigned OOB = 0x80000000u;
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int apieces = (p.win_rows + 7) >> 3;
+    float* Aw = smem;                                 // [apieces * 8][32]
+    float* Gs = smem + apieces * 256;                 // [TW_BR][TN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
+    const int k0 = tk * 32, n0 = tn * TN;
+    const int nsub = wave % NSUB, part = wave / NSUB;
+    const int V = p.V, TVg = p.T_g * V;
+    const int sbeg = blockIdx.y * p.stages_per_split;
+    const int send = min(sbeg + p.stages_per_split, p.total_stages);
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+
+    // per-lane part of the source addresses of a piece: a: row lane/8, channels (lane%8)*4;  g: row lane/(TN/4)
+    const int a_lr = lane >> 3, akc = k0 + (lane & 7) * 4;
+    const bool a_cok = akc < p.K;
+    const int g_lr = lane / (TN / 4), gnc = n0 + (lane % (TN / 4)) * 4;
+    const bool g_cok = gnc < p.N;
+    const bool strided = p.a_s != 1 || p.a_o != 0;
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) acc[j] = zero16();
+
+    // fragment bases: window row of g-row r and tap j is r + j*V; this wave's rows start at part * 2 * STEPS
+    const float* abase = Aw + (part * STEPS * 2 + h) * 32 + l31;
+    const float* gbase = Gs + (part * STEPS * 2 + h) * TN + nsub * 32 + l31;
+    const int tapstride = V * 32;
+
+    for (int sid = sbeg; sid < send; ++sid) {
+        const int n = sid / p.stages_per_sample;
+        const int r0 = (sid - n * p.stages_per_sample) * TW_BR;      // first g row of the stage inside the sample
+        __syncthreads();                                             // previous stage's fragment reads are done
+        for (int pc = wave; pc < apieces; pc += 4) {
+            const int wr = pc * 8 + a_lr;
+            const int q = r0 + p.shift0 * V + wr;                    // row of the frame view inside the sample
+            const bool ok = a_cok && wr < p.win_rows && q >= 0 && q < p.Th_a * V;
+            int row = ok ? q : 0;
+            if (strided) {                                           // wave-uniform: even / odd frames of a
+                const int f = (int)((unsigned)row / (unsigned)V);
+                row = (f * p.a_s + p.a_o) * V + (row - f * V);
+            }
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + akc) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(Aw + pc * 256), 16, off, 0, 0, 0);
+        }
+        for (int pc = wave; pc < GPIECES; pc += 4) {
+            const int r = r0 + pc * GROWS + g_lr;
+            const unsigned off = (g_cok && r < TVg) ? (unsigned)((n * TVg + r) * p.ld_g + gnc) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr)(Gs + pc * 256), 16, off, 0, 0, 0);
+        }
+        __syncthreads();                                             // drains the DMA (vmcnt(0)) and publishes the stage
+        // ---- NTAP independent MFMA chains over this wave's rows of the stage ----------------------------------------
+#pragma unroll 4
+        for (int s = 0; s < STEPS; ++s) {
+            const float gv = gbase[2 * s * TN];
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j) acc[j] = mfma32(abase[2 * s * 32 + j * tapstride], gv, acc[j]);
+        }
+    }
+
+    // ---- partial slabs: [slab = split * NPART + part][tap][k][n] ------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+    const int slab = blockIdx.y * NPART + part;
+    const int ncol = n0 + nsub * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int tap = p.tap0 + j * p.tap_step;
+        const unsigned base = (unsigned)((slab * p.taps_total + tap) * p.K) * (unsigned)p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + acc_row(r, lane);
+            const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
+            const float val = acc[j][r];   // (bit_cast straight from a vector element stores element 0: go through a scalar)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
+        }
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+static int twgrad_parts(int N) { return N <= 64 ? 2 : 1; }
+
+extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N); }
+
+template <int NTAP>
+static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
+    static bool opt_in = false;   // once per instantiation; not a stream operation (stays out of graph captures)
+    if (!opt_in) {
+        const int max_lds = ((128 + 8 * 32) * 32 + 8192) * (int)sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        opt_in = true;
+    }
+    if (N <= 64) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128>), grid, dim3(256), lds, s, p);
+}
+
+extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                                int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
+                                int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit,
+                                void* stream) {
+    FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "tconv_wgrad: null pointer");
+    FGCN_REQUIRE(B > 0 && T_g > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0 && nsplit > 0 && nsplit <= 65535,
+                 FGCN_E_BADARG, "tconv_wgrad: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", B, T_g, V, K, N, nsplit);
+    FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_a % 4 == 0 && ld_g % 4 == 0 && ld_a >= K && ld_g >= N, FGCN_E_ALIGN,
+                 "tconv_wgrad: K, N and the row strides must be multiples of 4 (K=%d N=%d ld_a=%d ld_g=%d)", K, N, ld_a, ld_g);
+    FGCN_REQUIRE(aligned16(a) && aligned16(g), FGCN_E_ALIGN, "tconv_wgrad: 16-byte alignment");
+    FGCN_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_step >= 1 && tap0 >= 0 && tap0 + (ntaps - 1) * tap_step < taps_total,
+                 FGCN_E_BADARG, "tconv_wgrad: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
+    FGCN_REQUIRE(a_s >= 1 && a_o >= 0 && Th_a > 0 && (long long)(Th_a - 1) * a_s + a_o < T_a_full, FGCN_E_BADARG,
+                 "tconv_wgrad: frame view exceeds the tensor");
+    const long long a_bytes = (long long)B * T_a_full * V * ld_a * 4, g_bytes = (long long)B * T_g * V * ld_g * 4;
+    const int parts = twgrad_parts(N);
+    const long long p_bytes = (long long)nsplit * parts * taps_total * K * N * 4;
+    FGCN_REQUIRE(a_bytes < 0x7FFF0000ll && g_bytes < 0x7FFF0000ll && p_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "tconv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    TWgradP p;
+    p.a = a; p.g = g; p.partial = partial;
+    p.B = B; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
+    p.T_a_full = T_a_full; p.a_s = a_s; p.a_o = a_o; p.Th_a = Th_a;
+    p.shift0 = shift0; p.tap0 = tap0; p.tap_step = tap_step; p.taps_total = taps_total;
+    p.stage_rows = N <= 64 ? 128 : 64;
+    p.stages_per_sample = (int)cdiv((long long)T_g * V, p.stage_rows);
+    p.total_stages = B * p.stages_per_sample;
+    p.stages_per_split = (int)cdiv(p.total_stages, nsplit);
+    p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
+    p.win_rows = p.stage_rows + (ntaps - 1) * V;
+    p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
+    const size_t lds = (size_t)(((p.win_rows + 7) / 8) * 256 + 8192) * sizeof(float);
+    dim3 grid((unsigned)(cdiv(K, 32) * p.tiles_n), (unsigned)nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    switch (ntaps) {
+        case 9: launch_twgrad<9>(p, N, grid, lds, s); break;
+        case 5: launch_twgrad<5>(p, N, grid, lds, s); break;
+        case 4: launch_twgrad<4>(p, N, grid, lds, s); break;
+        case 3: launch_twgrad<3>(p, N, grid, lds, s); break;
+        case 2: launch_twgrad<2>(p, N, grid, lds, s); break;
+        case 1: launch_twgrad<1>(p, N, grid, lds, s); break;
+        default: return fgcn::fail(FGCN_E_BADARG, "tconv_wgrad: %d taps per call not instantiated (1-5, 9)", ntaps);
+    }
+    return launch_status("tconv_wgrad");
+}

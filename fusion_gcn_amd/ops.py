@@ -136,6 +136,48 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
     return out
 
 
+TWGRAD_TAPS = (1, 2, 3, 4, 5, 9)   # taps per call the multi-tap kernel is instantiated for
+
+
+def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1, out: Optional[torch.Tensor] = None,
+                accumulate: bool = False, all_taps: Optional[bool] = None) -> torch.Tensor:
+    """(taps, K, N) weight gradient of the (taps x 1) temporal convolution with stride ``stride`` and padding
+    (taps-1)//2: all taps in one pass over the rows (one call per residue class of the tap offset when strided).
+    a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` None picks the measured
+    faster kernel: the multi-tap pass for stride 1 (119-124 vs 106 TFLOP/s at 128/256 channels), the per-tap kernel
+    for strided convolutions (4-5 taps per pass amortise the staging less: 93-97 vs 107)."""
+    ensure_device()
+    _chk(a, "tconv_wgrad.a"), _chk(g, "tconv_wgrad.g")
+    B, T_a, V, K = a.shape
+    Bg, T_g, Vg, N = g.shape
+    pad = (taps - 1) // 2
+    if (Bg, Vg) != (B, V) or T_g != (T_a - 1) // stride + 1:
+        raise _lib.FgcnError(f"tconv_wgrad: shape mismatch a={tuple(a.shape)} g={tuple(g.shape)} stride={stride}")
+    calls = []
+    for par in range(stride):                       # taps j with (j - pad) % stride == par read frames of parity par
+        js = [j for j in range(taps) if (j - pad) % stride == par]
+        if js:
+            calls.append((par, js[0], len(js), (js[0] - pad - par) // stride))
+    if all_taps is None:
+        all_taps = stride == 1
+    if not all_taps or any(n not in TWGRAD_TAPS for _, _, n, _ in calls):
+        return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate)
+    lib = _lib.load()
+    tiles = ((K + 31) // 32) * ((N + 127) // 128 if N > 64 else 1)
+    stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
+    nsplit = max(1, min(1024 // max(tiles, 1), stages))
+    slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
+    partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
+    for par, tap0, ntaps, shift0 in calls:
+        th_a = (T_a - par + stride - 1) // stride
+        check(lib.fgcn_tconv_wgrad(_p(a), _p(g), _p(partial), B, T_g, V, K, N, K, N, T_a, stride, par, th_a,
+                                   ntaps, shift0, tap0, stride, taps, nsplit, _stream()), "fgcn_tconv_wgrad")
+    if out is None:
+        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
+    reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
+    return out
+
+
 def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
     """dst[i] (+)= sum_s src[s, i]."""
     ensure_device()

@@ -85,6 +85,19 @@ int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
                     int B, int T_a, int T_g, int V, int K, int N, int ld_a, int ld_g,
                     fgcn_tmap map, int nsplit, void* stream);
 
+/* Weight gradient of the (taps x 1) temporal convolution, all taps of one call in a single pass over the rows
+ * (backward of agcn.py:41-51 w.r.t. conv.weight):
+ *     partial[slab][tap0 + i*tap_step][k][n] = sum over the slab's rows (b, t, v) of
+ *                                              a[(b, (t + shift0 + i)*a_s + a_o, v), k] * g[(b, t, v), n],  i < ntaps
+ *   a: float[B][T_a_full][V][ld_a] seen through the frame view f -> f*a_s + a_o (Th_a frames; frames outside the view
+ *   contribute zeros), g: float[B][T_g][V][ld_g].  A stride-s convolution is s calls (one per residue of the tap offset).
+ *   partial: float[fgcn_tconv_wgrad_slabs(N, nsplit)][taps_total][K][N]; every slab of the taps of this call is written;
+ *   the caller sums the slabs (fgcn_reduce_sum).  ntaps in {1..5, 9}; K, N, ld_a, ld_g multiples of 4; tensors < 2 GiB. */
+int fgcn_tconv_wgrad_slabs(int N, int nsplit);
+int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                     int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
+                     int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
+
 /* dst[i] (+)= sum_s src[s*count + i]   (deterministic tree-free column sum; also bias / adj_b gradients) */
 int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream);
 

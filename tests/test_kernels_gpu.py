@@ -100,6 +100,37 @@ def test_rows_gemm_data_gradient_map(kt, s, T):
     assert rel_l2(dx.cpu().numpy(), dx_want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("B,T,V,K,N,kt,s", [
+    (3, 20, 25, 64, 64, 9, 1),      # two row halves per stage (N <= 64), 9 taps
+    (2, 21, 25, 64, 128, 9, 2),     # stride 2, odd T: even frames 5 taps + odd frames 4 taps
+    (2, 20, 27, 128, 128, 9, 2),    # stride 2, even T, V = 27 (largest window)
+    (2, 13, 18, 128, 256, 9, 1),    # two 128-column tiles
+    (1, 2, 25, 32, 96, 9, 1),       # a sample shorter than one stage, N tail inside a 128 tile
+    (2, 9, 20, 40, 36, 3, 1),       # ragged K / N, 3 taps
+    (2, 7, 32, 64, 64, 5, 1),       # V = 32, 5 taps
+    (3, 40, 25, 256, 256, 9, 1),    # 256 channels
+    (2, 11, 25, 64, 64, 7, 1),      # 7 taps: not instantiated -> falls back to the per-tap kernel
+])
+def test_tconv_wgrad_all_taps_in_one_pass(B, T, V, K, N, kt, s):
+    """The multi-tap temporal weight gradient equals autograd's conv weight gradient (and the per-tap kernel)."""
+    from fusion_gcn_amd import ops
+    T_out = (T - 1) // s + 1
+    x = rnd(B, T, V, K, seed=31)
+    w = rnd(kt, K, N, seed=32, scale=0.1).requires_grad_(True)
+    dy = rnd(B, T_out, V, N, seed=33)
+    y = ref_rows_conv(x, w, ops.conv_tmap(kt, s), T_out)
+    (dw_want,) = torch.autograd.grad((y * dy).sum(), w)
+    got = ops.tconv_wgrad(to_gpu(x), to_gpu(dy), taps=kt, stride=s, all_taps=True)
+    assert rel_l2(got.cpu().numpy(), dw_want.numpy()) < RED_TOL
+    ref = ops.rows_wgrad(to_gpu(x), to_gpu(dy), K=K, N=N, tmap=ops.conv_tmap(kt, s))
+    assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < RED_TOL
+    again = ops.tconv_wgrad(to_gpu(x), to_gpu(dy), taps=kt, stride=s, all_taps=True)
+    assert torch.equal(got, again)          # fixed-order slabs: bitwise reproducible
+    acc = got.clone()
+    ops.tconv_wgrad(to_gpu(x), to_gpu(dy), taps=kt, stride=s, out=acc, accumulate=True, all_taps=True)
+    assert rel_l2(acc.cpu().numpy(), 2 * dw_want.numpy()) < RED_TOL
+
+
 @pytest.mark.parametrize("B,T,V,C,O,s", [(3, 20, 25, 64, 64, 1), (2, 21, 25, 64, 128, 2), (2, 20, 27, 128, 128, 2),
                                          (2, 13, 18, 128, 256, 1), (3, 7, 32, 32, 96, 1), (2, 1, 25, 64, 64, 2),
                                          (1, 40, 25, 256, 256, 1), (2, 9, 20, 64, 64, 2)])

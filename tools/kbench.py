@@ -3,7 +3,7 @@
 family with HIP events on torch's current stream and prints ms, TFLOP/s (algorithmic) and GB/s (algorithmic).
 Used to A/B kernel variants (fgcn_set_tuning) in one process on one device.
 
-    python tools/kbench.py [--b 128] [--reps 10] [--only gemm,wgrad,spatial,joint,elem]
+    python tools/kbench.py [--b 128] [--reps 10] [--only gemm,wgrad,spatial,joint,elem] [--tune 5=1]
 """
 import argparse
 import os
@@ -45,7 +45,7 @@ def bench_gemm(B, reps):
              ("emb 1x1", 300, 300, 64, 96, 1, 1), ("emb 1x1", 150, 150, 128, 192, 1, 1),
              ("emb 1x1", 75, 75, 256, 384, 1, 1), ("dagg 1x1", 300, 300, 64, 192, 1, 1),
              ("dagg 1x1", 75, 75, 256, 768, 1, 1), ("down 1x1", 300, 300, 64, 128, 1, 1)]
-    for k0, k1 in ((0, 0), (1, 0), (2, 1)):
+    for k0, k1 in ((1, 0),):
         lib.fgcn_set_tuning(0, k0)
         lib.fgcn_set_tuning(1, k1)
         print(f"-- rows_gemm, tuning small={k0} wide={k1}")
@@ -70,7 +70,7 @@ def bench_tconv(B, reps):
     lib = _lib.load()
     for three in (0, 1):
         lib.fgcn_set_tuning(4, three)
-        print(f"-- conv_halo, workgroups per CU hint = {2 + three}")
+        print(f"-- conv_halo, workgroups per CU hint = {3 - three}")
         for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
             Tp = (T - 1) // s + 1
             wt = rnd(9, c, c) * (9 * c) ** -0.5
@@ -93,6 +93,7 @@ def bench_tconv(B, reps):
 
 def bench_wgrad(B, reps):
     cases = [("tconv", 300, 300, 64, 64, 9, 1), ("tconv", 150, 150, 128, 128, 9, 1), ("tconv", 75, 75, 256, 256, 9, 1),
+             ("tconv s2", 300, 150, 128, 128, 9, 2), ("tconv s2", 150, 75, 256, 256, 9, 2),
              ("conv_d", 300, 300, 192, 64, 1, 1), ("conv_d", 75, 75, 768, 256, 1, 1), ("emb", 300, 300, 64, 96, 1, 1),
              ("emb", 75, 75, 256, 384, 1, 1)]
     for name, ta, tg, K, N, kt, s in cases:
@@ -100,6 +101,10 @@ def bench_wgrad(B, reps):
         tm = ops.conv_tmap(kt, s)
         ms = timeit(lambda: ops.rows_wgrad(a, g, K=K, N=N, tmap=tm), reps)
         report(f"rows_wgrad {name} T{ta} K{kt}x{K} N{N}", ms, 2.0 * B * tg * V * kt * K * N, 4.0 * B * V * (ta * K + tg * N))
+        if kt > 1:
+            ms = timeit(lambda: ops.tconv_wgrad(a, g, taps=kt, stride=s, all_taps=True), reps)
+            report(f"tconv_wgrad {name} T{ta} K{kt}x{K} N{N} (all taps)", ms, 2.0 * B * tg * V * kt * K * N,
+                   4.0 * B * V * (ta * K + tg * N))
 
 
 def bench_spatial(B, reps):
@@ -188,7 +193,12 @@ def main():
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_bwd,joint,elem")
+    ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     args = ap.parse_args()
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        _lib.load().fgcn_set_tuning(int(k), int(v))
+        print(f"-- tuning {k} = {v}")
     fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem, jointdbg=bench_jointdbg)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
