@@ -6,10 +6,11 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one train-mode forward + backward (CrossEntropy, gradients for all 3.47 M parameters) of the
-10-block AGCN (fusion_gcn_amd.models.mmargcn.agcn.Model, NTU-RGB-D graph, 60 classes) over the GLOBAL batch of
-64 synthetic clips, already resident in HBM; with N > 1 the batch is sharded over the ranks (8 clips per GPU at
-N = 8: strong scaling, per-replica BatchNorm) and the step includes the single RCCL all-reduce of the flat
-gradient buffer.  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
+10-block AGCN (fusion_gcn_amd.models.mmargcn.agcn.Model, NTU-RGB-D graph, 60 classes) over synthetic clips already
+resident in HBM.  Data parallel: every rank holds the headline shape, 64 clips (weak scaling: the global batch is
+64 x N, per-replica BatchNorm as in the reference's DataParallel), and the step includes the single RCCL all-reduce
+of the flat 13.9 MB gradient buffer; `--scaling strong` instead shards ONE 64-clip batch over the ranks (8 clips per
+GPU at N = 8).  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
   roofline      the dominant kernel (halo-tile 9x1 temporal conv on the f32 MFMA), timed live with HIP events on
@@ -150,12 +151,28 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def measured_traffic(dom, samples):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 correction of MI355X_MICROARCH.md applied: FETCH_SIZE counts 16-byte-per-lane
+    reads at half their bytes).  Only valid for the shape it was collected at; None otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            rec = json.load(f)["conv_halo_fwd"]
+    except (OSError, KeyError, ValueError):
+        return None
+    if rec["channels"] != dom["channels"] or rec["frames"] != dom["frames"] or rec["samples"] != samples:
+        return None
+    return rec["traffic_bytes"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=SHAPE["N"], help="GLOBAL clip batch (sharded over ranks)")
+    ap.add_argument("--batch", type=int, default=SHAPE["N"], help="clips per GPU (weak) / global clip batch (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -180,7 +197,7 @@ def main():
     broadcast_parameters(model)
     grads = FlatGradients(model.parameters())
 
-    n_global = args.batch
+    n_global = args.batch * world if args.scaling == "weak" else args.batch
     shard = shard_batch(n_global, rank, world)
     g = torch.Generator().manual_seed(1)
     x_all = torch.randn(n_global, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"], generator=g)
@@ -261,7 +278,7 @@ def main():
             "metric": "clips/sec (N,C,T,V,M)=(64,3,300,25,2) fwd+bwd",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
                                    "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
                                    % n_global,
@@ -277,7 +294,7 @@ def main():
             dom = max(kern, key=lambda k: k["ms"])
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                               "traffic": None,
+                               "traffic": measured_traffic(dom, (shard.stop - shard.start) * SHAPE["M"]),
                                "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4}> (9x1 temporal conv forward, "
                                          f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),

@@ -10,16 +10,32 @@ constexpr int ELEM_ROWS_PER_TILE = 64;    // small tiles keep >= 8 workgroups pe
 constexpr int ELEM_MAX_TILES = 2048;
 
 // ---- BatchNorm finalize ------------------------------------------------------------------------------------
-// block = 32 channels x 32 partial-groups; double accumulation of the float tile sums, fixed summation order.
+// block = 8 channels x 128 partial-groups (C/8 workgroups, 4 loads in flight per thread: the 7500-tile partial arrays
+// of the headline shape were a 48 us serial walk with 32 groups on C/32 workgroups); double accumulation of the float
+// tile sums, fixed summation order.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials, int P, long long count,
                                                            const float* gamma, const float* beta, float* rmean,
                                                            float* rvar, float momentum, float eps, float* out, int C) {
-    __shared__ double s1[32][33], s2[32][33];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double s1[128][9], s2[128][9];
+    const int cl = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int i = g; i < P; i += 32) {
+        int i = g;
+        for (; i + 384 < P; i += 512) {
+            float x0[4], x1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x0[u] = partials[((long long)(i + 128 * u) * 2 + 0) * C + c];
+                x1[u] = partials[((long long)(i + 128 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a += (double)x0[u];
+                b += (double)x1[u];
+            }
+        }
+        for (; i < P; i += 128) {
             a += (double)partials[((long long)i * 2 + 0) * C + c];
             b += (double)partials[((long long)i * 2 + 1) * C + c];
         }
@@ -28,7 +44,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
     s2[g][cl] = b;
     __syncthreads();
     if (g == 0 && c < C) {
-        for (int i = 1; i < 32; ++i) {
+        for (int i = 1; i < 128; ++i) {
             a += s1[i][cl];
             b += s2[i][cl];
         }
@@ -216,7 +232,7 @@ extern "C" int fgcn_bn_finalize(const float* partials, int n_partials, long long
                                 float* out_vec, int C, void* stream) {
     FGCN_REQUIRE(partials && gamma && beta && out_vec && n_partials > 0 && count > 0 && C > 0, FGCN_E_BADARG,
                  "bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 8)), dim3(1024), 0, (hipStream_t)stream, partials,
                        n_partials, count, gamma, beta, running_mean, running_var, momentum, eps, out_vec, C);
     return launch_status("bn_finalize");
 }

@@ -215,7 +215,7 @@ struct GramP {
     const float* in1;
     const float* in2;
     float* partial;
-    int B, T, V, ld1, ld2, t_chunk, n_items;
+    int B, T, V, ld1, ld2, t_chunk, n_items, share1;
     unsigned in1_bytes, in2_bytes;
     struct Item {  // dword fields: read with scalar loads (the 16-bit ABI fields went through vector memory + vmcnt(0))
         int c1, c2, width, mat;
@@ -236,7 +236,7 @@ __device__ __forceinline__ f32x4 load4_masked(const float* p, int c, int width, 
     return v;
 }
 
-__global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
+__global__ __launch_bounds__(256, 3) void joint_gram_kernel(GramP p) {
     __shared__ float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -247,9 +247,8 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
     const bool row_ok = l31 < V;
     const int vv = row_ok ? l31 : 0;
 
-    // Branch-free buffer loads (absent joints / channels read as zeros through an out-of-range offset); the 8 loads of
-    // the next 32-channel group (next group of the item, next item, or this wave's next frame) are in flight while the
-    // 16 MFMAs of the current group run.  Widths are multiples of 4 (host check).
+    // Branch-free buffer loads (absent joints / channels read as zeros through an out-of-range offset).  Widths are
+    // multiples of 4 (host check).
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.in1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, p.in2_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
@@ -263,45 +262,63 @@ __global__ __launch_bounds__(256) void joint_gram_kernel(GramP p) {
         ic2[i] = __builtin_amdgcn_readfirstlane(have ? p.items[i].c2 : 0);
         iw[i] = __builtin_amdgcn_readfirstlane(have ? p.items[i].width : 0);
     }
-    auto issue = [&](int t, int it, int q0, f32x4 (&a)[4], f32x4 (&b)[4]) {
-        const bool ok = row_ok && t < t1 && it < p.n_items;
+    // No software prefetch: the kernel is HBM-bound and 4-5 waves per SIMD (about 100 VGPRs) hide the load latency better
+    // than a second set of 32 staging registers at 2 waves per SIMD did (3.3 TB/s).  When every item contracts the same
+    // channels of in1 (dA^_k = x^T dagg_k: x is shared by the three subsets) its fragments are loaded once per group.
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};
+    const bool share1 = p.share1 != 0;
+    auto load1 = [&](int t, int it, int q0, f32x4 (&a)[4]) {
         const int c1 = it == 0 ? ic1[0] : (it == 1 ? ic1[1] : ic1[2]);
+        const int width = it == 0 ? iw[0] : (it == 1 ? iw[1] : iw[2]);
+        const unsigned o1 = ((unsigned)((n * p.T + t) * V + vv) * (unsigned)p.ld1 + c1 + 4 * h) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 r1, (row_ok && 8 * (q0 + j) + 4 * h < width) ? o1 + 32u * (q0 + j) : OOB, 0, 0));
+    };
+    auto load2 = [&](int t, int it, int q0, f32x4 (&b)[4]) {
         const int c2 = it == 0 ? ic2[0] : (it == 1 ? ic2[1] : ic2[2]);
         const int width = it == 0 ? iw[0] : (it == 1 ? iw[1] : iw[2]);
-        const unsigned row = (unsigned)((n * p.T + (t < t1 ? t : t0)) * V + vv);
-        const unsigned o1 = (row * (unsigned)p.ld1 + c1 + 4 * h) * 4u, o2 = (row * (unsigned)p.ld2 + c2 + 4 * h) * 4u;
+        const unsigned o2 = ((unsigned)((n * p.T + t) * V + vv) * (unsigned)p.ld2 + c2 + 4 * h) * 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 8 * (q0 + j) + 4 * h;          // lane half h contracts channels 8q + 4h + e on both operands
-            const bool cok = ok && c < width;
-            a[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, cok ? o1 + 32u * (q0 + j) : OOB, 0, 0));
-            b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, cok ? o2 + 32u * (q0 + j) : OOB, 0, 0));
-        }
+        for (int j = 0; j < 4; ++j)
+            b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 r2, (row_ok && 8 * (q0 + j) + 4 * h < width) ? o2 + 32u * (q0 + j) : OOB, 0, 0));
     };
-
-    f32x16 acc[3] = {zero16(), zero16(), zero16()};
-    f32x4 ac[4], bc[4], an[4], bn[4];
-    issue(t0 + wave, 0, 0, ac, bc);
+    const int nq0 = (iw[0] + 7) >> 3;
     for (int t = t0 + wave; t < t1; t += 4) {
+        if (share1) {
+            for (int q0 = 0; q0 < nq0; q0 += 4) {
+                f32x4 ac[4];
+                load1(t, 0, q0, ac);
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            if (it < p.n_items) {
-                const int nq = (iw[it] + 7) >> 3;
-                for (int q0 = 0; q0 < nq; q0 += 4) {
-                    if (q0 + 4 < nq) issue(t, it, q0 + 4, an, bn);
-                    else if (it + 1 < p.n_items) issue(t, it + 1, 0, an, bn);
-                    else issue(t + 4, 0, 0, an, bn);
+                for (int it = 0; it < 3; ++it) {
+                    if (it < p.n_items) {
+                        f32x4 bc[4];
+                        load2(t, it, q0, bc);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (q0 + j < nq) {   // wave-uniform
+                        for (int j = 0; j < 4; ++j)   // groups past the width multiply zeros
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[it] = mfma32(ac[j][e], bc[j][e], acc[it]);
-                        }
                     }
+                }
+            }
+        } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ac[j] = an[j];
-                        bc[j] = bn[j];
+            for (int it = 0; it < 3; ++it) {
+                if (it < p.n_items) {
+                    const int nq = (iw[it] + 7) >> 3;
+                    for (int q0 = 0; q0 < nq; q0 += 4) {
+                        f32x4 ac[4], bc[4];
+                        load1(t, it, q0, ac);
+                        load2(t, it, q0, bc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (q0 + j < nq) {   // wave-uniform (narrow embeddings: 16 channels = 2 groups)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[it] = mfma32(ac[j][e], bc[j][e], acc[it]);
+                            }
+                        }
                     }
                 }
             }
@@ -448,6 +465,9 @@ extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partia
         p.items[i].c1 = items[i].c1; p.items[i].c2 = items[i].c2;
         p.items[i].width = items[i].width; p.items[i].mat = items[i].mat;
     }
+    p.share1 = 1;
+    for (int i = 1; i < n_items; ++i)
+        if (items[i].c1 != items[0].c1 || items[i].width != items[0].width) p.share1 = 0;
     dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
     hipLaunchKernelGGL(joint_gram_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return launch_status("joint_gram");

@@ -143,9 +143,8 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
                 accumulate: bool = False, all_taps: Optional[bool] = None) -> torch.Tensor:
     """(taps, K, N) weight gradient of the (taps x 1) temporal convolution with stride ``stride`` and padding
     (taps-1)//2: all taps in one pass over the rows (one call per residue class of the tap offset when strided).
-    a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` None picks the measured
-    faster kernel: the multi-tap pass for stride 1 (119-124 vs 106 TFLOP/s at 128/256 channels), the per-tap kernel
-    for strided convolutions (4-5 taps per pass amortise the staging less: 93-97 vs 107)."""
+    a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` False forces the
+    per-tap kernel (measured slower: 105-107 vs 107-126 TFLOP/s at 64-256 channels, 111-113 for the strided ones)."""
     ensure_device()
     _chk(a, "tconv_wgrad.a"), _chk(g, "tconv_wgrad.g")
     B, T_a, V, K = a.shape
@@ -159,13 +158,13 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
         if js:
             calls.append((par, js[0], len(js), (js[0] - pad - par) // stride))
     if all_taps is None:
-        all_taps = stride == 1
+        all_taps = True
     if not all_taps or any(n not in TWGRAD_TAPS for _, _, n, _ in calls):
         return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate)
     lib = _lib.load()
     tiles = ((K + 31) // 32) * ((N + 127) // 128 if N > 64 else 1)
     stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
-    nsplit = max(1, min(1024 // max(tiles, 1), stages))
+    nsplit = max(1, min(512 // max(tiles, 1), stages))   # 512 workgroups = two per CU, all resident at once
     slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
     for par, tap0, ntaps, shift0 in calls:
