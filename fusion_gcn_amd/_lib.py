@@ -55,6 +55,8 @@ SIGNATURES = {
     "fgcn_rows_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_tconv_wgrad_slabs": (_I, [_I, _I]),
     "fgcn_tconv_wgrad": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
+    "fgcn_pw_wgrad_chunks": (_I, [_I, _I]),
+    "fgcn_pw_wgrad": (_I, [_P, _P, _P] + [_I] * 11 + [_P]),
     "fgcn_reduce_sum": (_I, [_P, _P, _I, _LL, _I, _P]),
     "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),

@@ -25,6 +25,7 @@ struct TWgradP {
     int shift0, tap0, tap_step, taps_total;
     int stages_per_sample, total_stages, stages_per_split;
     int tiles_n, win_rows, stage_rows;
+    int chunk_mode;   // 0: accumulator j = tap j (window rows shifted by j*V); 1: accumulator j = in-channel chunk j (1x1 conv)
     unsigned a_bytes, g_bytes, p_bytes;
 };
 
@@ -42,14 +43,15 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     constexpr unsigned OOB = 0x80000000u;
     using lds_ptr = __attribute__((address_space(3))) void*;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int apieces = (p.win_rows + 7) >> 3;
-    float* Aw = smem;                                 // [apieces * 8][32]
+    const int ppp = (p.win_rows + 7) >> 3;            // LDS-DMA pieces (8 rows x 32 channels) per plane
+    const int apieces = p.chunk_mode ? ppp * NTAP : ppp;
+    float* Aw = smem;                                 // tap mode: [ppp * 8][32]; chunk mode: [NTAP][ppp * 8][32]
     float* Gs = smem + apieces * 256;                 // [TW_BR][TN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
-    const int k0 = tk * 32, n0 = tn * TN;
+    const int k0 = tk * (p.chunk_mode ? 32 * NTAP : 32), n0 = tn * TN;
     const int nsub = wave % NSUB, part = wave / NSUB;
     const int V = p.V, TVg = p.T_g * V;
     const int sbeg = blockIdx.y * p.stages_per_split;
@@ -60,7 +62,6 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
 
     // per-lane part of the source addresses of a piece: a: row lane/8, channels (lane%8)*4;  g: row lane/(TN/4)
     const int a_lr = lane >> 3, akc = k0 + (lane & 7) * 4;
-    const bool a_cok = akc < p.K;
     const int g_lr = lane / (TN / 4), gnc = n0 + (lane % (TN / 4)) * 4;
     const bool g_cok = gnc < p.N;
     const bool strided = p.a_s != 1 || p.a_o != 0;
@@ -72,22 +73,24 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     // fragment bases: window row of g-row r and tap j is r + j*V; this wave's rows start at part * 2 * STEPS
     const float* abase = Aw + (part * STEPS * 2 + h) * 32 + l31;
     const float* gbase = Gs + (part * STEPS * 2 + h) * TN + nsub * 32 + l31;
-    const int tapstride = V * 32;
+    const int tapstride = p.chunk_mode ? ppp * 256 : V * 32;
 
     for (int sid = sbeg; sid < send; ++sid) {
         const int n = sid / p.stages_per_sample;
         const int r0 = (sid - n * p.stages_per_sample) * TW_BR;      // first g row of the stage inside the sample
         __syncthreads();                                             // previous stage's fragment reads are done
         for (int pc = wave; pc < apieces; pc += 4) {
-            const int wr = pc * 8 + a_lr;
+            const int plane = p.chunk_mode ? pc / ppp : 0;           // wave-uniform
+            const int wr = (pc - plane * ppp) * 8 + a_lr;
             const int q = r0 + p.shift0 * V + wr;                    // row of the frame view inside the sample
-            const bool ok = a_cok && wr < p.win_rows && q >= 0 && q < p.Th_a * V;
+            const int chan = akc + plane * 32;
+            const bool ok = chan < p.K && wr < p.win_rows && q >= 0 && q < p.Th_a * V;
             int row = ok ? q : 0;
             if (strided) {                                           // wave-uniform: even / odd frames of a
                 const int f = (int)((unsigned)row / (unsigned)V);
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
-            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + akc) * 4u : OOB;
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + chan) * 4u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(Aw + pc * 256), 16, off, 0, 0, 0);
         }
         for (int pc = wave; pc < GPIECES; pc += 4) {
@@ -111,11 +114,12 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     const int ncol = n0 + nsub * 32 + l31;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
-        const int tap = p.tap0 + j * p.tap_step;
+        const int tap = p.chunk_mode ? 0 : p.tap0 + j * p.tap_step;
+        const int kj = k0 + (p.chunk_mode ? 32 * j : 0);
         const unsigned base = (unsigned)((slab * p.taps_total + tap) * p.K) * (unsigned)p.N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = k0 + acc_row(r, lane);
+            const int k = kj + acc_row(r, lane);
             const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
             const float val = acc[j][r];   // (bit_cast straight from a vector element stores element 0: go through a scalar)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
@@ -135,7 +139,7 @@ template <int NTAP>
 static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
     static bool opt_in = false;   // once per instantiation; not a stream operation (stays out of graph captures)
     if (!opt_in) {
-        const int max_lds = ((128 + 8 * 32) * 32 + 8192) * (int)sizeof(float);
+        const int max_lds = 160 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 128>),
@@ -146,25 +150,22 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
     else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128>), grid, dim3(256), lds, s, p);
 }
 
-extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
-                                int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
-                                int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit,
-                                void* stream) {
-    FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "tconv_wgrad: null pointer");
+static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                         int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a, int nacc, int chunk_mode,
+                         int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream, const char* what) {
+    FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "%s: null pointer", what);
     FGCN_REQUIRE(B > 0 && T_g > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0 && nsplit > 0 && nsplit <= 65535,
-                 FGCN_E_BADARG, "tconv_wgrad: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", B, T_g, V, K, N, nsplit);
+                 FGCN_E_BADARG, "%s: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", what, B, T_g, V, K, N, nsplit);
     FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_a % 4 == 0 && ld_g % 4 == 0 && ld_a >= K && ld_g >= N, FGCN_E_ALIGN,
-                 "tconv_wgrad: K, N and the row strides must be multiples of 4 (K=%d N=%d ld_a=%d ld_g=%d)", K, N, ld_a, ld_g);
-    FGCN_REQUIRE(aligned16(a) && aligned16(g), FGCN_E_ALIGN, "tconv_wgrad: 16-byte alignment");
-    FGCN_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_step >= 1 && tap0 >= 0 && tap0 + (ntaps - 1) * tap_step < taps_total,
-                 FGCN_E_BADARG, "tconv_wgrad: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
+                 "%s: K, N and the row strides must be multiples of 4 (K=%d N=%d ld_a=%d ld_g=%d)", what, K, N, ld_a, ld_g);
+    FGCN_REQUIRE(aligned16(a) && aligned16(g), FGCN_E_ALIGN, "%s: 16-byte alignment", what);
     FGCN_REQUIRE(a_s >= 1 && a_o >= 0 && Th_a > 0 && (long long)(Th_a - 1) * a_s + a_o < T_a_full, FGCN_E_BADARG,
-                 "tconv_wgrad: frame view exceeds the tensor");
+                 "%s: frame view exceeds the tensor", what);
     const long long a_bytes = (long long)B * T_a_full * V * ld_a * 4, g_bytes = (long long)B * T_g * V * ld_g * 4;
     const int parts = twgrad_parts(N);
     const long long p_bytes = (long long)nsplit * parts * taps_total * K * N * 4;
     FGCN_REQUIRE(a_bytes < 0x7FFF0000ll && g_bytes < 0x7FFF0000ll && p_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
-                 "tconv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+                 "%s: tensors must be smaller than 2 GiB (32-bit buffer offsets)", what);
     TWgradP p;
     p.a = a; p.g = g; p.partial = partial;
     p.B = B; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
@@ -175,19 +176,51 @@ extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, 
     p.total_stages = B * p.stages_per_sample;
     p.stages_per_split = (int)cdiv(p.total_stages, nsplit);
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
-    p.win_rows = p.stage_rows + (ntaps - 1) * V;
+    p.chunk_mode = chunk_mode;
+    p.win_rows = chunk_mode ? p.stage_rows : p.stage_rows + (nacc - 1) * V;
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
-    const size_t lds = (size_t)(((p.win_rows + 7) / 8) * 256 + 8192) * sizeof(float);
-    dim3 grid((unsigned)(cdiv(K, 32) * p.tiles_n), (unsigned)nsplit);
+    const int planes = chunk_mode ? nacc : 1;
+    const size_t lds = (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
+    FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
+    const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);
+    dim3 grid((unsigned)(tiles_k * p.tiles_n), (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
-    switch (ntaps) {
+    switch (nacc) {
         case 9: launch_twgrad<9>(p, N, grid, lds, s); break;
+        case 6: launch_twgrad<6>(p, N, grid, lds, s); break;
         case 5: launch_twgrad<5>(p, N, grid, lds, s); break;
         case 4: launch_twgrad<4>(p, N, grid, lds, s); break;
         case 3: launch_twgrad<3>(p, N, grid, lds, s); break;
         case 2: launch_twgrad<2>(p, N, grid, lds, s); break;
         case 1: launch_twgrad<1>(p, N, grid, lds, s); break;
-        default: return fgcn::fail(FGCN_E_BADARG, "tconv_wgrad: %d taps per call not instantiated (1-5, 9)", ntaps);
+        default: return fgcn::fail(FGCN_E_BADARG, "%s: %d accumulators per wave not instantiated (1-6, 9)", what, nacc);
     }
-    return launch_status("tconv_wgrad");
+    return launch_status(what);
+}
+
+extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                                int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
+                                int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit,
+                                void* stream) {
+    FGCN_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_step >= 1 && tap0 >= 0 && tap0 + (ntaps - 1) * tap_step < taps_total,
+                 FGCN_E_BADARG, "tconv_wgrad: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
+    return twgrad_launch(a, g, partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s, a_o, Th_a, ntaps, 0, shift0, tap0,
+                         tap_step, taps_total, nsplit, stream, "tconv_wgrad");
+}
+
+/* in-channel chunks (32 channels each = one accumulator) per wave for a 1x1 weight gradient: a divisor of the chunk
+ * count, at most 6 (128-column tiles, 64-row stages) or 3 (64-column tiles, 128-row stages): two workgroups per CU */
+extern "C" int fgcn_pw_wgrad_chunks(int K, int N) {
+    const int c = (int)cdiv(K, 32), cap = N <= 64 ? 3 : 6;
+    if (c <= cap) return c;
+    for (int d = cap; d >= 2; --d)
+        if (c % d == 0) return d;
+    return cap;
+}
+
+extern "C" int fgcn_pw_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                             int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream) {
+    FGCN_REQUIRE(a_s >= 1 && T_g > 0, FGCN_E_BADARG, "pw_wgrad: bad frame view");
+    return twgrad_launch(a, g, partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s, a_o, T_g, fgcn_pw_wgrad_chunks(K, N), 1,
+                         0, 0, 1, 1, nsplit, stream, "pw_wgrad");
 }

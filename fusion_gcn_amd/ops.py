@@ -116,8 +116,10 @@ def _pick_nsplit(M: int, K: int, N: int, taps: int) -> int:
 
 
 def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_POINTWISE, a_coff: int = 0,
-               g_coff: int = 0, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """(taps, K, N) weight gradient: sum over rows of a[src(row, tap), k] * g[row, n]."""
+               g_coff: int = 0, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+               wide: Optional[bool] = None) -> torch.Tensor:
+    """(taps, K, N) weight gradient: sum over rows of a[src(row, tap), k] * g[row, n].  1x1 convolutions with K a multiple
+    of 32 take the multi-accumulator kernel (``wide``; False forces the generic per-tap kernel)."""
     ensure_device()
     _chk(a, "rows_wgrad.a"), _chk(g, "rows_wgrad.g")
     B, T_a, V, ld_a = a.shape
@@ -126,17 +128,32 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         raise _lib.FgcnError(f"rows_wgrad: shape mismatch a={tuple(a.shape)} g={tuple(g.shape)} K={K} N={N}")
     taps = tmap[0]
     lib = _lib.load()
+    if out is None:
+        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
+    ta, tb, tc, td = tmap[1:]
+    if wide is None:
+        wide = K >= 384      # measured: +2-3 % at K = 384 / 768, -10..-25 % for narrower inputs (tools/kbench.py wgrad)
+    if wide and taps == 1 and tc == 0 and td == 1 and ta >= 1 and K % 32 == 0 and (T_g - 1) * ta < T_a:
+        # 1x1 (optionally strided) convolution: one accumulator per 32-channel chunk, every g fragment feeds 2-6 MFMAs
+        chunks = lib.fgcn_pw_wgrad_chunks(K, N)
+        tiles = ((K + 32 * chunks - 1) // (32 * chunks)) * ((N + 127) // 128 if N > 64 else 1)
+        stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
+        nsplit = max(1, min(512 // max(tiles, 1), stages))
+        slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
+        partial = torch.empty((slabs, K, N), device=a.device, dtype=torch.float32)
+        check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
+                                nsplit, _stream()), "fgcn_pw_wgrad")
+        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
+        return out
     nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
     partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
     check(lib.fgcn_rows_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_a, T_g, V, K, N, ld_a, ld_g,
                               TMap(*tmap), nsplit, _stream()), "fgcn_rows_wgrad")
-    if out is None:
-        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
     reduce_sum(partial.view(nsplit, -1), out.view(-1), accumulate=accumulate)
     return out
 
 
-TWGRAD_TAPS = (1, 2, 3, 4, 5, 9)   # taps per call the multi-tap kernel is instantiated for
+TWGRAD_TAPS = (1, 2, 3, 4, 5, 6, 9)   # taps per call the multi-tap kernel is instantiated for
 
 
 def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1, out: Optional[torch.Tensor] = None,
@@ -160,7 +177,7 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     if all_taps is None:
         all_taps = True
     if not all_taps or any(n not in TWGRAD_TAPS for _, _, n, _ in calls):
-        return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate)
+        return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate, wide=False)
     lib = _lib.load()
     tiles = ((K + 31) // 32) * ((N + 127) // 128 if N > 64 else 1)
     stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)

@@ -98,6 +98,14 @@ int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int 
                      int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                      int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
 
+/* Weight gradient of a 1x1 convolution (theta|phi embedding, conv_d on the stacked agg, down, residual): the same
+ * kernel with one accumulator per 32-channel chunk of a instead of per tap (each g fragment feeds up to 6 MFMAs):
+ *     partial[slab][k][n] = sum over the slab's rows (b, t, v) of a[(b, t*a_s + a_o, v), k] * g[(b, t, v), n]
+ *   partial: float[fgcn_tconv_wgrad_slabs(N, nsplit)][K][N].  Same alignment / size rules as fgcn_tconv_wgrad. */
+int fgcn_pw_wgrad_chunks(int K, int N);
+int fgcn_pw_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
+                  int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream);
+
 /* dst[i] (+)= sum_s src[s*count + i]   (deterministic tree-free column sum; also bias / adj_b gradients) */
 int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream);
 

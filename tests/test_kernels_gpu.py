@@ -181,6 +181,38 @@ def test_rows_wgrad(B, T, V, K, N, kt, s):
     (want,) = torch.autograd.grad((y * g).sum(), w)
     got = ops.rows_wgrad(to_gpu(a), to_gpu(g), K=K, N=N, tmap=tmap)
     assert rel_l2(got.cpu().numpy(), want.numpy()) < RED_TOL
+    generic = ops.rows_wgrad(to_gpu(a), to_gpu(g), K=K, N=N, tmap=tmap, wide=False)
+    assert rel_l2(generic.cpu().numpy(), want.numpy()) < RED_TOL
+
+
+@pytest.mark.parametrize("B,T,V,K,N,s", [
+    (2, 30, 25, 192, 64, 1),      # conv_d on the stacked agg, 64 columns: 2 tiles of 3 chunks, two row halves per stage
+    (1, 12, 25, 768, 256, 1),     # 24 chunks = 4 tiles of 6, two column tiles
+    (3, 20, 18, 64, 96, 1),       # theta|phi embedding: N tail inside a 128-column tile
+    (2, 21, 27, 64, 128, 2),      # strided residual conv (frames 2t of a), odd T
+    (2, 9, 20, 160, 36, 1),       # 5 chunks, ragged N
+    (1, 1, 5, 32, 4, 1),          # tiny: one frame, one chunk
+    (2, 10, 25, 224, 64, 1),      # 7 chunks: not a multiple of the per-wave chunk count (tile tail reads zeros)
+])
+def test_pointwise_wgrad_channel_chunks(B, T, V, K, N, s):
+    """1x1 weight gradients on the multi-accumulator kernel (one accumulator per 32-channel chunk) equal autograd and the
+    generic kernel; channel windows (a_coff / g_coff) and accumulation work; runs are bitwise reproducible."""
+    from fusion_gcn_amd import ops
+    T_out = (T - 1) // s + 1
+    tmap = (1, s, 0, 0, 1)
+    a, g = rnd(B, T, V, K + 32, seed=41), rnd(B, T_out, V, N + 8, seed=42)
+    w = torch.zeros(1, K, N, dtype=torch.float64, requires_grad=True)
+    y = ref_rows_conv(a[..., 32:], w, tmap, T_out)
+    (want,) = torch.autograd.grad((y * g[..., 4:4 + N]).sum(), w)
+    kw = dict(K=K, N=N, tmap=tmap, a_coff=32, g_coff=4)
+    got = ops.rows_wgrad(to_gpu(a), to_gpu(g), wide=True, **kw)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < RED_TOL
+    ref = ops.rows_wgrad(to_gpu(a), to_gpu(g), wide=False, **kw)
+    assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < RED_TOL
+    assert torch.equal(got, ops.rows_wgrad(to_gpu(a), to_gpu(g), wide=True, **kw))
+    acc = got.clone()
+    ops.rows_wgrad(to_gpu(a), to_gpu(g), wide=True, out=acc, accumulate=True, **kw)
+    assert rel_l2(acc.cpu().numpy(), 2 * want.numpy()) < RED_TOL
 
 
 def test_reduce_sum_and_col_sum_and_pack():
