@@ -80,7 +80,7 @@ def build_model(device):
     return model.to(device).train()
 
 
-def time_dominant_kernel(device, b_local: int, reps: int = 10):
+def time_dominant_kernel(device, b_local: int, reps: int = 10, widths=(64, 128, 256)):
     """Live HIP-event timing of the halo-tile temporal-conv kernel (conv_halo_kernel: with rows_wgrad_kernel the
     largest share of the step) at the three channel widths of the model, forward form with bias and BatchNorm
     partial sums exactly as the block launches it; returns per-launch algorithmic FLOPs and mean duration."""
@@ -88,6 +88,8 @@ def time_dominant_kernel(device, b_local: int, reps: int = 10):
     out = []
     T = SHAPE["T"]
     for c, t in ((64, T), (128, (T - 1) // 2 + 1), (256, ((T - 1) // 2) // 2 + 1)):
+        if c not in widths:
+            continue
         x = torch.randn(b_local, t, SHAPE["V"], c, device=device)
         w4 = ops.pack_k4(torch.randn(9, c, c, device=device) * (9 * c) ** -0.5)
         bias = torch.randn(c, device=device)
@@ -176,6 +178,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
+                         "profiles/*_dominant_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +197,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.kernel_only:
+        kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
+        print(json.dumps({"kernel": "conv_halo_kernel<4,3> forward, 256 channels", **kern[0]}), flush=True)
+        return
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
     model = build_model(device)
     broadcast_parameters(model)
@@ -295,7 +304,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                                "traffic": measured_traffic(dom, (shard.stop - shard.start) * SHAPE["M"]),
-                               "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4}> (9x1 temporal conv forward, "
+                               "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4},3> (9x1 temporal conv forward, "
                                          f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),
                                "flop_per_launch": dom["flops"],
