@@ -41,7 +41,7 @@ inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // Kernel-variant selectors (fgcn_set_tuning): defaults are the measured-best variants; tests and tools/kbench.py
 // flip them to compare.  key 0: row-GEMM tile for <= 64 output channels, key 1: for wider outputs (see fgcn_gemm.hip);
-// key 2: fused spatial backward ablation; key 3: channel-group mix ablation; key 4: halo conv register budget (0: 3
+// key 4: halo conv register budget (0: 3
 // workgroups per CU, 1: 2); key 5: XCD-aware workgroup order, bit 0 row GEMM (off), bit 1 halo conv (off), bit 2
 // disables it for the weight gradient (on by default), bit 3 disables the column-tile-fastest grid of the row GEMM.
 int tuning(int key);

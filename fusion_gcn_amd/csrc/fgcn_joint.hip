@@ -106,7 +106,7 @@ struct MixVP {
     const float* in;
     float* out;
     const float* mats;
-    int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, t_chunk, dbg;
+    int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, t_chunk;
     unsigned in_bytes, out_bytes;
     struct Item {  // dword fields only: the kernel reads them with scalar loads (16-bit fields went through vector memory)
         int out_c, nterms, img[3], in_c[3];
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int k = 2 * s + h, u = acc_row(s, lane);
-        koff[s] = (lane_ok && k < V && !(p.dbg & 4)) ? (unsigned)(k * p.ld_in + VW * l31) * 4u : OOB;
-        uoff[s] = (lane_ok && u < V && !(p.dbg & 1)) ? (unsigned)(u * p.ld_out + VW * l31) * 4u : OOB;
+        koff[s] = (lane_ok && k < V) ? (unsigned)(k * p.ld_in + VW * l31) * 4u : OOB;
+        uoff[s] = (lane_ok && u < V) ? (unsigned)(u * p.ld_out + VW * l31) * 4u : OOB;
     }
     const float* arow = &img[h * 32 + l31];
 
@@ -221,20 +221,6 @@ struct GramP {
         int c1, c2, width, mat;
     } items[FGCN_GRAM_MAX_ITEMS];
 };
-
-__device__ __forceinline__ f32x4 load4_masked(const float* p, int c, int width, bool row_ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok && c < width) {
-        if (c + 3 < width) {
-            v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < width) v[e] = p[e];
-        }
-    }
-    return v;
-}
 
 __global__ __launch_bounds__(256, 3) void joint_gram_kernel(GramP p) {
     __shared__ float red[4 * 1024];
@@ -513,7 +499,6 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out;
     p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items;
     p.t_chunk = pick_t_chunk(B, T);
-    p.dbg = fgcn::tuning(3);
     for (int i = 0; i < n_items; ++i) {
         const fgcn_mixv_item& it = items[i];
         FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.nch >= vw && it.nch <= 32 * vw && it.nch % vw == 0 &&

@@ -30,7 +30,6 @@ struct SpatialBwdP {
     float* partial;
     int B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, ns, a_batched, t_chunk, accumulate;
     unsigned dy_bytes, x_bytes, w_bytes;
-    int dbg;
 };
 
 __device__ __forceinline__ f32x4 sb_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -161,11 +160,9 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(SpatialBwdP p) {
                 }
                 // ---- (b) dx tile += A^_k . D : register r of D is contraction row w = (r&3) + 8(r>>2) + 4h -------
                 const float* ak = ah + (k * 32 + l31) * BAHS + 4 * h;
-                if (!(p.dbg & 1))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accx = mfma32(ak[(r & 3) + 8 * (r >> 2)], D[r], accx);
                 // ---- (c) dA^_k += x_t[:, ci tile] . D^T through the wave-private tile T[w][c] --------------------
-                if (!(p.dbg & 2)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * BTTS + l31] = D[r];
 #pragma unroll
@@ -173,7 +170,6 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(SpatialBwdP p) {
                     const f32x4 tb = *reinterpret_cast<const f32x4*>(&T[l31 * BTTS + 8 * q + 4 * h]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acca[k] = mfma32(xa[q][e], tb[e], acca[k]);
-                }
                 }
             }
             // ---- dx tile of this channel tile: rows v in the registers, channels on the lanes (128 B per half-wave) --
@@ -240,7 +236,7 @@ extern "C" int fgcn_spatial_bwd(const float* dy, const float* x, const float* a_
     FGCN_REQUIRE(ci <= 8, FGCN_E_BADARG, "spatial_bwd: at most 256 input channels (Cin=%d)", Cin);
     SpatialBwdP p{dy, x, a_hat, wdt4, dx, partial, B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, n_subsets, a_hat_batched,
                   spatial_bwd_t_chunk(B, T), accumulate, (unsigned)dyb, (unsigned)xb,
-                  (unsigned)((long long)n_subsets * Cout * Cin * 4), fgcn::tuning(2)};
+                  (unsigned)((long long)n_subsets * Cout * Cin * 4)};
     // joint matrices + transpose tiles (4608 floats, reused as the 4096-float final-sum scratch) + 4 dy frame images
     const size_t lds = (((3 * 32 * BAHS + 3) & ~3) + 4 * 32 * BTTS + 4 * V * (Cout + 4)) * sizeof(float);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "spatial_bwd: V=%d x Cout=%d needs %zu bytes of LDS (> 160 KiB)", V, Cout,

@@ -123,9 +123,6 @@ def bench_spatial(B, reps):
 
 
 def bench_spatial_bwd(B, reps):
-  for dbg in (0,):
-    _lib.load().fgcn_set_tuning(2, dbg)
-    print("-- spatial_bwd dbg", dbg)
     for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
         x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
         wdt4 = ops.pack_k4(rnd(3, cout, cin) * (3 * cin) ** -0.5)
@@ -133,7 +130,6 @@ def bench_spatial_bwd(B, reps):
         ms = timeit(lambda: ops.spatial_bwd(dy, x, a, wdt4, dx, accumulate=True), reps)
         rows = B * T * V
         report(f"spatial_bwd T{T} {cin}->{cout}", ms, rows * (12.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (3 * cin + cout))
-  _lib.load().fgcn_set_tuning(2, 0)
 
 
 def bench_joint(B, reps):
@@ -165,21 +161,6 @@ def bench_joint(B, reps):
         report(f"gram dA^ T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
 
 
-def bench_jointdbg(B, reps):
-    """Ablation of the vectorised mix kernel (tuning 3: bit0 no stores, bit1 no MFMA, bit2 no loads)."""
-    lib = _lib.load()
-    T, c = 300, 64
-    x, a = rnd(B, T, V, c), rnd(B, 3, V, V) * 0.2
-    agg, dx = torch.empty(B, T, V, 3 * c, device=DEV), torch.zeros(B, T, V, c, device=DEV)
-    for dbg in (0, 1, 4, 5):
-        lib.fgcn_set_tuning(3, dbg)
-        ms1 = timeit(lambda: block.mix_agg(x, agg, a, c), reps)
-        ms2 = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=True), reps)
-        ms3 = timeit(lambda: block.mix_dx(agg, dx, a, c, accumulate=False), reps)
-        print(f"dbg={dbg} mix_agg {ms1:.3f}  mix_dx(acc) {ms2:.3f}  mix_dx(noacc) {ms3:.3f}", flush=True)
-    lib.fgcn_set_tuning(3, 0)
-
-
 def bench_elem(B, reps):
     for T, c in ((300, 64), (75, 256)):
         rows = B * T * V
@@ -205,7 +186,7 @@ def main():
         k, v = kv.split("=")
         _lib.load().fgcn_set_tuning(int(k), int(v))
         print(f"-- tuning {k} = {v}")
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem, jointdbg=bench_jointdbg)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
