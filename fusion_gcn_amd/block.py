@@ -362,16 +362,15 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
-        gw = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1))
-        G["residual.conv.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
+        G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1), conv_param=(1, cin_true))
         G["residual.conv.bias"] = _bias_grad(dr, cout, train)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
     # -- temporal conv -------------------------------------------------------------------------------------------------------
     dg = new(B, T, V, cout)
     temporal_dgrad(du, dg, W, kt, s)
-    gw = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s)                            # (kt, c, o)
-    G["tcn1.conv.weight"] = gw.permute(2, 1, 0).unsqueeze(-1)
+    # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
+    G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
     G["tcn1.conv.bias"] = _bias_grad(du, cout, train)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
@@ -380,8 +379,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         ops.rows_gemm(dd, W["down_t"], dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
-        gw = ops.rows_wgrad(x, dd, K=cin, N=cout)
-        G["gcn1.down.0.weight"] = gw[0, :cin_true].t().reshape(cout, cin_true, 1, 1)
+        G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
         G["gcn1.down.0.bias"] = _bias_grad(dd, cout, train)
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
@@ -395,11 +393,11 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     agg = new(B, T, V, c3)
     mix_agg(x, agg, a_hat, cin)
-    gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)[0]                              # (3cin, cout)
+    gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
     del agg
     dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
-        G[f"gcn1.conv_d.{k}.weight"] = gw[k * cin:k * cin + cin_true].t().reshape(cout, cin_true, 1, 1)
+        G[f"gcn1.conv_d.{k}.weight"] = gw[k]
         G[f"gcn1.conv_d.{k}.bias"] = dbias if k == 0 else dbias.clone()          # three parameters, three buffers
     if cfg.fused_spatial_bwd:
         # dagg = dy . Wd, dx += dagg . A^^T and dA^ = x^T . dagg in one kernel; dagg never reaches HBM
@@ -421,12 +419,12 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         demb = new(B, T, V, 6 * ic)
         mix_demb(emb, demb, d_s, ic)
         ops.rows_gemm(demb, W["emb_t"], dx, K=6 * ic, N=cx, accumulate=dx_live)
-        gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic)[0].t()                        # (6ic, cin)
+        gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true))     # (6ic, cin_true, 1, 1)
         gb = ops.col_sum(demb, 6 * ic)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic
-                G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic, :cin_true].reshape(ic, cin_true, 1, 1)
+                G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic]
                 G[f"gcn1.{grp}.{k}.bias"] = gb[lo:lo + ic]
     return (dx if need_dx else None), G
 

@@ -381,6 +381,35 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(float* dst, const floa
     }
 }
 
+// Same sum, but dst is written through strides: src slab element i = (tap, k, n) of a [taps][K][N] weight gradient goes
+// to dst[tap*st_tap + k*st_k + n*st_n] (k < K_dst), i.e. straight into the parameter's own (out, in, taps, 1) layout,
+// so autograd takes the tensor as it is instead of launching a transposing copy per parameter.
+__global__ __launch_bounds__(1024) void reduce_sum_strided_kernel(float* dst, const float* src, int S, int taps, int K, int N,
+                                                                  int K_dst, long long st_tap, long long st_k,
+                                                                  long long st_n, int accumulate) {
+    __shared__ float red[16][65];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const long long count = (long long)taps * K * N;
+    const long long i = (long long)blockIdx.x * 64 + x;
+    float t = 0.f;
+    if (i < count)
+        for (int s = y; s < S; s += 16) t += src[(long long)s * count + i];
+    red[y][x] = t;
+    __syncthreads();
+    if (y == 0 && i < count) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][x];
+        const int n = (int)(i % N);
+        const long long tk = i / N;
+        const int k = (int)(tk % K), tap = (int)(tk / K);
+        if (k < K_dst) {
+            float* d = dst + tap * st_tap + k * st_k + n * st_n;
+            *d = accumulate ? *d + a : a;
+        }
+    }
+}
+
 __global__ void pack_weight_kernel(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
                                    long long st_tap, long long st_k, long long st_n, int flip) {
     const long long total = (long long)taps * K * N_dst;
@@ -513,6 +542,17 @@ extern "C" int fgcn_reduce_sum(float* dst, const float* src, int S, long long co
     hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)cdiv(count, 64)), dim3(64, 16), 0, (hipStream_t)stream, dst, src,
                        S, count, accumulate);
     return launch_status("reduce_sum");
+}
+
+extern "C" int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K, int N, int K_dst,
+                                       long long st_tap, long long st_k, long long st_n, int accumulate, void* stream) {
+    FGCN_REQUIRE(dst && src && S > 0 && taps > 0 && K > 0 && N > 0 && K_dst > 0 && K_dst <= K, FGCN_E_BADARG,
+                 "reduce_sum_strided: bad argument");
+    const long long count = (long long)taps * K * N;
+    FGCN_REQUIRE(cdiv(count, 64) < (1ll << 31), FGCN_E_BADARG, "reduce_sum_strided: count too large");
+    hipLaunchKernelGGL(reduce_sum_strided_kernel, dim3((unsigned)cdiv(count, 64)), dim3(64, 16), 0, (hipStream_t)stream, dst,
+                       src, S, taps, K, N, K_dst, st_tap, st_k, st_n, accumulate);
+    return launch_status("reduce_sum_strided");
 }
 
 extern "C" int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,

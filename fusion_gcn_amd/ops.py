@@ -115,11 +115,41 @@ def _pick_nsplit(M: int, K: int, N: int, taps: int) -> int:
     return int(max(1, min(want, (M + 511) // 512)))
 
 
+def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optional[torch.Tensor], accumulate: bool,
+                  conv_param: Optional[Tuple[int, int]]) -> torch.Tensor:
+    """Sum the (slabs, taps, K, N) partial weight gradients.  Default result: (taps, K, N).  ``conv_param=(groups, K_true)``
+    writes the parameter layout instead: (groups, N, K_true, taps // groups, 1) -- `groups` stacked convolutions (conv_d's
+    three subsets arrive as K = groups * K_in rows of one GEMM), input channels beyond K_true dropped (padding)."""
+    slabs = partial.shape[0]
+    if conv_param is None:
+        if out is None:
+            out = torch.empty((taps, K, N), device=partial.device, dtype=torch.float32)
+        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
+        return out
+    groups, k_true = conv_param
+    if groups > 1:                      # (1, groups*K_in, N) reinterpreted as (groups, K_in, N): one "tap" per group
+        if taps != 1 or K % groups:
+            raise _lib.FgcnError("conv_param groups need a 1x1 convolution with K divisible by groups")
+        g_taps, g_k, kt = groups, K // groups, 1
+        shape, st_tap, st_k, st_n = (groups, N, k_true, 1, 1), N * k_true, 1, k_true
+    else:
+        g_taps, g_k, kt = taps, K, taps
+        shape, st_tap, st_k, st_n = (N, k_true, kt, 1), 1, kt, k_true * kt
+    if out is None:
+        out = torch.empty(shape, device=partial.device, dtype=torch.float32)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise _lib.FgcnError(f"weight-gradient output must be contiguous {shape}, got {tuple(out.shape)}")
+    check(_lib.load().fgcn_reduce_sum_strided(_p(out), _p(partial), slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n,
+                                              int(accumulate), _stream()), "fgcn_reduce_sum_strided")
+    return out
+
+
 def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_POINTWISE, a_coff: int = 0,
                g_coff: int = 0, out: Optional[torch.Tensor] = None, accumulate: bool = False,
-               wide: Optional[bool] = None) -> torch.Tensor:
+               wide: Optional[bool] = None, conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """(taps, K, N) weight gradient: sum over rows of a[src(row, tap), k] * g[row, n].  1x1 convolutions with K a multiple
-    of 32 take the multi-accumulator kernel (``wide``; False forces the generic per-tap kernel)."""
+    of 32 take the multi-accumulator kernel (``wide``; False forces the generic per-tap kernel).  ``conv_param`` returns
+    the gradient in the convolution parameter's own layout (see ``_reduce_slabs``)."""
     ensure_device()
     _chk(a, "rows_wgrad.a"), _chk(g, "rows_wgrad.g")
     B, T_a, V, ld_a = a.shape
@@ -128,8 +158,6 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         raise _lib.FgcnError(f"rows_wgrad: shape mismatch a={tuple(a.shape)} g={tuple(g.shape)} K={K} N={N}")
     taps = tmap[0]
     lib = _lib.load()
-    if out is None:
-        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
     ta, tb, tc, td = tmap[1:]
     if wide is None:
         wide = K >= 384      # measured: +2-3 % at K = 384 / 768, -10..-25 % for narrower inputs (tools/kbench.py wgrad)
@@ -143,21 +171,20 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         partial = torch.empty((slabs, K, N), device=a.device, dtype=torch.float32)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
                                 nsplit, _stream()), "fgcn_pw_wgrad")
-        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
-        return out
+        return _reduce_slabs(partial.view(slabs, 1, K, N), 1, K, N, out, accumulate, conv_param)
     nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
     partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
     check(lib.fgcn_rows_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_a, T_g, V, K, N, ld_a, ld_g,
                               TMap(*tmap), nsplit, _stream()), "fgcn_rows_wgrad")
-    reduce_sum(partial.view(nsplit, -1), out.view(-1), accumulate=accumulate)
-    return out
+    return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
 TWGRAD_TAPS = (1, 2, 3, 4, 5, 6, 9)   # taps per call the multi-tap kernel is instantiated for
 
 
 def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1, out: Optional[torch.Tensor] = None,
-                accumulate: bool = False, all_taps: Optional[bool] = None) -> torch.Tensor:
+                accumulate: bool = False, all_taps: Optional[bool] = None,
+                conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """(taps, K, N) weight gradient of the (taps x 1) temporal convolution with stride ``stride`` and padding
     (taps-1)//2: all taps in one pass over the rows (one call per residue class of the tap offset when strided).
     a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` False forces the
@@ -177,21 +204,22 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     if all_taps is None:
         all_taps = True
     if not all_taps or any(n not in TWGRAD_TAPS for _, _, n, _ in calls):
-        return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate, wide=False)
+        return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate, wide=False,
+                          conv_param=conv_param)
     lib = _lib.load()
     tiles = ((K + 31) // 32) * ((N + 127) // 128 if N > 64 else 1)
     stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
-    nsplit = max(1, min(512 // max(tiles, 1), stages))   # 512 workgroups = two per CU, all resident at once
+    # at most 512 workgroups (two per CU, all resident at once); small batches: >= 16 stages per workgroup while that still
+    # leaves a workgroup per CU -- fewer slabs for the reduction
+    cap = max(1, 512 // max(tiles, 1))
+    nsplit = max(1, min(cap, max(stages // 16, min(stages, max(1, 256 // max(tiles, 1))))))
     slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
     for par, tap0, ntaps, shift0 in calls:
         th_a = (T_a - par + stride - 1) // stride
         check(lib.fgcn_tconv_wgrad(_p(a), _p(g), _p(partial), B, T_g, V, K, N, K, N, T_a, stride, par, th_a,
                                    ntaps, shift0, tap0, stride, taps, nsplit, _stream()), "fgcn_tconv_wgrad")
-    if out is None:
-        out = torch.empty((taps, K, N), device=a.device, dtype=torch.float32)
-    reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
-    return out
+    return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
 def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False) -> torch.Tensor:

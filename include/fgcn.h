@@ -109,6 +109,12 @@ int fgcn_pw_wgrad(const float* a, const float* g, float* partial, int B, int T_g
 /* dst[i] (+)= sum_s src[s*count + i]   (deterministic tree-free column sum; also bias / adj_b gradients) */
 int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream);
 
+/* The same slab sum written through strides: element (tap, k, n) of the [taps][K][N] slabs lands at
+ * dst[tap*st_tap + k*st_k + n*st_n] for k < K_dst (input channels beyond K_dst are padding) -- i.e. directly in a conv
+ * parameter's own (out, in, taps, 1) layout, so the gradient needs no transposing copy. */
+int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K, int N, int K_dst,
+                            long long st_tap, long long st_k, long long st_n, int accumulate, void* stream);
+
 /* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
  * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */
 int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,

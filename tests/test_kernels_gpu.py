@@ -215,6 +215,31 @@ def test_pointwise_wgrad_channel_chunks(B, T, V, K, N, s):
     assert rel_l2(acc.cpu().numpy(), 2 * want.numpy()) < RED_TOL
 
 
+def test_weight_gradients_in_parameter_layout():
+    """conv_param=(groups, K_true): the slab reduction writes the conv parameter's own (out, in, taps, 1) layout, dropping
+    padded input channels and splitting stacked convolutions (conv_d's three subsets)."""
+    from fusion_gcn_amd import ops
+    B, T, V = 2, 12, 25
+    a, g = rnd(B, T, V, 64, seed=51), rnd(B, T, V, 96, seed=52)
+    ref = ops.tconv_wgrad(to_gpu(a), to_gpu(g), taps=9)                              # (9, 64, 96)
+    got = ops.tconv_wgrad(to_gpu(a), to_gpu(g), taps=9, conv_param=(1, 64))          # (96, 64, 9, 1)
+    assert got.shape == (96, 64, 9, 1) and got.is_contiguous()
+    assert torch.equal(got[..., 0], ref.permute(2, 1, 0))
+    ref1 = ops.rows_wgrad(to_gpu(a), to_gpu(g), K=64, N=96)[0]                       # (64, 96)
+    got1 = ops.rows_wgrad(to_gpu(a), to_gpu(g), K=64, N=96, conv_param=(1, 61))      # 3 padded input channels dropped
+    assert got1.shape == (96, 61, 1, 1) and torch.equal(got1[:, :, 0, 0], ref1[:61].t())
+    a3 = rnd(B, T, V, 3 * 128, seed=53)
+    for wide in (False, True):
+        ref3 = ops.rows_wgrad(to_gpu(a3), to_gpu(g), K=384, N=96, wide=wide)[0]      # (3*128, 96)
+        got3 = ops.rows_wgrad(to_gpu(a3), to_gpu(g), K=384, N=96, wide=wide, conv_param=(3, 128))
+        assert got3.shape == (3, 96, 128, 1, 1)
+        for k in range(3):
+            assert torch.equal(got3[k, :, :, 0, 0], ref3[128 * k:128 * (k + 1)].t())
+    acc = got1.clone()
+    ops.rows_wgrad(to_gpu(a), to_gpu(g), K=64, N=96, conv_param=(1, 61), out=acc, accumulate=True)
+    assert rel_l2(acc.cpu().numpy(), 2 * got1.cpu().numpy()) < 1e-6
+
+
 def test_reduce_sum_and_col_sum_and_pack():
     from fusion_gcn_amd import ops
     src = rnd(37, 1000, seed=12)
