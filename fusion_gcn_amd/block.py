@@ -11,12 +11,14 @@ Kernel schedule of one block, train mode (B = N*M samples):
   forward   rows_gemm(theta|phi 1x1)  -> joint_gram (V x V affinity) -> adj_softmax (A^ = A + B + C)
             spatial_fwd  [fused x.A^_k + conv_d, BN partial sums]   (or joint_mix + rows_gemm when fused_spatial=False)
             bn_finalize -> [rows_gemm(down) -> bn_finalize] -> bn_act (BN + down/identity + ReLU = G)
-            rows_gemm(9x1 temporal conv, stride s, BN partial sums) -> bn_finalize
+            tconv_halo (9x1 temporal conv, stride 1; rows_gemm for stride 2) with BN partial sums -> bn_finalize
             [rows_gemm(residual 1x1 stride s) -> bn_finalize] -> bn_act (BN + residual + ReLU = O)
-  backward  bn_act_bwd (O)  -> rows_gemm(dgrad 9x1) / rows_wgrad(9x1) -> bn_act_bwd (G)
-            rows_gemm(dY.Wd) -> joint_mix(agg recompute) -> rows_wgrad(conv_d) -> joint_mix(dx) -> joint_gram(dA^)
-            adj_softmax_bwd -> joint_mix(dtheta, dphi) -> rows_gemm(dx) / rows_wgrad(theta|phi)
-            + down / residual conv dgrad & wgrad, bias gradients by col_sum.
+  backward  bn_act_bwd (O)  -> tconv_halo(data gradient 9x1; two parity passes when strided) / tconv_wgrad(all taps)
+            -> bn_act_bwd (G)
+            rows_gemm(dY.Wd) -> joint_mix_vec(agg recompute) -> rows_wgrad / pw_wgrad(conv_d) -> joint_mix_vec(dx)
+            -> joint_gram(dA^) -> adj_softmax_bwd -> joint_mix_vec(dtheta, dphi) -> rows_gemm(dx) / rows_wgrad(theta|phi)
+            + down / residual conv dgrad & wgrad, bias gradients by col_sum; every weight gradient is reduced from its
+            slabs straight into the parameter's (out, in, taps, 1) layout (reduce_sum_strided).
 """
 from __future__ import annotations
 
