@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-scaling", action="store_true",
+                    help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-only", action="store_true",
@@ -191,11 +193,18 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # FGCN_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through the host): a plumbing check, never a measurement.
+    backend = os.environ.get("FGCN_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.kernel_only:
         kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
@@ -207,31 +216,34 @@ def main():
     grads = FlatGradients(model.parameters())
 
     n_global = args.batch * world if args.scaling == "weak" else args.batch
-    shard = shard_batch(n_global, rank, world)
-    g = torch.Generator().manual_seed(1)
-    x_all = torch.randn(n_global, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"], generator=g)
-    y_all = torch.randint(0, SHAPE["classes"], (n_global,), generator=g)
-    x = x_all[shard].to(device).contiguous()      # resident in HBM before the timed region
-    y = y_all[shard].to(device)
-    del x_all
 
-    def fwd_bwd():
-        loss = F.cross_entropy(model(x), y)
-        loss.backward()
-        return loss
+    def resident_shard(n_total):
+        """This rank's clips of a seeded synthetic batch of n_total clips, resident in HBM before any timed region."""
+        shard = shard_batch(n_total, rank, world)
+        g = torch.Generator().manual_seed(1)
+        x_all = torch.randn(n_total, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"], generator=g)
+        y_all = torch.randint(0, SHAPE["classes"], (n_total,), generator=g)
+        return x_all[shard].to(device).contiguous(), y_all[shard].to(device), shard.stop - shard.start
 
-    def step_eager():
-        grads.zero()
-        loss = fwd_bwd()
-        if world > 1:
-            grads.all_reduce_mean()     # gather into the flat buffer + ONE RCCL all-reduce + 1/world
-        return loss
+    def make_step(x, y):
+        """-> (step function, launch mode).  The step is ~630 kernel launches; at 8 clips per GPU their host cost exceeds
+        the GPU time, so forward + backward are captured once into a HIP graph (our ctypes launches go to torch's capturing
+        stream) and replayed; inputs, parameters and gradient buffers are static, the data-parallel exchange stays
+        outside the graph."""
+        def fwd_bwd():
+            loss = F.cross_entropy(model(x), y)
+            loss.backward()
+            return loss
 
-    # The step is ~1100 kernel launches; at 8 clips per GPU (N = 8) their host cost exceeds the GPU time, so the whole
-    # forward + backward is captured once into a HIP graph (our ctypes launches go to torch's capturing stream) and
-    # replayed; inputs, parameters and gradient buffers are static, the data-parallel exchange stays outside the graph.
-    step, mode = step_eager, "eager"
-    if not args.no_graph:
+        def step_eager():
+            grads.zero()
+            loss = fwd_bwd()
+            if world > 1:
+                grads.all_reduce_mean()     # gather into the flat buffer + ONE RCCL all-reduce + 1/world
+            return loss
+
+        if args.no_graph:
+            return step_eager, "eager"
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -250,35 +262,56 @@ def main():
                 if world > 1:
                     grads.all_reduce_mean()
                 return static_loss
-            step, mode = step_graph, "hipgraph"
+            return step_graph, "hipgraph"
         except Exception as e:  # noqa: BLE001 - report and fall back to eager launches
             log(f"graph capture failed ({type(e).__name__}: {e}); running eager")
             torch.cuda.synchronize()
-            step, mode = step_eager, "eager"
+            return step_eager, "eager"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"model + data resident on {device}; warm-up x{args.warmup}")
-    for _ in range(args.warmup):
-        step()
-    fence()
-    log(f"timing {args.steps} steps")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    loss_val = float(loss.detach())
-    log(f"{args.steps} steps in {elapsed:.3f} s; timing the dominant kernel")
+    def timed(step, steps, warmup):
+        """Seconds for `steps` steps after `warmup` untimed ones: barrier + synchronize on both sides, max over ranks."""
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        return elapsed, float(loss.detach())
 
-    kern = None if args.no_kernel_timing else time_dominant_kernel(device, (shard.stop - shard.start) * SHAPE["M"])
+    x, y, n_local = resident_shard(n_global)
+    step, mode = make_step(x, y)
+    log(f"model + {n_local} clips resident on {device}; warm-up x{args.warmup}, timing {args.steps} steps")
+    elapsed, loss_val = timed(step, args.steps, args.warmup)
+    log(f"{args.steps} steps in {elapsed:.3f} s")
+
+    # With more than one GPU the other reading of "data-parallel scaling" is reported beside the headline number in the
+    # same line: ONE batch of --batch clips sharded over the ranks (strong scaling; 8 clips per GPU at N = 8).
+    other = None
+    if world > 1 and not args.no_other_scaling and args.batch >= world:
+        # (no try/except: a rank that skipped a collective would leave the others hanging; an error ends the job loudly)
+        n_other = args.batch if args.scaling == "weak" else args.batch * world
+        del step
+        x2, y2, n_local2 = resident_shard(n_other)
+        step2, mode2 = make_step(x2, y2)
+        steps2 = max(args.steps, 10)
+        el2, _ = timed(step2, steps2, max(args.warmup, 2))
+        other = {"scaling": "strong" if args.scaling == "weak" else "weak", "global_batch": n_other,
+                 "per_gpu_batch": n_local2, "value": round(n_other * steps2 / el2, 2), "unit": "clips/s",
+                 "ms_per_step": round(1e3 * el2 / steps2, 3), "steps": steps2, "launch": mode2}
+        del step2, x2, y2
+
+    kern = None if args.no_kernel_timing else time_dominant_kernel(device, n_local * SHAPE["M"])
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         clips_per_s = n_global * args.steps / elapsed
@@ -291,7 +324,7 @@ def main():
             "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
                                    "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
                                    % n_global,
-                       "global_batch": n_global, "per_gpu_batch": shard.stop - shard.start,
+                       "global_batch": n_global, "per_gpu_batch": n_local,
                        "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5)},
             "step_fractions": {
                 "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
@@ -303,13 +336,15 @@ def main():
             dom = max(kern, key=lambda k: k["ms"])
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                               "traffic": measured_traffic(dom, (shard.stop - shard.start) * SHAPE["M"]),
+                               "traffic": measured_traffic(dom, n_local * SHAPE["M"]),
                                "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4},3> (9x1 temporal conv forward, "
                                          f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),
                                "flop_per_launch": dom["flops"],
                                "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
                                               for d in kern]}
+        if other:
+            out["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on the host cores")
             out["cpu_baseline"] = cpu_baseline()

@@ -459,3 +459,64 @@ class STBlockFunction(torch.autograd.Function):
                 g = torch.zeros_like(P[n])          # static-adjacency: embedding convs get no gradient
             grads.append(g)
         return (dx, None, None, None, None, None, *grads)
+
+
+class LinearFunction(torch.autograd.Function):
+    """logits = h . W^T + b on the row GEMM (reference: nn.Linear `fc`, mmargcn/agcn.py:177,200): keeps the classifier off
+    hipBLASLt, whose `UserArgs` kernels do not survive HIP-graph replay at small row counts (the 8-clip shard of a
+    strong-scaling run produced wrong logits from the second replay on)."""
+
+    @staticmethod
+    def forward(ctx, h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        n, k = h.shape
+        classes = weight.shape[0]
+        npad = _r4(classes)
+        wt = torch.zeros((1, k, npad), device=h.device, dtype=torch.float32)
+        wt[0, :, :classes] = weight.t()
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(npad, device=h.device, dtype=torch.float32)
+            bp[:classes] = bias
+        hc = h.contiguous()
+        out = torch.empty((n, 1, 1, npad), device=h.device, dtype=torch.float32)
+        ops.rows_gemm(hc.view(n, 1, 1, k), wt, out, K=k, N=npad, bias=bp)
+        ctx.save_for_backward(hc, weight)
+        ctx.has_bias = bias is not None
+        return out.view(n, npad)[:, :classes]
+
+    @staticmethod
+    def backward(ctx, d_out: torch.Tensor):
+        hc, weight = ctx.saved_tensors
+        n, k = hc.shape
+        classes = weight.shape[0]
+        npad = _r4(classes)
+        dl = torch.zeros((n, 1, 1, npad), device=hc.device, dtype=torch.float32)
+        dl.view(n, npad)[:, :classes] = d_out
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w = torch.zeros((1, npad, k), device=hc.device, dtype=torch.float32)
+            w[0, :classes] = weight
+            dh = torch.empty((n, 1, 1, k), device=hc.device, dtype=torch.float32)
+            ops.rows_gemm(dl, w, dh, K=npad, N=k)
+            dh = dh.view(n, k)
+        if ctx.needs_input_grad[1]:
+            gw = ops.rows_wgrad(hc.view(n, 1, 1, k), dl, K=k, N=npad, wide=False)      # (1, k, npad)
+            dw = gw[0, :, :classes].t().contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_sum(dl.view(n, 1, 1, npad), npad)[:classes].contiguous()
+        return dh, dw, db
+
+
+class GroupMeanFunction(torch.autograd.Function):
+    """(G, R, C) -> (G, C) global average pooling on fgcn_group_mean (reference: x.view(N, M, c, -1).mean(3).mean(1),
+    mmargcn/agcn.py:196-197 -- equal-sized groups, so one mean over all M*T'*V rows of a clip)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor):
+        ctx.shape = tuple(x.shape)
+        return ops.group_mean(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, d_out: torch.Tensor):
+        G, R, C = ctx.shape
+        return (d_out / R).unsqueeze(1).expand(G, R, C).contiguous()

@@ -211,6 +211,38 @@ __global__ void col_sum_kernel(const float* x, float* partials, long long rows, 
     }
 }
 
+// ---- global average pooling: out[g][c] = mean over the R rows of group g (agcn.py:196-197, x.mean(3).mean(1)) -----------
+// Two fixed-order stages, no atomics / semaphores (torch's multi-block mean did not survive HIP-graph replay inside the
+// captured step: wrong pooled features from the second replay on at 8 clips).
+__global__ __launch_bounds__(1024) void group_sum_kernel(const float* x, float* partial, int rows, int C, int ld, int splits) {
+    __shared__ float red[16][65];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int g = blockIdx.y, sp = blockIdx.z;
+    const int c = blockIdx.x * 64 + tx;
+    const int per = (rows + splits - 1) / splits;
+    const int r0 = sp * per, r1 = min(r0 + per, rows);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + ty; r < r1; r += 16) s += x[((long long)g * rows + r) * ld + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][tx];
+        partial[((long long)g * splits + sp) * C + c] = a;
+    }
+}
+
+__global__ void group_mean_finish_kernel(const float* partial, float* out, int groups, int C, int splits, float inv_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const int g = i / C, c = i - g * C;
+    float a = 0.f;
+    for (int sp = 0; sp < splits; ++sp) a += partial[((long long)g * splits + sp) * C + c];
+    out[i] = a * inv_rows;
+}
+
 }  // namespace fgcn
 
 using namespace fgcn;
@@ -342,4 +374,23 @@ extern "C" int fgcn_col_sum(const float* x, float* partials, long long rows, int
     hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)fgcn_elem_tiles(rows)), blk, lds, (hipStream_t)stream, x, partials,
                        rows, rows_per_tile_for(rows), C, ld);
     return launch_status("col_sum");
+}
+
+extern "C" int fgcn_group_mean_splits(int groups, int rows) {
+    int splits = 1;
+    while (splits < 32 && (long long)groups * splits < 512 && rows / (splits * 2) >= 64) splits *= 2;
+    return splits;
+}
+
+extern "C" int fgcn_group_mean(const float* x, float* partial, float* out, int groups, int rows, int C, int ld,
+                               void* stream) {
+    FGCN_REQUIRE(x && partial && out && groups > 0 && groups <= 65535 && rows > 0 && C > 0 && ld >= C, FGCN_E_BADARG,
+                 "group_mean: bad argument (groups=%d rows=%d C=%d ld=%d)", groups, rows, C, ld);
+    const int splits = fgcn_group_mean_splits(groups, rows);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)groups, (unsigned)splits), dim3(64, 16), 0, s, x,
+                       partial, rows, C, ld, splits);
+    hipLaunchKernelGGL(group_mean_finish_kernel, dim3((unsigned)cdiv((long long)groups * C, 256)), dim3(256), 0, s, partial,
+                       out, groups, C, splits, 1.f / (float)rows);
+    return launch_status("group_mean");
 }

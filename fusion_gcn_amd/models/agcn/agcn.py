@@ -129,5 +129,5 @@ class Model(nn.Module):
         for layer in (self.l1, self.l2, self.l3, self.l4, self.l5, self.l6, self.l7, self.l8, self.l9, self.l10):
             h = layer(h)
         c_new = h.size(-1)
-        h = h.view(N, M, -1, c_new).mean(2).mean(1)
-        return self.fc(h)
+        h = _base.GroupMeanFunction.apply(h.view(N, -1, c_new))
+        return _base.LinearFunction.apply(h.contiguous(), self.fc.weight, self.fc.bias)   # fc on the row GEMM

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...block import BlockConfig, STBlockFunction, bn_names, pack_weights, param_names
+from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, pack_weights, param_names
 from ...util.partition_strategy import GraphPartitionStrategy
 
 
@@ -247,7 +247,7 @@ class Model(nn.Module):
             h = layer(h)
         # (N*M, T', V, C') -> mean over (T', V) then over persons
         c_new = h.size(-1)
-        h = h.view(N, M, -1, c_new).mean(2).mean(1)
-        if self.fc is not None:
-            h = self.fc(h)
+        h = GroupMeanFunction.apply(h.view(N, -1, c_new))   # mean over persons, frames and joints (equal-sized groups)
+        if self.fc is not None:    # nn.Linear is the parameter container; the arithmetic is the row GEMM
+            h = LinearFunction.apply(h.contiguous(), self.fc.weight, self.fc.bias)
         return h

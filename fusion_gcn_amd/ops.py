@@ -429,6 +429,19 @@ def col_sum(x: torch.Tensor, C: int, coff: int = 0) -> torch.Tensor:
     return reduce_sum(partials, out)
 
 
+def group_mean(x: torch.Tensor) -> torch.Tensor:
+    """(G, R, C) -> (G, C): mean over the R rows of every group (global average pooling), fixed summation order."""
+    ensure_device()
+    _chk(x, "group_mean.x")
+    G, R, C = x.shape
+    lib = _lib.load()
+    splits = lib.fgcn_group_mean_splits(G, R)
+    partial = torch.empty((G * splits, C), device=x.device, dtype=torch.float32)
+    out = torch.empty((G, C), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_group_mean(_p(x), _p(partial), _p(out), G, R, C, C, _stream()), "fgcn_group_mean")
+    return out
+
+
 # ---- fused spatial forward -----------------------------------------------------------------------------------------
 def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
                 Cout: int, stats: bool = True):

@@ -120,6 +120,12 @@ int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K
 int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
                      long long st_tap, long long st_k, long long st_n, int flip, void* stream);
 
+/* Global average pooling in front of the classifier (agcn.py:196-197: mean over frames and joints, then persons):
+ * out[g][c] = mean over the `rows` consecutive rows of group g of x[(g*rows + r)*ld + c].  Two fixed-order stages;
+ * partial: float[groups * fgcn_group_mean_splits(groups, rows)][C]. */
+int fgcn_group_mean_splits(int groups, int rows);
+int fgcn_group_mean(const float* x, float* partial, float* out, int groups, int rows, int C, int ld, void* stream);
+
 /* ---- joint-mixing kernels (the "graph" part: A.X over the K=3 partition adjacencies) ------------------ */
 typedef struct {
     short mat;        /* which V x V matrix of the sample (0..n_mats-1) */

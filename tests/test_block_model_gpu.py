@@ -299,3 +299,59 @@ def test_size_independent_properties_at_headline_shape():
     loss.backward()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_pool_and_classifier_kernels_and_graph_replay():
+    """Global average pooling and fc run on libfgcn (equal to torch.mean / nn.Linear incl. gradients), and a captured
+    forward+backward of the 8-clip headline shard replays to the same logits every time (with torch's multi-block mean
+    in the graph the pooled features were wrong from the second replay on)."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd.block import LinearFunction
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for n, k, classes in ((8, 256, 60), (3, 256, 27), (64, 128, 35)):
+        h = torch.randn(n, k, device=dev, requires_grad=True)
+        w = (torch.randn(classes, k, device=dev) * 0.1).requires_grad_(True)
+        b = torch.randn(classes, device=dev, requires_grad=True)
+        dy = torch.randn(n, classes, device=dev)
+        want = F.linear(h.double(), w.double(), b.double())
+        gh, gw, gb = torch.autograd.grad((want * dy.double()).sum(), (h, w, b))
+        got = LinearFunction.apply(h, w, b)
+        assert float((got.double() - want).norm() / want.norm()) < 3e-6
+        dh, dw, db = torch.autograd.grad((got * dy).sum(), (h, w, b))
+        for a_, b_ in ((dh, gh), (dw, gw), (db, gb)):
+            assert float((a_.double() - b_).norm() / b_.norm()) < 3e-6
+    from fusion_gcn_amd import ops
+    for G, R, C in ((8, 3750, 256), (3, 77, 64), (64, 500, 128), (1, 1, 4)):
+        xs = torch.randn(G, R, C, device=dev)
+        got = ops.group_mean(xs)
+        want = xs.double().mean(1)
+        assert float((got.double() - want).norm() / want.norm()) < 3e-6
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    model = Model((2, 300, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev).train()
+    x = torch.randn(8, 2, 300, 25, 3, device=dev)
+    y = torch.randint(0, 60, (8,), device=dev)
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        out = model(x)
+        F.cross_entropy(out, y).backward()
+        return out
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ref = fwd_bwd().detach().clone()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = fwd_bwd()
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float((static_out.detach() - ref).norm() / ref.norm()) < 1e-6
