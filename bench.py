@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-dp", action="store_true",
+                    help="N > 1 only: check the exchanged gradient buffer of the (graph) step against an eager step")
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -235,6 +237,12 @@ def main():
             loss.backward()
             return loss
 
+        def fwd_bwd_checked():
+            grads.zero()
+            loss = fwd_bwd()
+            torch.cuda.synchronize()
+            return loss.detach()
+
         def step_eager():
             grads.zero()
             loss = fwd_bwd()
@@ -252,10 +260,20 @@ def main():
                     step_eager()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            eager_loss = float(fwd_bwd_checked())
             graph = torch.cuda.CUDAGraph()
             grads.zero()
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
+                if world > 1:
+                    grads.gather()      # the copy into the flat exchange buffer is part of the replayed step
+            # a replayed graph must reproduce the eager loss (parameters do not change): twice, with a sync in between
+            for _ in range(2):
+                graph.replay()
+                torch.cuda.synchronize()
+                got = float(static_loss.detach())
+                if abs(got - eager_loss) > 1e-4 * max(1.0, abs(eager_loss)):
+                    raise RuntimeError(f"graph replay loss {got} != eager loss {eager_loss}")
 
             def step_graph():
                 graph.replay()
@@ -301,7 +319,6 @@ def main():
     if world > 1 and not args.no_other_scaling and args.batch >= world:
         # (no try/except: a rank that skipped a collective would leave the others hanging; an error ends the job loudly)
         n_other = args.batch if args.scaling == "weak" else args.batch * world
-        del step
         x2, y2, n_local2 = resident_shard(n_other)
         step2, mode2 = make_step(x2, y2)
         steps2 = max(args.steps, 10)
@@ -310,6 +327,20 @@ def main():
                  "per_gpu_batch": n_local2, "value": round(n_other * steps2 / el2, 2), "unit": "clips/s",
                  "ms_per_step": round(1e3 * el2 / steps2, 3), "steps": steps2, "launch": mode2}
         del step2, x2, y2
+
+    if args.verify_dp and world > 1:   # after all timed regions
+        # the replayed step must leave the same averaged gradients in the flat buffer as an eager step
+        step()
+        torch.cuda.synchronize()
+        got = grads.flat.clone()
+        grads.zero()
+        F.cross_entropy(model(x), y).backward()
+        grads.all_reduce_mean()
+        torch.cuda.synchronize()
+        err = float((got - grads.flat).norm() / grads.flat.norm())
+        log(f"verify-dp: flat gradient buffer, {mode} step vs eager step: rel-L2 {err:.2e}")
+        if err > 1e-5:
+            raise SystemExit("verify-dp failed")
 
     kern = None if args.no_kernel_timing else time_dominant_kernel(device, n_local * SHAPE["M"])
     if rank == 0:
