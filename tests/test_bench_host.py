@@ -1,0 +1,27 @@
+"""Host-side pieces of bench.py that need no GPU: the algorithmic cost model behind `step_fractions` / `roofline`
+(116.44 GFLOP and 411.42 MB per clip at the headline shape) and the committed PMC traffic record."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_costs_match_the_survey():
+    flops, byts = bench.algorithmic_costs(64)
+    assert abs(flops / 64 / 1e9 - 116.44) < 0.01
+    assert abs(byts / 64 / 1e6 - 411.42) < 0.01
+    f1, b1 = bench.algorithmic_costs(1)
+    assert abs(f1 * 64 - flops) < 1e-6 * flops and abs(b1 * 64 - byts) < 1e-6 * byts      # linear in the clip count
+    # the f32 MFMA roof in clips/s that DESIGN.md quotes
+    assert abs(bench.PEAK_F32_MFMA_TFLOPS * 1e12 / (flops / 64) - 1351) < 5
+
+
+def test_traffic_record_is_for_the_dominant_kernel_shape():
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["conv_halo_fwd"]
+    dom = dict(channels=256, frames=75)
+    assert bench.measured_traffic(dom, 128) == rec["traffic_bytes"] == (2 * rec["fetch_size_kib_raw"] + rec["write_size_kib"]) * 1024
+    assert bench.measured_traffic(dom, 16) is None                      # other batch: not the measured shape
+    assert bench.measured_traffic(dict(channels=64, frames=300), 128) is None
+    assert rec["algorithmic_bytes"] == 4 * 128 * 75 * 25 * 2 * 256
