@@ -192,6 +192,33 @@ def main():
     store["mm22.eval.logits"] = mm(x).detach().numpy()
     mm.train()
     store["mm22.train.logits"] = mm(x).detach().numpy()
+    # ---- (vi-b) the other BASELINE shapes at fixture size: cfg 3 on the NTU graph (V = 25 + 2, M = 2), cfg 4 = MMAct
+    #      COCO-18 graph + 4 IMU joints (V = 22, C = 3, M = 2, 35 classes) and MMAct skeleton-only (V = 18, C = 2)
+    def model_case(tag, model, shape, classes):
+        n = shape[0]
+        x = t64(filler.skeleton_input(f"x.{tag}", shape, empty_second_body=(shape[1] > 1)))
+        labels = torch.from_numpy((filler.uniform(f"y.{tag}", (n,), 0, classes)).astype(np.int64))
+        model.eval()
+        store[f"{tag}.eval.logits"] = model(x).detach().numpy()
+        model.train()
+        logits = model(x)
+        loss = F.cross_entropy(logits, labels)
+        loss.backward()
+        store[f"{tag}.labels"] = labels.numpy()
+        store[f"{tag}.train.logits"] = logits.detach().numpy()
+        store[f"{tag}.train.loss"] = loss.detach().numpy()
+        for name, p in model.named_parameters():
+            store[f"{tag}.gl2.{name}"] = p.grad.norm().numpy()
+
+    for tag, gname, shape, classes, n_imu in (("ntu27", "ntu", (2, 2, 16, 27, 3), 60, 2),
+                                              ("mmact22", "mmact", (2, 2, 16, 22, 3), 35, 4)):
+        m2 = ref_mm.Model({"skeleton": shape[1:]}, classes, gs[gname], mode="skeleton_imu_spatial_fusion",
+                          num_imu_joints=n_imu, imu_enhanced_mode="append_center").double()
+        filler.fill_state_dict(m2.state_dict(), rename=lambda k: k.replace("_model.agcn.", ""))
+        model_case(tag, m2, shape, classes)
+    m3 = ref_agcn.Model((2, 16, 18, 2), 35, gs["mmact"]).double()
+    filler.fill_state_dict(m3.state_dict())
+    model_case("mmact18", m3, (2, 2, 16, 18, 2), 35)
     np.savez(os.path.join(OUT, "mmargcn.npz"), **store)
 
     # ---- (vii) state-dict manifests -------------------------------------------------------------

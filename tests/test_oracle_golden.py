@@ -33,6 +33,12 @@ def adj_for(name):
     if name == "utd_imu2_center":
         return graph_oracle.spatial_partition_stack(
             graph_oracle.imu_fusion_edges(utd.skeleton_edges, 20, "append_center", 2, center_joint=1))
+    if name == "ntu_imu2_center":
+        return graph_oracle.spatial_partition_stack(
+            graph_oracle.imu_fusion_edges(ntu.skeleton_edges, 25, "append_center", 2, center_joint=ntu.center_joint))
+    if name == "mmact_imu4_center":
+        return graph_oracle.spatial_partition_stack(
+            graph_oracle.imu_fusion_edges(mmact.skeleton_edges, 18, "append_center", 4, center_joint=mmact.center_joint))
     raise KeyError(name)
 
 
@@ -176,6 +182,26 @@ def test_mmargcn_spatial_fusion_logits(golden):
     x = t64(filler.skeleton_input("x.mm22", shape))
     assert rel_l2(O.model_forward(x, sd, train=False).numpy(), ref["mm22.eval.logits"]) < TOL
     assert rel_l2(O.model_forward(x, sd, train=True).numpy(), ref["mm22.train.logits"]) < TOL
+
+
+@pytest.mark.parametrize("tag,gname,shape,classes", [("ntu27", "ntu_imu2_center", (2, 2, 16, 27, 3), 60),
+                                                     ("mmact22", "mmact_imu4_center", (2, 2, 16, 22, 3), 35),
+                                                     ("mmact18", "mmact", (2, 2, 16, 18, 2), 35)])
+def test_other_baseline_shapes(golden, tag, gname, shape, classes):
+    """BASELINE configs 3 and 4 at fixture size (NTU graph + 2 IMU joints, V = 27; MMAct COCO-18 + 4 IMU joints, V = 22,
+    35 classes; MMAct skeleton-only, C = 2): logits, loss and every parameter-gradient norm against the reference."""
+    ref = golden("mmargcn.npz")
+    sd = fill_block(O.new_state_dict(shape[1:], classes, adj_for(gname), dtype=torch.float64))
+    x = t64(filler.skeleton_input(f"x.{tag}", shape, empty_second_body=True))
+    labels = torch.from_numpy(ref[f"{tag}.labels"])
+    assert rel_l2(O.model_forward(x, sd, train=False).numpy(), ref[f"{tag}.eval.logits"]) < TOL
+    logits, loss, grads, _ = O.loss_and_grads(x, labels, sd)
+    assert rel_l2(logits.numpy(), ref[f"{tag}.train.logits"]) < TOL
+    assert abs(float(loss) - float(ref[f"{tag}.train.loss"])) < 1e-10
+    for k, g in grads.items():
+        key = f"{tag}.gl2.{k}" if f"{tag}.gl2.{k}" in ref.files else f"{tag}.gl2._model.agcn.{k}"   # mmargcn wraps the AGCN
+        want = float(ref[key])
+        assert abs(float(g.norm()) - want) <= 1e-8 * want + 1e-11, k
 
 
 def test_state_dict_manifest_matches_reference():
