@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", choices=("f32", "bf16"), default="f32",
+                    help="f32: the headline parity path; bf16: BASELINE config 5 (bf16 MFMA operands, f32 accumulation)")
     ap.add_argument("--verify-dp", action="store_true",
                     help="N > 1 only: check the exchanged gradient buffer of the (graph) step against an eager step")
     ap.add_argument("--no-other-scaling", action="store_true",
@@ -212,6 +214,8 @@ def main():
         kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
         print(json.dumps({"kernel": "conv_halo_kernel<4,3> forward, 256 channels", **kern[0]}), flush=True)
         return
+    from fusion_gcn_amd import ops as _ops
+    _ops.set_math_mode(args.math)
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
     model = build_model(device)
     broadcast_parameters(model)
@@ -351,7 +355,9 @@ def main():
             "metric": "clips/sec (N,C,T,V,M)=(64,3,300,25,2) fwd+bwd",
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32" if args.math == "f32" else "bf16 MFMA operands, f32 accumulate / storage / statistics",
+            "data": "synthetic",
             "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
                                    "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
                                    % n_global,

@@ -48,6 +48,8 @@ SIGNATURES = {
     "fgcn_last_error": (C.c_char_p, []),
     "fgcn_check_device": (_I, []),
     "fgcn_set_tuning": (_I, [_I, _I]),
+    "fgcn_set_math_mode": (_I, [_I]),
+    "fgcn_get_math_mode": (_I, []),
     "fgcn_rows_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_rows_gemm_tiles": (_I, [_LL]),
     "fgcn_tconv_halo_tiles": (_I, [_I, _I, _I, _I]),

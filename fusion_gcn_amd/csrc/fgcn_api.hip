@@ -10,7 +10,18 @@ char* error_buffer() {
 }
 static int g_tuning[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
+static int g_math_mode = FGCN_MATH_F32;
+int math_mode() { return g_math_mode; }
 }  // namespace fgcn
+
+extern "C" int fgcn_set_math_mode(int mode) {
+    if (mode != FGCN_MATH_F32 && mode != FGCN_MATH_BF16)
+        return fgcn::fail(FGCN_E_BADARG, "set_math_mode: %d is neither FGCN_MATH_F32 nor FGCN_MATH_BF16", mode);
+    fgcn::g_math_mode = mode;
+    return FGCN_OK;
+}
+
+extern "C" int fgcn_get_math_mode(void) { return fgcn::g_math_mode; }
 
 extern "C" int fgcn_set_tuning(int key, int value) {
     if (key < 0 || key >= 8) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);

@@ -34,7 +34,8 @@ struct RowsGemmP {
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
 // DB = double-buffered LDS (one barrier per K chunk instead of two, at twice the LDS footprint).
-template <int MT, int NT, bool DB>
+// BF: FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments are read)
+template <int MT, int NT, bool DB, bool BF>
 __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kernel(RowsGemmP p) {
     constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
     constexpr int AR = 4 * MT;                         // A-tile rows staged per thread
@@ -144,15 +145,29 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
             f32x4 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(arow + mt * 32 * AS + 8 * q);
+            if constexpr (BF) {
+                s16x4 ap[MT], bp[NT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bv[NT];
+                for (int mt = 0; mt < MT; ++mt) ap[mt] = pack_bf16(av[mt]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bcol[(8 * q + e) * BN + nt * 32];
+                for (int nt = 0; nt < NT; ++nt)
+                    bp[nt] = pack_bf16(bcol[(8 * q + 0) * BN + nt * 32], bcol[(8 * q + 1) * BN + nt * 32],
+                                       bcol[(8 * q + 2) * BN + nt * 32], bcol[(8 * q + 3) * BN + nt * 32]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[mt][e], bv[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_bf16(ap[mt], bp[nt], acc[mt][nt]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bcol[(8 * q + e) * BN + nt * 32];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(av[mt][e], bv[nt], acc[mt][nt]);
+                }
             }
         }
     }
@@ -241,6 +256,7 @@ struct WgradP {
     int tiles, nsplit, per_xcd;   // per_xcd > 0: 1-D grid, XCD-aware order (see the kernel)
 };
 
+template <bool BF>
 __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
     constexpr int BR = 64, TK = 64, TN = 64;
     __shared__ __attribute__((aligned(16))) float As[BR * TK];
@@ -343,10 +359,21 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(WgradP p) {
             advance();
             load_stage();
         }
-        const float* ap = &As[(lane >> 5) * TK + wk * 32 + (lane & 31)];
-        const float* gp = &Gs[(lane >> 5) * TN + wn * 32 + (lane & 31)];
+        if constexpr (BF) {   // 8 rows per MFMA: lane half h contracts rows 8g + 4h + (0..3)
+            const float* ap = &As[4 * (lane >> 5) * TK + wk * 32 + (lane & 31)];
+            const float* gp = &Gs[4 * (lane >> 5) * TN + wn * 32 + (lane & 31)];
+#pragma unroll 4
+            for (int g8 = 0; g8 < BR / 8; ++g8) {
+                const float* a = ap + 8 * g8 * TK;
+                const float* g = gp + 8 * g8 * TN;
+                acc = mfma_bf16(pack_bf16(a[0], a[TK], a[2 * TK], a[3 * TK]), pack_bf16(g[0], g[TN], g[2 * TN], g[3 * TN]), acc);
+            }
+        } else {
+            const float* ap = &As[(lane >> 5) * TK + wk * 32 + (lane & 31)];
+            const float* gp = &Gs[(lane >> 5) * TN + wn * 32 + (lane & 31)];
 #pragma unroll 8
-        for (int s = 0; s < BR / 2; ++s) acc = mfma32(ap[2 * s * TK], gp[2 * s * TN], acc);
+            for (int s = 0; s < BR / 2; ++s) acc = mfma32(ap[2 * s * TK], gp[2 * s * TN], acc);
+        }
     }
 
     const int n = n0 + wn * 32 + (lane & 31);
@@ -482,7 +509,12 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
         p.per_xcd = -1;
         grid = dim3((unsigned)p.tiles_n, (unsigned)tiles_m);
     }
-#define FGCN_LAUNCH(MT_, NT_, DB_) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_>), grid, dim3(256), 0, s, p)
+    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
+#define FGCN_LAUNCH(MT_, NT_, DB_)                                                                         \
+    do {                                                                                                   \
+        if (bf) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true>), grid, dim3(256), 0, s, p);     \
+        else hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, false>), grid, dim3(256), 0, s, p);       \
+    } while (0)
     if (mt == 2) {
         if (nt == 1) { if (db) FGCN_LAUNCH(2, 1, true); else FGCN_LAUNCH(2, 1, false); }
         else { if (db) FGCN_LAUNCH(2, 2, true); else FGCN_LAUNCH(2, 2, false); }
@@ -525,13 +557,17 @@ extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
     p.tiles = (int)cdiv(K, 64) * p.tilesN;
     p.nsplit = nsplit;
     const long long total = (long long)p.tiles * map.taps * nsplit;
+    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
     if (!(fgcn::tuning(5) & 4) && total < (1ll << 30)) {   // measured: -7 % at 64 channels, neutral above
         p.per_xcd = (int)cdiv(total, 8);
-        hipLaunchKernelGGL(rows_wgrad_kernel, dim3((unsigned)(p.per_xcd * 8)), dim3(256), 0, (hipStream_t)stream, p);
+        const dim3 grid((unsigned)(p.per_xcd * 8));
+        if (bf) hipLaunchKernelGGL(rows_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(rows_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         p.per_xcd = 0;
-        dim3 grid((unsigned)p.tiles, (unsigned)map.taps, (unsigned)nsplit);
-        hipLaunchKernelGGL(rows_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+        const dim3 grid((unsigned)p.tiles, (unsigned)map.taps, (unsigned)nsplit);
+        if (bf) hipLaunchKernelGGL(rows_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(rows_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     return launch_status("rows_wgrad");
 }

@@ -49,7 +49,8 @@ __device__ __forceinline__ f32x4 sp_load4(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int CT_IN, int CT_OUT>
+// BF: FGCN_MATH_BF16 for step 2 (the Cin x Cout contraction); step 1 (the <= 32-joint mixing) stays f32
+template <int CT_IN, int CT_OUT, bool BF>
 __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
     constexpr int WROW = CT_OUT * 32;                 // padded Cout
     constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond num_records: the load returns 0
@@ -114,7 +115,9 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
     };
 
     float xcur[16], xnxt[16];
-    constexpr bool PREFETCH_W = CT_OUT <= 4;   // at 256 outputs a second weight set measured slower (1.33 -> 1.47 ms)
+    // at 256 outputs a second weight set measured slower in f32 (1.33 -> 1.47 ms); with bf16 MFMAs (8 per weight group instead
+    // of 32) the un-prefetched loads are pure exposed latency (2.4 ms), so that mode always prefetches
+    constexpr bool PREFETCH_W = CT_OUT <= 4 || BF;
     f32x4 wcur[CT_OUT], wnxt[PREFETCH_W ? CT_OUT : 1];
     load_x(t0 + wave, 0, xcur);
     if constexpr (PREFETCH_W) load_w(0, 0, 0, wcur);
@@ -154,10 +157,16 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
                         } else {
                             load_w(ci, k, g, wcur);     // 256 output channels: no registers left for a second set
                         }
+                        if constexpr (BF) {
+                            const s16x4 bp = pack_bf16(agg[4 * g], agg[4 * g + 1], agg[4 * g + 2], agg[4 * g + 3]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                            for (int ot = 0; ot < CT_OUT; ++ot) acc[ot] = mfma_bf16(pack_bf16(wcur[ot]), bp, acc[ot]);
+                        } else {
 #pragma unroll
-                            for (int ot = 0; ot < CT_OUT; ++ot) acc[ot] = mfma32(wcur[ot][e], agg[4 * g + e], acc[ot]);
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int ot = 0; ot < CT_OUT; ++ot) acc[ot] = mfma32(wcur[ot][e], agg[4 * g + e], acc[ot]);
+                        }
                         if constexpr (PREFETCH_W) {
 #pragma unroll
                             for (int ot = 0; ot < CT_OUT; ++ot) wcur[ot] = wnxt[ot];
@@ -244,11 +253,16 @@ static void launch_spatial(const SpatialP& p, hipStream_t s) {
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
     static bool lds_opt_in = false;  // once per instantiation (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in && lds > 48 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO>), grid, dim3(256), lds, s, p);
+    if (fgcn::math_mode() == FGCN_MATH_BF16)
+        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, true>), grid, dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, false>), grid, dim3(256), lds, s, p);
 }
 
 template <int CI>

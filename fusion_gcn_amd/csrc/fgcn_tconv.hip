@@ -48,7 +48,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // MINB = workgroups per CU the register allocation aims at (launch-bounds hint; fgcn_set_tuning key 4 picks 2 or 3)
-template <int NT, int MINB>
+// BF: FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments are read)
+template <int NT, int MINB, bool BF>
 __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,10 +156,16 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
             }
             a1 = a_read(it + 1, ok1);
             if (!ok0) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                const s16x4 ap = pack_bf16(a0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ap, pack_bf16(b0[nt]), acc[nt]);
+            } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a0[e], b0[nt][e], acc[nt]);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a0[e], b0[nt][e], acc[nt]);
+            }
             if (it + 2 < IT) {
                 const unsigned so = w_soff(it + 2, kc);
 #pragma unroll
@@ -166,10 +173,16 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
                 a0 = a_read(it + 2, ok0);
             }
             if (!ok1) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                const s16x4 ap = pack_bf16(a1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ap, pack_bf16(b1[nt]), acc[nt]);
+            } else {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a1[e], b1[nt][e], acc[nt]);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a1[e], b1[nt][e], acc[nt]);
+            }
         }
     }
 
@@ -304,14 +317,17 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     static bool lds_opt_in = false;  // once per process (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in) {               // V > 25 needs more than the default dynamic-LDS limit (gfx950: 160 KiB per CU)
         const int max_lds = 32 * HALO_MAX_STAGE * HAS * (int)sizeof(float);
-#define FGCN_HALO_ATTR(NT_, MB_)                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_>), \
+#define FGCN_HALO_ATTR(NT_, MB_)                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, false>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, true>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
         FGCN_HALO_ATTR(2, 2); FGCN_HALO_ATTR(2, 3); FGCN_HALO_ATTR(4, 2); FGCN_HALO_ATTR(4, 3);
 #undef FGCN_HALO_ATTR
         lds_opt_in = true;
     }
     const bool three = fgcn::tuning(4) == 0;   // 3 workgroups per CU measured faster (64 channels: 0.73 -> 0.63 ms)
+    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
     p.tiles_m = (int)tiles;
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
@@ -320,12 +336,18 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         p.per_xcd = (int)cdiv(tiles * p.tiles_n, 8);
         grid = dim3((unsigned)(p.per_xcd * 8));
     }
+#define FGCN_HALO_LAUNCH(NT_, MB_)                                                                           \
+    do {                                                                                                     \
+        if (bf) hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, true>), grid, dim3(256), lds, s, p);          \
+        else hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, false>), grid, dim3(256), lds, s, p);            \
+    } while (0)
     if (N <= 64) {
-        if (three) hipLaunchKernelGGL((conv_halo_kernel<2, 3>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((conv_halo_kernel<2, 2>), grid, dim3(256), lds, s, p);
+        if (three) FGCN_HALO_LAUNCH(2, 3);
+        else FGCN_HALO_LAUNCH(2, 2);
     } else {
-        if (three) hipLaunchKernelGGL((conv_halo_kernel<4, 3>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((conv_halo_kernel<4, 2>), grid, dim3(256), lds, s, p);
+        if (three) FGCN_HALO_LAUNCH(4, 3);
+        else FGCN_HALO_LAUNCH(4, 2);
     }
+#undef FGCN_HALO_LAUNCH
     return launch_status("tconv_halo");
 }

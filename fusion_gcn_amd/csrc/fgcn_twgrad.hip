@@ -33,7 +33,8 @@ struct TWgradP {
 // Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`: one wave instruction drops 1 KiB = 8 window rows x 32 channels, or
 // 1024/TN g rows, straight into LDS; rows / channels that do not exist are out-of-range buffer reads = zeros): no
 // staging registers, which is what lets 9 x 16 accumulator registers and two workgroups per CU coexist.
-template <int NTAP, int TN>
+// BF: FGCN_MATH_BF16 -- 8 rows per bf16 MFMA (lane half h contracts rows 8g + 4h + (0..3)), operands rounded as read
+template <int NTAP, int TN, bool BF>
 __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     constexpr int TW_BR = 8192 / TN;                  // rows per stage: 64 (TN 128) or 128 (TN 64), 32 KiB of g
     constexpr int NSUB = TN / 32, NPART = 4 / NSUB;   // column tiles, row parts of a stage
@@ -100,11 +101,26 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
         }
         __syncthreads();                                             // drains the DMA (vmcnt(0)) and publishes the stage
         // ---- NTAP independent MFMA chains over this wave's rows of the stage ----------------------------------------
-#pragma unroll 4
-        for (int s = 0; s < STEPS; ++s) {
-            const float gv = gbase[2 * s * TN];
+        if constexpr (BF) {
+            const float* ab = abase + 3 * h * 32;          // rows 4h + e instead of h
+            const float* gb = gbase + 3 * h * TN;
+#pragma unroll 2
+            for (int g8 = 0; g8 < STEPS / 4; ++g8) {
+                const float* g = gb + 8 * g8 * TN;
+                const s16x4 gp = pack_bf16(g[0], g[TN], g[2 * TN], g[3 * TN]);
 #pragma unroll
-            for (int j = 0; j < NTAP; ++j) acc[j] = mfma32(abase[2 * s * 32 + j * tapstride], gv, acc[j]);
+                for (int j = 0; j < NTAP; ++j) {
+                    const float* a = ab + 8 * g8 * 32 + j * tapstride;
+                    acc[j] = mfma_bf16(pack_bf16(a[0], a[32], a[64], a[96]), gp, acc[j]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int s = 0; s < STEPS; ++s) {
+                const float gv = gbase[2 * s * TN];
+#pragma unroll
+                for (int j = 0; j < NTAP; ++j) acc[j] = mfma32(abase[2 * s * 32 + j * tapstride], gv, acc[j]);
+            }
         }
     }
 
@@ -140,14 +156,21 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
     static bool opt_in = false;   // once per instantiation; not a stream operation (stays out of graph captures)
     if (!opt_in) {
         const int max_lds = 160 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define FGCN_TW_ATTR(TN_, BF_)                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, TN_, BF_>),  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
+        FGCN_TW_ATTR(64, false); FGCN_TW_ATTR(64, true); FGCN_TW_ATTR(128, false); FGCN_TW_ATTR(128, true);
+#undef FGCN_TW_ATTR
         opt_in = true;
     }
-    if (N <= 64) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128>), grid, dim3(256), lds, s, p);
+    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
+    if (N <= 64) {
+        if (bf) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64, false>), grid, dim3(256), lds, s, p);
+    } else {
+        if (bf) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128, false>), grid, dim3(256), lds, s, p);
+    }
 }
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,

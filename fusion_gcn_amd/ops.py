@@ -6,6 +6,7 @@ here computes anything in torch: a missing library or a non-gfx950 device raises
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -14,6 +15,34 @@ from . import _lib
 from ._lib import GramItem, MixItem, MixTerm, TMap, check
 
 TMAP_POINTWISE = (1, 1, 0, 0, 1)
+
+
+MATH_MODES = {"f32": 0, "bf16": 1}     # FGCN_MATH_F32 / FGCN_MATH_BF16 (include/fgcn.h)
+
+
+def set_math_mode(mode: str) -> None:
+    """Arithmetic of the convolution / GEMM kernels, process-wide: "f32" (default, the parity path) or "bf16" (BASELINE
+    config 5: operands rounded to bfloat16 as the MFMA fragments are formed, float32 accumulation; everything in HBM,
+    BatchNorm statistics, softmax and the joint mixing stay float32)."""
+    if mode not in MATH_MODES:
+        raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16)")
+    check(_lib.load().fgcn_set_math_mode(MATH_MODES[mode]), "fgcn_set_math_mode")
+
+
+def get_math_mode() -> str:
+    return {v: k for k, v in MATH_MODES.items()}[_lib.load().fgcn_get_math_mode()]
+
+
+@contextlib.contextmanager
+def math_mode(mode: str):
+    """with ops.math_mode("bf16"): forward AND backward of the step -- the counterpart of the reference's
+    MixedPrecisionStep (session/procedures/step.py:55-78, autocast around model(x)); no loss scaling is needed."""
+    prev = get_math_mode()
+    set_math_mode(mode)
+    try:
+        yield
+    finally:
+        set_math_mode(prev)
 
 
 def conv_tmap(kt: int, stride: int) -> Tuple[int, int, int, int, int]:
@@ -160,7 +189,9 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
     lib = _lib.load()
     ta, tb, tc, td = tmap[1:]
     if wide is None:
-        wide = K >= 384      # measured: +2-3 % at K = 384 / 768, -10..-25 % for narrower inputs (tools/kbench.py wgrad)
+        # measured (tools/kbench.py wgrad): f32 +2-3 % at K = 384 / 768, -10..-25 % for narrower inputs; bf16 mode: faster or
+        # equal at every width (the per-tap kernel's two LDS dwords per MFMA become the limit)
+        wide = K >= 384 or get_math_mode() == "bf16"
     if wide and taps == 1 and tc == 0 and td == 1 and ta >= 1 and K % 32 == 0 and (T_g - 1) * ta < T_a:
         # 1x1 (optionally strided) convolution: one accumulator per 32-channel chunk, every g fragment feeds 2-6 MFMAs
         chunks = lib.fgcn_pw_wgrad_chunks(K, N)

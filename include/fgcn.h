@@ -43,6 +43,18 @@ int fgcn_check_device(void);
  *        double-buffered LDS.  key 1: wider N: 0 = two barriers per K chunk (default), 1 = double-buffered LDS. */
 int fgcn_set_tuning(int key, int value);
 
+/* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
+ * session/procedures/step.py:55-78, which wraps model(x) in autocast):
+ *   FGCN_MATH_F32  (default) v_mfma_f32_32x32x2_f32 on float32 operands -- the parity path (<= 1e-3 rel);
+ *   FGCN_MATH_BF16 (BASELINE config 5) operands rounded to bfloat16 (round-to-nearest-even) as the fragments are
+ *                  formed, v_mfma_f32_32x32x8_bf16 with float32 accumulation; tensors in HBM, BatchNorm statistics,
+ *                  softmax, the joint mixing and every reduction stay float32.  Different tolerance contract:
+ *                  logits <= 1e-2 rel, gradient cosine >= 0.98 against the f32 path. */
+#define FGCN_MATH_F32 0
+#define FGCN_MATH_BF16 1
+int fgcn_set_math_mode(int mode);
+int fgcn_get_math_mode(void);
+
 /* Temporal index map shared by the row GEMMs: for output frame `to` and tap `j`
  *     num = to*ta + j*tb + tc ;  valid iff num >= 0, num % td == 0 and num/td < T_in ;  ti = num/td.
  * forward conv (kernel kt, stride s, pad p): ta=s tb=1 tc=-p td=1 ; its data gradient: ta=1 tb=-1 tc=p td=s. */

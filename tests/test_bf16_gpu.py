@@ -1,0 +1,153 @@
+"""BASELINE config 5: the bf16-operand mode of the convolution / GEMM kernels (FGCN_MATH_BF16).
+
+Kernel level: the result must equal the float64 product of the bf16-ROUNDED operands (same rounding, f32 accumulation),
+so the tolerance stays tight.  Model level: the different contract SURVEY.md sets for bf16 (the reference under
+torch.autocast(bfloat16) deviates 3.4e-3 on logits and 1.7e-1 on the flat gradient from its own f32 run): logits <= 1e-2
+rel, loss <= 1e-2 abs, gradient cosine >= 0.98 against the f32 path on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import filler
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5          # f32 accumulation of exactly representable products
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def bf(x):
+    """round to bfloat16 (RNE), back to float64"""
+    return x.float().to(torch.bfloat16).double()
+
+
+def gpu(x):
+    return x.float().to(dev()).contiguous()
+
+
+@pytest.fixture(autouse=True)
+def _bf16_mode():
+    from fusion_gcn_amd import ops
+    with ops.math_mode("bf16"):
+        yield
+    assert ops.get_math_mode() == "f32"
+
+
+def conv_ref(x, w, kt, s, T_out, bias=None):
+    """x (B,T,V,K), w (kt,K,N): temporal conv, padding (kt-1)//2, stride s"""
+    B, T, V, K = x.shape
+    pad = (kt - 1) // 2
+    out = torch.zeros(B, T_out, V, w.shape[2], dtype=torch.float64)
+    for j in range(kt):
+        for to in range(T_out):
+            ti = to * s + j - pad
+            if 0 <= ti < T:
+                out[:, to] += x[:, ti] @ w[j]
+    return out if bias is None else out + bias
+
+
+@pytest.mark.parametrize("B,T,V,K,N,kt,s", [(2, 20, 25, 64, 64, 9, 1), (2, 21, 25, 64, 128, 9, 2), (3, 10, 18, 128, 96, 1, 1),
+                                            (2, 9, 27, 4, 64, 1, 1), (1, 7, 5, 40, 36, 3, 1)])
+def test_rows_gemm_bf16(B, T, V, K, N, kt, s):
+    from fusion_gcn_amd import ops
+    T_out = (T - 1) // s + 1
+    x, w, b = rnd(B, T, V, K, seed=1), rnd(kt, K, N, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    want = conv_ref(bf(x), bf(w), kt, s, T_out, b)
+    out = torch.empty(B, T_out, V, N, device=dev())
+    part = ops.rows_gemm(gpu(x), gpu(w), out, K=K, N=N, tmap=ops.conv_tmap(kt, s), bias=gpu(b), stats=True)
+    assert rel_l2(out.cpu().numpy(), want.numpy()) < TOL
+    assert rel_l2(part.double().sum(0)[0].cpu().numpy(), want.reshape(-1, N).sum(0).numpy()) < 1e-4
+    # and it is NOT the f32 result: the operands really are rounded
+    assert rel_l2(out.cpu().numpy(), conv_ref(x, w, kt, s, T_out, b).numpy()) > 1e-4
+
+
+@pytest.mark.parametrize("B,T,V,C,O", [(3, 20, 25, 64, 64), (2, 13, 18, 128, 256), (2, 9, 27, 64, 128)])
+def test_halo_conv_bf16_forward_and_data_gradient(B, T, V, C, O):
+    from fusion_gcn_amd import block, ops
+    wt = rnd(9, C, O, seed=4, scale=(9 * C) ** -0.5)
+    W = {"t": gpu(wt), "t_t": gpu(wt.permute(0, 2, 1))}
+    W["t4"], W["t_t4"] = ops.pack_k4(W["t"]), ops.pack_k4(W["t_t"])
+    x, b = rnd(B, T, V, C, seed=5), rnd(O, seed=6)
+    u = torch.empty(B, T, V, O, device=dev())
+    block.temporal_fwd(gpu(x), u, W, gpu(b), 9, 1, stats=True)
+    assert rel_l2(u.cpu().numpy(), conv_ref(bf(x), bf(wt), 9, 1, T, b).numpy()) < TOL
+    du = rnd(B, T, V, O, seed=7)
+    dg = torch.empty(B, T, V, C, device=dev())
+    block.temporal_dgrad(gpu(du), dg, W, 9, 1)
+    want = conv_ref(bf(du), bf(wt.flip(0).permute(0, 2, 1)), 9, 1, T)          # data gradient = conv with flipped W^T
+    assert rel_l2(dg.cpu().numpy(), want.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,T,V,K,N,kt,s", [(3, 20, 25, 64, 64, 9, 1), (2, 21, 25, 64, 128, 9, 2), (2, 13, 18, 128, 256, 9, 1),
+                                            (2, 30, 25, 192, 64, 1, 1), (1, 12, 25, 768, 256, 1, 1)])
+def test_weight_gradients_bf16(B, T, V, K, N, kt, s):
+    from fusion_gcn_amd import ops
+    T_out = (T - 1) // s + 1
+    pad = (kt - 1) // 2
+    a, g = rnd(B, T, V, K, seed=8), rnd(B, T_out, V, N, seed=9)
+    ab, gb = bf(a), bf(g)
+    want = torch.zeros(kt, K, N, dtype=torch.float64)
+    for j in range(kt):
+        for to in range(T_out):
+            ti = to * s + j - pad
+            if 0 <= ti < T:
+                want[j] += torch.einsum("bvk,bvn->kn", ab[:, ti], gb[:, to])
+    if kt > 1:
+        got = ops.tconv_wgrad(gpu(a), gpu(g), taps=kt, stride=s)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-4
+    for wide in ((False, True) if kt == 1 else (False,)):
+        got = ops.rows_wgrad(gpu(a), gpu(g), K=K, N=N, tmap=ops.conv_tmap(kt, s), wide=wide)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("V,cin,cout", [(25, 64, 64), (18, 64, 128), (27, 128, 256), (25, 4, 64)])
+def test_fused_spatial_forward_bf16(V, cin, cout):
+    """Step 1 (x . A^_k) stays f32; its result and the conv_d weights are rounded for step 2."""
+    from fusion_gcn_amd import ops
+    B, T = 2, 6
+    x, a = rnd(B, T, V, cin, seed=10), rnd(B, 3, V, V, seed=11, scale=0.3)
+    wd, bias = rnd(3 * cin, cout, seed=12, scale=(3 * cin) ** -0.5), rnd(cout, seed=13)
+    agg = torch.einsum("btvc,bkvw->btwkc", x.float().double(), a.float().double()).reshape(B, T, V, 3 * cin)
+    want = bf(agg) @ bf(wd) + bias
+    y, _ = ops.spatial_fwd(gpu(x), gpu(a), ops.pack_k4(gpu(wd).unsqueeze(0))[0], gpu(bias), Cin=cin, Cout=cout, stats=True)
+    # agg is formed in f32 on the GPU and in f64 here: a handful of values round to the neighbouring bf16
+    assert rel_l2(y.cpu().numpy(), want.numpy()) < 2e-3
+
+
+def test_config5_model_contract():
+    """cfg-2 shape at fixture size (N=2, M=2, T=32, V=25), train mode: bf16 mode against the f32 mode of the same model."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    shape, classes = (2, 2, 32, 25, 3), 60
+    model = Model(shape[1:], classes, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint))
+    filler.fill_state_dict(model.state_dict())
+    model = model.to(dev()).train()
+    x = torch.from_numpy(filler.skeleton_input("x.cfg2_small", shape, empty_second_body=True)).float().to(dev())
+    y = torch.from_numpy(filler.uniform("y.cfg2_small", (shape[0],), 0, classes).astype(np.int64)).to(dev())
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        logits = model(x)
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        return logits.detach().clone(), float(loss.detach()), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    lg_b, loss_b, g_b = run()                       # bf16 (autouse fixture)
+    with ops.math_mode("f32"):
+        lg_f, loss_f, g_f = run()
+    e_logits = float((lg_b - lg_f).norm() / lg_f.norm())
+    cos = float(torch.dot(g_b, g_f) / (g_b.norm() * g_f.norm()))
+    print(f"config 5: logits rel-L2 {e_logits:.2e}, loss {loss_b:.5f} vs {loss_f:.5f}, gradient cosine {cos:.4f}")
+    assert e_logits < 1e-2 and abs(loss_b - loss_f) < 1e-2 and cos > 0.98
+    assert e_logits > 1e-5                          # the mode really changes the arithmetic

@@ -181,11 +181,14 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
+    ap.add_argument("--math", default="f32", choices=("f32", "bf16"), help="fgcn_set_math_mode")
     args = ap.parse_args()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         _lib.load().fgcn_set_tuning(int(k), int(v))
         print(f"-- tuning {k} = {v}")
+    ops.set_math_mode(args.math)
+    print(f"-- math mode {args.math}")
     fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
