@@ -155,6 +155,7 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
+FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
 
 
@@ -407,8 +408,11 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     else:
         dagg = new(B, T, V, c3)
         ops.rows_gemm(dy, W["d_t"], dagg, K=cout, N=c3)
-        mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
-        part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
+        if FUSED_DAGG and x.shape[3] == cin:
+            part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live)     # dx and dA^ from one pass over dagg
+        else:
+            mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
+            part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     dx_live = True
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
     db = torch.empty_like(P["gcn1.adj_b"])

@@ -329,6 +329,142 @@ __global__ __launch_bounds__(256, 3) void joint_gram_kernel(GramP p) {
     }
 }
 
+// ---- fused consumer of dagg: dx (+)= sum_k dagg_k . A^_k^T  AND  dA^_k = x^T . dagg_k in one pass ---------------------------
+// The unfused pair (joint_mix_vec for dx, joint_gram for dA^) read the 3-activation-wide dagg twice.  Here a wave takes a
+// frame, walks it in 32-channel chunks and parks the x chunk and each subset's dagg chunk once in wave-private LDS tiles
+// ([32 joints][32 + 4], whole 128-byte lines per load instruction); the gram reads the tiles joint-per-lane
+// (16-byte fragments = 4 k-steps), the mix reads the same dagg tile channel-per-lane.  No workgroup barrier in the loop.
+struct DaggP {
+    const float* x;
+    const float* dagg;
+    const float* mats;
+    float* dx;
+    float* partial;
+    int B, T, V, C, ld_x, ld_d, ld_dx, n_sub, mats_batched, t_chunk, accumulate;
+    unsigned x_bytes, d_bytes;
+};
+
+constexpr int DTS = 36;   // tile row stride: 16-byte reads of 8 consecutive rows hit 32 distinct banks
+
+template <int KS>
+__global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* img = dsm;                                  // [3][k = in joint w][i = out joint v] = A^_k[v][w]
+    float* tiles = dsm + 3 * IMG;                      // [4 waves][2][32][DTS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V, C = p.C, NS = p.n_sub;
+    float* xt = tiles + wave * 2 * 32 * DTS;
+    float* dt = xt + 32 * DTS;
+
+    const float* msrc = p.mats + (p.mats_batched ? (long long)n * NS * V * V : 0);
+    for (int e = tid; e < 3 * IMG; e += 256) {
+        const int k = e >> 10, w = (e >> 5) & 31, v = e & 31;
+        img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+    }
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dagg, 0, p.d_bytes, 0x00020000);
+    // dx rows of this workgroup's frames: offsets relative to frame t0 (no tensor-size limit on dx)
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dx + ((long long)n * p.T + t0) * V * p.ld_dx), 0, (unsigned)((t1 - t0) * V * p.ld_dx) * 4u, 0x00020000);
+
+    // staging: lane -> (row = lane / 8 + 8 * pass, 16-byte group lane % 8); all 32 rows are written (absent joints and
+    // channels load zeros), so the tiles never hold stale data
+    const int srow = lane >> 3, sg = lane & 7;
+    auto stage = [&](const __amdgpu_buffer_rsrc_t& r, unsigned frow_bytes, int ld, int c, int cw, float* tile) {
+        f32x4 v[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 8 * ps + srow;
+            const bool ok = row < V && 4 * sg < cw;
+            v[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  r, ok ? frow_bytes + (unsigned)(row * ld + c + 4 * sg) * 4u : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(&tile[(8 * ps + srow) * DTS + 4 * sg]) = v[ps];
+    };
+
+    f32x16 accg[3] = {zero16(), zero16(), zero16()};
+    const float* xa = xt + l31 * DTS + 4 * h;          // gram fragments: lane = joint
+    const float* db = dt + l31 * DTS + 4 * h;
+    const float* dm = dt + h * DTS + l31;              // mix B operand: lane = channel, joints 2s + h
+    const float* am = img + h * 32 + l31;              // mix A operand: image row k = w = 2s + h, lane = out joint v
+    const int u0 = 4 * h;                              // accumulator register r holds out joint (r&3) + 8(r>>2) + 4h
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const unsigned row0 = (unsigned)((n * p.T + t) * V);
+        const unsigned fx = row0 * (unsigned)p.ld_x * 4u, fd = row0 * (unsigned)p.ld_d * 4u;
+        for (int c0 = 0; c0 < C; c0 += 32) {
+            const int cw = min(32, C - c0);
+            stage(rx, fx, p.ld_x, c0, cw, xt);
+            f32x16 accx = zero16();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k < NS) {                          // wave-uniform
+                    stage(rd, fd, p.ld_d, k * C + c0, cw, dt);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {      // dA^_k += x chunk . dagg_k chunk^T (channels 8q + 4h + e)
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(xa + 8 * q);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(db + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accg[k] = mfma32(av[e], bv[e], accg[k]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)       // dx chunk += A^_k . dagg_k chunk (joints 2s + h)
+                        accx = mfma32(am[k * IMG + s * 64], dm[2 * s * DTS], accx);
+                }
+            }
+            // dx chunk: rows v in the registers, 32 channels on the lanes
+            const int c = c0 + l31;
+            const unsigned coff = c < C ? (unsigned)(((t - t0) * V + u0) * p.ld_dx + c) * 4u : OOB;
+            const unsigned rstep = (unsigned)p.ld_dx * 4u;
+            float old[16];
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           rdx, (coff != OOB && u0 + dr < V) ? coff + dr * rstep : OOB, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (dr >= 2 * KS) continue;            // compile-time: register r only holds padding joints
+                const float val = accx[r] + old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdx,
+                                                      (coff != OOB && u0 + dr < V) ? coff + dr * rstep : OOB, 0, 0);
+            }
+        }
+    }
+    // deterministic cross-wave sum of the gram accumulators (the tiles are free now: reuse them as [4 waves][1024])
+    const int nchunk = gridDim.x;
+    float* red = tiles;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < NS) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = accg[k][r];
+            __syncthreads();
+            float* dst = p.partial + (((long long)n * nchunk + chunk) * NS + k) * 1024;
+            for (int e = tid; e < 1024; e += 256) {
+                const float sum = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+                const int r = e >> 6, l = e & 63;
+                dst[acc_row(r, l) * 32 + (l & 31)] = sum;
+            }
+        }
+    }
+}
+
 // One 32 x 32 thread block per (sample, subset) matrix: thread (v, w) sums its chunk partials (consecutive threads read
 // consecutive addresses), the matrix goes through LDS and every thread reduces its own column (dim -2 of the (V, V)
 // affinity).  adj_ab may be given as two addends (adj_a, adj_b) so the caller needs no separate add kernel.
@@ -536,4 +672,33 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
 #undef FGCN_MIXV
 #undef FGCN_MIXV_KS
     return launch_status("joint_mix_vec");
+}
+
+extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* mats, float* dx, float* partial,
+                               int B, int T, int V, int C, int ld_x, int ld_dagg, int ld_dx, int n_subsets,
+                               int mats_batched, int t_chunk, int accumulate, void* stream) {
+    FGCN_REQUIRE(x && dagg && mats && dx && partial, FGCN_E_BADARG, "joint_dagg: null pointer");
+    FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V && C > 0 && t_chunk > 0, FGCN_E_BADARG,
+                 "joint_dagg: bad sizes B=%d T=%d V=%d C=%d", B, T, V, C);
+    FGCN_REQUIRE(n_subsets >= 1 && n_subsets <= 3, FGCN_E_BADARG, "joint_dagg: n_subsets=%d (1..3)", n_subsets);
+    FGCN_REQUIRE(C % 4 == 0 && ld_x % 4 == 0 && ld_dagg % 4 == 0 && ld_x >= C && ld_dagg >= n_subsets * C && ld_dx >= C &&
+                     aligned16(x) && aligned16(dagg),
+                 FGCN_E_ALIGN, "joint_dagg: C and the row strides must be multiples of 4 and cover the channels");
+    const long long xb = (long long)B * T * V * ld_x * 4, db = (long long)B * T * V * ld_dagg * 4;
+    FGCN_REQUIRE(xb < 0x7FFF0000ll && db < 0x7FFF0000ll && (long long)t_chunk * V * ld_dx * 4 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "joint_dagg: x and dagg must be smaller than 2 GiB");
+    DaggP p;
+    p.x = x; p.dagg = dagg; p.mats = mats; p.dx = dx; p.partial = partial;
+    p.B = B; p.T = T; p.V = V; p.C = C; p.ld_x = ld_x; p.ld_d = ld_dagg; p.ld_dx = ld_dx; p.n_sub = n_subsets;
+    p.mats_batched = mats_batched; p.t_chunk = t_chunk; p.accumulate = accumulate;
+    p.x_bytes = (unsigned)xb; p.d_bytes = (unsigned)db;
+    const size_t lds = (size_t)(3 * IMG + 4 * 2 * 32 * DTS) * sizeof(float);   // 49,152 bytes: three workgroups per CU
+    dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    const int ks = (V + 3) / 4 * 2;
+    if (ks <= 10) hipLaunchKernelGGL(joint_dagg_kernel<10>, grid, dim3(256), lds, s, p);
+    else if (ks <= 12) hipLaunchKernelGGL(joint_dagg_kernel<12>, grid, dim3(256), lds, s, p);
+    else if (ks <= 14) hipLaunchKernelGGL(joint_dagg_kernel<14>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(joint_dagg_kernel<16>, grid, dim3(256), lds, s, p);
+    return launch_status("joint_dagg");
 }

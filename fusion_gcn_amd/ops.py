@@ -355,6 +355,23 @@ def joint_gram(in1: torch.Tensor, in2: torch.Tensor, items: Sequence[Tuple[int, 
     return partial
 
 
+def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torch.Tensor, *, accumulate: bool) -> torch.Tensor:
+    """dx (+)= sum_k dagg_k . A^_k^T and the partial grams dA^_k = x^T dagg_k in one pass over dagg.
+    x (B,T,V,C), dagg (B,T,V,ns*C), mats (B or 1, ns, V, V), dx (B,T,V,>=C) -> partial (B, nchunk, ns, 32, 32)."""
+    ensure_device()
+    _chk(x, "joint_dagg.x"), _chk(dagg, "joint_dagg.dagg"), _chk(mats, "joint_dagg.mats"), _chk(dx, "joint_dagg.dx")
+    B, T, V, C = x.shape
+    ns = mats.shape[1]
+    if dagg.shape != (B, T, V, ns * C) or dx.shape[:3] != (B, T, V) or mats.shape[0] not in (1, B) or mats.shape[2:] != (V, V):
+        raise _lib.FgcnError(f"joint_dagg: shape mismatch x={tuple(x.shape)} dagg={tuple(dagg.shape)} mats={tuple(mats.shape)}")
+    chunk = gram_t_chunk(B, T)
+    nchunk = (T + chunk - 1) // chunk
+    partial = torch.empty((B, nchunk, ns, 32, 32), device=x.device, dtype=torch.float32)
+    check(_lib.load().fgcn_joint_dagg(_p(x), _p(dagg), _p(mats), _p(dx), _p(partial), B, T, V, C, C, ns * C, dx.shape[3], ns,
+                                      int(mats.shape[0] != 1), chunk, int(accumulate), _stream()), "fgcn_joint_dagg")
+    return partial
+
+
 def adj_softmax_fwd(partial: Optional[torch.Tensor], scale: float, adj_a: torch.Tensor, B: int,
                     use_softmax: bool = True, adj_b: Optional[torch.Tensor] = None):
     """a_hat = softmax_v(scale * sum partial) + adj_a + adj_b  -> (C (B,K,V,V) or None, a_hat (B,K,V,V))."""

@@ -196,6 +196,15 @@ int fgcn_joint_gram(const float* in1, const float* in2, float* partial, int B, i
                     int ld1, int ld2, int t_chunk, int n_mats, const fgcn_gram_item* items, int n_items,
                     void* stream);
 
+/* Both consumers of dagg = dY . Wd in one pass over it (backward of agcn.py:109-110):
+ *     dx[(n,t,v), c]        (+)= sum_k sum_w A^_k[n][v][w] * dagg[(n,t,w), k*C + c]
+ *     partial[n][chunk][k][v][w] = sum_{t in chunk} sum_c x[(n,t,v), c] * dagg[(n,t,w), k*C + c]      (32x32 padded)
+ *   i.e. fgcn_joint_mix_vec (dx) and fgcn_joint_gram (dA^_k = x^T dagg_k) without reading the 3*C-wide dagg twice.
+ *   mats: float[B or 1][n_subsets][V][V]; partial: float[B][ceil(T/t_chunk)][n_subsets][32][32].  C % 4 == 0. */
+int fgcn_joint_dagg(const float* x, const float* dagg, const float* mats, float* dx, float* partial,
+                    int B, int T, int V, int C, int ld_x, int ld_dagg, int ld_dx, int n_subsets,
+                    int mats_batched, int t_chunk, int accumulate, void* stream);
+
 /* S = scale * sum_chunks partial ; C[n,k,:,w] = softmax over v ; a_hat = C + adj_a[k] + adj_b[k]   (agcn.py:84,100,106-108)
  *   c_out, a_hat: float[B][K][V][V]; adj_a (constant partition adjacency), adj_b (learned, may be NULL): float[K][V][V].
  *   use_softmax = 0 gives the static-adjacency case a_hat = adj_a + adj_b (c_out untouched). */

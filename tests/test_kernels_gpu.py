@@ -332,6 +332,30 @@ def test_joint_mix_embedding_gradient(ic, order, monkeypatch):
     assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("V,T,C,B", [(25, 30, 64, 3), (18, 33, 128, 2), (27, 12, 256, 2), (22, 9, 4, 2), (32, 5, 96, 1), (25, 300, 64, 2)])
+def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
+    """One pass over dagg gives both dx (+)= sum_k dagg_k . A^_k^T and dA^_k = x^T dagg_k (float64 einsums), with and without
+    accumulation, per-sample and shared matrices; the partial grams sum to what joint_gram produces."""
+    from fusion_gcn_amd import ops
+    x, a = rnd(B, T, V, C, seed=90), rnd(B, 3, V, V, seed=91, scale=0.3)
+    dagg, base = rnd(B, T, V, 3 * C, seed=92), rnd(B, T, V, C, seed=93)
+    d4 = dagg.reshape(B, T, V, 3, C)
+    want_dx = torch.einsum("btwkc,bkvw->btvc", d4, a)
+    want_g = torch.einsum("btvc,btwkc->bkvw", x, d4)
+    for acc in (False, True):
+        dx = to_gpu(base)
+        part = ops.joint_dagg(to_gpu(x), to_gpu(dagg), to_gpu(a), dx, accumulate=acc)
+        assert rel_l2(dx.cpu().numpy(), (want_dx + (base if acc else 0)).numpy()) < FWD_TOL
+        got_g = part.double().sum(1)[:, :, :V, :V].cpu()
+        assert rel_l2(got_g.numpy(), want_g.numpy()) < RED_TOL
+        assert float(part[:, :, :, V:, :].abs().max() if V < 32 else 0.0) == 0.0        # padding stays zero
+    ref = ops.joint_gram(to_gpu(x), to_gpu(dagg), [(0, k * C, C) for k in range(3)])
+    assert rel_l2(part.sum(1).cpu().numpy(), ref.sum(1).cpu().numpy()) < RED_TOL
+    dx = to_gpu(base)
+    ops.joint_dagg(to_gpu(x), to_gpu(dagg), to_gpu(a[:1]), dx, accumulate=False)     # static (shared) adjacency
+    assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", d4, a[0]).numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("V,T,ic", [(25, 30, 16), (18, 33, 32), (27, 12, 64), (22, 300, 16)])
 def test_joint_gram_and_adjacency_softmax(V, T, ic):
     from fusion_gcn_amd import ops

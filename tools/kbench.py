@@ -159,6 +159,9 @@ def bench_joint(B, reps):
         report(f"gram score T{T} ic{ic}", ms, 6.0 * rows * V * ic, 4.0 * rows * 6 * ic)
         ms = timeit(lambda: ops.joint_gram(x, agg, [(0, k * c, c) for k in range(3)]), reps)
         report(f"gram dA^ T{T} C{c}", ms, 6.0 * rows * V * c, 4.0 * rows * 4 * c)
+        a, dx = rnd(B, 3, V, V) * 0.2, torch.zeros(B, T, V, c, device=DEV)
+        ms = timeit(lambda: ops.joint_dagg(x, agg, a, dx, accumulate=True), reps)
+        report(f"joint_dagg (dx += and dA^ fused) T{T} C{c}", ms, 12.0 * rows * V * c, 4.0 * rows * 6 * c)
 
 
 def bench_elem(B, reps):
