@@ -65,7 +65,8 @@ SIGNATURES = {
     "fgcn_group_mean": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
-    "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P]),
+    "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P, _P]),
+    "fgcn_joint_mix_chunks": (_I, [_I, _I]),
     "fgcn_joint_gram": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(GramItem), _I, _P]),
     "fgcn_joint_dagg": (_I, [_P] * 5 + [_I] * 11 + [_P]),
     "fgcn_adj_softmax_fwd": (_I, [_P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

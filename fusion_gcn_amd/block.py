@@ -195,12 +195,13 @@ def mix_dx(dagg: torch.Tensor, dx: torch.Tensor, a_hat: torch.Tensor, cin: int, 
     ops.joint_mix_vec(dagg, dx, a_hat, spec, vw=vw, accumulate=accumulate)
 
 
-def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) -> None:
-    """dtheta_k = dS_k . phi_k, dphi_k = dS_k^T . theta_k over the embedding layout [th0 ph0 th1 ph1 th2 ph2]."""
+def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) -> torch.Tensor:
+    """dtheta_k = dS_k . phi_k, dphi_k = dS_k^T . theta_k over the embedding layout [th0 ph0 th1 ph1 th2 ph2];
+    returns the column sums of demb (the theta|phi bias gradient), fused into the mix where the kernel allows."""
     vw = _vec_width(ic)
     if not vw:
         ops.joint_mix(emb, demb, d_s, spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
-        return
+        return ops.col_sum(demb, 6 * ic)
     g = 32 * vw
     spec = []
     for k in range(NUM_SUBSETS):
@@ -208,7 +209,11 @@ def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) 
         for c0 in range(0, ic, g):
             spec.append(dict(out_c=th + c0, nch=min(g, ic), terms=[(k, 0, ph + c0)]))
             spec.append(dict(out_c=ph + c0, nch=min(g, ic), terms=[(k, 1, th + c0)]))
-    ops.joint_mix_vec(emb, demb, d_s, spec, vw=vw)
+    if len(spec) > ops.MIX_MAX_ITEMS:
+        ops.joint_mix_vec(emb, demb, d_s, spec, vw=vw)
+        return ops.col_sum(demb, 6 * ic)
+    _, sums = ops.joint_mix_vec(emb, demb, d_s, spec, vw=vw, colsum=True)
+    return sums
 
 
 def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], bias: torch.Tensor, kt: int, s: int,
@@ -423,10 +428,9 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     if not cfg.static_adjacency:
         emb = S["emb"]
         demb = new(B, T, V, 6 * ic)
-        mix_demb(emb, demb, d_s, ic)
+        gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
         ops.rows_gemm(demb, W["emb_t"], dx, K=6 * ic, N=cx, accumulate=dx_live)
         gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true))     # (6ic, cin_true, 1, 1)
-        gb = ops.col_sum(demb, 6 * ic)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic

@@ -107,6 +107,7 @@ struct MixVP {
     float* out;
     const float* mats;
     int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, t_chunk;
+    float* colsum;   // optional: per-workgroup column sums of everything this launch writes, [B * chunks][ld_out]
     unsigned in_bytes, out_bytes;
     struct Item {  // dword fields only: the kernel reads them with scalar loads (16-bit fields went through vector memory)
         int out_c, nterms, img[3], in_c[3];
@@ -135,12 +136,15 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
     using vec = __attribute__((ext_vector_type(VW))) float;
     using raw = typename MixVec<VW>::raw;
     __shared__ float img[2 * MIX_MAX_MATS * IMG];
+    extern __shared__ float cs[];                     // [4 waves][ld_out] column sums (only with p.colsum)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n = blockIdx.y;
     const int t0 = blockIdx.x * p.t_chunk;
     const int t1 = min(t0 + p.t_chunk, p.T);
     const int V = p.V;
+    if (p.colsum)
+        for (int i = tid; i < 4 * p.ld_out; i += 256) cs[i] = 0.f;
 
     // image 2m + tr holds A[i = out joint][k = in joint] = tr ? M_m[k][i] : M_m[i][k] at [k][i]
     const float* msrc = p.mats + (p.mats_batched ? (long long)n * p.n_mats * V * V : 0);
@@ -207,7 +211,25 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
                 if constexpr (ACC) v += __builtin_bit_cast(vec, old[r]);
                 MixVec<VW>::store(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
             }
+            if constexpr (!ACC) {
+                if (p.colsum) {   // wave-uniform.  Rows >= V and absent channels are exact zeros (zero-padded images / loads)
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum += acc[m][r];
+                        sum += __shfl_xor(sum, 32);
+                        if (h == 0 && lane_ok) cs[wave * p.ld_out + item.out_c + VW * l31 + m] += sum;   // wave-private row
+                    }
+                }
+            }
         }
+    }
+    if (p.colsum) {
+        __syncthreads();
+        float* dst = p.colsum + ((long long)n * gridDim.x + blockIdx.x) * p.ld_out;
+        for (int c = tid; c < p.ld_out; c += 256)
+            dst[c] = cs[c] + cs[p.ld_out + c] + cs[2 * p.ld_out + c] + cs[3 * p.ld_out + c];
     }
 }
 
@@ -523,6 +545,7 @@ __global__ __launch_bounds__(1024) void adj_softmax_bwd_kernel(const float* part
 
 using namespace fgcn;
 
+extern "C" int fgcn_joint_mix_chunks(int B, int T);
 static int pick_t_chunk(int B, int T) {
     // enough workgroups to fill 256 CUs a few times over, at least 4 frames (one per wave) per workgroup
     int chunk = 32;
@@ -617,8 +640,10 @@ extern "C" int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scal
 
 extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
                                   int ld_in, int ld_out, int n_mats, int mats_batched,
-                                  const fgcn_mixv_item* items, int n_items, int vw, int accumulate, void* stream) {
+                                  const fgcn_mixv_item* items, int n_items, int vw, int accumulate,
+                                  float* colsum_partial, void* stream) {
     FGCN_REQUIRE(in && out && mats && items, FGCN_E_BADARG, "joint_mix_vec: null pointer");
+    FGCN_REQUIRE(!(colsum_partial && accumulate), FGCN_E_BADARG, "joint_mix_vec: column sums only without accumulation");
     FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
                  "joint_mix_vec: bad B/T/V (%d,%d,%d)", B, T, V);
     FGCN_REQUIRE(n_mats >= 1 && n_mats <= MIX_MAX_MATS && n_items >= 1 && n_items <= FGCN_MIX_MAX_ITEMS,
@@ -635,6 +660,7 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     p.B = B; p.T = T; p.V = V; p.ld_in = ld_in; p.ld_out = ld_out;
     p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items;
     p.t_chunk = pick_t_chunk(B, T);
+    p.colsum = colsum_partial;
     for (int i = 0; i < n_items; ++i) {
         const fgcn_mixv_item& it = items[i];
         FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.nch >= vw && it.nch <= 32 * vw && it.nch % vw == 0 &&
@@ -655,12 +681,14 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     dim3 grid((unsigned)cdiv(T, p.t_chunk), (unsigned)B);
     const hipStream_t st = (hipStream_t)stream;
     const int ks = (V + 3) / 4 * 2;  // k-steps, rounded up to even
-#define FGCN_MIXV_KS(VW_, ACC_)                                                                              \
-    do {                                                                                                     \
-        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10>), grid, dim3(256), 0, st, p);      \
-        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12>), grid, dim3(256), 0, st, p); \
-        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16>), grid, dim3(256), 0, st, p);               \
+    const size_t cs_lds = colsum_partial ? (size_t)4 * ld_out * sizeof(float) : 0;
+    FGCN_REQUIRE(cs_lds <= 32 * 1024, FGCN_E_BADARG, "joint_mix_vec: ld_out=%d too wide for the column-sum scratch", ld_out);
+#define FGCN_MIXV_KS(VW_, ACC_)                                                                                   \
+    do {                                                                                                          \
+        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10>), grid, dim3(256), cs_lds, st, p);      \
+        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12>), grid, dim3(256), cs_lds, st, p); \
+        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14>), grid, dim3(256), cs_lds, st, p); \
+        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16>), grid, dim3(256), cs_lds, st, p);               \
     } while (0)
 #define FGCN_MIXV(VW_)                            \
     do {                                          \
@@ -702,3 +730,5 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
     else hipLaunchKernelGGL(joint_dagg_kernel<16>, grid, dim3(256), lds, s, p);
     return launch_status("joint_dagg");
 }
+
+extern "C" int fgcn_joint_mix_chunks(int B, int T) { return (int)cdiv(T, pick_t_chunk(B, T)); }

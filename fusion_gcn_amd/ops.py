@@ -308,14 +308,21 @@ MIX_MAX_ITEMS = 24   # FGCN_MIX_MAX_ITEMS (include/fgcn.h)
 
 
 def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec: Sequence[dict], *, vw: int,
-                  accumulate: bool = False) -> torch.Tensor:
-    """Vectorised joint mix over whole channel groups; spec: [{out_c, nch, terms: [(mat, transpose, in_c)]}]."""
+                  accumulate: bool = False, colsum: bool = False):
+    """Channel-group joint mix; spec: [{out_c, nch, terms: [(mat, transpose, in_c)]}].  ``colsum`` also returns the
+    per-channel sums of everything written (ld_out,) -- a bias gradient without another pass over ``out``."""
     ensure_device()
     _chk(inp, "joint_mix_vec.in"), _chk(out, "joint_mix_vec.out"), _chk(mats, "joint_mix_vec.mats")
     B, T, V, ld_in = inp.shape
     if out.shape[:3] != inp.shape[:3] or mats.shape[-1] != V or mats.shape[-2] != V or mats.shape[0] not in (1, B):
         raise _lib.FgcnError(f"joint_mix_vec: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} "
                              f"mats={tuple(mats.shape)}")
+    lib = _lib.load()
+    if colsum and (accumulate or len(spec) > MIX_MAX_ITEMS):
+        raise _lib.FgcnError("joint_mix_vec: column sums need one launch without accumulation")
+    partial = None
+    if colsum:
+        partial = torch.empty((B * lib.fgcn_joint_mix_chunks(B, T), out.shape[3]), device=inp.device, dtype=torch.float32)
     for lo in range(0, len(spec), MIX_MAX_ITEMS):   # one launch per FGCN_MIX_MAX_ITEMS items
         part = spec[lo:lo + MIX_MAX_ITEMS]
         arr = (_lib.MixVItem * len(part))()
@@ -323,9 +330,13 @@ def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec
             arr[i].out_c, arr[i].nch, arr[i].nterms = it["out_c"], it["nch"], len(it["terms"])
             for j, (mat, tr, in_c) in enumerate(it["terms"]):
                 arr[i].term[j] = _lib.MixVTerm(mat, tr, in_c)
-        check(_lib.load().fgcn_joint_mix_vec(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], mats.shape[1],
-                                             int(mats.shape[0] != 1), arr, len(part), vw, int(accumulate), _stream()),
+        check(lib.fgcn_joint_mix_vec(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], mats.shape[1],
+                                     int(mats.shape[0] != 1), arr, len(part), vw, int(accumulate), _p(partial), _stream()),
               "fgcn_joint_mix_vec")
+    if colsum:
+        sums = torch.empty((out.shape[3],), device=inp.device, dtype=torch.float32)
+        reduce_sum(partial, sums)
+        return out, sums
     return out
 
 

@@ -180,7 +180,12 @@ typedef struct {
 } fgcn_mixv_item;
 int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
                        int ld_in, int ld_out, int n_mats, int mats_batched,
-                       const fgcn_mixv_item* items, int n_items, int vw, int accumulate, void* stream);
+                       const fgcn_mixv_item* items, int n_items, int vw, int accumulate,
+                       float* colsum_partial, void* stream);
+/* colsum_partial (optional, only without accumulation): float[B * fgcn_joint_mix_chunks(B, T)][ld_out]; row i receives the
+ * column sums of everything workgroup i wrote (the theta|phi bias gradient falls out of the embedding-gradient mix
+ * instead of a separate pass over its output); channels no item writes receive 0. */
+int fgcn_joint_mix_chunks(int B, int T);
 
 typedef struct {
     short c1;     /* first channel of in1 */

@@ -328,7 +328,9 @@ def test_joint_mix_embedding_gradient(ic, order, monkeypatch):
         ops.joint_mix(to_gpu(emb), out, to_gpu(ds), block.spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
     else:
         monkeypatch.setattr(block, "MIX_VW_ORDER", order)
-        block.mix_demb(to_gpu(emb), out, to_gpu(ds), ic)
+        sums = block.mix_demb(to_gpu(emb), out, to_gpu(ds), ic)
+        # the column sums (theta|phi bias gradient) come out of the same launch
+        assert rel_l2(sums.cpu().numpy(), want.reshape(-1, 6 * ic).sum(0).numpy()) < RED_TOL
     assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
 
 
