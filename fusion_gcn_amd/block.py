@@ -156,6 +156,10 @@ def spec_dx(cin: int) -> List[dict]:
 
 
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
+FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
+# ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
+# tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
+FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128}
 MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
 
 
@@ -399,10 +403,14 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     a_hat = S["a_hat"]
     c3 = 3 * cin
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
-    agg = new(B, T, V, c3)
-    mix_agg(x, agg, a_hat, cin)
-    gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
-    del agg
+    if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
+        # agg = x . A^ is formed in registers and contracted with dy at once: never written
+        gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
+    else:
+        agg = new(B, T, V, c3)
+        mix_agg(x, agg, a_hat, cin)
+        gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
+        del agg
     dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]

@@ -487,6 +487,136 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
     }
 }
 
+// ---- fused agg recompute + conv_d weight gradient: dWd_k[c][o] = sum_{n,t,v} (x . A^_k)[(n,t,v), c] * dy[(n,t,v), o] ---------
+// The unfused pair wrote agg = x . A^ (3 activations wide) with joint_mix_vec and read it back in the weight-gradient GEMM.
+// Here a workgroup owns a (32 in-channel x 64 out-channel) tile of all three subsets for the frames [t0, t1) of one
+// sample; a wave takes a frame: the x chunk and the dy chunk land in wave-private LDS tiles, agg_k (joints x 32 channels)
+// is formed in the accumulator registers (KS MFMAs) and those registers are the A operand of the weight-gradient MFMAs
+// as they stand: register r of lane (c, h) holds joint (r&3) + 8(r>>2) + 4h, which is exactly a 2-deep contraction step
+// whose B operand is dy[joint][o].  Deterministic partial slabs [n * chunks + chunk][3 * Cin][Cout], summed by the caller.
+struct SWgradP {
+    const float* x;
+    const float* dy;
+    const float* mats;
+    float* partial;
+    int B, T, V, Cin, Cout, ld_x, ld_dy, n_sub, mats_batched, t_chunk, tiles_o;
+    unsigned x_bytes, dy_bytes, p_bytes;
+};
+
+constexpr int YTS = 68;   // dy tile row stride (64 channels + 4)
+
+template <int KS, bool BF>
+__global__ __launch_bounds__(256, 2) void spatial_wgrad_kernel(SWgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    float* img = wsm;                                  // [3][kk = in joint v][i = out joint w] = A^_k[v][w]
+    float* tiles = wsm + 3 * IMG;                      // [4 waves][32 * DTS + 32 * YTS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;
+    const int tc = tile / p.tiles_o, to = tile - tc * p.tiles_o;
+    const int c0 = tc * 32, o0 = to * 64;
+    const int t0 = chunk * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V, NS = p.n_sub;
+    float* xt = tiles + wave * (32 * DTS + 32 * YTS);
+    float* yt = xt + 32 * DTS;
+
+    const float* msrc = p.mats + (p.mats_batched ? (long long)n * NS * V * V : 0);
+    for (int e = tid; e < 3 * IMG; e += 256) {
+        const int k = e >> 10, v = (e >> 5) & 31, w = e & 31;
+        img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+    }
+    __syncthreads();
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const int cw = min(32, p.Cin - c0), ow = min(64, p.Cout - o0);
+
+    f32x16 accw[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) accw[k][0] = accw[k][1] = zero16();
+    const float* xb = xt + h * DTS + l31;              // mix B operand: joint 2s + h, lane = channel
+    const float* am = img + h * 32 + l31;              // mix A operand: image row kk = v = 2s + h, lane = out joint
+    const float* yb = yt + 4 * h * YTS + l31;          // weight-gradient B operand: joint (r&3) + 8(r>>2) + 4h, lane = o
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const unsigned row0 = (unsigned)((n * p.T + t) * V);
+        {   // x chunk: lane -> (row lane/8 + 8 pass, 16-byte group lane%8); dy chunk: (row lane/16 + 4 pass, group lane%16)
+            const int xr = lane >> 3, xg = lane & 7, yr = lane >> 4, yg = lane & 15;
+            f32x4 xv[4], yv[8];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = 8 * ps + xr;
+                xv[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rx, (row < V && 4 * xg < cw) ? ((row0 + row) * (unsigned)p.ld_x + c0 + 4 * xg) * 4u : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = 4 * ps + yr;
+                yv[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    ry, (row < V && 4 * yg < ow) ? ((row0 + row) * (unsigned)p.ld_dy + o0 + 4 * yg) * 4u : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(&xt[(8 * ps + xr) * DTS + 4 * xg]) = xv[ps];
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f32x4*>(&yt[(4 * ps + yr) * YTS + 4 * yg]) = yv[ps];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < NS) {                              // wave-uniform
+                f32x16 agg = zero16();                 // agg_k chunk: rows = out joint, lanes = channel
+#pragma unroll
+                for (int s = 0; s < KS; ++s) agg = mfma32(am[k * IMG + s * 64], xb[2 * s * DTS], agg);
+                if constexpr (BF) {
+                    // 8 joints per bf16 MFMA: registers 4g..4g+3 of lane half h are joints 8g + 4h + (0..3)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (8 * g >= 2 * KS) continue;
+                        const s16x4 ap = pack_bf16(agg[4 * g], agg[4 * g + 1], agg[4 * g + 2], agg[4 * g + 3]);
+                        const float* yrow = yb + 8 * g * YTS;
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot)
+                            accw[k][ot] = mfma_bf16(ap, pack_bf16(yrow[ot * 32], yrow[YTS + ot * 32], yrow[2 * YTS + ot * 32],
+                                                                  yrow[3 * YTS + ot * 32]), accw[k][ot]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        if (dr >= 2 * KS) continue;    // compile-time: register r only holds padding joints (exact zeros)
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) accw[k][ot] = mfma32(agg[r], yb[dr * YTS + ot * 32], accw[k][ot]);
+                    }
+                }
+            }
+        }
+    }
+    // cross-wave sum (fixed order) and the slab: partial[slab][k * Cin + c0 + c][o0 + o]
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+    const unsigned slab = (unsigned)(n * gridDim.y + chunk);
+    float* red = tiles;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= NS) continue;
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = accw[k][ot][r];
+            __syncthreads();
+            for (int e = tid; e < 1024; e += 256) {
+                const float sum = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+                const int r = e >> 6, l = e & 63;
+                const int c = acc_row(r, l), o = ot * 32 + (l & 31);
+                const unsigned off = (c < cw && o < ow)
+                                         ? ((slab * (unsigned)(NS * p.Cin) + (unsigned)(k * p.Cin + c0 + c)) * (unsigned)p.Cout + o0 + o) * 4u
+                                         : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rp, off, 0, 0);
+            }
+        }
+    }
+}
+
 // One 32 x 32 thread block per (sample, subset) matrix: thread (v, w) sums its chunk partials (consecutive threads read
 // consecutive addresses), the matrix goes through LDS and every thread reduces its own column (dim -2 of the (V, V)
 // affinity).  adj_ab may be given as two addends (adj_a, adj_b) so the caller needs no separate add kernel.
@@ -732,3 +862,60 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
 }
 
 extern "C" int fgcn_joint_mix_chunks(int B, int T) { return (int)cdiv(T, pick_t_chunk(B, T)); }
+
+extern "C" int fgcn_spatial_wgrad_chunks(int B, int T, int Cin, int Cout) {
+    const long long tiles = cdiv(Cin, 32) * cdiv(Cout, 64);
+    long long nchunk = cdiv(1024, tiles * B);          // about a thousand workgroups, at least 4 frames (one per wave) each
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > cdiv(T, 4)) nchunk = cdiv(T, 4);
+    return (int)cdiv(T, cdiv(T, nchunk));
+}
+
+extern "C" int fgcn_spatial_wgrad(const float* x, const float* dy, const float* mats, float* partial,
+                                  int B, int T, int V, int Cin, int Cout, int ld_x, int ld_dy, int n_subsets,
+                                  int mats_batched, void* stream) {
+    FGCN_REQUIRE(x && dy && mats && partial, FGCN_E_BADARG, "spatial_wgrad: null pointer");
+    FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V && Cin > 0 && Cout > 0, FGCN_E_BADARG,
+                 "spatial_wgrad: bad sizes B=%d T=%d V=%d Cin=%d Cout=%d", B, T, V, Cin, Cout);
+    FGCN_REQUIRE(n_subsets >= 1 && n_subsets <= 3, FGCN_E_BADARG, "spatial_wgrad: n_subsets=%d (1..3)", n_subsets);
+    FGCN_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_x >= Cin && ld_dy >= Cout &&
+                     aligned16(x) && aligned16(dy),
+                 FGCN_E_ALIGN, "spatial_wgrad: channels and row strides must be multiples of 4");
+    const int nchunk = fgcn_spatial_wgrad_chunks(B, T, Cin, Cout);
+    const long long xb = (long long)B * T * V * ld_x * 4, yb = (long long)B * T * V * ld_dy * 4;
+    const long long pb = (long long)B * nchunk * n_subsets * Cin * Cout * 4;
+    FGCN_REQUIRE(xb < 0x7FFF0000ll && yb < 0x7FFF0000ll && pb < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "spatial_wgrad: tensors must be smaller than 2 GiB");
+    SWgradP p;
+    p.x = x; p.dy = dy; p.mats = mats; p.partial = partial;
+    p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.Cout = Cout; p.ld_x = ld_x; p.ld_dy = ld_dy; p.n_sub = n_subsets;
+    p.mats_batched = mats_batched; p.t_chunk = (int)cdiv(T, nchunk); p.tiles_o = (int)cdiv(Cout, 64);
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb; p.p_bytes = (unsigned)pb;
+    const size_t lds = (size_t)(3 * IMG + 4 * (32 * DTS + 32 * YTS)) * sizeof(float);   // 65,536 bytes: two workgroups per CU
+    dim3 grid((unsigned)(cdiv(Cin, 32) * p.tiles_o), (unsigned)nchunk, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
+    const int ks = (V + 3) / 4 * 2;
+    static bool lds_opt_in = false;   // once per process; not a stream operation (stays out of graph captures)
+#define FGCN_SW(KS_)                                                                                                   \
+    do {                                                                                                               \
+        if (bf) hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, true>), grid, dim3(256), lds, s, p);                     \
+        else hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, false>), grid, dim3(256), lds, s, p);                       \
+    } while (0)
+#define FGCN_SW_ATTR(KS_)                                                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, false>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, true>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    if (!lds_opt_in) {
+        FGCN_SW_ATTR(10); FGCN_SW_ATTR(12); FGCN_SW_ATTR(14); FGCN_SW_ATTR(16);
+        lds_opt_in = true;
+    }
+    if (ks <= 10) FGCN_SW(10);
+    else if (ks <= 12) FGCN_SW(12);
+    else if (ks <= 14) FGCN_SW(14);
+    else FGCN_SW(16);
+#undef FGCN_SW
+#undef FGCN_SW_ATTR
+    return launch_status("spatial_wgrad");
+}

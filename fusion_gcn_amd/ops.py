@@ -366,6 +366,24 @@ def joint_gram(in1: torch.Tensor, in2: torch.Tensor, items: Sequence[Tuple[int, 
     return partial
 
 
+def spatial_wgrad(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+                  accumulate: bool = False, conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """conv_d weight gradient with agg = x . A^ recomputed on chip: (1, ns*Cin, Cout), or the parameter layout with
+    ``conv_param=(ns, cin_true)``.  x (B,T,V,Cin), dy (B,T,V,Cout), mats (B or 1, ns, V, V)."""
+    ensure_device()
+    _chk(x, "spatial_wgrad.x"), _chk(dy, "spatial_wgrad.dy"), _chk(mats, "spatial_wgrad.mats")
+    B, T, V, Cin = x.shape
+    Cout, ns = dy.shape[3], mats.shape[1]
+    if dy.shape[:3] != (B, T, V) or mats.shape[0] not in (1, B) or mats.shape[2:] != (V, V):
+        raise _lib.FgcnError(f"spatial_wgrad: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} mats={tuple(mats.shape)}")
+    lib = _lib.load()
+    slabs = B * lib.fgcn_spatial_wgrad_chunks(B, T, Cin, Cout)
+    partial = torch.empty((slabs, 1, ns * Cin, Cout), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_spatial_wgrad(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, Cin, Cout, ns,
+                                 int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad")
+    return _reduce_slabs(partial, 1, ns * Cin, Cout, out, accumulate, conv_param)
+
+
 def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torch.Tensor, *, accumulate: bool) -> torch.Tensor:
     """dx (+)= sum_k dagg_k . A^_k^T and the partial grams dA^_k = x^T dagg_k in one pass over dagg.
     x (B,T,V,C), dagg (B,T,V,ns*C), mats (B or 1, ns, V, V), dx (B,T,V,>=C) -> partial (B, nchunk, ns, 32, 32)."""

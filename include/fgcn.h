@@ -201,6 +201,17 @@ int fgcn_joint_gram(const float* in1, const float* in2, float* partial, int B, i
                     int ld1, int ld2, int t_chunk, int n_mats, const fgcn_gram_item* items, int n_items,
                     void* stream);
 
+/* Weight gradient of conv_d with the aggregation recomputed on chip (backward of agcn.py:109-110 w.r.t. conv_d[k].weight):
+ *     partial[slab][k*Cin + c][o] = sum over the slab's frames of (n, t) and joints w of
+ *                                   (sum_v x[(n,t,v), c] * A^_k[n][v][w]) * dy[(n,t,w), o]
+ *   replaces fgcn_joint_mix_vec (agg = x . A^, 3 activations wide, written to HBM) + the row weight-gradient GEMM over it.
+ *   partial: float[B * fgcn_spatial_wgrad_chunks(B, T, Cin, Cout)][n_subsets * Cin][Cout]; the caller sums the slabs.
+ *   Honors fgcn_set_math_mode for the Cin x Cout contraction (the joint mixing stays f32). */
+int fgcn_spatial_wgrad_chunks(int B, int T, int Cin, int Cout);
+int fgcn_spatial_wgrad(const float* x, const float* dy, const float* mats, float* partial,
+                       int B, int T, int V, int Cin, int Cout, int ld_x, int ld_dy, int n_subsets,
+                       int mats_batched, void* stream);
+
 /* Both consumers of dagg = dY . Wd in one pass over it (backward of agcn.py:109-110):
  *     dx[(n,t,v), c]        (+)= sum_k sum_w A^_k[n][v][w] * dagg[(n,t,w), k*C + c]
  *     partial[n][chunk][k][v][w] = sum_{t in chunk} sum_c x[(n,t,v), c] * dagg[(n,t,w), k*C + c]      (32x32 padded)

@@ -151,3 +151,15 @@ def test_config5_model_contract():
     print(f"config 5: logits rel-L2 {e_logits:.2e}, loss {loss_b:.5f} vs {loss_f:.5f}, gradient cosine {cos:.4f}")
     assert e_logits < 1e-2 and abs(loss_b - loss_f) < 1e-2 and cos > 0.98
     assert e_logits > 1e-5                          # the mode really changes the arithmetic
+
+
+@pytest.mark.parametrize("V,cin,cout", [(25, 64, 64), (18, 64, 128), (27, 128, 128)])
+def test_spatial_wgrad_bf16(V, cin, cout):
+    """agg is formed in f32, then agg and dy are rounded for the Cin x Cout contraction."""
+    from fusion_gcn_amd import ops
+    B, T = 2, 6
+    x, a, dy = rnd(B, T, V, cin, seed=20), rnd(B, 3, V, V, seed=21, scale=0.3), rnd(B, T, V, cout, seed=22)
+    agg = torch.einsum("btvc,bkvw->btwkc", x.float().double(), a.float().double())
+    want = torch.einsum("btwkc,btwo->kco", bf(agg), bf(dy)).reshape(3 * cin, cout)
+    got = ops.spatial_wgrad(gpu(x), gpu(dy), gpu(a))
+    assert rel_l2(got[0].cpu().numpy(), want.numpy()) < 2e-3      # a few agg values round to the neighbouring bf16

@@ -334,6 +334,33 @@ def test_joint_mix_embedding_gradient(ic, order, monkeypatch):
     assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 30, 64, 64, 3), (18, 33, 64, 128, 2), (27, 12, 128, 128, 2), (22, 9, 4, 64, 2),
+                                            (32, 5, 96, 36, 1), (25, 300, 64, 64, 2), (25, 7, 256, 256, 1)])
+def test_spatial_wgrad_fused_agg_recompute(V, T, cin, cout, B):
+    """conv_d weight gradient with agg = x . A^ formed on chip equals the float64 einsum and the unfused pair
+    (joint_mix_vec + row weight gradient), in both output layouts; bitwise reproducible."""
+    from fusion_gcn_amd import block, ops
+    x, a, dy = rnd(B, T, V, cin, seed=95), rnd(B, 3, V, V, seed=96, scale=0.3), rnd(B, T, V, cout, seed=97)
+    agg = torch.einsum("btvc,bkvw->btwkc", x, a)                              # (B,T,W,3,cin)
+    want = torch.einsum("btwkc,btwo->kco", agg, dy).reshape(3 * cin, cout)
+    got = ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a))
+    assert got.shape == (1, 3 * cin, cout)
+    assert rel_l2(got[0].cpu().numpy(), want.numpy()) < RED_TOL
+    assert torch.equal(got, ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a)))
+    agg_g = torch.empty(B, T, V, 3 * cin, device=dev())
+    block.mix_agg(to_gpu(x), agg_g, to_gpu(a), cin)
+    ref = ops.rows_wgrad(agg_g, to_gpu(dy), K=3 * cin, N=cout)
+    assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < RED_TOL
+    pl = ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a), conv_param=(3, cin - (1 if cin == 4 else 0)))
+    k_true = cin - (1 if cin == 4 else 0)
+    assert pl.shape == (3, cout, k_true, 1, 1)
+    for k in range(3):
+        assert torch.equal(pl[k, :, :, 0, 0], got[0, k * cin:k * cin + k_true].t())
+    shared = ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a[:1]))         # static adjacency: one matrix set
+    want1 = torch.einsum("btwkc,btwo->kco", torch.einsum("btvc,kvw->btwkc", x, a[0]), dy).reshape(3 * cin, cout)
+    assert rel_l2(shared[0].cpu().numpy(), want1.numpy()) < RED_TOL
+
+
 @pytest.mark.parametrize("V,T,C,B", [(25, 30, 64, 3), (18, 33, 128, 2), (27, 12, 256, 2), (22, 9, 4, 2), (32, 5, 96, 1), (25, 300, 64, 2)])
 def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     """One pass over dagg gives both dx (+)= sum_k dagg_k . A^_k^T and dA^_k = x^T dagg_k (float64 einsums), with and without

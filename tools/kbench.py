@@ -122,6 +122,23 @@ def bench_spatial(B, reps):
         report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
 
 
+def bench_spatial_wgrad(B, reps):
+    """conv_d weight gradient: fused agg recompute vs joint_mix_vec + row weight gradient."""
+    for T, cin, cout in ((300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
+        x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
+        agg = torch.empty(B, T, V, 3 * cin, device=DEV)
+        rows = B * T * V
+        fl = rows * (6.0 * V * cin + 6.0 * cin * cout)
+        ms = timeit(lambda: ops.spatial_wgrad(x, dy, a), reps)
+        report(f"spatial_wgrad fused T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (cin + cout))
+
+        def pair():
+            block.mix_agg(x, agg, a, cin)
+            ops.rows_wgrad(agg, dy, K=3 * cin, N=cout)
+        ms = timeit(pair, reps)
+        report(f"mix_agg + rows_wgrad     T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (8 * cin + cout))
+
+
 def bench_spatial_bwd(B, reps):
     for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
         x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
@@ -182,7 +199,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_bwd,joint,elem")
+    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -192,7 +209,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
