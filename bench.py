@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
+                    help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-only", action="store_true",
                     help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
@@ -216,6 +218,9 @@ def main():
         return
     from fusion_gcn_amd import ops as _ops
     _ops.set_math_mode(args.math)
+    from fusion_gcn_amd import block as _block
+    _block.WGRAD_SIDE_STREAM = args.wgrad_stream != "main"
+    _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
     model = build_model(device)
     broadcast_parameters(model)

@@ -75,9 +75,9 @@ SIGNATURES = {
     "fgcn_adj_softmax_bwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),
     "fgcn_bn_finalize": (_I, [_P, _I, _LL, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "fgcn_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _P, _I, _P]),
-    "fgcn_bn_act": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
-    "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
-    "fgcn_bn_act_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "fgcn_bn_act": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_elem_tiles": (_I, [_LL]),
     "fgcn_col_sum": (_I, [_P, _P, _LL, _I, _I, _P]),
     "fgcn_spatial_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

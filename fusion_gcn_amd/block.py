@@ -22,6 +22,7 @@ Kernel schedule of one block, train mode (B = N*M samples):
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -311,11 +312,11 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         d = new(B, T, V, cout)
         part = ops.rows_gemm(x, W["down"], d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
         vec_d = _bn_vec(part, B * T * V, P, bufs, "gcn1.down.1", train)
-        g = ops.bn_act(y, vec_y, d, vec_d, relu=True)
+        g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True)
     else:
         d, vec_d = None, None
-        g = ops.bn_act(y, vec_y, x, None, relu=True)
-    S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g)
+        g, g_sign = ops.bn_act(y, vec_y, x, None, relu=True, sign_mask=True)
+    S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign)   # *_sign: 1 bit per element, the backward's ReLU gate
 
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
     kt = W["t"].shape[0]
@@ -324,19 +325,56 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     if cfg.residual == "none":
-        o = ops.bn_act(u, vec_u, None, None, relu=True)
+        o, o_sign = ops.bn_act(u, vec_u, None, None, relu=True, sign_mask=True)
     elif cfg.residual == "identity":
-        o = ops.bn_act(u, vec_u, x, None, relu=True)
+        o, o_sign = ops.bn_act(u, vec_u, x, None, relu=True, sign_mask=True)
     else:
         r = new(B, Tp, V, cout)
         part = ops.rows_gemm(x, W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
         vec_r = _bn_vec(part, B * Tp * V, P, bufs, "residual.bn", train)
-        o = ops.bn_act(u, vec_u, r, vec_r, relu=True)
-    S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=o)
+        o, o_sign = ops.bn_act(u, vec_u, r, vec_r, relu=True, sign_mask=True)
+    S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=o, o_sign=o_sign)
     return o, S
 
 
 # ---- backward --------------------------------------------------------------------------------------------------------
+# Weight gradients are leaves of the backward graph: nothing downstream in the block reads them.  They are MFMA-bound
+# while the chain that continues on the main stream (BatchNorm backward, the joint kernels, the narrow 1x1 data
+# gradients) is HBM-bound, so with WGRAD_SIDE_STREAM they are launched on a second HIP stream and share the CUs with
+# that chain (fork after the producer of their inputs, one join at the end of the block's backward; a HIP-graph capture
+# records the same fork/join as parallel branches).  WGRAD_STREAM_PRIORITY: 0 normal, -1 high (torch convention).
+WGRAD_SIDE_STREAM = True
+WGRAD_STREAM_PRIORITY = 0
+_side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+class _WgradBranch:
+    def __init__(self, device: torch.device, enabled: bool):
+        self.enabled = enabled and device.type == "cuda"
+        self.forked = False
+        if self.enabled:
+            key = (device.index, WGRAD_STREAM_PRIORITY)
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=device, priority=WGRAD_STREAM_PRIORITY)
+            self.main, self.side = torch.cuda.current_stream(device), _side_streams[key]
+
+    @contextlib.contextmanager
+    def __call__(self):
+        """Kernels launched (and tensors allocated) inside run on the side stream, after everything the main stream
+        holds so far.  Inputs must stay referenced until join(); outputs are only read on the main stream after it."""
+        if not self.enabled:
+            yield
+            return
+        self.side.wait_stream(self.main)
+        self.forked = True
+        with torch.cuda.stream(self.side):
+            yield
+
+    def join(self) -> None:
+        if self.enabled and self.forked:
+            self.main.wait_stream(self.side)
+
+
 def _bias_grad(d: torch.Tensor, c: int, train: bool) -> torch.Tensor:
     """Gradient of a conv bias that feeds a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
     block output does not depend on that bias and its gradient is exactly zero (the reference's autograd produces
@@ -362,19 +400,25 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
 
     dx = new(B, T, V, cx)
     dx_live = False      # becomes True once dx holds a valid partial sum
+    wgrad = _WgradBranch(dev, WGRAD_SIDE_STREAM)
 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
     if cfg.residual == "none":
-        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train)
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train,
+                                     sign_mask=S["o_sign"])
     elif cfg.residual == "identity":
-        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx)
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
+                                     sign_mask=S["o_sign"])
         dx_live = True
     else:
-        du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train)
+        du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train,
+                                      sign_mask=S["o_sign"])
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
-        G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1), conv_param=(1, cin_true))
+        with wgrad():
+            G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
+                                                       conv_param=(1, cin_true))
         G["residual.conv.bias"] = _bias_grad(dr, cout, train)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
@@ -382,20 +426,23 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     dg = new(B, T, V, cout)
     temporal_dgrad(du, dg, W, kt, s)
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
-    G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
+    with wgrad():
+        G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
     G["tcn1.conv.bias"] = _bias_grad(du, cout, train)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
     if cfg.has_down:
-        dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train)
+        dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train,
+                                      sign_mask=S["g_sign"])
         G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         ops.rows_gemm(dd, W["down_t"], dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
-        G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
+        with wgrad():
+            G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
         G["gcn1.down.0.bias"] = _bias_grad(dd, cout, train)
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
-                                     db_accumulate=dx_live)
+                                     db_accumulate=dx_live, sign_mask=S["g_sign"])
         dx_live = True
     G["gcn1.bn.weight"], G["gcn1.bn.bias"] = sums[1], sums[0]
 
@@ -403,14 +450,15 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     a_hat = S["a_hat"]
     c3 = 3 * cin
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
-    if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
-        # agg = x . A^ is formed in registers and contracted with dy at once: never written
-        gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
-    else:
-        agg = new(B, T, V, c3)
-        mix_agg(x, agg, a_hat, cin)
-        gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
-        del agg
+    with wgrad():
+        if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
+            # agg = x . A^ is formed in registers and contracted with dy at once: never written
+            gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
+        else:
+            agg = new(B, T, V, c3)
+            mix_agg(x, agg, a_hat, cin)
+            gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
+            del agg
     dbias = _bias_grad(dy, cout, train)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
@@ -437,13 +485,15 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         emb = S["emb"]
         demb = new(B, T, V, 6 * ic)
         gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
+        with wgrad():
+            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true))     # (6ic, cin_true, 1, 1)
         ops.rows_gemm(demb, W["emb_t"], dx, K=6 * ic, N=cx, accumulate=dx_live)
-        gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true))     # (6ic, cin_true, 1, 1)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic
                 G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic]
                 G[f"gcn1.{grp}.{k}.bias"] = gb[lo:lo + ic]
+    wgrad.join()
     return (dx if need_dx else None), G
 
 

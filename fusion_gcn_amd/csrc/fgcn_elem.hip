@@ -78,9 +78,11 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // ---- forward epilogue ----------------------------------------------------------------------------------------
-template <int RES>
+// MASK: also writes the sign bits of the result (bit e%8 of byte e/8 = [out[e] > 0]) for the backward passes, which then
+// read 1/32 of an activation instead of `out`; a lane pair shares a byte (n4 is even, host check).
+template <int RES, bool MASK>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
-                                                     float* out, long long n4, int C, int relu) {
+                                                     float* out, unsigned char* mask, long long n4, int C, int relu) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
@@ -99,15 +101,34 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
         }
         *reinterpret_cast<f32x4*>(out + i * 4) = y;
+        if (MASK) {
+            const int nib = (y[0] > 0.f ? 1 : 0) | (y[1] > 0.f ? 2 : 0) | (y[2] > 0.f ? 4 : 0) | (y[3] > 0.f ? 8 : 0);
+            const int other = __shfl_xor(nib, 1);
+            if (!(threadIdx.x & 1)) mask[i >> 1] = (unsigned char)(nib | (other << 4));
+        }
+    }
+}
+
+// [out > 0] of the four elements at offset o (multiple of 4) from the sign-bit image or from `out` itself
+template <bool MASKED>
+__device__ __forceinline__ void relu_gate(f32x4& dp, const float* out, const unsigned char* mask, long long o) {
+    if (MASKED) {
+        const int nib = mask[o >> 3] >> (int)(o & 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[e] = (nib >> e) & 1 ? dp[e] : 0.f;
+    } else {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(out + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[e] = y[e] > 0.f ? dp[e] : 0.f;
     }
 }
 
 // ---- backward pass 1: per-channel reductions ---------------------------------------------------------------
 // blockDim = (C/4, ny): thread (x, y) owns channels 4x..4x+3 and rows y, y+ny, ... of its tile.
-template <int RES>
-__global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const float* a, const float* va,
-                                         const float* b, const float* vb, float* partials, long long rows,
-                                         long long rows_per_tile, int C, int relu) {
+template <int RES, bool MASKED>
+__global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const unsigned char* mask, const float* a,
+                                         const float* va, const float* b, const float* vb, float* partials,
+                                         long long rows, long long rows_per_tile, int C, int relu) {
     extern __shared__ float red[];  // [ny][3][C]
     const int c = threadIdx.x * 4;
     const long long r0 = (long long)blockIdx.x * rows_per_tile;
@@ -123,11 +144,7 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
     for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
         const long long o = r * C + c;
         f32x4 dp = *reinterpret_cast<const f32x4*>(dout + o);
-        if (relu) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(out + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dp[e] = y[e] > 0.f ? dp[e] : 0.f;
-        }
+        if (relu) relu_gate<MASKED>(dp, out, mask, o);
         const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
         s1 += dp;
         s2 += dp * ah;
@@ -148,8 +165,9 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
 }
 
 // ---- backward pass 2: apply -----------------------------------------------------------------------------------
-template <int RES>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* out, const float* a,
+template <int RES, bool MASKED>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* out,
+                                                               const unsigned char* mask, const float* a,
                                                                const float* va, const float* b, const float* vb,
                                                                const float* sums, float* da, float* db, long long n4,
                                                                int C, int relu, int train, float inv_m,
@@ -158,11 +176,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
         f32x4 dp = *reinterpret_cast<const f32x4*>(dout + i * 4);
-        if (relu) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(out + i * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dp[e] = y[e] > 0.f ? dp[e] : 0.f;
-        }
+        if (relu) relu_gate<MASKED>(dp, out, mask, i * 4);
         const f32x4 sc_a = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         f32x4 ga = dp;
         if (train) {
@@ -288,7 +302,7 @@ static int check_elem(const char* what, long long rows, int C, int res_mode, con
 }
 
 extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
-                           long long rows, int C, int res_mode, int relu, void* stream) {
+                           unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream) {
     FGCN_REQUIRE(a && vec_a && out, FGCN_E_BADARG, "bn_act: null pointer");
     if (int e = check_elem("bn_act", rows, C, res_mode, b, vec_b)) return e;
     FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
@@ -296,10 +310,19 @@ extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, c
     const long long n4 = rows * C / 4;
     FGCN_REQUIRE(n4 < (1ll << 30), FGCN_E_BADARG, "elementwise kernel: tensor too large (>= 2^32 elements)");
     hipStream_t s = (hipStream_t)stream;
+    FGCN_REQUIRE(!sign_mask || n4 % 2 == 0, FGCN_E_BADARG, "bn_act: a sign mask needs rows*C to be a multiple of 8");
     dim3 g(stream_blocks(n4)), blk(256);
-    if (res_mode == 0) hipLaunchKernelGGL(bn_act_kernel<0>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
-    else if (res_mode == 1) hipLaunchKernelGGL(bn_act_kernel<1>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
-    else hipLaunchKernelGGL(bn_act_kernel<2>, g, blk, 0, s, a, vec_a, b, vec_b, out, n4, C, relu);
+#define FGCN_BN_ACT(RES_)                                                                                         \
+    do {                                                                                                          \
+        if (sign_mask)                                                                                            \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu); \
+    } while (0)
+    if (res_mode == 0) FGCN_BN_ACT(0);
+    else if (res_mode == 1) FGCN_BN_ACT(1);
+    else FGCN_BN_ACT(2);
+#undef FGCN_BN_ACT
     return launch_status("bn_act");
 }
 
@@ -312,10 +335,12 @@ static int reduce_block(int C, dim3* blk) {
     return 0;
 }
 
-extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const float* a, const float* vec_a,
-                                      const float* b, const float* vec_b, float* partials, int n_tiles, long long rows,
-                                      int C, int res_mode, int relu, void* stream) {
-    FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out), FGCN_E_BADARG, "bn_act_bwd_reduce: null pointer");
+extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const unsigned char* sign_mask,
+                                      const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                      float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
+                                      void* stream) {
+    FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out || sign_mask), FGCN_E_BADARG,
+                 "bn_act_bwd_reduce: null pointer");
     if (int e = check_elem("bn_act_bwd_reduce", rows, C, res_mode, b, vec_b)) return e;
     FGCN_REQUIRE(n_tiles == fgcn_elem_tiles(rows), FGCN_E_BADARG, "bn_act_bwd_reduce: n_tiles must be %d",
                  fgcn_elem_tiles(rows));
@@ -326,20 +351,24 @@ extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const
     const long long rpt = rows_per_tile_for(rows);
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)n_tiles);
-    if (res_mode == 2)
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<2>, g, blk, lds, s, dout, out, a, vec_a, b, vec_b, partials, rows,
-                           rpt, C, relu);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, g, blk, lds, s, dout, out, a, vec_a, b, vec_b, partials, rows,
-                           rpt, C, relu);
+#define FGCN_BN_RED(RES_, M_)                                                                                      \
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
+                       partials, rows, rpt, C, relu)
+    if (res_mode == 2) {
+        if (sign_mask) FGCN_BN_RED(2, true); else FGCN_BN_RED(2, false);
+    } else {
+        if (sign_mask) FGCN_BN_RED(0, true); else FGCN_BN_RED(0, false);
+    }
+#undef FGCN_BN_RED
     return launch_status("bn_act_bwd_reduce");
 }
 
-extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const float* a, const float* vec_a,
-                                     const float* b, const float* vec_b, const float* sums, float* da, float* db,
+extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned char* sign_mask,
+                                     const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                     const float* sums, float* da, float* db,
                                      long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
                                      void* stream) {
-    FGCN_REQUIRE(dout && vec_a && da && (!relu || out) && (!train || (a && sums)), FGCN_E_BADARG,
+    FGCN_REQUIRE(dout && vec_a && da && (!relu || out || sign_mask) && (!train || (a && sums)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: null pointer");
     FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG,
                  "bn_act_bwd_apply: bad shape/res_mode");
@@ -350,15 +379,17 @@ extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const 
     const float inv_m = 1.f / (float)rows;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
-    if (res_mode == 0 || !db)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<0>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
-                           relu, train, inv_m, db_accumulate);
-    else if (res_mode == 1)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
-                           relu, train, inv_m, db_accumulate);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<2>, g, blk, 0, s, dout, out, a, vec_a, b, vec_b, sums, da, db, n4, C,
-                           relu, train, inv_m, db_accumulate);
+#define FGCN_BN_APP(RES_, M_)                                                                                      \
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
+                       da, db, n4, C, relu, train, inv_m, db_accumulate)
+    if (res_mode == 0 || !db) {
+        if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
+    } else if (res_mode == 1) {
+        if (sign_mask) FGCN_BN_APP(1, true); else FGCN_BN_APP(1, false);
+    } else {
+        if (sign_mask) FGCN_BN_APP(2, true); else FGCN_BN_APP(2, false);
+    }
+#undef FGCN_BN_APP
     return launch_status("bn_act_bwd_apply");
 }
 

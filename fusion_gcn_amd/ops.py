@@ -452,8 +452,10 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float = 1e-5) ->
 
 
 def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = None, vec_b: Optional[torch.Tensor] = None,
-           relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(a*scale_a + shift_a + [b | b*scale_b + shift_b])."""
+           relu: bool = True, out: Optional[torch.Tensor] = None, sign_mask: bool = False):
+    """act(a*scale_a + shift_a + [b | b*scale_b + shift_b]).  ``sign_mask``: -> (out, mask) where mask holds one bit per
+    element, [out > 0] (uint8, numel/8; None when the element count is not a multiple of 8) -- what the backward's
+    ReLU gate reads instead of ``out``."""
     ensure_device()
     _chk(a, "bn_act.a")
     C = a.shape[-1]
@@ -463,15 +465,20 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
         raise _lib.FgcnError(f"bn_act: residual shape {tuple(b.shape)} != {tuple(a.shape)}")
     if out is None:
         out = torch.empty_like(a)
-    check(_lib.load().fgcn_bn_act(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(out), rows, C, res_mode, int(relu), _stream()),
-          "fgcn_bn_act")
-    return out
+    mask = None
+    if sign_mask and relu and a.numel() % 8 == 0:
+        mask = torch.empty(a.numel() // 8, device=a.device, dtype=torch.uint8)
+    check(_lib.load().fgcn_bn_act(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(out), _p(mask), rows, C, res_mode, int(relu),
+                                  _stream()), "fgcn_bn_act")
+    return (out, mask) if sign_mask else out
 
 
-def bn_act_bwd(dout: torch.Tensor, out: torch.Tensor, a: torch.Tensor, vec_a: torch.Tensor,
+def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor, vec_a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
-               res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False):
-    """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b."""
+               res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
+               sign_mask: Optional[torch.Tensor] = None):
+    """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
+    The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``."""
     ensure_device()
     _chk(dout, "bn_act_bwd.dout"), _chk(a, "bn_act_bwd.a")
     C = a.shape[-1]
@@ -479,15 +486,17 @@ def bn_act_bwd(dout: torch.Tensor, out: torch.Tensor, a: torch.Tensor, vec_a: to
     lib = _lib.load()
     tiles = lib.fgcn_elem_tiles(rows)
     partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
-    check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials), tiles, rows, C,
-                                     res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
+    if sign_mask is not None and (sign_mask.dtype != torch.uint8 or sign_mask.numel() * 8 != a.numel()):
+        raise _lib.FgcnError("bn_act_bwd: sign_mask must be the uint8 bit image of bn_act (numel/8 bytes)")
+    check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
+                                     tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
     sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
     reduce_sum(partials.view(tiles, -1), sums.view(-1))
     da = torch.empty_like(a)
     if res_mode != 0 and db is None:
         db = torch.empty_like(a)
-    check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da), _p(db), rows,
-                                    C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
+    check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
+                                    _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
           "fgcn_bn_act_bwd_apply")
     return da, db, sums
 

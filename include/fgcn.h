@@ -244,19 +244,22 @@ int fgcn_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 /* out = act( a*scale_a + shift_a + r ),  r = 0 | b | b*scale_b + shift_b          (agcn.py:113-115, :135-136)
  *   res_mode: 0 none, 1 identity, 2 batch-normalised.  vec_a / vec_b: the float[4][C] of fgcn_bn_finalize.
  *   rows x C elements, all tensors share row stride ld (== C). relu: 0/1. */
+/*   sign_mask (may be NULL; needs rows*C % 8 == 0): also stores bit e%8 of byte e/8 = [out[e] > 0] -- rows*C/8 bytes the
+ *   backward passes can read instead of the whole of `out` (the ReLU gate of the reference's autograd). */
 int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
-                long long rows, int C, int res_mode, int relu, void* stream);
+                unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream);
 
 /* Backward of the above, pass 1 (reductions): with dP = dout .* [out > 0] (or dout when relu = 0)
- *   partials[tile][0][c] = sum dP, [1] = sum dP * a_hat, [2] = sum dP * b_hat   (a_hat = (a-mean_a)*rstd_a). */
-int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const float* a, const float* vec_a,
-                           const float* b, const float* vec_b, float* partials, int n_tiles,
+ *   partials[tile][0][c] = sum dP, [1] = sum dP * a_hat, [2] = sum dP * b_hat   (a_hat = (a-mean_a)*rstd_a).
+ *   The gate comes from sign_mask when it is given (then `out` may be NULL), else from `out`. */
+int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const unsigned char* sign_mask, const float* a,
+                           const float* vec_a, const float* b, const float* vec_b, float* partials, int n_tiles,
                            long long rows, int C, int res_mode, int relu, void* stream);
 /* pass 2: da = scale_a * (dP - s1/m - a_hat*s2a/m) (train) or scale_a*dP (eval);
  *         db = dP (identity) or scale_b*(dP - s1/m - b_hat*s2b/m);  sums: float[3][C] reduced partials.
  *   db may be NULL (res_mode 0); db_accumulate adds into db instead of storing. */
-int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const float* a, const float* vec_a,
-                          const float* b, const float* vec_b, const float* sums, float* da, float* db,
+int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned char* sign_mask, const float* a,
+                          const float* vec_a, const float* b, const float* vec_b, const float* sums, float* da, float* db,
                           long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
                           void* stream);
 /* number of row tiles the reduce kernel uses for `rows` rows (leading dim of its partials) */

@@ -433,7 +433,7 @@ def test_joint_gram_general_operands():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("C,res_mode", [(64, 0), (64, 1), (128, 2), (256, 2), (16, 1)])
+@pytest.mark.parametrize("C,res_mode", [(64, 0), (64, 1), (128, 2), (256, 2), (16, 1), (12, 1)])
 def test_batchnorm_epilogue_forward_backward(C, res_mode):
     from fusion_gcn_amd import ops
     rows = 3 * 17 * 25
@@ -468,6 +468,14 @@ def test_batchnorm_epilogue_forward_backward(C, res_mode):
     ag, bg = to_gpu(a), (to_gpu(b) if b is not None else None)
     out = ops.bn_act(ag, vec_a, bg, vec_b, relu=True)
     assert rel_l2(out.cpu().numpy(), out_want.detach().numpy()) < FWD_TOL
+    # the sign-bit image the backward can read instead of `out`: bit e%8 of byte e/8 = [out[e] > 0], same output tensor
+    out2, sign = ops.bn_act(ag, vec_a, bg, vec_b, relu=True, sign_mask=True)
+    assert torch.equal(out2, out)
+    if (rows * C) % 8 == 0:
+        want_bits = np.packbits((out.cpu().numpy().reshape(-1) > 0), bitorder="little")
+        assert np.array_equal(sign.cpu().numpy(), want_bits)
+    else:
+        assert sign is None
 
     dout = rnd(rows, C, seed=46)
     ins = [a_r] + ([b_r] if b_r is not None else [])
@@ -482,6 +490,11 @@ def test_batchnorm_epilogue_forward_backward(C, res_mode):
     a_hat = (a - a.mean(0)) / torch.sqrt(a.var(0, unbiased=False) + 1e-5)
     assert rel_l2(sums[0].cpu().numpy(), dp.sum(0).numpy()) < RED_TOL
     assert rel_l2(sums[1].cpu().numpy(), (dp * a_hat).sum(0).numpy()) < RED_TOL
+    if (rows * C) % 8 == 0:          # gate from the bit image: bit-identical to the gate from the tensor
+        bits = torch.from_numpy(np.packbits((out_want.detach().numpy().reshape(-1) > 0), bitorder="little")).to(dev())
+        da2, db2, sums2 = ops.bn_act_bwd(to_gpu(dout), None, ag, vec_a, bg, vec_b, res_mode=res_mode, relu=True,
+                                         train=True, sign_mask=bits)
+        assert torch.equal(da2, da) and torch.equal(sums2, sums) and (db is None or torch.equal(db2, db))
     # eval-mode coefficients
     vec_e = ops.bn_eval_coeffs(to_gpu(gam), to_gpu(bet), rm, rv)
     want_scale = gam / torch.sqrt(rv.cpu().double() + 1e-5)

@@ -191,6 +191,11 @@ def bench_elem(B, reps):
         report(f"bn_act identity T{T} C{c}", ms, 0, 4.0 * rows * 3 * c)
         ms = timeit(lambda: ops.bn_act_bwd(a, out, b, vec, a, None, res_mode=1, db=torch.empty_like(a)), reps)
         report(f"bn_act_bwd identity T{T} C{c} (reduce+apply)", ms, 0, 4.0 * rows * 8 * c)
+        ms = timeit(lambda: ops.bn_act(a, vec, b, None, relu=True, out=out, sign_mask=True), reps)
+        report(f"bn_act identity + sign bits T{T} C{c}", ms, 0, 4.0 * rows * (3 + 1 / 32) * c)
+        _, sign = ops.bn_act(a, vec, b, None, relu=True, out=out, sign_mask=True)
+        ms = timeit(lambda: ops.bn_act_bwd(a, None, b, vec, a, None, res_mode=1, db=torch.empty_like(a), sign_mask=sign), reps)
+        report(f"bn_act_bwd identity T{T} C{c} (reduce+apply, gate from sign bits)", ms, 0, 4.0 * rows * (6 + 2 / 32) * c)
         ms = timeit(lambda: ops.col_sum(a, c), reps)
         report(f"col_sum T{T} C{c}", ms, 0, 4.0 * rows * c)
 
