@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--math", choices=("f32", "bf16", "bf16x3"), default="f32",
                     help="f32: the headline parity path; bf16: BASELINE config 5 (bf16 MFMA operands, f32 accumulation)")
     ap.add_argument("--verify-dp", action="store_true",
                     help="N > 1 only: check the exchanged gradient buffer of the (graph) step against an eager step")

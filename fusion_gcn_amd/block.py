@@ -127,11 +127,13 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torc
         W["t"] = wt.permute(2, 1, 0).contiguous()                                 # (kt, c, o)
         W["t_t"] = wt.permute(2, 0, 1).contiguous()                               # (kt, o, c)
         # k-interleaved forms for the halo-tile kernel; a stride-2 conv runs as an even-tap and an odd-tap pass
+        # (ops.pack_conv: k-interleaved f32, or the three-way bf16 split in math mode bf16x3 -- the cache key of the
+        # packed set includes the math mode)
         if cfg.stride == 1:
-            W["t4"], W["t_t4"] = ops.pack_k4(W["t"]), ops.pack_k4(W["t_t"])
+            W["t4"], W["t_t4"] = ops.pack_conv(W["t"]), ops.pack_conv(W["t_t"])
         else:
             for par, tag in ((0, "e"), (1, "o")):      # data gradient only (see temporal_fwd)
-                W[f"t_t4_{tag}"] = ops.pack_k4(W["t_t"][par::2].contiguous())
+                W[f"t_t4_{tag}"] = ops.pack_conv(W["t_t"][par::2].contiguous())
         if cfg.residual == "conv":
             w = _pad_last(P["residual.conv.weight"].view(cout, cin), cx)
             W["res"] = w.t().contiguous().unsqueeze(0)
@@ -160,7 +162,7 @@ FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg ins
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
-FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128}
+FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 64}
 MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
 
 

@@ -15,8 +15,8 @@ int math_mode() { return g_math_mode; }
 }  // namespace fgcn
 
 extern "C" int fgcn_set_math_mode(int mode) {
-    if (mode != FGCN_MATH_F32 && mode != FGCN_MATH_BF16)
-        return fgcn::fail(FGCN_E_BADARG, "set_math_mode: %d is neither FGCN_MATH_F32 nor FGCN_MATH_BF16", mode);
+    if (mode != FGCN_MATH_F32 && mode != FGCN_MATH_BF16 && mode != FGCN_MATH_BF16X3)
+        return fgcn::fail(FGCN_E_BADARG, "set_math_mode: %d is not one of FGCN_MATH_F32 / BF16 / BF16X3", mode);
     fgcn::g_math_mode = mode;
     return FGCN_OK;
 }

@@ -73,6 +73,87 @@ __device__ __forceinline__ f32x16 mfma_bf16(s16x4 a, s16x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
 }
 
+
+// FGCN_MATH_BF16X3: f32-accurate products on the bf16 matrix pipe.  x = x_h + x_m + x_l with three bf16 terms (8 + 8 + 8
+// significand bits: the split is exact), and a.b is the sum of the six partial products down to 2^-16 of the leading one
+// (h.h, h.m, m.h, m.m, h.l, l.h); the dropped ones (m.l, l.m, l.l) are below 2^-23 |a.b|, i.e. below the rounding of an
+// f32 product.  Every partial product is exact in the f32 accumulator.  Six bf16 MFMAs (16 cycles each) replace four f32
+// MFMAs (64 cycles each): 2.67x the f32 matrix rate at f32 accuracy.
+// Frag<MM>: the operand fragment of one bf16 MFMA (4 consecutive k per lane) in math mode MM (1: rounded, 2: split).
+// The production kernels of this mode use v_mfma_f32_32x32x16_bf16 (8 k per lane: lane (r, h) holds k = 8h + j, 32 cycles
+// per instruction = the full bf16 rate) on operands that were split ONCE -- weights by fgcn_pack_split3 in HBM, activation
+// tiles as they are staged into LDS: splitting a fragment in registers costs 22 vector instructions per 4 values, which
+// only pays where the fragment feeds many MFMAs.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ f32x16 mfma_bf16_k16(u32x4v a, u32x4v b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six partial products of a three-way split pair (index 0 = high, 1 = middle, 2 = low part), small terms first
+__device__ __forceinline__ f32x16 mfma_x3_k16(const u32x4v (&a)[3], const u32x4v (&b)[3], f32x16 c) {
+    c = mfma_bf16_k16(a[2], b[0], c);
+    c = mfma_bf16_k16(a[0], b[2], c);
+    c = mfma_bf16_k16(a[1], b[1], c);
+    c = mfma_bf16_k16(a[1], b[0], c);
+    c = mfma_bf16_k16(a[0], b[1], c);
+    return mfma_bf16_k16(a[0], b[0], c);
+}
+
+template <int MM> struct Frag;
+template <> struct Frag<1> { s16x4 h; };
+template <> struct Frag<2> { s16x4 h, m, l; };
+
+__device__ __forceinline__ void split_bf16_pair(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+    const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+}
+
+// four values -> their high / middle / low bf16 parts, 8 bytes each (element order kept)
+__device__ __forceinline__ void split3_x4(f32x4 a, u32x2& h, u32x2& m, u32x2& l) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_bf16_pair(a[0], a[1], h0, m0, l0);
+    split_bf16_pair(a[2], a[3], h1, m1, l1);
+    h = u32x2{h0, h1};
+    m = u32x2{m0, m1};
+    l = u32x2{l0, l1};
+}
+
+template <int MM>
+__device__ __forceinline__ Frag<MM> make_frag(float a0, float a1, float a2, float a3) {
+    Frag<MM> f;
+    if constexpr (MM == 1) {
+        f.h = pack_bf16(a0, a1, a2, a3);
+    } else {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_bf16_pair(a0, a1, h0, m0, l0);
+        split_bf16_pair(a2, a3, h1, m1, l1);
+        f.h = __builtin_bit_cast(s16x4, u32x2{h0, h1});
+        f.m = __builtin_bit_cast(s16x4, u32x2{m0, m1});
+        f.l = __builtin_bit_cast(s16x4, u32x2{l0, l1});
+    }
+    return f;
+}
+template <int MM>
+__device__ __forceinline__ Frag<MM> make_frag(f32x4 a) { return make_frag<MM>(a[0], a[1], a[2], a[3]); }
+
+template <int MM>
+__device__ __forceinline__ f32x16 mfma_frag(const Frag<MM>& a, const Frag<MM>& b, f32x16 c) {
+    if constexpr (MM == 2) {          // small terms first
+        c = mfma_bf16(a.l, b.h, c);
+        c = mfma_bf16(a.h, b.l, c);
+        c = mfma_bf16(a.m, b.m, c);
+        c = mfma_bf16(a.m, b.h, c);
+        c = mfma_bf16(a.h, b.m, c);
+    }
+    return mfma_bf16(a.h, b.h, c);
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ f32x16 zero16() {

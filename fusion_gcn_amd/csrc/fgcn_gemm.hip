@@ -437,6 +437,32 @@ __global__ __launch_bounds__(1024) void reduce_sum_strided_kernel(float* dst, co
     }
 }
 
+// FGCN_MATH_BF16X3 weights: (taps, K, N) f32 -> [part][tap][ceil(K/8)][N][8] bf16, part 0/1/2 = high / middle / low term of
+// the exact three-way split w = w_h + w_m + w_l; 8 consecutive k per (n) = one lane's B fragment of
+// v_mfma_f32_32x32x16_bf16 (16 bytes, lanes = consecutive n).  Channels beyond K are zeros.
+__global__ void pack_split3_kernel(unsigned short* dst, const float* src, int taps, int K, int N, int K8) {
+    const long long total = (long long)taps * K8 * N;
+    const long long plane = total * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const long long tk = i / N;
+        const int k8 = (int)(tk % K8), tap = (int)(tk / K8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * k8 + j;
+            v[j] = k < K ? src[((long long)tap * K + k) * N + n] : 0.f;
+        }
+        u32x2 h0, m0, l0, h1, m1, l1;
+        split3_x4(f32x4{v[0], v[1], v[2], v[3]}, h0, m0, l0);
+        split3_x4(f32x4{v[4], v[5], v[6], v[7]}, h1, m1, l1);
+        u32x4v* out = reinterpret_cast<u32x4v*>(dst + i * 8);
+        out[0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4v*>(dst + plane + i * 8) = u32x4v{m0[0], m0[1], m1[0], m1[1]};
+        *reinterpret_cast<u32x4v*>(dst + 2 * plane + i * 8) = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
 __global__ void pack_weight_kernel(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
                                    long long st_tap, long long st_k, long long st_n, int flip) {
     const long long total = (long long)taps * K * N_dst;
@@ -589,6 +615,17 @@ extern "C" int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int 
     hipLaunchKernelGGL(reduce_sum_strided_kernel, dim3((unsigned)cdiv(count, 64)), dim3(64, 16), 0, (hipStream_t)stream, dst,
                        src, S, taps, K, N, K_dst, st_tap, st_k, st_n, accumulate);
     return launch_status("reduce_sum_strided");
+}
+
+extern "C" int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, void* stream) {
+    FGCN_REQUIRE(dst && src && taps > 0 && K > 0 && N > 0, FGCN_E_BADARG, "pack_split3: bad argument (taps=%d K=%d N=%d)",
+                 taps, K, N);
+    FGCN_REQUIRE(aligned16(dst), FGCN_E_ALIGN, "pack_split3: 16-byte alignment");
+    const int K8 = (K + 7) / 8;
+    const long long total = (long long)taps * K8 * N;
+    const unsigned blocks = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    hipLaunchKernelGGL(pack_split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, taps, K, N, K8);
+    return launch_status("pack_split3");
 }
 
 extern "C" int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,

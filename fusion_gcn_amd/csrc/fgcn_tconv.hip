@@ -19,6 +19,7 @@
 // Strided convolutions run as two stride-1 passes over the even / odd frames ("virtual frames" with a stride and
 // offset on the input or output side), so no tap is ever multiplied with a structurally-zero row.
 #include "fgcn_common.hpp"
+#include <type_traits>
 
 namespace fgcn {
 
@@ -30,6 +31,7 @@ struct HaloP {
     float* stats;
     long long Mv;                       // virtual rows = B * Tv * V
     unsigned in_bytes, w_bytes, out_bytes;
+    unsigned w_plane_bytes;             // FGCN_MATH_BF16X3: bytes of one part (high / middle / low) of the split weights
     int tiles_m, tiles_n, per_xcd;   // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
     int Tv, V, K, N, ld_in, ld_out;
     int T_in_full, in_s, in_o, Th_in;   // input frame of virtual frame th: th*in_s + in_o (valid while th < Th_in)
@@ -41,6 +43,7 @@ struct HaloP {
 
 constexpr int HAS = 36;                 // LDS row stride of the halo image (32 channels + 4 pad: conflict-free b128)
 constexpr int HALO_MAX_STAGE = 13;      // ceil((128 + 8*32) / 32) + 1
+constexpr int XSB = 80;                 // FGCN_MATH_BF16X3: LDS row stride in bytes of one bf16 part (32 channels + 8 pad)
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -48,8 +51,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // MINB = workgroups per CU the register allocation aims at (launch-bounds hint; fgcn_set_tuning key 4 picks 2 or 3)
-// BF: FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments are read)
-template <int NT, int MINB, bool BF>
+// MM: math mode -- FGCN_MATH_F32 or FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments
+// are read); FGCN_MATH_BF16X3 is conv_halo_x3_kernel below
+template <int NT, int MINB, int MM>
 __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,10 +160,10 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
             }
             a1 = a_read(it + 1, ok1);
             if (!ok0) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) {
-                const s16x4 ap = pack_bf16(a0);
+            if constexpr (MM != 0) {
+                const Frag<MM> ap = make_frag<MM>(a0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ap, pack_bf16(b0[nt]), acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_frag<MM>(ap, make_frag<MM>(b0[nt]), acc[nt]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
                 a0 = a_read(it + 2, ok0);
             }
             if (!ok1) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) {
-                const s16x4 ap = pack_bf16(a1);
+            if constexpr (MM != 0) {
+                const Frag<MM> ap = make_frag<MM>(a1);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ap, pack_bf16(b1[nt]), acc[nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_frag<MM>(ap, make_frag<MM>(b1[nt]), acc[nt]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
             }
         }
     }
+
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
@@ -266,6 +271,237 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     }
 }
 
+// ---- FGCN_MATH_BF16X3 ------------------------------------------------------------------------------------------------
+// Same halo-tile scheme on the bf16 matrix pipe at f32 accuracy (fgcn_common.hpp): the image is split into its three
+// bf16 parts as it is staged (three planes of [row][32 + 8 pad] bf16: one ds_read_b128 per part = the 8 k of a lane), the
+// weights come pre-split from HBM (fgcn_pack_split3: [part][tap][k/8][n][8]); one step = 16 channels = one
+// v_mfma_f32_32x32x16_bf16 per partial product.  Six bf16 MFMAs move the work of eight f32 ones in 3/8 of the cycles, so
+// the weight stream (6 instead of 4 bytes per weight) would need 4x the L2 bandwidth of the f32 kernel: the waves are
+// therefore arranged 2 x 2 over the (128 rows x 64*NT columns) tile -- a wave owns 64 rows (MT = 2 row tiles) x 32*NT
+// columns and every weight fragment feeds two row tiles (the 4 x 1 arrangement of the f32 kernel measured L2-bound:
+// 64 B/clk/CU).  Weights are prefetched one unit (one column tile of one step) ahead in a ring of two fragment sets,
+// across step and chunk boundaries; past the last unit the address wraps to the first one (a valid, unused load).
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
+    static_assert(MT == 2 && (NT == 1 || NT == 2), "wave tile is 64 rows x 32 or 64 columns");
+    extern __shared__ __attribute__((aligned(16))) float Ah[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const long long m0 = (long long)bm * 128;
+    constexpr int BN = 2 * NT * 32;                  // columns of the workgroup tile
+    const int n0 = bn * BN;
+    const int V = p.V, TvV = p.Tv * p.V;
+    const unsigned k4b = (tid & 7) * 16;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
+
+    bool row_ok[MT];
+    int th_lane[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long mrow = m0 + (wr * MT + mt) * 32 + l31;
+        row_ok[mt] = mrow < p.Mv;
+        th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
+    }
+
+    unsigned src_off[HALO_MAX_STAGE];
+    const int nstage = (p.halo_rows + 31) >> 5;
+#pragma unroll
+    for (int i = 0; i < HALO_MAX_STAGE; ++i) {
+        src_off[i] = 0x80000000u;
+        const int r = (tid >> 3) + 32 * i;
+        const long long hv = m0 + (long long)p.dmin * V + r;
+        if (i < nstage && hv >= 0 && hv < p.Mv) {
+            const unsigned hu = (unsigned)hv;
+            const int n = (int)(hu / (unsigned)TvV);
+            const int rem = (int)(hu - (unsigned)n * (unsigned)TvV);
+            const int th = (int)((unsigned)rem / (unsigned)V);
+            const int v = rem - th * V;
+            const int fr = th * p.in_s + p.in_o;
+            if (th < p.Th_in && fr < p.T_in_full)
+                src_off[i] = (unsigned)(((((long long)n * p.T_in_full + fr) * V + v) * p.ld_in) * 4) + k4b;
+        }
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16();
+
+    const int col = n0 + wc * NT * 32 + l31;         // + nt*32
+    unsigned wvoff[NT];                              // per-lane byte offset into one part: (h*N + col) * 8 bf16
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wvoff[nt] = (unsigned)(((long long)h * p.N + col + nt * 32) * 16);
+
+    unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
+    const unsigned plane = (unsigned)p.halo_rows * XSB;
+    const unsigned char* xrow = Xh + (wr * MT * 32 + l31) * XSB + 16 * h;
+    const int IT2 = p.taps * 2;                      // (tap, 16-channel half) steps per 32-channel chunk
+    const int K8 = p.K >> 3;
+    auto load_w = [&](u32x4v (&dst)[3], int nt, int it, int kc) {
+        if (it >= IT2) {                             // (at most two steps past the chunk: IT2 >= 2)
+            it -= IT2;
+            kc += 32;
+        }
+        if (kc >= p.K) {
+            it = 0;
+            kc = 0;
+        }
+        const int j = it >> 1, s2 = it & 1;
+        const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 2 * s2) * p.N) * 16);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nt], so + pl * p.w_plane_bytes, 0);
+    };
+    auto load_a = [&](u32x4v (&dst)[MT][3], int it) {
+        const int j = it >> 1, s2 = it & 1;
+        const int d = j * p.tb + p.tc;
+        const unsigned char* src = xrow + (d - p.dmin) * V * XSB + 32 * s2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ts = th_lane[mt] + d;
+            const bool ok = row_ok[mt] && ts >= 0 && ts < p.Th_in;      // frame mask of this (row, tap)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x4v v = *reinterpret_cast<const u32x4v*>(src + mt * 32 * XSB + pl * plane);
+                dst[mt][pl] = ok ? v : u32x4v{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    u32x4v wq[2][3];
+    load_w(wq[0], 0, 0, 0);
+    // one step: NT units; `odd` = parity of the step (selects the ring slot when NT == 1)
+    auto step = [&](const u32x4v (&a)[MT][3], int it, int kc, auto odd) {
+        if constexpr (NT == 2) {
+            load_w(wq[1], 1, it, kc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma_x3_k16(a[mt], wq[0], acc[mt][0]);
+            load_w(wq[0], 0, it + 1, kc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][1] = mfma_x3_k16(a[mt], wq[1], acc[mt][1]);
+        } else {
+            constexpr int cur = decltype(odd)::value;
+            load_w(wq[cur ^ 1], 0, it + 1, kc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma_x3_k16(a[mt], wq[cur], acc[mt][0]);
+        }
+    };
+    using Even = std::integral_constant<int, 0>;
+    using Odd = std::integral_constant<int, 1>;
+
+    for (int kc = 0; kc < p.K; kc += 32) {
+        __syncthreads();                             // previous chunk's image reads are done
+        {
+            f32x4 stage[HALO_MAX_STAGE];
+#pragma unroll
+            for (int i = 0; i < HALO_MAX_STAGE; ++i)
+                if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+#pragma unroll
+            for (int i = 0; i < HALO_MAX_STAGE; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                if (i < nstage && r < p.halo_rows) {
+                    u32x2 ph, pm, pl;
+                    split3_x4(stage[i], ph, pm, pl);
+                    unsigned char* dst = Xh + r * XSB + (tid & 7) * 8;
+                    *reinterpret_cast<u32x2*>(dst) = ph;
+                    *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
+                }
+            }
+        }
+        __syncthreads();
+        u32x4v x0[MT][3], x1[MT][3];
+        load_a(x0, 0);
+        for (int it = 0; it < IT2; it += 2) {        // IT2 is even
+            load_a(x1, it + 1);
+            step(x0, it, kc, Even{});
+            if (it + 2 < IT2) load_a(x0, it + 2);
+            step(x1, it + 1, kc, Odd{});
+        }
+    }
+
+    // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums ---------------------------------
+    const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+    float ssum[NT], ssq[NT], bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.f;
+        ssq[nt] = 0.f;
+        bv[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rbias, col + nt * 32 < p.N ? (unsigned)(col + nt * 32) * 4u : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        unsigned rowoff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = m0 + (wr * MT + mt) * 32 + acc_row(r, lane);
+            bool ok = m < p.Mv;
+            unsigned orow = (unsigned)(ok ? m : 0);
+            if (!plain_out) {                              // wave-uniform
+                const int n = (int)(orow / (unsigned)TvV);
+                const int rem = (int)(orow - (unsigned)n * (unsigned)TvV);
+                const int th = (int)((unsigned)rem / (unsigned)V);
+                const int v = rem - th * V;
+                ok = ok && th < p.Th_out;
+                orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
+            }
+            rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = col + nt * 32;
+            const unsigned coff = c < p.N ? (unsigned)c * 4u : OOB;
+            float old[16];
+            if (p.accumulate) {                            // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rout, (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff, 0, 0));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned off = (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff;
+                const float val = acc[mt][nt][r] + bv[nt] + old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+                const float kept = off != OOB ? val : 0.f;
+                ssum[nt] += kept;
+                ssq[nt] += kept * kept;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float* red = Ah;                                   // [which][wr][BN]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float a = ssum[nt] + __shfl_xor(ssum[nt], 32);
+            const float b = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (lane < 32) {
+                red[(0 * 2 + wr) * BN + (wc * NT + nt) * 32 + lane] = a;
+                red[(1 * 2 + wr) * BN + (wc * NT + nt) * 32 + lane] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.N)
+                p.stats[((long long)bm * 2 + which) * p.N + n0 + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
+        }
+    }
+}
+
 }  // namespace fgcn
 
 using namespace fgcn;
@@ -292,13 +528,17 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                  "tconv_halo: bad frame views");
     FGCN_REQUIRE((long long)(Th_in - 1) * in_s + in_o < T_in_full && (long long)(Th - 1) * out_s + out_o < T_out_full,
                  FGCN_E_BADARG, "tconv_halo: frame view exceeds the tensor (Th=%d Th_in=%d)", Th, Th_in);
-    const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4, w_bytes = (long long)taps * K * N * 4;
+    const int mm = fgcn::math_mode();
+    // FGCN_MATH_BF16X3: w4 is the split form (fgcn_pack_split3: three bf16 parts of [tap][K/8][N][8]) = 6 bytes per weight
+    const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4;
+    const long long w_bytes = (long long)taps * K * N * (mm == FGCN_MATH_BF16X3 ? 6 : 4);
     const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
     FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     HaloP p;
     p.in = in; p.out = out; p.w4 = w4; p.bias = bias; p.stats = stat_partials;
     p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes; p.out_bytes = (unsigned)out_bytes;
+    p.w_plane_bytes = (unsigned)((long long)taps * K * N * 2);
     p.Tv = Th > Th_in ? Th : Th_in;
     p.Mv = (long long)B * p.Tv * V;
     p.V = V; p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out;
@@ -310,36 +550,44 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const int dmax = d0 < d1 ? d1 : d0;
     p.halo_rows = 128 + (dmax - p.dmin) * V;
     FGCN_REQUIRE(p.halo_rows <= 32 * HALO_MAX_STAGE, FGCN_E_BADARG, "tconv_halo: halo of %d rows too large", p.halo_rows);
-    const size_t lds = (size_t)p.halo_rows * HAS * sizeof(float);
+    const size_t lds = mm == FGCN_MATH_BF16X3 ? (size_t)p.halo_rows * XSB * 3 : (size_t)p.halo_rows * HAS * sizeof(float);
     const long long tiles = cdiv(p.Mv, 128);
     FGCN_REQUIRE(p.Mv < (1ll << 31) - 4096, FGCN_E_BADARG, "tconv_halo: too many rows (32-bit row indices)");
     hipStream_t s = (hipStream_t)stream;
     static bool lds_opt_in = false;  // once per process (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in) {               // V > 25 needs more than the default dynamic-LDS limit (gfx950: 160 KiB per CU)
-        const int max_lds = 32 * HALO_MAX_STAGE * HAS * (int)sizeof(float);
+        const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;   // the larger of the two image forms
 #define FGCN_HALO_ATTR(NT_, MB_)                                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, false>),          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, 0>),              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, true>),           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT_, MB_, 1>),              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
         FGCN_HALO_ATTR(2, 2); FGCN_HALO_ATTR(2, 3); FGCN_HALO_ATTR(4, 2); FGCN_HALO_ATTR(4, 3);
 #undef FGCN_HALO_ATTR
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         lds_opt_in = true;
     }
     const bool three = fgcn::tuning(4) == 0;   // 3 workgroups per CU measured faster (64 channels: 0.73 -> 0.63 ms)
-    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
     p.tiles_m = (int)tiles;
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
     p.per_xcd = 0;
+    if (mm == FGCN_MATH_BF16X3) {
+        if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2>), grid, dim3(256), lds, s, p);
+        return launch_status("tconv_halo");
+    }
     if ((fgcn::tuning(5) & 2) && tiles * p.tiles_n < (1ll << 30)) {   // measured neutral: off
         p.per_xcd = (int)cdiv(tiles * p.tiles_n, 8);
         grid = dim3((unsigned)(p.per_xcd * 8));
     }
 #define FGCN_HALO_LAUNCH(NT_, MB_)                                                                           \
     do {                                                                                                     \
-        if (bf) hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, true>), grid, dim3(256), lds, s, p);          \
-        else hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, false>), grid, dim3(256), lds, s, p);            \
+        if (mm == FGCN_MATH_BF16) hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, 1>), grid, dim3(256), lds, s, p); \
+        else hipLaunchKernelGGL((conv_halo_kernel<NT_, MB_, 0>), grid, dim3(256), lds, s, p);                \
     } while (0)
     if (N <= 64) {
         if (three) FGCN_HALO_LAUNCH(2, 3);

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, pack_weights, param_names
 from ...util.partition_strategy import GraphPartitionStrategy
 
@@ -153,7 +154,7 @@ class SpatialTemporalConv(nn.Module):
         return [self._tensor(bn).num_batches_tracked for bn in bn_names(self.cfg)]
 
     def _packed(self, params):
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (ops.get_math_mode(),) + tuple((p.data_ptr(), p._version) for p in params)   # the packed forms depend on the mode
         if self._wcache is None or self._wcache[0] != key:
             P = dict(zip(param_names(self.cfg), params))
             self._wcache = (key, pack_weights(P, self.cfg))

@@ -17,15 +17,16 @@ from ._lib import GramItem, MixItem, MixTerm, TMap, check
 TMAP_POINTWISE = (1, 1, 0, 0, 1)
 
 
-MATH_MODES = {"f32": 0, "bf16": 1}     # FGCN_MATH_F32 / FGCN_MATH_BF16 (include/fgcn.h)
+MATH_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}     # FGCN_MATH_F32 / _BF16 / _BF16X3 (include/fgcn.h)
 
 
 def set_math_mode(mode: str) -> None:
     """Arithmetic of the convolution / GEMM kernels, process-wide: "f32" (default, the parity path) or "bf16" (BASELINE
     config 5: operands rounded to bfloat16 as the MFMA fragments are formed, float32 accumulation; everything in HBM,
-    BatchNorm statistics, softmax and the joint mixing stay float32)."""
+    BatchNorm statistics, softmax and the joint mixing stay float32) or "bf16x3" (float32-accurate: operands split into
+    three bfloat16 terms, six partial products per MFMA step, float32 accumulation -- same tolerances as "f32")."""
     if mode not in MATH_MODES:
-        raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16)")
+        raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16 | bf16x3)")
     check(_lib.load().fgcn_set_math_mode(MATH_MODES[mode]), "fgcn_set_math_mode")
 
 
@@ -114,17 +115,41 @@ def pack_k4(w: torch.Tensor) -> torch.Tensor:
     return w.view(taps, K // 4, 4, N).permute(0, 1, 3, 2).contiguous()
 
 
+def pack_split3(w: torch.Tensor) -> torch.Tensor:
+    """(taps, K, N) f32 packed weights -> the FGCN_MATH_BF16X3 form: (3, taps, ceil(K/8), N, 8) bfloat16, the exact
+    three-way split w = w_h + w_m + w_l in the fragment order of v_mfma_f32_32x32x16_bf16."""
+    ensure_device()
+    _chk(w, "pack_split3.w")
+    taps, K, N = w.shape
+    out = torch.empty((3, taps, (K + 7) // 8, N, 8), device=w.device, dtype=torch.bfloat16)
+    check(_lib.load().fgcn_pack_split3(_p(out), _p(w), taps, K, N, _stream()), "fgcn_pack_split3")
+    return out
+
+
+def pack_conv(w: torch.Tensor) -> torch.Tensor:
+    """Packed (taps, K, N) weights in the streamed form of the current math mode: ``pack_k4`` (f32 / bf16) or
+    ``pack_split3`` (bf16x3)."""
+    return pack_split3(w) if get_math_mode() == "bf16x3" else pack_k4(w)
+
+
 def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
                in_view=None, out_view=(1, 0), bias: Optional[torch.Tensor] = None, stats: bool = False,
                accumulate: bool = False) -> Optional[torch.Tensor]:
     """Halo-tile temporal conv over virtual frames [0, Th): input frame th*in_s + in_o (th < Th_in), output frame
     th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked."""
     ensure_device()
-    _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out"), _chk(w4, "tconv_halo.w4")
+    _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out")
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
-    K, N = w4.shape[1] * 4, w4.shape[2]
-    if (Bo, Vo) != (B, V) or w4.shape[0] != taps or w4.shape[3] != 4 or K > ld_in or N > ld_out:
+    split = get_math_mode() == "bf16x3"          # the weights then are the pack_split3 form
+    if split:
+        if w4.dtype != torch.bfloat16 or w4.dim() != 5 or w4.shape[0] != 3 or w4.shape[4] != 8 or not w4.is_contiguous():
+            raise _lib.FgcnError(f"tconv_halo: math mode bf16x3 takes pack_split3 weights, got {w4.dtype} {tuple(w4.shape)}")
+        w_taps, K, N = w4.shape[1], w4.shape[2] * 8, w4.shape[3]
+    else:
+        _chk(w4, "tconv_halo.w4")
+        w_taps, K, N = w4.shape[0], w4.shape[1] * 4, w4.shape[2]
+    if (Bo, Vo) != (B, V) or w_taps != taps or (not split and w4.shape[3] != 4) or K > ld_in or N > ld_out:
         raise _lib.FgcnError(f"tconv_halo: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} w4={tuple(w4.shape)}")
     in_s, in_o, Th_in = in_view if in_view is not None else (1, 0, T_in)
     out_s, out_o = out_view

@@ -49,9 +49,15 @@ int fgcn_set_tuning(int key, int value);
  *   FGCN_MATH_BF16 (BASELINE config 5) operands rounded to bfloat16 (round-to-nearest-even) as the fragments are
  *                  formed, v_mfma_f32_32x32x8_bf16 with float32 accumulation; tensors in HBM, BatchNorm statistics,
  *                  softmax, the joint mixing and every reduction stay float32.  Different tolerance contract:
- *                  logits <= 1e-2 rel, gradient cosine >= 0.98 against the f32 path. */
+ *                  logits <= 1e-2 rel, gradient cosine >= 0.98 against the f32 path.
+ *   FGCN_MATH_BF16X3 float32-accurate products on the bf16 matrix pipe: both operand fragments are split exactly into
+ *                  three bfloat16 terms (x = x_h + x_m + x_l, 24 significand bits) and the six partial products down
+ *                  to 2^-16 of the leading one are accumulated in float32 (the dropped ones are below 2^-23 |a.b|, the
+ *                  rounding of a float32 product).  Six bf16 MFMAs replace four f32 MFMAs (2.67x the f32 matrix
+ *                  rate); same tolerance contract as FGCN_MATH_F32 (the parity tests run in both). */
 #define FGCN_MATH_F32 0
 #define FGCN_MATH_BF16 1
+#define FGCN_MATH_BF16X3 2
 int fgcn_set_math_mode(int mode);
 int fgcn_get_math_mode(void);
 
@@ -126,6 +132,11 @@ int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int ac
  * parameter's own (out, in, taps, 1) layout, so the gradient needs no transposing copy. */
 int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K, int N, int K_dst,
                             long long st_tap, long long st_k, long long st_n, int accumulate, void* stream);
+
+/* FGCN_MATH_BF16X3 form of a packed (taps, K, N) weight: dst = unsigned short[3][taps][ceil(K/8)][N][8], part 0/1/2 the
+ * high / middle / low bfloat16 term of the exact split w = w_h + w_m + w_l (channels beyond K are zeros).  This is
+ * what fgcn_tconv_halo takes as `w4` while that math mode is selected. */
+int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, void* stream);
 
 /* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
  * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */

@@ -41,3 +41,24 @@ def rel_l2(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
+
+
+# The kernel / block / model parity modules run twice on the GPU: in the default math mode (exact f32 MFMA) and in
+# "bf16x3" (f32-accurate split-bf16 products, include/fgcn.h) -- the same oracle, the same tolerances.
+BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.module.__name__.split(".")[-1] in BOTH_MATH_MODES and "fgcn_math" in metafunc.fixturenames:
+        metafunc.parametrize("fgcn_math", ["f32", "bf16x3"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def fgcn_math(request):
+    mode = getattr(request, "param", "f32")
+    if mode == "f32":
+        yield mode
+        return
+    from fusion_gcn_amd import ops
+    with ops.math_mode(mode):
+        yield mode

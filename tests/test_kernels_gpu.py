@@ -146,11 +146,11 @@ def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
     wg, wg_t = to_gpu(wt), to_gpu(wt.permute(0, 2, 1))
     W = {"t": wg, "t_t": wg_t}
     if s == 1:
-        W["t4"], W["t_t4"] = ops.pack_k4(wg), ops.pack_k4(wg_t)
+        W["t4"], W["t_t4"] = ops.pack_conv(wg), ops.pack_conv(wg_t)        # the streamed form of the current math mode
     else:
         for par, tag in ((0, "e"), (1, "o")):
-            W[f"t4_{tag}"] = ops.pack_k4(wg[par::2].contiguous())
-            W[f"t_t4_{tag}"] = ops.pack_k4(wg_t[par::2].contiguous())
+            W[f"t4_{tag}"] = ops.pack_conv(wg[par::2].contiguous())
+            W[f"t_t4_{tag}"] = ops.pack_conv(wg_t[par::2].contiguous())
     x = rnd(B, T, V, C, seed=82).requires_grad_(True)
     want = ref_rows_conv(x, wt, ops.conv_tmap(kt, s), Tp, bias)
     u = torch.full((B, Tp, V, O), 3.0, device=dev())

@@ -78,11 +78,11 @@ def bench_tconv(B, reps):
             wt = rnd(9, c, c) * (9 * c) ** -0.5
             W = {"t": wt, "t_t": wt.permute(0, 2, 1).contiguous()}
             if s == 1:
-                W["t4"], W["t_t4"] = ops.pack_k4(wt), ops.pack_k4(wt.permute(0, 2, 1).contiguous())
+                W["t4"], W["t_t4"] = ops.pack_conv(wt), ops.pack_conv(wt.permute(0, 2, 1).contiguous())
             else:
                 for par, tag in ((0, "e"), (1, "o")):
-                    W[f"t4_{tag}"] = ops.pack_k4(wt[par::2].contiguous())
-                    W[f"t_t4_{tag}"] = ops.pack_k4(wt.permute(0, 2, 1)[par::2].contiguous())
+                    W[f"t4_{tag}"] = ops.pack_conv(wt[par::2].contiguous())
+                    W[f"t_t4_{tag}"] = ops.pack_conv(wt.permute(0, 2, 1)[par::2].contiguous())
             g, u, bias = rnd(B, T, V, c), torch.empty(B, Tp, V, c, device=DEV), rnd(c)
             du, dg = rnd(B, Tp, V, c), torch.empty(B, T, V, c, device=DEV)
             fl = 2.0 * B * Tp * V * 9 * c * c
@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
-    ap.add_argument("--math", default="f32", choices=("f32", "bf16"), help="fgcn_set_math_mode")
+    ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3"), help="fgcn_set_math_mode")
     args = ap.parse_args()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
