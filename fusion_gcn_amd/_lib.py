@@ -63,7 +63,7 @@ SIGNATURES = {
     "fgcn_reduce_sum_strided": (_I, [_P, _P, _I, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_group_mean_splits": (_I, [_I, _I]),
     "fgcn_group_mean": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "fgcn_pack_split3": (_I, [_P, _P, _I, _I, _I, _P]),
+    "fgcn_pack_split3": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
     "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P, _P]),

@@ -115,7 +115,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torc
             W["emb_b"] = torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
         d = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
         W["d"] = torch.cat([w.t() for w in d], 0).contiguous()                    # (3cx, cout)
-        W["d4"] = ops.pack_k4(W["d"].unsqueeze(0))[0]                             # (3cx/4, cout, 4) for the fused kernel
+        W["d4"] = ops.pack_spatial(W["d"], cx)                                    # (3cx/4, cout, 4) for the fused kernel
         W["d_t"] = torch.cat(d, 1).contiguous().unsqueeze(0)                      # (1, cout, 3cx)
         W["dt4"] = ops.pack_k4(torch.stack(d, 0).contiguous())                    # (3, cout/4, cx, 4) fused backward
         W["d_b"] = (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()

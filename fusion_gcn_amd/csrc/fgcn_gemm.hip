@@ -440,7 +440,10 @@ __global__ __launch_bounds__(1024) void reduce_sum_strided_kernel(float* dst, co
 // FGCN_MATH_BF16X3 weights: (taps, K, N) f32 -> [part][tap][ceil(K/8)][N][8] bf16, part 0/1/2 = high / middle / low term of
 // the exact three-way split w = w_h + w_m + w_l; 8 consecutive k per (n) = one lane's B fragment of
 // v_mfma_f32_32x32x16_bf16 (16 bytes, lanes = consecutive n).  Channels beyond K are zeros.
-__global__ void pack_split3_kernel(unsigned short* dst, const float* src, int taps, int K, int N, int K8) {
+// acc_order: group k8 = 2*k16 + h holds k = 16*k16 + 4h + (j & 3) + 8*(j >> 2) instead of 8*k8 + j -- the order in which
+// the registers of a 32x32 accumulator tile (rows (r&3) + 8(r>>2) + 4h) enumerate its rows, for kernels that feed an
+// accumulator straight back as the other operand (spatial_fwd step 2).
+__global__ void pack_split3_kernel(unsigned short* dst, const float* src, int taps, int K, int N, int K8, int acc_order) {
     const long long total = (long long)taps * K8 * N;
     const long long plane = total * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -450,7 +453,7 @@ __global__ void pack_split3_kernel(unsigned short* dst, const float* src, int ta
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = 8 * k8 + j;
+            const int k = acc_order ? 16 * (k8 >> 1) + 4 * (k8 & 1) + (j & 3) + 8 * (j >> 2) : 8 * k8 + j;
             v[j] = k < K ? src[((long long)tap * K + k) * N + n] : 0.f;
         }
         u32x2 h0, m0, l0, h1, m1, l1;
@@ -617,14 +620,16 @@ extern "C" int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int 
     return launch_status("reduce_sum_strided");
 }
 
-extern "C" int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, void* stream) {
+extern "C" int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, int acc_order,
+                                void* stream) {
     FGCN_REQUIRE(dst && src && taps > 0 && K > 0 && N > 0, FGCN_E_BADARG, "pack_split3: bad argument (taps=%d K=%d N=%d)",
                  taps, K, N);
     FGCN_REQUIRE(aligned16(dst), FGCN_E_ALIGN, "pack_split3: 16-byte alignment");
-    const int K8 = (K + 7) / 8;
+    const int K8 = acc_order ? (K + 15) / 16 * 2 : (K + 7) / 8;
     const long long total = (long long)taps * K8 * N;
     const unsigned blocks = (unsigned)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
-    hipLaunchKernelGGL(pack_split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, taps, K, N, K8);
+    hipLaunchKernelGGL(pack_split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, taps, K, N, K8,
+                       acc_order);
     return launch_status("pack_split3");
 }
 

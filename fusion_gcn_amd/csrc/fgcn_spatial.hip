@@ -37,6 +37,7 @@ struct SpatialP {
     float* stats;
     int B, T, V, Cin, Cout, ld_x, ld_y, ns, a_batched, t_chunk;
     unsigned x_bytes, w_bytes;
+    unsigned w_plane_bytes;   // FGCN_MATH_BF16X3: bytes of one part of the split weights
 };
 
 constexpr int TTS = 36;   // row stride of the per-wave transpose tile (32 channels + 4 pad)
@@ -49,9 +50,14 @@ __device__ __forceinline__ f32x4 sp_load4(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-// BF: FGCN_MATH_BF16 for step 2 (the Cin x Cout contraction); step 1 (the <= 32-joint mixing) stays f32
-template <int CT_IN, int CT_OUT, bool BF>
-__global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
+// MM: math mode of step 2 (the Cin x Cout contraction); step 1 (the <= 32-joint mixing) stays f32.
+//   FGCN_MATH_BF16  : operands rounded as the fragments are formed, one bf16 MFMA per four f32 ones.
+//   FGCN_MATH_BF16X3: f32-accurate split products on v_mfma_f32_32x32x16_bf16 (fgcn_common.hpp).  Registers 8gp..8gp+7 of
+//                     the step-1 accumulator are one operand fragment (rows 16gp + 4h + (j&3) + 8(j>>2)), split in
+//                     registers once per CT_OUT column tiles; the weights come pre-split in the same row order
+//                     (fgcn_pack_split3, acc_order): [part][(k*Cin + c)/16][h][o][8].  Whole 32-channel tiles only.
+template <int CT_IN, int CT_OUT, int MM>
+__global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && (CT_IN <= 2 || MM == 2))) ? 2 : 1)) void spatial_fwd_kernel(SpatialP p) {
     constexpr int WROW = CT_OUT * 32;                 // padded Cout
     constexpr unsigned OOB = 0x80000000u;             // buffer offset beyond num_records: the load returns 0
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,7 +87,10 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
         ah[(k * 32 + v) * AHS + w] = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
     }
     for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
-    for (int i = tid; i < WROW; i += 256) bl[i] = (p.bias && i < p.Cout) ? p.bias[i] : 0.f;
+    // blockIdx.z = column block of WROW outputs (bf16x3 runs 256 outputs as two 128-column blocks: two workgroups per CU
+    // and no register spills, at the price of forming agg twice)
+    const int ob = blockIdx.z * WROW;
+    for (int i = tid; i < WROW; i += 256) bl[i] = (p.bias && ob + i < p.Cout) ? p.bias[ob + i] : 0.f;
     __syncthreads();                                  // the only workgroup barrier before the final statistics sum
 
     const int ksteps = (V + 1) >> 1;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
     unsigned wvo[CT_OUT];
 #pragma unroll
     for (int ot = 0; ot < CT_OUT; ++ot) {
-        const int o = ot * 32 + l31;
+        const int o = ob + ot * 32 + l31;
         wvo[ot] = o < p.Cout ? (unsigned)(h * p.Cout + o) * 16u : OOB;
     }
     // x of frame t, channel tile ci: 16 branch-free dword loads (joint 2s + h of channel ci*32 + lane)
@@ -114,13 +123,31 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
         for (int ot = 0; ot < CT_OUT; ++ot) wv[ot] = sp_load4(rw, gok ? wvo[ot] : OOB, so);
     };
 
-    float xcur[16], xnxt[16];
+    // LATE_X (bf16x3 with >= 4 output tiles): no second x tile -- the next tile is loaded into xcur right after the last
+    // subset's step 1 consumed it (its step 2 covers the latency); 16 registers less
+    constexpr bool LATE_X = MM == 2 && CT_OUT >= 4;
+    float xcur[16], xnxt[LATE_X ? 1 : 16];
     // at 256 outputs a second weight set measured slower in f32 (1.33 -> 1.47 ms); with bf16 MFMAs (8 per weight group instead
     // of 32) the un-prefetched loads are pure exposed latency (2.4 ms), so that mode always prefetches
+    constexpr bool BF = MM == 1;
     constexpr bool PREFETCH_W = CT_OUT <= 4 || BF;
-    f32x4 wcur[CT_OUT], wnxt[PREFETCH_W ? CT_OUT : 1];
+    f32x4 wcur[MM == 2 ? 1 : CT_OUT], wnxt[(PREFETCH_W && MM != 2) ? CT_OUT : 1];
+    // bf16x3: the fragment sets of one 16-channel group (3 parts x CT_OUT column tiles); a column tile's set is reloaded
+    // with the next group's right after its MFMAs were issued, so CT_OUT - 1 units of MFMAs cover the load
+    u32x4v w3[MM == 2 ? CT_OUT : 1][3];
+    auto load_w3 = [&](int ci, int k, int gp, int ot, u32x4v (&wv)[3]) {
+        const unsigned so = (unsigned)((((k * p.Cin + ci * 32) >> 4) + gp) * 2 * p.Cout) * 16u;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            wv[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[ot], so + pl * p.w_plane_bytes, 0);
+    };
     load_x(t0 + wave, 0, xcur);
-    if constexpr (PREFETCH_W) load_w(0, 0, 0, wcur);
+    if constexpr (MM == 2) {
+#pragma unroll
+        for (int ot = 0; ot < CT_OUT; ++ot) load_w3(0, 0, 0, ot, w3[ot]);
+    } else if constexpr (PREFETCH_W) {
+        load_w(0, 0, 0, wcur);
+    }
     for (int tg = t0; tg < t1; tg += 4) {
         const int t = tg + wave;
         const bool tv = t < t1;
@@ -131,8 +158,10 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
 #pragma unroll 1
         for (int ci = 0; ci < CT_IN; ++ci) {
             // next tile's x (next channel tile, or the first tile of this wave's next frame) flies during the MFMAs
-            if (ci + 1 < CT_IN) load_x(t, ci + 1, xnxt);
-            else load_x(t + 4, 0, xnxt);
+            if constexpr (!LATE_X) {
+                if (ci + 1 < CT_IN) load_x(t, ci + 1, xnxt);
+                else load_x(t + 4, 0, xnxt);
+            }
             const int cleft = p.Cin - ci * 32;          // valid input channels in this tile
 #pragma unroll 1
             for (int k = 0; k < NS; ++k) {
@@ -142,10 +171,38 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
 #pragma unroll
                 for (int s = 0; s < 16; ++s)
                     if (s < ksteps) agg = mfma32(xcur[s], ak[(2 * s + h) * AHS], agg);
+                if constexpr (LATE_X) {
+                    if (k == NS - 1) {
+                        if (ci + 1 < CT_IN) load_x(t, ci + 1, xcur);
+                        else load_x(t + 4, 0, xcur);
+                    }
+                }
                 // step 2: y^T tiles; registers 4g..4g+3 of agg are contraction rows c = 8g + 4h + (0..3).
                 // The weights of the NEXT step (next group, next subset, next channel tile, or the next frame's first
                 // step) are requested before this step's MFMAs.
                 const int nG = cleft >= 32 ? 4 : (cleft + 7) >> 3;   // channel groups that exist (Cin = 4: one)
+                if constexpr (MM == 2) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        int nci = ci, nk = k, ngp = 1;               // the group after this one (wave-uniform)
+                        if (gp == 1) {
+                            ngp = 0;
+                            if (k + 1 < NS) nk = k + 1;
+                            else if (ci + 1 < CT_IN) nci = ci + 1, nk = 0;
+                            else nci = 0, nk = 0;
+                        }
+                        u32x2 h0, m0, l0, h1, m1, l1;
+                        split3_x4(f32x4{agg[8 * gp], agg[8 * gp + 1], agg[8 * gp + 2], agg[8 * gp + 3]}, h0, m0, l0);
+                        split3_x4(f32x4{agg[8 * gp + 4], agg[8 * gp + 5], agg[8 * gp + 6], agg[8 * gp + 7]}, h1, m1, l1);
+                        const u32x4v b3[3] = {u32x4v{h0[0], h0[1], h1[0], h1[1]}, u32x4v{m0[0], m0[1], m1[0], m1[1]},
+                                              u32x4v{l0[0], l0[1], l1[0], l1[1]}};
+#pragma unroll
+                        for (int ot = 0; ot < CT_OUT; ++ot) {
+                            acc[ot] = mfma_x3_k16(w3[ot], b3, acc[ot]);
+                            load_w3(nci, nk, ngp, ot, w3[ot]);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (g < nG) {                       // wave-uniform
@@ -175,7 +232,8 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) xcur[s] = xnxt[s];
+            for (int s = 0; s < 16; ++s)
+                if constexpr (!LATE_X) xcur[s] = xnxt[s];
         }
 
         // ---- epilogue for this frame: transpose each 32(o) x 32(w) accumulator through a wave-private LDS tile so
@@ -188,9 +246,9 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4*>(&T[l31 * TTS + 8 * g + 4 * h]) =
                     f32x4{acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]};
-            const int o = ot * 32 + c4;
+            const int ol = ot * 32 + c4, o = ob + ol;   // column inside this block / in the tensor
             const bool ook = o < p.Cout;                // Cout % 4 == 0: the quad is all-in or all-out
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bl[o]);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bl[ol]);
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -215,8 +273,8 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
                 if (lane < 8 && ook) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        st[(wave * 2 + 0) * WROW + o + e] += s1[e];
-                        st[(wave * 2 + 1) * WROW + o + e] += s2[e];
+                        st[(wave * 2 + 0) * WROW + ol + e] += s1[e];
+                        st[(wave * 2 + 1) * WROW + ol + e] += s2[e];
                     }
                 }
             }
@@ -228,8 +286,8 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && CT_IN <= 2)) 
         const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         for (int i = tid; i < 2 * WROW; i += 256) {
             const int which = i / WROW, o = i - which * WROW;
-            if (o < p.Cout)
-                p.stats[(wg * 2 + which) * p.Cout + o] = st[(0 * 2 + which) * WROW + o] + st[(1 * 2 + which) * WROW + o] +
+            if (ob + o < p.Cout)
+                p.stats[(wg * 2 + which) * p.Cout + ob + o] = st[(0 * 2 + which) * WROW + o] + st[(1 * 2 + which) * WROW + o] +
                                                           st[(2 * 2 + which) * WROW + o] + st[(3 * 2 + which) * WROW + o];
         }
     }
@@ -250,19 +308,24 @@ extern "C" int fgcn_spatial_tiles(int B, int T) { return (int)(B * cdiv(T, spati
 template <int CI, int CO>
 static void launch_spatial(const SpatialP& p, hipStream_t s) {
     const size_t lds = (((3 * 32 * AHS + 3) & ~3) + 4 * 2 * CO * 32 + 4 * 32 * TTS + CO * 32) * sizeof(float);
-    dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B);
+    dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B, (unsigned)cdiv(p.Cout, CO * 32));
     static bool lds_opt_in = false;  // once per instantiation (not a stream operation: keep it out of graph captures)
     if (!lds_opt_in && lds > 48 * 1024) {  // gfx950 has 160 KiB of LDS per CU; opt in beyond the default dynamic limit
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_fwd_kernel<CI, CO, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_opt_in = true;
     }
-    if (fgcn::math_mode() == FGCN_MATH_BF16)
-        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, true>), grid, dim3(256), lds, s, p);
+    const int mm = fgcn::math_mode();
+    if (mm == FGCN_MATH_BF16X3 && p.Cin % 32 == 0)      // (narrower inputs: the exact f32 kernel, f32 pack_k4 weights)
+        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, 2>), grid, dim3(256), lds, s, p);
+    else if (mm == FGCN_MATH_BF16)
+        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, 1>), grid, dim3(256), lds, s, p);
     else
-        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, false>), grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL((spatial_fwd_kernel<CI, CO, 0>), grid, dim3(256), lds, s, p);
 }
 
 template <int CI>
@@ -271,7 +334,10 @@ static int dispatch_out(int co, const SpatialP& p, hipStream_t s) {
         case 1: launch_spatial<CI, 1>(p, s); return 0;
         case 2: launch_spatial<CI, 2>(p, s); return 0;
         case 4: launch_spatial<CI, 4>(p, s); return 0;
-        case 8: launch_spatial<CI, 8>(p, s); return 0;
+        case 8:
+            if (fgcn::math_mode() == FGCN_MATH_BF16X3 && p.Cin % 32 == 0) launch_spatial<CI, 4>(p, s);   // two column blocks
+            else launch_spatial<CI, 8>(p, s);
+            return 0;
     }
     return -1;
 }
@@ -291,11 +357,14 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
     auto tiles = [](int c) { int t = (c + 31) / 32; return t <= 1 ? 1 : t <= 2 ? 2 : t <= 4 ? 4 : t <= 8 ? 8 : -1; };
     const int ci = tiles(Cin), co = tiles(Cout);
     FGCN_REQUIRE(ci > 0 && co > 0, FGCN_E_BADARG, "spatial_fwd: at most 256 channels (Cin=%d Cout=%d)", Cin, Cout);
-    const long long x_bytes = (long long)B * T * V * ld_x * 4, w_bytes = (long long)n_subsets * Cin * Cout * 4;
+    const bool split = fgcn::math_mode() == FGCN_MATH_BF16X3 && Cin % 32 == 0;   // wd: fgcn_pack_split3(acc_order) form
+    const long long x_bytes = (long long)B * T * V * ld_x * 4;
+    const long long w_bytes = (long long)n_subsets * Cin * Cout * (split ? 6 : 4);
     FGCN_REQUIRE(x_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "spatial_fwd: x must be smaller than 2 GiB (32-bit buffer offsets)");
     FGCN_REQUIRE(aligned16(x) || true, FGCN_E_ALIGN, "spatial_fwd: alignment");
     SpatialP p{x, a_hat, wd, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, n_subsets, a_hat_batched,
-               spatial_t_chunk(B, T), (unsigned)x_bytes, (unsigned)w_bytes};
+               spatial_t_chunk(B, T), (unsigned)x_bytes, (unsigned)w_bytes,
+               (unsigned)((long long)n_subsets * Cin * Cout * 2)};
     hipStream_t s = (hipStream_t)stream;
     int rc = -1;
     switch (ci) {

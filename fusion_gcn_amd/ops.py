@@ -115,14 +115,16 @@ def pack_k4(w: torch.Tensor) -> torch.Tensor:
     return w.view(taps, K // 4, 4, N).permute(0, 1, 3, 2).contiguous()
 
 
-def pack_split3(w: torch.Tensor) -> torch.Tensor:
+def pack_split3(w: torch.Tensor, acc_order: bool = False) -> torch.Tensor:
     """(taps, K, N) f32 packed weights -> the FGCN_MATH_BF16X3 form: (3, taps, ceil(K/8), N, 8) bfloat16, the exact
-    three-way split w = w_h + w_m + w_l in the fragment order of v_mfma_f32_32x32x16_bf16."""
+    three-way split w = w_h + w_m + w_l in the fragment order of v_mfma_f32_32x32x16_bf16.  ``acc_order``: the k order in
+    which an MFMA accumulator enumerates its rows (spatial_fwd's weights; K is padded to a multiple of 16)."""
     ensure_device()
     _chk(w, "pack_split3.w")
     taps, K, N = w.shape
-    out = torch.empty((3, taps, (K + 7) // 8, N, 8), device=w.device, dtype=torch.bfloat16)
-    check(_lib.load().fgcn_pack_split3(_p(out), _p(w), taps, K, N, _stream()), "fgcn_pack_split3")
+    k8 = (K + 15) // 16 * 2 if acc_order else (K + 7) // 8
+    out = torch.empty((3, taps, k8, N, 8), device=w.device, dtype=torch.bfloat16)
+    check(_lib.load().fgcn_pack_split3(_p(out), _p(w), taps, K, N, int(acc_order), _stream()), "fgcn_pack_split3")
     return out
 
 
@@ -130,6 +132,14 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
     """Packed (taps, K, N) weights in the streamed form of the current math mode: ``pack_k4`` (f32 / bf16) or
     ``pack_split3`` (bf16x3)."""
     return pack_split3(w) if get_math_mode() == "bf16x3" else pack_k4(w)
+
+
+def pack_spatial(wd: torch.Tensor, cin: int) -> torch.Tensor:
+    """The stacked (K*Cin, Cout) conv_d matrix in the form spatial_fwd streams in the current math mode: ``pack_k4``
+    (K*Cin/4, Cout, 4), or in bf16x3 (whole 32-channel tiles only) the accumulator-ordered three-way split."""
+    if get_math_mode() == "bf16x3" and cin % 32 == 0:
+        return pack_split3(wd.unsqueeze(0), acc_order=True)
+    return pack_k4(wd.unsqueeze(0))[0]
 
 
 def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
@@ -559,11 +569,16 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     """y = sum_k conv_d[k](x . A^_k) fused; wd = pack_k4 of the stacked (K*Cin, Cout) matrix, i.e. (K*Cin/4, Cout, 4).
     -> (y (B,T,V,Cout), stats partials or None)."""
     ensure_device()
-    _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat"), _chk(wd, "spatial_fwd.wd")
+    _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat")
     B, T, V, ld_x = x.shape
     ns = a_hat.shape[1]
-    if tuple(wd.shape) != (ns * Cin // 4, Cout, 4) or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
-        raise _lib.FgcnError(f"spatial_fwd: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} wd={tuple(wd.shape)}")
+    if get_math_mode() == "bf16x3" and Cin % 32 == 0:      # weights in the pack_spatial split form
+        w_ok = wd.dtype == torch.bfloat16 and tuple(wd.shape) == (3, 1, ns * Cin // 8, Cout, 8) and wd.is_contiguous()
+    else:
+        w_ok = wd.dtype == torch.float32 and tuple(wd.shape) == (ns * Cin // 4, Cout, 4) and wd.is_contiguous()
+    if not w_ok or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
+        raise _lib.FgcnError(f"spatial_fwd: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} "
+                             f"wd={wd.dtype} {tuple(wd.shape)} (math mode {get_math_mode()}: weights from pack_spatial)")
     lib = _lib.load()
     y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
     part = torch.empty((lib.fgcn_spatial_tiles(B, T), 2, Cout), device=x.device, dtype=torch.float32) if stats else None

@@ -135,8 +135,10 @@ int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K
 
 /* FGCN_MATH_BF16X3 form of a packed (taps, K, N) weight: dst = unsigned short[3][taps][ceil(K/8)][N][8], part 0/1/2 the
  * high / middle / low bfloat16 term of the exact split w = w_h + w_m + w_l (channels beyond K are zeros).  This is
- * what fgcn_tconv_halo takes as `w4` while that math mode is selected. */
-int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, void* stream);
+ * what fgcn_tconv_halo takes as `w4` while that math mode is selected.  acc_order = 1 (fgcn_spatial_fwd's `wd` in that
+ * mode; ceil(K/16)*2 groups): group 2*k16 + h holds k = 16*k16 + 4h + (j & 3) + 8*(j >> 2), the order in which a 32x32
+ * MFMA accumulator enumerates its rows. */
+int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, int acc_order, void* stream);
 
 /* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
  * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */

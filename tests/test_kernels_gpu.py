@@ -517,7 +517,7 @@ def test_fused_spatial_forward(B, T, V, cin, cout, batched):
     bias = rnd(cout, seed=53)
     agg = torch.einsum("btvc,bkvw->btwkc", x, a.expand(B, 3, V, V)).reshape(B, T, V, 3 * cin)
     want = agg @ wd + bias
-    y, part = ops.spatial_fwd(to_gpu(x), to_gpu(a), ops.pack_k4(to_gpu(wd).unsqueeze(0))[0], to_gpu(bias), Cin=cin, Cout=cout,
+    y, part = ops.spatial_fwd(to_gpu(x), to_gpu(a), ops.pack_spatial(to_gpu(wd), cin), to_gpu(bias), Cin=cin, Cout=cout,
                               stats=True)
     assert rel_l2(y.cpu().numpy(), want.numpy()) < FWD_TOL
     tot = part.double().sum(0).cpu()

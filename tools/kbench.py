@@ -116,7 +116,7 @@ def bench_wgrad(B, reps):
 def bench_spatial(B, reps):
     for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
         x, a = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2
-        wd, bias = ops.pack_k4((rnd(3 * cin, cout) * (3 * cin) ** -0.5).unsqueeze(0))[0], rnd(cout)
+        wd, bias = ops.pack_spatial(rnd(3 * cin, cout) * (3 * cin) ** -0.5, cin), rnd(cout)
         ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
         rows = B * T * V
         report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
