@@ -124,6 +124,17 @@ __device__ __forceinline__ void split3_x4(f32x4 a, u32x2& h, u32x2& m, u32x2& l)
     l = u32x2{l0, l1};
 }
 
+// eight values (one lane's k = 8h + j fragment of v_mfma_f32_32x32x16_bf16) -> the three bf16 parts, 16 bytes each
+__device__ __forceinline__ void split3_x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                          u32x4v (&q)[3]) {
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split3_x4(f32x4{v0, v1, v2, v3}, h0, m0, l0);
+    split3_x4(f32x4{v4, v5, v6, v7}, h1, m1, l1);
+    q[0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+    q[1] = u32x4v{m0[0], m0[1], m1[0], m1[1]};
+    q[2] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+}
+
 template <int MM>
 __device__ __forceinline__ Frag<MM> make_frag(float a0, float a1, float a2, float a3) {
     Frag<MM> f;

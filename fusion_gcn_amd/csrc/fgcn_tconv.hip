@@ -281,9 +281,18 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // columns and every weight fragment feeds two row tiles (the 4 x 1 arrangement of the f32 kernel measured L2-bound:
 // 64 B/clk/CU).  Weights are prefetched one unit (one column tile of one step) ahead in a ring of two fragment sets,
 // across step and chunk boundaries; past the last unit the address wraps to the first one (a valid, unused load).
-template <int MT, int NT>
+// KC = channels per staged chunk: 32 for the temporal convs (image = tile + halo rows); 64 for 1x1 convolutions (taps = 1:
+// no halo, 128 rows), where a chunk is only KC/16 steps of MFMAs -- there the NEXT chunk's rows are requested before the
+// MFMAs of the current one and parked in registers (PF), so the global latency is not paid between two barriers.
+template <int MT, int NT, int KC>
 __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
-    static_assert(MT == 2 && (NT == 1 || NT == 2), "wave tile is 64 rows x 32 or 64 columns");
+    static_assert(MT == 2 && (NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
+    constexpr int XS = KC * 2 + 16;                  // LDS row stride of one bf16 part, bytes (conflict-free b128 reads)
+    constexpr int TPR = KC / 4;                      // threads per staged row (16 bytes each)
+    constexpr int RPP = 256 / TPR;                   // rows per staging pass
+    constexpr int SPC = KC / 16;                     // steps per tap and chunk
+    constexpr bool PF = KC == 64;
+    constexpr int NST = PF ? 8 : HALO_MAX_STAGE;     // staging passes (PF: 128 rows, checked by the host)
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
     constexpr int BN = 2 * NT * 32;                  // columns of the workgroup tile
     const int n0 = bn * BN;
     const int V = p.V, TvV = p.Tv * p.V;
-    const unsigned k4b = (tid & 7) * 16;
+    const unsigned k4b = (tid % TPR) * 16;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
@@ -307,12 +316,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
         th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
     }
 
-    unsigned src_off[HALO_MAX_STAGE];
-    const int nstage = (p.halo_rows + 31) >> 5;
+    unsigned src_off[NST];
+    const int nstage = (p.halo_rows + RPP - 1) / RPP;
 #pragma unroll
-    for (int i = 0; i < HALO_MAX_STAGE; ++i) {
+    for (int i = 0; i < NST; ++i) {
         src_off[i] = 0x80000000u;
-        const int r = (tid >> 3) + 32 * i;
+        const int r = tid / TPR + RPP * i;
         const long long hv = m0 + (long long)p.dmin * V + r;
         if (i < nstage && hv >= 0 && hv < p.Mv) {
             const unsigned hu = (unsigned)hv;
@@ -338,36 +347,36 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
     for (int nt = 0; nt < NT; ++nt) wvoff[nt] = (unsigned)(((long long)h * p.N + col + nt * 32) * 16);
 
     unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
-    const unsigned plane = (unsigned)p.halo_rows * XSB;
-    const unsigned char* xrow = Xh + (wr * MT * 32 + l31) * XSB + 16 * h;
-    const int IT2 = p.taps * 2;                      // (tap, 16-channel half) steps per 32-channel chunk
+    const unsigned plane = (unsigned)p.halo_rows * XS;
+    const unsigned char* xrow = Xh + (wr * MT * 32 + l31) * XS + 16 * h;
+    const int IT2 = p.taps * SPC;                    // (tap, 16-channel group) steps per chunk
     const int K8 = p.K >> 3;
     auto load_w = [&](u32x4v (&dst)[3], int nt, int it, int kc) {
         if (it >= IT2) {                             // (at most two steps past the chunk: IT2 >= 2)
             it -= IT2;
-            kc += 32;
+            kc += KC;
         }
         if (kc >= p.K) {
             it = 0;
             kc = 0;
         }
-        const int j = it >> 1, s2 = it & 1;
+        const int j = it / SPC, s2 = it % SPC;
         const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 2 * s2) * p.N) * 16);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nt], so + pl * p.w_plane_bytes, 0);
     };
     auto load_a = [&](u32x4v (&dst)[MT][3], int it) {
-        const int j = it >> 1, s2 = it & 1;
+        const int j = it / SPC, s2 = it % SPC;
         const int d = j * p.tb + p.tc;
-        const unsigned char* src = xrow + (d - p.dmin) * V * XSB + 32 * s2;
+        const unsigned char* src = xrow + (d - p.dmin) * V * XS + 32 * s2;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int ts = th_lane[mt] + d;
             const bool ok = row_ok[mt] && ts >= 0 && ts < p.Th_in;      // frame mask of this (row, tap)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const u32x4v v = *reinterpret_cast<const u32x4v*>(src + mt * 32 * XSB + pl * plane);
+                const u32x4v v = *reinterpret_cast<const u32x4v*>(src + mt * 32 * XS + pl * plane);
                 dst[mt][pl] = ok ? v : u32x4v{0u, 0u, 0u, 0u};
             }
         }
@@ -393,27 +402,35 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
     using Even = std::integral_constant<int, 0>;
     using Odd = std::integral_constant<int, 1>;
 
-    for (int kc = 0; kc < p.K; kc += 32) {
-        __syncthreads();                             // previous chunk's image reads are done
-        {
-            f32x4 stage[HALO_MAX_STAGE];
+    f32x4 stage[NST];
+    auto fetch = [&](int kc) {
 #pragma unroll
-            for (int i = 0; i < HALO_MAX_STAGE; ++i)
-                if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+        for (int i = 0; i < NST; ++i)
+            if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+    };
+    auto deposit = [&]() {                           // split the staged rows into the three bf16 planes
 #pragma unroll
-            for (int i = 0; i < HALO_MAX_STAGE; ++i) {
-                const int r = (tid >> 3) + 32 * i;
-                if (i < nstage && r < p.halo_rows) {
-                    u32x2 ph, pm, pl;
-                    split3_x4(stage[i], ph, pm, pl);
-                    unsigned char* dst = Xh + r * XSB + (tid & 7) * 8;
-                    *reinterpret_cast<u32x2*>(dst) = ph;
-                    *reinterpret_cast<u32x2*>(dst + plane) = pm;
-                    *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
-                }
+        for (int i = 0; i < NST; ++i) {
+            const int r = tid / TPR + RPP * i;
+            if (i < nstage && r < p.halo_rows) {
+                u32x2 ph, pm, pl;
+                split3_x4(stage[i], ph, pm, pl);
+                unsigned char* dst = Xh + r * XS + (tid % TPR) * 8;
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
             }
         }
+    };
+    if constexpr (PF) fetch(0);
+    for (int kc = 0; kc < p.K; kc += KC) {
+        __syncthreads();                             // previous chunk's image reads are done
+        if constexpr (!PF) fetch(kc);
+        deposit();
         __syncthreads();
+        if constexpr (PF) {
+            if (kc + KC < p.K) fetch(kc + KC);       // lands during the MFMAs below
+        }
         u32x4v x0[MT][3], x1[MT][3];
         load_a(x0, 0);
         for (int it = 0; it < IT2; it += 2) {        // IT2 is even
@@ -564,9 +581,13 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
         FGCN_HALO_ATTR(2, 2); FGCN_HALO_ATTR(2, 3); FGCN_HALO_ATTR(4, 2); FGCN_HALO_ATTR(4, 3);
 #undef FGCN_HALO_ATTR
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1, 32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2, 32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         lds_opt_in = true;
     }
@@ -576,8 +597,14 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
     p.per_xcd = 0;
     if (mm == FGCN_MATH_BF16X3) {
-        if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2>), grid, dim3(256), lds, s, p);
+        if (taps == 1 && K % 64 == 0) {              // 1x1 convolution: 64-channel chunks, next chunk prefetched
+            const size_t lds64 = (size_t)128 * (64 * 2 + 16) * 3;
+            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1, 64>), grid, dim3(256), lds64, s, p);
+            else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2, 64>), grid, dim3(256), lds64, s, p);
+        } else {
+            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1, 32>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2, 32>), grid, dim3(256), lds, s, p);
+        }
         return launch_status("tconv_halo");
     }
     if ((fgcn::tuning(5) & 2) && tiles * p.tiles_n < (1ll << 30)) {   // measured neutral: off

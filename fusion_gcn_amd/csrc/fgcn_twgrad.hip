@@ -33,8 +33,12 @@ struct TWgradP {
 // Staging is LDS-DMA (`buffer_load_dwordx4 ... lds`: one wave instruction drops 1 KiB = 8 window rows x 32 channels, or
 // 1024/TN g rows, straight into LDS; rows / channels that do not exist are out-of-range buffer reads = zeros): no
 // staging registers, which is what lets 9 x 16 accumulator registers and two workgroups per CU coexist.
-// BF: FGCN_MATH_BF16 -- 8 rows per bf16 MFMA (lane half h contracts rows 8g + 4h + (0..3)), operands rounded as read
-template <int NTAP, int TN, bool BF>
+// MM: FGCN_MATH_BF16 -- 8 rows per bf16 MFMA (lane half h contracts rows 8g + 4h + (0..3)), operands rounded as read;
+//     FGCN_MATH_BF16X3 -- 16 rows per step on v_mfma_f32_32x32x16_bf16 (lane half h contracts rows 16g + 8h + (0..7)), both
+//     fragments split into three bf16 parts as they are read (the contraction runs along the image rows, so the split
+//     cannot be done once per row at staging time without a transposed plane layout): 44 vector instructions per
+//     fragment, ten fragments per 54 MFMAs -- about even with the matrix pipe, still ~2x the f32 rate
+template <int NTAP, int TN, int MM>
 __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     constexpr int TW_BR = 8192 / TN;                  // rows per stage: 64 (TN 128) or 128 (TN 64), 32 KiB of g
     constexpr int NSUB = TN / 32, NPART = 4 / NSUB;   // column tiles, row parts of a stage
@@ -101,7 +105,23 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
         }
         __syncthreads();                                             // drains the DMA (vmcnt(0)) and publishes the stage
         // ---- NTAP independent MFMA chains over this wave's rows of the stage ----------------------------------------
-        if constexpr (BF) {
+        if constexpr (MM == 2) {
+            const float* ab = abase + 7 * h * 32;          // rows 8h + e instead of h
+            const float* gb = gbase + 7 * h * TN;
+#pragma unroll 1
+            for (int g16 = 0; g16 < STEPS / 8; ++g16) {
+                const float* g = gb + 16 * g16 * TN;
+                u32x4v gq[3];
+                split3_x8(g[0], g[TN], g[2 * TN], g[3 * TN], g[4 * TN], g[5 * TN], g[6 * TN], g[7 * TN], gq);
+#pragma unroll
+                for (int j = 0; j < NTAP; ++j) {
+                    const float* a = ab + 16 * g16 * 32 + j * tapstride;
+                    u32x4v aq[3];
+                    split3_x8(a[0], a[32], a[64], a[96], a[128], a[160], a[192], a[224], aq);
+                    acc[j] = mfma_x3_k16(aq, gq, acc[j]);
+                }
+            }
+        } else if constexpr (MM == 1) {
             const float* ab = abase + 3 * h * 32;          // rows 4h + e instead of h
             const float* gb = gbase + 3 * h * TN;
 #pragma unroll 2
@@ -159,18 +179,21 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 #define FGCN_TW_ATTR(TN_, BF_)                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_kernel<NTAP, TN_, BF_>),  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
-        FGCN_TW_ATTR(64, false); FGCN_TW_ATTR(64, true); FGCN_TW_ATTR(128, false); FGCN_TW_ATTR(128, true);
+        FGCN_TW_ATTR(64, 0); FGCN_TW_ATTR(64, 1); FGCN_TW_ATTR(64, 2); FGCN_TW_ATTR(128, 0); FGCN_TW_ATTR(128, 1);
+        FGCN_TW_ATTR(128, 2);
 #undef FGCN_TW_ATTR
         opt_in = true;
     }
-    const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
-    if (N <= 64) {
-        if (bf) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 64, false>), grid, dim3(256), lds, s, p);
-    } else {
-        if (bf) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, 128, false>), grid, dim3(256), lds, s, p);
-    }
+    const int mm = fgcn::math_mode();
+#define FGCN_TW_LAUNCH(TN_)                                                                                   \
+    do {                                                                                                      \
+        if (mm == FGCN_MATH_BF16X3) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, TN_, 2>), grid, dim3(256), lds, s, p); \
+        else if (mm == FGCN_MATH_BF16) hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, TN_, 1>), grid, dim3(256), lds, s, p); \
+        else hipLaunchKernelGGL((tconv_wgrad_kernel<NTAP, TN_, 0>), grid, dim3(256), lds, s, p);              \
+    } while (0)
+    if (N <= 64) FGCN_TW_LAUNCH(64);
+    else FGCN_TW_LAUNCH(128);
+#undef FGCN_TW_LAUNCH
 }
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,

@@ -226,7 +226,7 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
     if wide is None:
         # measured (tools/kbench.py wgrad): f32 +2-3 % at K = 384 / 768, -10..-25 % for narrower inputs; bf16 mode: faster or
         # equal at every width (the per-tap kernel's two LDS dwords per MFMA become the limit)
-        wide = K >= 384 or get_math_mode() == "bf16"
+        wide = K >= 384 or get_math_mode() != "f32"
     if wide and taps == 1 and tc == 0 and td == 1 and ta >= 1 and K % 32 == 0 and (T_g - 1) * ta < T_a:
         # 1x1 (optionally strided) convolution: one accumulator per 32-channel chunk, every g fragment feeds 2-6 MFMAs
         chunks = lib.fgcn_pw_wgrad_chunks(K, N)

@@ -58,6 +58,10 @@ def bench_gemm(B, reps):
             rows = B * tout * V
             report(f"rows_gemm {name} T{tin}->{tout} K{kt}x{K} N{N}", ms, 2.0 * rows * kt * K * N,
                    4.0 * (B * tin * V * K + rows * N))
+            if kt == 1 and K % 32 == 0 and ops.get_math_mode() == "bf16x3":
+                w3 = ops.pack_split3(w)
+                ms = timeit(lambda: ops.tconv_halo(x, w3, y, Th=tout, taps=1, tb=1, tc=0, stats=True), reps)
+                report(f"  same on the split-bf16 halo kernel (taps = 1)", ms, 2.0 * rows * K * N, 4.0 * (rows * K + rows * N))
     lib.fgcn_set_tuning(0, 1)
     lib.fgcn_set_tuning(1, 0)
     # data gradient of the strided conv (half of the taps are empty for every output frame)
