@@ -12,9 +12,15 @@ resident in HBM.  Data parallel: every rank holds the headline shape, 64 clips (
 of the flat 13.9 MB gradient buffer; `--scaling strong` instead shards ONE 64-clip batch over the ranks (8 clips per
 GPU at N = 8).  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
 
+Arithmetic (`--math`, reported in `dtype`): the default "bf16x3" forms every float32 product of the convolution / GEMM
+kernels from exact three-way bfloat16 splits of both operands (six partial products, float32 accumulation: float32
+accuracy -- the parity tests run it at the float32 tolerances) on the bf16 matrix pipe; "f32" issues
+v_mfma_f32_32x32x2_f32 directly and is timed in the same run at N = 1 (`f32_mfma_mode`); "bf16" is BASELINE config 5.
+
 Extra objects in that line:
-  roofline      the dominant kernel (halo-tile 9x1 temporal conv on the f32 MFMA), timed live with HIP events on
-                the stream it runs on, against the f32 matrix peak of MI355X_MICROARCH.md (157.3 TFLOP/s).
+  roofline      the dominant kernel (halo-tile 9x1 temporal conv), timed live with HIP events on the stream it runs on,
+                against the matrix peak of its arithmetic (MI355X_MICROARCH.md): bf16 dense 2500 TFLOP/s / 6 partial
+                products = 416.7 TFLOP/s of float32-equivalent work in bf16x3 mode, 157.3 TFLOP/s for the f32 MFMA.
   cpu_baseline  the CPU oracle (oracle/agcn_oracle.py = stock-torch restatement of the reference model) timed on
                 this box's host cores on a bounded sample of the same workload (N = 16 clips).
 """
@@ -35,6 +41,16 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_SPLIT3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # float32-equivalent FLOPs when every product costs six bf16 MFMAs
+MATH_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT3_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}
+MATH_DTYPE = {
+    "f32": "f32",
+    "bf16x3": "f32 (products from exact 3-way bf16 splits of both operands: 6 bf16 MFMAs per product group, f32 accumulate; "
+              "f32 storage / statistics; same parity tolerances as the f32 MFMA path)",
+    "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics"}
+MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_kernel<{nt},3> (bf16 operands)",
+               "bf16x3": "conv_halo_x3_kernel<2,{nt2},32>"}
 PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
 SHAPE = dict(N=64, M=2, T=300, V=25, C=3, classes=60)
 
@@ -91,7 +107,7 @@ def time_dominant_kernel(device, b_local: int, reps: int = 10, widths=(64, 128, 
         if c not in widths:
             continue
         x = torch.randn(b_local, t, SHAPE["V"], c, device=device)
-        w4 = ops.pack_k4(torch.randn(9, c, c, device=device) * (9 * c) ** -0.5)
+        w4 = ops.pack_conv(torch.randn(9, c, c, device=device) * (9 * c) ** -0.5)   # the current math mode's form
         bias = torch.randn(c, device=device)
         y = torch.empty_like(x)
 
@@ -153,13 +169,13 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def measured_traffic(dom, samples):
+def measured_traffic(dom, samples, math="f32"):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 correction of MI355X_MICROARCH.md applied: FETCH_SIZE counts 16-byte-per-lane
     reads at half their bytes).  Only valid for the shape it was collected at; None otherwise."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            rec = json.load(f)["conv_halo_fwd"]
+            rec = json.load(f)[{"f32": "conv_halo_fwd", "bf16x3": "conv_halo_x3_fwd"}[math]]
     except (OSError, KeyError, ValueError):
         return None
     if rec["channels"] != dom["channels"] or rec["frames"] != dom["frames"] or rec["samples"] != samples:
@@ -176,8 +192,11 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", choices=("f32", "bf16", "bf16x3"), default="f32",
-                    help="f32: the headline parity path; bf16: BASELINE config 5 (bf16 MFMA operands, f32 accumulation)")
+    ap.add_argument("--math", choices=("f32", "bf16", "bf16x3"), default="bf16x3",
+                    help="bf16x3 (default): f32-accurate split-bf16 products; f32: v_mfma_f32 directly; bf16: BASELINE "
+                         "config 5 (bf16 MFMA operands, f32 accumulation)")
+    ap.add_argument("--no-f32-mode", action="store_true",
+                    help="N = 1 only: skip the secondary timing of the exact-f32-MFMA mode (f32_mfma_mode)")
     ap.add_argument("--verify-dp", action="store_true",
                     help="N > 1 only: check the exchanged gradient buffer of the (graph) step against an eager step")
     ap.add_argument("--no-other-scaling", action="store_true",
@@ -212,12 +231,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.kernel_only:
-        kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
-        print(json.dumps({"kernel": "conv_halo_kernel<4,3> forward, 256 channels", **kern[0]}), flush=True)
-        return
     from fusion_gcn_amd import ops as _ops
     _ops.set_math_mode(args.math)
+    if args.kernel_only:
+        kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
+        print(json.dumps({"kernel": MATH_KERNEL[args.math].format(nt=4, nt2=2) + " forward, 256 channels", **kern[0]}), flush=True)
+        return
     from fusion_gcn_amd import block as _block
     _block.WGRAD_SIDE_STREAM = args.wgrad_stream != "main"
     _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
@@ -242,6 +261,11 @@ def main():
         stream) and replayed; inputs, parameters and gradient buffers are static, the data-parallel exchange stays
         outside the graph."""
         def fwd_bwd():
+            # a training step follows an optimizer update, so the packed / split weight forms the kernels stream are rebuilt
+            # from the parameters inside every timed step (the blocks cache them per parameter version otherwise)
+            for m in model.modules():
+                if hasattr(m, "_wcache"):
+                    m._wcache = None
             loss = F.cross_entropy(model(x), y)
             loss.backward()
             return loss
@@ -352,6 +376,16 @@ def main():
             raise SystemExit("verify-dp failed")
 
     kern = None if args.no_kernel_timing else time_dominant_kernel(device, n_local * SHAPE["M"])
+    f32_mode = None
+    if world == 1 and args.math == "bf16x3" and not args.no_f32_mode:
+        # the same step with v_mfma_f32_32x32x2_f32 issued directly, for reference beside the headline number
+        _ops.set_math_mode("f32")
+        step_f, mode_f = make_step(x, y)
+        el_f, loss_f = timed(step_f, args.steps, args.warmup)
+        f32_mode = {"value": round(n_global * args.steps / el_f, 2), "unit": "clips/s",
+                    "ms_per_step": round(1e3 * el_f / args.steps, 3), "loss": round(float(loss_f), 5), "launch": mode_f}
+        _ops.set_math_mode(args.math)
+        del step_f
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         clips_per_s = n_global * args.steps / elapsed
@@ -361,7 +395,7 @@ def main():
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.math == "f32" else "bf16 MFMA operands, f32 accumulate / storage / statistics",
+            "dtype": MATH_DTYPE[args.math],
             "data": "synthetic",
             "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
                                    "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
@@ -370,21 +404,29 @@ def main():
                        "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5)},
             "step_fractions": {
                 "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+                "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
                 "hbm": round(byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4),
                 "algorithmic_gflop_per_clip": round(flops / n_global / 1e9, 2),
                 "algorithmic_mb_per_clip": round(byts / n_global / 1e6, 2)},
         }
         if kern:
             dom = max(kern, key=lambda k: k["ms"])
-            out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                               "traffic": measured_traffic(dom, n_local * SHAPE["M"]),
-                               "kernel": f"conv_halo_kernel<{2 if dom['channels'] <= 64 else 4},3> (9x1 temporal conv forward, "
+            peak = MATH_PEAK[args.math]
+            kname = MATH_KERNEL[args.math].format(nt=2 if dom["channels"] <= 64 else 4, nt2=1 if dom["channels"] <= 64 else 2)
+            out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
+                               "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
+                               "traffic": measured_traffic(dom, n_local * SHAPE["M"], args.math),
+                               "peak_is": {"f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "v_mfma_f32_32x32x16_bf16 dense",
+                                           "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)"}[args.math],
+                               "frac_of_f32_mfma_peak": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                               "kernel": f"{kname} (9x1 temporal conv forward, "
                                          f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),
                                "flop_per_launch": dom["flops"],
                                "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
                                               for d in kern]}
+        if f32_mode:
+            out["f32_mfma_mode"] = f32_mode
         if other:
             out["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
