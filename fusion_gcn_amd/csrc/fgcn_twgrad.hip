@@ -163,13 +163,180 @@ __global__ __launch_bounds__(256, 2) void tconv_wgrad_kernel(TWgradP p) {
     }
 }
 
+// ---- FGCN_MATH_BF16X3, all taps, >= 128 output channels -------------------------------------------------------------------
+// The contraction of a weight gradient runs along the image ROWS, so the split fragments of v_mfma_f32_32x32x16_bf16 (8
+// consecutive rows of one channel per lane) cannot be read from a row-major image with plain LDS reads.  Splitting the
+// fragments in registers as they are read (kernel above, MM = 2) costs 44 vector instructions per fragment, ten fragments
+// per 54 MFMAs: the vector unit, not the matrix pipe, sets the pace (1.2x over f32).  Here the stage is split ONCE, as it
+// is written to LDS (three bf16 planes, row-major), and the fragments come from `ds_read_b64_tr_b16`, gfx950's transposing
+// LDS read (a 16-lane group reads 4 rows x 16 channels and every lane receives 4 rows of its channel): no vector work in
+// the MFMA loop.
+//   * workgroup = 512 threads (8 waves, one workgroup per CU): wave = (column tile nsub 0..3, row half `part`); a stage is
+//     64 rows of g x 128 columns and the a window over all taps (64 + (taps-1) V rows x 32 channels);
+//   * staging goes through registers: the NEXT stage's rows are requested before the MFMAs of the current one, split and
+//     written between two barriers afterwards (one LDS image, the global latency stays behind the matrix work);
+//   * planes: a [row][32] bf16 (64-byte rows: the 4 x 64 bytes of a transposed read cover all banks once),
+//     g [row][128] bf16 with 320-byte rows (4 consecutive rows land 64 bytes apart modulo 256: conflict-free).
+constexpr int X3_SA = 64;                // bytes per row of an a plane
+constexpr int X3_APASS = 6;              // passes of 64 rows: window <= 128 + 8 * 32 = 384 rows (V <= 32, 9 taps)
+// TN = 128: waves = 4 column tiles x 2 row halves of a 64-row stage; TN = 64: 2 column tiles x 4 row quarters of a 128-row
+// stage (a wave always owns 32 rows = two 16-row steps).  g rows are padded by 64 bytes: 4 consecutive rows then land 64
+// bytes apart modulo 256 = one transposed read touches every bank once.
+constexpr int x3_rows(int tn) { return tn == 128 ? 64 : 128; }
+constexpr int x3_sg(int tn) { return tn * 2 + 64; }
+
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
+    using v4s = __attribute__((ext_vector_type(4))) short;
+    const v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <int NTAP, int TN>
+__global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int X3_R = x3_rows(TN), X3_SG = x3_sg(TN);
+    constexpr int NSUBS = TN / 32, NPARTS = 8 / NSUBS;
+    constexpr int GT = TN / 4, GRP = 512 / GT;                    // g staging: threads per row, rows per pass (4 passes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nsub = wave % NSUBS, part = wave / NSUBS;
+    const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
+    const int k0 = tk * 32, n0 = tn * TN;
+    const int V = p.V, TVg = p.T_g * V;
+    const int win = p.win_rows;                                   // X3_R + (NTAP - 1) * V
+    const unsigned a_plane = (unsigned)win * X3_SA, g_plane = X3_R * X3_SG;
+    unsigned char* Ap = lds_raw;                                  // [3][win][32] bf16
+    unsigned char* Gp = lds_raw + 3 * a_plane;                    // [3][X3_R][128 (+32 pad)] bf16
+    const int sbeg = blockIdx.y * p.stages_per_split;
+    const int send = min(sbeg + p.stages_per_split, p.total_stages);
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+    const bool strided = p.a_s != 1 || p.a_o != 0;
+
+    // staging roles: a: row tid/8 + 64*i, channels k0 + (tid%8)*4;  g: row tid/GT + GRP*i, columns n0 + (tid%GT)*4
+    const int a_row = tid >> 3, a_c4 = tid & 7, g_row = tid / GT, g_c4 = tid % GT;
+    const bool a_cok = k0 + a_c4 * 4 < p.K, g_cok = n0 + g_c4 * 4 < p.N;
+    f32x4 sa[X3_APASS], sg[4];
+    auto fetch = [&](int sid) {
+        const int n = sid / p.stages_per_sample;
+        const int r0 = (sid - n * p.stages_per_sample) * X3_R;
+#pragma unroll
+        for (int i = 0; i < X3_APASS; ++i) {
+            const int wr = a_row + 64 * i;
+            const int q = r0 + p.shift0 * V + wr;                 // row of the frame view inside the sample
+            const bool ok = a_cok && wr < win && q >= 0 && q < p.Th_a * V;
+            int row = ok ? q : 0;
+            if (strided) {
+                const int f = (int)((unsigned)row / (unsigned)V);
+                row = (f * p.a_s + p.a_o) * V + (row - f * V);
+            }
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + a_c4 * 4) * 4u : OOB;
+            if (i * 64 < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + g_row + GRP * i;
+            const unsigned off = (g_cok && r < TVg) ? (unsigned)((n * TVg + r) * p.ld_g + n0 + g_c4 * 4) * 4u : OOB;
+            sg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int i = 0; i < X3_APASS; ++i) {
+            const int wr = a_row + 64 * i;
+            if (i * 64 < win && wr < win) {
+                u32x2 ph, pm, pl;
+                split3_x4(sa[i], ph, pm, pl);
+                unsigned char* d = Ap + wr * X3_SA + a_c4 * 8;
+                *reinterpret_cast<u32x2*>(d) = ph;
+                *reinterpret_cast<u32x2*>(d + a_plane) = pm;
+                *reinterpret_cast<u32x2*>(d + 2 * a_plane) = pl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 ph, pm, pl;
+            split3_x4(sg[i], ph, pm, pl);
+            unsigned char* d = Gp + (g_row + GRP * i) * X3_SG + g_c4 * 8;
+            *reinterpret_cast<u32x2*>(d) = ph;
+            *reinterpret_cast<u32x2*>(d + g_plane) = pm;
+            *reinterpret_cast<u32x2*>(d + 2 * g_plane) = pl;
+        }
+    };
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) acc[j] = zero16();
+
+    // transposed-read addresses: lane (group g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, c = lane & 3) supplies row
+    // 8h + q (+4 for the second half of the fragment) and channels 16 g16 + 4c .. +3; it receives channel lane & 31.
+    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, c4 = lane & 3;
+    const unsigned char* a_lane = Ap + (part * 32 + 8 * h + q4) * X3_SA + (16 * g16 + 4 * c4) * 2;
+    const unsigned char* g_lane = Gp + (part * 32 + 8 * h + q4) * X3_SG + (nsub * 32 + 16 * g16 + 4 * c4) * 2;
+    auto frag = [&](const unsigned char* base, unsigned plane, int row_stride, u32x4v (&f)[3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const u32x2 lo = lds_read_tr16(base + pl * plane);
+            const u32x2 hi = lds_read_tr16(base + pl * plane + 4 * row_stride);
+            f[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
+
+    if (sbeg < send) fetch(sbeg);
+    for (int sid = sbeg; sid < send; ++sid) {
+        __syncthreads();                                          // the previous stage's fragment reads are done
+        deposit();
+        __syncthreads();
+        if (sid + 1 < send) fetch(sid + 1);                       // lands during the MFMAs below
+#pragma unroll
+        for (int s16 = 0; s16 < 2; ++s16) {                       // this wave's 32 rows of the stage: two 16-row steps
+            u32x4v gq[3];
+            frag(g_lane + s16 * 16 * X3_SG, g_plane, X3_SG, gq);
+#pragma unroll
+            for (int j = 0; j < NTAP; ++j) {
+                u32x4v aq[3];
+                frag(a_lane + (s16 * 16 + j * V) * X3_SA, a_plane, X3_SA, aq);
+                acc[j] = mfma_x3_k16(aq, gq, acc[j]);
+            }
+        }
+    }
+
+    // ---- partial slabs: [slab = split * NPARTS + part][tap][k][n] -----------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+    const int slab = blockIdx.y * NPARTS + part;
+    const int ncol = n0 + nsub * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < NTAP; ++j) {
+        const int tap = p.tap0 + j * p.tap_step;
+        const unsigned base = (unsigned)((slab * p.taps_total + tap) * p.K) * (unsigned)p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + acc_row(r, lane);
+            const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
+            const float val = acc[j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
+        }
+    }
+}
+
 }  // namespace fgcn
 
 using namespace fgcn;
 
-static int twgrad_parts(int N) { return N <= 64 ? 2 : 1; }
+// row parts of a stage = partial slabs per row split.  The split-bf16 all-taps kernel (math mode bf16x3, > 64 output
+// channels) always works in two row halves.
+static bool twgrad_use_x3(int N, int chunk_mode) { return fgcn::math_mode() == FGCN_MATH_BF16X3 && !chunk_mode; }
+static int twgrad_parts(int N, int chunk_mode) {
+    if (twgrad_use_x3(N, chunk_mode)) return N <= 64 ? 4 : 2;
+    return N <= 64 ? 2 : 1;
+}
 
-extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N); }
+extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 0); }
+extern "C" int fgcn_pw_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 1); }
+/* workgroups of one launch that are resident at once (the row-split count is chosen so that tiles * nsplit fits) */
+extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) ? 256 : 512; }
 
 template <int NTAP>
 static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
@@ -196,6 +363,20 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 #undef FGCN_TW_LAUNCH
 }
 
+template <int NTAP>
+static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
+    static bool opt_in = false;
+    if (!opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        opt_in = true;
+    }
+    if (N <= 64) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 64>), grid, dim3(512), lds, s, p);
+    else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 128>), grid, dim3(512), lds, s, p);
+}
+
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                          int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a, int nacc, int chunk_mode,
                          int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream, const char* what) {
@@ -208,7 +389,8 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     FGCN_REQUIRE(a_s >= 1 && a_o >= 0 && Th_a > 0 && (long long)(Th_a - 1) * a_s + a_o < T_a_full, FGCN_E_BADARG,
                  "%s: frame view exceeds the tensor", what);
     const long long a_bytes = (long long)B * T_a_full * V * ld_a * 4, g_bytes = (long long)B * T_g * V * ld_g * 4;
-    const int parts = twgrad_parts(N);
+    const int parts = twgrad_parts(N, chunk_mode);
+    const bool x3 = twgrad_use_x3(N, chunk_mode);
     const long long p_bytes = (long long)nsplit * parts * taps_total * K * N * 4;
     FGCN_REQUIRE(a_bytes < 0x7FFF0000ll && g_bytes < 0x7FFF0000ll && p_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "%s: tensors must be smaller than 2 GiB (32-bit buffer offsets)", what);
@@ -226,11 +408,26 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.win_rows = chunk_mode ? p.stage_rows : p.stage_rows + (nacc - 1) * V;
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
     const int planes = chunk_mode ? nacc : 1;
-    const size_t lds = (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
+    const int tn_x3 = N <= 64 ? 64 : 128;
+    const size_t lds = x3 ? (size_t)3 * ((size_t)p.win_rows * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
+                          : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
+    FGCN_REQUIRE(!x3 || p.win_rows <= 64 * X3_APASS, FGCN_E_BADARG, "%s: window of %d rows too large", what, p.win_rows);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
     const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);
     dim3 grid((unsigned)(tiles_k * p.tiles_n), (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
+    if (x3) {
+        switch (nacc) {
+            case 9: launch_twgrad_x3<9>(p, N, grid, lds, s); break;
+            case 5: launch_twgrad_x3<5>(p, N, grid, lds, s); break;
+            case 4: launch_twgrad_x3<4>(p, N, grid, lds, s); break;
+            case 3: launch_twgrad_x3<3>(p, N, grid, lds, s); break;
+            case 2: launch_twgrad_x3<2>(p, N, grid, lds, s); break;
+            case 1: launch_twgrad_x3<1>(p, N, grid, lds, s); break;
+            default: return fgcn::fail(FGCN_E_BADARG, "%s: %d taps per pass not instantiated", what, nacc);
+        }
+        return launch_status(what);
+    }
     switch (nacc) {
         case 9: launch_twgrad<9>(p, N, grid, lds, s); break;
         case 6: launch_twgrad<6>(p, N, grid, lds, s); break;

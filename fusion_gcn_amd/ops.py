@@ -233,7 +233,7 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         tiles = ((K + 32 * chunks - 1) // (32 * chunks)) * ((N + 127) // 128 if N > 64 else 1)
         stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
         nsplit = max(1, min(512 // max(tiles, 1), stages))
-        slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
+        slabs = lib.fgcn_pw_wgrad_slabs(N, nsplit)
         partial = torch.empty((slabs, K, N), device=a.device, dtype=torch.float32)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
                                 nsplit, _stream()), "fgcn_pw_wgrad")
@@ -275,9 +275,9 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     lib = _lib.load()
     tiles = ((K + 31) // 32) * ((N + 127) // 128 if N > 64 else 1)
     stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
-    # at most 512 workgroups (two per CU, all resident at once); small batches: >= 16 stages per workgroup while that still
-    # leaves a workgroup per CU -- fewer slabs for the reduction
-    cap = max(1, 512 // max(tiles, 1))
+    # at most 512 workgroups (two per CU, all resident at once; 256 for the one-workgroup-per-CU split-bf16 kernel); small
+    # batches: >= 16 stages per workgroup while that still leaves a workgroup per CU -- fewer slabs for the reduction
+    cap = max(1, lib.fgcn_tconv_wgrad_resident(N) // max(tiles, 1))
     nsplit = max(1, min(cap, max(stages // 16, min(stages, max(1, 256 // max(tiles, 1))))))
     slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)

@@ -112,6 +112,10 @@ int fgcn_rows_wgrad(const float* a, const float* g, float* partial,
  *   partial: float[fgcn_tconv_wgrad_slabs(N, nsplit)][taps_total][K][N]; every slab of the taps of this call is written;
  *   the caller sums the slabs (fgcn_reduce_sum).  ntaps in {1..5, 9}; K, N, ld_a, ld_g multiples of 4; tensors < 2 GiB. */
 int fgcn_tconv_wgrad_slabs(int N, int nsplit);
+/* slabs of fgcn_pw_wgrad's partial buffer, and the number of workgroups of a fgcn_tconv_wgrad launch that are resident
+ * at once in the current math mode (choose nsplit so that tiles * nsplit stays within it) */
+int fgcn_pw_wgrad_slabs(int N, int nsplit);
+int fgcn_tconv_wgrad_resident(int N);
 int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                      int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                      int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
