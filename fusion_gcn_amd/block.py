@@ -132,8 +132,10 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torc
         if cfg.stride == 1:
             W["t4"], W["t_t4"] = ops.pack_conv(W["t"]), ops.pack_conv(W["t_t"])
         else:
-            for par, tag in ((0, "e"), (1, "o")):      # data gradient only (see temporal_fwd)
+            for par, tag in ((0, "e"), (1, "o")):      # data gradient; forward too in bf16x3 (see temporal_fwd)
                 W[f"t_t4_{tag}"] = ops.pack_conv(W["t_t"][par::2].contiguous())
+                if ops.get_math_mode() == "bf16x3":
+                    W[f"t4_{tag}"] = ops.pack_conv(W["t"][par::2].contiguous())
         if cfg.residual == "conv":
             w = _pad_last(P["residual.conv.weight"].view(cout, cin), cx)
             W["res"] = w.t().contiguous().unsqueeze(0)
@@ -245,8 +247,16 @@ def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], b
     T, Tp = g.shape[1], u.shape[1]
     if s == 1 and "t4" in W:
         return ops.tconv_halo(g, W["t4"], u, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=stats)
-    # strided forward: the per-tap row GEMM measures faster than two accumulating halo passes over the even / odd
-    # input frames (1.26 vs 1.54 ms at 128 channels, T 300 -> 150); the parity split pays on the data gradient only
+    if s == 2 and "t4_e" in W and pad % 2 == 0 and T > 1:
+        # output frame to meets tap j = 2j' + par at input frame 2 (to + j' - pad/2) + par: one pass over the even input
+        # frames (taps 0, 2, ..), one accumulating pass over the odd ones (which also takes the BatchNorm sums)
+        ops.tconv_halo(g, W["t4_e"], u, Th=Tp, taps=(kt + 1) // 2, tb=1, tc=-(pad // 2), in_view=(2, 0, (T + 1) // 2),
+                       bias=bias)
+        return ops.tconv_halo(g, W["t4_o"], u, Th=Tp, taps=kt // 2, tb=1, tc=-(pad // 2), in_view=(2, 1, T // 2),
+                              stats=stats, accumulate=True)
+    # strided forward in f32: the per-tap row GEMM measures faster than two accumulating halo passes over the even / odd
+    # input frames (1.26 vs 1.54 ms at 128 channels, T 300 -> 150); on the split-bf16 kernels (math mode bf16x3: the packed
+    # set then holds t4_e / t4_o) the two passes win
     return ops.rows_gemm(g, W["t"], u, K=g.shape[3], N=u.shape[3], tmap=ops.conv_tmap(kt, s), bias=bias, stats=stats)
 
 
