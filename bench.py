@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
                     help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs for A/B runs, e.g. 6=21505")
     ap.add_argument("--kernel-only", action="store_true",
                     help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
                          "profiles/*_dominant_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of")
@@ -233,6 +234,9 @@ def main():
 
     from fusion_gcn_amd import ops as _ops
     _ops.set_math_mode(args.math)
+    for kv in filter(None, args.tune.split(",")):
+        from fusion_gcn_amd import _lib as _flib
+        _flib.load().fgcn_set_tuning(*(int(t) for t in kv.split("=")))
     if args.kernel_only:
         kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
         print(json.dumps({"kernel": MATH_KERNEL[args.math].format(nt=4, nt2=2) + " forward, 256 channels", **kern[0]}), flush=True)

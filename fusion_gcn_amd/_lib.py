@@ -58,6 +58,7 @@ SIGNATURES = {
     "fgcn_tconv_wgrad_slabs": (_I, [_I, _I]),
     "fgcn_pw_wgrad_slabs": (_I, [_I, _I]),
     "fgcn_tconv_wgrad_resident": (_I, [_I]),
+    "fgcn_pw_wgrad_resident": (_I, [_I]),
     "fgcn_tconv_wgrad": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
     "fgcn_pw_wgrad_chunks": (_I, [_I, _I]),
     "fgcn_pw_wgrad": (_I, [_P, _P, _P] + [_I] * 11 + [_P]),

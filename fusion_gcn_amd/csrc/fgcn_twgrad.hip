@@ -191,7 +191,10 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-template <int NTAP, int TN>
+// CH (1x1 convolutions, fgcn_pw_wgrad): accumulator j = in-channel chunk j instead of tap j -- the "window" is then NTAP
+// images of the stage's rows, one per 32-channel chunk (window row chunk * X3_R + r), and the fragment of accumulator j
+// starts X3_R rows further instead of V rows further; everything else is the same kernel.
+template <int NTAP, int TN, bool CH>
 __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int X3_R = x3_rows(TN), X3_SG = x3_sg(TN);
@@ -202,9 +205,9 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     const int l31 = lane & 31, h = lane >> 5;
     const int nsub = wave % NSUBS, part = wave / NSUBS;
     const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
-    const int k0 = tk * 32, n0 = tn * TN;
+    const int k0 = tk * (CH ? 32 * NTAP : 32), n0 = tn * TN;
     const int V = p.V, TVg = p.T_g * V;
-    const int win = p.win_rows;                                   // X3_R + (NTAP - 1) * V
+    const int win = CH ? NTAP * X3_R : p.win_rows;                // tap mode: X3_R + (NTAP - 1) * V
     const unsigned a_plane = (unsigned)win * X3_SA, g_plane = X3_R * X3_SG;
     unsigned char* Ap = lds_raw;                                  // [3][win][32] bf16
     unsigned char* Gp = lds_raw + 3 * a_plane;                    // [3][X3_R][128 (+32 pad)] bf16
@@ -225,14 +228,15 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
 #pragma unroll
         for (int i = 0; i < X3_APASS; ++i) {
             const int wr = a_row + 64 * i;
-            const int q = r0 + p.shift0 * V + wr;                 // row of the frame view inside the sample
-            const bool ok = a_cok && wr < win && q >= 0 && q < p.Th_a * V;
+            const int chunk = CH ? (64 * i) / X3_R : 0;           // compile-time per pass
+            const int q = CH ? r0 + wr - chunk * X3_R : r0 + p.shift0 * V + wr;   // row of the frame view inside the sample
+            const bool ok = (CH ? k0 + chunk * 32 + a_c4 * 4 < p.K : a_cok) && wr < win && q >= 0 && q < p.Th_a * V;
             int row = ok ? q : 0;
             if (strided) {
                 const int f = (int)((unsigned)row / (unsigned)V);
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
-            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + a_c4 * 4) * 4u : OOB;
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + chunk * 32 + a_c4 * 4) * 4u : OOB;
             if (i * 64 < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
         }
 #pragma unroll
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
 #pragma unroll
             for (int j = 0; j < NTAP; ++j) {
                 u32x4v aq[3];
-                frag(a_lane + (s16 * 16 + j * V) * X3_SA, a_plane, X3_SA, aq);
+                frag(a_lane + (s16 * 16 + j * (CH ? X3_R : V)) * X3_SA, a_plane, X3_SA, aq);
                 acc[j] = mfma_x3_k16(aq, gq, acc[j]);
             }
         }
@@ -309,11 +313,12 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     const int ncol = n0 + nsub * 32 + l31;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
-        const int tap = p.tap0 + j * p.tap_step;
+        const int tap = CH ? 0 : p.tap0 + j * p.tap_step;
+        const int kj = k0 + (CH ? 32 * j : 0);
         const unsigned base = (unsigned)((slab * p.taps_total + tap) * p.K) * (unsigned)p.N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int k = k0 + acc_row(r, lane);
+            const int k = kj + acc_row(r, lane);
             const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
             const float val = acc[j][r];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
@@ -327,7 +332,11 @@ using namespace fgcn;
 
 // row parts of a stage = partial slabs per row split.  The split-bf16 all-taps kernel (math mode bf16x3, > 64 output
 // channels) always works in two row halves.
-static bool twgrad_use_x3(int N, int chunk_mode) { return fgcn::math_mode() == FGCN_MATH_BF16X3 && !chunk_mode; }
+// (tuning key 6 bit 0: 1x1 weight gradients of that mode on the 256-thread kernel that splits fragments as it reads them --
+// the A/B switch of tools/kbench.py)
+static bool twgrad_use_x3(int N, int chunk_mode) {
+    return fgcn::math_mode() == FGCN_MATH_BF16X3 && !(chunk_mode && (fgcn::tuning(6) & 1));
+}
 static int twgrad_parts(int N, int chunk_mode) {
     if (twgrad_use_x3(N, chunk_mode)) return N <= 64 ? 4 : 2;
     return N <= 64 ? 2 : 1;
@@ -337,6 +346,7 @@ extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgra
 extern "C" int fgcn_pw_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 1); }
 /* workgroups of one launch that are resident at once (the row-split count is chosen so that tiles * nsplit fits) */
 extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) ? 256 : 512; }
+extern "C" int fgcn_pw_wgrad_resident(int N) { return twgrad_use_x3(N, 1) ? 256 : 512; }
 
 template <int NTAP>
 static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
@@ -363,18 +373,23 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 #undef FGCN_TW_LAUNCH
 }
 
-template <int NTAP>
+template <int NTAP, bool CH>
 static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
+    static_assert(!CH || NTAP <= 6, "chunk mode: at most 6 (128 columns) / 3 (64 columns) chunks fit the staging passes");
     static bool opt_in = false;
     if (!opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 64>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 128, CH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (!CH || NTAP <= 3)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 64, CH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         opt_in = true;
     }
-    if (N <= 64) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 64>), grid, dim3(512), lds, s, p);
-    else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 128>), grid, dim3(512), lds, s, p);
+    if (N <= 64) {
+        if constexpr (!CH || NTAP <= 3) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 64, CH>), grid, dim3(512), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 128, CH>), grid, dim3(512), lds, s, p);
+    }
 }
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
@@ -409,21 +424,34 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
     const int planes = chunk_mode ? nacc : 1;
     const int tn_x3 = N <= 64 ? 64 : 128;
-    const size_t lds = x3 ? (size_t)3 * ((size_t)p.win_rows * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
+    const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3) : p.win_rows;
+    const size_t lds = x3 ? (size_t)3 * ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
                           : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
-    FGCN_REQUIRE(!x3 || p.win_rows <= 64 * X3_APASS, FGCN_E_BADARG, "%s: window of %d rows too large", what, p.win_rows);
+    FGCN_REQUIRE(!x3 || win_x3 <= 64 * X3_APASS, FGCN_E_BADARG, "%s: window of %d rows too large", what, win_x3);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
     const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);
     dim3 grid((unsigned)(tiles_k * p.tiles_n), (unsigned)nsplit);
     hipStream_t s = (hipStream_t)stream;
+    if (x3 && chunk_mode) {
+        switch (nacc) {
+            case 6: launch_twgrad_x3<6, true>(p, N, grid, lds, s); break;
+            case 5: launch_twgrad_x3<5, true>(p, N, grid, lds, s); break;
+            case 4: launch_twgrad_x3<4, true>(p, N, grid, lds, s); break;
+            case 3: launch_twgrad_x3<3, true>(p, N, grid, lds, s); break;
+            case 2: launch_twgrad_x3<2, true>(p, N, grid, lds, s); break;
+            case 1: launch_twgrad_x3<1, true>(p, N, grid, lds, s); break;
+            default: return fgcn::fail(FGCN_E_BADARG, "%s: %d chunks per pass not instantiated", what, nacc);
+        }
+        return launch_status(what);
+    }
     if (x3) {
         switch (nacc) {
-            case 9: launch_twgrad_x3<9>(p, N, grid, lds, s); break;
-            case 5: launch_twgrad_x3<5>(p, N, grid, lds, s); break;
-            case 4: launch_twgrad_x3<4>(p, N, grid, lds, s); break;
-            case 3: launch_twgrad_x3<3>(p, N, grid, lds, s); break;
-            case 2: launch_twgrad_x3<2>(p, N, grid, lds, s); break;
-            case 1: launch_twgrad_x3<1>(p, N, grid, lds, s); break;
+            case 9: launch_twgrad_x3<9, false>(p, N, grid, lds, s); break;
+            case 5: launch_twgrad_x3<5, false>(p, N, grid, lds, s); break;
+            case 4: launch_twgrad_x3<4, false>(p, N, grid, lds, s); break;
+            case 3: launch_twgrad_x3<3, false>(p, N, grid, lds, s); break;
+            case 2: launch_twgrad_x3<2, false>(p, N, grid, lds, s); break;
+            case 1: launch_twgrad_x3<1, false>(p, N, grid, lds, s); break;
             default: return fgcn::fail(FGCN_E_BADARG, "%s: %d taps per pass not instantiated", what, nacc);
         }
         return launch_status(what);

@@ -232,7 +232,7 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         chunks = lib.fgcn_pw_wgrad_chunks(K, N)
         tiles = ((K + 32 * chunks - 1) // (32 * chunks)) * ((N + 127) // 128 if N > 64 else 1)
         stages = B * ((T_g * V + 63) // 64) if N > 64 else B * ((T_g * V + 127) // 128)
-        nsplit = max(1, min(512 // max(tiles, 1), stages))
+        nsplit = max(1, min(lib.fgcn_pw_wgrad_resident(N) // max(tiles, 1), stages))   # every workgroup resident at once
         slabs = lib.fgcn_pw_wgrad_slabs(N, nsplit)
         partial = torch.empty((slabs, K, N), device=a.device, dtype=torch.float32)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,

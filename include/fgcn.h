@@ -116,6 +116,7 @@ int fgcn_tconv_wgrad_slabs(int N, int nsplit);
  * at once in the current math mode (choose nsplit so that tiles * nsplit stays within it) */
 int fgcn_pw_wgrad_slabs(int N, int nsplit);
 int fgcn_tconv_wgrad_resident(int N);
+int fgcn_pw_wgrad_resident(int N);
 int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                      int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                      int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);

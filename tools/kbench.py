@@ -101,7 +101,8 @@ def bench_wgrad(B, reps):
     cases = [("tconv", 300, 300, 64, 64, 9, 1), ("tconv", 150, 150, 128, 128, 9, 1), ("tconv", 75, 75, 256, 256, 9, 1),
              ("tconv s2", 300, 150, 128, 128, 9, 2), ("tconv s2", 150, 75, 256, 256, 9, 2),
              ("conv_d", 300, 300, 192, 64, 1, 1), ("conv_d", 150, 150, 384, 128, 1, 1), ("conv_d", 75, 75, 768, 256, 1, 1),
-             ("emb", 300, 300, 64, 96, 1, 1), ("emb", 150, 150, 128, 192, 1, 1), ("emb", 75, 75, 256, 384, 1, 1)]
+             ("emb", 300, 300, 64, 96, 1, 1), ("emb", 150, 150, 128, 192, 1, 1), ("emb", 75, 75, 256, 384, 1, 1),
+             ("down", 300, 300, 64, 128, 1, 1), ("down", 150, 150, 128, 256, 1, 1), ("res s2", 300, 150, 64, 128, 1, 2)]
     for name, ta, tg, K, N, kt, s in cases:
         a, g = rnd(B, ta, V, K), rnd(B, tg, V, N)
         tm = ops.conv_tmap(kt, s)
@@ -111,6 +112,12 @@ def bench_wgrad(B, reps):
             ms = timeit(lambda: ops.rows_wgrad(a, g, K=K, N=N, tmap=tm, wide=True), reps)
             report(f"pw_wgrad {name} T{ta} K{K} N{N} (channel chunks)", ms, 2.0 * B * tg * V * K * N,
                    4.0 * B * V * (ta * K + tg * N))
+            if ops.get_math_mode() == "bf16x3":
+                _lib.load().fgcn_set_tuning(6, 1)
+                ms = timeit(lambda: ops.rows_wgrad(a, g, K=K, N=N, tmap=tm, wide=True), reps)
+                _lib.load().fgcn_set_tuning(6, 0)
+                report("  same, fragments split as they are read (256-thread kernel)", ms, 2.0 * B * tg * V * K * N,
+                       4.0 * B * V * (ta * K + tg * N))
         if kt > 1:
             ms = timeit(lambda: ops.tconv_wgrad(a, g, taps=kt, stride=s, all_taps=True), reps)
             report(f"tconv_wgrad {name} T{ta} K{kt}x{K} N{N} (all taps)", ms, 2.0 * B * tg * V * kt * K * N,
