@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
                     help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--keep-packed", action="store_true",
+                    help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
+                         "rebuilding them from the parameters inside every timed step")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs for A/B runs, e.g. 6=21505")
     ap.add_argument("--kernel-only", action="store_true",
                     help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
@@ -268,7 +271,7 @@ def main():
             # a training step follows an optimizer update, so the packed / split weight forms the kernels stream are rebuilt
             # from the parameters inside every timed step (the blocks cache them per parameter version otherwise)
             for m in model.modules():
-                if hasattr(m, "_wcache"):
+                if hasattr(m, "_wcache") and not args.keep_packed:
                     m._wcache = None
             loss = F.cross_entropy(model(x), y)
             loss.backward()
