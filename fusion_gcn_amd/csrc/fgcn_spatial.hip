@@ -293,9 +293,235 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && (CT_IN <= 2 |
     }
 }
 
+
+// ---- FGCN_MATH_BF16X3, whole 32-channel input tiles --------------------------------------------------------------------
+// The kernel above (MM = 2) hands every weight fragment to ONE frame (32 MFMA columns): at 6 bytes per weight and six
+// 32-cycle MFMAs per fragment set each wave pulls 16 B/clk of weights, 64 B/clk per CU -- the L2 -> CU limit -- and its step 1
+// still runs on the f32 MFMA (13 x 64 cycles per tile and subset).  Here
+//   * a wave owns TWO frames: every weight fragment set feeds both (half the weight stream per FLOP);
+//   * step 1 is split-bf16 too: x is split once per (frame, channel tile) as it arrives (lane = channel, 8 consecutive joints
+//     per 16-byte fragment), A^_k is split once per workgroup into LDS as [subset][part][w][v] bf16 (one ds_read_b128 = the 8
+//     joints of a lane's fragment): 2 x 6 MFMAs of 32 cycles instead of 13 of 64;
+//   * a workgroup covers 64 output columns (blockIdx.z = column block; agg is re-formed per block -- at 384 cycles per tile
+//     and subset that is cheaper than the registers a wider block would need for two frames).
+// Same accumulator-as-operand chain, weight format (fgcn_pack_split3, acc_order), epilogue and statistics as above.
+constexpr int AHB = 80;    // bytes per [w] row of a split A^ plane (32 joints x bf16 + 16 pad: conflict-free b128 reads)
+
+template <int CT_IN>
+__global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
+    constexpr int CT_OUT = 2, WROW = CT_OUT * 32;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* ahs = reinterpret_cast<unsigned char*>(smem);      // [3 subsets][3 parts][32 w][AHB]
+    float* st = smem + (9 * 32 * AHB) / 4;                            // [4 waves][2][WROW]
+    float* tt = st + 4 * 2 * WROW;                                    // [4 waves][32][TTS]
+    float* bl = tt + 4 * 32 * TTS;                                    // [WROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int V = p.V, NS = p.ns;
+    const int t0 = blockIdx.x * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.y + ((long long)n * p.T + t0) * V * p.ld_y), 0, (unsigned)((t1 - t0) * V * p.ld_y) * 4u, 0x00020000);
+
+    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * NS * V * V : 0);
+    for (int i = tid; i < 3 * 32 * 32; i += 256) {
+        const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
+        const float a = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+        unsigned ph, pm, pl;
+        split_bf16_pair(a, 0.f, ph, pm, pl);
+        unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * 3) * 32 + w) * AHB) + v;
+        d[0] = (unsigned short)ph;
+        d[32 * AHB / 2] = (unsigned short)pm;
+        d[2 * 32 * AHB / 2] = (unsigned short)pl;
+    }
+    for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
+    const int ob = blockIdx.z * WROW;
+    for (int i = tid; i < WROW; i += 256) bl[i] = (p.bias && ob + i < p.Cout) ? p.bias[ob + i] : 0.f;
+    __syncthreads();
+
+    unsigned wvo[CT_OUT];
+#pragma unroll
+    for (int ot = 0; ot < CT_OUT; ++ot) {
+        const int o = ob + ot * 32 + l31;
+        wvo[ot] = o < p.Cout ? (unsigned)(h * p.Cout + o) * 16u : OOB;
+    }
+    // x of frame t, channel tile ci: lane = channel, register 8s + j = joint 16s + 8h + j (the k order of the 32x32x16 fragment);
+    // the joint's row offset splits into a per-lane part (8h rows) and a scalar part (16s + j rows, the instruction's soffset)
+    const unsigned row_b = (unsigned)p.ld_x * 4u;
+    auto load_x = [&](int t, int ci, float (&xv)[16]) {
+        const bool ok = t < t1;
+        const unsigned base = (unsigned)((((long long)n * p.T + (ok ? t : t0)) * V + 8 * h) * p.ld_x + ci * 32 + l31) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int vs = 16 * (r >> 3) + (r & 7);
+            xv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (ok && vs + 8 * h < V) ? base : OOB,
+                                                                                   (unsigned)vs * row_b, 0));
+        }
+    };
+    u32x4v w3[CT_OUT][3];
+    auto load_w3 = [&](int ci, int k, int gp, int ot, u32x4v (&wv)[3]) {
+        const unsigned so = (unsigned)((((k * p.Cin + ci * 32) >> 4) + gp) * 2 * p.Cout) * 16u;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            wv[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[ot], so + pl * p.w_plane_bytes, 0);
+    };
+    const unsigned char* af_lane = ahs + l31 * AHB + 16 * h;           // + (k*3 + part) * 32 * AHB + 32 * s
+
+    float xr[2][16];
+    load_x(t0 + 2 * wave, 0, xr[0]);
+    load_x(t0 + 2 * wave + 1, 0, xr[1]);
+#pragma unroll
+    for (int ot = 0; ot < CT_OUT; ++ot) load_w3(0, 0, 0, ot, w3[ot]);
+
+    for (int tg = t0; tg < t1; tg += 8) {
+        const int tA = tg + 2 * wave;
+        f32x16 acc[2][CT_OUT];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < CT_OUT; ++i) acc[f][i] = zero16();
+
+#pragma unroll 1
+        for (int ci = 0; ci < CT_IN; ++ci) {
+            u32x4v xs[2][2][3];                                       // [frame][16-joint step][part]
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    split3_x8(xr[f][8 * s2], xr[f][8 * s2 + 1], xr[f][8 * s2 + 2], xr[f][8 * s2 + 3], xr[f][8 * s2 + 4],
+                              xr[f][8 * s2 + 5], xr[f][8 * s2 + 6], xr[f][8 * s2 + 7], xs[f][s2]);
+            // one subset: step 1 for both frames, then step 2; `last` (compile time) = the tile's final subset, after whose
+            // step 1 the split x is dead and the next tile's x is requested into the same registers
+            auto subset = [&](int k, auto last) {
+                f32x16 agg[2] = {zero16(), zero16()};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4v af[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * 3 + pl) * 32 * AHB + 32 * s2);
+                    agg[0] = mfma_x3_k16(xs[0][s2], af, agg[0]);
+                    agg[1] = mfma_x3_k16(xs[1][s2], af, agg[1]);
+                }
+                if constexpr (decltype(last)::value) {
+                    if (ci + 1 < CT_IN) {
+                        load_x(tA, ci + 1, xr[0]);
+                        load_x(tA + 1, ci + 1, xr[1]);
+                    } else {
+                        load_x(tA + 8, 0, xr[0]);
+                        load_x(tA + 9, 0, xr[1]);
+                    }
+                }
+                // step 2: registers 8gp..8gp+7 of agg are contraction rows c = 16gp + 4h + (j&3) + 8(j>>2)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    int nci = ci, nk = k, ngp = 1;                    // the group after this one (wave-uniform)
+                    if (gp == 1) {
+                        ngp = 0;
+                        if (!decltype(last)::value) nk = k + 1;
+                        else if (ci + 1 < CT_IN) nci = ci + 1, nk = 0;
+                        else nci = 0, nk = 0;
+                    }
+                    u32x4v b3[2][3];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        u32x2 h0, m0, l0, h1, m1, l1;
+                        split3_x4(f32x4{agg[f][8 * gp], agg[f][8 * gp + 1], agg[f][8 * gp + 2], agg[f][8 * gp + 3]}, h0, m0, l0);
+                        split3_x4(f32x4{agg[f][8 * gp + 4], agg[f][8 * gp + 5], agg[f][8 * gp + 6], agg[f][8 * gp + 7]}, h1, m1, l1);
+                        b3[f][0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+                        b3[f][1] = u32x4v{m0[0], m0[1], m1[0], m1[1]};
+                        b3[f][2] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+                    }
+#pragma unroll
+                    for (int ot = 0; ot < CT_OUT; ++ot) {
+                        acc[0][ot] = mfma_x3_k16(w3[ot], b3[0], acc[0][ot]);
+                        acc[1][ot] = mfma_x3_k16(w3[ot], b3[1], acc[1][ot]);
+                        load_w3(nci, nk, ngp, ot, w3[ot]);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int k = 0; k + 1 < NS; ++k) subset(k, std::false_type{});
+            subset(NS - 1, std::true_type{});
+        }
+
+        // ---- epilogue, one frame after the other through the wave-private transpose tile ------------------------------------
+        float* T = tt + wave * 32 * TTS;
+        const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int t = tA + f;
+            const bool tv = t < t1;
+#pragma unroll
+            for (int ot = 0; ot < CT_OUT; ++ot) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(&T[l31 * TTS + 8 * g + 4 * h]) =
+                        f32x4{acc[f][ot][4 * g], acc[f][ot][4 * g + 1], acc[f][ot][4 * g + 2], acc[f][ot][4 * g + 3]};
+                const int ol = ot * 32 + c4, o = ob + ol;
+                const bool ook = o < p.Cout;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bl[ol]);
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = rr + 8 * i;
+                    const f32x4 val = *reinterpret_cast<const f32x4*>(&T[r * TTS + c4]) + b4;
+                    const bool keep = tv && r < V && ook;
+                    const unsigned off = keep ? (unsigned)(((t - t0) * V + r) * p.ld_y + o) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, val), ry, off, 0, 0);
+                    const f32x4 kept = keep ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+                    s1 += kept;
+                    s2 += kept * kept;
+                }
+                if (p.stats) {
+#pragma unroll
+                    for (int m = 8; m <= 32; m <<= 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            s1[e] += __shfl_xor(s1[e], m);
+                            s2[e] += __shfl_xor(s2[e], m);
+                        }
+                    }
+                    if (lane < 8 && ook) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            st[(wave * 2 + 0) * WROW + ol + e] += s1[e];
+                            st[(wave * 2 + 1) * WROW + ol + e] += s2[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats) {
+        __syncthreads();
+        const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * WROW; i += 256) {
+            const int which = i / WROW, o = i - which * WROW;
+            if (ob + o < p.Cout)
+                p.stats[(wg * 2 + which) * p.Cout + ob + o] = st[(0 * 2 + which) * WROW + o] + st[(1 * 2 + which) * WROW + o] +
+                                                          st[(2 * 2 + which) * WROW + o] + st[(3 * 2 + which) * WROW + o];
+        }
+    }
+}
+
 }  // namespace fgcn
 
 using namespace fgcn;
+
+template <int CI>
+static void launch_spatial_x3(const SpatialP& p, hipStream_t s) {
+    const size_t lds = (size_t)9 * 32 * AHB + (4 * 2 * 64 + 4 * 32 * TTS + 64) * sizeof(float);
+    dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B, (unsigned)cdiv(p.Cout, 64));
+    hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI>), grid, dim3(256), lds, s, p);
+}
 
 static int spatial_t_chunk(int B, int T) {
     int chunk = 32;
@@ -367,6 +593,15 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
                (unsigned)((long long)n_subsets * Cin * Cout * 2)};
     hipStream_t s = (hipStream_t)stream;
     int rc = -1;
+    if (split && !(fgcn::tuning(7) & 1)) {     // two frames per wave, split-bf16 aggregation (tuning key 7 bit 0: the older form)
+        switch (ci) {
+            case 1: launch_spatial_x3<1>(p, s); break;
+            case 2: launch_spatial_x3<2>(p, s); break;
+            case 4: launch_spatial_x3<4>(p, s); break;
+            case 8: launch_spatial_x3<8>(p, s); break;
+        }
+        return launch_status("spatial_fwd");
+    }
     switch (ci) {
         case 1: rc = dispatch_out<1>(co, p, s); break;
         case 2: rc = dispatch_out<2>(co, p, s); break;

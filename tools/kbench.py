@@ -131,6 +131,12 @@ def bench_spatial(B, reps):
         ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
         rows = B * T * V
         report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
+        if ops.get_math_mode() == "bf16x3" and cin % 32 == 0:
+            _lib.load().fgcn_set_tuning(7, 1)
+            ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
+            _lib.load().fgcn_set_tuning(7, 0)
+            report("  same, one frame per wave, f32 aggregation (older form)", ms, rows * (6.0 * V * cin + 6.0 * cin * cout),
+                   4.0 * rows * (cin + cout))
 
 
 def bench_spatial_wgrad(B, reps):
