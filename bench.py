@@ -205,6 +205,10 @@ def main():
     ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
                     help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--optimizer", choices=("none", "adam", "sgd"), default="none",
+                    help="also run the fused parameter update (fusion_gcn_amd.optim.FlatOptimizer: ADAM weight_decay 0.01 as "
+                         "config/utd-mhad/skeleton/agcn.yaml, or SGD momentum 0.9 nesterov) inside every timed step; the "
+                         "headline metric is fwd+bwd, so the default leaves it out")
     ap.add_argument("--keep-packed", action="store_true",
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
@@ -251,6 +255,11 @@ def main():
     model = build_model(device)
     broadcast_parameters(model)
     grads = FlatGradients(model.parameters())
+    opt = None
+    if args.optimizer != "none":       # before any graph capture: the parameters move into one flat buffer
+        from fusion_gcn_amd.optim import FlatOptimizer
+        opt = (FlatOptimizer(model.parameters(), "ADAM", 1e-5, grads=grads, weight_decay=0.01) if args.optimizer == "adam"
+               else FlatOptimizer(model.parameters(), "SGD", 1e-5, grads=grads, momentum=0.9, nesterov=True, weight_decay=1e-4))
 
     n_global = args.batch * world if args.scaling == "weak" else args.batch
 
@@ -288,6 +297,8 @@ def main():
             loss = fwd_bwd()
             if world > 1:
                 grads.all_reduce_mean()     # gather into the flat buffer + ONE RCCL all-reduce + 1/world
+            if opt is not None:
+                opt.step()                  # one launch over the flat parameter / gradient / state buffers
             return loss
 
         if args.no_graph:
@@ -305,7 +316,7 @@ def main():
             grads.zero()
             with torch.cuda.graph(graph):
                 static_loss = fwd_bwd()
-                if world > 1:
+                if world > 1 or opt is not None:
                     grads.gather()      # the copy into the flat exchange buffer is part of the replayed step
             # a replayed graph must reproduce the eager loss (parameters do not change): twice, with a sync in between
             for _ in range(2):
@@ -319,6 +330,8 @@ def main():
                 graph.replay()
                 if world > 1:
                     grads.all_reduce_mean()
+                if opt is not None:
+                    opt.step()
                 return static_loss
             return step_graph, "hipgraph"
         except Exception as e:  # noqa: BLE001 - report and fall back to eager launches
@@ -408,7 +421,8 @@ def main():
                                    "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
                                    % n_global,
                        "global_batch": n_global, "per_gpu_batch": n_local,
-                       "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5)},
+                       "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5),
+                       "optimizer_step_in_timed_region": args.optimizer},
             "step_fractions": {
                 "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                 "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),

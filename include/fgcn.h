@@ -308,6 +308,23 @@ int fgcn_spatial_bwd(const float* dy, const float* x, const float* a_hat, const 
                      int n_subsets, int a_hat_batched, int accumulate, void* stream);
 int fgcn_spatial_bwd_chunks(int B, int T);
 
+/* ---- the step after the path: parameter update over flat buffers ------------------- */
+/* One launch applies torch.optim's update to every trainable value of the model (reference: create_optimizer,
+ * torch_src/session_helper.py:80-84, optimizer.step() in session/session.py:176-183):
+ *   FGCN_OPT_SGD    d = g + wd*p;  buf = first step ? d : momentum*buf + (1-dampening)*d;  d = nesterov ? d + momentum*buf : buf;
+ *                   p -= lr*d                                                        (state1 = buf, NULL when momentum == 0)
+ *   FGCN_OPT_ADAM   g += wd*p;  m += (g-m)(1-beta1);  v = beta2*v + (1-beta2) g*g;
+ *                   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)   (state1 = exp_avg, state2 = exp_avg_sq)
+ *   FGCN_OPT_ADAMW  p *= 1 - lr*wd first, g untouched, then the same moments and update.
+ * g is read as grad_scale * grads (the 1/world of the data-parallel average).  params, grads, state*: float[n], 16-byte
+ * aligned, n % 4 == 0 (padding elements must hold zeros in all buffers); step counts from 1.  amsgrad / maximize: not built. */
+#define FGCN_OPT_SGD 0
+#define FGCN_OPT_ADAM 1
+#define FGCN_OPT_ADAMW 2
+int fgcn_optim_step(float* params, const float* grads, float* state1, float* state2, long long n, int kind,
+                    float lr, float weight_decay, float grad_scale, float beta1, float beta2, float eps,
+                    float momentum, float dampening, int nesterov, long long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
