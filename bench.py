@@ -205,6 +205,10 @@ def main():
     ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
                     help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--loader", choices=("none", "resident", "streaming"), default="none",
+                    help="feed every timed step from a feature file in the reference's on-disk format through "
+                         "fusion_gcn_amd.data.ClipBatches (resident: split uploaded once, device-side gather; streaming: pinned "
+                         "double-buffered H2D copies on a side stream = the PCIe-inclusive rate); default: one HBM-resident batch")
     ap.add_argument("--optimizer", choices=("none", "adam", "sgd"), default="none",
                     help="also run the fused parameter update (fusion_gcn_amd.optim.FlatOptimizer: ADAM weight_decay 0.01 as "
                          "config/utd-mhad/skeleton/agcn.yaml, or SGD momentum 0.9 nesterov) inside every timed step; the "
@@ -362,6 +366,41 @@ def main():
 
     x, y, n_local = resident_shard(n_global)
     step, mode = make_step(x, y)
+    pipeline = None
+    if args.loader != "none":
+        # a synthetic split in the reference's file format (4 global batches of clips), read back through the dataset interface
+        import tempfile
+
+        import numpy as np
+
+        from fusion_gcn_amd.data import ClipBatches, MultiModalDataset, NumpyDatasetLoader, NumpyWriter
+        root = tempfile.mkdtemp(prefix=f"fgcn_bench_r{rank}_")
+        n_file = 4 * n_global
+        rng = np.random.default_rng(1)
+        with NumpyWriter(os.path.join(root, "skeleton_train_features.npy"), np.float32,
+                         (n_file, SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"])) as w:
+            for _ in range(n_file):
+                w.collect_next(rng.standard_normal((SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"]), dtype=np.float32))
+        np.save(os.path.join(root, "train_labels.npy"), rng.integers(0, SHAPE["classes"], n_file))
+        batches = ClipBatches(MultiModalDataset([(root, NumpyDatasetLoader())], "train"), n_global, shuffle=True, drop_last=True,
+                              seed=1, rank=rank, world=world, device=device, resident=args.loader == "resident")
+        compute_step = step
+
+        def epochs():
+            e = 0
+            while True:
+                batches.set_epoch(e)
+                yield from batches
+                e += 1
+        feed = epochs()
+
+        def step():         # noqa: F811 - the timed step now starts with the batch hand-over into the step's static input
+            feats, lab, _ = next(feed)
+            x.copy_(feats, non_blocking=True)
+            y.copy_(lab, non_blocking=True)
+            return compute_step()
+        pipeline = {"mode": args.loader, "file_clips": n_file, "bytes_per_step_h2d": 0 if args.loader == "resident"
+                    else int(n_local * SHAPE["M"] * SHAPE["T"] * SHAPE["V"] * SHAPE["C"] * 4)}
     log(f"model + {n_local} clips resident on {device}; warm-up x{args.warmup}, timing {args.steps} steps")
     elapsed, loss_val = timed(step, args.steps, args.warmup)
     log(f"{args.steps} steps in {elapsed:.3f} s")
@@ -422,7 +461,7 @@ def main():
                                    % n_global,
                        "global_batch": n_global, "per_gpu_batch": n_local,
                        "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5),
-                       "optimizer_step_in_timed_region": args.optimizer},
+                       "optimizer_step_in_timed_region": args.optimizer, "input_pipeline": pipeline or "one HBM-resident batch"},
             "step_fractions": {
                 "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
                 "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
