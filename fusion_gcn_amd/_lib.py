@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfgcn.so")
+LIB_PATH = os.environ.get("FGCN_LIB") or os.path.join(_HERE, "libfgcn.so")   # FGCN_LIB: timing-probe builds (tools/probes)
 
 c_float_p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 

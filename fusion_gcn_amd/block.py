@@ -98,52 +98,91 @@ def _pad_last(t: torch.Tensor, n: int) -> torch.Tensor:
     return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
 
 
-def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> Dict[str, torch.Tensor]:
-    """Reference-layout parameters -> packed (taps, K, N) matrices for rows_gemm / spatial_fwd.
+class PackedWeights(dict):
+    """The packed / split forms of one block's parameters, each built on first use (torch.no_grad) and kept: a math mode or
+    a block variant only pays for the forms its kernels stream (the split-bf16 mode, e.g., never touches most float32
+    forms).  ``key in W`` says whether the form exists for this block and mode; ``W.get(key)`` builds it when it does."""
+
+    def __init__(self, builders):
+        super().__init__()
+        self._builders = builders
+
+    def __missing__(self, key):
+        build = self._builders.get(key)
+        if build is None:
+            raise KeyError(key)
+        with torch.no_grad():
+            value = build()
+        self[key] = value
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._builders
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
+def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
+    """Reference-layout parameters -> packed (taps, K, N) matrices for rows_gemm / spatial_fwd / tconv_halo, built lazily.
     The input-channel dimension is zero-padded from cin to cx (= cin rounded up to 4): the kernels then see a
-    cx-channel block whose extra input channel is identically zero (only the 3-channel network input pads)."""
+    cx-channel block whose extra input channel is identically zero (only the 3-channel network input pads).
+    The math mode is read once, here (the model keys its cache of packed sets on it)."""
     cin, cout, ic, cx = cfg.cin, cfg.cout, cfg.ic, cfg.cx
-    W: Dict[str, torch.Tensor] = {}
-    with torch.no_grad():
-        if not cfg.static_adjacency:
-            rows = []
-            for k in range(NUM_SUBSETS):                       # embedding channel order [th0 ph0 th1 ph1 th2 ph2]
-                rows += [P[f"gcn1.conv_a.{k}.weight"].view(ic, cin), P[f"gcn1.conv_b.{k}.weight"].view(ic, cin)]
-            emb_t = _pad_last(torch.cat(rows, 0), cx)          # (6ic, cx)
-            W["emb"] = emb_t.t().contiguous().unsqueeze(0)     # (1, cx, 6ic)
-            W["emb_t"] = emb_t.contiguous().unsqueeze(0)       # (1, 6ic, cx)  data-gradient form
-            W["emb_b"] = torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
-        d = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
-        W["d"] = torch.cat([w.t() for w in d], 0).contiguous()                    # (3cx, cout)
-        W["d4"] = ops.pack_spatial(W["d"], cx)                                    # (3cx/4, cout, 4) for the fused kernel
-        W["d_t"] = torch.cat(d, 1).contiguous().unsqueeze(0)                      # (1, cout, 3cx)
-        W["dt4"] = ops.pack_k4(torch.stack(d, 0).contiguous())                    # (3, cout/4, cx, 4) fused backward
-        W["d_b"] = (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()
-        if cfg.has_down:
-            w = _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx)
-            W["down"] = w.t().contiguous().unsqueeze(0)                           # (1, cx, cout)
-            W["down_t"] = w.contiguous().unsqueeze(0)                             # (1, cout, cx)
-        wt = P["tcn1.conv.weight"].view(cout, cout, -1)                           # (o, c, kt)
-        W["t"] = wt.permute(2, 1, 0).contiguous()                                 # (kt, c, o)
-        W["t_t"] = wt.permute(2, 0, 1).contiguous()                               # (kt, o, c)
-        # k-interleaved forms for the halo-tile kernel; a stride-2 conv runs as an even-tap and an odd-tap pass
-        # (ops.pack_conv: k-interleaved f32, or the three-way bf16 split in math mode bf16x3 -- the cache key of the
-        # packed set includes the math mode)
-        if cfg.stride == 1:
-            W["t4"], W["t_t4"] = ops.pack_conv(W["t"]), ops.pack_conv(W["t_t"])
-        else:
-            for par, tag in ((0, "e"), (1, "o")):      # data gradient; forward too in bf16x3 (see temporal_fwd)
-                W[f"t_t4_{tag}"] = ops.pack_conv(W["t_t"][par::2].contiguous())
-                if ops.get_math_mode() == "bf16x3":
-                    W[f"t4_{tag}"] = ops.pack_conv(W["t"][par::2].contiguous())
-        if cfg.residual == "conv":
-            w = _pad_last(P["residual.conv.weight"].view(cout, cin), cx)
-            W["res"] = w.t().contiguous().unsqueeze(0)
-            W["res_t"] = w.contiguous().unsqueeze(0)
-        if ops.get_math_mode() == "bf16x3":            # split forms of the 1x1 weights pw_gemm may route to the halo kernel
-            for key in ("emb", "emb_t", "d_t", "down", "down_t"):
-                if key in W and W[key].shape[1] % 64 == 0:
-                    W[key + "_s3"] = ops.pack_split3(W[key])
+    x3 = ops.get_math_mode() == "bf16x3"
+    B: Dict[str, object] = {}
+    memo: Dict[str, object] = {}
+
+    def once(name, fn):
+        if name not in memo:
+            memo[name] = fn()
+        return memo[name]
+
+    def emb_t():                                               # (6ic, cx), embedding channel order [th0 ph0 th1 ph1 th2 ph2]
+        rows = []
+        for k in range(NUM_SUBSETS):
+            rows += [P[f"gcn1.conv_a.{k}.weight"].view(ic, cin), P[f"gcn1.conv_b.{k}.weight"].view(ic, cin)]
+        return _pad_last(torch.cat(rows, 0), cx)
+
+    def d_list():
+        return [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
+
+    if not cfg.static_adjacency:
+        B["emb"] = lambda: once("emb_t", emb_t).t().contiguous().unsqueeze(0)      # (1, cx, 6ic)
+        B["emb_t"] = lambda: once("emb_t", emb_t).contiguous().unsqueeze(0)        # (1, 6ic, cx)  data-gradient form
+        B["emb_b"] = lambda: torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
+    B["d"] = lambda: torch.cat([w.t() for w in once("d", d_list)], 0).contiguous()               # (3cx, cout)
+    B["d4"] = lambda: ops.pack_spatial(W["d"], cx)                                              # for the fused kernel
+    B["d_t"] = lambda: torch.cat(once("d", d_list), 1).contiguous().unsqueeze(0)                # (1, cout, 3cx)
+    B["dt4"] = lambda: ops.pack_k4(torch.stack(once("d", d_list), 0).contiguous())              # (3, cout/4, cx, 4) fused backward
+    B["d_b"] = lambda: (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()
+    if cfg.has_down:
+        down = lambda: once("down", lambda: _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx))   # noqa: E731
+        B["down"] = lambda: down().t().contiguous().unsqueeze(0)                                # (1, cx, cout)
+        B["down_t"] = lambda: down().contiguous().unsqueeze(0)                                  # (1, cout, cx)
+    wt = lambda: P["tcn1.conv.weight"].view(cout, cout, -1)                                     # noqa: E731  (o, c, kt)
+    B["t"] = lambda: wt().permute(2, 1, 0).contiguous()                                         # (kt, c, o)
+    B["t_t"] = lambda: wt().permute(2, 0, 1).contiguous()                                       # (kt, o, c)
+    # k-interleaved forms for the halo-tile kernel (ops.pack_conv: k-interleaved f32, or the three-way bf16 split in math
+    # mode bf16x3); a stride-2 conv runs as an even-tap and an odd-tap pass
+    if cfg.stride == 1:
+        B["t4"] = lambda: ops.pack_conv(W["t"])
+        B["t_t4"] = lambda: ops.pack_conv(W["t_t"])
+    else:
+        for par, tag in ((0, "e"), (1, "o")):      # data gradient; forward too in bf16x3 (see temporal_fwd)
+            B[f"t_t4_{tag}"] = lambda par=par: ops.pack_conv(W["t_t"][par::2].contiguous())
+            if x3:
+                B[f"t4_{tag}"] = lambda par=par: ops.pack_conv(W["t"][par::2].contiguous())
+    if cfg.residual == "conv":
+        res = lambda: once("res", lambda: _pad_last(P["residual.conv.weight"].view(cout, cin), cx))   # noqa: E731
+        B["res"] = lambda: res().t().contiguous().unsqueeze(0)
+        B["res_t"] = lambda: res().contiguous().unsqueeze(0)
+    if x3:                                         # split forms of the 1x1 weights pw_gemm may route to the halo kernel
+        kdim = {"emb": cx, "emb_t": 6 * ic, "d_t": cout, "down": cx, "down_t": cout}
+        for key in ("emb", "emb_t", "d_t", "down", "down_t"):
+            if key in B and kdim[key] % 64 == 0:
+                B[key + "_s3"] = lambda key=key: ops.pack_split3(W[key])
+    W = PackedWeights(B)
     return W
 
 
@@ -346,7 +385,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign)   # *_sign: 1 bit per element, the backward's ReLU gate
 
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
-    kt = W["t"].shape[0]
+    kt = P["tcn1.conv.weight"].shape[2]
     u = new(B, Tp, V, cout)
     part = temporal_fwd(g, u, W, P["tcn1.conv.bias"], kt, s, stats=train)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
@@ -402,13 +441,24 @@ class _WgradBranch:
             self.main.wait_stream(self.side)
 
 
-def _bias_grad(d: torch.Tensor, c: int, train: bool) -> torch.Tensor:
-    """Gradient of a conv bias that feeds a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
-    block output does not depend on that bias and its gradient is exactly zero (the reference's autograd produces
-    ~1e-9 rounding noise there); only eval-mode statistics make it a real column sum."""
-    if train:
-        return torch.zeros(c, device=d.device, dtype=torch.float32)
-    return ops.col_sum(d, c)
+class _BiasGrads:
+    """Gradients of conv biases that feed a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
+    block output does not depend on such a bias and its gradient is exactly zero (the reference's autograd produces
+    ~1e-9 rounding noise there): all of a block's are disjoint slices of ONE zero-filled
+    allocation (one fill launch per block; every parameter still gets memory of its own).  Only eval-mode statistics make
+    them real column sums."""
+
+    def __init__(self, cfg: BlockConfig, device, train: bool):
+        self.train = train
+        n = (NUM_SUBSETS + 1 + int(cfg.has_down) + int(cfg.residual == "conv")) * cfg.cout
+        self.pool = torch.zeros(n, device=device, dtype=torch.float32) if train else None
+        self.used = 0
+
+    def __call__(self, d: torch.Tensor, c: int) -> torch.Tensor:
+        if not self.train:
+            return ops.col_sum(d, c)
+        self.used += c
+        return self.pool[self.used - c:self.used]
 
 
 def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
@@ -423,11 +473,12 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     G: Dict[str, torch.Tensor] = {}
     d_o = d_o.contiguous()
-    kt = W["t"].shape[0]
+    kt = P["tcn1.conv.weight"].shape[2]
 
     dx = new(B, T, V, cx)
     dx_live = False      # becomes True once dx holds a valid partial sum
     wgrad = _WgradBranch(dev, WGRAD_SIDE_STREAM)
+    bias_grad = _BiasGrads(cfg, dev, train)
 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
     if cfg.residual == "none":
@@ -446,7 +497,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         with wgrad():
             G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
                                                        conv_param=(1, cin_true))
-        G["residual.conv.bias"] = _bias_grad(dr, cout, train)
+        G["residual.conv.bias"] = bias_grad(dr, cout)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
     # -- temporal conv -------------------------------------------------------------------------------------------------------
@@ -455,7 +506,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
     with wgrad():
         G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
-    G["tcn1.conv.bias"] = _bias_grad(du, cout, train)
+    G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
     if cfg.has_down:
@@ -466,7 +517,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         dx_live = True
         with wgrad():
             G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
-        G["gcn1.down.0.bias"] = _bias_grad(dd, cout, train)
+        G["gcn1.down.0.bias"] = bias_grad(dd, cout)
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
                                      db_accumulate=dx_live, sign_mask=S["g_sign"])
@@ -486,10 +537,11 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
             mix_agg(x, agg, a_hat, cin)
             gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
             del agg
-    dbias = _bias_grad(dy, cout, train)
+    dbias = None if train else ops.col_sum(dy, cout)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
-        G[f"gcn1.conv_d.{k}.bias"] = dbias if k == 0 else dbias.clone()          # three parameters, three buffers
+        # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
+        G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
     if cfg.fused_spatial_bwd:
         # dagg = dy . Wd, dx += dagg . A^^T and dA^ = x^T . dagg in one kernel; dagg never reaches HBM
         part = ops.spatial_bwd(dy, x, a_hat, W["dt4"], dx, accumulate=dx_live)

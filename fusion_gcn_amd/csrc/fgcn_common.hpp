@@ -88,7 +88,15 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
 __device__ __forceinline__ f32x16 mfma_bf16_k16(u32x4v a, u32x4v b, f32x16 c) {
+#ifdef FGCN_PROBE_16X16   // timing probe only (wrong numerics): the same FLOPs as two 16x16x32 instructions
+    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 // the six partial products of a three-way split pair (index 0 = high, 1 = middle, 2 = low part), small terms first
 __device__ __forceinline__ f32x16 mfma_x3_k16(const u32x4v (&a)[3], const u32x4v (&b)[3], f32x16 c) {
