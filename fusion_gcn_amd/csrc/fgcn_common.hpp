@@ -108,6 +108,21 @@ __device__ __forceinline__ f32x16 mfma_x3_k16(const u32x4v (&a)[3], const u32x4v
     return mfma_bf16_k16(a[0], b[0], c);
 }
 
+// the same six partial products on v_mfma_f32_16x16x32_bf16 (lane (i, g = lane >> 4) holds k = 8g + j; accumulator register r of
+// lane (col, g) = row 4g + r): half the accumulator traffic per FLOP of the 32x32x16 form -- under these kernels the chip
+// holds its clock with it where the 32x32 form makes it throttle
+__device__ __forceinline__ f32x4 mfma_bf16_k32(u32x4v a, u32x4v b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_x3_k32(const u32x4v (&a)[3], const u32x4v (&b)[3], f32x4 c) {
+    c = mfma_bf16_k32(a[2], b[0], c);
+    c = mfma_bf16_k32(a[0], b[2], c);
+    c = mfma_bf16_k32(a[1], b[1], c);
+    c = mfma_bf16_k32(a[1], b[0], c);
+    c = mfma_bf16_k32(a[0], b[1], c);
+    return mfma_bf16_k32(a[0], b[0], c);
+}
+
 template <int MM> struct Frag;
 template <> struct Frag<1> { s16x4 h; };
 template <> struct Frag<2> { s16x4 h, m, l; };

@@ -202,7 +202,6 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     constexpr int GT = TN / 4, GRP = 512 / GT;                    // g staging: threads per row, rows per pass (4 passes)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
     const int nsub = wave % NSUBS, part = wave / NSUBS;
     const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
     const int k0 = tk * (CH ? 32 * NTAP : 32), n0 = tn * TN;
@@ -270,15 +269,22 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
         }
     };
 
-    f32x16 acc[NTAP];
+    // 16x16x32 MFMAs: the wave's (32 in-channel x 32 column) region is 2 x 2 tiles of 16 x 16 per accumulator set, and its 32
+    // rows of the stage are ONE contraction step
+    f32x4 acc[NTAP][2][2];
 #pragma unroll
-    for (int j = 0; j < NTAP; ++j) acc[j] = zero16();
+    for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[j][kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transposed-read addresses: lane (group g16 = (lane >> 4) & 1, q = (lane & 15) >> 2, c = lane & 3) supplies row
-    // 8h + q (+4 for the second half of the fragment) and channels 16 g16 + 4c .. +3; it receives channel lane & 31.
-    const int g16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, c4 = lane & 3;
-    const unsigned char* a_lane = Ap + (part * 32 + 8 * h + q4) * X3_SA + (16 * g16 + 4 * c4) * 2;
-    const unsigned char* g_lane = Gp + (part * 32 + 8 * h + q4) * X3_SG + (nsub * 32 + 16 * g16 + 4 * c4) * 2;
+    // transposed-read addresses: the 16-lane group g4 = lane >> 4 reads rows 8 g4 + q (+4 for the second half of the fragment)
+    // x 16 channels (lane (q = (lane & 15) >> 2, c = lane & 3) supplies row q, channels 4c .. 4c+3) and every lane receives the 8
+    // rows 8 g4 .. 8 g4 + 7 of channel lane & 15 of the tile: the k = 8g + j operand order of v_mfma_f32_16x16x32_bf16
+    const int g4 = lane >> 4, q4 = (lane & 15) >> 2, c4 = lane & 3, l15 = lane & 15;
+    const unsigned char* a_lane = Ap + (part * 32 + 8 * g4 + q4) * X3_SA + (4 * c4) * 2;                 // + 32 bytes per tile
+    const unsigned char* g_lane = Gp + (part * 32 + 8 * g4 + q4) * X3_SG + (nsub * 32 + 4 * c4) * 2;
     auto frag = [&](const unsigned char* base, unsigned plane, int row_stride, u32x4v (&f)[3]) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
@@ -294,35 +300,42 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
         deposit();
         __syncthreads();
         if (sid + 1 < send) fetch(sid + 1);                       // lands during the MFMAs below
+        u32x4v gq[2][3];
 #pragma unroll
-        for (int s16 = 0; s16 < 2; ++s16) {                       // this wave's 32 rows of the stage: two 16-row steps
-            u32x4v gq[3];
-            frag(g_lane + s16 * 16 * X3_SG, g_plane, X3_SG, gq);
+        for (int nt = 0; nt < 2; ++nt) frag(g_lane + nt * 32, g_plane, X3_SG, gq[nt]);
 #pragma unroll
-            for (int j = 0; j < NTAP; ++j) {
-                u32x4v aq[3];
-                frag(a_lane + (s16 * 16 + j * (CH ? X3_R : V)) * X3_SA, a_plane, X3_SA, aq);
-                acc[j] = mfma_x3_k16(aq, gq, acc[j]);
-            }
+        for (int j = 0; j < NTAP; ++j) {
+            u32x4v aq[2][3];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) frag(a_lane + (j * (CH ? X3_R : V)) * X3_SA + kt * 32, a_plane, X3_SA, aq[kt]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[j][kt][nt] = mfma_x3_k32(aq[kt], gq[nt], acc[j][kt][nt]);
         }
     }
 
     // ---- partial slabs: [slab = split * NPARTS + part][tap][k][n] -----------------------------------------------------
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
     const int slab = blockIdx.y * NPARTS + part;
-    const int ncol = n0 + nsub * 32 + l31;
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         const int tap = CH ? 0 : p.tap0 + j * p.tap_step;
         const int kj = k0 + (CH ? 32 * j : 0);
         const unsigned base = (unsigned)((slab * p.taps_total + tap) * p.K) * (unsigned)p.N;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kj + acc_row(r, lane);
-            const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
-            const float val = acc[j][r];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
-        }
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int ncol = n0 + nsub * 32 + 16 * nt + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = kj + 16 * kt + 4 * g4 + r;
+                    const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
+                    const float val = acc[j][kt][nt][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
+                }
+            }
     }
 }
 
