@@ -41,7 +41,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA (32x32x16 / 16x16x32), dense
 PEAK_SPLIT3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # float32-equivalent FLOPs when every product costs six bf16 MFMAs
 MATH_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT3_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}
 MATH_DTYPE = {
@@ -50,7 +50,7 @@ MATH_DTYPE = {
               "f32 storage / statistics; same parity tolerances as the f32 MFMA path)",
     "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics"}
 MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_kernel<{nt},3> (bf16 operands)",
-               "bf16x3": "conv_halo_x3_kernel<2,{nt2},32>"}
+               "bf16x3": "conv_halo_x3k32_kernel<{nt2},32>"}
 PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
 SHAPE = dict(N=64, M=2, T=300, V=25, C=3, classes=60)
 

@@ -519,6 +519,238 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
     }
 }
 
+
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16 ---------------------------------------------------------------------------
+// Half the accumulator traffic per FLOP of the 32x32x16 form: under this kernel the chip holds ~1.85 GHz with the 32x32 shape
+// and the timing probe gave +4-5 % for the 16x16 one.  A step is one tap x 32 channels (the
+// whole chunk at KC = 32); lane (i = lane & 15, g = lane >> 4) holds k = 8g + j of row / column i.  The wave's 64 x (32 NT)
+// tile is 4 row tiles x 2 NT column tiles of 16 x 16; the four image fragments of a step stay resident and are replaced
+// one by one during the step's last unit (right after each one's last MFMA), the weight fragments ride the same two-slot
+// ring, one unit (one 16-column tile = 24 MFMAs) ahead.
+template <int NT, int KC>
+__global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
+    constexpr int XS = KC * 2 + 16;
+    constexpr int TPR = KC / 4;
+    constexpr int RPP = 256 / TPR;
+    constexpr int SPC = KC / 32;                     // steps per tap and chunk
+    constexpr bool PF = KC == 64;
+    constexpr int NST = PF ? 8 : HALO_MAX_STAGE;
+    constexpr int NU = 2 * NT;                       // 16-column tiles (units) of a wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float Ah[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const long long m0 = (long long)bm * 128;
+    constexpr int BN = 2 * NT * 32;
+    const int n0 = bn * BN;
+    const int V = p.V, TvV = p.Tv * p.V;
+    const unsigned k4b = (tid % TPR) * 16;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
+
+    bool row_ok[4];
+    int th_lane[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const long long mrow = m0 + wr * 64 + mt * 16 + l15;
+        row_ok[mt] = mrow < p.Mv;
+        th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
+    }
+
+    unsigned src_off[NST];
+    const int nstage = (p.halo_rows + RPP - 1) / RPP;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        src_off[i] = OOB;
+        const int r = tid / TPR + RPP * i;
+        const long long hv = m0 + (long long)p.dmin * V + r;
+        if (i < nstage && hv >= 0 && hv < p.Mv) {
+            const unsigned hu = (unsigned)hv;
+            const int n = (int)(hu / (unsigned)TvV);
+            const int rem = (int)(hu - (unsigned)n * (unsigned)TvV);
+            const int th = (int)((unsigned)rem / (unsigned)V);
+            const int v = rem - th * V;
+            const int fr = th * p.in_s + p.in_o;
+            if (th < p.Th_in && fr < p.T_in_full)
+                src_off[i] = (unsigned)(((((long long)n * p.T_in_full + fr) * V + v) * p.ld_in) * 4) + k4b;
+        }
+    }
+
+    f32x4 acc[4][NU];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) acc[mt][nu] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int col = n0 + wc * NT * 32 + l15;         // + nu*16
+    unsigned wvoff[NU];                              // per-lane byte offset into one part: (g4*N + col) * 8 bf16
+#pragma unroll
+    for (int nu = 0; nu < NU; ++nu) wvoff[nu] = (unsigned)(((long long)g4 * p.N + col + nu * 16) * 16);
+
+    unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
+    const unsigned plane = (unsigned)p.halo_rows * XS;
+    const unsigned char* xrow = Xh + (wr * 64 + l15) * XS + 16 * g4;
+    const int IT2 = p.taps * SPC;                    // (tap, 32-channel group) steps per chunk
+    const int K8 = p.K >> 3;
+    auto load_w = [&](u32x4v (&dst)[3], int nu, int it, int kc) {
+        if (it >= IT2) {                             // (at most one step past the chunk)
+            it -= IT2;
+            kc += KC;
+        }
+        if (kc >= p.K) {                             // past the last unit: a valid, unused load
+            it = 0;
+            kc = 0;
+        }
+        const int j = it / SPC, s2 = it - j * SPC;
+        const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 4 * s2) * p.N) * 16);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
+    };
+    auto load_a = [&](u32x4v (&dst)[3], int mt, int it) {
+        const int j = it / SPC, s2 = it - j * SPC;
+        const int d = j * p.tb + p.tc;
+        const unsigned char* src = xrow + ((d - p.dmin) * V + mt * 16) * XS + 64 * s2;
+        const int ts = th_lane[mt] + d;
+        const bool ok = row_ok[mt] && ts >= 0 && ts < p.Th_in;          // frame mask of this (row, tap)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const u32x4v v = *reinterpret_cast<const u32x4v*>(src + pl * plane);
+            dst[pl] = ok ? v : u32x4v{0u, 0u, 0u, 0u};
+        }
+    };
+
+    f32x4 stage[NST];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+    };
+    auto deposit = [&]() {                           // split the staged rows into the three bf16 planes
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int r = tid / TPR + RPP * i;
+            if (i < nstage && r < p.halo_rows) {
+                u32x2 ph, pm, pl;
+                split3_x4(stage[i], ph, pm, pl);
+                unsigned char* dst = Xh + r * XS + (tid % TPR) * 8;
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
+            }
+        }
+    };
+
+    u32x4v a[4][3], wq[2][3];
+    load_w(wq[0], 0, 0, 0);
+    if constexpr (PF) fetch(0);
+    for (int kc = 0; kc < p.K; kc += KC) {
+        __syncthreads();                             // previous chunk's image reads are done
+        if constexpr (!PF) fetch(kc);
+        deposit();
+        __syncthreads();
+        if constexpr (PF) {
+            if (kc + KC < p.K) fetch(kc + KC);       // lands during the MFMAs below
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) load_a(a[mt], mt, 0);
+#pragma unroll 1
+        for (int it = 0; it < IT2; ++it) {
+            const int itn = it + 1 < IT2 ? it + 1 : it;                  // the chunk's last step re-reads itself (unused)
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], nu + 1, it, kc);
+                else load_w(wq[0], 0, it + 1, kc);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums ---------------------------------
+    // accumulator register r of lane (col l15, g4) = row 4 g4 + r of the 16 x 16 tile
+    const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+    float ssum[NU], ssq[NU], bv[NU];
+    unsigned coff[NU];
+#pragma unroll
+    for (int nu = 0; nu < NU; ++nu) {
+        ssum[nu] = 0.f;
+        ssq[nu] = 0.f;
+        coff[nu] = col + nu * 16 < p.N ? (unsigned)(col + nu * 16) * 4u : OOB;
+        bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        unsigned rowoff[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long m = m0 + wr * 64 + mt * 16 + 4 * g4 + r;
+            bool ok = m < p.Mv;
+            unsigned orow = (unsigned)(ok ? m : 0);
+            if (!plain_out) {                              // wave-uniform
+                const int n = (int)(orow / (unsigned)TvV);
+                const int rem = (int)(orow - (unsigned)n * (unsigned)TvV);
+                const int th = (int)((unsigned)rem / (unsigned)V);
+                const int v = rem - th * V;
+                ok = ok && th < p.Th_out;
+                orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
+            }
+            rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
+        }
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            float old[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                old[r] = 0.f;
+                if (p.accumulate)                          // wave-uniform
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rout, (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
+                const float val = acc[mt][nu][r] + bv[nu] + old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+                const float kept = off != OOB ? val : 0.f;
+                ssum[nu] += kept;
+                ssq[nu] += kept * kept;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float* red = Ah;                                   // [which][wr][BN]
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            float sa = ssum[nu] + __shfl_xor(ssum[nu], 16);
+            float sb = ssq[nu] + __shfl_xor(ssq[nu], 16);
+            sa += __shfl_xor(sa, 32);
+            sb += __shfl_xor(sb, 32);
+            if (lane < 16) {
+                red[(0 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sa;
+                red[(1 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sb;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.N)
+                p.stats[((long long)bm * 2 + which) * p.N + n0 + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
+        }
+    }
+}
+
 }  // namespace fgcn
 
 using namespace fgcn;
@@ -596,6 +828,30 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
     p.per_xcd = 0;
+    if (mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 2) && !((fgcn::tuning(7) & 4) && N <= 64)) {     // 16x16x32 MFMA form (tuning key 7 bit 1: the 32x32x16 one)
+        static bool opt_in = false;
+        if (!opt_in) {
+            const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<1, 32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<2, 32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<1, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<2, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+            opt_in = true;
+        }
+        if (taps == 1 && K % 64 == 0) {
+            const size_t lds64 = (size_t)128 * (64 * 2 + 16) * 3;
+            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 64>), grid, dim3(256), lds64, s, p);
+            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 64>), grid, dim3(256), lds64, s, p);
+        } else {
+            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32>), grid, dim3(256), lds, s, p);
+            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32>), grid, dim3(256), lds, s, p);
+        }
+        return launch_status("tconv_halo");
+    }
     if (mm == FGCN_MATH_BF16X3) {
         if (taps == 1 && K % 64 == 0) {              // 1x1 convolution: 64-channel chunks, next chunk prefetched
             const size_t lds64 = (size_t)128 * (64 * 2 + 16) * 3;

@@ -74,9 +74,11 @@ def bench_tconv(B, reps):
     """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2; tuning key 4 picks the
     register budget (2 or 3 workgroups per CU)."""
     lib = _lib.load()
+    x3 = ops.get_math_mode() == "bf16x3"
     for three in (0, 1):
+        lib.fgcn_set_tuning(7, 2 * three if x3 else 0)
         lib.fgcn_set_tuning(4, three)
-        print(f"-- conv_halo, workgroups per CU hint = {3 - three}")
+        print(f"-- conv_halo, " + (f"MFMA shape {('16x16x32', '32x32x16')[three]}" if x3 else f"workgroups per CU hint = {3 - three}"))
         for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
             Tp = (T - 1) // s + 1
             wt = rnd(9, c, c) * (9 * c) ** -0.5
@@ -95,6 +97,7 @@ def bench_tconv(B, reps):
             ms = timeit(lambda: block.temporal_dgrad(du, dg, W, 9, s), reps)
             report(f"tconv_halo dgrad T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
     lib.fgcn_set_tuning(4, 0)
+    lib.fgcn_set_tuning(7, 0)
 
 
 def bench_wgrad(B, reps):
