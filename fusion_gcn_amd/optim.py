@@ -103,6 +103,10 @@ class FlatOptimizer(torch.optim.Optimizer):
                                  float(g.get("dampening", 0.0)), int(bool(g.get("nesterov", False))), self.steps,
                                  torch.cuda.current_stream(self.flat.device).cuda_stream)
         _lib.check(rc, "fgcn_optim_step")
+        # the kernel wrote through raw pointers: tell autograd (and everything keyed on tensor versions, like the blocks'
+        # cache of packed weights) that every parameter changed in place -- metadata only, no launches
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
         return loss
 
     # ---- torch.optim state-dict layout (per-parameter entries are views of the flat state) ---------------------------------

@@ -89,6 +89,12 @@ def test_fused_update_matches_torch_optim(name, args):
         for pr, po in zip(ref_model.parameters(), model.parameters()):
             err = float((po.detach().cpu() - pr.detach()).norm() / pr.detach().norm())
             assert err < 2e-6, (name, args, it, err)
+    # the raw-pointer update is visible to autograd's version counters (the blocks key their packed-weight cache on them)
+    v0 = [p._version for p in model.parameters()]
+    for po in model.parameters():
+        po.grad = torch.zeros_like(po)
+    opt.step()
+    assert all(p._version > v for p, v in zip(model.parameters(), v0))
     # padding between the views stays zero (the kernel runs over the whole buffer)
     used = torch.zeros_like(opt.flat, dtype=torch.bool)
     for v, p in zip(opt.grads.views, opt.params):
@@ -101,7 +107,7 @@ def test_fused_update_matches_torch_optim(name, args):
     opt2 = FlatOptimizer(copy.deepcopy(ref_model).to(dev).parameters(), name, 0.05, **args)
     opt2.load_state_dict(ref.state_dict())
     if name != "SGD":
-        assert opt2.steps == 6
+        assert opt2.steps == 6 and opt.steps == 7
         a, b = opt2.state_dict()["state"][0]["exp_avg_sq"].cpu(), ref.state_dict()["state"][0]["exp_avg_sq"]
         assert torch.equal(a, b)
 
