@@ -129,7 +129,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     cx-channel block whose extra input channel is identically zero (only the 3-channel network input pads).
     The math mode is read once, here (the model keys its cache of packed sets on it)."""
     cin, cout, ic, cx = cfg.cin, cfg.cout, cfg.ic, cfg.cx
-    x3 = ops.get_math_mode() == "bf16x3"
+    x3 = ops.get_math_mode() in ops.SPLIT_MODES       # modes whose halo kernel takes the split weight form
     B: Dict[str, object] = {}
     memo: Dict[str, object] = {}
 

@@ -527,8 +527,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
 // tile is 4 row tiles x 2 NT column tiles of 16 x 16; the four image fragments of a step stay resident and are replaced
 // one by one during the step's last unit (right after each one's last MFMA), the weight fragments ride the same two-slot
 // ring, one unit (one 16-column tile = 24 MFMAs) ahead.
-template <int NT, int KC>
-__global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
+// NP = bf16 parts per operand: 3 = FGCN_MATH_BF16X3 (six partial products), 1 = FGCN_MATH_BF16 (operands rounded to bf16 once --
+// activations as the image is staged, weights by fgcn_pack_split3, whose part 0 is the round-to-nearest-even bf16 -- and ONE
+// MFMA per product group: a sixth of the matrix work, a third of the LDS image and of the weight stream).
+template <int NT, int KC, int NP>
+__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(NP == 1 || NP == 3, "one or three bf16 parts per operand");
     static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
     constexpr int XS = KC * 2 + 16;
     constexpr int TPR = KC / 4;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
     const unsigned char* xrow = Xh + (wr * 64 + l15) * XS + 16 * g4;
     const int IT2 = p.taps * SPC;                    // (tap, 32-channel group) steps per chunk
     const int K8 = p.K >> 3;
-    auto load_w = [&](u32x4v (&dst)[3], int nu, int it, int kc) {
+    auto load_w = [&](u32x4v (&dst)[NP], int nu, int it, int kc) {
         if (it >= IT2) {                             // (at most one step past the chunk)
             it -= IT2;
             kc += KC;
@@ -608,17 +612,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
         const int j = it / SPC, s2 = it - j * SPC;
         const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 4 * s2) * p.N) * 16);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
     };
-    auto load_a = [&](u32x4v (&dst)[3], int mt, int it) {
+    auto load_a = [&](u32x4v (&dst)[NP], int mt, int it) {
         const int j = it / SPC, s2 = it - j * SPC;
         const int d = j * p.tb + p.tc;
         const unsigned char* src = xrow + ((d - p.dmin) * V + mt * 16) * XS + 64 * s2;
         const int ts = th_lane[mt] + d;
         const bool ok = row_ok[mt] && ts >= 0 && ts < p.Th_in;          // frame mask of this (row, tap)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
             const u32x4v v = *reinterpret_cast<const u32x4v*>(src + pl * plane);
             dst[pl] = ok ? v : u32x4v{0u, 0u, 0u, 0u};
         }
@@ -639,13 +643,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
                 split3_x4(stage[i], ph, pm, pl);
                 unsigned char* dst = Xh + r * XS + (tid % TPR) * 8;
                 *reinterpret_cast<u32x2*>(dst) = ph;
-                *reinterpret_cast<u32x2*>(dst + plane) = pm;
-                *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
+                if constexpr (NP == 3) {
+                    *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
+                }
             }
         }
     };
 
-    u32x4v a[4][3], wq[2][3];
+    u32x4v a[4][NP], wq[2][NP];
     load_w(wq[0], 0, 0, 0);
     if constexpr (PF) fetch(0);
     for (int kc = 0; kc < p.K; kc += KC) {
@@ -667,7 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3k32_kernel(HaloP p) {
                 else load_w(wq[0], 0, it + 1, kc);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
                     if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
                 }
             }
@@ -778,9 +785,10 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     FGCN_REQUIRE((long long)(Th_in - 1) * in_s + in_o < T_in_full && (long long)(Th - 1) * out_s + out_o < T_out_full,
                  FGCN_E_BADARG, "tconv_halo: frame view exceeds the tensor (Th=%d Th_in=%d)", Th, Th_in);
     const int mm = fgcn::math_mode();
-    // FGCN_MATH_BF16X3: w4 is the split form (fgcn_pack_split3: three bf16 parts of [tap][K/8][N][8]) = 6 bytes per weight
+    // FGCN_MATH_BF16X3 / FGCN_MATH_BF16: w4 is the split form (fgcn_pack_split3: three bf16 parts of [tap][K/8][N][8]) = 6 bytes
+    // per weight; the bf16 mode reads part 0 only (the round-to-nearest-even bf16 of the weight)
     const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4;
-    const long long w_bytes = (long long)taps * K * N * (mm == FGCN_MATH_BF16X3 ? 6 : 4);
+    const long long w_bytes = (long long)taps * K * N * (mm != FGCN_MATH_F32 ? 6 : 4);   // split form in both bf16 modes
     const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
     FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -828,28 +836,36 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
     p.per_xcd = 0;
-    if (mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 2) && !((fgcn::tuning(7) & 4) && N <= 64)) {     // 16x16x32 MFMA form (tuning key 7 bit 1: the 32x32x16 one)
+    if ((mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 2) && !((fgcn::tuning(7) & 4) && N <= 64)) || mm == FGCN_MATH_BF16) {
+        // 16x16x32 MFMA form (tuning key 7 bit 1: the 32x32x16 one); FGCN_MATH_BF16: the same kernel with one bf16 part
         static bool opt_in = false;
         if (!opt_in) {
             const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<1, 32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<2, 32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<1, 64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<2, 64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define FGCN_K32_ATTR(NT_, KC_)                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3>),             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1>),             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
+            FGCN_K32_ATTR(1, 32); FGCN_K32_ATTR(2, 32); FGCN_K32_ATTR(1, 64); FGCN_K32_ATTR(2, 64);
+#undef FGCN_K32_ATTR
             opt_in = true;
         }
-        if (taps == 1 && K % 64 == 0) {
-            const size_t lds64 = (size_t)128 * (64 * 2 + 16) * 3;
-            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 64>), grid, dim3(256), lds64, s, p);
-            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 64>), grid, dim3(256), lds64, s, p);
+        const bool one = mm == FGCN_MATH_BF16;
+        const bool pw = taps == 1 && K % 64 == 0;
+        const size_t lds_k = pw ? (size_t)128 * (64 * 2 + 16) * (one ? 1 : 3) : (size_t)p.halo_rows * XSB * (one ? 1 : 3);
+#define FGCN_K32_LAUNCH(NT_, KC_)                                                                                \
+    do {                                                                                                         \
+        if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1>), grid, dim3(256), lds_k, s, p);       \
+        else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3>), grid, dim3(256), lds_k, s, p);           \
+    } while (0)
+        if (pw) {
+            if (N <= 64) FGCN_K32_LAUNCH(1, 64);
+            else FGCN_K32_LAUNCH(2, 64);
         } else {
-            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32>), grid, dim3(256), lds, s, p);
+            if (N <= 64) FGCN_K32_LAUNCH(1, 32);
+            else FGCN_K32_LAUNCH(2, 32);
         }
+#undef FGCN_K32_LAUNCH
         return launch_status("tconv_halo");
     }
     if (mm == FGCN_MATH_BF16X3) {

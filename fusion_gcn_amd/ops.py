@@ -128,10 +128,13 @@ def pack_split3(w: torch.Tensor, acc_order: bool = False) -> torch.Tensor:
     return out
 
 
+SPLIT_MODES = ("bf16x3", "bf16")      # math modes whose halo-tile kernel streams fgcn_pack_split3 weights (bf16: part 0 only)
+
+
 def pack_conv(w: torch.Tensor) -> torch.Tensor:
-    """Packed (taps, K, N) weights in the streamed form of the current math mode: ``pack_k4`` (f32 / bf16) or
-    ``pack_split3`` (bf16x3)."""
-    return pack_split3(w) if get_math_mode() == "bf16x3" else pack_k4(w)
+    """Packed (taps, K, N) weights in the form tconv_halo streams in the current math mode: ``pack_k4`` (f32) or
+    ``pack_split3`` (bf16x3, and bf16, which reads only the rounded high part)."""
+    return pack_split3(w) if get_math_mode() in SPLIT_MODES else pack_k4(w)
 
 
 def pack_spatial(wd: torch.Tensor, cin: int) -> torch.Tensor:
@@ -151,10 +154,10 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out")
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
-    split = get_math_mode() == "bf16x3"          # the weights then are the pack_split3 form
+    split = get_math_mode() in SPLIT_MODES       # the weights then are the pack_split3 form
     if split:
         if w4.dtype != torch.bfloat16 or w4.dim() != 5 or w4.shape[0] != 3 or w4.shape[4] != 8 or not w4.is_contiguous():
-            raise _lib.FgcnError(f"tconv_halo: math mode bf16x3 takes pack_split3 weights, got {w4.dtype} {tuple(w4.shape)}")
+            raise _lib.FgcnError(f"tconv_halo: math mode {get_math_mode()} takes pack_split3 weights, got {w4.dtype} {tuple(w4.shape)}")
         w_taps, K, N = w4.shape[1], w4.shape[2] * 8, w4.shape[3]
     else:
         _chk(w4, "tconv_halo.w4")

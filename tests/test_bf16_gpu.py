@@ -74,7 +74,7 @@ def test_halo_conv_bf16_forward_and_data_gradient(B, T, V, C, O):
     from fusion_gcn_amd import block, ops
     wt = rnd(9, C, O, seed=4, scale=(9 * C) ** -0.5)
     W = {"t": gpu(wt), "t_t": gpu(wt.permute(0, 2, 1))}
-    W["t4"], W["t_t4"] = ops.pack_k4(W["t"]), ops.pack_k4(W["t_t"])
+    W["t4"], W["t_t4"] = ops.pack_conv(W["t"]), ops.pack_conv(W["t_t"])
     x, b = rnd(B, T, V, C, seed=5), rnd(O, seed=6)
     u = torch.empty(B, T, V, O, device=dev())
     block.temporal_fwd(gpu(x), u, W, gpu(b), 9, 1, stats=True)
