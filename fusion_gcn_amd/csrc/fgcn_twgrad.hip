@@ -194,7 +194,9 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 // CH (1x1 convolutions, fgcn_pw_wgrad): accumulator j = in-channel chunk j instead of tap j -- the "window" is then NTAP
 // images of the stage's rows, one per 32-channel chunk (window row chunk * X3_R + r), and the fragment of accumulator j
 // starts X3_R rows further instead of V rows further; everything else is the same kernel.
-template <int NTAP, int TN, bool CH>
+// NP = bf16 parts per operand: 3 (FGCN_MATH_BF16X3) or 1 (FGCN_MATH_BF16: operands rounded once as the stage is written, one
+// MFMA per product group).
+template <int NTAP, int TN, bool CH, int NP>
 __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int X3_R = x3_rows(TN), X3_SG = x3_sg(TN);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     const int win = CH ? NTAP * X3_R : p.win_rows;                // tap mode: X3_R + (NTAP - 1) * V
     const unsigned a_plane = (unsigned)win * X3_SA, g_plane = X3_R * X3_SG;
     unsigned char* Ap = lds_raw;                                  // [3][win][32] bf16
-    unsigned char* Gp = lds_raw + 3 * a_plane;                    // [3][X3_R][128 (+32 pad)] bf16
+    unsigned char* Gp = lds_raw + NP * a_plane;                   // [NP][X3_R][128 (+32 pad)] bf16
     const int sbeg = blockIdx.y * p.stages_per_split;
     const int send = min(sbeg + p.stages_per_split, p.total_stages);
 
@@ -254,8 +256,10 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
                 split3_x4(sa[i], ph, pm, pl);
                 unsigned char* d = Ap + wr * X3_SA + a_c4 * 8;
                 *reinterpret_cast<u32x2*>(d) = ph;
-                *reinterpret_cast<u32x2*>(d + a_plane) = pm;
-                *reinterpret_cast<u32x2*>(d + 2 * a_plane) = pl;
+                if constexpr (NP == 3) {
+                    *reinterpret_cast<u32x2*>(d + a_plane) = pm;
+                    *reinterpret_cast<u32x2*>(d + 2 * a_plane) = pl;
+                }
             }
         }
 #pragma unroll
@@ -264,8 +268,10 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
             split3_x4(sg[i], ph, pm, pl);
             unsigned char* d = Gp + (g_row + GRP * i) * X3_SG + g_c4 * 8;
             *reinterpret_cast<u32x2*>(d) = ph;
-            *reinterpret_cast<u32x2*>(d + g_plane) = pm;
-            *reinterpret_cast<u32x2*>(d + 2 * g_plane) = pl;
+            if constexpr (NP == 3) {
+                *reinterpret_cast<u32x2*>(d + g_plane) = pm;
+                *reinterpret_cast<u32x2*>(d + 2 * g_plane) = pl;
+            }
         }
     };
 
@@ -285,9 +291,9 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     const int g4 = lane >> 4, q4 = (lane & 15) >> 2, c4 = lane & 3, l15 = lane & 15;
     const unsigned char* a_lane = Ap + (part * 32 + 8 * g4 + q4) * X3_SA + (4 * c4) * 2;                 // + 32 bytes per tile
     const unsigned char* g_lane = Gp + (part * 32 + 8 * g4 + q4) * X3_SG + (nsub * 32 + 4 * c4) * 2;
-    auto frag = [&](const unsigned char* base, unsigned plane, int row_stride, u32x4v (&f)[3]) {
+    auto frag = [&](const unsigned char* base, unsigned plane, int row_stride, u32x4v (&f)[NP]) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NP; ++pl) {
             const u32x2 lo = lds_read_tr16(base + pl * plane);
             const u32x2 hi = lds_read_tr16(base + pl * plane + 4 * row_stride);
             f[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
@@ -300,18 +306,21 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
         deposit();
         __syncthreads();
         if (sid + 1 < send) fetch(sid + 1);                       // lands during the MFMAs below
-        u32x4v gq[2][3];
+        u32x4v gq[2][NP];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) frag(g_lane + nt * 32, g_plane, X3_SG, gq[nt]);
 #pragma unroll
         for (int j = 0; j < NTAP; ++j) {
-            u32x4v aq[2][3];
+            u32x4v aq[2][NP];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) frag(a_lane + (j * (CH ? X3_R : V)) * X3_SA + kt * 32, a_plane, X3_SA, aq[kt]);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[j][kt][nt] = mfma_x3_k32(aq[kt], gq[nt], acc[j][kt][nt]);
+                for (int nt = 0; nt < 2; ++nt) {
+                    if constexpr (NP == 3) acc[j][kt][nt] = mfma_x3_k32(aq[kt], gq[nt], acc[j][kt][nt]);
+                    else acc[j][kt][nt] = mfma_bf16_k32(aq[kt][0], gq[nt][0], acc[j][kt][nt]);
+                }
         }
     }
 
@@ -348,7 +357,7 @@ using namespace fgcn;
 // (tuning key 6 bit 0: 1x1 weight gradients of that mode on the 256-thread kernel that splits fragments as it reads them --
 // the A/B switch of tools/kbench.py)
 static bool twgrad_use_x3(int N, int chunk_mode) {
-    return fgcn::math_mode() == FGCN_MATH_BF16X3 && !(chunk_mode && (fgcn::tuning(6) & 1));
+    return fgcn::math_mode() != FGCN_MATH_F32 && !(chunk_mode && (fgcn::tuning(6) & 1));   // both bf16 modes (3 parts / 1 part)
 }
 static int twgrad_parts(int N, int chunk_mode) {
     if (twgrad_use_x3(N, chunk_mode)) return N <= 64 ? 4 : 2;
@@ -391,18 +400,28 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
     static_assert(!CH || NTAP <= 6, "chunk mode: at most 6 (128 columns) / 3 (64 columns) chunks fit the staging passes");
     static bool opt_in = false;
     if (!opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 128, CH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if constexpr (!CH || NTAP <= 3)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, 64, CH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define FGCN_TWX_ATTR(TN_)                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1>),         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        FGCN_TWX_ATTR(128);
+        if constexpr (!CH || NTAP <= 3) { FGCN_TWX_ATTR(64); }
+#undef FGCN_TWX_ATTR
         opt_in = true;
     }
+    const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
+#define FGCN_TWX_LAUNCH(TN_)                                                                                    \
+    do {                                                                                                        \
+        if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1>), grid, dim3(512), lds, s, p);    \
+        else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3>), grid, dim3(512), lds, s, p);        \
+    } while (0)
     if (N <= 64) {
-        if constexpr (!CH || NTAP <= 3) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 64, CH>), grid, dim3(512), lds, s, p);
+        if constexpr (!CH || NTAP <= 3) FGCN_TWX_LAUNCH(64);
     } else {
-        hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, 128, CH>), grid, dim3(512), lds, s, p);
+        FGCN_TWX_LAUNCH(128);
     }
+#undef FGCN_TWX_LAUNCH
 }
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
@@ -438,7 +457,8 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     const int planes = chunk_mode ? nacc : 1;
     const int tn_x3 = N <= 64 ? 64 : 128;
     const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3) : p.win_rows;
-    const size_t lds = x3 ? (size_t)3 * ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
+    const size_t lds = x3 ? (size_t)(fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3) *
+                                ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
                           : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
     FGCN_REQUIRE(!x3 || win_x3 <= 64 * X3_APASS, FGCN_E_BADARG, "%s: window of %d rows too large", what, win_x3);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);

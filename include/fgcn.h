@@ -46,10 +46,11 @@ int fgcn_set_tuning(int key, int value);
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
  * session/procedures/step.py:55-78, which wraps model(x) in autocast):
  *   FGCN_MATH_F32  (default) v_mfma_f32_32x32x2_f32 on float32 operands -- the parity path (<= 1e-3 rel);
- *   FGCN_MATH_BF16 (BASELINE config 5) operands rounded to bfloat16 (round-to-nearest-even) as the fragments are
- *                  formed, v_mfma_f32_32x32x8_bf16 with float32 accumulation; tensors in HBM, BatchNorm statistics,
- *                  softmax, the joint mixing and every reduction stay float32.  Different tolerance contract:
- *                  logits <= 1e-2 rel, gradient cosine >= 0.98 against the f32 path.
+ *   FGCN_MATH_BF16 (BASELINE config 5) operands rounded to bfloat16 (round-to-nearest-even) once -- as a tile is staged,
+ *                  as a fragment is formed, or (weights of fgcn_tconv_halo) by fgcn_pack_split3 -- bf16 MFMAs with float32
+ *                  accumulation; tensors in HBM, BatchNorm statistics, softmax, the joint mixing and every reduction
+ *                  stay float32.  Different tolerance contract: logits <= 1e-2 rel, gradient cosine >= 0.98 against the
+ *                  f32 path.
  *   FGCN_MATH_BF16X3 float32-accurate products on the bf16 matrix pipe: both operand fragments are split exactly into
  *                  three bfloat16 terms (x = x_h + x_m + x_l, 24 significand bits) and the six partial products down
  *                  to 2^-16 of the leading one are accumulated in float32 (the dropped ones are below 2^-23 |a.b|, the
@@ -86,7 +87,8 @@ int fgcn_rows_gemm_tiles(long long M);
  * A stride-1 conv is one call with identity views; a stride-2 conv (or its data gradient) is two calls, one per frame
  * parity of the strided side, so no tap meets a structurally empty row.  The input tile plus its temporal halo is
  * staged in LDS once per 32 input channels and all taps run from it.
- *   w4: k-interleaved packed weights float[taps][K/4][N][4]  (w4[j][k/4][n][k%4] = W[j][k][n]);  K % 32 == 0.
+ *   w4 (FGCN_MATH_F32): k-interleaved packed weights float[taps][K/4][N][4]  (w4[j][k/4][n][k%4] = W[j][k][n]);
+ *   w4 (FGCN_MATH_BF16X3 and FGCN_MATH_BF16): the fgcn_pack_split3 form (the bf16 mode reads its part 0 only);  K % 32 == 0.
  *   stat_partials: float[fgcn_tconv_halo_tiles(B, Th, Th_in, V)][2][N] or NULL (sums of the values written, after
  *   accumulation).  Tensors must be smaller than 2 GiB (32-bit buffer offsets). */
 int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
@@ -139,8 +141,8 @@ int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K
                             long long st_tap, long long st_k, long long st_n, int accumulate, void* stream);
 
 /* FGCN_MATH_BF16X3 form of a packed (taps, K, N) weight: dst = unsigned short[3][taps][ceil(K/8)][N][8], part 0/1/2 the
- * high / middle / low bfloat16 term of the exact split w = w_h + w_m + w_l (channels beyond K are zeros).  This is
- * what fgcn_tconv_halo takes as `w4` while that math mode is selected.  acc_order = 1 (fgcn_spatial_fwd's `wd` in that
+ * high / middle / low bfloat16 term of the exact split w = w_h + w_m + w_l (channels beyond K are zeros; part 0 alone is the
+ * round-to-nearest-even bfloat16 of w).  This is what fgcn_tconv_halo takes as `w4` in both bf16 math modes.  acc_order = 1 (fgcn_spatial_fwd's `wd` in that
  * mode; ceil(K/16)*2 groups): group 2*k16 + h holds k = 16*k16 + 4h + (j & 3) + 8*(j >> 2), the order in which a 32x32
  * MFMA accumulator enumerates its rows. */
 int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, int acc_order, void* stream);
