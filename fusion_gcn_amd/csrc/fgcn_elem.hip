@@ -425,3 +425,36 @@ extern "C" int fgcn_group_mean(const float* x, float* partial, float* out, int g
                        out, groups, C, splits, 1.f / (float)rows);
     return launch_status("group_mean");
 }
+
+// ---- batched transpose (node-major <-> feature-major images of the 1-D graph convolutions) -------
+// out[b][c][r] = in[b][r][c] for r < R, c < C; in rows have stride ld_in, out rows stride ld_out >= R, and the columns
+// [R, ld_out) of every out row are zero-filled (the padded contraction index of the adjacency product).
+namespace fgcn {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int R, int C, int ld_in, int ld_out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (long long)b * R * ld_in;
+    float* dst = out + (long long)b * C * ld_out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(long long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < C && r < ld_out) dst[(long long)c * ld_out + r] = tile[tx][ty + 8 * i];   // r >= R: the zero padding
+    }
+}
+}  // namespace fgcn
+
+extern "C" int fgcn_transpose(const float* in, float* out, int B, int R, int C, int ld_in, int ld_out, void* stream) {
+    FGCN_REQUIRE(in && out && B > 0 && R > 0 && C > 0, FGCN_E_BADARG, "transpose: null pointer or empty shape");
+    FGCN_REQUIRE(ld_in >= C && ld_out >= R && B <= 65535 && (C + 31) / 32 <= 65535, FGCN_E_BADARG,
+                 "transpose: strides must cover the rows (ld_in=%d C=%d ld_out=%d R=%d)", ld_in, C, ld_out, R);
+    dim3 grid((unsigned)((ld_out + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(fgcn::transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, ld_in, ld_out);
+    return fgcn::launch_status("transpose");
+}

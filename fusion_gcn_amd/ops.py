@@ -609,3 +609,25 @@ def spatial_bwd(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, wdt4: to
                                x.shape[3], dx.shape[3], ns, int(a_hat.shape[0] != 1), int(accumulate), _stream()),
           "fgcn_spatial_bwd")
     return partial
+
+
+def transpose(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
+    """(B, R, C) -> (B, C, ld_out) with out[b, c, r] = x[b, r, c] and the columns [R, ld_out) zero-filled (ld_out >= R)."""
+    ensure_device()
+    _chk(x, "transpose.x")
+    B, R, C = x.shape
+    ld_out = R if ld_out is None else ld_out
+    out = torch.empty((B, C, ld_out), device=x.device, dtype=torch.float32)
+    check(_lib.load().fgcn_transpose(_p(x), _p(out), B, R, C, C, ld_out, _stream()), "fgcn_transpose")
+    return out
+
+
+def transpose_into(x: torch.Tensor, rows: int) -> torch.Tensor:
+    """(B, C, ld) feature-major with `rows` valid columns -> (B, rows, C): the inverse of ``transpose`` (drops the padding)."""
+    ensure_device()
+    _chk(x, "transpose_into.x")
+    B, C, ld = x.shape
+    out = torch.empty((B, rows, C), device=x.device, dtype=torch.float32)
+    # out[b][r][c] = x[b][c][r]: a transpose of the (C x rows) image with input row stride ld
+    check(_lib.load().fgcn_transpose(_p(x), _p(out), B, C, rows, ld, C, _stream()), "fgcn_transpose")
+    return out

@@ -310,6 +310,14 @@ int fgcn_spatial_bwd(const float* dy, const float* x, const float* a_hat, const 
                      int n_subsets, int a_hat_batched, int accumulate, void* stream);
 int fgcn_spatial_bwd_chunks(int B, int T);
 
+/* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
+/* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:
+ *     out[b][c][r] = in[b][r][c]  (r < R, c < C);  out rows have stride ld_out >= R, their columns [R, ld_out) are zero-filled.
+ * STGCNGraphConvolution (torch_src/models/mmargcn/graph_convolution.py:12-52) is then three existing entry points: the 1x1
+ * Conv1d = fgcn_rows_gemm over node-major rows, `torch.matmul(support, adj.t())` = fgcn_rows_gemm / fgcn_tconv_halo (taps = 1)
+ * over feature-major rows with the V x V adjacency as the shared weight, residual + ReLU = fgcn_bn_act. */
+int fgcn_transpose(const float* in, float* out, int B, int R, int C, int ld_in, int ld_out, void* stream);
+
 /* ---- the step after the path: parameter update over flat buffers ------------------- */
 /* One launch applies torch.optim's update to every trainable value of the model (reference: create_optimizer,
  * torch_src/session_helper.py:80-84, optimizer.step() in session/session.py:176-183):
