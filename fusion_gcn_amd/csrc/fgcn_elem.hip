@@ -129,38 +129,44 @@ template <int RES, bool MASKED>
 __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const unsigned char* mask, const float* a,
                                          const float* va, const float* b, const float* vb, float* partials,
                                          long long rows, long long rows_per_tile, int C, int relu) {
-    extern __shared__ float red[];  // [ny][3][C]
-    const int c = threadIdx.x * 4;
+    extern __shared__ float red[];  // [ny][3][Cw], Cw = the channel window of this block: 4 * blockDim.x channels from c0
+    const int Cw = blockDim.x * 4, c0 = blockIdx.y * Cw, cl = threadIdx.x * 4;
+    const int c = c0 + cl;
+    const bool cok = c < C;                              // (C % 4 == 0: a quad is all-in or all-out)
     const long long r0 = (long long)blockIdx.x * rows_per_tile;
     const long long r1 = min(r0 + rows_per_tile, rows);
-    const f32x4 mean_a = *reinterpret_cast<const f32x4*>(va + c);
-    const f32x4 rstd_a = *reinterpret_cast<const f32x4*>(va + C + c);
-    f32x4 mean_b = {0.f, 0.f, 0.f, 0.f}, rstd_b = {0.f, 0.f, 0.f, 0.f};
-    if (RES == 2) {
-        mean_b = *reinterpret_cast<const f32x4*>(vb + c);
-        rstd_b = *reinterpret_cast<const f32x4*>(vb + C + c);
+    f32x4 mean_a = {0.f, 0.f, 0.f, 0.f}, rstd_a = mean_a, mean_b = mean_a, rstd_b = mean_a;
+    if (cok) {
+        mean_a = *reinterpret_cast<const f32x4*>(va + c);
+        rstd_a = *reinterpret_cast<const f32x4*>(va + C + c);
+        if (RES == 2) {
+            mean_b = *reinterpret_cast<const f32x4*>(vb + c);
+            rstd_b = *reinterpret_cast<const f32x4*>(vb + C + c);
+        }
     }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
-    for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
-        const long long o = r * C + c;
-        f32x4 dp = *reinterpret_cast<const f32x4*>(dout + o);
-        if (relu) relu_gate<MASKED>(dp, out, mask, o);
-        const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
-        s1 += dp;
-        s2 += dp * ah;
-        if (RES == 2) s3 += dp * ((*reinterpret_cast<const f32x4*>(b + o) - mean_b) * rstd_b);
-    }
-    float* mine = red + (long long)threadIdx.y * 3 * C;
-    *reinterpret_cast<f32x4*>(mine + c) = s1;
-    *reinterpret_cast<f32x4*>(mine + C + c) = s2;
-    *reinterpret_cast<f32x4*>(mine + 2 * C + c) = s3;
+    if (cok)
+        for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
+            const long long o = r * C + c;
+            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + o);
+            if (relu) relu_gate<MASKED>(dp, out, mask, o);
+            const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
+            s1 += dp;
+            s2 += dp * ah;
+            if (RES == 2) s3 += dp * ((*reinterpret_cast<const f32x4*>(b + o) - mean_b) * rstd_b);
+        }
+    float* mine = red + (long long)threadIdx.y * 3 * Cw;
+    *reinterpret_cast<f32x4*>(mine + cl) = s1;
+    *reinterpret_cast<f32x4*>(mine + Cw + cl) = s2;
+    *reinterpret_cast<f32x4*>(mine + 2 * Cw + cl) = s3;
     __syncthreads();
     const int nthreads = blockDim.x * blockDim.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    for (int i = t; i < 3 * C; i += nthreads) {
+    for (int i = t; i < 3 * Cw; i += nthreads) {
+        const int which = i / Cw, ci = i - which * Cw;
         float s = 0.f;
-        for (int y = 0; y < (int)blockDim.y; ++y) s += red[y * 3 * C + i];
-        partials[(long long)blockIdx.x * 3 * C + i] = s;
+        for (int y = 0; y < (int)blockDim.y; ++y) s += red[y * 3 * Cw + i];
+        if (c0 + ci < C) partials[(long long)blockIdx.x * 3 * C + which * C + c0 + ci] = s;
     }
 }
 
@@ -327,8 +333,9 @@ extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, c
 }
 
 static int reduce_block(int C, dim3* blk) {
-    const int cx = C / 4;
-    if (cx < 1 || cx > 256) return -1;
+    int cx = C / 4;
+    if (cx < 1) return -1;
+    if (cx > 256) cx = 256;                    // wider tensors: 1024-channel windows on gridDim.y
     int ny = 256 / cx;
     if (ny > 32) ny = 32;
     *blk = dim3((unsigned)cx, (unsigned)ny);
@@ -345,12 +352,12 @@ extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const
     FGCN_REQUIRE(n_tiles == fgcn_elem_tiles(rows), FGCN_E_BADARG, "bn_act_bwd_reduce: n_tiles must be %d",
                  fgcn_elem_tiles(rows));
     dim3 blk;
-    FGCN_REQUIRE(reduce_block(C, &blk) == 0, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d unsupported (4..1024)", C);
-    const size_t lds = (size_t)blk.y * 3 * C * sizeof(float);
+    FGCN_REQUIRE(reduce_block(C, &blk) == 0, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d unsupported", C);
+    const size_t lds = (size_t)blk.y * 3 * blk.x * 4 * sizeof(float);
     FGCN_REQUIRE(lds <= 64 * 1024, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d needs too much LDS", C);
     const long long rpt = rows_per_tile_for(rows);
     hipStream_t s = (hipStream_t)stream;
-    dim3 g((unsigned)n_tiles);
+    dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
 #define FGCN_BN_RED(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
                        partials, rows, rpt, C, relu)

@@ -102,10 +102,11 @@ class _GraphConv1dFunction(torch.autograd.Function):
         dx = None
         g_res_w = g_res_b = g_res_g = g_res_beta = None
         if mod.res_kind == "none":
-            d_main, _, _ = ops.bn_act_bwd(d_out, out, out, vec_id, None, None, res_mode=0, train=False, sign_mask=mask)
+            d_main, _, _ = ops.bn_act_bwd(d_out, out, out, vec_id, None, None, res_mode=0, train=False, sign_mask=mask, need_sums=False)
         elif mod.res_kind == "identity":
             dx = torch.empty_like(x)
-            d_main, _, _ = ops.bn_act_bwd(d_out, out, out, vec_id, x, None, res_mode=1, train=False, db=dx, sign_mask=mask)
+            d_main, _, _ = ops.bn_act_bwd(d_out, out, out, vec_id, x, None, res_mode=1, train=False, db=dx, sign_mask=mask,
+                                          need_sums=False)
         else:
             d_main = torch.empty((B, V, O), device=dev, dtype=torch.float32)
             dr, _, sums = ops.bn_act_bwd(d_out, out, r, vec_r, out, None, res_mode=1, train=train, db=d_main, sign_mask=mask)

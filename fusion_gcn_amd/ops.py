@@ -514,22 +514,25 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
 def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor, vec_a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
-               sign_mask: Optional[torch.Tensor] = None):
+               sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
-    The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``."""
+    The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
+    ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass."""
     ensure_device()
     _chk(dout, "bn_act_bwd.dout"), _chk(a, "bn_act_bwd.a")
     C = a.shape[-1]
     rows = a.numel() // C
     lib = _lib.load()
-    tiles = lib.fgcn_elem_tiles(rows)
-    partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
     if sign_mask is not None and (sign_mask.dtype != torch.uint8 or sign_mask.numel() * 8 != a.numel()):
         raise _lib.FgcnError("bn_act_bwd: sign_mask must be the uint8 bit image of bn_act (numel/8 bytes)")
-    check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
-                                     tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
-    sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
-    reduce_sum(partials.view(tiles, -1), sums.view(-1))
+    sums = None
+    if need_sums or train:
+        tiles = lib.fgcn_elem_tiles(rows)
+        partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
+        check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
+                                         tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
+        sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
+        reduce_sum(partials.view(tiles, -1), sums.view(-1))
     da = torch.empty_like(a)
     if res_mode != 0 and db is None:
         db = torch.empty_like(a)
@@ -543,6 +546,8 @@ def col_sum(x: torch.Tensor, C: int, coff: int = 0) -> torch.Tensor:
     """Per-channel sum over all rows of x[..., coff:coff+C] -> (C,)."""
     ensure_device()
     _chk(x, "col_sum.x")
+    if C > 1024:            # the kernel's block covers up to 1024 channels: wider tensors in channel windows
+        return torch.cat([col_sum(x, min(1024, C - c0), coff + c0) for c0 in range(0, C, 1024)])
     ld = x.shape[-1]
     rows = x.numel() // ld
     lib = _lib.load()

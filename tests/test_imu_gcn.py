@@ -94,7 +94,7 @@ def test_agcn_variant_and_other_modes_fail_loudly():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["value48", "sensor16", "value240", "value1956"])
+@pytest.mark.parametrize("tag", ["value48", "sensor16", "value240", "value1956", "wide2048"])
 def test_hip_imu_gcn_matches_the_oracle(tag):
     dev = torch.device("cuda:0")
     if tag in CASES:
@@ -102,6 +102,9 @@ def test_hip_imu_gcn_matches_the_oracle(tag):
     elif tag == "value240":   # V = 240 nodes (not a multiple of 64: padded contraction), all three residual kinds, widths to 128
         shape, classes, batch = (40, 6), 27, 4
         kw = dict(gc_model="stgcn", graph_node_format="node_per_value", num_layers=5, inner_feature_dim=64)
+    elif tag == "wide2048":   # the config's widths: a Conv1d + BatchNorm residual into 2048 channels (1024-channel windows)
+        shape, classes, batch = (8, 6), 27, 2
+        kw = dict(gc_model="stgcn", graph_node_format="node_per_value", num_layers=4, inner_feature_dim=1024)
     else:                     # the UTD-MHAD config's node count (326 x 6 = 1956), narrow
         shape, classes, batch = (326, 6), 27, 2
         kw = dict(gc_model="stgcn", graph_node_format="node_per_value", num_layers=3, inner_feature_dim=32)

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Step time of the IMU graph model of config/utd-mhad/imu/imu_gcn_v1_stgcn.yaml (mode imu_gcn, gc_model stgcn, node_per_value,
+inner_feature_dim 512, 10 layers, batch 8; UTD-MHAD inertial sequences resampled to 326 x 6 -> 1956 nodes): fwd+bwd on one
+MI355X in the math modes, with the algorithmic FLOPs, next to the float32 CPU oracle on a 2-sample slice."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=326)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--cpu", action="store_true", help="also time the oracle on the host cores (2 samples)")
+    args = ap.parse_args()
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.models.mmargcn.mmargcn import Model
+    dev = torch.device("cuda:0")
+    shape, classes = (args.frames, 6), 27
+    torch.manual_seed(1)
+    model = Model({"inertial": shape}, classes, None, mode="imu_gcn", gc_model="stgcn", graph_node_format="node_per_value",
+                  inner_feature_dim=args.width, num_layers=args.layers).to(dev).train()
+    x = torch.randn(args.batch, *shape, device=dev)
+    y = torch.randint(0, classes, (args.batch,), device=dev)
+    V = shape[0] * shape[1]
+    flops, f = 0.0, 1
+    for layer in model._model.gcn.layers:
+        o = layer.out_features
+        flops += 2.0 * args.batch * V * f * o * (2 if layer.res_kind == "conv" else 1) + 2.0 * args.batch * o * V * V
+        f = o
+    flops *= 3
+    out = {"nodes": V, "batch": args.batch, "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
+    for mode in ("f32", "bf16x3", "bf16"):
+        with ops.math_mode(mode):
+            for _ in range(2):
+                model.zero_grad(set_to_none=True)
+                F.cross_entropy(model(x), y).backward()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.zero_grad(set_to_none=True)
+                loss = F.cross_entropy(model(x), y)
+                loss.backward()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+        out[mode] = {"ms_per_step": round(1e3 * dt, 2), "samples_per_s": round(args.batch / dt, 1),
+                     "tflops": round(flops / dt / 1e12, 1), "loss": round(float(loss.detach()), 5)}
+    if args.cpu:
+        from oracle import imu_gcn_oracle as O
+        sd = {k.replace("_model.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
+        xs, ys = x[:2].cpu(), y[:2].cpu()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        O.loss_and_grads(xs, ys, sd)
+        t0 = time.perf_counter()
+        O.loss_and_grads(xs, ys, sd)
+        dt = time.perf_counter() - t0
+        out["cpu_oracle"] = {"samples_per_s": round(2 / dt, 3), "threads": torch.get_num_threads(), "sample": "2 samples, 1 iteration"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
