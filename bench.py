@@ -213,6 +213,8 @@ def main():
                     help="also run the fused parameter update (fusion_gcn_amd.optim.FlatOptimizer: ADAM weight_decay 0.01 as "
                          "config/utd-mhad/skeleton/agcn.yaml, or SGD momentum 0.9 nesterov) inside every timed step; the "
                          "headline metric is fwd+bwd, so the default leaves it out")
+    ap.add_argument("--agg-wgrad-max-cout", type=int, default=None,
+                    help="A/B only: widest block whose conv_d weight gradient uses the fused aggregation kernel (block.FUSED_AGG_WGRAD_MAX_COUT)")
     ap.add_argument("--keep-packed", action="store_true",
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
@@ -253,6 +255,8 @@ def main():
         print(json.dumps({"kernel": MATH_KERNEL[args.math].format(nt=4, nt2=2) + " forward, 256 channels", **kern[0]}), flush=True)
         return
     from fusion_gcn_amd import block as _block
+    if args.agg_wgrad_max_cout is not None:
+        _block.FUSED_AGG_WGRAD_MAX_COUT[args.math] = args.agg_wgrad_max_cout
     _block.WGRAD_SIDE_STREAM = args.wgrad_stream != "main"
     _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
