@@ -24,6 +24,9 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 import models.mmargcn.imu_feature_models as ref_imu  # noqa: E402  (reference)
+import models.mmargcn.mmargcn as ref_mm  # noqa: E402  (reference)
+from util.graph import Graph  # noqa: E402  (reference)
+from datasets.utd_mhad import constants as utd  # noqa: E402  (reference)
 
 from oracle import filler  # noqa: E402
 
@@ -34,6 +37,9 @@ CASES = {   # tag: (data_shape, classes, batch, model kwargs)
                                     inner_feature_dim=8, adjacency_normalization="row", num_temporal_back_connections=2,
                                     inter_signal_back_connections=True)),
 }
+
+
+LATE_KW = dict(gc_model="stgcn", graph_node_format="node_per_sensor", num_signals=2, num_layers=4, inner_feature_dim=64)
 
 
 def main():
@@ -65,6 +71,27 @@ def main():
                 store[f"{tag}.after.{k}"] = v.numpy().copy()
         store[f"{tag}.keys"] = np.array(sorted(sd0))
         store[f"{tag}.adj"] = sd0["gcn.gc1.adj"].numpy()
+    # ---- mode skeleton_imu_gcn_late_fusion (late_fusion_models.py:45-75) with the stgcn IMU branch ---------------------------
+    tag, classes, batch = "late", 27, 3
+    shapes = {"skeleton": (1, 16, 20, 3), "inertial": (8, 6)}
+    model = ref_mm.Model(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint),
+                         mode="skeleton_imu_gcn_late_fusion", **LATE_KW).double()
+    filler.fill_state_dict(model.state_dict(), skip=("adj", "adj_a", "A"), rename=lambda k: k.replace("_model.", ""))
+    x = {"skeleton": torch.from_numpy(filler.skeleton_input("x.late.skeleton", (batch, *shapes["skeleton"]))).double(),
+         "inertial": torch.from_numpy(filler.bellish("x.late.inertial", (batch, *shapes["inertial"]), scale=0.5)).double()}
+    labels = torch.from_numpy(filler.uniform("y.late", (batch,), 0, classes).astype(np.int64))
+    store["late.keys"] = np.array(sorted(k.replace("_model.", "") for k in model.state_dict()))
+    model.eval()
+    store["late.eval.logits"] = model(x).detach().numpy()
+    model.train()
+    logits = model(x)
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    store["late.labels"] = labels.numpy()
+    store["late.train.logits"] = logits.detach().numpy()
+    store["late.train.loss"] = loss.detach().numpy()
+    for name, p in model.named_parameters():
+        store[f"late.gl2.{name.replace('_model.', '')}"] = p.grad.norm().numpy()
     store["torch_version"] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(OUT, "imu_gcn.npz"), **store)
     print("wrote", os.path.join(OUT, "imu_gcn.npz"), os.path.getsize(os.path.join(OUT, "imu_gcn.npz")), "bytes")
