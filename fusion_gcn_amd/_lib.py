@@ -89,6 +89,8 @@ SIGNATURES = {
     "fgcn_spatial_bwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "fgcn_spatial_bwd_chunks": (_I, [_I, _I]),
     "fgcn_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fgcn_row_softmax_fwd": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _P]),
+    "fgcn_row_softmax_bwd": (_I, [_P, _P, _P, _LL, _I, _I, _F, _P]),
     "fgcn_optim_step": (_I, [_P, _P, _P, _P, _LL, _I, _F, _F, _F, _F, _F, _F, _F, _F, _I, _LL, _P]),
 }
 

@@ -465,3 +465,72 @@ extern "C" int fgcn_transpose(const float* in, float* out, int B, int R, int C, 
     hipLaunchKernelGGL(fgcn::transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C, ld_in, ld_out);
     return fgcn::launch_status("transpose");
 }
+
+// ---- row softmax of the transposed joint affinity on large graphs (AGCNGraphConvolution, graph_convolution.py:95-100) -------------
+// The reference takes softmax over dim -2 of S = theta^T phi / ic  (N, V, V); the host forms S^T (row w, column v), so the
+// softmax runs along the contiguous axis: one wave per row, V up to a few thousand.
+//   fwd:  c = softmax(scale * st[row][0:V]);  a = c + adj_t[(row % (K*V))][0:V];  columns [V, ld) of c and a are zero-filled
+//   bwd:  ds = scale * c .* (da - sum_v c .* da)
+namespace fgcn {
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const float* st, const float* adj_t, float* c_out, float* a_out,
+                                                              long long rows, int V, int ld, int KV, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* s = st + row * ld;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, s[v] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += expf(s[v] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    const float* ad = adj_t + (row % KV) * (long long)ld;
+    for (int v = lane; v < ld; v += 64) {
+        const float c = v < V ? expf(s[v] * scale - mx) * inv : 0.f;
+        c_out[row * ld + v] = c;
+        a_out[row * ld + v] = v < V ? c + ad[v] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* da, const float* c, float* ds, long long rows, int V,
+                                                              int ld, float scale) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* d = da + row * ld;
+    const float* cc = c + row * ld;
+    float dot = 0.f;
+    for (int v = lane; v < V; v += 64) dot += cc[v] * d[v];
+    dot = wave_sum(dot);
+    for (int v = lane; v < ld; v += 64) ds[row * ld + v] = v < V ? scale * cc[v] * (d[v] - dot) : 0.f;
+}
+}  // namespace fgcn
+
+extern "C" int fgcn_row_softmax_fwd(const float* st, const float* adj_t, float* c_out, float* a_out, long long rows, int V,
+                                    int ld, int KV, float scale, void* stream) {
+    FGCN_REQUIRE(st && adj_t && c_out && a_out && rows > 0 && V > 0 && ld >= V && KV > 0, FGCN_E_BADARG,
+                 "row_softmax_fwd: bad argument (rows=%lld V=%d ld=%d)", rows, V, ld);
+    hipLaunchKernelGGL(fgcn::row_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, st, adj_t,
+                       c_out, a_out, rows, V, ld, KV, scale);
+    return fgcn::launch_status("row_softmax_fwd");
+}
+
+extern "C" int fgcn_row_softmax_bwd(const float* da, const float* c, float* ds, long long rows, int V, int ld, float scale,
+                                    void* stream) {
+    FGCN_REQUIRE(da && c && ds && rows > 0 && V > 0 && ld >= V, FGCN_E_BADARG, "row_softmax_bwd: bad argument");
+    hipLaunchKernelGGL(fgcn::row_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, da, c, ds,
+                       rows, V, ld, scale);
+    return fgcn::launch_status("row_softmax_bwd");
+}

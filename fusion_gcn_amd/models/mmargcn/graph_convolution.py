@@ -11,8 +11,8 @@ points plus a transpose (include/fgcn.h):
     (Vp x Vp) weight by the same row GEMM (``B*O`` rows), then transposed back;
   * residual (identity, or Conv1d + BatchNorm1d with batch statistics from the GEMM epilogue) + ReLU = ``fgcn_bn_act``.
 
-``AGCNGraphConvolution`` (:56-113, per-sample V x V attention for V in the hundreds) needs batched V-tiled kernels that are
-not built yet and raises.
+``AGCNGraphConvolution`` (:56-113: per-sample V x V attention) reuses the same pieces with per-sample matrices as the GEMM
+weight and a row softmax on the transposed scores (``fgcn_row_softmax_*``); see ``_AgcnConv1dFunction``.
 """
 from __future__ import annotations
 
@@ -190,8 +190,186 @@ class STGCNGraphConvolution(nn.Module):
             res[1].weight if res is not None else None, res[1].bias if res is not None else None)
 
 
+class _AgcnConv1dFunction(torch.autograd.Function):
+    """AGCNGraphConvolution.forward (graph_convolution.py:91-113) on node-major x (B, V, Fp), V % 4 == 0.
+
+    Per-sample V x V products are row GEMMs with one sample's matrix as the weight (3 B small launches per product: the
+    graphs of this model have hundreds of nodes and batches of 8-64).  The scores are formed TRANSPOSED,
+    S^T_k[b][w][v] = phi_k[w] . theta_k[v] / ic, so the reference's softmax over dim -2 runs along the contiguous axis
+    (fgcn_row_softmax_*) and A^^T_k = C^T_k + (adj_a + adj_b)_k^T is directly the row operand of the aggregation
+    agg_k[b] = A^^T_k[b] . x[b]."""
+
+    @staticmethod
+    def forward(ctx, x, mod, train, adj_b, *params):
+        B, V, Fp = x.shape
+        O, ic, Fin = mod.out_features, mod.inter_c, mod.in_features
+        dev = x.device
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)      # noqa: E731
+        P = dict(zip(mod._param_names(), params))
+        with torch.no_grad():
+            rows = []
+            for k in range(3):
+                rows += [P[f"conv_a.{k}.weight"].view(ic, Fin), P[f"conv_b.{k}.weight"].view(ic, Fin)]
+            w_emb = torch.zeros((1, Fp, 6 * ic), device=dev, dtype=torch.float32)
+            w_emb[0, :Fin] = torch.cat(rows, 0).t()                                   # [th0 ph0 th1 ph1 th2 ph2]
+            b_emb = torch.cat([P[f"conv_{g}.{k}.bias"] for k in range(3) for g in "ab"]).contiguous()
+            w_d = torch.zeros((1, 3 * Fp, O), device=dev, dtype=torch.float32)
+            for k in range(3):
+                w_d[0, k * Fp:k * Fp + Fin] = P[f"conv_d.{k}.weight"].view(O, Fin).t()
+            b_d = (P["conv_d.0.bias"] + P["conv_d.1.bias"] + P["conv_d.2.bias"]).contiguous()
+            adj_t = (mod.adj_a + adj_b).transpose(1, 2).contiguous()                  # (3, V(w), V(v))
+        emb = new(B, V, 6 * ic)
+        ops.rows_gemm(_rows4(x), w_emb, _rows4(emb), K=Fp, N=6 * ic, bias=b_emb)
+        tp = emb.view(B, V, 6, ic).permute(2, 0, 1, 3).contiguous()                    # (6, B, V, ic): theta_k = tp[2k], phi_k = tp[2k+1]
+        th_fm = ops.transpose(tp[0::2].reshape(3 * B, V, ic))                          # (3B, ic, V): theta_k[b]^T as a (K = c, N = v) weight
+        st = new(B, 3, V, V)
+        for k in range(3):
+            for b in range(B):
+                ops.rows_gemm(tp[2 * k + 1, b].view(1, V, 1, ic), th_fm[k * B + b].view(1, ic, V), st[b, k].view(1, V, 1, V),
+                              K=ic, N=V)
+        c_t, a_t = ops.row_softmax_fwd(st, adj_t, V, 1.0 / ic)
+        agg = new(B, V, 3 * Fp)
+        for k in range(3):
+            for b in range(B):
+                ops.rows_gemm(a_t[b, k].view(1, V, 1, V), x[b].view(1, V, Fp), agg[b].view(1, V, 1, 3 * Fp), K=V, N=Fp,
+                              out_coff=k * Fp)
+        y = new(B, V, O)
+        part = ops.rows_gemm(_rows4(agg), w_d, _rows4(y), K=3 * Fp, N=O, bias=b_d, stats=train)
+        vec_y = (ops.bn_finalize(part, B * V, P["bn.weight"], P["bn.bias"], mod.bn.running_mean, mod.bn.running_var) if train
+                 else ops.bn_eval_coeffs(P["bn.weight"], P["bn.bias"], mod.bn.running_mean, mod.bn.running_var))
+        d = vec_d = w_down = None
+        if mod.has_down:
+            with torch.no_grad():
+                w_down = torch.zeros((1, Fp, O), device=dev, dtype=torch.float32)
+                w_down[0, :Fin] = P["down.0.weight"].view(O, Fin).t()
+            d = new(B, V, O)
+            part = ops.rows_gemm(_rows4(x), w_down, _rows4(d), K=Fp, N=O, bias=P["down.0.bias"], stats=train)
+            bn_d = mod.down[1]
+            vec_d = (ops.bn_finalize(part, B * V, P["down.1.weight"], P["down.1.bias"], bn_d.running_mean, bn_d.running_var)
+                     if train else ops.bn_eval_coeffs(P["down.1.weight"], P["down.1.bias"], bn_d.running_mean, bn_d.running_var))
+            out, mask = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True)
+        else:
+            out, mask = ops.bn_act(y, vec_y, x, None, relu=True, sign_mask=True)
+        if train:
+            mod.bn.num_batches_tracked += 1
+            if mod.has_down:
+                mod.down[1].num_batches_tracked += 1
+        ctx.mod, ctx.train = mod, train
+        ctx.packed = (w_emb, w_d, w_down)
+        ctx.save_for_backward(x, tp, c_t, a_t, agg, y, vec_y, d, vec_d, out, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, tp, c_t, a_t, agg, y, vec_y, d, vec_d, out, mask = ctx.saved_tensors
+        mod, train = ctx.mod, ctx.train
+        w_emb, w_d, w_down = ctx.packed
+        B, V, Fp = x.shape
+        O, ic, Fin = mod.out_features, mod.inter_c, mod.in_features
+        dev = x.device
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)      # noqa: E731
+        zeros = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)             # noqa: E731
+        G = {}
+        d_out = d_out.contiguous()
+        dx = new(B, V, Fp)
+        if mod.has_down:
+            dy, dd, sums = ops.bn_act_bwd(d_out, out, y, vec_y, d, vec_d, res_mode=2, train=train, sign_mask=mask)
+            G["down.1.weight"], G["down.1.bias"] = sums[2], sums[0].clone()
+            ops.rows_gemm(_rows4(dd), w_down[0].t().contiguous().unsqueeze(0), _rows4(dx), K=O, N=Fp)
+            G["down.0.weight"] = ops.rows_wgrad(_rows4(x), _rows4(dd), K=Fp, N=O, conv_param=(1, Fin)).view(O, Fin, 1)
+            G["down.0.bias"] = zeros(O) if train else ops.col_sum(_rows4(dd), O)
+        else:
+            dy, _, sums = ops.bn_act_bwd(d_out, out, y, vec_y, x, None, res_mode=1, train=train, db=dx, sign_mask=mask)
+        G["bn.weight"], G["bn.bias"] = sums[1], sums[0]
+        # conv_d: weights, bias (in front of a BatchNorm: exactly zero in train mode), and dagg_k = dy . Wd_k
+        gw = ops.rows_wgrad(_rows4(agg), _rows4(dy), K=3 * Fp, N=O, conv_param=(3, Fin))       # (3, O, Fin, 1, 1)
+        dbias = None if train else ops.col_sum(_rows4(dy), O)
+        dagg = new(3, B, V, Fp)
+        for k in range(3):
+            G[f"conv_d.{k}.weight"] = gw[k].view(O, Fin, 1)
+            G[f"conv_d.{k}.bias"] = zeros(O) if train else (dbias if k == 0 else dbias.clone())
+            wk_t = w_d[0, k * Fp:(k + 1) * Fp].t().contiguous().unsqueeze(0)                     # (1, O, Fp)
+            ops.rows_gemm(_rows4(dy), wk_t, _rows4(dagg[k]), K=O, N=Fp)
+        # through the aggregation: dx += A^_k . dagg_k,  dA^^T_k = dagg_k . x^T
+        a_n = ops.transpose(a_t.view(B * 3, V, V))                                                # (3B, V(v), V(w)): A^_k[b]
+        x_fm = ops.transpose(x)                                                                   # (B, Fp, V)
+        da_t = new(B, 3, V, V)
+        for k in range(3):
+            for b in range(B):
+                ops.rows_gemm(a_n[b * 3 + k].view(1, V, 1, V), dagg[k, b].view(1, V, Fp), dx[b].view(1, V, 1, Fp), K=V, N=Fp,
+                              accumulate=True)
+                ops.rows_gemm(dagg[k, b].view(1, V, 1, Fp), x_fm[b].view(1, Fp, V), da_t[b, k].view(1, V, 1, V), K=Fp, N=V)
+        g_adj_t = new(3, V, V)
+        ops.reduce_sum(da_t.view(B, -1), g_adj_t.view(-1))
+        G["adj_b"] = g_adj_t.transpose(1, 2).contiguous()
+        # softmax, then the embeddings: dphi_k = dS^T_k . theta_k,  dtheta_k = dS_k . phi_k
+        ds_t = ops.row_softmax_bwd(da_t, c_t, V, 1.0 / ic)
+        ds_n = ops.transpose(ds_t.view(B * 3, V, V))                                              # (3B, V(v), V(w))
+        dtp = new(6, B, V, ic)
+        for k in range(3):
+            for b in range(B):
+                ops.rows_gemm(ds_t[b, k].view(1, V, 1, V), tp[2 * k, b].view(1, V, ic), dtp[2 * k + 1, b].view(1, V, 1, ic), K=V, N=ic)
+                ops.rows_gemm(ds_n[b * 3 + k].view(1, V, 1, V), tp[2 * k + 1, b].view(1, V, ic), dtp[2 * k, b].view(1, V, 1, ic), K=V, N=ic)
+        demb = dtp.permute(1, 2, 0, 3).reshape(B, V, 6 * ic).contiguous()
+        ops.rows_gemm(_rows4(demb), w_emb[0].t().contiguous().unsqueeze(0), _rows4(dx), K=6 * ic, N=Fp, accumulate=True)
+        gw = ops.rows_wgrad(_rows4(x), _rows4(demb), K=Fp, N=6 * ic, conv_param=(1, Fin))        # (6ic, Fin, 1, 1)
+        gb = ops.col_sum(_rows4(demb), 6 * ic)
+        for k in range(3):
+            for j, g in enumerate("ab"):
+                lo = (2 * k + j) * ic
+                G[f"conv_{g}.{k}.weight"] = gw[lo:lo + ic].reshape(ic, Fin, 1)
+                G[f"conv_{g}.{k}.bias"] = gb[lo:lo + ic]
+        grads = [G[n] for n in mod._param_names()]
+        return (dx if ctx.needs_input_grad[0] else None, None, None, G["adj_b"], *grads)
+
+
 class AGCNGraphConvolution(nn.Module):
+    """Same constructor, parameters, initialisation and state-dict keys as the reference class (graph_convolution.py:56-113);
+    ``forward`` takes and returns the node-major image (B, V, Fp) like ``STGCNGraphConvolution``."""
+
     def __init__(self, in_features, out_features, adj, **kwargs):
         super().__init__()
-        raise NotImplementedError("AGCNGraphConvolution (per-sample V x V attention on IMU graphs) is not built yet: "
-                                  "use gc_model='stgcn' (SURVEY.md section 8 row f1, DESIGN.md section 0)")
+        import numpy as np
+        from .agcn import bn_init, conv_branch_init, conv_init
+        coff_embedding = kwargs.get("coff_embedding", 4)
+        num_subset = kwargs.get("num_subset", 3)
+        if num_subset != 3 or out_features % (4 * coff_embedding) or adj.shape[-1] % 4:
+            raise ValueError("HIP AGCN graph convolution: 3 subsets, out_features % 16 == 0 and a node count % 4 == 0 "
+                             f"(got {num_subset}, {out_features}, {adj.shape[-1]})")
+        self.in_features, self.out_features = in_features, out_features
+        self.inter_c = out_features // coff_embedding
+        self.num_subset = num_subset
+        self.adj_b = nn.Parameter(torch.from_numpy(np.asarray(adj).astype(np.float32)))
+        nn.init.constant_(self.adj_b, 1e-6)
+        self.register_buffer("adj_a", torch.from_numpy(np.asarray(adj).astype(np.float32)))
+        self.conv_a, self.conv_b, self.conv_d = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(num_subset):
+            self.conv_a.append(nn.Conv1d(in_features, self.inter_c, 1))
+            self.conv_b.append(nn.Conv1d(in_features, self.inter_c, 1))
+            self.conv_d.append(nn.Conv1d(in_features, out_features, 1))
+        self.has_down = in_features != out_features
+        if self.has_down:
+            self.down = nn.Sequential(nn.Conv1d(in_features, out_features, 1), nn.BatchNorm1d(out_features))
+        self.bn = nn.BatchNorm1d(out_features)
+        for m in self.modules():
+            if isinstance(m, nn.Conv1d):
+                conv_init(m)
+            elif isinstance(m, nn.BatchNorm1d):
+                bn_init(m, 1)
+        bn_init(self.bn, 1e-6)
+        for i in range(num_subset):
+            conv_branch_init(self.conv_d[i], num_subset)
+
+    def _param_names(self):
+        names = []
+        for grp in ("conv_a", "conv_b", "conv_d"):
+            for k in range(3):
+                names += [f"{grp}.{k}.weight", f"{grp}.{k}.bias"]
+        names += ["bn.weight", "bn.bias"]
+        if self.has_down:
+            names += ["down.0.weight", "down.0.bias", "down.1.weight", "down.1.bias"]
+        return names
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        params = dict(self.named_parameters())
+        return _AgcnConv1dFunction.apply(x, self, self.training, self.adj_b, *[params[n] for n in self._param_names()])

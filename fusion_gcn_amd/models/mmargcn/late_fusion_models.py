@@ -1,7 +1,6 @@
 """``mode: skeleton_imu_gcn_late_fusion`` -- the skeleton AGCN and the IMU graph model side by side, their pooled features
 fused (concatenate / sum / ...) and classified by one ``fc`` (reference torch_src/models/mmargcn/late_fusion_models.py:45-75).
-Both branches run on libfgcn kernels (agcn.Model; ImuGCN with ``gc_model: stgcn`` -- the ``agcn`` graph convolution of the IMU
-branch is not built yet and raises); the fusion is a torch reduction over two (N, C) tensors, ``fc`` the row GEMM."""
+Both branches run on libfgcn kernels (agcn.Model; ImuGCN with either graph convolution); the fusion is a torch reduction over two (N, C) tensors, ``fc`` the row GEMM."""
 import torch.nn as nn
 
 from ...block import LinearFunction

@@ -1,7 +1,6 @@
 """``model: mmargcn`` — mode dispatcher (reference torch_src/models/mmargcn/mmargcn.py:9-57).
 
-Only the modes on the AGCN / ST-GCN hot path -- plus ``imu_gcn`` and ``skeleton_imu_gcn_late_fusion`` (SURVEY.md section 8 row f1;
-their ``gc_model: stgcn`` variant) --
+Only the modes on the AGCN / ST-GCN hot path -- plus ``imu_gcn`` and ``skeleton_imu_gcn_late_fusion`` --
 are backed by HIP kernels; the reference's other 13 modes (RGB encoders, signal images, late fusion) are out of scope
  and raise with a clear message instead of silently running something else.
 """

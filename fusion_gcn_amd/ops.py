@@ -636,3 +636,27 @@ def transpose_into(x: torch.Tensor, rows: int) -> torch.Tensor:
     # out[b][r][c] = x[b][c][r]: a transpose of the (C x rows) image with input row stride ld
     check(_lib.load().fgcn_transpose(_p(x), _p(out), B, C, rows, ld, C, _stream()), "fgcn_transpose")
     return out
+
+
+def row_softmax_fwd(st: torch.Tensor, adj_t: torch.Tensor, V: int, scale: float):
+    """st (B, K, V, ld) transposed scores -> (c, a): c = softmax over the last axis of scale*st[..., :V], a = c + adj_t (K, V, ld);
+    padding columns zero."""
+    ensure_device()
+    _chk(st, "row_softmax_fwd.st"), _chk(adj_t, "row_softmax_fwd.adj_t")
+    B, K, Vr, ld = st.shape
+    if Vr != V or tuple(adj_t.shape) != (K, V, ld):
+        raise _lib.FgcnError(f"row_softmax_fwd: shape mismatch st={tuple(st.shape)} adj_t={tuple(adj_t.shape)}")
+    c, a = torch.empty_like(st), torch.empty_like(st)
+    check(_lib.load().fgcn_row_softmax_fwd(_p(st), _p(adj_t), _p(c), _p(a), B * K * V, V, ld, K * V, float(scale), _stream()),
+          "fgcn_row_softmax_fwd")
+    return c, a
+
+
+def row_softmax_bwd(da: torch.Tensor, c: torch.Tensor, V: int, scale: float) -> torch.Tensor:
+    ensure_device()
+    _chk(da, "row_softmax_bwd.da"), _chk(c, "row_softmax_bwd.c")
+    ds = torch.empty_like(da)
+    rows = da.numel() // da.shape[-1]
+    check(_lib.load().fgcn_row_softmax_bwd(_p(da), _p(c), _p(ds), rows, V, da.shape[-1], float(scale), _stream()),
+          "fgcn_row_softmax_bwd")
+    return ds

@@ -318,6 +318,15 @@ int fgcn_spatial_bwd_chunks(int B, int T);
  * over feature-major rows with the V x V adjacency as the shared weight, residual + ReLU = fgcn_bn_act. */
 int fgcn_transpose(const float* in, float* out, int B, int R, int C, int ld_in, int ld_out, void* stream);
 
+/* Softmax of AGCNGraphConvolution's attention (graph_convolution.py:95-100: softmax over dim -2 of theta^T phi / ic, then
+ * + adj[i]) on the TRANSPOSED scores st[row = (b, k, w)][v], so that it runs along the contiguous axis (V up to thousands):
+ *     c = softmax_v(scale * st[row][0:V]);   a = c + adj_t[row % KV][0:V]   (adj_t: float[K*V][ld] = (adj_a + adj_b)^T per subset)
+ *     backward: ds = scale * c .* (da - sum_v c .* da).
+ * Rows have stride ld >= V; the columns [V, ld) of every output row are zero-filled. */
+int fgcn_row_softmax_fwd(const float* st, const float* adj_t, float* c_out, float* a_out, long long rows, int V, int ld,
+                         int KV, float scale, void* stream);
+int fgcn_row_softmax_bwd(const float* da, const float* c, float* ds, long long rows, int V, int ld, float scale, void* stream);
+
 /* ---- the step after the path: parameter update over flat buffers ------------------- */
 /* One launch applies torch.optim's update to every trainable value of the model (reference: create_optimizer,
  * torch_src/session_helper.py:80-84, optimizer.step() in session/session.py:176-183):

@@ -36,6 +36,10 @@ CASES = {   # tag: (data_shape, classes, batch, model kwargs)
     "sensor16": ((8, 6), 5, 4, dict(gc_model="stgcn", graph_node_format="node_per_sensor", num_signals=2, num_layers=4,
                                     inner_feature_dim=8, adjacency_normalization="row", num_temporal_back_connections=2,
                                     inter_signal_back_connections=True)),
+    "agcn_sensor16": ((8, 6), 5, 3, dict(gc_model="agcn", graph_node_format="node_per_sensor", num_signals=2, num_layers=4,
+                                         inner_feature_dim=16)),
+    "agcn_value48": ((8, 6), 7, 2, dict(gc_model="agcn", graph_node_format="node_per_value", num_layers=3, inner_feature_dim=16,
+                                        inter_signal_back_connections=True)),
 }
 
 
@@ -51,7 +55,7 @@ def main():
         store[f"adj.{tag}"] = ref_imu.build_imu_graph_adjacency(shape, sig, "stgcn", False, **kw).double().numpy()
     for tag, (shape, classes, batch, kw) in CASES.items():
         model = ref_imu.ImuGCN({"inertial": shape}, classes, **kw).double()
-        filler.fill_state_dict(model.state_dict(), skip=("adj",))
+        filler.fill_state_dict(model.state_dict(), skip=("adj", "adj_a"))
         x = torch.from_numpy(filler.bellish(f"x.{tag}", (batch, *shape), scale=0.5)).double()
         labels = torch.from_numpy(filler.uniform(f"y.{tag}", (batch,), 0, classes).astype(np.int64))
         sd0 = {k: v.clone() for k, v in model.state_dict().items()}
@@ -70,28 +74,29 @@ def main():
             if k.endswith(("running_mean", "running_var")):
                 store[f"{tag}.after.{k}"] = v.numpy().copy()
         store[f"{tag}.keys"] = np.array(sorted(sd0))
-        store[f"{tag}.adj"] = sd0["gcn.gc1.adj"].numpy()
-    # ---- mode skeleton_imu_gcn_late_fusion (late_fusion_models.py:45-75) with the stgcn IMU branch ---------------------------
-    tag, classes, batch = "late", 27, 3
-    shapes = {"skeleton": (1, 16, 20, 3), "inertial": (8, 6)}
-    model = ref_mm.Model(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint),
-                         mode="skeleton_imu_gcn_late_fusion", **LATE_KW).double()
-    filler.fill_state_dict(model.state_dict(), skip=("adj", "adj_a", "A"), rename=lambda k: k.replace("_model.", ""))
-    x = {"skeleton": torch.from_numpy(filler.skeleton_input("x.late.skeleton", (batch, *shapes["skeleton"]))).double(),
-         "inertial": torch.from_numpy(filler.bellish("x.late.inertial", (batch, *shapes["inertial"]), scale=0.5)).double()}
-    labels = torch.from_numpy(filler.uniform("y.late", (batch,), 0, classes).astype(np.int64))
-    store["late.keys"] = np.array(sorted(k.replace("_model.", "") for k in model.state_dict()))
-    model.eval()
-    store["late.eval.logits"] = model(x).detach().numpy()
-    model.train()
-    logits = model(x)
-    loss = F.cross_entropy(logits, labels)
-    loss.backward()
-    store["late.labels"] = labels.numpy()
-    store["late.train.logits"] = logits.detach().numpy()
-    store["late.train.loss"] = loss.detach().numpy()
-    for name, p in model.named_parameters():
-        store[f"late.gl2.{name.replace('_model.', '')}"] = p.grad.norm().numpy()
+        store[f"{tag}.adj"] = sd0["gcn.gc1.adj" if "gcn.gc1.adj" in sd0 else "gcn.gc1.adj_a"].numpy()
+    # ---- mode skeleton_imu_gcn_late_fusion (late_fusion_models.py:45-75), IMU branch stgcn / agcn ------------------------------
+    for tag, late_kw in (("late", LATE_KW), ("late_agcn", dict(LATE_KW, gc_model="agcn"))):
+        classes, batch = 27, 3
+        shapes = {"skeleton": (1, 16, 20, 3), "inertial": (8, 6)}
+        model = ref_mm.Model(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint),
+                             mode="skeleton_imu_gcn_late_fusion", **late_kw).double()
+        filler.fill_state_dict(model.state_dict(), skip=("adj", "adj_a", "A"), rename=lambda k: k.replace("_model.", ""))
+        x = {"skeleton": torch.from_numpy(filler.skeleton_input("x.late.skeleton", (batch, *shapes["skeleton"]))).double(),
+             "inertial": torch.from_numpy(filler.bellish("x.late.inertial", (batch, *shapes["inertial"]), scale=0.5)).double()}
+        labels = torch.from_numpy(filler.uniform("y.late", (batch,), 0, classes).astype(np.int64))
+        store[f"{tag}.keys"] = np.array(sorted(k.replace("_model.", "") for k in model.state_dict()))
+        model.eval()
+        store[f"{tag}.eval.logits"] = model(x).detach().numpy()
+        model.train()
+        logits = model(x)
+        loss = F.cross_entropy(logits, labels)
+        loss.backward()
+        store[f"{tag}.labels"] = labels.numpy()
+        store[f"{tag}.train.logits"] = logits.detach().numpy()
+        store[f"{tag}.train.loss"] = loss.detach().numpy()
+        for name, p in model.named_parameters():
+            store[f"{tag}.gl2.{name.replace('_model.', '')}"] = p.grad.norm().numpy()
     store["torch_version"] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(OUT, "imu_gcn.npz"), **store)
     print("wrote", os.path.join(OUT, "imu_gcn.npz"), os.path.getsize(os.path.join(OUT, "imu_gcn.npz")), "bytes")

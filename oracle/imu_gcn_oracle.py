@@ -63,6 +63,23 @@ def gcn_forward(x: Tensor, sd: Dict[str, Tensor], prefix: str = "gcn.", train: b
     b, f, v = x.shape
     h = _bn(torch.flatten(x, start_dim=1), sd, prefix + "bn.", train).reshape(b, f, v)
     i = 1
+    while f"{prefix}gc{i}.conv_a.0.weight" in sd:          # AGCNGraphConvolution layers (graph_convolution.py:91-113)
+        p = f"{prefix}gc{i}."
+        adj = (sd[p + "adj_a"] + sd[p + "adj_b"]).to(h.dtype)
+        y = None
+        for k in range(3):
+            a1 = F.conv1d(h, sd[f"{p}conv_a.{k}.weight"], sd[f"{p}conv_a.{k}.bias"]).permute(0, 2, 1)
+            a2 = F.conv1d(h, sd[f"{p}conv_b.{k}.weight"], sd[f"{p}conv_b.{k}.bias"])
+            a1 = torch.softmax(torch.matmul(a1, a2) / a1.size(-1), dim=-2) + adj[k]
+            z = F.conv1d(torch.matmul(h, a1), sd[f"{p}conv_d.{k}.weight"], sd[f"{p}conv_d.{k}.bias"])
+            y = z + y if y is not None else z
+        y = _bn(y, sd, p + "bn.", train)
+        if p + "down.0.weight" in sd:
+            y = y + _bn(F.conv1d(h, sd[p + "down.0.weight"], sd[p + "down.0.bias"]), sd, p + "down.1.", train)
+        else:
+            y = y + h
+        h = torch.relu(y)
+        i += 1
     while f"{prefix}gc{i}.conv.weight" in sd:
         p = f"{prefix}gc{i}."
         support = F.conv1d(h, sd[p + "conv.weight"], sd[p + "conv.bias"])
@@ -93,7 +110,7 @@ def imu_gcn_forward(x: Tensor, sd: Dict[str, Tensor], graph_node_format: str = "
 
 def loss_and_grads(x: Tensor, labels: Tensor, sd: Dict[str, Tensor], **kw):
     params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
-              if v.is_floating_point() and not k.endswith(("running_mean", "running_var", ".adj"))}
+              if v.is_floating_point() and not k.endswith(("running_mean", "running_var", ".adj", ".adj_a"))}
     full = dict(sd)
     full.update(params)
     logits = imu_gcn_forward(x, full, **kw)

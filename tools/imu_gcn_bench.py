@@ -22,7 +22,12 @@ def main():
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="also time the oracle on the host cores (2 samples)")
+    ap.add_argument("--late", action="store_true",
+                    help="instead: mode skeleton_imu_gcn_late_fusion as config/utd-mhad/skeleton+imu/late_fusion/*.yaml (skeleton "
+                         "(1, 128, 20, 3) + inertial (326, 6), gc_model agcn, node_per_sensor, num_signals 2, batch 8)")
     args = ap.parse_args()
+    if args.late:
+        return late(args)
     from fusion_gcn_amd import ops
     from fusion_gcn_amd.models.mmargcn.mmargcn import Model
     dev = torch.device("cuda:0")
@@ -65,6 +70,36 @@ def main():
         O.loss_and_grads(xs, ys, sd)
         dt = time.perf_counter() - t0
         out["cpu_oracle"] = {"samples_per_s": round(2 / dt, 3), "threads": torch.get_num_threads(), "sample": "2 samples, 1 iteration"}
+    print(json.dumps(out))
+
+
+def late(args):
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.mmargcn import Model
+    from fusion_gcn_amd.util import Graph
+    dev = torch.device("cuda:0")
+    shapes, classes = {"skeleton": (1, 128, 20, 3), "inertial": (args.frames, 6)}, 27
+    torch.manual_seed(1)
+    model = Model(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint), mode="skeleton_imu_gcn_late_fusion",
+                  graph_node_format="node_per_sensor", num_signals=2, gc_model="agcn", fusion="concatenate").to(dev).train()
+    x = {k: torch.randn(args.batch, *v, device=dev) for k, v in shapes.items()}
+    y = torch.randint(0, classes, (args.batch,), device=dev)
+    out = {"mode": "skeleton_imu_gcn_late_fusion", "imu_nodes": args.frames * 2, "batch": args.batch}
+    for mode in ("f32", "bf16x3"):
+        with ops.math_mode(mode):
+            for _ in range(2):
+                model.zero_grad(set_to_none=True)
+                F.cross_entropy(model(x), y).backward()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.zero_grad(set_to_none=True)
+                loss = F.cross_entropy(model(x), y)
+                loss.backward()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+        out[mode] = {"ms_per_step": round(1e3 * dt, 2), "samples_per_s": round(args.batch / dt, 1), "loss": round(float(loss.detach()), 5)}
     print(json.dumps(out))
 
 
