@@ -30,6 +30,7 @@ struct RowsGemmP {
     long long in_elems;  // B * T_in * V * ld_in
     unsigned w_bytes;
     int tiles_m, tiles_n, per_xcd;  // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
+    long long in_bs, out_bs, w_bs;  // fgcn_rows_gemm_batched: element strides of blockIdx.z's problem (0 otherwise)
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
@@ -38,6 +39,9 @@ struct RowsGemmP {
 template <int MT, int NT, bool DB, bool BF>
 __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kernel(RowsGemmP p) {
     constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
+    p.in += (long long)blockIdx.z * p.in_bs;           // batched form: one independent problem per blockIdx.z
+    p.out += (long long)blockIdx.z * p.out_bs;
+    p.w += (long long)blockIdx.z * p.w_bs;
     constexpr int AR = 4 * MT;                         // A-tile rows staged per thread
     __shared__ __attribute__((aligned(16))) float As[NBUF * BM * AS];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF * BK * BN];
@@ -492,10 +496,13 @@ static int check_tmap(const fgcn_tmap& m) {
     return FGCN_OK;
 }
 
-extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
-                              int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
-                              fgcn_tmap map, int accumulate, void* stream) {
+static int rows_gemm_launch(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
+                            int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                            fgcn_tmap map, int accumulate, int batch, long long in_bs, long long out_bs, long long w_bs,
+                            void* stream) {
     FGCN_REQUIRE(in && out && w, FGCN_E_BADARG, "rows_gemm: null pointer");
+    FGCN_REQUIRE(batch >= 1 && batch <= 65535 && in_bs % 4 == 0 && out_bs % 4 == 0 && w_bs % 4 == 0, FGCN_E_BADARG,
+                 "rows_gemm: batch=%d / batch strides must be multiples of 4 floats", batch);
     FGCN_REQUIRE(B > 0 && T_in > 0 && T_out > 0 && V > 0 && K > 0 && N > 0, FGCN_E_BADARG,
                  "rows_gemm: non-positive size B=%d T_in=%d T_out=%d V=%d K=%d N=%d", B, T_in, T_out, V, K, N);
     FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, FGCN_E_ALIGN,
@@ -508,7 +515,7 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     if (int e = check_tmap(map)) return e;
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
                 map.taps, map.ta, map.tb, map.tc, map.td, accumulate,
-                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0};
+                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0, in_bs, out_bs, w_bs};
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;
@@ -529,14 +536,14 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     p.tiles_m = (int)tiles_m;
     p.tiles_n = (int)cdiv(N, 32 * nt);
     const long long total = tiles_m * p.tiles_n;
-    dim3 grid((unsigned)tiles_m, (unsigned)p.tiles_n);
+    dim3 grid((unsigned)tiles_m, (unsigned)p.tiles_n, (unsigned)batch);
     if ((fgcn::tuning(5) & 1) && p.tiles_n > 1 && total < (1ll << 30)) {   // measured slower than the plain 2-D grid: off
         p.per_xcd = (int)cdiv(total, 8);
-        grid = dim3((unsigned)(p.per_xcd * 8));
+        grid = dim3((unsigned)(p.per_xcd * 8), 1, (unsigned)batch);
     }
     else if (!(fgcn::tuning(5) & 8) && p.tiles_n > 1 && tiles_m < 65536) {   // measured 1-3 % faster than row tile fastest
         p.per_xcd = -1;
-        grid = dim3((unsigned)p.tiles_n, (unsigned)tiles_m);
+        grid = dim3((unsigned)p.tiles_n, (unsigned)tiles_m, (unsigned)batch);
     }
     const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
 #define FGCN_LAUNCH(MT_, NT_, DB_)                                                                         \
@@ -557,6 +564,22 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
     }
 #undef FGCN_LAUNCH
     return launch_status("rows_gemm");
+}
+
+extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
+                              int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                              fgcn_tmap map, int accumulate, void* stream) {
+    return rows_gemm_launch(in, out, w, bias, stat_partials, B, T_in, T_out, V, K, N, ld_in, ld_out, map, accumulate, 1, 0, 0, 0,
+                            stream);
+}
+
+extern "C" int fgcn_rows_gemm_batched(const float* in, float* out, const float* w, int batch, long long in_bstride,
+                                      long long out_bstride, long long w_bstride, int rows, int K, int N, int ld_in, int ld_out,
+                                      int accumulate, void* stream) {
+    FGCN_REQUIRE(rows > 0, FGCN_E_BADARG, "rows_gemm_batched: rows=%d", rows);
+    const fgcn_tmap pointwise{1, 1, 0, 0, 1};
+    return rows_gemm_launch(in, out, w, nullptr, nullptr, 1, rows, rows, 1, K, N, ld_in, ld_out, pointwise, accumulate, batch,
+                            in_bstride, out_bstride, w_bstride, stream);
 }
 
 extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,

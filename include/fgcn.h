@@ -78,6 +78,13 @@ typedef struct {
 int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
                    int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
                    fgcn_tmap map, int accumulate, void* stream);
+/* `batch` independent problems out_b[rows x N] (+)= in_b[rows x K] . w_b[K x N] in one launch (one per blockIdx.z): problem b
+ * reads in + b*in_bstride, w + b*w_bstride and writes out + b*out_bstride (strides in floats, multiples of 4; row strides
+ * ld_in / ld_out as above).  The per-sample V x V products of AGCNGraphConvolution on IMU graphs
+ * (torch_src/models/mmargcn/graph_convolution.py:96-101 and their backward): one sample's matrix is the weight. */
+int fgcn_rows_gemm_batched(const float* in, float* out, const float* w, int batch, long long in_bstride,
+                           long long out_bstride, long long w_bstride, int rows, int K, int N, int ld_in, int ld_out,
+                           int accumulate, void* stream);
 /* number of row tiles = leading dimension of stat_partials for M = B*T_out*V rows */
 int fgcn_rows_gemm_tiles(long long M);
 
