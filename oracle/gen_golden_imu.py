@@ -97,6 +97,18 @@ def main():
         store[f"{tag}.train.loss"] = loss.detach().numpy()
         for name, p in model.named_parameters():
             store[f"{tag}.gl2.{name.replace('_model.', '')}"] = p.grad.norm().numpy()
+    # ---- mode skeleton_imu_channel_fusion (early_fusion_models.py:25-45): IMU signals as extra channels of every joint ----------
+    shapes, classes, batch = {"skeleton": (1, 16, 20, 3), "inertial": (16, 6)}, 27, 2
+    model = ref_mm.Model(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint),
+                         mode="skeleton_imu_channel_fusion", num_layers=4).double()
+    filler.fill_state_dict(model.state_dict(), skip=("adj_a", "A"), rename=lambda k: k.replace("_model.agcn.", ""))
+    x = {"skeleton": torch.from_numpy(filler.skeleton_input("x.chan.skeleton", (batch, *shapes["skeleton"]))).double(),
+         "inertial": torch.from_numpy(filler.bellish("x.chan.inertial", (batch, *shapes["inertial"]), scale=0.5)).double()}
+    model.eval()
+    store["chan.eval.logits"] = model(x).detach().numpy()
+    model.train()
+    store["chan.train.logits"] = model(x).detach().numpy()
+    store["chan.keys"] = np.array(sorted(k.replace("_model.", "") for k in model.state_dict()))
     store["torch_version"] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(OUT, "imu_gcn.npz"), **store)
     print("wrote", os.path.join(OUT, "imu_gcn.npz"), os.path.getsize(os.path.join(OUT, "imu_gcn.npz")), "bytes")

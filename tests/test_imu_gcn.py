@@ -249,3 +249,51 @@ def test_hip_late_fusion_matches_the_oracle(gc_model):
             assert float(got.norm()) < 1e-6, k
         else:
             assert abs(float(got.norm()) - wn) < 1e-2 * wn, (k, float(got.norm()), wn)   # as the cfg-3/4 fixtures: norms within 1 %
+
+
+# ---- mode skeleton_imu_channel_fusion: IMU signals broadcast to every joint as extra input channels -----------------------------
+def chan_build(double=False):
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.mmargcn import Model
+    from fusion_gcn_amd.util import Graph
+    shapes = {"skeleton": (1, 16, 20, 3), "inertial": (16, 6)}
+    model = Model(shapes, 27, Graph(utd.skeleton_edges, center_joint=utd.center_joint), mode="skeleton_imu_channel_fusion",
+                  num_layers=4)
+    if double:
+        model = model.double()
+    filler.fill_state_dict(model.state_dict(), skip=("adj_a", "A"), rename=lambda k: k.replace("_model.agcn.", ""))
+    sd = {k.replace("_model.agcn.", ""): (v.detach().double().clone() if v.is_floating_point() else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    x = {"skeleton": torch.from_numpy(filler.skeleton_input("x.chan.skeleton", (2, *shapes["skeleton"]))).double(),
+         "inertial": torch.from_numpy(filler.bellish("x.chan.inertial", (2, *shapes["inertial"]), scale=0.5)).double()}
+    return model, sd, x
+
+
+def chan_oracle(x, sd, train):
+    from oracle import agcn_oracle as OA
+    imu = x["inertial"].unsqueeze(1).unsqueeze(3).expand(-1, x["skeleton"].shape[1], -1, x["skeleton"].shape[3], -1)
+    return OA.model_forward(torch.cat([x["skeleton"], imu], dim=-1), sd, train=train, num_layers=4)
+
+
+def test_channel_fusion_oracle_matches_the_reference():
+    model, sd, x = chan_build(double=True)
+    assert sorted(k.replace("_model.", "") for k in model.state_dict()) == list(GOLD["chan.keys"])
+    assert rel_l2(chan_oracle(x, sd, False).detach().numpy(), GOLD["chan.eval.logits"]) < 1e-10
+    assert rel_l2(chan_oracle(x, sd, True).detach().numpy(), GOLD["chan.train.logits"]) < 1e-10
+
+
+@pytest.mark.gpu
+def test_hip_channel_fusion_matches_the_reference():
+    dev = torch.device("cuda:0")
+    model, sd, x = chan_build()
+    model = model.to(dev)
+    xg = {k: v.float().to(dev) for k, v in x.items()}
+    model.eval()
+    with torch.no_grad():
+        assert rel_l2(model(xg).cpu().double().numpy(), chan_oracle(x, sd, False).detach().numpy()) < 5e-5
+    model.train()
+    logits = model(xg)
+    assert rel_l2(logits.detach().cpu().double().numpy(), chan_oracle(x, sd, True).detach().numpy()) < 5e-5
+    assert rel_l2(logits.detach().cpu().double().numpy(), GOLD["chan.train.logits"]) < 5e-5
+    logits.square().sum().backward()                       # the 9-channel input block runs its backward
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
