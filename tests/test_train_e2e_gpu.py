@@ -84,3 +84,56 @@ def test_three_training_steps_match_the_oracle_loop(tmp_path, fgcn_math):
     # (three updates amplify the fp32-vs-fp64 ReLU-flip floor of the gradients, 3e-4..2e-3 per step: SURVEY.md section 0 fact 9)
     assert rel_l2(got_t.numpy(), want_t.detach().numpy()) < 5e-3
     assert torch.isfinite(got).all()
+
+
+def test_late_fusion_trains_from_two_feature_files(tmp_path, fgcn_math):
+    """Two modalities on disk -> MultiModalDataset / ClipBatches (dict batches) -> mode skeleton_imu_gcn_late_fusion with the AGCN
+    IMU branch -> FlatOptimizer: two SGD steps against the same loop on the float64 oracle."""
+    import test_imu_gcn as TI
+    from fusion_gcn_amd.data import ClipBatches, MultiModalDataset, NumpyDatasetLoader, NumpyWriter
+    from fusion_gcn_amd.optim import FlatOptimizer
+    dev = torch.device("cuda:0")
+    n, bs = 6, 3
+    feats = {"skeleton": filler.skeleton_input("x.e2e.late.skeleton", (n, *TI.LATE_SHAPES["skeleton"])).astype(np.float32),
+             "inertial": filler.bellish("x.e2e.late.inertial", (n, *TI.LATE_SHAPES["inertial"]), scale=0.5).astype(np.float32)}
+    labels = filler.uniform("y.e2e.late", (n,), 0, 27).astype(np.int64)
+    for name, a in feats.items():
+        with NumpyWriter(str(tmp_path / f"{name}_train_features.npy"), np.float32, a.shape) as w:
+            for s in a:
+                w.collect_next(s)
+    np.save(tmp_path / "train_labels.npy", labels)
+    ds = MultiModalDataset([(str(tmp_path), NumpyDatasetLoader())], "train")
+    assert set(ds.features_data) == {"skeleton", "inertial"}
+
+    model, sd = TI.late_build(gc_model="agcn")
+    model = model.to(dev).train()
+    hyper = dict(momentum=0.9, nesterov=True, weight_decay=1e-4)
+    opt = FlatOptimizer(model.parameters(), "SGD", 0.01, **hyper)
+    names = [k.replace("_model.", "") for k, _ in model.named_parameters()]
+    ref_params = [sd[k] for k in names]
+    ref_opt = torch.optim.SGD(ref_params, 0.01, **hyper)
+    losses, ref_losses = [], []
+    for x, y, idx in ClipBatches(ds, bs, shuffle=False, device=dev, resident=True):
+        assert isinstance(x, dict) and x["skeleton"].is_cuda
+        opt.zero_grad()
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        xi = {k: torch.from_numpy(v[idx.numpy()]).double() for k, v in feats.items()}
+        _, ref_loss, grads = TI.late_loss_and_grads(xi, torch.from_numpy(labels[idx.numpy()]), sd)
+        ref_opt.zero_grad()
+        for k, p in zip(names, ref_params):
+            p.grad = grads[k] if grads[k] is not None else torch.zeros_like(p)
+        ref_opt.step()
+        ref_losses.append(float(ref_loss))
+    assert len(losses) == 2
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 3e-4 * max(1.0, abs(b)), (losses, ref_losses)
+    worst = ("", 0.0)
+    for (name, p), k in zip(model.named_parameters(), names):
+        want = sd[k].numpy()
+        if np.abs(want).max() == 0:
+            continue
+        worst = max(worst, (k, rel_l2(p.detach().cpu().double().numpy(), want)), key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
