@@ -399,9 +399,19 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(float* dst, const floa
     __shared__ float red[16][65];
     const int x = threadIdx.x, y = threadIdx.y;
     const long long i = (long long)blockIdx.x * 64 + x;
+    // eight independent loads in flight per thread (the slab walk is latency-bound: S reaches 2048 for the BatchNorm partials
+    // while only a few workgroups cover `count`); the eight sub-sums are added in a fixed order
     float t = 0.f;
-    if (i < count)
-        for (int s = y; s < S; s += 16) t += src[(long long)s * count + i];
+    if (i < count) {
+        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = y;
+        for (; s + 7 * 16 < S; s += 8 * 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] += src[(long long)(s + 16 * k) * count + i];
+        }
+        for (int k = 0; s < S; s += 16, ++k) u[k] += src[(long long)s * count + i];
+        t = ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    }
     red[y][x] = t;
     __syncthreads();
     if (y == 0 && i < count) {
@@ -422,9 +432,19 @@ __global__ __launch_bounds__(1024) void reduce_sum_strided_kernel(float* dst, co
     const int x = threadIdx.x, y = threadIdx.y;
     const long long count = (long long)taps * K * N;
     const long long i = (long long)blockIdx.x * 64 + x;
+    // eight independent loads in flight per thread (the slab walk is latency-bound: S reaches 2048 for the BatchNorm partials
+    // while only a few workgroups cover `count`); the eight sub-sums are added in a fixed order
     float t = 0.f;
-    if (i < count)
-        for (int s = y; s < S; s += 16) t += src[(long long)s * count + i];
+    if (i < count) {
+        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = y;
+        for (; s + 7 * 16 < S; s += 8 * 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] += src[(long long)(s + 16 * k) * count + i];
+        }
+        for (int k = 0; s < S; s += 16, ++k) u[k] += src[(long long)s * count + i];
+        t = ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    }
     red[y][x] = t;
     __syncthreads();
     if (y == 0 && i < count) {
