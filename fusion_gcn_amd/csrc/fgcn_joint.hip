@@ -397,17 +397,20 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
         (void*)(p.dx + ((long long)n * p.T + t0) * V * p.ld_dx), 0, (unsigned)((t1 - t0) * V * p.ld_dx) * 4u, 0x00020000);
 
     // staging: lane -> (row = lane / 8 + 8 * pass, 16-byte group lane % 8); all 32 rows are written (absent joints and
-    // channels load zeros), so the tiles never hold stale data
+    // channels load zeros), so the tiles never hold stale data.  The global loads of a tile are issued one tile AHEAD (the x
+    // chunk of the next (frame, channel chunk), the next subset's dagg chunk) and parked in registers while the MFMAs of the
+    // current tile run; they are written to the wave-private LDS tile right before that tile's own MFMAs.
     const int srow = lane >> 3, sg = lane & 7;
-    auto stage = [&](const __amdgpu_buffer_rsrc_t& r, unsigned frow_bytes, int ld, int c, int cw, float* tile) {
-        f32x4 v[4];
+    auto loadt = [&](const __amdgpu_buffer_rsrc_t& r, unsigned frow_bytes, int ld, int c, int cw, bool valid, f32x4 (&v)[4]) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = 8 * ps + srow;
-            const bool ok = row < V && 4 * sg < cw;
+            const bool ok = valid && row < V && 4 * sg < cw;
             v[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   r, ok ? frow_bytes + (unsigned)(row * ld + c + 4 * sg) * 4u : OOB, 0, 0));
         }
+    };
+    auto storet = [&](float* tile, const f32x4 (&v)[4]) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(&tile[(8 * ps + srow) * DTS + 4 * sg]) = v[ps];
     };
@@ -418,17 +421,31 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
     const float* dm = dt + h * DTS + l31;              // mix B operand: lane = channel, joints 2s + h
     const float* am = img + h * 32 + l31;              // mix A operand: image row k = w = 2s + h, lane = out joint v
     const int u0 = 4 * h;                              // accumulator register r holds out joint (r&3) + 8(r>>2) + 4h
+    auto frame_bytes = [&](int t, int ld) { return (unsigned)((n * p.T + t) * V) * (unsigned)ld * 4u; };
+    f32x4 vx[4], vd[4];
+    {
+        const int t = t0 + wave;
+        loadt(rx, frame_bytes(t, p.ld_x), p.ld_x, 0, min(32, C), t < t1, vx);
+        loadt(rd, frame_bytes(t, p.ld_d), p.ld_d, 0, min(32, C), t < t1, vd);
+    }
     for (int t = t0 + wave; t < t1; t += 4) {
-        const unsigned row0 = (unsigned)((n * p.T + t) * V);
-        const unsigned fx = row0 * (unsigned)p.ld_x * 4u, fd = row0 * (unsigned)p.ld_d * 4u;
+        const unsigned fd = frame_bytes(t, p.ld_d);
         for (int c0 = 0; c0 < C; c0 += 32) {
             const int cw = min(32, C - c0);
-            stage(rx, fx, p.ld_x, c0, cw, xt);
+            // the (frame, chunk) after this one
+            const bool same_t = c0 + 32 < C;
+            const int tn = same_t ? t : t + 4, cn = same_t ? c0 + 32 : 0;
+            const int cwn = min(32, C - cn);
+            const bool nvalid = tn < t1;
+            storet(xt, vx);
+            loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, cn, cwn, nvalid, vx);
             f32x16 accx = zero16();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < NS) {                          // wave-uniform
-                    stage(rd, fd, p.ld_d, k * C + c0, cw, dt);
+                    storet(dt, vd);
+                    if (k + 1 < NS) loadt(rd, fd, p.ld_d, (k + 1) * C + c0, cw, true, vd);
+                    else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {      // dA^_k += x chunk . dagg_k chunk^T (channels 8q + 4h + e)
                         const f32x4 av = *reinterpret_cast<const f32x4*>(xa + 8 * q);
