@@ -85,8 +85,16 @@ def build_model(device):
     from fusion_gcn_amd.models.mmargcn.agcn import Model
     from fusion_gcn_amd.util import Graph
     torch.manual_seed(1)
-    model = Model((SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"]), SHAPE["classes"],
-                  Graph(ntu.skeleton_edges, center_joint=ntu.center_joint))
+    if SHAPE["V"] == 25:
+        model = Model((SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"]), SHAPE["classes"],
+                      Graph(ntu.skeleton_edges, center_joint=ntu.center_joint))
+    else:   # BASELINE configs 3 / 4: IMU modalities as extra joints (mode skeleton_imu_spatial_fusion)
+        from fusion_gcn_amd.datasets.mmact import constants as mmact
+        from fusion_gcn_amd.models.mmargcn.mmargcn import Model as MM
+        c, n_imu = (ntu, 2) if SHAPE["V"] == 27 else (mmact, 4)
+        model = MM({"skeleton": (SHAPE["M"], SHAPE["T"], SHAPE["V"], SHAPE["C"])}, SHAPE["classes"],
+                   Graph(c.skeleton_edges, center_joint=c.center_joint), mode="skeleton_imu_spatial_fusion",
+                   num_imu_joints=n_imu, imu_enhanced_mode="append_center")
     # the reference initialises the gcn BatchNorm scale and adj_b at 1e-6 (blocks start as near-identities); use O(1)
     # values so every kernel sees realistic magnitudes (timing does not depend on them, ReLU sparsity does slightly)
     with torch.no_grad():
@@ -205,6 +213,9 @@ def main():
     ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
                     help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--joints", type=int, choices=(25, 27, 22), default=25,
+                    help="25: the headline (BASELINE config 2); 27: config 3 (NTU graph + 2 IMU joints); 22: config 4 (MMAct COCO-18 + "
+                         "4 IMU joints, 35 classes) -- parity-test shapes timed for the record, not the headline")
     ap.add_argument("--loader", choices=("none", "resident", "streaming"), default="none",
                     help="feed every timed step from a feature file in the reference's on-disk format through "
                          "fusion_gcn_amd.data.ClipBatches (resident: split uploaded once, device-side gather; streaming: pinned "
@@ -223,6 +234,9 @@ def main():
                     help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
                          "profiles/*_dominant_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of")
     args = ap.parse_args()
+    if args.joints != 25:
+        SHAPE["V"] = args.joints
+        SHAPE["classes"] = 35 if args.joints == 22 else 60
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -454,15 +468,16 @@ def main():
         clips_per_s = n_global * args.steps / elapsed
         flops, byts = algorithmic_costs(n_global)
         out = {
-            "metric": "clips/sec (N,C,T,V,M)=(64,3,300,25,2) fwd+bwd",
+            "metric": "clips/sec (N,C,T,V,M)=(64,3,300,%d,2) fwd+bwd" % SHAPE["V"],
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": MATH_DTYPE[args.math],
             "data": "synthetic",
-            "config": {"workload": "AGCN 10-block fwd+bwd, NTU-RGB-D graph, synthetic (N,C,T,V,M)=(%d,3,300,25,2), "
-                                   "60 classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
-                                   % n_global,
+            "config": {"workload": "AGCN 10-block fwd+bwd, %s, synthetic (N,C,T,V,M)=(%d,3,300,%d,2), "
+                                   "%d classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
+                                   % ({25: "NTU-RGB-D graph", 27: "NTU-RGB-D graph + 2 IMU joints", 22: "MMAct COCO-18 graph + 4 IMU joints"}
+                                      [SHAPE["V"]], n_global, SHAPE["V"], SHAPE["classes"]),
                        "global_batch": n_global, "per_gpu_batch": n_local,
                        "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5),
                        "optimizer_step_in_timed_region": args.optimizer, "input_pipeline": pipeline or "one HBM-resident batch"},
