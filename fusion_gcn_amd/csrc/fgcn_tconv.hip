@@ -530,8 +530,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
 // NP = bf16 parts per operand: 3 = FGCN_MATH_BF16X3 (six partial products), 1 = FGCN_MATH_BF16 (operands rounded to bf16 once --
 // activations as the image is staged, weights by fgcn_pack_split3, whose part 0 is the round-to-nearest-even bf16 -- and ONE
 // MFMA per product group: a sixth of the matrix work, a third of the LDS image and of the weight stream).
-template <int NT, int KC, int NP>
+// MTW = 16-row tiles per wave: 4 (128 output rows per workgroup) or 3 (96 rows: for more than 25 joints the 128-row tile's halo
+// image -- 128 + 8 V rows x 3 planes -- no longer fits twice into the 160 KB of LDS; the shorter tile keeps two workgroups per CU).
+template <int NT, int KC, int NP, int MTW = 4>
 __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(MTW == 3 || MTW == 4, "wave tile: 48 or 64 rows");
+    constexpr int BMR = 32 * MTW;                    // output rows per workgroup
     static_assert(NP == 1 || NP == 3, "one or three bf16 parts per operand");
     static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
     constexpr int XS = KC * 2 + 16;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
     const int l15 = lane & 15, g4 = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     const int bm = blockIdx.x, bn = blockIdx.y;
-    const long long m0 = (long long)bm * 128;
+    const long long m0 = (long long)bm * BMR;
     constexpr int BN = 2 * NT * 32;
     const int n0 = bn * BN;
     const int V = p.V, TvV = p.Tv * p.V;
@@ -556,11 +560,11 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
 
-    bool row_ok[4];
-    int th_lane[4];
+    bool row_ok[MTW];
+    int th_lane[MTW];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const long long mrow = m0 + wr * 64 + mt * 16 + l15;
+    for (int mt = 0; mt < MTW; ++mt) {
+        const long long mrow = m0 + wr * (16 * MTW) + mt * 16 + l15;
         row_ok[mt] = mrow < p.Mv;
         th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
     }
@@ -584,9 +588,9 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
         }
     }
 
-    f32x4 acc[4][NU];
+    f32x4 acc[MTW][NU];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) acc[mt][nu] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
 
     unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
     const unsigned plane = (unsigned)p.halo_rows * XS;
-    const unsigned char* xrow = Xh + (wr * 64 + l15) * XS + 16 * g4;
+    const unsigned char* xrow = Xh + (wr * (16 * MTW) + l15) * XS + 16 * g4;
     const int IT2 = p.taps * SPC;                    // (tap, 32-channel group) steps per chunk
     const int K8 = p.K >> 3;
     auto load_w = [&](u32x4v (&dst)[NP], int nu, int it, int kc) {
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
         }
     };
 
-    u32x4v a[4][NP], wq[2][NP];
+    u32x4v a[MTW][NP], wq[2][NP];
     load_w(wq[0], 0, 0, 0);
     if constexpr (PF) fetch(0);
     for (int kc = 0; kc < p.K; kc += KC) {
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
             if (kc + KC < p.K) fetch(kc + KC);       // lands during the MFMAs below
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) load_a(a[mt], mt, 0);
+        for (int mt = 0; mt < MTW; ++mt) load_a(a[mt], mt, 0);
 #pragma unroll 1
         for (int it = 0; it < IT2; ++it) {
             const int itn = it + 1 < IT2 ? it + 1 : it;                  // the chunk's last step re-reads itself (unused)
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
                 if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], nu + 1, it, kc);
                 else load_w(wq[0], 0, it + 1, kc);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MTW; ++mt) {
                     if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
                     else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
                     if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
@@ -697,11 +701,11 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
         bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
         unsigned rowoff[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long m = m0 + wr * 64 + mt * 16 + 4 * g4 + r;
+            const long long m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
             bool ok = m < p.Mv;
             unsigned orow = (unsigned)(ok ? m : 0);
             if (!plain_out) {                              // wave-uniform
@@ -762,9 +766,16 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
 
 using namespace fgcn;
 
+// output rows per workgroup: 128, or 96 in the bf16 math modes when the 128-row tile's halo image (9 taps: 128 + 8 V rows, three
+// 80-byte planes) would not fit twice into LDS (V > 26)
+static int halo_tile_rows(int V) {
+    const bool k32 = fgcn::math_mode() == FGCN_MATH_BF16 || (fgcn::math_mode() == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 6));
+    return (k32 && (128 + 8 * V) * XSB * 3 > 80 * 1024) ? 96 : 128;
+}
+
 extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
     const int Tv = Th_out > Th_in ? Th_out : Th_in;
-    return (int)cdiv((long long)B * Tv * V, 128);
+    return (int)cdiv((long long)B * Tv * V, halo_tile_rows(V));
 }
 
 extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
@@ -805,10 +816,11 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
     const int dmax = d0 < d1 ? d1 : d0;
-    p.halo_rows = 128 + (dmax - p.dmin) * V;
+    const int bmr = halo_tile_rows(V);
+    p.halo_rows = bmr + (dmax - p.dmin) * V;
     FGCN_REQUIRE(p.halo_rows <= 32 * HALO_MAX_STAGE, FGCN_E_BADARG, "tconv_halo: halo of %d rows too large", p.halo_rows);
     const size_t lds = mm == FGCN_MATH_BF16X3 ? (size_t)p.halo_rows * XSB * 3 : (size_t)p.halo_rows * HAS * sizeof(float);
-    const long long tiles = cdiv(p.Mv, 128);
+    const long long tiles = cdiv(p.Mv, bmr);
     FGCN_REQUIRE(p.Mv < (1ll << 31) - 4096, FGCN_E_BADARG, "tconv_halo: too many rows (32-bit row indices)");
     hipStream_t s = (hipStream_t)stream;
     static bool lds_opt_in = false;  // once per process (not a stream operation: keep it out of graph captures)
@@ -842,9 +854,13 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         if (!opt_in) {
             const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
 #define FGCN_K32_ATTR(NT_, KC_)                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3>),             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3, 4>),          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1>),             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 4>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3, 3>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 3>),          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
             FGCN_K32_ATTR(1, 32); FGCN_K32_ATTR(2, 32); FGCN_K32_ATTR(1, 64); FGCN_K32_ATTR(2, 64);
 #undef FGCN_K32_ATTR
@@ -852,11 +868,16 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         }
         const bool one = mm == FGCN_MATH_BF16;
         const bool pw = taps == 1 && K % 64 == 0;
-        const size_t lds_k = pw ? (size_t)128 * (64 * 2 + 16) * (one ? 1 : 3) : (size_t)p.halo_rows * XSB * (one ? 1 : 3);
+        const size_t lds_k = pw ? (size_t)bmr * (64 * 2 + 16) * (one ? 1 : 3) : (size_t)p.halo_rows * XSB * (one ? 1 : 3);
 #define FGCN_K32_LAUNCH(NT_, KC_)                                                                                \
     do {                                                                                                         \
-        if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1>), grid, dim3(256), lds_k, s, p);       \
-        else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3>), grid, dim3(256), lds_k, s, p);           \
+        if (bmr == 96) {                                                                                         \
+            if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 3>), grid, dim3(256), lds_k, s, p); \
+            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 3>), grid, dim3(256), lds_k, s, p);     \
+        } else {                                                                                                 \
+            if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 4>), grid, dim3(256), lds_k, s, p); \
+            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 4>), grid, dim3(256), lds_k, s, p);     \
+        }                                                                                                        \
     } while (0)
         if (pw) {
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
