@@ -525,7 +525,8 @@ static void launch_spatial_x3(const SpatialP& p, hipStream_t s) {
 
 static int spatial_t_chunk(int B, int T) {
     int chunk = 32;
-    while (chunk > 4 && (long long)B * cdiv(T, chunk) < 1024) chunk >>= 1;
+    // (not below 8: the two-frames-per-wave kernel walks 8 frames per workgroup iteration; a 4-frame chunk left half its waves idle)
+    while (chunk > 8 && (long long)B * cdiv(T, chunk) < 1024) chunk >>= 1;
     return chunk;
 }
 
