@@ -27,39 +27,34 @@ class unit_tcn(_base.TemporalConv):
 
 
 class unit_gcn(_base._KernelBacked):
+    """Parameter container of the adaptive graph convolution under the 2s-AGCN names (``PA``, ``conv_a/b/d.<k>``, ``down``, ``bn``)."""
+
     def __init__(self, in_channels, out_channels, A, coff_embedding=4, num_subset=3):
         super().__init__()
-        if coff_embedding != 4 or num_subset != 3:
+        if (coff_embedding, num_subset) != (4, 3):
             raise ValueError("the HIP AGCN block implements coff_embedding=4, num_subset=3")
-        inter_channels = out_channels // coff_embedding
-        self.inter_c = inter_channels
-        self.PA = nn.Parameter(torch.from_numpy(A.astype(np.float32)))
-        nn.init.constant_(self.PA, 1e-6)
-        self.A = torch.from_numpy(A.astype(np.float32))     # plain attribute: not in the state dict
-        self.num_subset = num_subset
+        adjacency = torch.from_numpy(np.asarray(A, dtype=np.float32))
+        self.num_subset, self.inter_c = num_subset, out_channels // coff_embedding
+        self.A = adjacency                                   # plain attribute: not in the state dict (reference :60-62)
+        self.PA = nn.Parameter(torch.full_like(adjacency, 1e-6))
         self.adj_c = [None] * num_subset
-        self.conv_a = nn.ModuleList()
-        self.conv_b = nn.ModuleList()
-        self.conv_d = nn.ModuleList()
-        for _ in range(self.num_subset):
-            self.conv_a.append(nn.Conv2d(in_channels, inter_channels, 1))
-            self.conv_b.append(nn.Conv2d(in_channels, inter_channels, 1))
-            self.conv_d.append(nn.Conv2d(in_channels, out_channels, 1))
-        if in_channels != out_channels:
-            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
-        else:
-            self.down = lambda x: x
+        widths = {"conv_a": self.inter_c, "conv_b": self.inter_c, "conv_d": out_channels}
+        for name, width in widths.items():
+            setattr(self, name, nn.ModuleList(nn.Conv2d(in_channels, width, 1) for _ in range(num_subset)))
+        self.down = (nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+                     if in_channels != out_channels else (lambda x: x))
         self.bn = nn.BatchNorm2d(out_channels)
-        self.soft = nn.Softmax(-2)
-        self.relu = nn.ReLU()
+        self.soft, self.relu = nn.Softmax(-2), nn.ReLU()
+        # the reference's initialisation (:84-93): kaiming fan-out convs, unit BatchNorms, the output BatchNorm and PA at
+        # 1e-6, conv_d with the branch-count variance
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 conv_init(m)
             elif isinstance(m, nn.BatchNorm2d):
                 bn_init(m, 1)
         bn_init(self.bn, 1e-6)
-        for i in range(self.num_subset):
-            conv_branch_init(self.conv_d[i], self.num_subset)
+        for conv in self.conv_d:
+            conv_branch_init(conv, num_subset)
 
     def _apply(self, fn, *args, **kwargs):
         # keep the non-registered constant adjacency on the module's device (.cuda() / .to())
@@ -95,39 +90,35 @@ class TCN_GCN_unit(_base.SpatialTemporalConv):
         return self.gcn1.A
 
 
+# (in, out, stride) of l1..l10; l1 has no block residual
+_LAYERS = ((None, 64, 1), (64, 64, 1), (64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 128, 1), (128, 256, 2),
+           (256, 256, 1), (256, 256, 1))
+
+
 class Model(nn.Module):
     def __init__(self, data_shape, num_classes, graph, **kwargs):
         super().__init__()
-        # data_shape = (num_persons, num_frames, num_joints, num_channels)
-        num_persons, _, num_joints, num_channels = data_shape["skeleton"]
-        adj = kwargs.get("adjacency_matrix", None)
+        num_persons, _, num_joints, num_channels = data_shape["skeleton"]      # (persons, frames, joints, channels)
+        adj = kwargs.get("adjacency_matrix")
         if adj is None:
             adj = GraphPartitionStrategy().get_adjacency_matrix_array(graph)
-        kw = dict(static_adjacency=kwargs.get("static_adjacency", False), fused_spatial=kwargs.get("fused_spatial", True))
+        kw = {k: kwargs.get(k, default) for k, default in (("static_adjacency", False), ("fused_spatial", True))}
         self.data_bn = nn.BatchNorm1d(num_persons * num_channels * num_joints)
-        self.l1 = TCN_GCN_unit(num_channels, 64, adj, residual=False, **kw)
-        self.l2 = TCN_GCN_unit(64, 64, adj, **kw)
-        self.l3 = TCN_GCN_unit(64, 64, adj, **kw)
-        self.l4 = TCN_GCN_unit(64, 64, adj, **kw)
-        self.l5 = TCN_GCN_unit(64, 128, adj, stride=2, **kw)
-        self.l6 = TCN_GCN_unit(128, 128, adj, **kw)
-        self.l7 = TCN_GCN_unit(128, 128, adj, **kw)
-        self.l8 = TCN_GCN_unit(128, 256, adj, stride=2, **kw)
-        self.l9 = TCN_GCN_unit(256, 256, adj, **kw)
-        self.l10 = TCN_GCN_unit(256, 256, adj, **kw)
-        self.fc = nn.Linear(256, num_classes)
-        nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / num_classes))
         bn_init(self.data_bn, 1)
+        for i, (cin, cout, stride) in enumerate(_LAYERS, start=1):
+            setattr(self, f"l{i}", TCN_GCN_unit(num_channels if cin is None else cin, cout, adj, stride=stride,
+                                                residual=cin is not None, **kw))
+        self.fc = nn.Linear(_LAYERS[-1][1], num_classes)
+        nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / num_classes))
 
     _blocks_input = _base.Model._blocks_input
     _bump_batch_counters = _base.Model._bump_batch_counters
 
     def forward(self, x):
-        N, M, T, V, C = x.size()
+        clips = x.size(0)
         h = self._blocks_input(x)
         self._bump_batch_counters()
-        for layer in (self.l1, self.l2, self.l3, self.l4, self.l5, self.l6, self.l7, self.l8, self.l9, self.l10):
-            h = layer(h)
-        c_new = h.size(-1)
-        h = _base.GroupMeanFunction.apply(h.view(N, -1, c_new))
+        for i in range(1, len(_LAYERS) + 1):
+            h = getattr(self, f"l{i}")(h)
+        h = _base.GroupMeanFunction.apply(h.view(clips, -1, h.size(-1)))
         return _base.LinearFunction.apply(h.contiguous(), self.fc.weight, self.fc.bias)   # fc on the row GEMM

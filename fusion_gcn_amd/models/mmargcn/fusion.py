@@ -7,56 +7,46 @@ inter-connected.  The ``Fusion`` combiners of that file (:9-62; used by the late
 vectors) are one-line torch reductions and are mirrored as they are.
 """
 import functools
-import inspect
 
 import torch
 
 from ...util.graph import Graph
 
 
+def _weighted(stack: torch.Tensor, weights) -> torch.Tensor:
+    return (stack * weights).sum(-1)
+
+
+# fusion type -> reduction over the tuple of equally shaped feature tensors (stacked on a new last axis where needed)
+_COMBINERS = {
+    "sum": lambda ts, o: functools.reduce(torch.add, ts),
+    "product": lambda ts, o: functools.reduce(torch.mul, ts),
+    "average": lambda ts, o: torch.stack(ts, dim=-1).mean(-1),
+    "weighted_average": lambda ts, o: _weighted(torch.stack(ts, dim=-1), o["weights"]),
+    "concatenate": lambda ts, o: torch.cat(ts, dim=o["concatenate_dim"]),
+}
+_OPTIONS = {"weighted_average": ("weights",), "concatenate": ("concatenate_dim",)}
+
+
 class Fusion:
+    """``combine(*tensors)`` of the reference's Fusion classes, as one object: the fusion type picks the reduction."""
+
+    def __init__(self, fusion_type: str, **options):
+        self.fusion_type, self.options = fusion_type, options
+
     def combine(self, *tensors: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError
-
-
-class SumFusion(Fusion):
-    def combine(self, *tensors):
-        return functools.reduce(torch.add, tensors)
-
-
-class ProductFusion(Fusion):
-    def combine(self, *tensors):
-        return functools.reduce(torch.mul, tensors)
-
-
-class AverageFusion(Fusion):
-    def combine(self, *tensors):
-        return torch.mean(torch.stack(tensors, dim=-1), dim=-1)
-
-
-class WeightedAverageFusion(Fusion):
-    def __init__(self, weights: torch.Tensor):
-        self.weights = weights
-
-    def combine(self, *tensors):
-        return torch.sum(torch.stack(tensors, dim=-1) * self.weights, dim=-1)
-
-
-class ConcatenateFusion(Fusion):
-    def __init__(self, concatenate_dim: int):
-        self._dim = concatenate_dim
-
-    def combine(self, *tensors):
-        return torch.cat(tensors, dim=self._dim)
+        return _COMBINERS[self.fusion_type](tensors, self.options)
 
 
 def get_fusion(fusion_type: str, **kwargs) -> Fusion:
-    fusion_types = {"sum": SumFusion, "product": ProductFusion, "concatenate": ConcatenateFusion,
-                    "average": AverageFusion, "weighted_average": WeightedAverageFusion}
-    if fusion_type not in fusion_types:
+    """Same call as the reference's factory: options a fusion type does not take are ignored (e.g. ``concatenate_dim`` for "sum")."""
+    if fusion_type not in _COMBINERS:
         raise ValueError("Unsupported fusion: " + fusion_type)
-    args = inspect.getfullargspec(fusion_types[fusion_type].__init__).args
-    return fusion_types[fusion_type](**{k: v for k, v in kwargs.items() if k in args})
+    wanted = _OPTIONS.get(fusion_type, ())
+    missing = [k for k in wanted if k not in kwargs]
+    if missing:
+        raise TypeError(f"fusion {fusion_type!r} needs {missing}")
+    return Fusion(fusion_type, **{k: kwargs[k] for k in wanted})
 
 
 def get_skeleton_imu_fusion_graph(skeleton_graph: Graph, imu_enhanced_mode: str, num_imu_joints: int, **kwargs) -> Graph:

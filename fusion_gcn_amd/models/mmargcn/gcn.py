@@ -4,7 +4,7 @@ convolutions (width doubling every third layer), mean over the nodes, ``fc``.  S
 (``gc<i>.*``, ``bn.*``, ``fc.*``); the layers run node-major on libfgcn kernels (graph_convolution.py), pooling and ``fc`` on
 ``fgcn_group_mean`` / ``fgcn_rows_gemm``."""
 import math
-from typing import Union
+from typing import List, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -13,46 +13,50 @@ import torch.nn.functional as F
 from ...block import GroupMeanFunction, LinearFunction
 from .graph_convolution import AGCNGraphConvolution, STGCNGraphConvolution
 
+_GRAPH_CONVS = {"stgcn": STGCNGraphConvolution, "agcn": AGCNGraphConvolution}
+
+
+def layer_plan(feature_dim: int, width: int, num_layers: int, extra_top: bool) -> List[Tuple[int, int, bool]]:
+    """(in, out, is_input_layer) per graph convolution: the input layer (built without residual and dropout), an optional
+    second layer of the same width, then layers whose width doubles at every third position (gcn.py:42-58)."""
+    plan = [(feature_dim, width, True)]
+    if extra_top:
+        plan.append((width, width, False))
+    for pos in range(1, num_layers - len(plan) + 1):
+        nxt = width * 2 if pos % 3 == 0 else width
+        plan.append((width, nxt, False))
+        width = nxt
+    return plan
+
 
 class GCN(nn.Module):
     def __init__(self, adj: Union[torch.Tensor, torch.sparse.Tensor], data_shape: tuple, num_classes: int,
                  dropout: float = 0., sparse: bool = False, gc_model: str = "stgcn", num_layers: int = 10,
                  inner_feature_dim: int = 64, include_additional_top_layer: bool = False, without_fc: bool = False):
         super().__init__()
-        assert num_layers >= 2
-        if gc_model == "stgcn":
-            gc = STGCNGraphConvolution
-        elif gc_model == "agcn":
-            gc = AGCNGraphConvolution
-        else:
+        if num_layers < 2:
+            raise AssertionError("num_layers >= 2")
+        if gc_model not in _GRAPH_CONVS:
             raise ValueError(f"Model {gc_model} not supported.")
+        conv = _GRAPH_CONVS[gc_model]
         feature_dim, num_nodes = data_shape
-        self.layers = [gc(feature_dim, inner_feature_dim, adj, sparse=sparse, residual=False)]
-        if include_additional_top_layer:
-            self.layers.append(gc(inner_feature_dim, inner_feature_dim, adj, sparse=sparse, dropout=dropout))
-        k = 0
-        for i in range(len(self.layers), num_layers):
-            k += 1
-            in_feature_dim = inner_feature_dim
-            if k == 3:
-                inner_feature_dim *= 2
-                k = 0
-            self.layers.append(gc(in_feature_dim, inner_feature_dim, adj, sparse=sparse, dropout=dropout))
         self.bn = nn.BatchNorm1d(feature_dim * num_nodes)
-        for layer_idx, layer in enumerate(self.layers):
-            setattr(self, f"gc{layer_idx + 1}", layer)
-        if without_fc:
-            self.fc = None
-        else:
-            self.fc = nn.Linear(inner_feature_dim, num_classes)
+        self.layers = []
+        for idx, (cin, cout, first) in enumerate(layer_plan(feature_dim, inner_feature_dim, num_layers,
+                                                             include_additional_top_layer), start=1):
+            layer = conv(cin, cout, adj, sparse=sparse, residual=False) if first else conv(cin, cout, adj, sparse=sparse,
+                                                                                          dropout=dropout)
+            self.layers.append(layer)
+            setattr(self, f"gc{idx}", layer)          # the reference's attribute / state-dict names
+        self.fc = None
+        if not without_fc:
+            self.fc = nn.Linear(self.layers[-1].out_features, num_classes)
             nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / num_classes))
 
     def forward(self, x):
         batch_size, feature_dim, num_nodes = x.size()
-        x = torch.flatten(x, start_dim=1)
-        x = self.bn(x)                                   # (input BatchNorm: a torch op, as data_bn of the skeleton model)
-        x = torch.reshape(x, (batch_size, feature_dim, num_nodes))
-        h = x.permute(0, 2, 1)                           # node-major (B, V, F), channels padded to 4
+        x = self.bn(torch.flatten(x, start_dim=1))       # (input BatchNorm: a torch op, as data_bn of the skeleton model)
+        h = x.view(batch_size, feature_dim, num_nodes).permute(0, 2, 1)   # node-major (B, V, F), channels padded to 4
         pad = (-feature_dim) % 4
         h = (F.pad(h, (0, pad)) if pad else h).contiguous()
         for layer in self.layers:
