@@ -7,10 +7,14 @@
 
 One "step" = one train-mode forward + backward (CrossEntropy, gradients for all 3.47 M parameters) of the
 10-block AGCN (fusion_gcn_amd.models.mmargcn.agcn.Model, NTU-RGB-D graph, 60 classes) over synthetic clips already
-resident in HBM.  Data parallel: every rank holds the headline shape, 64 clips (weak scaling: the global batch is
-64 x N, per-replica BatchNorm as in the reference's DataParallel), and the step includes the single RCCL all-reduce
-of the flat 13.9 MB gradient buffer; `--scaling strong` instead shards ONE 64-clip batch over the ranks (8 clips per
-GPU at N = 8).  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
+resident in HBM.  Data parallel (`--gpus N`): ONE 64-clip batch is sharded over the N ranks (strong scaling, the north
+star's "shard the clip batch across the 8 GPUs": 8 clips per GPU at N = 8, per-replica BatchNorm as in the reference's
+DataParallel) and the step includes the single RCCL all-reduce of the flat 13.9 MB gradient buffer; the weak-scaling
+reading (64 clips on every GPU) is measured right after it and reported as `other_scaling` (`--scaling weak` swaps the
+two).  No optimizer step (the metric is fwd+bwd).  Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (a child `torch.distributed.run`, before this
+process touches the GPU) and relays rank 0's JSON line.
 
 Arithmetic (`--math`, reported in `dtype`): the default "bf16x3" forms every float32 product of the convolution / GEMM
 kernels from exact three-way bfloat16 splits of both operands (six partial products, float32 accumulation: float32
@@ -191,14 +195,66 @@ def measured_traffic(dom, samples, math="f32"):
     return rec["traffic_bytes"]
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: run the same command line under torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1) as a CHILD process and pass its output and exit code through.  This process never
+    initialises the GPU, so nothing is re-exec'ed after a HIP call."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """The multi-rank control flow of the benchmark without a GPU (tests/test_bench_host.py): rendezvous, the shard of the
+    global batch this rank would hold, one all-reduce of a buffer of the gradient exchange's size, max-over-ranks timing,
+    rank 0's JSON line.  Not a measurement: value is null."""
+    from fusion_gcn_amd.dp import shard_batch
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("FGCN_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+    n_global = args.batch * world if args.scaling == "weak" else args.batch
+    shard = shard_batch(n_global, rank, world)
+    flat = torch.full((3_469_510,), float(rank + 1))
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(flat)
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(flat[0]) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "clips/sec (N,C,T,V,M)=(64,3,300,%d,2) fwd+bwd" % SHAPE["V"], "value": None, "unit": "clips/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dry_run": True, "data": "synthetic",
+                          "config": {"global_batch": n_global, "per_gpu_batch": shard.stop - shard.start,
+                                     "parallelism": f"dp{world}", "exchange_s": round(float(t), 4)}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=SHAPE["N"], help="clips per GPU (weak) / global clip batch (strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --batch clips on every GPU; strong: --batch clips sharded over the GPUs")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): ONE batch of --batch clips sharded over the GPUs; weak: --batch clips on every GPU")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check without a GPU: rendezvous, batch sharding, one all-reduce of a gradient-sized buffer "
+                         "over FGCN_BENCH_BACKEND (gloo), then the JSON line with value null")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=("f32", "bf16", "bf16x3"), default="bf16x3",
                     help="bf16x3 (default): f32-accurate split-bf16 products; f32: v_mfma_f32 directly; bf16: BASELINE "
@@ -238,12 +294,17 @@ def main():
         SHAPE["V"] = args.joints
         SHAPE["classes"] = 35 if args.joints == 22 else 60
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))     # nothing has touched the GPU yet: the ranks are fresh child processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.batch % world:
+        raise SystemExit(f"--batch {args.batch} is not divisible by {world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     # FGCN_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks (ranks

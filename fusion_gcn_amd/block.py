@@ -586,17 +586,30 @@ class STBlockFunction(torch.autograd.Function):
         names = param_names(cfg)
         P = dict(zip(names, params))
         o, S = block_forward(x, P, bufs, W, cfg, train)
-        ctx.cfg, ctx.train, ctx.names, ctx.W, ctx.S = cfg, train, names, W, S
-        ctx.save_for_backward(*params)
+        # the block's input and output go through save_for_backward (an output kept on ctx would be a reference cycle
+        # o -> grad_fn -> ctx -> o that only the garbage collector frees); the other activations are private to the block
+        # (the backward gates on the one-bit sign image of o, so o itself is only kept when that image does not exist;
+        # nn.Dropout(inplace=True) after the block may then overwrite o freely, as in the reference's Model)
+        keep_o = S["o_sign"] is None
+        S["x"] = S["o"] = None
+        ctx.cfg, ctx.train, ctx.names, ctx.W, ctx.S, ctx.keep_o = cfg, train, names, W, S, keep_o
+        ctx.save_for_backward(x, *((o,) if keep_o else ()), *params)
         if holder is not None:
             holder["adj_c"] = S["c_mat"]
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        P = dict(zip(ctx.names, ctx.saved_tensors))
-        dx, G = block_backward(d_o, ctx.S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0])
+        if ctx.S is None:
+            raise RuntimeError("STBlockFunction: backward ran twice -- the block frees its saved activations after the first "
+                               "backward (retain_graph is not supported; run the forward again)")
+        x, *params = ctx.saved_tensors
+        o = params.pop(0) if ctx.keep_o else None
+        P = dict(zip(ctx.names, params))
+        S = dict(ctx.S, x=x, o=o)
         ctx.S = None
+        dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0])
+        del S
         grads = []
         for i, n in enumerate(ctx.names):
             g = G.get(n) if ctx.needs_input_grad[6 + i] else None

@@ -181,7 +181,9 @@ def temporal_conv(x: Tensor, sd, p: str, stride: int, train: bool, stats: Option
 
 
 def st_block(x: Tensor, sd, p: str, stride: int, residual: bool, train: bool, stats: Optional[Stats] = None,
-             static_adjacency: bool = False):
+             static_adjacency: bool = False, capture: Optional[dict] = None):
+    """``capture``: receives the two ReLU outputs of the block, ``{p}.g`` and ``{p}.o`` (detached) -- the ReLU decisions
+    the model-level gradient-parity test compares and injects (oracle/relu_masks.py)."""
     g, adj_c = spatial_graph_conv(x, sd, f"{p}.gcn1", train, stats, static_adjacency)
     z = temporal_conv(g, sd, f"{p}.tcn1", stride, train, stats)
     if not residual:
@@ -190,11 +192,15 @@ def st_block(x: Tensor, sd, p: str, stride: int, residual: bool, train: bool, st
         res = temporal_conv(x, sd, f"{p}.residual", stride, train, stats)
     else:
         res = x
-    return torch.relu(z + res), adj_c
+    o = torch.relu(z + res)
+    if capture is not None:
+        capture[f"{p}.g"], capture[f"{p}.o"] = g.detach(), o.detach()
+    return o, adj_c
 
 
 def model_forward(x: Tensor, sd, train: bool = True, stats: Optional[Stats] = None, num_layers: int = 10,
-                  start: int = 64, static_adjacency: bool = False, return_blocks: bool = False):
+                  start: int = 64, static_adjacency: bool = False, return_blocks: bool = False,
+                  capture: Optional[dict] = None):
     """x: (N, M, T, V, C) -> logits (N, classes) (or pooled features if the dict has no ``fc``)."""
     n, m, t, v, c = x.shape
     h = x.permute(0, 1, 3, 4, 2).reshape(n, m * v * c, t)
@@ -202,7 +208,7 @@ def model_forward(x: Tensor, sd, train: bool = True, stats: Optional[Stats] = No
     h = h.reshape(n, m, v, c, t).permute(0, 1, 3, 4, 2).reshape(n * m, c, t, v)
     blocks = []
     for i, b in enumerate(block_plan(c, num_layers, start)):
-        h, _ = st_block(h, sd, f"l{i}", b["stride"], b["residual"], train, stats, static_adjacency)
+        h, _ = st_block(h, sd, f"l{i}", b["stride"], b["residual"], train, stats, static_adjacency, capture)
         if return_blocks:
             blocks.append(h)
     feat = h.reshape(n, m, h.shape[1], -1).mean(3).mean(1)

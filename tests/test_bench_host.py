@@ -25,3 +25,25 @@ def test_traffic_record_is_for_the_dominant_kernel_shape():
     assert bench.measured_traffic(dom, 16) is None                      # other batch: not the measured shape
     assert bench.measured_traffic(dict(channels=64, frames=300), 128) is None
     assert rec["algorithmic_bytes"] == 4 * 128 * 75 * 25 * 2 * 256
+
+
+def test_bench_starts_its_own_ranks_and_reports_strong_scaling():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses): bench.py starts the two ranks itself
+    (a child torch.distributed.run, 127.0.0.1 rendezvous), shards ONE 64-clip batch over them (strong scaling is the reported
+    data-parallel figure) and rank 0 prints one JSON line.  --dry-run: the same control flow over gloo, no GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["FGCN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dry_run"] is True
+    assert out["config"]["global_batch"] == 64 and out["config"]["per_gpu_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    # a batch that does not divide over the ranks is refused before any work
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "7", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -1,0 +1,75 @@
+"""Model-level gradient parity with ReLU-decision accounting (north star: <= 1e-3 rel vs the CPU reference).
+
+The flat gradient of the 10-block model against the float64 oracle (oracle/agcn_oracle.py, pinned to the reference's own
+outputs by tests/test_oracle_golden.py), at BASELINE configs[0] (cfg1) and the config-2 fixture shape:
+
+  (i)   ReLU decisions of the HIP forward vs the oracle's, per block (20 ReLU layers);
+  (ii)  HIP backward gated on the ORACLE's decisions (written into the saved one-bit sign images): <= 1e-4 -- what is left
+        is arithmetic only, so a real backward bug at model scale cannot hide behind "ReLU flips";
+  (iii) the un-injected error is bounded by what the counted flips explain.
+
+Reference: autograd over torch_src/models/mmargcn/agcn.py:183-200; floor of the reference against itself (fp32 vs fp64 on
+these two cases): tests/golden/model.npz ``*.ref_f32_vs_f64_grad_rel`` = 8.5e-5 / 2.5e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import relu_masks as RM
+
+pytestmark = pytest.mark.gpu
+
+INJECTED_TOL = 1e-4          # arithmetic-only gradient error of the whole model
+FLIP_GAIN = 2.0              # un-injected error <= INJECTED_TOL + FLIP_GAIN * sqrt(flips / decisions per ReLU layer)
+# measured on MI355X (gpurun_out r02): cfg1 4 flips of 5.6 M decisions -> 1.9e-3 as is, 9.6e-7 injected; the smoke case ONE flip
+# of 2.25 M -> 3.5e-3 as is, 1.2e-6 injected: one flipped element of a 1e5-element layer is sqrt(1e-5) = 3e-3 of the gradient
+
+
+def _case(tag, shape, classes, gname):
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    c = {"utd": utd, "ntu": ntu}[gname]
+    n, m, t, v, ch = shape
+    model = Model((m, t, v, ch), classes, Graph(c.skeleton_edges, center_joint=c.center_joint))
+    filler.fill_state_dict(model.state_dict())
+    x = torch.from_numpy(filler.skeleton_input(f"x.{tag}", shape, empty_second_body=(m > 1)))
+    labels = torch.from_numpy(filler.uniform(f"y.{tag}", (n,), 0, classes).astype(np.int64))
+    return model, x, labels
+
+
+def flip_bound(flips: int, decisions: int, layers: int = 20) -> float:
+    """Error a correct float32 backward may show when ``flips`` of ``decisions`` ReLU decisions differ from the oracle's: each
+    flipped element removes / adds one upstream gradient element of typical magnitude, so the relative error grows like
+    sqrt(flip fraction of one layer) (the reference's own fp32 run against its fp64 run shows the
+    same jumps, 12 flips at N = 16 -> 7.3e-4).  With no flip the bound is the arithmetic-only 1e-4."""
+    return INJECTED_TOL + FLIP_GAIN * math.sqrt(flips / (decisions / layers))
+
+
+@pytest.mark.parametrize("tag,shape,classes,gname", [("cfg1", (2, 1, 100, 20, 3), 27, "utd"),
+                                                     ("cfg2_small", (2, 2, 32, 25, 3), 60, "ntu")])
+def test_flat_gradient_with_relu_flip_accounting(golden, tag, shape, classes, gname, fgcn_math):
+    dev = torch.device("cuda:0")
+    model, x, labels = _case(tag, shape, classes, gname)
+    sd = {k: (v.detach().double().clone() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    rep = RM.gradient_parity_report(model, x.float().to(dev), labels.to(dev), x.double(), labels, sd)
+    ref_floor = float(golden("model.npz")[f"{tag}.ref_f32_vs_f64_grad_rel"])
+    frac = rep["flips"] / rep["decisions"]
+    print(f"[{tag} {fgcn_math}] logits {rep['logits_err']:.2e} loss {rep['loss_err']:.2e} | ReLU flips {rep['flips']} of "
+          f"{rep['decisions']} ({frac:.2e}) per block (g, o): {rep['flips_per_block']} | flat-grad rel-L2: plain "
+          f"{rep['err_plain']:.2e}, oracle decisions injected {rep['err_injected']:.2e} "
+          f"(reference fp32-vs-fp64 on this case: {ref_floor:.2e})")
+    assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5
+    # (i) flips are rare: only pre-activations within float32 rounding of zero can flip
+    assert frac < 2e-5, rep["flips_per_block"]
+    # (ii) arithmetic-only error
+    assert rep["err_injected"] < INJECTED_TOL, rep
+    # (iii) the rest is explained by the counted flips
+    assert rep["err_plain"] <= flip_bound(rep["flips"], rep["decisions"]), rep
+    # the north star's 1e-3 is met with a factor 100 to spare once the decisions agree; without a flip it is met as is
+    if rep["flips"] == 0:
+        assert rep["err_plain"] < INJECTED_TOL
