@@ -195,8 +195,10 @@ class ClipBatches:
         self.epoch = epoch
 
     def __len__(self) -> int:
+        """Batches per epoch, the same on every rank (a ragged tail shorter than the world size yields no batch)."""
         n = len(self.ds)
-        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+        full, tail = divmod(n, self.bs)
+        return full + int(not self.drop_last and tail >= self.world)
 
     def _order(self) -> torch.Tensor:
         n = len(self.ds)
@@ -206,13 +208,17 @@ class ClipBatches:
 
     def _shards(self) -> Iterator[torch.Tensor]:
         order = self._order()
-        for b in range(len(self)):
+        for b in range((len(order) + self.bs - 1) // self.bs if not self.drop_last else len(order) // self.bs):
             glob = order[b * self.bs:(b + 1) * self.bs]
-            if len(glob) == self.bs:
-                yield glob[shard_batch(self.bs, self.rank, self.world)]
-            else:                                   # ragged last batch: as even a split as possible, in order
-                per = (len(glob) + self.world - 1) // self.world
-                yield glob[self.rank * per:(self.rank + 1) * per]
+            if len(glob) != self.bs:
+                # ragged last batch (drop_last=False).  Every rank must step the same number of times with the same shard
+                # size: ranks average their gradients with equal weight in ONE collective, so an empty or shorter shard would
+                # hang the all-reduce or skew the mean.  The tail is trimmed to a multiple of the world size (at most
+                # world - 1 clips of the epoch are left out, none when world == 1) and skipped when nothing is left.
+                glob = glob[:len(glob) // self.world * self.world]
+                if len(glob) == 0:
+                    continue
+            yield glob[shard_batch(len(glob), self.rank, self.world)]
 
     def _out(self, feats: Dict[str, torch.Tensor]) -> Features:
         return feats[self.keys[0]] if len(self.keys) == 1 else feats

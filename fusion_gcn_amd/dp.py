@@ -19,7 +19,8 @@ import torch.distributed as dist
 class FlatGradients:
     """Flat fp32 gradient buffer for the data-parallel exchange."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], allow_unused: bool = False):
+        self.allow_unused = allow_unused
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -43,6 +44,11 @@ class FlatGradients:
         src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
+                # torch.optim skips parameters without a gradient; the flat update cannot, so an unused parameter is an
+                # error unless the caller opted into "zero gradient" semantics (weight decay / momentum still apply)
+                if not self.allow_unused:
+                    raise RuntimeError("FlatGradients.gather: a trainable parameter received no gradient this step "
+                                       "(unused in the forward?); pass allow_unused=True to treat it as a zero gradient")
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
@@ -76,5 +82,11 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """Make every replica start from rank ``src``'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    # in place on t.detach() under no_grad: that alias shares the tensor's version counter, so everything keyed on parameter
+    # versions (the blocks' cache of packed weights) sees the change; a write through ``t.data`` would not bump it
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src, group=group)
+    for m in module.modules():
+        if hasattr(m, "_wcache"):
+            m._wcache = None

@@ -26,38 +26,24 @@ class unit_tcn(_base.TemporalConv):
         self.relu = nn.ReLU()          # defined but never applied by the reference either (:46,51-52)
 
 
-class unit_gcn(_base._KernelBacked):
-    """Parameter container of the adaptive graph convolution under the 2s-AGCN names (``PA``, ``conv_a/b/d.<k>``, ``down``, ``bn``)."""
+class unit_gcn(_base.GraphConvParams):
+    """The adaptive graph convolution's parameters under the 2s-AGCN names: learned adjacency ``PA``; the constant adjacency ``A``
+    is a plain attribute, NOT part of the state dict (reference :60-62), so it follows the module through .to() / .cuda() by hand."""
+
+    ADJ_PARAM = "PA"
 
     def __init__(self, in_channels, out_channels, A, coff_embedding=4, num_subset=3):
-        super().__init__()
         if (coff_embedding, num_subset) != (4, 3):
             raise ValueError("the HIP AGCN block implements coff_embedding=4, num_subset=3")
-        adjacency = torch.from_numpy(np.asarray(A, dtype=np.float32))
-        self.num_subset, self.inter_c = num_subset, out_channels // coff_embedding
-        self.A = adjacency                                   # plain attribute: not in the state dict (reference :60-62)
-        self.PA = nn.Parameter(torch.full_like(adjacency, 1e-6))
-        self.adj_c = [None] * num_subset
-        widths = {"conv_a": self.inter_c, "conv_b": self.inter_c, "conv_d": out_channels}
-        for name, width in widths.items():
-            setattr(self, name, nn.ModuleList(nn.Conv2d(in_channels, width, 1) for _ in range(num_subset)))
-        self.down = (nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
-                     if in_channels != out_channels else (lambda x: x))
-        self.bn = nn.BatchNorm2d(out_channels)
+        super().__init__(in_channels, out_channels, torch.from_numpy(np.asarray(A, dtype=np.float32)), num_subset)
+        self.num_subset, self.inter_c = num_subset, self.embedding_channels
         self.soft, self.relu = nn.Softmax(-2), nn.ReLU()
-        # the reference's initialisation (:84-93): kaiming fan-out convs, unit BatchNorms, the output BatchNorm and PA at
-        # 1e-6, conv_d with the branch-count variance
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                conv_init(m)
-            elif isinstance(m, nn.BatchNorm2d):
-                bn_init(m, 1)
-        bn_init(self.bn, 1e-6)
-        for conv in self.conv_d:
-            conv_branch_init(conv, num_subset)
+
+    def setattr_adjacency(self, adjacency: torch.Tensor) -> None:
+        self.PA = nn.Parameter(torch.full_like(adjacency, 1e-6))
+        self.A = adjacency
 
     def _apply(self, fn, *args, **kwargs):
-        # keep the non-registered constant adjacency on the module's device (.cuda() / .to())
         out = super()._apply(fn, *args, **kwargs)
         self.A = fn(self.A)
         return out
@@ -65,26 +51,11 @@ class unit_gcn(_base._KernelBacked):
 
 class TCN_GCN_unit(_base.SpatialTemporalConv):
     _ADJ_PARAM = "gcn1.PA"
+    _GCN, _TCN = unit_gcn, unit_tcn
 
     def __init__(self, in_channels, out_channels, A, stride=1, residual=True, **kw):
-        nn.Module.__init__(self)
-        self.gcn1 = unit_gcn(in_channels, out_channels, A)
-        self.tcn1 = unit_tcn(out_channels, out_channels, stride=stride)
+        super().__init__(in_channels, out_channels, A, stride=stride, residual=residual, **kw)
         self.relu = nn.ReLU()
-        self.out_channels = out_channels
-        if not residual:
-            self.residual = lambda x: 0
-            res = "none"
-        elif (in_channels == out_channels) and (stride == 1):
-            self.residual = lambda x: x
-            res = "identity"
-        else:
-            self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
-            res = "conv"
-        self.cfg = _base.BlockConfig(cin=in_channels, cout=out_channels, stride=stride, residual=res,
-                                     has_down=in_channels != out_channels, **kw)
-        self.cfg.validate()
-        self._wcache = None
 
     def _adj_a(self) -> torch.Tensor:
         return self.gcn1.A

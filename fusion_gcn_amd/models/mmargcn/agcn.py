@@ -25,21 +25,38 @@ from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunc
 from ...util.partition_strategy import GraphPartitionStrategy
 
 
-def conv_branch_init(conv, branches):
-    weight = conv.weight
-    n, k1, k2 = weight.size(0), weight.size(1), weight.size(2)
-    nn.init.normal_(weight, 0, math.sqrt(2. / (n * k1 * k2 * branches)))
-    nn.init.constant_(conv.bias, 0)
+# ---- initialisation (reference agcn.py:18-34) -------------------------------------------------------------------------------
+# Every convolution of the network is drawn from N(0, 2 / fan) with a bias of zero; what differs is the fan: the kaiming
+# fan-out (out_channels x kernel area) everywhere, except conv_d, whose three subset branches are summed and therefore share
+# one fan (out x in x kernel height x branches).  BatchNorms are constants.  The helpers keep the reference's names.
+def _gaussian_conv(conv, fan: float) -> None:
+    with torch.no_grad():
+        conv.weight.normal_(0, math.sqrt(2.0) / math.sqrt(fan))
+        conv.bias.zero_()
 
 
 def conv_init(conv):
-    nn.init.kaiming_normal_(conv.weight, mode="fan_out")
-    nn.init.constant_(conv.bias, 0)
+    """kaiming-normal, fan-out mode: fan = out_channels x kernel positions (Conv2d and the 1-D graph models' Conv1d alike)."""
+    _gaussian_conv(conv, conv.weight.shape[0] * math.prod(conv.weight.shape[2:]))
+
+
+def conv_branch_init(conv, branches):
+    out_c, in_c, k = conv.weight.shape[:3]
+    _gaussian_conv(conv, out_c * in_c * k * branches)
 
 
 def bn_init(bn, scale):
-    nn.init.constant_(bn.weight, scale)
-    nn.init.constant_(bn.bias, 0)
+    with torch.no_grad():
+        bn.weight.fill_(scale)
+        bn.bias.zero_()
+
+
+def _identity(x):
+    return x
+
+
+def _nothing(x):
+    return 0
 
 
 class _KernelBacked(nn.Module):
@@ -51,54 +68,68 @@ class _KernelBacked(nn.Module):
 
 
 class TemporalConv(_KernelBacked):
+    """Parameters of BN(Conv2d((k, 1), stride (s, 1), 'same' padding in time)) -- no activation (reference :37-51)."""
+
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 9, stride: int = 1):
         super().__init__()
-        pad = int((kernel_size - 1) / 2)
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(pad, 0),
-                              stride=(stride, 1))
+        self.conv = nn.Conv2d(in_channels, out_channels, (kernel_size, 1), stride=(stride, 1), padding=((kernel_size - 1) // 2, 0))
         self.bn = nn.BatchNorm2d(out_channels)
         conv_init(self.conv)
         bn_init(self.bn, 1)
 
 
-class SpatialGraphConv(_KernelBacked):
-    def __init__(self, in_channels: int, out_channels: int, adj: np.ndarray, coff_embedding: int = 4,
-                 num_subsets: int = 3):
+class GraphConvParams(_KernelBacked):
+    """Parameters of the adaptive graph convolution, shared by both spellings of the model: the learned adjacency (``adj_b`` here,
+    ``PA`` in models/agcn), the three (theta, phi, W_d) 1x1 convolutions per subset, the optional channel-matching branch and
+    the output BatchNorm.  Registration order = the reference's state-dict order (:62-83); initial values = :62-63,86-94."""
+
+    ADJ_PARAM = "adj_b"
+    BRANCHES = ("conv_a", "conv_b", "conv_d")        # theta, phi (out/4 channels each), W_d (out channels)
+
+    def __init__(self, in_channels: int, out_channels: int, adjacency: torch.Tensor, num_subsets: int):
         super().__init__()
-        if coff_embedding != 4 or num_subsets != 3:
-            raise ValueError("the HIP AGCN block implements coff_embedding=4, num_subsets=3 (the reference's only use)")
-        inter_channels = out_channels // coff_embedding
-        self.inter_channels = inter_channels
-        self.num_subsets = num_subsets
-
-        self.adj_b = nn.Parameter(torch.from_numpy(adj.astype(np.float32)))
-        nn.init.constant_(self.adj_b, 1e-6)
-        self.register_buffer("adj_a", torch.from_numpy(adj.astype(np.float32)))
-        self.adj_c = [None] * self.num_subsets      # last forward's data-dependent adjacencies (metrics side output)
-
-        self.conv_a = nn.ModuleList()
-        self.conv_b = nn.ModuleList()
-        self.conv_d = nn.ModuleList()
-        for _ in range(self.num_subsets):
-            self.conv_a.append(nn.Conv2d(in_channels, inter_channels, 1))
-            self.conv_b.append(nn.Conv2d(in_channels, inter_channels, 1))
-            self.conv_d.append(nn.Conv2d(in_channels, out_channels, 1))
-
-        if in_channels != out_channels:
-            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
-        else:
-            self.down = lambda x: x
-
+        self.setattr_adjacency(adjacency)
+        self.adj_c = [None] * num_subsets            # last forward's data-dependent adjacencies (metrics side output)
+        inner = self.embedding_channels = out_channels // 4
+        for name in self.BRANCHES:
+            width = out_channels if name == "conv_d" else inner
+            setattr(self, name, nn.ModuleList(nn.Conv2d(in_channels, width, 1) for _ in range(num_subsets)))
+        self.down = (nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+                     if in_channels != out_channels else _identity)
         self.bn = nn.BatchNorm2d(out_channels)
+        self.reset_parameters(num_subsets)
 
+    def setattr_adjacency(self, adjacency: torch.Tensor) -> None:
+        setattr(self, self.ADJ_PARAM, nn.Parameter(torch.full_like(adjacency, 1e-6)))
+        self.register_buffer("adj_a", adjacency.clone())
+
+    def reset_parameters(self, num_subsets: int) -> None:
+        """One pass over the sub-modules in registration order (= the order the reference draws in), then the two overrides:
+        the output BatchNorm starts at 1e-6 (the block starts as its shortcut) and conv_d takes the branch fan."""
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 conv_init(m)
             elif isinstance(m, nn.BatchNorm2d):
                 bn_init(m, 1)
         bn_init(self.bn, 1e-6)
-        for i in range(self.num_subsets):
-            conv_branch_init(self.conv_d[i], self.num_subsets)
+        for conv in self.conv_d:
+            conv_branch_init(conv, num_subsets)
+
+
+class SpatialGraphConv(GraphConvParams):
+    def __init__(self, in_channels: int, out_channels: int, adj: np.ndarray, coff_embedding: int = 4,
+                 num_subsets: int = 3):
+        if coff_embedding != 4 or num_subsets != 3:
+            raise ValueError("the HIP AGCN block implements coff_embedding=4, num_subsets=3 (the reference's only use)")
+        super().__init__(in_channels, out_channels, torch.from_numpy(np.asarray(adj, dtype=np.float32)), num_subsets)
+        self.inter_channels, self.num_subsets = self.embedding_channels, num_subsets
+
+
+def residual_kind(in_channels: int, out_channels: int, stride: int, residual: bool) -> str:
+    """Which shortcut a block takes around gcn + tcn (reference :125-132): none / the input itself / a strided 1x1 TemporalConv."""
+    if not residual:
+        return "none"
+    return "identity" if (in_channels == out_channels and stride == 1) else "conv"
 
 
 class SpatialTemporalConv(nn.Module):
@@ -108,22 +139,18 @@ class SpatialTemporalConv(nn.Module):
     # canonical (block.py) tensor name -> attribute path; subclasses with other spellings override
     _ADJ_PARAM = "gcn1.adj_b"
 
+    _GCN, _TCN = SpatialGraphConv, TemporalConv
+
     def __init__(self, in_channels, out_channels, adj, stride=1, residual=True, static_adjacency: bool = False,
                  fused_spatial: bool = True):
         super().__init__()
-        self.gcn1 = SpatialGraphConv(in_channels, out_channels, adj)
-        self.tcn1 = TemporalConv(out_channels, out_channels, stride=stride)
+        self.gcn1 = self._GCN(in_channels, out_channels, adj)
+        self.tcn1 = self._TCN(out_channels, out_channels, stride=stride)
         self.out_channels = out_channels
-        if not residual:
-            self.residual = lambda x: 0
-            res = "none"
-        elif (in_channels == out_channels) and (stride == 1):
-            self.residual = lambda x: x
-            res = "identity"
-        else:
-            self.residual = TemporalConv(in_channels, out_channels, kernel_size=1, stride=stride)
-            res = "conv"
-        self.cfg = BlockConfig(cin=in_channels, cout=out_channels, stride=stride, residual=res,
+        kind = residual_kind(in_channels, out_channels, stride, residual)
+        self.residual = {"none": lambda: _nothing, "identity": lambda: _identity,
+                         "conv": lambda: self._TCN(in_channels, out_channels, kernel_size=1, stride=stride)}[kind]()
+        self.cfg = BlockConfig(cin=in_channels, cout=out_channels, stride=stride, residual=kind,
                                has_down=in_channels != out_channels, static_adjacency=static_adjacency,
                                fused_spatial=fused_spatial)
         self.cfg.validate()
@@ -179,6 +206,10 @@ class SpatialTemporalConv(nn.Module):
         return self.forward(xc).permute(0, 3, 1, 2)
 
 
+# (width multiplier of start_feature_size, temporal stride) of the ten blocks (reference :152-163); the first has no shortcut
+BLOCK_PLAN = ((1, 1), (1, 1), (1, 1), (1, 1), (2, 2), (2, 1), (2, 1), (4, 2), (4, 1), (4, 1))
+
+
 class Model(nn.Module):
     _BLOCK = SpatialTemporalConv
 
@@ -190,34 +221,28 @@ class Model(nn.Module):
         num_persons, _, num_joints, num_channels = data_shape
         adj = adjacency_matrix if adjacency_matrix is not None else GraphPartitionStrategy().get_adjacency_matrix_array(graph)
         self.data_bn = nn.BatchNorm1d(num_persons * num_channels * num_joints)
-        f = start_feature_size
         kw = dict(static_adjacency=static_adjacency, fused_spatial=fused_spatial)
-        self.layers = [
-            self._BLOCK(num_channels, f, adj, residual=False, **kw),
-            self._BLOCK(f, f, adj, **kw),
-            self._BLOCK(f, f, adj, **kw),
-            self._BLOCK(f, f, adj, **kw),
-            self._BLOCK(f, f * 2, adj, stride=2, **kw),
-            self._BLOCK(f * 2, f * 2, adj, **kw),
-            self._BLOCK(f * 2, f * 2, adj, **kw),
-            self._BLOCK(f * 2, f * 4, adj, stride=2, **kw),
-            self._BLOCK(f * 4, f * 4, adj, **kw),
-            self._BLOCK(f * 4, f * 4, adj, **kw),
-        ]
-        self.layers = self.layers[:min(len(self.layers), num_layers)]
-        if dropout > 0:   # reference: a Dropout after every block but the last, shifting the l<i> indices
-            for i in range(1, len(self.layers) * 2 - 1, 2):
-                self.layers.insert(i, nn.Dropout(dropout, inplace=True))
-        for layer_idx, layer in enumerate(self.layers):
-            setattr(self, f"l{layer_idx}", layer)
-        last = [l for l in self.layers if isinstance(l, SpatialTemporalConv)][-1]
-        if without_fc:
-            self.fc = None
-            self.out_channels = last.out_channels
-        else:
-            self.fc = nn.Linear(last.out_channels, num_classes)
-            nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / num_classes))
-            self.out_channels = num_classes
+        # all ten blocks are constructed (and draw their initial weights) before the list is cut to num_layers, as in the
+        # reference (:152-164): a shorter model built from the same seed then starts from the same parameters, `fc` included
+        blocks, cin = [], num_channels
+        for index, (mult, stride) in enumerate(BLOCK_PLAN):
+            blocks.append(self._BLOCK(cin, start_feature_size * mult, adj, stride=stride, residual=index > 0, **kw))
+            cin = blocks[-1].out_channels
+        blocks = blocks[:min(len(blocks), num_layers)]
+        cin = blocks[-1].out_channels
+        # reference :166-172: with dropout, an in-place Dropout sits between consecutive blocks and takes an l<i> slot of its own
+        self.layers = []
+        for blk in blocks:
+            if self.layers and dropout > 0:
+                self.layers.append(nn.Dropout(dropout, inplace=True))
+            self.layers.append(blk)
+        for slot, layer in enumerate(self.layers):
+            setattr(self, f"l{slot}", layer)
+        self.fc = None if without_fc else nn.Linear(cin, num_classes)
+        self.out_channels = cin if without_fc else num_classes
+        if self.fc is not None:
+            with torch.no_grad():
+                self.fc.weight.normal_(0, math.sqrt(2. / num_classes))
         bn_init(self.data_bn, 1)
 
     def _blocks_input(self, x: torch.Tensor) -> torch.Tensor:

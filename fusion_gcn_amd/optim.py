@@ -88,6 +88,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._check_homes()
         self.grads.gather()                   # p.grad -> the flat buffer (no copy when they already are views of it)
         g = self.param_groups[0]
         lib = _lib.load()
@@ -109,9 +110,25 @@ class FlatOptimizer(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(p)
         return loss
 
+    def _check_homes(self) -> None:
+        """Every parameter must still live in the flat buffer: a later model.to() / .float() / load_state_dict(assign=True) /
+        ``p.data = ...`` gives it new storage, and the fused update would then train an orphaned copy while the model's weights
+        stay frozen.  Pointer comparisons only (no launches).  Create the optimizer after the model's final .to() / cast."""
+        base = self.flat.data_ptr()
+        for p, v in zip(self.params, self.grads.views):
+            if p.data_ptr() != base + 4 * v.storage_offset():
+                raise _lib.FgcnError("FlatOptimizer: a parameter no longer aliases the flat parameter buffer (the model was moved, "
+                                     "cast or re-assigned after the optimizer was created); build the optimizer after the final "
+                                     ".to() / cast")
+
     # ---- torch.optim state-dict layout (per-parameter entries are views of the flat state) ---------------------------------
     def _views(self, flat: torch.Tensor):
         return [flat[v.storage_offset():v.storage_offset() + p.numel()].view_as(p) for p, v in zip(self.params, self.grads.views)]
+
+    def _slots(self):
+        """Position of every trainable parameter in ``param_groups[0]["params"]`` (frozen parameters keep their slot, stateless)."""
+        where = {id(p): i for i, p in enumerate(self.param_groups[0]["params"])}
+        return [where[id(p)] for p in self.params]
 
     def state_dict(self) -> Dict:
         """Same layout as the torch optimizer of that name: {"state": {i: {...}}, "param_groups": [...]}."""
@@ -119,11 +136,11 @@ class FlatOptimizer(torch.optim.Optimizer):
         if self.steps:
             s1 = self._views(self.state1) if self.state1 is not None else None
             s2 = self._views(self.state2) if self.state2 is not None else None
-            for i in range(len(self.params)):
+            for i, slot in enumerate(self._slots()):      # torch's layout: state index = position in param_groups[0]["params"]
                 if self.kind == "SGD":
-                    state[i] = {"momentum_buffer": s1[i].clone() if s1 is not None else None}
+                    state[slot] = {"momentum_buffer": s1[i].clone() if s1 is not None else None}
                 else:
-                    state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": s1[i].clone(), "exp_avg_sq": s2[i].clone()}
+                    state[slot] = {"step": torch.tensor(float(self.steps)), "exp_avg": s1[i].clone(), "exp_avg_sq": s2[i].clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
         group["params"] = list(range(len(self.param_groups[0]["params"])))
         return {"state": state, "param_groups": [group]}
@@ -139,8 +156,8 @@ class FlatOptimizer(torch.optim.Optimizer):
             s1 = self._views(self.state1) if self.state1 is not None else None
             s2 = self._views(self.state2) if self.state2 is not None else None
             with torch.no_grad():
-                for i in range(len(self.params)):
-                    e = st[i] if i in st else st[str(i)]
+                for i, slot in enumerate(self._slots()):
+                    e = st[slot] if slot in st else st[str(slot)]
                     if self.kind == "SGD":
                         if s1 is not None and e.get("momentum_buffer") is not None:
                             s1[i].copy_(e["momentum_buffer"])

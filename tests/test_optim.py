@@ -126,3 +126,31 @@ def test_grad_scale_is_the_data_parallel_average():
     oa.step(), ob.step()
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+
+
+def test_step_refuses_parameters_that_left_the_flat_buffer():
+    """A model moved / cast / re-assigned after the optimizer was built would keep training an orphaned copy: step() checks the
+    aliasing (pointer comparisons) and raises instead.  Frozen parameters keep torch's state-dict slot numbering."""
+    from fusion_gcn_amd._lib import FgcnError
+    from fusion_gcn_amd.optim import FlatOptimizer
+    m = small_model()
+    list(m.parameters())[1].requires_grad_(False)                 # a frozen parameter in the middle
+    opt = FlatOptimizer(m.parameters(), "SGD", 0.1, momentum=0.9)
+    assert opt._slots() == [0] + list(range(2, len(list(m.parameters()))))
+    assert opt.state_dict()["param_groups"][0]["params"] == list(range(len(list(m.parameters()))))
+    opt._check_homes()
+    p = next(m.parameters())
+    p.data = p.data.clone()
+    with pytest.raises(FgcnError, match="no longer aliases"):
+        opt.step()
+
+
+def test_unused_parameter_is_an_error_not_a_silent_zero_gradient():
+    from fusion_gcn_amd.dp import FlatGradients
+    m = small_model()
+    g = FlatGradients(m.parameters())
+    for p in list(m.parameters())[:-1]:
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match="no gradient"):
+        g.gather()
+    FlatGradients(m.parameters(), allow_unused=True).gather()
