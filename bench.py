@@ -363,8 +363,8 @@ def main():
             # a training step follows an optimizer update, so the packed / split weight forms the kernels stream are rebuilt
             # from the parameters inside every timed step (the blocks cache them per parameter version otherwise)
             for m in model.modules():
-                if hasattr(m, "_wcache") and not args.keep_packed:
-                    m._wcache = None
+                if hasattr(m, "mark_packed_stale") and not args.keep_packed:
+                    m.mark_packed_stale()
             loss = F.cross_entropy(model(x), y)
             loss.backward()
             return loss

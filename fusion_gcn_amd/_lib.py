@@ -40,6 +40,23 @@ class GramItem(C.Structure):
     _fields_ = [("c1", C.c_short), ("c2", C.c_short), ("width", C.c_short), ("mat", C.c_short)]
 
 
+class PackSeg(C.Structure):
+    """fgcn_pack_seg: one strided window of a parameter tensor inside a packed form."""
+    _fields_ = [("src", C.c_void_p), ("st_tap", C.c_longlong), ("st_k", C.c_longlong), ("st_n", C.c_longlong),
+                ("t0", C.c_int), ("tlen", C.c_int), ("k0", C.c_int), ("klen", C.c_int), ("n0", C.c_int), ("nlen", C.c_int),
+                ("tap0", C.c_int), ("tap_step", C.c_int)]
+
+
+PACK_MAX_SEG = 6            # FGCN_PACK_MAX_SEG
+PACK_MODES = {"plain": 0, "k4": 1, "split3": 2, "split3_acc": 3}       # FGCN_PACK_*
+
+
+class PackItem(C.Structure):
+    """fgcn_pack_item: one packed / split weight form = a sum of segments + the layout its consumer streams."""
+    _fields_ = [("dst", C.c_void_p), ("mode", C.c_int), ("taps", C.c_int), ("K", C.c_int), ("N", C.c_int),
+                ("kgroups", C.c_int), ("nseg", C.c_int), ("seg", PackSeg * PACK_MAX_SEG)]
+
+
 _I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); mirrors include/fgcn.h one to one
@@ -69,13 +86,16 @@ SIGNATURES = {
     "fgcn_group_mean": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_pack_split3": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fgcn_pack_weight": (_I, [_P, _P, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
+    "fgcn_pack_kgroups": (_I, [_I, _I]),
+    "fgcn_pack_units": (_LL, [_I, _I, _I, _I]),
+    "fgcn_pack_run": (_I, [_P, _P, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
     "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P, _P]),
     "fgcn_joint_mix_chunks": (_I, [_I, _I]),
     "fgcn_joint_gram": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(GramItem), _I, _P]),
     "fgcn_spatial_wgrad_chunks": (_I, [_I, _I, _I, _I]),
     "fgcn_spatial_wgrad": (_I, [_P] * 4 + [_I] * 9 + [_P]),
-    "fgcn_joint_dagg": (_I, [_P] * 5 + [_I] * 11 + [_P]),
+    "fgcn_joint_dagg": (_I, [_P] * 5 + [_I] * 11 + [_P] * 5),
     "fgcn_adj_softmax_fwd": (_I, [_P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_adj_softmax_bwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),
     "fgcn_bn_finalize": (_I, [_P, _I, _LL, _P, _P, _P, _P, _F, _F, _P, _I, _P]),

@@ -30,6 +30,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .packing import Form, PackedWeights, Seg
 
 NUM_SUBSETS = 3
 
@@ -98,92 +99,73 @@ def _pad_last(t: torch.Tensor, n: int) -> torch.Tensor:
     return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
 
 
-class PackedWeights(dict):
-    """The packed / split forms of one block's parameters, each built on first use (torch.no_grad) and kept: a math mode or
-    a block variant only pays for the forms its kernels stream (the split-bf16 mode, e.g., never touches most float32
-    forms).  ``key in W`` says whether the form exists for this block and mode; ``W.get(key)`` builds it when it does."""
-
-    def __init__(self, builders):
-        super().__init__()
-        self._builders = builders
-
-    def __missing__(self, key):
-        build = self._builders.get(key)
-        if build is None:
-            raise KeyError(key)
-        with torch.no_grad():
-            value = build()
-        self[key] = value
-        return value
-
-    def __contains__(self, key):
-        return dict.__contains__(self, key) or key in self._builders
-
-    def get(self, key, default=None):
-        return self[key] if key in self else default
-
-
 def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
-    """Reference-layout parameters -> packed (taps, K, N) matrices for rows_gemm / spatial_fwd / tconv_halo, built lazily.
-    The input-channel dimension is zero-padded from cin to cx (= cin rounded up to 4): the kernels then see a
-    cx-channel block whose extra input channel is identically zero (only the 3-channel network input pads).
-    The math mode is read once, here (the model keys its cache of packed sets on it)."""
+    """Reference-layout parameters -> the packed forms rows_gemm / spatial_fwd / tconv_halo stream, as DATA (packing.Form: the
+    logical (taps, K, N) matrix as windows of the parameter tensors + the consumer's layout); a form is materialised on first use
+    and refreshed with all the others in one launch afterwards.  The input-channel dimension is zero-padded from cin to cx (= cin
+    rounded up to 4): the kernels then see a cx-channel block whose extra input channel is identically zero (only the 3-channel
+    network input pads).  The math mode is read once, here (the block keys its set of forms on it)."""
     cin, cout, ic, cx = cfg.cin, cfg.cout, cfg.ic, cfg.cx
-    x3 = ops.get_math_mode() in ops.SPLIT_MODES       # modes whose halo kernel takes the split weight form
-    B: Dict[str, object] = {}
-    memo: Dict[str, object] = {}
+    mode = ops.get_math_mode()
+    x3 = mode in ops.SPLIT_MODES                     # modes whose halo kernel takes the split weight form
+    conv_form = "split3" if x3 else "k4"
+    F: Dict[str, Form] = {}
+    conv = lambda name: P[name].detach()             # noqa: E731  (O, I, kt, 1) contiguous: strides o: I*kt, i: kt, tap: 1
 
-    def once(name, fn):
-        if name not in memo:
-            memo[name] = fn()
-        return memo[name]
-
-    def emb_t():                                               # (6ic, cx), embedding channel order [th0 ph0 th1 ph1 th2 ph2]
-        rows = []
-        for k in range(NUM_SUBSETS):
-            rows += [P[f"gcn1.conv_a.{k}.weight"].view(ic, cin), P[f"gcn1.conv_b.{k}.weight"].view(ic, cin)]
-        return _pad_last(torch.cat(rows, 0), cx)
-
-    def d_list():
-        return [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(NUM_SUBSETS)]
+    def one_by_one(name, K_in):
+        """(1, K_in-padded, O) and its transpose from a 1x1 conv weight (O, K_in, 1, 1)"""
+        w = conv(name)
+        o = w.shape[0]
+        return ([Seg(w, st_k=1, st_n=K_in, klen=K_in, nlen=o)], [Seg(w, st_k=K_in, st_n=1, klen=o, nlen=K_in)])
 
     if not cfg.static_adjacency:
-        B["emb"] = lambda: once("emb_t", emb_t).t().contiguous().unsqueeze(0)      # (1, cx, 6ic)
-        B["emb_t"] = lambda: once("emb_t", emb_t).contiguous().unsqueeze(0)        # (1, 6ic, cx)  data-gradient form
-        B["emb_b"] = lambda: torch.cat([P[f"gcn1.conv_{g}.{k}.bias"] for k in range(NUM_SUBSETS) for g in "ab"]).contiguous()
-    B["d"] = lambda: torch.cat([w.t() for w in once("d", d_list)], 0).contiguous()               # (3cx, cout)
-    B["d4"] = lambda: ops.pack_spatial(W["d"], cx)                                              # for the fused kernel
-    B["d_t"] = lambda: torch.cat(once("d", d_list), 1).contiguous().unsqueeze(0)                # (1, cout, 3cx)
-    B["dt4"] = lambda: ops.pack_k4(torch.stack(once("d", d_list), 0).contiguous())              # (3, cout/4, cx, 4) fused backward
-    B["d_b"] = lambda: (P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]).contiguous()
-    if cfg.has_down:
-        down = lambda: once("down", lambda: _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx))   # noqa: E731
-        B["down"] = lambda: down().t().contiguous().unsqueeze(0)                                # (1, cx, cout)
-        B["down_t"] = lambda: down().contiguous().unsqueeze(0)                                  # (1, cout, cx)
-    wt = lambda: P["tcn1.conv.weight"].view(cout, cout, -1)                                     # noqa: E731  (o, c, kt)
-    B["t"] = lambda: wt().permute(2, 1, 0).contiguous()                                         # (kt, c, o)
-    B["t_t"] = lambda: wt().permute(2, 0, 1).contiguous()                                       # (kt, o, c)
-    # k-interleaved forms for the halo-tile kernel (ops.pack_conv: k-interleaved f32, or the three-way bf16 split in math
-    # mode bf16x3); a stride-2 conv runs as an even-tap and an odd-tap pass
-    if cfg.stride == 1:
-        B["t4"] = lambda: ops.pack_conv(W["t"])
-        B["t_t4"] = lambda: ops.pack_conv(W["t_t"])
+        # embedding channel order [th0 ph0 th1 ph1 th2 ph2]
+        emb = [conv(f"gcn1.conv_{g}.{k}.weight") for k in range(NUM_SUBSETS) for g in "ab"]
+        F["emb"] = Form("plain", 1, cx, 6 * ic, [Seg(w, st_k=1, st_n=cin, klen=cin, nlen=ic, n0=j * ic) for j, w in enumerate(emb)])
+        F["emb_t"] = Form("plain", 1, 6 * ic, cx, [Seg(w, st_k=cin, st_n=1, klen=ic, nlen=cin, k0=j * ic) for j, w in enumerate(emb)])
+        F["emb_b"] = Form("plain", 1, 1, 6 * ic, [Seg(P[f"gcn1.conv_{g}.{k}.bias"].detach(), st_k=0, st_n=1, klen=1, nlen=ic, n0=(2 * k + j) * ic)
+                                                   for k in range(NUM_SUBSETS) for j, g in enumerate("ab")], shape=(6 * ic,))
+    wd = [conv(f"gcn1.conv_d.{k}.weight") for k in range(NUM_SUBSETS)]
+    d_rows = [Seg(w, st_k=1, st_n=cin, klen=cin, nlen=cout, k0=k * cx) for k, w in enumerate(wd)]          # (3cx, cout)
+    F["d"] = Form("plain", 1, 3 * cx, cout, d_rows, shape=(3 * cx, cout))
+    if mode == "bf16x3" and cx % 32 == 0:            # the fused spatial kernel's form (ops.pack_spatial)
+        F["d4"] = Form("split3_acc", 1, 3 * cx, cout, d_rows)
     else:
-        for par, tag in ((0, "e"), (1, "o")):      # data gradient; forward too in bf16x3 (see temporal_fwd)
-            B[f"t_t4_{tag}"] = lambda par=par: ops.pack_conv(W["t_t"][par::2].contiguous())
+        F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
+    d_cols = [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, n0=k * cx) for k, w in enumerate(wd)]          # (1, cout, 3cx)
+    F["d_t"] = Form("plain", 1, cout, 3 * cx, d_cols)
+    F["dt4"] = Form("k4", NUM_SUBSETS, cout, cx, [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, t0=k) for k, w in enumerate(wd)])
+    # the kernel adds the sum of the three biases: overlapping segments are summed
+    F["d_b"] = Form("plain", 1, 1, cout, [Seg(P[f"gcn1.conv_d.{k}.bias"].detach(), st_k=0, st_n=1, klen=1, nlen=cout)
+                                          for k in range(NUM_SUBSETS)], shape=(cout,))
+    if cfg.has_down:
+        fwd, bwd = one_by_one("gcn1.down.0.weight", cin)
+        F["down"], F["down_t"] = Form("plain", 1, cx, cout, fwd), Form("plain", 1, cout, cx, bwd)
+    wt = conv("tcn1.conv.weight")                    # (o, c, kt, 1)
+    kt = wt.shape[2]
+    t_seg = lambda **kw: [Seg(wt, st_tap=1, st_k=kt, st_n=cout * kt, klen=cout, nlen=cout, **kw)]           # noqa: E731  (kt, c, o)
+    tt_seg = lambda **kw: [Seg(wt, st_tap=1, st_k=cout * kt, st_n=kt, klen=cout, nlen=cout, **kw)]          # noqa: E731  (kt, o, c)
+    F["t"] = Form("plain", kt, cout, cout, t_seg(tlen=kt))
+    F["t_t"] = Form("plain", kt, cout, cout, tt_seg(tlen=kt))
+    # the halo-tile kernel's forms (ops.pack_conv: k-interleaved f32, or the three-way bf16 split in the bf16 math modes); a
+    # stride-2 conv runs as an even-tap and an odd-tap pass
+    if cfg.stride == 1:
+        F["t4"] = Form(conv_form, kt, cout, cout, t_seg(tlen=kt))
+        F["t_t4"] = Form(conv_form, kt, cout, cout, tt_seg(tlen=kt))
+    else:
+        for par, tag in ((0, "e"), (1, "o")):        # data gradient; forward too in the split modes (see temporal_fwd)
+            n_par = (kt - par + 1) // 2
+            F[f"t_t4_{tag}"] = Form(conv_form, n_par, cout, cout, tt_seg(tlen=n_par, tap0=par, tap_step=2))
             if x3:
-                B[f"t4_{tag}"] = lambda par=par: ops.pack_conv(W["t"][par::2].contiguous())
+                F[f"t4_{tag}"] = Form(conv_form, n_par, cout, cout, t_seg(tlen=n_par, tap0=par, tap_step=2))
     if cfg.residual == "conv":
-        res = lambda: once("res", lambda: _pad_last(P["residual.conv.weight"].view(cout, cin), cx))   # noqa: E731
-        B["res"] = lambda: res().t().contiguous().unsqueeze(0)
-        B["res_t"] = lambda: res().contiguous().unsqueeze(0)
-    if x3:                                         # split forms of the 1x1 weights pw_gemm may route to the halo kernel
-        kdim = {"emb": cx, "emb_t": 6 * ic, "d_t": cout, "down": cx, "down_t": cout}
+        fwd, bwd = one_by_one("residual.conv.weight", cin)
+        F["res"], F["res_t"] = Form("plain", 1, cx, cout, fwd), Form("plain", 1, cout, cx, bwd)
+    if x3:                                           # split forms of the 1x1 weights pw_gemm may route to the halo kernel
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
-            if key in B and kdim[key] % 64 == 0:
-                B[key + "_s3"] = lambda key=key: ops.pack_split3(W[key])
-    W = PackedWeights(B)
-    return W
+            if key in F and F[key].K % 64 == 0:
+                F[key + "_s3"] = Form("split3", 1, F[key].K, F[key].N, F[key].segs)
+    return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
 def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Tensor, *, K: int, N: int,
@@ -215,6 +197,7 @@ def spec_dx(cin: int) -> List[dict]:
 
 
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
+GATED_SHORTCUTS = True   # identity-shortcut gradients added to dx by joint_dagg from the sign images (see block_backward)
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
@@ -477,6 +460,13 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
 
     dx = new(B, T, V, cx)
     dx_live = False      # becomes True once dx holds a valid partial sum
+    # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
+    # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
+    # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
+    gate_in_dagg = (GATED_SHORTCUTS and FUSED_DAGG and not cfg.fused_spatial_bwd and not cfg.has_down and cfg.residual == "identity"
+                    and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
+                    and d_o.numel() * 4 < 0x7FFF0000)
+    gated: List[tuple] = []
     wgrad = _WgradBranch(dev, WGRAD_SIDE_STREAM)
     bias_grad = _BiasGrads(cfg, dev, train)
 
@@ -484,6 +474,10 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     if cfg.residual == "none":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train,
                                      sign_mask=S["o_sign"])
+    elif cfg.residual == "identity" and gate_in_dagg:
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, need_db=False,
+                                     sign_mask=S["o_sign"])
+        gated.append((d_o, S["o_sign"]))           # dx += d_o * [o > 0], added by joint_dagg below
     elif cfg.residual == "identity":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
                                      sign_mask=S["o_sign"])
@@ -518,6 +512,10 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         with wgrad():
             G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
         G["gcn1.down.0.bias"] = bias_grad(dd, cout)
+    elif gate_in_dagg:
+        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
+                                     sign_mask=S["g_sign"])
+        gated.append((dg, S["g_sign"]))            # dx += dg * [g > 0]
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
                                      db_accumulate=dx_live, sign_mask=S["g_sign"])
@@ -549,7 +547,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
         dagg = new(B, T, V, c3)
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3)
         if FUSED_DAGG and x.shape[3] == cin:
-            part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live)     # dx and dA^ from one pass over dagg
+            part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
         else:
             mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
             part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])

@@ -364,11 +364,16 @@ struct DaggP {
     float* partial;
     int B, T, V, C, ld_x, ld_d, ld_dx, n_sub, mats_batched, t_chunk, accumulate;
     unsigned x_bytes, d_bytes;
+    // up to two gated addends of dx: dx += e[i] * [bit of m[i]] -- contiguous (B, T, V, C) tensors with fgcn_bn_act's sign image
+    // (the ReLU-gated gradients that reach x through the block's identity shortcuts; agcn.py:114,135)
+    const float* e[2];
+    const unsigned char* m[2];
+    int n_extra;
 };
 
 constexpr int DTS = 36;   // tile row stride: 16-byte reads of 8 consecutive rows hit 32 distinct banks
 
-template <int KS>
+template <int KS, int NE>
 __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* img = dsm;                                  // [3][k = in joint w][i = out joint v] = A^_k[v][w]
@@ -395,6 +400,16 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
     // dx rows of this workgroup's frames: offsets relative to frame t0 (no tensor-size limit on dx)
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.dx + ((long long)n * p.T + t0) * V * p.ld_dx), 0, (unsigned)((t1 - t0) * V * p.ld_dx) * 4u, 0x00020000);
+
+    // gated addends: resources over this workgroup's frames (element index relative to frame t0; C % 8 == 0 keeps the sign
+    // image byte-aligned at every frame)
+    __amdgpu_buffer_rsrc_t re[NE > 0 ? NE : 1], rm[NE > 0 ? NE : 1];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const long long e0 = ((long long)n * p.T + t0) * V * C;
+        re[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.e[i] + e0), 0, (unsigned)((t1 - t0) * V * C) * 4u, 0x00020000);
+        rm[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.m[i] + (e0 >> 3)), 0, (unsigned)((t1 - t0) * V * C) >> 3, 0x00020000);
+    }
 
     // staging: lane -> (row = lane / 8 + 8 * pass, 16-byte group lane % 8); all 32 rows are written (absent joints and
     // channels load zeros), so the tiles never hold stale data.  The global loads of a tile are issued one tile AHEAD (the x
@@ -473,6 +488,28 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            }
+            if constexpr (NE > 0) {                    // + e_i[v][c] where the sign image of m_i has the element's bit set
+                const unsigned erel = c < C ? (unsigned)(((t - t0) * V + u0) * C + c) : OOB;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    float ev[16];
+                    unsigned mb[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const bool ok = erel != OOB && u0 + dr < V;
+                        const unsigned el = erel + (unsigned)(dr * C);
+                        ev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re[i], ok ? el * 4u : OOB, 0, 0));
+                        mb[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm[i], ok ? el >> 3 : OOB, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const unsigned el = erel + (unsigned)(dr * C);
+                        old[r] += (mb[r] >> (el & 7u)) & 1u ? ev[r] : 0.f;
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -634,6 +671,24 @@ __global__ __launch_bounds__(256, 2) void spatial_wgrad_kernel(SWgradP p) {
     }
 }
 
+// sum of the nchunk per-chunk partial matrices at this thread's element: eight loads in flight, four running sums (the
+// 75-chunk walk of an 8-clip shard was a 20 us chain of dependent loads), fixed order -> bitwise reproducible
+__device__ __forceinline__ float sum_chunk_partials(const float* src, int nchunk, long long stride) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = src[(long long)(c + u) * stride];
+        s0 += x[0] + x[4];
+        s1 += x[1] + x[5];
+        s2 += x[2] + x[6];
+        s3 += x[3] + x[7];
+    }
+    for (; c < nchunk; ++c) s0 += src[(long long)c * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // One 32 x 32 thread block per (sample, subset) matrix: thread (v, w) sums its chunk partials (consecutive threads read
 // consecutive addresses), the matrix goes through LDS and every thread reduces its own column (dim -2 of the (V, V)
 // affinity).  adj_ab may be given as two addends (adj_a, adj_b) so the caller needs no separate add kernel.
@@ -650,9 +705,8 @@ __global__ __launch_bounds__(1024) void adj_softmax_fwd_kernel(const float* part
         if (in) a_hat[o] = ab;
         return;
     }
-    float s = 0.f;
     const float* src = partial + ((long long)n * nchunk * K + k) * 1024 + threadIdx.x;
-    for (int c = 0; c < nchunk; ++c) s += src[(long long)c * K * 1024];
+    float s = sum_chunk_partials(src, nchunk, (long long)K * 1024);
     s *= scale;
     S[v][w] = in ? s : -INFINITY;
     __syncthreads();
@@ -675,9 +729,8 @@ __global__ __launch_bounds__(1024) void adj_softmax_bwd_kernel(const float* part
     const int n = blockIdx.x / K, k = blockIdx.x - n * K;
     const bool in = v < V && w < V;
     const long long o = ((long long)(n * K + k) * V + v) * V + w;
-    float dc = 0.f;
     const float* src = partial + ((long long)n * nchunk * K + k) * 1024 + threadIdx.x;
-    for (int c = 0; c < nchunk; ++c) dc += src[(long long)c * K * 1024];
+    const float dc = sum_chunk_partials(src, nchunk, (long long)K * 1024);
     if (in) d_a_hat[o] = dc;
     if (!c_in || !d_s) return;
     const float cv = in ? c_in[o] : 0.f;
@@ -851,8 +904,13 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
 
 extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* mats, float* dx, float* partial,
                                int B, int T, int V, int C, int ld_x, int ld_dagg, int ld_dx, int n_subsets,
-                               int mats_batched, int t_chunk, int accumulate, void* stream) {
+                               int mats_batched, int t_chunk, int accumulate, const float* extra1,
+                               const unsigned char* mask1, const float* extra2, const unsigned char* mask2, void* stream) {
     FGCN_REQUIRE(x && dagg && mats && dx && partial, FGCN_E_BADARG, "joint_dagg: null pointer");
+    const int n_extra = extra1 ? (extra2 ? 2 : 1) : 0;
+    FGCN_REQUIRE((!extra1 || mask1) && (!extra2 || (mask2 && extra1)), FGCN_E_BADARG, "joint_dagg: a gated addend needs its sign image");
+    FGCN_REQUIRE(n_extra == 0 || (C % 8 == 0 && (long long)B * T * V * C * 4 < 0x7FFF0000ll), FGCN_E_BADARG,
+                 "joint_dagg: gated addends need C %% 8 == 0 (C=%d) and tensors below 2 GiB", C);
     FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V && C > 0 && t_chunk > 0, FGCN_E_BADARG,
                  "joint_dagg: bad sizes B=%d T=%d V=%d C=%d", B, T, V, C);
     FGCN_REQUIRE(n_subsets >= 1 && n_subsets <= 3, FGCN_E_BADARG, "joint_dagg: n_subsets=%d (1..3)", n_subsets);
@@ -867,14 +925,22 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
     p.B = B; p.T = T; p.V = V; p.C = C; p.ld_x = ld_x; p.ld_d = ld_dagg; p.ld_dx = ld_dx; p.n_sub = n_subsets;
     p.mats_batched = mats_batched; p.t_chunk = t_chunk; p.accumulate = accumulate;
     p.x_bytes = (unsigned)xb; p.d_bytes = (unsigned)db;
+    p.e[0] = extra1; p.m[0] = mask1; p.e[1] = extra2; p.m[1] = mask2; p.n_extra = n_extra;
     const size_t lds = (size_t)(3 * IMG + 4 * 2 * 32 * DTS) * sizeof(float);   // 49,152 bytes: three workgroups per CU
     dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     const int ks = (V + 3) / 4 * 2;
-    if (ks <= 10) hipLaunchKernelGGL(joint_dagg_kernel<10>, grid, dim3(256), lds, s, p);
-    else if (ks <= 12) hipLaunchKernelGGL(joint_dagg_kernel<12>, grid, dim3(256), lds, s, p);
-    else if (ks <= 14) hipLaunchKernelGGL(joint_dagg_kernel<14>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(joint_dagg_kernel<16>, grid, dim3(256), lds, s, p);
+#define FGCN_DAGG(KS_)                                                                                    \
+    do {                                                                                                  \
+        if (n_extra == 2) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2>), grid, dim3(256), lds, s, p);    \
+        else if (n_extra == 1) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 1>), grid, dim3(256), lds, s, p); \
+        else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0>), grid, dim3(256), lds, s, p);                 \
+    } while (0)
+    if (ks <= 10) FGCN_DAGG(10);
+    else if (ks <= 12) FGCN_DAGG(12);
+    else if (ks <= 14) FGCN_DAGG(14);
+    else FGCN_DAGG(16);
+#undef FGCN_DAGG
     return launch_status("joint_dagg");
 }
 

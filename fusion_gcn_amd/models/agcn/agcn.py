@@ -89,6 +89,7 @@ class Model(nn.Module):
         clips = x.size(0)
         h = self._blocks_input(x)
         self._bump_batch_counters()
+        _base.refresh_packed_weights(self)
         for i in range(1, len(_LAYERS) + 1):
             h = getattr(self, f"l{i}")(h)
         h = _base.GroupMeanFunction.apply(h.view(clips, -1, h.size(-1)))

@@ -154,7 +154,8 @@ class SpatialTemporalConv(nn.Module):
                                has_down=in_channels != out_channels, static_adjacency=static_adjacency,
                                fused_spatial=fused_spatial)
         self.cfg.validate()
-        self._wcache = None
+        self._wcache = None          # ((math mode, parameter addresses), packing.PackedWeights)
+        self._wversions = None       # parameter versions the packed contents were built from
 
     # -- tensors by canonical name ------------------------------------------------------------------------------------
     def _tensor(self, name: str) -> torch.Tensor:
@@ -181,11 +182,24 @@ class SpatialTemporalConv(nn.Module):
         return [self._tensor(bn).num_batches_tracked for bn in bn_names(self.cfg)]
 
     def _packed(self, params):
-        key = (ops.get_math_mode(),) + tuple((p.data_ptr(), p._version) for p in params)   # the packed forms depend on the mode
-        if self._wcache is None or self._wcache[0] != key:
-            P = dict(zip(param_names(self.cfg), params))
-            self._wcache = (key, pack_weights(P, self.cfg))
-        return self._wcache[1]
+        """The block's packed weight forms for the current math mode.  The set (buffers + form table) is rebuilt when a parameter
+        moved; its CONTENTS are re-packed when a parameter changed (version counters; FlatOptimizer.step and load_state_dict bump
+        them) -- by the enclosing Model for all blocks in one launch, or here for a block used on its own."""
+        mode = ops.get_math_mode()
+        where = (mode,) + tuple(p.data_ptr() for p in params)
+        if self._wcache is None or self._wcache[0] != where:
+            self._wcache = (where, pack_weights(dict(zip(param_names(self.cfg), params)), self.cfg))
+            self._wversions = None
+        W = self._wcache[1]
+        versions = tuple(p._version for p in params)
+        if self._wversions != versions or not W.fresh:
+            W.refresh()
+            self._wversions = versions
+        return W
+
+    def mark_packed_stale(self) -> None:
+        """Force a re-pack at the next forward (what an optimizer step does through the version counters)."""
+        self._wversions = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         names = param_names(self.cfg)
@@ -204,6 +218,36 @@ class SpatialTemporalConv(nn.Module):
         pad = self.cfg.cx - self.cfg.cin
         xc = (F.pad(xc, (0, pad)) if pad else xc).contiguous()
         return self.forward(xc).permute(0, 3, 1, 2)
+
+
+def refresh_packed_weights(model: nn.Module) -> None:
+    """Re-pack the weight forms of ALL blocks whose parameters changed since they were packed, in ONE launch (packing.PackPlan
+    over every live form of those blocks; the plan is cached on the model until the set of live forms changes).  Blocks that
+    have no forms yet (first forward in this math mode) build theirs lazily inside their own forward."""
+    from ...packing import PackPlan
+    mode = ops.get_math_mode()
+    stale = []
+    for blk in model.modules():
+        if not isinstance(blk, SpatialTemporalConv) or blk._wcache is None:
+            continue
+        params = [blk._tensor(n) for n in param_names(blk.cfg)]
+        if blk._wcache[0] != (mode,) + tuple(p.data_ptr() for p in params):
+            continue                                    # moved parameters / other math mode: the block rebuilds its set itself
+        versions = tuple(p._version for p in params)
+        if blk._wversions != versions:
+            stale.append((blk, versions))
+    if not stale:
+        return
+    forms = [f for blk, _ in stale for f in blk._wcache[1].live_forms()]
+    sig = (mode, tuple(id(f) for f in forms))
+    cached = getattr(model, "_pack_plan", None)
+    if cached is None or cached[0] != sig:
+        cached = (sig, PackPlan(forms))
+        model._pack_plan = cached
+    cached[1].run()
+    for blk, versions in stale:
+        blk._wcache[1].fresh = True
+        blk._wversions = versions
 
 
 # (width multiplier of start_feature_size, temporal stride) of the ten blocks (reference :152-163); the first has no shortcut
@@ -269,6 +313,7 @@ class Model(nn.Module):
         N, M, T, V, C = x.size()
         h = self._blocks_input(x)
         self._bump_batch_counters()
+        refresh_packed_weights(self)
         for layer in self.layers:
             h = layer(h)
         # (N*M, T', V, C') -> mean over (T', V) then over persons

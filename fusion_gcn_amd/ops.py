@@ -422,10 +422,20 @@ def spatial_wgrad(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *, out:
     return _reduce_slabs(partial, 1, ns * Cin, Cout, out, accumulate, conv_param)
 
 
-def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torch.Tensor, *, accumulate: bool) -> torch.Tensor:
+def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torch.Tensor, *, accumulate: bool,
+               gated: Sequence[Tuple[torch.Tensor, torch.Tensor]] = ()) -> torch.Tensor:
     """dx (+)= sum_k dagg_k . A^_k^T and the partial grams dA^_k = x^T dagg_k in one pass over dagg.
-    x (B,T,V,C), dagg (B,T,V,ns*C), mats (B or 1, ns, V, V), dx (B,T,V,>=C) -> partial (B, nchunk, ns, 32, 32)."""
+    x (B,T,V,C), dagg (B,T,V,ns*C), mats (B or 1, ns, V, V), dx (B,T,V,>=C) -> partial (B, nchunk, ns, 32, 32).
+    ``gated``: up to two (tensor, sign image) pairs added to dx where the image's bit is set (contiguous (B,T,V,C) tensors and
+    bn_act's uint8 bit image of the same element count): the ReLU-gated gradients of the block's identity shortcuts."""
     ensure_device()
+    if len(gated) > 2:
+        raise _lib.FgcnError("joint_dagg: at most two gated addends")
+    for e, m in gated:
+        _chk(e, "joint_dagg.gated")
+        if tuple(e.shape) != tuple(x.shape) or m.dtype != torch.uint8 or m.numel() * 8 != e.numel() or not m.is_cuda:
+            raise _lib.FgcnError(f"joint_dagg: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
+    ex = [(_p(e), m.data_ptr()) for e, m in gated] + [(None, None)] * (2 - len(gated))
     _chk(x, "joint_dagg.x"), _chk(dagg, "joint_dagg.dagg"), _chk(mats, "joint_dagg.mats"), _chk(dx, "joint_dagg.dx")
     B, T, V, C = x.shape
     ns = mats.shape[1]
@@ -435,7 +445,8 @@ def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torc
     nchunk = (T + chunk - 1) // chunk
     partial = torch.empty((B, nchunk, ns, 32, 32), device=x.device, dtype=torch.float32)
     check(_lib.load().fgcn_joint_dagg(_p(x), _p(dagg), _p(mats), _p(dx), _p(partial), B, T, V, C, C, ns * C, dx.shape[3], ns,
-                                      int(mats.shape[0] != 1), chunk, int(accumulate), _stream()), "fgcn_joint_dagg")
+                                      int(mats.shape[0] != 1), chunk, int(accumulate), ex[0][0], ex[0][1], ex[1][0], ex[1][1],
+                                      _stream()), "fgcn_joint_dagg")
     return partial
 
 
@@ -514,7 +525,7 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
 def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor, vec_a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
-               sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True):
+               sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
     ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass."""
@@ -534,7 +545,7 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
         sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
         reduce_sum(partials.view(tiles, -1), sums.view(-1))
     da = torch.empty_like(a)
-    if res_mode != 0 and db is None:
+    if res_mode != 0 and db is None and need_db:   # need_db=False (identity residual): the caller adds the gated gradient itself
         db = torch.empty_like(a)
     check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
                                     _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),

@@ -154,6 +154,40 @@ int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K
  * MFMA accumulator enumerates its rows. */
 int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, int acc_order, void* stream);
 
+/* All packed / split weight forms of a model in ONE launch (the step after an optimizer update re-lays-out ~250 small
+ * matrices; as separate launches they sit on the critical path of a small-batch step).  An item describes one form: the
+ * logical matrix W[tap][k][n] (taps x K x N) as the SUM of up to FGCN_PACK_MAX_SEG source segments -- segment s covers
+ * taps [t0, t0+tlen), rows [k0, k0+klen), columns [n0, n0+nlen) and reads
+ *     src[((tap-t0)*tap_step + tap0)*st_tap + (k-k0)*st_k + (n-n0)*st_n]
+ * (disjoint segments = concatenation of parameters along k or n; overlapping = their sum, e.g. conv_d's three biases; an
+ * uncovered range = zero padding of the channel count) -- and the layout written to dst:
+ *   FGCN_PACK_PLAIN       float[taps][K][N]
+ *   FGCN_PACK_K4          float[taps][ceil(K/4)][N][4]        (k-interleaved: fgcn_tconv_halo / fgcn_spatial_fwd, f32 mode)
+ *   FGCN_PACK_SPLIT3      the fgcn_pack_split3 form, acc_order 0   (unsigned short[3][taps][ceil(K/8)][N][8])
+ *   FGCN_PACK_SPLIT3_ACC  the fgcn_pack_split3 form, acc_order 1
+ * `kgroups` must equal fgcn_pack_kgroups(mode, K).  items_dev: the item table in DEVICE memory; blockmap_dev: int[2] per
+ * workgroup = (item index, index of the workgroup's first 256 units within the item), fgcn_pack_units(...) units per item
+ * (one unit = one element, float4, or 8-value split group).  The reference's counterpart is nothing: its Conv2d weights are
+ * consumed in place by ATen (agcn.py:41-42,71-73,77). */
+#define FGCN_PACK_MAX_SEG 6
+#define FGCN_PACK_PLAIN 0
+#define FGCN_PACK_K4 1
+#define FGCN_PACK_SPLIT3 2
+#define FGCN_PACK_SPLIT3_ACC 3
+typedef struct {
+    const float* src;
+    long long st_tap, st_k, st_n;
+    int t0, tlen, k0, klen, n0, nlen, tap0, tap_step;
+} fgcn_pack_seg;
+typedef struct {
+    void* dst;
+    int mode, taps, K, N, kgroups, nseg;
+    fgcn_pack_seg seg[FGCN_PACK_MAX_SEG];
+} fgcn_pack_item;
+int fgcn_pack_kgroups(int mode, int K);
+long long fgcn_pack_units(int mode, int taps, int K, int N);
+int fgcn_pack_run(const fgcn_pack_item* items_dev, const int* blockmap_dev, int n_workgroups, void* stream);
+
 /* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
  * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */
 int fgcn_pack_weight(float* dst, const float* src, int taps, int K, int N_src, int N_dst,
@@ -243,10 +277,17 @@ int fgcn_spatial_wgrad(const float* x, const float* dy, const float* mats, float
  *     dx[(n,t,v), c]        (+)= sum_k sum_w A^_k[n][v][w] * dagg[(n,t,w), k*C + c]
  *     partial[n][chunk][k][v][w] = sum_{t in chunk} sum_c x[(n,t,v), c] * dagg[(n,t,w), k*C + c]      (32x32 padded)
  *   i.e. fgcn_joint_mix_vec (dx) and fgcn_joint_gram (dA^_k = x^T dagg_k) without reading the 3*C-wide dagg twice.
- *   mats: float[B or 1][n_subsets][V][V]; partial: float[B][ceil(T/t_chunk)][n_subsets][32][32].  C % 4 == 0. */
+ *   mats: float[B or 1][n_subsets][V][V]; partial: float[B][ceil(T/t_chunk)][n_subsets][32][32].  C % 4 == 0.
+ *   extra1/mask1, extra2/mask2 (NULL or both of a pair): gated addends of dx,
+ *     dx[(n,t,v), c] += extra_i[(n,t,v), c] * [bit ((n,t,v)*C + c) of mask_i]
+ *   -- the gradients that reach x through the block's identity shortcuts (y += x before the ReLU of the graph convolution,
+ *   agcn.py:114, and + residual(x) before the block's output ReLU, agcn.py:135): extra = incoming gradient of that ReLU,
+ *   mask = fgcn_bn_act's sign image of its output; contiguous float[B][T][V][C], C % 8 == 0.  Writing them here saves the
+ *   BatchNorm-backward kernels a read-modify-write of dx each. */
 int fgcn_joint_dagg(const float* x, const float* dagg, const float* mats, float* dx, float* partial,
                     int B, int T, int V, int C, int ld_x, int ld_dagg, int ld_dx, int n_subsets,
-                    int mats_batched, int t_chunk, int accumulate, void* stream);
+                    int mats_batched, int t_chunk, int accumulate, const float* extra1, const unsigned char* mask1,
+                    const float* extra2, const unsigned char* mask2, void* stream);
 
 /* S = scale * sum_chunks partial ; C[n,k,:,w] = softmax over v ; a_hat = C + adj_a[k] + adj_b[k]   (agcn.py:84,100,106-108)
  *   c_out, a_hat: float[B][K][V][V]; adj_a (constant partition adjacency), adj_b (learned, may be NULL): float[K][V][V].

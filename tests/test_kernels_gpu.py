@@ -385,6 +385,28 @@ def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", d4, a[0]).numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("V,T,C,B,n_gated", [(25, 30, 64, 3, 2), (18, 33, 128, 2, 1), (27, 12, 256, 2, 2), (25, 301, 64, 2, 2)])
+def test_joint_dagg_adds_the_gated_shortcut_gradients(V, T, C, B, n_gated):
+    """dx = sum_k dagg_k . A^_k^T + sum_i e_i * [bit of mask_i]: the ReLU-gated gradients of the identity shortcuts (agcn.py:114,135)
+    read from bn_act's one-bit sign images, with and without accumulation; the sign images come from the real bn_act kernel."""
+    from fusion_gcn_amd import ops
+    x, a = rnd(B, T, V, C, seed=95), rnd(B, 3, V, V, seed=96, scale=0.3)
+    dagg, base = rnd(B, T, V, 3 * C, seed=97), rnd(B, T, V, C, seed=98)
+    want = torch.einsum("btwkc,bkvw->btvc", dagg.reshape(B, T, V, 3, C), a)
+    gated = []
+    ident = torch.stack([torch.zeros(C), torch.ones(C), torch.ones(C), torch.zeros(C)]).float().to(dev())   # mean 0, rstd/scale 1, shift 0
+    for i in range(n_gated):
+        e, pre = rnd(B, T, V, C, seed=100 + i), rnd(B, T, V, C, seed=110 + i)
+        out, mask = ops.bn_act(to_gpu(pre), ident, relu=True, sign_mask=True)
+        assert mask is not None
+        want = want + e * (pre.float() > 0)
+        gated.append((to_gpu(e), mask))
+    for acc in (False, True):
+        dx = to_gpu(base)
+        ops.joint_dagg(to_gpu(x), to_gpu(dagg), to_gpu(a), dx, accumulate=acc, gated=gated)
+        assert rel_l2(dx.cpu().numpy(), (want + (base if acc else 0)).numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("V,T,ic", [(25, 30, 16), (18, 33, 32), (27, 12, 64), (22, 300, 16)])
 def test_joint_gram_and_adjacency_softmax(V, T, ic):
     from fusion_gcn_amd import ops
