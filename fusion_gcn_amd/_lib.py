@@ -57,6 +57,14 @@ class PackItem(C.Structure):
                 ("kgroups", C.c_int), ("nseg", C.c_int), ("seg", PackSeg * PACK_MAX_SEG)]
 
 
+class ReduceItem(C.Structure):
+    """fgcn_reduce_item: one slab sum of a batched fgcn_reduce_multi launch."""
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("st_tap", C.c_longlong), ("st_k", C.c_longlong), ("st_n", C.c_longlong),
+                ("S", C.c_int), ("taps", C.c_int), ("K", C.c_int), ("N", C.c_int), ("K_dst", C.c_int), ("accumulate", C.c_int)]
+
+
+REDUCE_MAX_ITEMS = 8        # FGCN_REDUCE_MAX_ITEMS
+
 _I, _LL, _F, _P = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); mirrors include/fgcn.h one to one
@@ -82,6 +90,7 @@ SIGNATURES = {
     "fgcn_pw_wgrad": (_I, [_P, _P, _P] + [_I] * 11 + [_P]),
     "fgcn_reduce_sum": (_I, [_P, _P, _I, _LL, _I, _P]),
     "fgcn_reduce_sum_strided": (_I, [_P, _P, _I, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
+    "fgcn_reduce_multi": (_I, [C.POINTER(ReduceItem), _I, _P]),
     "fgcn_group_mean_splits": (_I, [_I, _I]),
     "fgcn_group_mean": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_pack_split3": (_I, [_P, _P, _I, _I, _I, _I, _P]),

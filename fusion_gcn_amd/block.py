@@ -197,7 +197,10 @@ def spec_dx(cin: int) -> List[dict]:
 
 
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
-GATED_SHORTCUTS = True   # identity-shortcut gradients added to dx by joint_dagg from the sign images (see block_backward)
+# identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
+# block_backward).  Measured neutral on MI355X (tools/probes/gated_dagg_probe.py, B = 128: the two apply kernels save 0.16 ms per
+# block, the two extra tensor reads cost joint_dagg 0.15 ms; slower at 8 clips), so off; the kernel form stays tested.
+GATED_SHORTCUTS = False
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
@@ -446,7 +449,19 @@ class _BiasGrads:
 
 def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
                    W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True):
-    """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape})."""
+    """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape}).
+    The leaf reductions of the block (weight-gradient slabs, adj_b, embedding-bias partials) are collected and issued as one
+    launch at the end, on the weight-gradient stream, before it joins the main stream (ops.deferred_reductions)."""
+    with ops.deferred_reductions() as batch:
+        wgrad = _WgradBranch(d_o.device, WGRAD_SIDE_STREAM)
+        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, wgrad)
+        with wgrad():                 # after everything both streams hold so far
+            batch.flush()
+        wgrad.join()
+    return out
+
+
+def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, wgrad: "_WgradBranch"):
     x = S["x"]
     B, T, V, cx = x.shape
     cout, ic, s = cfg.cout, cfg.ic, cfg.stride
@@ -467,7 +482,6 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and d_o.numel() * 4 < 0x7FFF0000)
     gated: List[tuple] = []
-    wgrad = _WgradBranch(dev, WGRAD_SIDE_STREAM)
     bias_grad = _BiasGrads(cfg, dev, train)
 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
@@ -554,7 +568,7 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     dx_live = True
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
     db = torch.empty_like(P["gcn1.adj_b"])
-    ops.reduce_sum(d_a_hat.view(B, -1), db.view(-1))
+    ops.reduce_sum(d_a_hat.view(B, -1), db.view(-1), leaf=True)
     G["gcn1.adj_b"] = db
 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
@@ -570,7 +584,6 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
                 lo = (2 * k + j) * ic
                 G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic]
                 G[f"gcn1.{grp}.{k}.bias"] = gb[lo:lo + ic]
-    wgrad.join()
     return (dx if need_dx else None), G
 
 

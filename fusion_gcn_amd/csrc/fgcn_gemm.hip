@@ -461,6 +461,53 @@ __global__ __launch_bounds__(1024) void reduce_sum_strided_kernel(float* dst, co
     }
 }
 
+// Several slab sums in one launch (fgcn_reduce_multi): the weight-gradient slabs, adj_b and bias-gradient partials of a block's
+// backward are leaves -- nothing in the block reads them -- so their reductions are collected and issued together at the end
+// (6-8 launches less per block; at 8 clips per GPU a launch costs as much as the sum it carries).  Item i covers workgroups
+// [first[i], first[i+1]); the arithmetic and its order are exactly reduce_sum_strided_kernel's.
+struct ReduceMultiP {
+    fgcn_reduce_item it[FGCN_REDUCE_MAX_ITEMS];
+    int first[FGCN_REDUCE_MAX_ITEMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceMultiP p) {
+    __shared__ float red[16][65];
+    int which = 0;
+#pragma unroll
+    for (int i = 1; i < FGCN_REDUCE_MAX_ITEMS; ++i)
+        if (i < p.n && (int)blockIdx.x >= p.first[i]) which = i;
+    const fgcn_reduce_item& it = p.it[which];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const long long count = (long long)it.taps * it.K * it.N;
+    const long long i = (long long)((int)blockIdx.x - p.first[which]) * 64 + x;
+    float t = 0.f;
+    if (i < count) {
+        float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = y;
+        for (; s + 7 * 16 < it.S; s += 8 * 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] += it.src[(long long)(s + 16 * k) * count + i];
+        }
+        for (int k = 0; s < it.S; s += 16, ++k) u[k] += it.src[(long long)s * count + i];
+        t = ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    }
+    red[y][x] = t;
+    __syncthreads();
+    if (y == 0 && i < count) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += red[k][x];
+        const int n = (int)(i % it.N);
+        const long long tk = i / it.N;
+        const int k = (int)(tk % it.K), tap = (int)(tk / it.K);
+        if (k < it.K_dst) {
+            float* d = it.dst + tap * it.st_tap + k * it.st_k + n * it.st_n;
+            *d = it.accumulate ? *d + a : a;
+        }
+    }
+}
+
 // FGCN_MATH_BF16X3 weights: (taps, K, N) f32 -> [part][tap][ceil(K/8)][N][8] bf16, part 0/1/2 = high / middle / low term of
 // the exact three-way split w = w_h + w_m + w_l; 8 consecutive k per (n) = one lane's B fragment of
 // v_mfma_f32_32x32x16_bf16 (16 bytes, lanes = consecutive n).  Channels beyond K are zeros.
@@ -661,6 +708,26 @@ extern "C" int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int 
     hipLaunchKernelGGL(reduce_sum_strided_kernel, dim3((unsigned)cdiv(count, 64)), dim3(64, 16), 0, (hipStream_t)stream, dst,
                        src, S, taps, K, N, K_dst, st_tap, st_k, st_n, accumulate);
     return launch_status("reduce_sum_strided");
+}
+
+extern "C" int fgcn_reduce_multi(const fgcn_reduce_item* items, int n_items, void* stream) {
+    FGCN_REQUIRE(items && n_items >= 1 && n_items <= FGCN_REDUCE_MAX_ITEMS, FGCN_E_BADARG, "reduce_multi: %d items (1..%d)",
+                 n_items, FGCN_REDUCE_MAX_ITEMS);
+    ReduceMultiP p;
+    long long blocks = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const fgcn_reduce_item& it = items[i];
+        FGCN_REQUIRE(it.dst && it.src && it.S > 0 && it.taps > 0 && it.K > 0 && it.N > 0 && it.K_dst > 0 && it.K_dst <= it.K,
+                     FGCN_E_BADARG, "reduce_multi: item %d malformed", i);
+        p.it[i] = it;
+        p.first[i] = (int)blocks;
+        blocks += cdiv((long long)it.taps * it.K * it.N, 64);
+        FGCN_REQUIRE(blocks < (1ll << 31), FGCN_E_BADARG, "reduce_multi: too much work for one grid");
+    }
+    for (int i = n_items; i <= FGCN_REDUCE_MAX_ITEMS; ++i) p.first[i] = (int)blocks;
+    p.n = n_items;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(64, 16), 0, (hipStream_t)stream, p);
+    return launch_status("reduce_multi");
 }
 
 extern "C" int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int N, int acc_order,

@@ -373,11 +373,13 @@ struct DaggP {
 
 constexpr int DTS = 36;   // tile row stride: 16-byte reads of 8 consecutive rows hit 32 distinct banks
 
-template <int KS, int NE>
-__global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
+// MB: workgroups per CU the register allocation aims at (the gated form needs ~187 VGPRs: 2; fgcn_set_tuning key 6 bit 3 forces 3)
+template <int KS, int NE, int MB = 3>
+__global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float* img = dsm;                                  // [3][k = in joint w][i = out joint v] = A^_k[v][w]
-    float* tiles = dsm + 3 * IMG;                      // [4 waves][2][32][DTS]
+    constexpr int NIMG = NE > 0 ? 4 : 3;               // + the identity (slot 3): gated addends ride the mix MFMAs
+    float* img = dsm;                                  // [NIMG][k = in joint w][i = out joint v] = A^_k[v][w]
+    float* tiles = dsm + NIMG * IMG;                   // [4 waves][2][32][DTS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -388,9 +390,10 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
     float* dt = xt + 32 * DTS;
 
     const float* msrc = p.mats + (p.mats_batched ? (long long)n * NS * V * V : 0);
-    for (int e = tid; e < 3 * IMG; e += 256) {
+    for (int e = tid; e < NIMG * IMG; e += 256) {
         const int k = e >> 10, w = (e >> 5) & 31, v = e & 31;
-        img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+        if (k < 3) img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+        else img[e] = (v == w && v < V) ? 1.f : 0.f;
     }
     __syncthreads();
 
@@ -430,6 +433,28 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
         for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<f32x4*>(&tile[(8 * ps + srow) * DTS + 4 * sg]) = v[ps];
     };
 
+    // gated addend tiles: the same staging (whole 128-byte lines), the sign-image nibble of each 16-byte group fetched beside
+    // it and applied as the tile is written to LDS; the tile then goes through the mix MFMAs against the identity image
+    auto loadg = [&](int i, int t, int c, int cw, bool valid, f32x4 (&v)[4], unsigned (&mb)[4]) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = 8 * ps + srow;
+            const bool ok = valid && row < V && 4 * sg < cw;
+            const unsigned el = (unsigned)(((t - t0) * V + row) * C + c + 4 * sg);
+            v[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(re[i], ok ? el * 4u : OOB, 0, 0));
+            mb[ps] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm[i], ok ? el >> 3 : OOB, 0, 0) >> (el & 4u);
+        }
+    };
+    auto storeg = [&](float* tile, const f32x4 (&v)[4], const unsigned (&mb)[4]) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            f32x4 g = v[ps];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (mb[ps] >> e) & 1u ? g[e] : 0.f;
+            *reinterpret_cast<f32x4*>(&tile[(8 * ps + srow) * DTS + 4 * sg]) = g;
+        }
+    };
+
     f32x16 accg[3] = {zero16(), zero16(), zero16()};
     const float* xa = xt + l31 * DTS + 4 * h;          // gram fragments: lane = joint
     const float* db = dt + l31 * DTS + 4 * h;
@@ -455,11 +480,13 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
             storet(xt, vx);
             loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, cn, cwn, nvalid, vx);
             f32x16 accx = zero16();
+            unsigned gm[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < NS) {                          // wave-uniform
                     storet(dt, vd);
                     if (k + 1 < NS) loadt(rd, fd, p.ld_d, (k + 1) * C + c0, cw, true, vd);
+                    else if (NE > 0) loadg(0, t, c0, cw, true, vd, gm);
                     else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {      // dA^_k += x chunk . dagg_k chunk^T (channels 8q + 4h + e)
@@ -472,6 +499,14 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
                     for (int s = 0; s < KS; ++s)       // dx chunk += A^_k . dagg_k chunk (joints 2s + h)
                         accx = mfma32(am[k * IMG + s * 64], dm[2 * s * DTS], accx);
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {             // dx chunk += I . (gated addend chunk)
+                storeg(dt, vd, gm);
+                if (i + 1 < NE) loadg(i + 1, t, c0, cw, true, vd, gm);
+                else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) accx = mfma32(am[3 * IMG + s * 64], dm[2 * s * DTS], accx);
             }
             // dx chunk: rows v in the registers, 32 channels on the lanes
             const int c = c0 + l31;
@@ -488,28 +523,6 @@ __global__ __launch_bounds__(256, 3) void joint_dagg_kernel(DaggP p) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) old[r] = 0.f;
-            }
-            if constexpr (NE > 0) {                    // + e_i[v][c] where the sign image of m_i has the element's bit set
-                const unsigned erel = c < C ? (unsigned)(((t - t0) * V + u0) * C + c) : OOB;
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    float ev[16];
-                    unsigned mb[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        const bool ok = erel != OOB && u0 + dr < V;
-                        const unsigned el = erel + (unsigned)(dr * C);
-                        ev[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re[i], ok ? el * 4u : OOB, 0, 0));
-                        mb[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm[i], ok ? el >> 3 : OOB, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        const unsigned el = erel + (unsigned)(dr * C);
-                        old[r] += (mb[r] >> (el & 7u)) & 1u ? ev[r] : 0.f;
-                    }
-                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -926,14 +939,17 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
     p.mats_batched = mats_batched; p.t_chunk = t_chunk; p.accumulate = accumulate;
     p.x_bytes = (unsigned)xb; p.d_bytes = (unsigned)db;
     p.e[0] = extra1; p.m[0] = mask1; p.e[1] = extra2; p.m[1] = mask2; p.n_extra = n_extra;
-    const size_t lds = (size_t)(3 * IMG + 4 * 2 * 32 * DTS) * sizeof(float);   // 49,152 bytes: three workgroups per CU
+    // 49,152 bytes (53,248 with the identity image of the gated form): three workgroups per CU
+    const size_t lds = (size_t)((n_extra ? 4 : 3) * IMG + 4 * 2 * 32 * DTS) * sizeof(float);
     dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     const int ks = (V + 3) / 4 * 2;
+    const bool three = (fgcn::tuning(6) & 8) != 0;
 #define FGCN_DAGG(KS_)                                                                                    \
     do {                                                                                                  \
-        if (n_extra == 2) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2>), grid, dim3(256), lds, s, p);    \
-        else if (n_extra == 1) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 1>), grid, dim3(256), lds, s, p); \
+        if (n_extra == 2 && three) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 3>), grid, dim3(256), lds, s, p); \
+        else if (n_extra == 2) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 2>), grid, dim3(256), lds, s, p); \
+        else if (n_extra == 1) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 1, 2>), grid, dim3(256), lds, s, p); \
         else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0>), grid, dim3(256), lds, s, p);                 \
     } while (0)
     if (ks <= 10) FGCN_DAGG(10);

@@ -176,6 +176,54 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     return part
 
 
+class ReduceBatch:
+    """Leaf reductions of a block's backward, collected and issued as ONE fgcn_reduce_multi launch per 8 items.
+
+    Inside ``with ops.deferred_reductions() as batch:`` the slab sums of the weight-gradient wrappers, and ``reduce_sum`` calls
+    marked ``leaf=True``, only record (dst, src, shape); ``batch.flush()`` launches them on the current stream.  The caller
+    must flush after every producer of the partial buffers has been enqueued on (or joined into) that stream, and must not
+    read the results before.  The batch keeps the partial buffers referenced until ``release()``."""
+
+    def __init__(self):
+        self.items: list = []
+        self.keep: list = []
+
+    def add(self, dst: torch.Tensor, src: torch.Tensor, S: int, taps: int, K: int, N: int, K_dst: int, st_tap: int, st_k: int,
+            st_n: int, accumulate: bool) -> None:
+        self.items.append(_lib.ReduceItem(dst.data_ptr(), src.data_ptr(), st_tap, st_k, st_n, S, taps, K, N, K_dst, int(accumulate)))
+        self.keep += [dst, src]
+
+    def flush(self) -> None:
+        lib = _lib.load()
+        for lo in range(0, len(self.items), _lib.REDUCE_MAX_ITEMS):
+            part = self.items[lo:lo + _lib.REDUCE_MAX_ITEMS]
+            arr = (_lib.ReduceItem * len(part))(*part)
+            check(lib.fgcn_reduce_multi(arr, len(part), _stream()), "fgcn_reduce_multi")
+        self.items = []
+
+    def release(self) -> None:
+        self.keep = []
+
+
+_reduce_batch: Optional[ReduceBatch] = None
+
+
+@contextlib.contextmanager
+def deferred_reductions():
+    """Collect leaf reductions instead of launching them one by one (see ReduceBatch); not re-entrant."""
+    global _reduce_batch
+    if _reduce_batch is not None:
+        raise _lib.FgcnError("deferred_reductions is not re-entrant")
+    batch = _reduce_batch = ReduceBatch()
+    try:
+        yield batch
+    finally:
+        _reduce_batch = None
+        if batch.items:          # an exception skipped the caller's flush: nothing may stay unreduced silently
+            batch.flush()
+        batch.release()
+
+
 def _pick_nsplit(M: int, K: int, N: int, taps: int) -> int:
     tiles = ((K + 63) // 64) * ((N + 63) // 64) * taps
     want = max(1, 2048 // tiles)
@@ -191,7 +239,7 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
     if conv_param is None:
         if out is None:
             out = torch.empty((taps, K, N), device=partial.device, dtype=torch.float32)
-        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate)
+        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate, leaf=True)
         return out
     groups, k_true = conv_param
     if groups > 1:                      # (1, groups*K_in, N) reinterpreted as (groups, K_in, N): one "tap" per group
@@ -206,6 +254,9 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
         out = torch.empty(shape, device=partial.device, dtype=torch.float32)
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise _lib.FgcnError(f"weight-gradient output must be contiguous {shape}, got {tuple(out.shape)}")
+    if _reduce_batch is not None:
+        _reduce_batch.add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
+        return out
     check(_lib.load().fgcn_reduce_sum_strided(_p(out), _p(partial), slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n,
                                               int(accumulate), _stream()), "fgcn_reduce_sum_strided")
     return out
@@ -291,13 +342,17 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
-def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
-    """dst[i] (+)= sum_s src[s, i]."""
+def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False, leaf: bool = False) -> torch.Tensor:
+    """dst[i] (+)= sum_s src[s, i].  ``leaf``: nothing reads ``dst`` before the enclosing ``deferred_reductions`` batch is flushed,
+    so the sum may ride in that batch's launch."""
     ensure_device()
     _chk(src, "reduce_sum.src"), _chk(dst, "reduce_sum.dst")
     S, count = src.shape[0], src[0].numel()
     if dst.numel() != count:
         raise _lib.FgcnError("reduce_sum: size mismatch")
+    if leaf and _reduce_batch is not None and count < (1 << 31):
+        _reduce_batch.add(dst, src, S, 1, 1, count, 1, 0, 0, 1, accumulate)
+        return dst
     check(_lib.load().fgcn_reduce_sum(_p(dst), _p(src), S, count, int(accumulate), _stream()), "fgcn_reduce_sum")
     return dst
 
@@ -373,7 +428,7 @@ def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec
               "fgcn_joint_mix_vec")
     if colsum:
         sums = torch.empty((out.shape[3],), device=inp.device, dtype=torch.float32)
-        reduce_sum(partial, sums)
+        reduce_sum(partial, sums, leaf=True)          # a bias gradient: a leaf of the backward
         return out, sums
     return out
 

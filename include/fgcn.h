@@ -147,6 +147,18 @@ int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int ac
 int fgcn_reduce_sum_strided(float* dst, const float* src, int S, int taps, int K, int N, int K_dst,
                             long long st_tap, long long st_k, long long st_n, int accumulate, void* stream);
 
+/* Up to FGCN_REDUCE_MAX_ITEMS of those slab sums in one launch (the leaf reductions of a block's backward -- weight-gradient
+ * slabs, adj_b, bias partials -- collected and issued together; same arithmetic and summation order as the single calls;
+ * a plain fgcn_reduce_sum over `count` elements is the item taps = K = K_dst = 1, N = count, st_n = 1). */
+#define FGCN_REDUCE_MAX_ITEMS 8
+typedef struct {
+    float* dst;
+    const float* src;
+    long long st_tap, st_k, st_n;
+    int S, taps, K, N, K_dst, accumulate;
+} fgcn_reduce_item;
+int fgcn_reduce_multi(const fgcn_reduce_item* items, int n_items, void* stream);
+
 /* FGCN_MATH_BF16X3 form of a packed (taps, K, N) weight: dst = unsigned short[3][taps][ceil(K/8)][N][8], part 0/1/2 the
  * high / middle / low bfloat16 term of the exact split w = w_h + w_m + w_l (channels beyond K are zeros; part 0 alone is the
  * round-to-nearest-even bfloat16 of w).  This is what fgcn_tconv_halo takes as `w4` in both bf16 math modes.  acc_order = 1 (fgcn_spatial_fwd's `wd` in that
