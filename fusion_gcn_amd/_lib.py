@@ -121,6 +121,9 @@ SIGNATURES = {
     "fgcn_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fgcn_row_softmax_fwd": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _P]),
     "fgcn_row_softmax_bwd": (_I, [_P, _P, _P, _LL, _I, _I, _F, _P]),
+    "fgcn_tmaxpool3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_tmaxpool3_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_unfold_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_optim_step": (_I, [_P, _P, _P, _P, _LL, _I, _F, _F, _F, _F, _F, _F, _F, _F, _I, _LL, _P]),
 }
 

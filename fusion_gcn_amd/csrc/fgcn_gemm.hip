@@ -469,7 +469,39 @@ struct ReduceMultiP {
     fgcn_reduce_item it[FGCN_REDUCE_MAX_ITEMS];
     int first[FGCN_REDUCE_MAX_ITEMS + 1];
     int n;
+    unsigned vec_mask;      // bit i: item i takes the few-slabs form below
 };
+
+// Few slabs, many elements (weight-gradient slabs: S = 16..64 slabs of up to 590k elements): a thread owns four consecutive
+// elements and walks the slabs itself with eight 16-byte loads in flight -- fully coalesced, no LDS, no barrier.  (The 16-way
+// slab-parallel form above is for the opposite shape, thousands of BatchNorm / bias partials of a few hundred elements; on
+// the weight-gradient slabs it ran 7x below the HBM rate: 0.45 ms per step.)  Fixed order: bitwise reproducible.
+__device__ __forceinline__ void reduce_item_vec(const fgcn_reduce_item& it, int block_local) {
+    const long long count = (long long)it.taps * it.K * it.N;
+    const long long i0 = ((long long)block_local * 1024 + threadIdx.y * 64 + threadIdx.x) * 4;
+    if (i0 >= count) return;
+    const float* src = it.src + i0;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int s = 0;
+    for (; s + 8 <= it.S; s += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long long)(s + u) * count);
+        a0 += v[0] + v[4];
+        a1 += v[1] + v[5];
+        a2 += v[2] + v[6];
+        a3 += v[3] + v[7];
+    }
+    for (; s < it.S; ++s) a0 += *reinterpret_cast<const f32x4*>(src + (long long)s * count);
+    const f32x4 a = (a0 + a1) + (a2 + a3);
+    const int n = (int)(i0 % it.N);                     // N % 4 == 0: the four elements share (tap, k)
+    const long long tk = i0 / it.N;
+    const int k = (int)(tk % it.K), tap = (int)(tk / it.K);
+    if (k >= it.K_dst) return;
+    float* d = it.dst + tap * it.st_tap + k * it.st_k + n * it.st_n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e * it.st_n] = it.accumulate ? d[e * it.st_n] + a[e] : a[e];
+}
 
 __global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceMultiP p) {
     __shared__ float red[16][65];
@@ -478,6 +510,10 @@ __global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceMultiP p) {
     for (int i = 1; i < FGCN_REDUCE_MAX_ITEMS; ++i)
         if (i < p.n && (int)blockIdx.x >= p.first[i]) which = i;
     const fgcn_reduce_item& it = p.it[which];
+    if ((p.vec_mask >> which) & 1u) {                  // block-uniform
+        reduce_item_vec(it, (int)blockIdx.x - p.first[which]);
+        return;
+    }
     const int x = threadIdx.x, y = threadIdx.y;
     const long long count = (long long)it.taps * it.K * it.N;
     const long long i = (long long)((int)blockIdx.x - p.first[which]) * 64 + x;
@@ -714,6 +750,7 @@ extern "C" int fgcn_reduce_multi(const fgcn_reduce_item* items, int n_items, voi
     FGCN_REQUIRE(items && n_items >= 1 && n_items <= FGCN_REDUCE_MAX_ITEMS, FGCN_E_BADARG, "reduce_multi: %d items (1..%d)",
                  n_items, FGCN_REDUCE_MAX_ITEMS);
     ReduceMultiP p;
+    p.vec_mask = 0;
     long long blocks = 0;
     for (int i = 0; i < n_items; ++i) {
         const fgcn_reduce_item& it = items[i];
@@ -721,7 +758,10 @@ extern "C" int fgcn_reduce_multi(const fgcn_reduce_item* items, int n_items, voi
                      FGCN_E_BADARG, "reduce_multi: item %d malformed", i);
         p.it[i] = it;
         p.first[i] = (int)blocks;
-        blocks += cdiv((long long)it.taps * it.K * it.N, 64);
+        const long long count = (long long)it.taps * it.K * it.N;
+        const bool vec = it.S <= 128 && it.N % 4 == 0 && count >= 4096 && aligned16(it.src) && count % 4 == 0;
+        if (vec) p.vec_mask |= 1u << i;
+        blocks += vec ? cdiv(count, 4096) : cdiv(count, 64);
         FGCN_REQUIRE(blocks < (1ll << 31), FGCN_E_BADARG, "reduce_multi: too much work for one grid");
     }
     for (int i = n_items; i <= FGCN_REDUCE_MAX_ITEMS; ++i) p.first[i] = (int)blocks;

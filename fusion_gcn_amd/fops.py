@@ -1,0 +1,232 @@
+"""Op-level autograd wrappers of libfgcn entry points (channels-last activations (B, T, V, C), float32).
+
+The AGCN block is one fused autograd.Function (block.py).  Models whose blocks are compositions of the same kernel families in
+other arrangements (MS-G3D: SURVEY.md section 8 row f3) are written like the reference's module code with these differentiable
+ops instead; each op is one or a few kernel launches forward and backward, nothing is computed by torch (small parameter
+re-layouts aside).  Without libfgcn / off gfx950 every op raises (ops.ensure_device).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def _rows4(t: torch.Tensor) -> torch.Tensor:
+    """(B, R, C) -> the (B, R, 1, C) view the row kernels index as (sample, frame, joint, channel)."""
+    return t.view(t.shape[0], t.shape[1], 1, t.shape[2])
+
+
+def _identity_vec(c: int, device) -> torch.Tensor:
+    v = torch.zeros((4, c), device=device, dtype=torch.float32)
+    v[1:3] = 1.0
+    return v
+
+
+class _ConvRows(torch.autograd.Function):
+    """y[(b, to, v), :] = bias + sum_j x[(b, to*ta + j*tb + tc, v), 0:K] . W[j]   (W packed (taps, K, N)); returns (y, BatchNorm
+    partial sums of y or an empty tensor).  ``zero_bias_grad``: the bias feeds a train-mode BatchNorm, its gradient is exactly
+    zero and is returned as such (the reference's autograd produces rounding noise there)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, tmap, T_out: int, stats: bool, zero_bias_grad: bool):
+        B, T, V, ld = x.shape
+        taps, K, N = w.shape
+        out = torch.empty((B, T_out, V, N), device=x.device, dtype=torch.float32)
+        if tuple(tmap) == ops.TMAP_POINTWISE:       # rows are rows: fold the node axis into the frames (node counts beyond the
+            x = x.view(B, T * V, 1, ld)             # 32-joint limit of the temporal kernels, e.g. MS-G3D's 135-node windows)
+            part = ops.rows_gemm(x, w.contiguous(), out.view(B, T * V, 1, N), K=K, N=N, bias=bias, stats=stats)
+        else:
+            part = ops.rows_gemm(x, w.contiguous(), out, K=K, N=N, tmap=tmap, bias=bias, stats=stats)
+        ctx.save_for_backward(x, w)
+        ctx.tmap, ctx.has_bias, ctx.zero_bias_grad = tmap, bias is not None, zero_bias_grad
+        if part is None:
+            part = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(part)
+        return out, part
+
+    @staticmethod
+    def backward(ctx, d_out, _d_part):
+        x, w = ctx.saved_tensors
+        taps, ta, tb, tc, td = ctx.tmap
+        _, K, N = w.shape
+        d_out = d_out.contiguous()
+        shape_out = None
+        if tuple(ctx.tmap) == ops.TMAP_POINTWISE:   # x was saved in its folded (B, T*V, 1, ld) form
+            shape_out = (d_out.shape[0], d_out.shape[1], d_out.shape[2], x.shape[3])
+            d_out = d_out.view(x.shape[0], x.shape[1], 1, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if x.shape[3] != K:
+                dx.zero_()                                           # channels beyond the K window receive nothing
+            ops.rows_gemm(d_out, w.transpose(1, 2).contiguous(), dx, K=N, N=K, tmap=(taps, td, -tb, -tc, ta))
+        if ctx.needs_input_grad[1]:
+            dw = ops.rows_wgrad(x, d_out, K=K, N=N, tmap=ctx.tmap)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, device=x.device, dtype=torch.float32) if ctx.zero_bias_grad else ops.col_sum(d_out, N)
+        if dx is not None and shape_out is not None:
+            dx = dx.view(shape_out)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_rows(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], tmap=ops.TMAP_POINTWISE, T_out: Optional[int] = None,
+              stats: bool = False, zero_bias_grad: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _ConvRows.apply(x, w, bias, tuple(tmap), x.shape[1] if T_out is None else T_out, stats, zero_bias_grad)
+
+
+class _BnAct(torch.autograd.Function):
+    """act(BatchNorm(a) [+ res]) with batch statistics from the producer's partial sums (train) or the running ones (eval)."""
+
+    @staticmethod
+    def forward(ctx, a, part, gamma, beta, running_mean, running_var, train: bool, res, relu: bool, eps: float, momentum: float):
+        C = a.shape[-1]
+        count = a.numel() // C
+        if train:
+            vec = ops.bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum=momentum, eps=eps)
+        else:
+            vec = ops.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=eps)
+        if relu:
+            out, mask = ops.bn_act(a, vec, res, None, relu=True, sign_mask=True)
+        else:
+            out, mask = ops.bn_act(a, vec, res, None, relu=False), None
+        ctx.train, ctx.relu, ctx.has_res = train, relu, res is not None
+        ctx.save_for_backward(a, vec, mask, out if (relu and mask is None) else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        a, vec, mask, out = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        da, dres, sums = ops.bn_act_bwd(d_out, out, a, vec, a if ctx.has_res else None, None, relu=ctx.relu, train=ctx.train,
+                                        res_mode=1 if ctx.has_res else 0, sign_mask=mask)
+        return da, None, sums[1], sums[0], None, None, None, (dres if ctx.has_res else None), None, None, None
+
+
+def bn_act(a: torch.Tensor, part: torch.Tensor, bn: torch.nn.Module, res: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """``bn``: an nn.BatchNorm2d used as the parameter / buffer container (its own forward is never called)."""
+    train = bn.training
+    if train:
+        bn.num_batches_tracked += 1
+    return _BnAct.apply(a, part, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, res, relu, bn.eps,
+                        0.1 if bn.momentum is None else bn.momentum)
+
+
+class _AddRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, relu: bool):
+        vec = _identity_vec(a.shape[-1], a.device)
+        if relu:
+            out, mask = ops.bn_act(a, vec, b, None, relu=True, sign_mask=True)
+        else:
+            out, mask = ops.bn_act(a, vec, b, None, relu=False), None
+        ctx.relu = relu
+        ctx.save_for_backward(a, vec, mask, out if (relu and mask is None) else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        a, vec, mask, out = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        if not ctx.relu:
+            return d_out, d_out, None
+        da, db, _ = ops.bn_act_bwd(d_out, out, a, vec, a, None, relu=True, train=False, res_mode=1, sign_mask=mask, need_sums=False)
+        return da, db, None
+
+
+def add_act(a: torch.Tensor, b: torch.Tensor, relu: bool = True) -> torch.Tensor:
+    """act(a + b) in one pass (fgcn_bn_act with identity coefficients); the backward gates both gradients from the sign image."""
+    return _AddRelu.apply(a.contiguous(), b.contiguous(), relu)
+
+
+class _NodeMix(torch.autograd.Function):
+    """Static multi-scale aggregation over the node axis: out[(b, t, v), s*C + c] = sum_u A[s*V + v, u] x[(b, t, u), c].
+
+    ``a_fm`` (Vp, Np) is the matrix in the layout the kernel contracts with: a_fm[u, v*S + s] = A[s*V + v, u], zero-padded to
+    Vp = V rounded up to 64 rows and Np = V*S rounded up to 4 columns.  The node axis goes through the feature-major image
+    (fgcn_transpose), the contraction is the row GEMM over the B*T*C feature rows with a_fm as the SHARED weight -- any number
+    of nodes (the spatial-temporal windows of MS-G3D have up to 135), unlike the <= 32-joint register kernels of the AGCN block."""
+
+    @staticmethod
+    def forward(ctx, x, a_fm, S: int):
+        B, T, V, C = x.shape
+        Vp, Np = a_fm.shape
+        x_fm = ops.transpose(x.view(B * T, V, C), Vp)                              # (BT, C, Vp), zero padding columns
+        out_fm = torch.empty((B * T, C, Np), device=x.device, dtype=torch.float32)
+        ops.rows_gemm(_rows4(x_fm), a_fm.contiguous().unsqueeze(0), _rows4(out_fm), K=Vp, N=Np)
+        out = ops.transpose_into(out_fm, V * S)                                     # (BT, V*S, C)
+        ctx.save_for_backward(x_fm, a_fm)
+        ctx.dims = (B, T, V, C, S)
+        return out.view(B, T, V, S * C)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x_fm, a_fm = ctx.saved_tensors
+        B, T, V, C, S = ctx.dims
+        Vp, Np = a_fm.shape
+        d_fm = ops.transpose(d_out.contiguous().view(B * T, V * S, C), Np)          # (BT, C, Np)
+        dx = da = None
+        if ctx.needs_input_grad[0]:
+            dx_fm = torch.empty((B * T, C, Vp), device=d_out.device, dtype=torch.float32)
+            ops.rows_gemm(_rows4(d_fm), a_fm.t().contiguous().unsqueeze(0), _rows4(dx_fm), K=Np, N=Vp)
+            dx = ops.transpose_into(dx_fm, V).view(B, T, V, C)
+        if ctx.needs_input_grad[1]:
+            da = ops.rows_wgrad(_rows4(x_fm), _rows4(d_fm), K=Vp, N=Np, wide=False)[0]
+        return dx, da, None
+
+
+def node_mix(x: torch.Tensor, a_fm: torch.Tensor, num_scales: int) -> torch.Tensor:
+    return _NodeMix.apply(x.contiguous(), a_fm, num_scales)
+
+
+def node_mix_matrix(a: torch.Tensor, num_scales: int) -> torch.Tensor:
+    """(S*V, V) stacked adjacency (differentiable: the learnable residual is part of it) -> the (Vp, Np) form ``node_mix`` takes."""
+    SV, V = a.shape
+    S = num_scales
+    assert SV == S * V
+    fm = a.view(S, V, V).permute(2, 1, 0).reshape(V, V * S)                         # [u, v*S + s] = A[s*V + v, u]
+    Vp, Np = (V + 63) // 64 * 64, (V * S + 3) // 4 * 4
+    return torch.nn.functional.pad(fm, (0, Np - V * S, 0, Vp - V))
+
+
+class _MaxPool3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride: int):
+        out, idx = ops.tmaxpool3_fwd(x, stride)
+        ctx.save_for_backward(idx)
+        ctx.T, ctx.stride = x.shape[1], stride
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (idx,) = ctx.saved_tensors
+        return ops.tmaxpool3_bwd(d_out.contiguous(), idx, ctx.T, ctx.stride), None
+
+
+def maxpool3(x: torch.Tensor, stride: int) -> torch.Tensor:
+    return _MaxPool3.apply(x.contiguous(), stride)
+
+
+class _Unfold(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, window: int, stride: int, dilation: int):
+        ctx.args = (x.shape[1], x.shape[2], window, stride, dilation)
+        return ops.unfold_windows(x, window, stride, dilation)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        T, V, window, stride, dilation = ctx.args
+        return ops.unfold_windows_bwd(d_out.contiguous(), T, V, window, stride, dilation), None, None, None
+
+
+def unfold_windows(x: torch.Tensor, window: int, stride: int, dilation: int = 1) -> torch.Tensor:
+    return _Unfold.apply(x.contiguous(), window, stride, dilation)
+
+
+def col_stats(x: torch.Tensor) -> torch.Tensor:
+    """BatchNorm partial sums of a tensor that no GEMM epilogue produced (the max-pooled branch); not differentiated (the
+    BatchNorm backward works from the tensor itself)."""
+    with torch.no_grad():
+        return ops.col_moments(x.detach().contiguous())

@@ -1,0 +1,136 @@
+"""Multi-branch temporal convolution of MS-G3D (reference torch_src/models/msg3d/ms_tcn.py:15-109).
+
+Six branches over the same input, concatenated on the channel axis, + a residual, + ReLU:
+  four:  1x1 conv -> BN -> ReLU -> (3 x 1) conv with dilation 1..4 and the block's stride -> BN
+  one:   1x1 conv -> BN -> ReLU -> (3 x 1) max pooling with the block's stride -> BN
+  one:   1x1 conv with the block's stride -> BN
+The module tree (``branches.<i>.<j>``, ``residual.{conv,bn}``) is the reference's, so checkpoints load; the sub-modules hold
+parameters only.  On the MI355X the five leading 1x1 convolutions that share the un-strided input are ONE row GEMM into a
+(B, T, V, 5 * branch) tensor with ONE fused BatchNorm + ReLU pass (BatchNorm is per channel, so the five BatchNorms are one
+over the concatenated channels); the dilated convolutions read their channel window of it (row GEMM with a temporal map
+ti = to*stride + j*dilation - dilation), the pooling branch its window through fgcn_tmaxpool3."""
+import torch
+import torch.nn as nn
+
+from ... import fops
+from .activation import activation_factory, is_relu
+from .mlp import pointwise_weight
+
+
+def temporal_weight(conv: nn.Conv2d) -> torch.Tensor:
+    """(O, I, k, 1) -> packed (k, I, O)."""
+    return conv.weight[..., 0].permute(2, 1, 0)
+
+
+def temporal_map(kernel_size: int, stride: int, dilation: int):
+    """ti = to*stride + j*dilation - pad with the reference's 'same' padding (ms_tcn.py:18)."""
+    pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+    return (kernel_size, stride, dilation, -pad, 1)
+
+
+def out_frames(T: int, stride: int) -> int:
+    return (T - 1) // stride + 1
+
+
+class _JoinedBatchNorm:
+    """Several per-channel BatchNorms applied to the channel-wise concatenation of their inputs as one: the parameters and running
+    statistics are concatenated for the kernel and the updated running statistics are split back.  (Differentiable for gamma / beta:
+    torch.cat of the parameters.)"""
+
+    def __init__(self, bns):
+        self.bns = list(bns)
+        self.training = self.bns[0].training
+        self.eps, self.momentum = self.bns[0].eps, self.bns[0].momentum
+        self.weight = torch.cat([b.weight for b in self.bns])
+        self.bias = torch.cat([b.bias for b in self.bns])
+        with torch.no_grad():
+            self.running_mean = torch.cat([b.running_mean for b in self.bns])
+            self.running_var = torch.cat([b.running_var for b in self.bns])
+        self.num_batches_tracked = 0        # counted on the members below
+
+    def scatter_running_stats(self) -> None:
+        if not self.training:
+            return
+        with torch.no_grad():
+            lo = 0
+            for b in self.bns:
+                c = b.num_features
+                b.running_mean.copy_(self.running_mean[lo:lo + c])
+                b.running_var.copy_(self.running_var[lo:lo + c])
+                b.num_batches_tracked += 1
+                lo += c
+
+
+class TemporalConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dilation=1):
+        super().__init__()
+        pad = (kernel_size + (kernel_size - 1) * (dilation - 1) - 1) // 2
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(pad, 0), stride=(stride, 1),
+                              dilation=(dilation, 1))
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def pre_bn(self, x: torch.Tensor, coff: int = 0):
+        """conv(x[..., coff:coff + in_channels]) with BatchNorm partial sums -> (y, partials)"""
+        k, s, d = self.conv.kernel_size[0], self.conv.stride[0], self.conv.dilation[0]
+        xin = x if coff == 0 and x.shape[-1] == self.conv.in_channels else x[..., coff:coff + self.conv.in_channels].contiguous()
+        return fops.conv_rows(xin, temporal_weight(self.conv), self.conv.bias, tmap=temporal_map(k, s, d),
+                              T_out=out_frames(x.shape[1], s), stats=self.bn.training, zero_bias_grad=self.bn.training)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y, part = self.pre_bn(x)
+        return fops.bn_act(y, part, self.bn)
+
+
+class MultiScale_TemporalConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilations=None, residual=True, residual_kernel_size=1,
+                 activation="relu"):
+        super().__init__()
+        dilations = [1, 2, 3, 4] if dilations is None else dilations
+        self.num_branches = len(dilations) + 2
+        assert out_channels % self.num_branches == 0, "# out channels should be multiples of # branches"
+        bc = out_channels // self.num_branches
+        self.stride, self.branch_channels = stride, bc
+
+        def head(**kw):
+            return [nn.Conv2d(in_channels, bc, kernel_size=1, padding=0, **kw), nn.BatchNorm2d(bc)]
+        self.branches = nn.ModuleList(
+            nn.Sequential(*head(), activation_factory(activation), TemporalConv(bc, bc, kernel_size=kernel_size, stride=stride, dilation=d))
+            for d in dilations)
+        self.branches.append(nn.Sequential(*head(), activation_factory(activation),
+                                           nn.MaxPool2d(kernel_size=(3, 1), stride=(stride, 1), padding=(1, 0)), nn.BatchNorm2d(bc)))
+        self.branches.append(nn.Sequential(*head(stride=(stride, 1))))
+        if not residual:
+            self.residual = lambda x: 0
+        elif in_channels == out_channels and stride == 1:
+            self.residual = lambda x: x
+        else:
+            self.residual = TemporalConv(in_channels, out_channels, kernel_size=residual_kernel_size, stride=stride)
+        self.act = activation_factory(activation)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        bc, s = self.branch_channels, self.stride
+        lead = self.branches[:-1]                       # the five branches that start with an un-strided 1x1 conv + BN + act
+        relu_heads = is_relu(lead[0][2])
+        # one GEMM + one BatchNorm/activation pass for the five heads
+        w = torch.cat([pointwise_weight(b[0]) for b in lead], dim=2)                   # (1, Cin, 5 bc)
+        bias = torch.cat([b[0].bias for b in lead])
+        joined = _JoinedBatchNorm([b[1] for b in lead])
+        h, part = fops.conv_rows(x, w, bias, stats=joined.training, zero_bias_grad=joined.training)
+        h = fops.bn_act(h, part, joined, relu=relu_heads)
+        joined.scatter_running_stats()
+        outs = []
+        for i, b in enumerate(lead[:-1]):               # dilated (3 x 1) convolutions on their channel windows
+            y, part = b[3].pre_bn(h, coff=i * bc)
+            outs.append(fops.bn_act(y, part, b[3].bn))
+        pooled = fops.maxpool3(h[..., (len(lead) - 1) * bc:].contiguous(), s)
+        outs.append(fops.bn_act(pooled, fops.col_stats(pooled) if lead[-1][4].training else pooled.new_empty(0), lead[-1][4]))
+        last = self.branches[-1]
+        y, part = fops.conv_rows(x, pointwise_weight(last[0]), last[0].bias, tmap=(1, s, 0, 0, 1), T_out=out_frames(x.shape[1], s),
+                                 stats=last[1].training, zero_bias_grad=last[1].training)
+        outs.append(fops.bn_act(y, part, last[1]))
+        out = torch.cat(outs, dim=-1)
+        res = self.residual(x)
+        relu_out = is_relu(self.act)
+        if isinstance(res, torch.Tensor):
+            return fops.add_act(out, res, relu=relu_out)
+        return fops.add_act(out, torch.zeros_like(out), relu=True) if relu_out else out

@@ -239,7 +239,10 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
     if conv_param is None:
         if out is None:
             out = torch.empty((taps, K, N), device=partial.device, dtype=torch.float32)
-        reduce_sum(partial.view(slabs, -1), out.view(-1), accumulate=accumulate, leaf=True)
+        batch = _reduce_batch if _reduce_batch is not None else ReduceBatch()
+        batch.add(out, partial, slabs, taps, K, N, K, K * N, N, 1, accumulate)       # same kernel form as the parameter layout
+        if batch is not _reduce_batch:
+            batch.flush()
         return out
     groups, k_true = conv_param
     if groups > 1:                      # (1, groups*K_in, N) reinterpreted as (groups, K_in, N): one "tap" per group
@@ -257,8 +260,9 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
     if _reduce_batch is not None:
         _reduce_batch.add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
         return out
-    check(_lib.load().fgcn_reduce_sum_strided(_p(out), _p(partial), slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n,
-                                              int(accumulate), _stream()), "fgcn_reduce_sum_strided")
+    one = ReduceBatch()          # on its own: the same kernel (its few-slabs form), one item
+    one.add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
+    one.flush()
     return out
 
 
@@ -741,3 +745,75 @@ def rows_gemm_batched(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, 
         raise _lib.FgcnError("rows_gemm_batched: a problem reaches outside its tensor")
     check(_lib.load().fgcn_rows_gemm_batched(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, rows,
                                              K, N, ld_in, ld_out, int(accumulate), _stream()), "fgcn_rows_gemm_batched")
+
+
+# ---- MS-G3D data movement -------------------------------------------------------------------------------------------------------
+def tmaxpool3_fwd(x: torch.Tensor, stride: int, coff: int = 0, C: Optional[int] = None):
+    """(3 x 1) temporal max pooling (padding 1) of the channel window [coff, coff + C) of x (B, T, V, ld) -> (out (B, T', V, C),
+    idx uint8 (B, T', V, C) = the winning tap)."""
+    ensure_device()
+    _chk(x, "tmaxpool3.x")
+    B, T, V, ld = x.shape
+    C = ld - coff if C is None else C
+    To = (T - 1) // stride + 1
+    out = torch.empty((B, To, V, C), device=x.device, dtype=torch.float32)
+    idx = torch.empty((B, To, V, C), device=x.device, dtype=torch.uint8)
+    check(_lib.load().fgcn_tmaxpool3_fwd(_p(x, coff), _p(out), idx.data_ptr(), B, T, To, V, C, ld, stride, _stream()), "fgcn_tmaxpool3_fwd")
+    return out, idx
+
+
+def tmaxpool3_bwd(dout: torch.Tensor, idx: torch.Tensor, T_in: int, stride: int, din: Optional[torch.Tensor] = None,
+                  coff: int = 0, accumulate: bool = False) -> torch.Tensor:
+    """Gradient of tmaxpool3_fwd into (the channel window at ``coff`` of) din (B, T_in, V, ld); a fresh (B, T_in, V, C) when None."""
+    ensure_device()
+    _chk(dout, "tmaxpool3_bwd.dout")
+    B, To, V, C = dout.shape
+    if din is None:
+        din = torch.empty((B, T_in, V, C), device=dout.device, dtype=torch.float32)
+    _chk(din, "tmaxpool3_bwd.din")
+    check(_lib.load().fgcn_tmaxpool3_bwd(_p(dout), idx.data_ptr(), _p(din, coff), B, T_in, To, V, C, din.shape[3], stride,
+                                         int(accumulate), _stream()), "fgcn_tmaxpool3_bwd")
+    return din
+
+
+def unfold_out_frames(T: int, window: int, stride: int, dilation: int) -> int:
+    pad = (window + (window - 1) * (dilation - 1) - 1) // 2
+    return (T + 2 * pad - dilation * (window - 1) - 1) // stride + 1
+
+
+def unfold_windows(x: torch.Tensor, window: int, stride: int, dilation: int = 1) -> torch.Tensor:
+    """x (B, T, V, C) -> (B, T', window * V, C): the frames around every stride-th frame as one node axis."""
+    ensure_device()
+    _chk(x, "unfold_windows.x")
+    B, T, V, C = x.shape
+    To = unfold_out_frames(T, window, stride, dilation)
+    out = torch.empty((B, To, window * V, C), device=x.device, dtype=torch.float32)
+    check(_lib.load().fgcn_unfold_windows(_p(x), _p(out), B, T, To, V, C, window, stride, dilation, 0, _stream()), "fgcn_unfold_windows")
+    return out
+
+
+def unfold_windows_bwd(dout: torch.Tensor, T: int, V: int, window: int, stride: int, dilation: int = 1) -> torch.Tensor:
+    ensure_device()
+    _chk(dout, "unfold_windows_bwd.dout")
+    B, To, WV, C = dout.shape
+    dx = torch.empty((B, T, V, C), device=dout.device, dtype=torch.float32)
+    check(_lib.load().fgcn_unfold_windows(_p(dout), _p(dx), B, T, To, V, C, window, stride, dilation, 1, _stream()), "fgcn_unfold_windows")
+    return dx
+
+
+def col_moments(x: torch.Tensor) -> torch.Tensor:
+    """BatchNorm partial sums of a tensor no GEMM epilogue produced: (tiles, 2, C) = per-tile (sum x, sum x*x) per channel, the
+    layout ``bn_finalize`` takes.  Runs the BatchNorm-backward reduction kernel with dout = a = x and identity statistics
+    (sum dout = sum x, sum dout * (a - 0) * 1 = sum x*x)."""
+    ensure_device()
+    _chk(x, "col_moments.x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _lib.load()
+    tiles = lib.fgcn_elem_tiles(rows)
+    vec = torch.zeros((4, C), device=x.device, dtype=torch.float32)
+    vec[1:3] = 1.0
+    partials = torch.empty((tiles, 3, C), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_bn_act_bwd_reduce(_p(x), None, None, _p(x), _p(vec), None, None, _p(partials), tiles, rows, C, 0, 0, _stream()),
+          "fgcn_bn_act_bwd_reduce")
+    return partials[:, :2].contiguous()

@@ -404,6 +404,26 @@ int fgcn_optim_step(float* params, const float* grads, float* state1, float* sta
                     float lr, float weight_decay, float grad_scale, float beta1, float beta2, float eps,
                     float momentum, float dampening, int nesterov, long long step, void* stream);
 
+/* ---- MS-G3D data movement ------------------------------------------------------------------
+ * (3 x 1) temporal max pooling with padding 1 and stride `stride` (nn.MaxPool2d((3,1), (stride,1), (1,0)) of
+ * MultiScale_TemporalConv's pooling branch, models/msg3d/ms_tcn.py:72-78):
+ *   out[(b, to, v), c] = max_j in[(b, to*stride + j - 1, v), c], j = 0..2 inside [0, T_in); idx = the winning tap (first maximum,
+ *   as torch keeps it).  `in` may be a channel window of a wider tensor (row stride ld_in); out / idx / dout are contiguous
+ *   (B, T_out, V, C), T_out = (T_in - 1) / stride + 1.  The backward is a gather: din[(b, ti, v), c] (+)= the dout of every
+ *   window that holds ti and whose winning tap is ti. */
+int fgcn_tmaxpool3_fwd(const float* in, float* out, unsigned char* idx, int B, int T_in, int T_out, int V, int C, int ld_in,
+                       int stride, void* stream);
+int fgcn_tmaxpool3_bwd(const float* dout, const unsigned char* idx, float* din, int B, int T_in, int T_out, int V, int C,
+                       int ld_in, int stride, int accumulate, void* stream);
+
+/* Temporal-window unfold (UnfoldTemporalWindows.forward, models/msg3d/ms_gtcn.py:37-45): the `window` frames around every
+ * stride-th frame become `window * V` nodes of one spatial-temporal graph,
+ *   out[(b, to, j*V + v), c] = x[(b, to*stride + j*dilation - pad, v), c]   (zeros outside [0, T)),
+ *   pad = (window + (window-1)*(dilation-1) - 1) / 2,  T_out = (T + 2 pad - dilation (window-1) - 1) / stride + 1.
+ * backward != 0: `in` is d(out) (B, T_out, window*V, C) and `out` receives dx (B, T, V, C) (a gather over the windows). */
+int fgcn_unfold_windows(const float* in, float* out, int B, int T, int T_out, int V, int C, int window, int stride,
+                        int dilation, int backward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ def fill_value_for(key: str, shape, salt: int = 0) -> np.ndarray:
         return uniform(key, shape, 0.6, 1.4, salt)
     if leaf in ("adj_b", "PA"):
         return uniform(key, shape, -0.15, 0.15, salt)
+    if leaf == "A_res":                             # MS-G3D's learnable residual adjacency (init +-1e-6 in the reference)
+        return uniform(key, shape, -0.03, 0.03, salt)
     if leaf == "bias":
         return uniform(key, shape, -0.2, 0.2, salt)
     if leaf == "weight" and len(shape) == 1:       # BatchNorm gamma

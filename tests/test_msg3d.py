@@ -1,0 +1,212 @@
+"""MS-G3D (reference torch_src/models/msg3d/*.py).
+
+CPU: the oracle (oracle/msg3d_oracle.py) against tests/golden/msg3d.npz, written by importing the reference
+(oracle/gen_golden_msg3d.py): logits, loss, every parameter-gradient norm, small gradients in full, running statistics, the
+adjacency stacks; the build's module tree must have the reference's state-dict keys in the reference's order and, from the
+same seed, the same initial values.  GPU: the HIP-backed model against the same golden vectors and the float64 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import filler
+from oracle import msg3d_oracle as O
+
+CASES = {"utd": ((2, 1, 16, 20, 3), 27), "ntu": ((2, 2, 12, 25, 3), 60)}
+# conv biases in front of a train-mode BatchNorm: analytically zero gradient (compared absolutely)
+ZERO_GRAD = (".0.bias", ".conv.bias", "out_conv.bias")
+
+
+def _graph(tag):
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.util import Graph
+    c = {"utd": utd, "ntu": ntu}[tag]
+    return Graph(c.skeleton_edges, center_joint=c.center_joint)
+
+
+def _filled_state(ref, tag):
+    """the reference's state dict (keys / shapes from the golden manifest) filled by the deterministic filler, float64"""
+    from fusion_gcn_amd.models.msg3d.msg3d import Model
+    shape, classes = CASES[tag]
+    model = Model({"skeleton": shape[1:]}, classes, _graph(tag)).double()      # filled in float64, like the reference's model was
+    filler.fill_state_dict(model.state_dict())
+    return model, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def _inputs(ref, tag):
+    shape, classes = CASES[tag]
+    x = torch.from_numpy(filler.skeleton_input(f"x.msg3d.{tag}", shape, empty_second_body=(shape[1] > 1)))
+    return x, torch.from_numpy(ref[f"{tag}.labels"])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_adjacency_stacks_match_the_reference(golden, tag):
+    ref = golden("msg3d.npz")
+    a = ref[f"{tag}.a_binary"]
+    assert np.array_equal(_graph(tag).get_adjacency_matrix().astype(np.float64), a)
+    assert np.array_equal(O.multi_scale_adjacency(a, 13).astype(np.float64), ref[f"{tag}.A_powers.sgcn1"])
+    for w in (3, 5):
+        assert np.array_equal(O.multi_scale_adjacency(O.spatial_temporal_graph(a, w), 6).astype(np.float64), ref[f"{tag}.A_scales.w{w}"])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_module_tree_has_the_references_keys_and_initial_values(golden, tag):
+    from fusion_gcn_amd.models.msg3d.msg3d import Model
+    ref = golden("msg3d.npz")
+    shape, classes = CASES[tag]
+    torch.manual_seed(1)
+    sd = Model({"skeleton": shape[1:]}, classes, _graph(tag)).state_dict()
+    assert list(sd.keys()) == [str(k) for k in ref[f"{tag}.keys"]]
+    got = np.array([[float(p.double().sum()), float((p.double() ** 2).sum())] for p in sd.values()])
+    assert np.allclose(got, ref[f"{tag}.init_fingerprint"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_oracle_matches_the_reference(golden, tag):
+    ref = golden("msg3d.npz")
+    _, sd = _filled_state(ref, tag)
+    x, labels = _inputs(ref, tag)
+    a = ref[f"{tag}.a_binary"]
+    with torch.no_grad():
+        ev = O.model_forward(x.double(), sd, a, train=False)
+    assert rel_l2(ev.numpy(), ref[f"{tag}.eval.logits"]) < 1e-10
+    logits, loss, grads, stats = O.loss_and_grads(x.double(), labels, sd, a)
+    assert rel_l2(logits.numpy(), ref[f"{tag}.train.logits"]) < 1e-10
+    assert abs(float(loss) - float(ref[f"{tag}.train.loss"])) < 1e-10
+    for k, g in grads.items():
+        want = float(ref[f"{tag}.gl2.{k}"])
+        assert abs(float(g.norm()) - want) <= 1e-8 * max(want, 1e-6), k
+        if f"{tag}.grad.{k}" in ref.files and want > 1e-9:
+            assert rel_l2(g.numpy(), ref[f"{tag}.grad.{k}"]) < 1e-8, k
+    for k in ref.files:
+        if k.startswith(f"{tag}.after."):
+            assert rel_l2(stats.updates[k[len(tag) + 7:]].numpy(), ref[k]) < 1e-10, k
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------------------------
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,C,stride", [(2, 11, 5, 16, 1), (2, 12, 25, 32, 2), (1, 7, 20, 64, 2), (3, 1, 4, 8, 1)])
+def test_temporal_max_pool_kernel(B, T, V, C, stride):
+    """fgcn_tmaxpool3 forward / backward vs nn.MaxPool2d((3,1), (stride,1), (1,0)) (ms_tcn.py:76), including ties (post-ReLU
+    zeros: torch routes the gradient to the first maximum)."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd import fops
+    x = torch.relu(rnd(B, T, V, C, seed=1)).float()                  # many exact ties at 0
+    x_ref = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)          # (B, C, T, V)
+    want = F.max_pool2d(x_ref, kernel_size=(3, 1), stride=(stride, 1), padding=(1, 0))
+    probe = rnd(*want.shape, seed=2)
+    (gx,) = torch.autograd.grad((want * probe).sum(), x_ref)
+    xg = x.to(dev()).requires_grad_(True)
+    got = fops.maxpool3(xg, stride)
+    assert torch.equal(got.detach().cpu().double(), want.detach().permute(0, 2, 3, 1))
+    (got * probe.permute(0, 2, 3, 1).float().to(dev())).sum().backward()
+    assert rel_l2(xg.grad.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,C,window,stride,dilation", [(2, 10, 5, 8, 3, 1, 1), (2, 11, 25, 4, 5, 2, 1), (1, 9, 20, 16, 3, 2, 2),
+                                                            (2, 4, 3, 4, 5, 1, 1)])
+def test_unfold_windows_kernel(B, T, V, C, window, stride, dilation):
+    from fusion_gcn_amd import fops
+    x = rnd(B, T, V, C, seed=3)
+    x_ref = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    want = O.unfold_windows(x_ref, window, stride, dilation)                      # (B, C, T', window * V)
+    probe = rnd(*want.shape, seed=4)
+    (gx,) = torch.autograd.grad((want * probe).sum(), x_ref)
+    xg = x.float().to(dev()).requires_grad_(True)
+    got = fops.unfold_windows(xg, window, stride, dilation)
+    assert torch.equal(got.detach().cpu().double(), want.detach().permute(0, 2, 3, 1).float().double())
+    (got * probe.permute(0, 2, 3, 1).float().to(dev())).sum().backward()
+    assert rel_l2(xg.grad.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,C,S", [(2, 6, 25, 4, 13), (2, 5, 75, 32, 6), (1, 3, 125, 16, 6), (2, 4, 20, 96, 13)])
+def test_node_mix_aggregation(B, T, V, C, S, fgcn_math):
+    """einsum('vu,nctu->nctv') over the stacked (S*V, V) matrix with the scales moved into the channel axis (ms_gcn.py:58-61,
+    ms_gtcn.py:118-121), for V up to the 125 nodes of a 5-frame window of a 25-joint skeleton; gradients for x and the matrix."""
+    from fusion_gcn_amd import fops
+    x, a = rnd(B, T, V, C, seed=5), rnd(S * V, V, seed=6) * 0.2
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    want = O.aggregate(xr.permute(0, 3, 1, 2), ar, S).permute(0, 2, 3, 1)         # (B, T, V, S*C)
+    probe = rnd(*want.shape, seed=7)
+    gx, ga = torch.autograd.grad((want * probe).sum(), (xr, ar))
+    xg, ag = x.float().to(dev()).requires_grad_(True), a.float().to(dev()).requires_grad_(True)
+    got = fops.node_mix(xg, fops.node_mix_matrix(ag, S), S)
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().numpy()) < 3e-6
+    (got * probe.float().to(dev())).sum().backward()
+    assert rel_l2(xg.grad.cpu().numpy(), gx.numpy()) < 3e-6
+    assert rel_l2(ag.grad.cpu().numpy(), ga.numpy()) < 2e-5
+
+
+def _gpu_model(tag):
+    from fusion_gcn_amd.models.msg3d.msg3d import Model
+    shape, classes = CASES[tag]
+    model = Model({"skeleton": shape[1:]}, classes, _graph(tag))
+    filler.fill_state_dict(model.state_dict())
+    sd = {k: (v.detach().double().clone() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    return model.to(dev()), sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_model_matches_the_reference_and_the_oracle(golden, tag, fgcn_math):
+    """Logits (eval and train) and loss against the REFERENCE's outputs; every parameter gradient against the float64 oracle (norms
+    within 1 %, the flat gradient within the ReLU-decision floor of float32); running statistics after one step."""
+    import torch.nn.functional as F
+    ref = golden("msg3d.npz")
+    model, sd = _gpu_model(tag)
+    x, labels = _inputs(ref, tag)
+    a = ref[f"{tag}.a_binary"]
+    model.eval()
+    with torch.no_grad():
+        e_eval = rel_l2(model(x.float().to(dev())).cpu().numpy(), ref[f"{tag}.eval.logits"])
+    model.train()
+    logits = model(x.float().to(dev()))
+    loss = F.cross_entropy(logits, labels.to(dev()))
+    loss.backward()
+    e_train = rel_l2(logits.detach().cpu().numpy(), ref[f"{tag}.train.logits"])
+    d_loss = abs(float(loss.detach()) - float(ref[f"{tag}.train.loss"]))
+    _, _, grads_o, stats = O.loss_and_grads(x.double(), labels, sd, a)
+    names = [n for n, _ in model.named_parameters()]
+    flat_g = torch.cat([p.grad.detach().double().flatten().cpu() for _, p in model.named_parameters()])
+    flat_o = torch.cat([grads_o[n].double().flatten() for n in names])
+    e_grad = float((flat_g - flat_o).norm() / flat_o.norm())
+    print(f"[msg3d {tag} {fgcn_math}] eval logits {e_eval:.2e}, train logits {e_train:.2e}, |loss diff| {d_loss:.2e}, flat gradient {e_grad:.2e}")
+    assert e_eval < 1e-4 and e_train < 1e-4 and d_loss < 1e-4
+    assert e_grad < 5e-3, e_grad
+    scale = max(float(g.abs().max()) for g in grads_o.values())
+    for n, p in model.named_parameters():
+        want = float(grads_o[n].norm())
+        if n.endswith(ZERO_GRAD) and not n.startswith("fc"):
+            assert float(p.grad.abs().max()) <= 1e-4 * scale, n
+        elif want > 1e-7 * scale:
+            assert abs(float(p.grad.norm()) - want) <= 2e-2 * want, (n, float(p.grad.norm()), want)
+    for k, v in stats.updates.items():
+        assert rel_l2(model.state_dict()[k].cpu().numpy(), v.numpy()) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_msg3d_resolves_through_import_model_and_loads_reference_shaped_checkpoints():
+    from fusion_gcn_amd.util.dynamic_import import import_model
+    Model = import_model("msg3d")
+    shape, classes = CASES["utd"]
+    a, b = Model({"skeleton": shape[1:]}, classes, _graph("utd")), Model({"skeleton": shape[1:]}, classes, _graph("utd"))
+    filler.fill_state_dict(a.state_dict())
+    b.load_state_dict(a.state_dict())
+    a, b = a.to(dev()).eval(), b.to(dev()).eval()
+    x = torch.from_numpy(filler.skeleton_input("x.msg3d.utd", shape)).float().to(dev())
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
