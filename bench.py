@@ -181,14 +181,23 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+TRAFFIC_RECORDS = ("r02_traffic.json", "r01_traffic.json")      # newest first
+
+
 def measured_traffic(dom, samples, math="f32"):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 correction of MI355X_MICROARCH.md applied: FETCH_SIZE counts 16-byte-per-lane
-    reads at half their bytes).  Only valid for the shape it was collected at; None otherwise."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            rec = json.load(f)[{"f32": "conv_halo_fwd", "bf16x3": "conv_halo_x3_fwd"}[math]]
-    except (OSError, KeyError, ValueError):
+    reads at half their bytes).  A STORED figure (PMC counters cannot be read from inside the benchmark process): only valid
+    for the kernel and shape it was collected at; None otherwise.  `tools/collect_profiles.sh` re-collects it."""
+    rec = None
+    for name in TRAFFIC_RECORDS:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)[{"f32": "conv_halo_fwd", "bf16x3": "conv_halo_x3_fwd"}[math]]
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if rec is None:
         return None
     if rec["channels"] != dom["channels"] or rec["frames"] != dom["frames"] or rec["samples"] != samples:
         return None
@@ -556,6 +565,11 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
                                "traffic": measured_traffic(dom, n_local * SHAPE["M"], args.math),
+                               "traffic_is": "stored rocprofv3 PMC record of this kernel at this shape (profiles/r0*_traffic.json: "
+                                             "2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run",
+                               "practical_ceiling_note": "MI355X_MICROARCH.md: tuned bf16 MFMA loops reach 1.25-1.48 PFLOP/s on random data "
+                                                         "(the chip lowers its clock to ~1.9 GHz under MFMA load); this kernel issues "
+                                                         "6 x achieved of bf16 MFMA work",
                                "peak_is": {"f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "v_mfma_f32_32x32x16_bf16 dense",
                                            "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)"}[args.math],
                                "frac_of_f32_mfma_peak": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),

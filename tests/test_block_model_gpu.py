@@ -447,3 +447,37 @@ def test_pool_and_classifier_kernels_and_graph_replay():
         graph.replay()
         torch.cuda.synchronize()
         assert float((static_out.detach() - ref).norm() / ref.norm()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_dropout_between_blocks_and_second_backward():
+    """reference Model(dropout > 0) puts an in-place nn.Dropout after every block but the last (agcn.py:166-169): the block's output is
+    overwritten in place after the block saved what its backward needs (the one-bit sign image, not the output itself), so a
+    training step must run; in eval mode dropout is the identity, so the logits equal those of the dropout-free model with the
+    same parameters; a second backward through the same graph raises a clear error instead of an opaque one."""
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    g = Graph(utd.skeleton_edges, center_joint=utd.center_joint)
+    shape = (2, 1, 24, 20, 3)
+    drop = Model(shape[1:], 27, g, dropout=0.25)
+    fill_module(drop)
+    plain = Model(shape[1:], 27, g)
+    # the Dropout modules take l<i> slots of their own: block i of the plain model is slot 2i of the dropout model
+    remap = {k: v for k, v in drop.state_dict().items()}
+    plain.load_state_dict({k.replace(f"l{int(k.split('.')[0][1:])}.", f"l{int(k.split('.')[0][1:]) // 2}.", 1) if k.startswith("l") else k: v
+                           for k, v in remap.items()})
+    drop, plain = drop.to(dev()), plain.to(dev())
+    x = torch.from_numpy(filler.skeleton_input("x.drop", shape)).float().to(dev())
+    drop.eval(), plain.eval()
+    with torch.no_grad():
+        assert torch.equal(drop(x), plain(x))
+    drop.train()
+    torch.manual_seed(0)
+    out = drop(x)
+    loss = out.square().mean()
+    loss.backward(retain_graph=True)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in drop.parameters())
+    assert float(sum(p.grad.abs().sum() for p in drop.parameters())) > 0
+    with pytest.raises(RuntimeError, match="backward ran twice"):
+        loss.backward()
