@@ -373,8 +373,13 @@ struct DaggP {
 
 constexpr int DTS = 36;   // tile row stride: 16-byte reads of 8 consecutive rows hit 32 distinct banks
 
-// MB: workgroups per CU the register allocation aims at (the gated form needs ~187 VGPRs: 2; fgcn_set_tuning key 6 bit 3 forces 3)
-template <int KS, int NE, int MB = 3>
+// MB: workgroups per CU the register allocation aims at (the gated form needs ~187 VGPRs: 2, key 6 bit 3 forces 3; the split-bf16
+// gram runs 3 per CU with 48 bytes of scratch -- measured 3-4 % faster than 2 per CU without -- and key 6 bit 3 selects 2)
+// X3: the gram dA^_k = x^T . dagg_k on the bf16 matrix pipe at f32 accuracy (math modes bf16x3 / bf16): the x chunk is split once
+// per (frame, chunk) into its three bf16 parts in registers (lane = joint, 8 consecutive channels per fragment), each dagg chunk
+// once per subset, and a 32-channel contraction is 2 x 6 v_mfma_f32_32x32x16_bf16 (384 cycles) instead of 16 f32 MFMAs (1024):
+// the f32 form of this kernel runs at about half the rate its matrix work allows and the gram is more than half of that work.
+template <int KS, int NE, int MB = 3, bool X3 = false>
 __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     constexpr int NIMG = NE > 0 ? 4 : 3;               // + the identity (slot 3): gated addends ride the mix MFMAs
@@ -481,6 +486,15 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
             loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, cn, cwn, nvalid, vx);
             f32x16 accx = zero16();
             unsigned gm[4] = {0u, 0u, 0u, 0u};
+            u32x4v xs3[2][3];                           // X3: the x chunk's gram fragments (channels 16s + 8h + j of joint l31)
+            if constexpr (X3) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xt + l31 * DTS + 16 * s2 + 8 * h);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xt + l31 * DTS + 16 * s2 + 8 * h + 4);
+                    split3_x8(a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], xs3[s2]);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < NS) {                          // wave-uniform
@@ -488,12 +502,23 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
                     if (k + 1 < NS) loadt(rd, fd, p.ld_d, (k + 1) * C + c0, cw, true, vd);
                     else if (NE > 0) loadg(0, t, c0, cw, true, vd, gm);
                     else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
+                    if constexpr (X3) {                // dA^_k += x chunk . dagg_k chunk^T, split-bf16 (channels 16s + 8h + j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {      // dA^_k += x chunk . dagg_k chunk^T (channels 8q + 4h + e)
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(xa + 8 * q);
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(db + 8 * q);
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(dt + l31 * DTS + 16 * s2 + 8 * h);
+                            const f32x4 b1 = *reinterpret_cast<const f32x4*>(dt + l31 * DTS + 16 * s2 + 8 * h + 4);
+                            u32x4v ds3[3];
+                            split3_x8(b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], ds3);
+                            accg[k] = mfma_x3_k16(xs3[s2], ds3, accg[k]);
+                        }
+                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) accg[k] = mfma32(av[e], bv[e], accg[k]);
+                        for (int q = 0; q < 4; ++q) {  // dA^_k += x chunk . dagg_k chunk^T (channels 8q + 4h + e)
+                            const f32x4 av = *reinterpret_cast<const f32x4*>(xa + 8 * q);
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(db + 8 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accg[k] = mfma32(av[e], bv[e], accg[k]);
+                        }
                     }
 #pragma unroll
                     for (int s = 0; s < KS; ++s)       // dx chunk += A^_k . dagg_k chunk (joints 2s + h)
@@ -945,11 +970,14 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
     hipStream_t s = (hipStream_t)stream;
     const int ks = (V + 3) / 4 * 2;
     const bool three = (fgcn::tuning(6) & 8) != 0;
+    const bool x3 = fgcn::math_mode() != FGCN_MATH_F32 && !(fgcn::tuning(6) & 16);   // key 6 bit 4: the f32-MFMA gram in every mode
 #define FGCN_DAGG(KS_)                                                                                    \
     do {                                                                                                  \
         if (n_extra == 2 && three) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 3>), grid, dim3(256), lds, s, p); \
         else if (n_extra == 2) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 2>), grid, dim3(256), lds, s, p); \
         else if (n_extra == 1) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 1, 2>), grid, dim3(256), lds, s, p); \
+        else if (x3 && !three) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 3, true>), grid, dim3(256), lds, s, p); \
+        else if (x3) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 2, true>), grid, dim3(256), lds, s, p); \
         else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0>), grid, dim3(256), lds, s, p);                 \
     } while (0)
     if (ks <= 10) FGCN_DAGG(10);
