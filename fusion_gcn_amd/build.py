@@ -45,15 +45,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > lib_m for f in sources() + _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out_dir: str = None) -> str:
+    """Compile every csrc/*.hip for gfx950 and link libfgcn.so.  Default: incremental, in-tree.  ``out_dir``: a from-scratch build
+    of all sources into that directory (objects and library), leaving the in-tree library alone -- what a fresh clone does
+    (tests/test_abi.py::test_fresh_build_from_sources)."""
+    obj_dir, lib = (OBJ, LIB) if out_dir is None else (out_dir, os.path.join(out_dir, "libfgcn.so"))
+    force = force or out_dir is not None
     if not force and not needs_build():
         return LIB
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     dep_m = max(os.path.getmtime(f) for f in _deps())
 
     def compile_one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), dep_m):
             return obj
         cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
@@ -66,13 +71,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources()))
-    tmp = LIB + ".tmp"
+    tmp = lib + ".tmp"
     r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, lib)
+    return lib
 
 
 if __name__ == "__main__":

@@ -19,10 +19,36 @@ def _rows4(t: torch.Tensor) -> torch.Tensor:
     return t.view(t.shape[0], t.shape[1], 1, t.shape[2])
 
 
+_identity_vecs = {}
+
+
 def _identity_vec(c: int, device) -> torch.Tensor:
-    v = torch.zeros((4, c), device=device, dtype=torch.float32)
-    v[1:3] = 1.0
+    """(4, C) = {mean 0, rstd 1, scale 1, shift 0}: fgcn_bn_act's coefficients of a tensor without a BatchNorm (read-only, cached)."""
+    key = (c, str(device))
+    v = _identity_vecs.get(key)
+    if v is None:
+        v = torch.zeros((4, c), device=device, dtype=torch.float32)
+        v[1:3] = 1.0
+        _identity_vecs[key] = v
     return v
+
+
+class deferred_batch_counters:
+    """``with deferred_batch_counters() as counters: ...``: the ``num_batches_tracked += 1`` of every BatchNorm that ``bn_act`` runs in
+    train mode inside the block is collected and issued as ONE multi-tensor add at exit (117 scalar-add launches per MS-G3D step
+    otherwise)."""
+    active = None
+
+    def __enter__(self):
+        self.buffers = []
+        deferred_batch_counters.active = self
+        return self
+
+    def __exit__(self, *exc):
+        deferred_batch_counters.active = None
+        if self.buffers and exc[0] is None:
+            torch._foreach_add_(self.buffers, 1)
+        return False
 
 
 class _ConvRows(torch.autograd.Function):
@@ -108,8 +134,11 @@ class _BnAct(torch.autograd.Function):
 def bn_act(a: torch.Tensor, part: torch.Tensor, bn: torch.nn.Module, res: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """``bn``: an nn.BatchNorm2d used as the parameter / buffer container (its own forward is never called)."""
     train = bn.training
-    if train:
-        bn.num_batches_tracked += 1
+    if train and isinstance(bn.num_batches_tracked, torch.Tensor):
+        if deferred_batch_counters.active is not None:
+            deferred_batch_counters.active.buffers.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     return _BnAct.apply(a, part, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, res, relu, bn.eps,
                         0.1 if bn.momentum is None else bn.momentum)
 

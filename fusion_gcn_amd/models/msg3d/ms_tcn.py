@@ -57,7 +57,10 @@ class _JoinedBatchNorm:
                 c = b.num_features
                 b.running_mean.copy_(self.running_mean[lo:lo + c])
                 b.running_var.copy_(self.running_var[lo:lo + c])
-                b.num_batches_tracked += 1
+                if fops.deferred_batch_counters.active is not None:
+                    fops.deferred_batch_counters.active.buffers.append(b.num_batches_tracked)
+                else:
+                    b.num_batches_tracked += 1
                 lo += c
 
 

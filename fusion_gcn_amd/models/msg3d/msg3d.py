@@ -21,7 +21,6 @@ from .mlp import MLP
 from .ms_gcn import MultiScale_GraphConv as MS_GCN
 from .ms_gtcn import SpatialTemporal_MS_GCN, UnfoldTemporalWindows
 from .ms_tcn import MultiScale_TemporalConv as MS_TCN
-from .ms_tcn import out_frames
 
 INPUT_CHANNELS = 3        # the reference singles the first block out by its 3 input channels (msg3d.py:38-39)
 
@@ -105,9 +104,10 @@ class Model(nn.Module):
         h = self.data_bn(x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T))
         h = h.view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)      # channels-last (B, T, V, C)
         h = F.pad(h, (0, (-C) % 4)).contiguous()                                      # 3 input channels travel as 4 (4th zero)
-        for i in range(1, len(_STAGES) + 1):
-            s = getattr(self, f"sgcn{i}")(h)
-            g = getattr(self, f"gcn3d{i}")(h)
-            h = getattr(self, f"tcn{i}")(fops.add_act(s, g, relu=True))
+        with fops.deferred_batch_counters():                                          # one multi-tensor add for all BatchNorm counters
+            for i in range(1, len(_STAGES) + 1):
+                s = getattr(self, f"sgcn{i}")(h)
+                g = getattr(self, f"gcn3d{i}")(h)
+                h = getattr(self, f"tcn{i}")(fops.add_act(s, g, relu=True))
         h = GroupMeanFunction.apply(h.reshape(N, -1, h.size(-1)))                     # mean over persons, frames and joints
         return LinearFunction.apply(h.contiguous(), self.fc.weight, self.fc.bias)

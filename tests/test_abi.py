@@ -82,3 +82,16 @@ def test_ops_fail_loudly_without_gpu():
     x = torch.zeros(1, 2, 5, 4)
     with pytest.raises(_lib.FgcnError):
         ops.rows_gemm(x, torch.zeros(1, 4, 4), torch.zeros(1, 2, 5, 4), K=4, N=4)
+
+
+def test_fresh_build_from_sources(tmp_path):
+    """What a fresh clone does: every csrc/*.hip compiled from scratch for gfx950 (hipcc cross-compiles without a GPU) into an empty
+    directory -- no prebuilt object or library of the tree is used -- and the result exports every symbol the header declares."""
+    lib_path = build.build(out_dir=str(tmp_path))
+    assert os.path.dirname(lib_path) == str(tmp_path) and os.path.getsize(lib_path) > 100_000
+    objs = [f for f in os.listdir(tmp_path) if f.endswith(".o")]
+    assert len(objs) == len(build.sources())
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
+    for n in _declared_symbols():
+        assert re.search(rf"\bT {n}\b", exported), f"fresh build does not export {n}"
