@@ -38,6 +38,10 @@ struct SpatialP {
     int B, T, V, Cin, Cout, ld_x, ld_y, ns, a_batched, t_chunk;
     unsigned x_bytes, w_bytes;
     unsigned w_plane_bytes;   // FGCN_MATH_BF16X3: bytes of one part of the split weights
+    // per_xcd > 0 (spatial_fwd_x3_kernel): 1-D grid in XCD-aware order, column block fastest -- the Cout / 64 column blocks of one
+    // (sample, frame chunk) re-read the same x rows; run back to back on one XCD they find them in its L2 (id b -> virtual
+    // workgroup (b % 8) * per_xcd + b / 8, consecutive ids go round-robin over the 8 XCDs)
+    int per_xcd, nchunk, ncol;
 };
 
 constexpr int TTS = 36;   // row stride of the per-wave transpose tile (32 channels + 4 pad)
@@ -319,9 +323,18 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int n = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.per_xcd > 0) {
+        const int vid = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+        if (vid >= p.nchunk * p.B * p.ncol) return;
+        bz = vid % p.ncol;
+        const int rest = vid / p.ncol;
+        bx = rest % p.nchunk;
+        by = rest / p.nchunk;
+    }
+    const int n = by;
     const int V = p.V, NS = p.ns;
-    const int t0 = blockIdx.x * p.t_chunk;
+    const int t0 = bx * p.t_chunk;
     const int t1 = min(t0 + p.t_chunk, p.T);
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
         d[2 * 32 * AHB / 2] = (unsigned short)pl;
     }
     for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
-    const int ob = blockIdx.z * WROW;
+    const int ob = bz * WROW;
     for (int i = tid; i < WROW; i += 256) bl[i] = (p.bias && ob + i < p.Cout) ? p.bias[ob + i] : 0.f;
     __syncthreads();
 
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
 
     if (p.stats) {
         __syncthreads();
-        const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long wg = (long long)by * (p.per_xcd > 0 ? p.nchunk : (int)gridDim.x) + bx;
         for (int i = tid; i < 2 * WROW; i += 256) {
             const int which = i / WROW, o = i - which * WROW;
             if (ob + o < p.Cout)
@@ -520,7 +533,16 @@ template <int CI>
 static void launch_spatial_x3(const SpatialP& p, hipStream_t s) {
     const size_t lds = (size_t)9 * 32 * AHB + (4 * 2 * 64 + 4 * 32 * TTS + 64) * sizeof(float);
     dim3 grid((unsigned)cdiv(p.T, p.t_chunk), (unsigned)p.B, (unsigned)cdiv(p.Cout, 64));
-    hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI>), grid, dim3(256), lds, s, p);
+    SpatialP q = p;
+    q.nchunk = (int)grid.x;
+    q.ncol = (int)grid.z;
+    q.per_xcd = 0;
+    const long long total = (long long)grid.x * grid.y * grid.z;
+    if (q.ncol > 1 && !(fgcn::tuning(5) & 16) && total < (1ll << 30)) {     // key 5 bit 4: the plain 3-D grid
+        q.per_xcd = (int)cdiv(total, 8);
+        grid = dim3((unsigned)(q.per_xcd * 8));
+    }
+    hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI>), grid, dim3(256), lds, s, q);
 }
 
 static int spatial_t_chunk(int B, int T) {
@@ -591,7 +613,7 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
     FGCN_REQUIRE(aligned16(x) || true, FGCN_E_ALIGN, "spatial_fwd: alignment");
     SpatialP p{x, a_hat, wd, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, n_subsets, a_hat_batched,
                spatial_t_chunk(B, T), (unsigned)x_bytes, (unsigned)w_bytes,
-               (unsigned)((long long)n_subsets * Cin * Cout * 2)};
+               (unsigned)((long long)n_subsets * Cin * Cout * 2), 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     int rc = -1;
     if (split && !(fgcn::tuning(7) & 1)) {     // two frames per wave, split-bf16 aggregation (tuning key 7 bit 0: the older form)
