@@ -47,3 +47,15 @@ def test_bench_starts_its_own_ranks_and_reports_strong_scaling():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "7", "--dry-run"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_round2_traffic_record_shows_the_fetch_reduction():
+    """profiles/r02_traffic.json holds the dominant kernel's PMC record before and after the XCD-aware workgroup order; bench.py
+    reports the newer one as `roofline.traffic` for the split-bf16 arithmetic."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    new, old = rec["conv_halo_x3_fwd"], rec["conv_halo_x3_fwd_plain_grid"]
+    for r in (new, old):
+        assert r["traffic_bytes"] == int((2 * r["fetch_size_kib_raw"] + r["write_size_kib"]) * 1024)
+        assert r["algorithmic_bytes"] == 4 * 128 * 75 * 25 * 2 * 256
+    assert new["traffic_bytes"] < 0.55 * old["traffic_bytes"] and new["traffic_bytes"] < 2 * new["algorithmic_bytes"]
+    assert bench.measured_traffic(dict(channels=256, frames=75), 128, "bf16x3") == new["traffic_bytes"]
