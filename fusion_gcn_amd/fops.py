@@ -51,6 +51,11 @@ class deferred_batch_counters:
         return False
 
 
+def _pointwise(tmap) -> bool:
+    taps, ta, _tb, tc, td = tmap
+    return taps == 1 and ta == 1 and tc == 0 and td == 1
+
+
 class _ConvRows(torch.autograd.Function):
     """y[(b, to, v), :] = bias + sum_j x[(b, to*ta + j*tb + tc, v), 0:K] . W[j]   (W packed (taps, K, N)); returns (y, BatchNorm
     partial sums of y or an empty tensor).  ``zero_bias_grad``: the bias feeds a train-mode BatchNorm, its gradient is exactly
@@ -61,7 +66,7 @@ class _ConvRows(torch.autograd.Function):
         B, T, V, ld = x.shape
         taps, K, N = w.shape
         out = torch.empty((B, T_out, V, N), device=x.device, dtype=torch.float32)
-        if tuple(tmap) == ops.TMAP_POINTWISE:       # rows are rows: fold the node axis into the frames (node counts beyond the
+        if _pointwise(tmap):                        # rows are rows: fold the node axis into the frames (node counts beyond the
             x = x.view(B, T * V, 1, ld)             # 32-joint limit of the temporal kernels, e.g. MS-G3D's 135-node windows)
             part = ops.rows_gemm(x, w.contiguous(), out.view(B, T * V, 1, N), K=K, N=N, bias=bias, stats=stats)
         else:
@@ -80,7 +85,7 @@ class _ConvRows(torch.autograd.Function):
         _, K, N = w.shape
         d_out = d_out.contiguous()
         shape_out = None
-        if tuple(ctx.tmap) == ops.TMAP_POINTWISE:   # x was saved in its folded (B, T*V, 1, ld) form
+        if _pointwise(ctx.tmap):                    # x was saved in its folded (B, T*V, 1, ld) form
             shape_out = (d_out.shape[0], d_out.shape[1], d_out.shape[2], x.shape[3])
             d_out = d_out.view(x.shape[0], x.shape[1], 1, N)
         dx = dw = db = None

@@ -210,3 +210,69 @@ def test_msg3d_resolves_through_import_model_and_loads_reference_shaped_checkpoi
     x = torch.from_numpy(filler.skeleton_input("x.msg3d.utd", shape)).float().to(dev())
     with torch.no_grad():
         assert torch.equal(a(x), b(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,K,N,kt,stride,dil", [(2, 12, 20, 16, 16, 3, 1, 1), (2, 13, 25, 32, 32, 3, 2, 3), (1, 9, 20, 64, 64, 3, 1, 4),
+                                                     (2, 10, 5, 96, 16, 1, 2, 1), (2, 8, 100, 576, 96, 1, 1, 1)])
+def test_conv_rows_matches_conv2d(B, T, V, K, N, kt, stride, dil, fgcn_math):
+    """fops.conv_rows (the row GEMM with a temporal map: dilation, stride, 'same' padding -- TemporalConv of ms_tcn.py:15-34 and the
+    1x1 convolutions) forward, input gradient, weight and bias gradients against torch's Conv2d in float64; V = 100 exercises the
+    folded node axis of the 1x1 form."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd import fops
+    from fusion_gcn_amd.models.msg3d.ms_tcn import out_frames, temporal_map
+    x, w, b = rnd(B, T, V, K, seed=11), rnd(N, K, kt, 1, seed=12) * (kt * K) ** -0.5, rnd(N, seed=13)
+    xr, wr, br = x.permute(0, 3, 1, 2).clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pad = (kt + (kt - 1) * (dil - 1) - 1) // 2
+    want = F.conv2d(xr, wr, br, stride=(stride, 1), padding=(pad, 0), dilation=(dil, 1))
+    probe = rnd(*want.shape, seed=14)
+    gx, gw, gb = torch.autograd.grad((want * probe).sum(), (xr, wr, br))
+    xg = x.float().to(dev()).requires_grad_(True)
+    wg, bg = w.float().to(dev()).requires_grad_(True), b.float().to(dev()).requires_grad_(True)
+    got, part = fops.conv_rows(xg, wg[..., 0].permute(2, 1, 0), bg, tmap=temporal_map(kt, stride, dil), T_out=out_frames(T, stride), stats=True)
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().permute(0, 2, 3, 1).numpy()) < 3e-6
+    flat = want.detach().permute(0, 2, 3, 1).reshape(-1, N)
+    assert rel_l2(part.double().sum(0)[0].cpu().numpy(), flat.sum(0).numpy()) < 2e-5          # BatchNorm partial sums of the epilogue
+    (got * probe.permute(0, 2, 3, 1).float().to(dev())).sum().backward()
+    assert rel_l2(xg.grad.cpu().numpy(), gx.permute(0, 2, 3, 1).numpy()) < 3e-6
+    assert rel_l2(wg.grad.cpu().numpy(), gw.numpy()) < 2e-5
+    assert rel_l2(bg.grad.cpu().numpy(), gb.numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stride,cin,cout", [(1, 96, 96), (2, 96, 192)])
+def test_multi_scale_temporal_block_matches_the_oracle(stride, cin, cout, fgcn_math):
+    """One MultiScale_TemporalConv (ms_tcn.py:37-109: six branches, joined head BatchNorm, dilated convs, pooling, residual) forward,
+    input gradient, every parameter gradient and the running statistics against the float64 oracle."""
+    from fusion_gcn_amd.models.msg3d.ms_tcn import MultiScale_TemporalConv
+    B, T, V = 2, 14, 20
+    blk = MultiScale_TemporalConv(cin, cout, stride=stride)
+    filler.fill_state_dict(blk.state_dict(), prefix="tcn1.")
+    sd = {"tcn1." + k: (v.detach().double().clone() if v.is_floating_point() else v.detach().clone()) for k, v in blk.state_dict().items()}
+    blk = blk.to(dev()).train()
+    x = torch.from_numpy(filler.bellish("x.mstcn", (B, cin, T, V)))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    live = dict(sd)
+    live.update(params)
+    xo = x.clone().requires_grad_(True)
+    stats = O.Stats()
+    want = O.ms_tcn(xo, live, "tcn1", stride, True, stats)
+    probe = rnd(*want.shape, seed=21)
+    grads = torch.autograd.grad((want * probe).sum(), [xo] + list(params.values()), allow_unused=True)
+    xg = x.float().permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    got = blk(xg)
+    assert rel_l2(got.detach().cpu().numpy(), want.detach().permute(0, 2, 3, 1).numpy()) < 2e-5
+    flips = int(((got.detach().cpu() > 0) != (want.detach().permute(0, 2, 3, 1) > 0)).sum())
+    (got * probe.permute(0, 2, 3, 1).float().to(dev())).sum().backward()
+    tol = 2e-4 if flips == 0 else 5e-3
+    assert rel_l2(xg.grad.cpu().numpy(), grads[0].permute(0, 2, 3, 1).numpy()) < tol, flips
+    scale = max(float(g.abs().max()) for g in grads[1:] if g is not None)
+    for (k, _), g in zip(params.items(), grads[1:]):
+        mine = dict(blk.named_parameters())[k[5:]].grad
+        if k.endswith(ZERO_GRAD):
+            assert float(mine.abs().max()) <= 1e-4 * scale, k
+        else:
+            assert rel_l2(mine.cpu().numpy(), g.numpy()) < tol, (k, flips)
+    for k, v in stats.updates.items():
+        assert rel_l2(blk.state_dict()[k[5:]].cpu().numpy(), v.numpy()) < 1e-5, k
