@@ -137,3 +137,25 @@ def test_late_fusion_trains_from_two_feature_files(tmp_path, fgcn_math):
             continue
         worst = max(worst, (k, rel_l2(p.detach().cpu().double().numpy(), want)), key=lambda t: t[1])
     assert worst[1] < 2e-3, worst
+
+
+def test_two_ranks_of_the_real_model_through_the_self_launching_bench():
+    """`python bench.py --gpus 2` with no launcher (the driver's form): bench.py starts two ranks itself; on this one-GPU box they
+    share the device and exchange over gloo (FGCN_BENCH_BACKEND) -- plumbing, not a measurement -- but it is the REAL model: ONE
+    16-clip batch sharded 8 + 8, HIP-graph step per rank, one flat all-reduce, and --verify-dp compares the exchanged gradient
+    buffer of the replayed step with an eager step (must be identical)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["FGCN_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "16", "--steps", "3", "--warmup", "1",
+                        "--verify-dp", "--no-kernel-timing"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "verify-dp: flat gradient buffer" in r.stderr and "rel-L2 0.00e+00" in r.stderr, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["per_gpu_batch"] == 8 and out["config"]["launch"] == "hipgraph"
+    assert out["other_scaling"]["scaling"] == "weak" and out["other_scaling"]["per_gpu_batch"] == 16
+    assert out["value"] > 0 and abs(out["config"]["loss"]) < 20
