@@ -291,6 +291,8 @@ def main():
                          "headline metric is fwd+bwd, so the default leaves it out")
     ap.add_argument("--agg-wgrad-max-cout", type=int, default=None,
                     help="A/B only: widest block whose conv_d weight gradient uses the fused aggregation kernel (block.FUSED_AGG_WGRAD_MAX_COUT)")
+    ap.add_argument("--no-bn-sums-in-dgrad", action="store_true",
+                    help="A/B only: BatchNorm-backward sums by the stand-alone reduction kernel instead of the data-gradient epilogue")
     ap.add_argument("--keep-packed", action="store_true",
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
@@ -341,6 +343,7 @@ def main():
     from fusion_gcn_amd import block as _block
     if args.agg_wgrad_max_cout is not None:
         _block.FUSED_AGG_WGRAD_MAX_COUT[args.math] = args.agg_wgrad_max_cout
+    _block.BN_SUMS_IN_DGRAD = not args.no_bn_sums_in_dgrad
     _block.WGRAD_SIDE_STREAM = args.wgrad_stream != "main"
     _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch

@@ -197,6 +197,7 @@ def spec_dx(cin: int) -> List[dict]:
 
 
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
+BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
 # block_backward).  Measured neutral on MI355X (tools/probes/gated_dagg_probe.py, B = 128: the two apply kernels save 0.16 ms per
 # block, the two extra tensor reads cost joint_dagg 0.15 ms; slower at 8 clips), so off; the kernel form stays tested.
@@ -285,12 +286,13 @@ def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], b
     return ops.rows_gemm(g, W["t"], u, K=g.shape[3], N=u.shape[3], tmap=ops.conv_tmap(kt, s), bias=bias, stats=stats)
 
 
-def temporal_dgrad(du: torch.Tensor, dg: torch.Tensor, W: Dict[str, torch.Tensor], kt: int, s: int) -> None:
-    """dg = data gradient of that convolution: dg[t] = sum_j W_j^T du[(t + pad - j) / s]."""
+def temporal_dgrad(du: torch.Tensor, dg: torch.Tensor, W: Dict[str, torch.Tensor], kt: int, s: int, bn_bwd=None):
+    """dg = data gradient of that convolution: dg[t] = sum_j W_j^T du[(t + pad - j) / s].  ``bn_bwd`` (stride 1, split-bf16 kernel):
+    the BatchNorm-backward sums of dg against (a, sign image, vec) from the kernel's epilogue -> partials, else None."""
     pad = (kt - 1) // 2
     T, Tp = dg.shape[1], du.shape[1]
     if s == 1 and "t_t4" in W:
-        ops.tconv_halo(du, W["t_t4"], dg, Th=T, taps=kt, tb=-1, tc=pad)
+        return ops.tconv_halo(du, W["t_t4"], dg, Th=T, taps=kt, tb=-1, tc=pad, bn_bwd=bn_bwd)
     elif s == 2 and "t_t4_e" in W and pad % 2 == 0:
         # frame t = 2*th + par only meets taps j = 2j' + par, at du frame th + pad/2 - j'
         ops.tconv_halo(du, W["t_t4_e"], dg, Th=(T + 1) // 2, taps=(kt + 1) // 2, tb=-1, tc=pad // 2, out_view=(2, 0))
@@ -510,7 +512,11 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
 
     # -- temporal conv -------------------------------------------------------------------------------------------------------
     dg = new(B, T, V, cout)
-    temporal_dgrad(du, dg, W, kt, s)
+    # identity blocks in the split-bf16 modes: the data-gradient kernel sums dg * [g > 0] and dg * [g > 0] * y_hat in its epilogue,
+    # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
+    fuse_sums = (BN_SUMS_IN_DGRAD and train and s == 1 and not cfg.has_down and S["g_sign"] is not None and "t_t4" in W
+                 and ops.tconv_halo_bn_sums())
+    g_partials = temporal_dgrad(du, dg, W, kt, s, bn_bwd=(S["y"], S["g_sign"], S["vec_y"]) if fuse_sums else None)
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
     with wgrad():
         G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
@@ -528,11 +534,11 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G["gcn1.down.0.bias"] = bias_grad(dd, cout)
     elif gate_in_dagg:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
-                                     sign_mask=S["g_sign"])
+                                     sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None)
         gated.append((dg, S["g_sign"]))            # dx += dg * [g > 0]
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
-                                     db_accumulate=dx_live, sign_mask=S["g_sign"])
+                                     db_accumulate=dx_live, sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None)
         dx_live = True
     G["gcn1.bn.weight"], G["gcn1.bn.bias"] = sums[1], sums[0]
 

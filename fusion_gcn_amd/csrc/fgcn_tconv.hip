@@ -39,6 +39,12 @@ struct HaloP {
     int taps, tb, tc;                   // d_j = j*tb + tc
     int dmin, halo_rows;
     int accumulate;
+    // BatchNorm-backward sums in the epilogue (conv_halo_x3k32_kernel; data-gradient calls): with bn_a != NULL `stats` receives, per
+    // row tile and column, sum dp and sum dp * (a - mean) * rstd, dp = value written * [bit of bn_mask] -- what
+    // fgcn_bn_act_bwd_reduce computes in a pass of its own over the tensor this kernel has just produced
+    const float* bn_a;
+    const unsigned char* bn_mask;
+    const float* bn_vec;
 };
 
 constexpr int HAS = 36;                 // LDS row stride of the halo image (32 channels + 4 pad: conflict-free b128)
@@ -702,12 +708,21 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
         (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NU], ssq[NU], bv[NU];
     unsigned coff[NU];
+    const bool bnb = p.bn_a != nullptr;                   // wave-uniform: BatchNorm-backward sums instead of the forward moments
+    const __amdgpu_buffer_rsrc_t rba = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? p.bn_a : p.out), 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbm = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? (const void*)p.bn_mask : (const void*)p.out), 0,
+                                                                         p.out_bytes >> 5, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbv = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? p.bn_vec : p.w4), 0,
+                                                                         bnb ? (unsigned)p.N * 8u : 0u, 0x00020000);
+    float bmean[NU], brstd[NU];
 #pragma unroll
     for (int nu = 0; nu < NU; ++nu) {
         ssum[nu] = 0.f;
         ssq[nu] = 0.f;
         coff[nu] = col + nu * 16 < p.N ? (unsigned)(col + nu * 16) * 4u : OOB;
         bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
+        bmean[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], 0, 0));
+        brstd[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], (unsigned)p.N * 4u, 0));
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
@@ -737,14 +752,30 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
                     old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                         rout, (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu], 0, 0));
             }
+            float av[4];
+            unsigned mb[4];
+            if (bnb) {                                     // wave-uniform: the BatchNorm input and the ReLU sign bits of these elements
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
+                    av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rba, off, 0, 0));
+                    mb[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbm, off == OOB ? OOB : off >> 5, 0, 0);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
                 const float val = acc[mt][nu][r] + bv[nu] + old[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
                 const float kept = off != OOB ? val : 0.f;
-                ssum[nu] += kept;
-                ssq[nu] += kept * kept;
+                if (bnb) {
+                    const float dp = (mb[r] >> ((off >> 2) & 7u)) & 1u ? kept : 0.f;
+                    ssum[nu] += dp;
+                    ssq[nu] += dp * ((av[r] - bmean[nu]) * brstd[nu]);
+                } else {
+                    ssum[nu] += kept;
+                    ssq[nu] += kept * kept;
+                }
             }
         }
     }
@@ -782,6 +813,12 @@ static int halo_tile_rows(int V) {
     return (k32 && (128 + 8 * V) * XSB * 3 > 80 * 1024) ? 96 : 128;
 }
 
+// 1 when fgcn_tconv_halo can emit the BatchNorm-backward sums in the current math mode / tuning (the 16x16x32 split-bf16 kernel)
+extern "C" int fgcn_tconv_halo_bn_sums(void) {
+    const int mm = fgcn::math_mode();
+    return (mm == FGCN_MATH_BF16 || (mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 6))) ? 1 : 0;
+}
+
 extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
     const int Tv = Th_out > Th_in ? Th_out : Th_in;
     return (int)cdiv((long long)B * Tv * V, halo_tile_rows(V));
@@ -791,8 +828,13 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                                int B, int Th, int V, int K, int N, int ld_in, int ld_out,
                                int T_in_full, int in_s, int in_o, int Th_in,
                                int T_out_full, int out_s, int out_o,
-                               int taps, int tb, int tc, int accumulate, void* stream) {
+                               int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                               const float* bn_vec, void* stream) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
+    FGCN_REQUIRE(!bn_a || (bn_mask && bn_vec && stat_partials && fgcn_tconv_halo_bn_sums() && ld_out == N && N % 8 == 0 &&
+                           out_s == 1 && out_o == 0 && T_out_full == Th),
+                 FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums need the split-bf16 kernel, a contiguous plain output (ld_out == N, "
+                 "N %% 8 == 0), the sign image, the coefficient vector and a partials buffer");
     FGCN_REQUIRE(B > 0 && Th > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0, FGCN_E_BADARG,
                  "tconv_halo: bad sizes B=%d Th=%d V=%d K=%d N=%d", B, Th, V, K, N);
     FGCN_REQUIRE(K % 32 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N, FGCN_E_ALIGN,
@@ -822,6 +864,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.T_in_full = T_in_full; p.in_s = in_s; p.in_o = in_o; p.Th_in = Th_in;
     p.T_out_full = T_out_full; p.out_s = out_s; p.out_o = out_o; p.Th_out = Th;
     p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
+    p.bn_a = bn_a; p.bn_mask = bn_mask; p.bn_vec = bn_vec;
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
     const int dmax = d0 < d1 ? d1 : d0;

@@ -145,11 +145,19 @@ def pack_spatial(wd: torch.Tensor, cin: int) -> torch.Tensor:
     return pack_k4(wd.unsqueeze(0))[0]
 
 
+def tconv_halo_bn_sums() -> bool:
+    """Whether ``tconv_halo(..., bn_bwd=...)`` is available in the current math mode (the split-bf16 kernel)."""
+    return bool(_lib.load().fgcn_tconv_halo_bn_sums())
+
+
 def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
                in_view=None, out_view=(1, 0), bias: Optional[torch.Tensor] = None, stats: bool = False,
-               accumulate: bool = False) -> Optional[torch.Tensor]:
+               accumulate: bool = False, bn_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> Optional[torch.Tensor]:
     """Halo-tile temporal conv over virtual frames [0, Th): input frame th*in_s + in_o (th < Th_in), output frame
-    th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked."""
+    th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked.
+    ``bn_bwd = (a, sign image, vec)``: the call is the data gradient of a conv whose input was relu(BatchNorm(a) + shortcut); the
+    returned partials (tiles, 2, N) then hold the BatchNorm-backward sums (sum dp, sum dp * a_hat) of what it writes
+    (``bn_act_bwd(..., partials=)`` takes them instead of running its own reduction pass)."""
     ensure_device()
     _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out")
     B, T_in, V, ld_in = inp.shape
@@ -168,10 +176,17 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     out_s, out_o = out_view
     lib = _lib.load()
     part = None
-    if stats:
+    bn = (None, None, None)
+    if bn_bwd is not None:
+        a, mask, vec = bn_bwd
+        _chk(a, "tconv_halo.bn_a"), _chk(vec, "tconv_halo.bn_vec")
+        if stats or tuple(a.shape) != tuple(out.shape) or mask.dtype != torch.uint8 or mask.numel() * 8 != out.numel() or vec.shape != (4, N):
+            raise _lib.FgcnError("tconv_halo: bn_bwd needs a like out, its sign image and the (4, N) BatchNorm vector, and excludes stats")
+        bn = (_p(a), mask.data_ptr(), _p(vec))
+    if stats or bn_bwd is not None:
         part = torch.empty((lib.fgcn_tconv_halo_tiles(B, Th, Th_in, V), 2, N), device=inp.device, dtype=torch.float32)
     check(lib.fgcn_tconv_halo(_p(inp), _p(out), _p(w4), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
-                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), _stream()),
+                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, _stream()),
           "fgcn_tconv_halo")
     return part
 
@@ -584,7 +599,8 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
 def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor, vec_a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
-               sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True):
+               sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True,
+               partials: Optional[torch.Tensor] = None):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
     ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass."""
@@ -596,7 +612,12 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     if sign_mask is not None and (sign_mask.dtype != torch.uint8 or sign_mask.numel() * 8 != a.numel()):
         raise _lib.FgcnError("bn_act_bwd: sign_mask must be the uint8 bit image of bn_act (numel/8 bytes)")
     sums = None
-    if need_sums or train:
+    if partials is not None:            # the producer of dout already summed (tconv_halo bn_bwd): (tiles, 2, C) -> sums[0:2]
+        if res_mode == 2 or partials.shape[1:] != (2, C):
+            raise _lib.FgcnError("bn_act_bwd: precomputed partials are (tiles, 2, C) sums of a BatchNorm without a second BatchNorm branch")
+        sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
+        reduce_sum(partials.view(partials.shape[0], -1), sums[:2].view(-1))
+    elif need_sums or train:
         tiles = lib.fgcn_elem_tiles(rows)
         partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
         check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),

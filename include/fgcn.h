@@ -99,11 +99,20 @@ int fgcn_rows_gemm_tiles(long long M);
  *   stat_partials: float[fgcn_tconv_halo_tiles(B, Th, Th_in, V)][2][N] or NULL (sums of the values written, after
  *   accumulation).  Tensors must be smaller than 2 GiB (32-bit buffer offsets). */
 int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
+/* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
+ * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
+ * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel
+ *   [0] sum dp,  [1] sum dp * (a - mean) * rstd,   dp = (value written) * [bit of bn_mask],
+ * bn_a = the BatchNorm's input (same shape as out, contiguous: ld_out == N), bn_mask = fgcn_bn_act's sign image of G, bn_vec =
+ * fgcn_bn_finalize's vector (mean at [0, N), rstd at [N, 2N)): what fgcn_bn_act_bwd_reduce computes in a pass of its own over dG
+ * and a (two activation reads and two launches less per identity block). */
+int fgcn_tconv_halo_bn_sums(void);
 int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
                     int B, int Th, int V, int K, int N, int ld_in, int ld_out,
                     int T_in_full, int in_s, int in_o, int Th_in,
                     int T_out_full, int out_s, int out_o,
-                    int taps, int tb, int tc, int accumulate, void* stream);
+                    int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                    const float* bn_vec, void* stream);
 
 /* partial[s][j][k][n] = sum over the s-th slice of rows m=(n,tg,v) of a[(n,ti(tg,j),v), k] * g[m, n]
  *   (weight gradient of the same convolutions; autograd backward of agcn.py:41-42,71-73,77).

@@ -385,6 +385,43 @@ def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", d4, a[0]).numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
+def test_halo_data_gradient_emits_the_batchnorm_backward_sums(B, T, V, C, fgcn_math):
+    """fgcn_tconv_halo with bn_a / bn_mask / bn_vec: the data gradient dG and, from its epilogue, sum dP and sum dP * a_hat with
+    dP = dG * [G > 0] (backward of G = relu(BN(a) + x), agcn.py:113-115) -- against the float64 formulas and against the
+    stand-alone reduction kernel on the same dG; the gradient itself is unchanged by the extra output."""
+    from fusion_gcn_amd import ops
+    if not ops.tconv_halo_bn_sums():
+        pytest.skip("the f32 halo kernel has no BatchNorm-backward epilogue (the block then runs the reduction kernel)")
+    kt = 9
+    du, wt = rnd(B, T, V, C, seed=120), rnd(kt, C, C, seed=121, scale=(kt * C) ** -0.5)      # packed (kt, o, c) data-gradient form
+    a, xres = rnd(B, T, V, C, seed=122), rnd(B, T, V, C, seed=123)
+    gamma, beta = rnd(C, seed=124).abs() + 0.5, rnd(C, seed=125)
+    mean, var = a.reshape(-1, C).mean(0), a.reshape(-1, C).var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    vec = torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd])
+    g_pre = (a - mean) * rstd * gamma + beta + xres
+    _, mask = ops.bn_act(to_gpu(a), to_gpu(vec), to_gpu(xres), None, relu=True, sign_mask=True)
+    dg_want = ref_rows_conv(du, wt, ops.conv_dgrad_tmap(kt, 1), T)
+    dp = dg_want * (g_pre.float() > 0)
+    want = torch.stack([dp.reshape(-1, C).sum(0), (dp * (a - mean) * rstd).reshape(-1, C).sum(0)])
+    w4 = ops.pack_conv(to_gpu(wt))
+    dg = torch.empty(B, T, V, C, device=dev())
+    part = ops.tconv_halo(to_gpu(du), w4, dg, Th=T, taps=kt, tb=-1, tc=4, bn_bwd=(to_gpu(a), mask, to_gpu(vec)))
+    assert rel_l2(dg.cpu().numpy(), dg_want.numpy()) < FWD_TOL
+    got = part.double().sum(0).cpu()
+    assert rel_l2(got.numpy(), want.numpy()) < RED_TOL
+    plain = torch.empty_like(dg)
+    ops.tconv_halo(to_gpu(du), w4, plain, Th=T, taps=kt, tb=-1, tc=4)
+    assert torch.equal(plain, dg)
+    _, _, sums = ops.bn_act_bwd(dg, None, to_gpu(a), to_gpu(vec), to_gpu(xres), None, res_mode=1, train=True, sign_mask=mask, need_db=False)
+    assert rel_l2(got.numpy(), sums[:2].double().cpu().numpy()) < RED_TOL
+    da1, _, s1 = ops.bn_act_bwd(dg, None, to_gpu(a), to_gpu(vec), to_gpu(xres), None, res_mode=1, train=True, sign_mask=mask, need_db=False,
+                                partials=part)
+    da0, _, _ = ops.bn_act_bwd(dg, None, to_gpu(a), to_gpu(vec), to_gpu(xres), None, res_mode=1, train=True, sign_mask=mask, need_db=False)
+    assert rel_l2(da1.cpu().numpy(), da0.cpu().numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("V,T,C,B,n_gated", [(25, 30, 64, 3, 2), (18, 33, 128, 2, 1), (27, 12, 256, 2, 2), (25, 301, 64, 2, 2)])
 def test_joint_dagg_adds_the_gated_shortcut_gradients(V, T, C, B, n_gated):
     """dx = sum_k dagg_k . A^_k^T + sum_i e_i * [bit of mask_i]: the ReLU-gated gradients of the identity shortcuts (agcn.py:114,135)
