@@ -121,11 +121,14 @@ class MultiScale_TemporalConv(nn.Module):
         h, part = fops.conv_rows(x, w, bias, stats=joined.training, zero_bias_grad=joined.training)
         h = fops.bn_act(h, part, joined, relu=relu_heads)
         joined.scatter_running_stats()
-        outs = []
-        for i, b in enumerate(lead[:-1]):               # dilated (3 x 1) convolutions on their channel windows
-            y, part = b[3].pre_bn(h, coff=i * bc)
-            outs.append(fops.bn_act(y, part, b[3].bn))
-        pooled = fops.maxpool3(h[..., (len(lead) - 1) * bc:].contiguous(), s)
+        # dilated (3 x 1) convolutions and the max pooling on their channel windows of h, read and differentiated in place
+        tconvs = [b[3] for b in lead[:-1]]
+        train = tconvs[0].bn.training
+        ys, pooled, parts = fops.window_branches(
+            h, [temporal_weight(t.conv) for t in tconvs], [t.conv.bias for t in tconvs],
+            [temporal_map(t.conv.kernel_size[0], t.conv.stride[0], t.conv.dilation[0]) for t in tconvs], bc, s, out_frames(x.shape[1], s),
+            stats=train, zero_bias_grad=train)
+        outs = [fops.bn_act(y, part, t.bn) for y, part, t in zip(ys, parts, tconvs)]
         outs.append(fops.bn_act(pooled, fops.col_stats(pooled) if lead[-1][4].training else pooled.new_empty(0), lead[-1][4]))
         last = self.branches[-1]
         y, part = fops.conv_rows(x, pointwise_weight(last[0]), last[0].bias, tmap=(1, s, 0, 0, 1), T_out=out_frames(x.shape[1], s),
