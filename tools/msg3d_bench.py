@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--modes", default="f32,bf16x3,bf16")
+    ap.add_argument("--graph", action="store_true", help="also time the step replayed from one captured HIP graph")
     args = ap.parse_args()
     from fusion_gcn_amd import ops
     from fusion_gcn_amd.datasets.utd_mhad import constants as utd
@@ -34,20 +36,60 @@ def main():
     y = torch.randint(0, classes, (args.batch,), device=dev)
     out = {"workload": f"MS-G3D fwd+bwd, batch {args.batch}, (M,T,V,C)={shape}, {classes} classes",
            "parameters": sum(p.numel() for p in model.parameters())}
-    for mode in ("f32", "bf16x3", "bf16"):
+    params = list(model.parameters())
+    # everything runs on one non-default stream: autograd pins each parameter's gradient accumulation to the stream of its first
+    # use, and a capture that has to synchronise with the legacy default stream is invalid (HIP ends it with a crash, not an error)
+    work = torch.cuda.Stream()
+    work.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(work)
+    graphs = []                                   # kept alive to the end: a graph's pool is shared with the tensors it produced
+    def step() -> torch.Tensor:
+        for p in params:
+            p.grad = None
+        loss = F.cross_entropy(model(x), y)
+        loss.backward()
+        return loss                                   # the caller must not hold it across a capture (see --graph below)
+
+    for mode in args.modes.split(","):
         with ops.math_mode(mode):
             for _ in range(2):
-                model.zero_grad(set_to_none=True)
-                F.cross_entropy(model(x), y).backward()
+                step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                model.zero_grad(set_to_none=True)
-                loss = F.cross_entropy(model(x), y)
-                loss.backward()
+                loss = step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
-        out[mode] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(float(loss), 5)}
+            eager_loss = float(loss.detach())
+            del loss
+            out[mode] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(eager_loss, 5)}
+            if args.graph:
+                # Every lazily built buffer exists after the eager steps: record forward + backward once and replay.  No reference
+                # to an earlier step's autograd graph may be alive here (tools/probes/msg3d_graph_probe.py: it pins the
+                # parameters' gradient accumulators to the other stream and later captures replay garbage), and the replayed
+                # loss is checked against the eager one.
+                for p in params:
+                    p.grad = None
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    gloss = F.cross_entropy(model(x), y)
+                    gloss.backward()
+                graphs.append((graph, gloss))
+                for _ in range(3):
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    got = float(gloss.detach())
+                    if got != eager_loss:
+                        raise RuntimeError(f"{mode}: graph replay loss {got} != eager loss {eager_loss}")
+                t0 = time.perf_counter()
+                for _ in range(args.steps * 4):
+                    graph.replay()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / (args.steps * 4)
+                got = float(gloss.detach())
+                if got != eager_loss:
+                    raise RuntimeError(f"{mode}: graph replay loss {got} != eager loss {eager_loss} after the timed replays")
+                out[mode]["graph"] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(got, 5)}
     if args.cpu:
         from oracle import msg3d_oracle as O
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
