@@ -250,6 +250,16 @@ def refresh_packed_weights(model: nn.Module) -> None:
         blk._wversions = versions
 
 
+def prepare_recording(model: nn.Module) -> None:
+    """``GraphStep`` hook of the AGCN models (session/procedures/step.py): build what the first forward after an optimizer update
+    builds lazily -- the one-launch re-pack plan over all blocks (device tables + an H2D copy, not recordable) -- before the
+    step is recorded."""
+    for blk in model.modules():
+        if isinstance(blk, SpatialTemporalConv):
+            blk.mark_packed_stale()
+    refresh_packed_weights(model)
+
+
 # (width multiplier of start_feature_size, temporal stride) of the ten blocks (reference :152-163); the first has no shortcut
 BLOCK_PLAN = ((1, 1), (1, 1), (1, 1), (1, 1), (2, 2), (2, 1), (2, 1), (4, 2), (4, 1), (4, 1))
 
@@ -300,6 +310,9 @@ class Model(nn.Module):
         if pad:
             h = F.pad(h, (0, pad))
         return h.contiguous()
+
+    def prepare_recording(self) -> None:
+        prepare_recording(self)
 
     def _bump_batch_counters(self) -> None:
         """num_batches_tracked += 1 for every block BatchNorm in one launch (26 scalar adds otherwise)."""

@@ -45,7 +45,7 @@ def rel_l2(a, b):
 
 # The kernel / block / model parity modules run twice on the GPU: in the default math mode (exact f32 MFMA) and in
 # "bf16x3" (f32-accurate split-bf16 products, include/fgcn.h) -- the same oracle, the same tolerances.
-BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu", "test_train_e2e_gpu", "test_imu_gcn", "test_grad_parity_gpu", "test_msg3d"}
+BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu", "test_train_e2e_gpu", "test_imu_gcn", "test_grad_parity_gpu", "test_msg3d", "test_session_gpu"}
 
 
 def pytest_generate_tests(metafunc):

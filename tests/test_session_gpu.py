@@ -1,0 +1,164 @@
+"""GraphStep (fusion_gcn_amd/session/procedures/step.py): training through recorded HIP graphs must be the eager training --
+same losses, same parameters, same BatchNorm statistics -- over several batch shapes per process (a ragged last batch = a second
+recording), with returned losses held by the caller (the case tools/probes/msg3d_graph_probe.py found to invalidate later
+recordings when streams are mixed), with gradient accumulation, and for the three model families."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import filler
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def agcn(shape=(1, 24, 20, 3), classes=27):
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    model = Model(shape, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint))
+    filler.fill_state_dict(model.state_dict())
+    return model
+
+
+def msg3d(shape=(1, 16, 20, 3), classes=27):
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.msg3d.msg3d import Model
+    from fusion_gcn_amd.util import Graph
+    torch.manual_seed(3)
+    return Model({"skeleton": shape}, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint))
+
+
+def batches(sizes, shape, classes, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(n, *shape, generator=g).to(DEV), torch.randint(0, classes, (n,), generator=g).to(DEV), torch.arange(n)) for n in sizes]
+
+
+def train(model, processor, data, lr=0.01):
+    from fusion_gcn_amd.optim import FlatOptimizer
+    from fusion_gcn_amd.session.session import Session
+    model = model.to(DEV).train()
+    opt = FlatOptimizer(model.parameters(), "SGD", lr, momentum=0.9)
+
+    class Keep:                       # holds every loss / prediction tensor it is handed, like a metrics container would
+        def __init__(self):
+            self.losses, self.preds = [], []
+
+        def update_training(self, loss, pair, m, idx):
+            self.losses.append(loss)
+            self.preds.append(pair[0])
+
+        def format_training(self):
+            return ""
+    keep = Keep()
+    Session.train_epoch(processor, model, F.cross_entropy, data, opt, None, keep)
+    torch.cuda.synchronize()
+    return model, keep
+
+
+def assert_same_training(a, b, keep_a, keep_b, tol=1e-6):
+    for la, lb in zip(keep_a.losses, keep_b.losses):
+        assert abs(float(la) - float(lb)) <= tol * max(1.0, abs(float(lb))), ([float(t) for t in keep_a.losses], [float(t) for t in keep_b.losses])
+    for pa, pb in zip(keep_a.preds, keep_b.preds):
+        assert float((pa - pb).abs().max()) <= tol * max(1.0, float(pb.abs().max()))
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb)
+    for k in sa:
+        va, vb = sa[k], sb[k]
+        if va.is_floating_point():
+            assert float((va - vb).abs().max()) <= tol * max(1e-3, float(vb.abs().max())), k
+        else:
+            assert torch.equal(va, vb), k                # BatchNorm batch counters: the warm-up and verification runs rolled back
+
+
+def test_graph_training_is_the_eager_training_over_two_batch_shapes(fgcn_math):
+    from fusion_gcn_amd.session.procedures import DefaultBatchProcessor, DefaultStep, GraphStep
+    shape, classes = (1, 24, 20, 3), 27
+    data = batches([4, 4, 4, 3, 4, 3], shape, classes)           # the 3-clip batches are a second recording
+    base = agcn(shape, classes)
+    step = GraphStep()
+    eager, keep_e = train(copy.deepcopy(base), DefaultBatchProcessor(DefaultStep()), data)
+    graph, keep_g = train(copy.deepcopy(base), DefaultBatchProcessor(step), data)
+    assert len(step._recorded) == 2 and step.replays == 6
+    assert_same_training(graph, eager, keep_g, keep_e)
+    # evaluation goes through the eager forward of the same step object; the weights the replays trained are the model's own
+    from fusion_gcn_amd.session.session import Session
+    seen = []
+
+    class Val:
+        def update_validation(self, loss, pair, m, idx):
+            seen.append(float(loss))
+
+        def format_all(self):
+            return ""
+    Session.validate_epoch(DefaultBatchProcessor(step), graph, F.cross_entropy, data[:2], None, Val())
+    Session.validate_epoch(DefaultBatchProcessor(DefaultStep()), eager, F.cross_entropy, data[:2], None, Val())
+    assert seen[:2] == pytest.approx(seen[2:], rel=1e-5) and step.replays == 6
+
+
+def test_graph_step_accumulates_micro_batches(fgcn_math):
+    from fusion_gcn_amd.session.procedures import DefaultStep, GradientAccumulationBatchProcessor, GraphStep
+    shape, classes = (1, 24, 20, 3), 27
+    data = batches([6, 6], shape, classes)
+    base = agcn(shape, classes)
+    step = GraphStep()
+    eager, keep_e = train(copy.deepcopy(base), GradientAccumulationBatchProcessor(DefaultStep(), 6, 2), data)
+    graph, keep_g = train(copy.deepcopy(base), GradientAccumulationBatchProcessor(step, 6, 2), data)
+    assert len(step._recorded) == 1 and step.replays == 6 and len(keep_g.losses) == 6
+    assert_same_training(graph, eager, keep_g, keep_e)
+
+
+def test_graph_step_msg3d_and_late_fusion(fgcn_math):
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.mmargcn import Model as MM
+    from fusion_gcn_amd.session.procedures import DefaultBatchProcessor, DefaultStep, GraphStep
+    from fusion_gcn_amd.util import Graph
+    shape, classes = (1, 16, 20, 3), 27
+    data = batches([2, 2, 3], shape, classes)
+    base = msg3d(shape, classes)
+    eager, keep_e = train(copy.deepcopy(base), DefaultBatchProcessor(DefaultStep()), data)
+    graph, keep_g = train(copy.deepcopy(base), DefaultBatchProcessor(GraphStep()), data)
+    assert_same_training(graph, eager, keep_g, keep_e)
+    # dictionary features: skeleton + inertial, late fusion with the AGCN IMU branch
+    shapes = {"skeleton": (1, 16, 20, 3), "inertial": (12, 6)}
+    torch.manual_seed(2)
+    base = MM(shapes, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint), mode="skeleton_imu_gcn_late_fusion",
+              graph_node_format="node_per_sensor", num_signals=2, gc_model="agcn", fusion="concatenate")
+    g = torch.Generator().manual_seed(9)
+    data = [({k: torch.randn(n, *s, generator=g).to(DEV) for k, s in shapes.items()}, torch.randint(0, classes, (n,), generator=g).to(DEV),
+             torch.arange(n)) for n in (3, 3, 2)]
+    eager, keep_e = train(copy.deepcopy(base), DefaultBatchProcessor(DefaultStep()), data)
+    graph, keep_g = train(copy.deepcopy(base), DefaultBatchProcessor(GraphStep()), data)
+    assert_same_training(graph, eager, keep_g, keep_e)
+
+
+def test_graph_step_rejects_foreign_gradients_and_records_again_after_a_move():
+    from fusion_gcn_amd.session.procedures import GraphStep
+    shape, classes = (1, 24, 20, 3), 27
+    (x, y, _), = batches([2], shape, classes)
+    model = agcn(shape, classes).to(DEV).train()
+    F.cross_entropy(model(x), y).backward()                          # an eager step first (nothing of it is kept), then the switch
+    model.zero_grad()
+    step = GraphStep()
+    y_pred, loss = step.forward(model, F.cross_entropy, x, y)
+    step.backward(loss)
+    first = [p.grad.clone() for p in model.parameters()]
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(step.grads.params, step.grads.views))
+    y_pred, loss = step.forward(model, F.cross_entropy, x, y)        # no zero_grad in between: the gradients accumulate
+    torch.cuda.synchronize()
+    for p, g in zip(model.parameters(), first):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-12)
+    next(model.parameters()).grad = torch.zeros_like(next(model.parameters()))
+    with pytest.raises(RuntimeError, match="neither None nor views"):
+        step.forward(model, F.cross_entropy, x, y)
+    # re-homed parameters (a FlatOptimizer created afterwards): the recording reads the old addresses and must be redone
+    from fusion_gcn_amd.optim import FlatOptimizer
+    opt = FlatOptimizer(model.parameters(), "SGD", 0.01, grads=step.grads)
+    opt.zero_grad()
+    step.forward(model, F.cross_entropy, x, y)
+    assert step.replays == 3 and len(step._recorded) == 1
+    torch.cuda.synchronize()
+    for p, g in zip(model.parameters(), first):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-12)

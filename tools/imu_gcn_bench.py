@@ -10,6 +10,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
@@ -22,6 +23,7 @@ def main():
     ap.add_argument("--layers", type=int, default=10)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="also time the oracle on the host cores (2 samples)")
+    ap.add_argument("--graph", action="store_true", help="also time the step replayed from a recorded HIP graph (GraphStep)")
     ap.add_argument("--late", action="store_true",
                     help="instead: mode skeleton_imu_gcn_late_fusion as config/utd-mhad/skeleton+imu/late_fusion/*.yaml (skeleton "
                          "(1, 128, 20, 3) + inertial (326, 6), gc_model agcn, node_per_sensor, num_signals 2, batch 8)")
@@ -45,21 +47,14 @@ def main():
         f = o
     flops *= 3
     out = {"nodes": V, "batch": args.batch, "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
+    from steptime import time_step
     for mode in ("f32", "bf16x3", "bf16"):
         with ops.math_mode(mode):
-            for _ in range(2):
-                model.zero_grad(set_to_none=True)
-                F.cross_entropy(model(x), y).backward()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                model.zero_grad(set_to_none=True)
-                loss = F.cross_entropy(model(x), y)
-                loss.backward()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-        out[mode] = {"ms_per_step": round(1e3 * dt, 2), "samples_per_s": round(args.batch / dt, 1),
-                     "tflops": round(flops / dt / 1e12, 1), "loss": round(float(loss.detach()), 5)}
+            t = time_step(model, x, y, args.steps, graph=args.graph)
+        out[mode] = {"ms_per_step": t["eager"]["ms_per_step"], "samples_per_s": t["eager"]["per_s"],
+                     "tflops": round(flops / t["eager"]["ms_per_step"] / 1e9, 1), "loss": t["eager"]["loss"]}
+        if args.graph:
+            out[mode]["graph"] = dict(t["graph"], tflops=round(flops / t["graph"]["ms_per_step"] / 1e9, 1))
     if args.cpu:
         from oracle import imu_gcn_oracle as O
         sd = {k.replace("_model.", ""): v.detach().cpu() for k, v in model.state_dict().items()}
@@ -86,20 +81,13 @@ def late(args):
     x = {k: torch.randn(args.batch, *v, device=dev) for k, v in shapes.items()}
     y = torch.randint(0, classes, (args.batch,), device=dev)
     out = {"mode": "skeleton_imu_gcn_late_fusion", "imu_nodes": args.frames * 2, "batch": args.batch}
+    from steptime import time_step
     for mode in ("f32", "bf16x3"):
         with ops.math_mode(mode):
-            for _ in range(2):
-                model.zero_grad(set_to_none=True)
-                F.cross_entropy(model(x), y).backward()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                model.zero_grad(set_to_none=True)
-                loss = F.cross_entropy(model(x), y)
-                loss.backward()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-        out[mode] = {"ms_per_step": round(1e3 * dt, 2), "samples_per_s": round(args.batch / dt, 1), "loss": round(float(loss.detach()), 5)}
+            t = time_step(model, x, y, args.steps, graph=args.graph)
+        out[mode] = {"ms_per_step": t["eager"]["ms_per_step"], "samples_per_s": t["eager"]["per_s"], "loss": t["eager"]["loss"]}
+        if args.graph:
+            out[mode]["graph"] = t["graph"]
     print(json.dumps(out))
 
 
