@@ -275,8 +275,9 @@ def main():
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--wgrad-stream", choices=("side", "main", "side-high", "side-low"), default="side",
-                    help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (default) or in line")
+    ap.add_argument("--wgrad-stream", choices=("auto", "side", "main", "side-high", "side-low"), default="auto",
+                    help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (side), in line (main), or by the "
+                         "size of the block's tensors (auto, the library default: side from ~24 clips per GPU upwards)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--joints", type=int, choices=(25, 27, 22), default=25,
                     help="25: the headline (BASELINE config 2); 27: config 3 (NTU graph + 2 IMU joints); 22: config 4 (MMAct COCO-18 + "
@@ -344,7 +345,7 @@ def main():
     if args.agg_wgrad_max_cout is not None:
         _block.FUSED_AGG_WGRAD_MAX_COUT[args.math] = args.agg_wgrad_max_cout
     _block.BN_SUMS_IN_DGRAD = not args.no_bn_sums_in_dgrad
-    _block.WGRAD_SIDE_STREAM = args.wgrad_stream != "main"
+    _block.WGRAD_SIDE_STREAM = "auto" if args.wgrad_stream == "auto" else args.wgrad_stream != "main"
     _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
     model = build_model(device)

@@ -394,10 +394,16 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 # ---- backward --------------------------------------------------------------------------------------------------------
 # Weight gradients are leaves of the backward graph: nothing downstream in the block reads them.  They are MFMA-bound
 # while the chain that continues on the main stream (BatchNorm backward, the joint kernels, the narrow 1x1 data
-# gradients) is HBM-bound, so with WGRAD_SIDE_STREAM they are launched on a second HIP stream and share the CUs with
-# that chain (fork after the producer of their inputs, one join at the end of the block's backward; a HIP-graph capture
-# records the same fork/join as parallel branches).  WGRAD_STREAM_PRIORITY: 0 normal, -1 high (torch convention).
-WGRAD_SIDE_STREAM = True
+# gradients) is HBM-bound, so they can be launched on a second HIP stream and share the CUs with that chain (fork after
+# the producer of their inputs, one join at the end of the block's backward; a HIP-graph capture records the same fork/join
+# as parallel branches).  What that buys depends on the size of the block's tensors (same-box A/B of the whole step, bf16x3,
+# side vs in line): 64 clips 64.5 vs 65.1 ms, 32 clips 33.6 vs 33.7, 16 clips 18.2 vs 18.0, 8 clips 10.69 vs 10.34 -- below
+# ~24 clips the ~65 cross-stream edges per step (6-16 us of idle GPU each in the replayed graph) cost more than the overlap
+# returns.  WGRAD_SIDE_STREAM: "auto" (side stream from WGRAD_SIDE_MIN_WORK output elements per block upwards -- B*T'*V*cout is
+# the same for all ten blocks of the model: 480,000 per sample), True, False.  WGRAD_STREAM_PRIORITY: 0 normal, -1 high (torch
+# convention; high priority measured 1.5x SLOWER at 8 clips).
+WGRAD_SIDE_STREAM = "auto"
+WGRAD_SIDE_MIN_WORK = 48 * 480_000
 WGRAD_STREAM_PRIORITY = 0
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
 
@@ -455,7 +461,8 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     The leaf reductions of the block (weight-gradient slabs, adj_b, embedding-bias partials) are collected and issued as one
     launch at the end, on the weight-gradient stream, before it joins the main stream (ops.deferred_reductions)."""
     with ops.deferred_reductions() as batch:
-        wgrad = _WgradBranch(d_o.device, WGRAD_SIDE_STREAM)
+        side = d_o.numel() >= WGRAD_SIDE_MIN_WORK if WGRAD_SIDE_STREAM == "auto" else bool(WGRAD_SIDE_STREAM)
+        wgrad = _WgradBranch(d_o.device, side)
         out = _block_backward(d_o, S, P, W, cfg, train, need_dx, wgrad)
         with wgrad():                 # after everything both streams hold so far
             batch.flush()
