@@ -162,3 +162,51 @@ def test_graph_step_rejects_foreign_gradients_and_records_again_after_a_move():
     torch.cuda.synchronize()
     for p, g in zip(model.parameters(), first):
         assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-12)
+
+
+def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
+    """Two steps, a checkpoint in the layout of the reference's CheckpointManager.save_checkpoint (progress.py:209-226: one
+    state_dict per object of ``state_dict_objects`` + "epoch", torch.save), fresh objects, load, two more steps == four steps."""
+    from fusion_gcn_amd.optim import create_optimizer
+    from fusion_gcn_amd.session.procedures import DefaultBatchProcessor, GraphStep
+    from fusion_gcn_amd.session.session import Session
+    shape, classes = (1, 24, 20, 3), 27
+    data = batches([4, 4, 4, 4], shape, classes)
+    base = agcn(shape, classes)
+
+    def objects(model):
+        opt = create_optimizer("ADAM", model, 1e-3, weight_decay=0.01)          # config/utd-mhad/skeleton/agcn.yaml:15-22
+        sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=3)
+        proc = DefaultBatchProcessor(GraphStep())
+        held = {"model": model, "optimizer": opt, "lr_scheduler": sched}
+        proc.get_state_dict_objects(held)
+        return opt, sched, proc, held
+
+    def run(model, opt, sched, proc, part):
+        for b in part:                                                         # one "epoch" per batch: the scheduler steps per epoch
+            Session.train_epoch(proc, model, F.cross_entropy, [b], opt)
+            sched.step()
+
+    straight = copy.deepcopy(base).to(DEV)
+    run(straight, *objects(straight)[:3], data)
+
+    first = copy.deepcopy(base).to(DEV)
+    opt, sched, proc, held = objects(first)
+    run(first, opt, sched, proc, data[:2])
+    torch.save({**{k: v.state_dict() for k, v in held.items()}, "epoch": 1}, tmp_path / "checkpoint_1_0.5.pt")
+
+    resumed = copy.deepcopy(base).to(DEV)
+    opt, sched, proc, held = objects(resumed)
+    cp = torch.load(tmp_path / "checkpoint_1_0.5.pt", weights_only=False)
+    for name, obj in held.items():
+        obj.load_state_dict(cp[name])
+    assert cp["epoch"] == 1 and opt.steps == 2
+    run(resumed, opt, sched, proc, data[2:])
+    torch.cuda.synchronize()
+    sa, sb = resumed.state_dict(), straight.state_dict()
+    for k in sa:
+        if sa[k].is_floating_point():
+            assert float((sa[k] - sb[k]).abs().max()) <= 1e-6 * max(1e-3, float(sb[k].abs().max())), k
+        else:
+            assert torch.equal(sa[k], sb[k]), k
+    assert opt.param_groups[0]["lr"] == pytest.approx(sched.get_last_lr()[0])
