@@ -7,11 +7,12 @@ re-layouts aside).  Without libfgcn / off gfx950 every op raises (ops.ensure_dev
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from . import ops
+from .packing import Form, PackPlan, Seg
 
 
 def _rows4(t: torch.Tensor) -> torch.Tensor:
@@ -313,3 +314,321 @@ def col_stats(x: torch.Tensor) -> torch.Tensor:
     BatchNorm backward works from the tensor itself)."""
     with torch.no_grad():
         return ops.col_moments(x.detach().contiguous())
+
+
+# ---- parameters in the layouts the kernels stream, re-packed for a whole model in one launch -----------------------------------
+# The ops above take weights already packed (taps, K, N); building that from an nn.Conv2d parameter with torch ops (reshape /
+# permute / contiguous / pad, and their backward) is ~10 tiny launches per convolution and step -- ~800 of MS-G3D's 1650.  Below the
+# packed matrices (and their transposes for the data gradients) are packing.Forms over the parameters, all of a model refreshed by
+# ONE fgcn_pack_run launch per step (refresh_forms), and the weight gradients come out of the wgrad kernels' reduction directly in
+# the parameter's own layout (ops.rows_wgrad(conv_param=...)): no torch op touches a weight.
+
+class ParamForms:
+    """The packed forms of one module's parameters, created (and packed once on their own) on first use."""
+
+    def __init__(self):
+        self.forms: Dict[str, Form] = {}
+        self.generation = 0
+
+    def get(self, name: str, make: Callable[[], Form], device) -> torch.Tensor:
+        f = self.forms.get(name)
+        if f is None:
+            f = make()
+            f.alloc(device)
+            PackPlan([f]).run()
+            self.forms[name] = f
+            self.generation += 1
+        return f.dst
+
+    def clear(self) -> None:
+        self.forms.clear()
+        self.generation += 1
+
+
+def refresh_forms(model: torch.nn.Module) -> None:
+    """Call at the top of a model's forward: re-pack every existing form of every sub-module when a parameter changed since the last
+    pack (version counters), in one launch; forms whose parameters moved (model.to(), an optimizer's flat home) are dropped and
+    rebuilt by their modules on use."""
+    sets = [m._forms for m in model.modules() if isinstance(getattr(m, "_forms", None), ParamForms)]
+    gen = sum(s.generation for s in sets)
+    if not any(s.forms for s in sets):
+        return
+    params = list(model.parameters())
+    homes = tuple(p.data_ptr() for p in params)
+    state = getattr(model, "_forms_state", None)
+    if state is not None and state["homes"] != homes:
+        for s_ in sets:
+            s_.clear()
+        model._forms_state = None
+        return
+    if state is None or state["gen"] != gen:
+        state = {"gen": gen, "homes": homes, "plan": PackPlan([f for s_ in sets for f in s_.forms.values()]), "versions": None}
+        model._forms_state = state
+    versions = tuple(p._version for p in params)
+    if state["versions"] != versions:
+        state["plan"].run()
+        state["versions"] = versions
+
+
+def mark_forms_stale(model: torch.nn.Module) -> None:
+    state = getattr(model, "_forms_state", None)
+    if state is not None:
+        state["versions"] = None
+
+
+def conv_weight_forms(weights: Sequence[torch.Tensor], k_pad: int = 0) -> Tuple[Form, Form]:
+    """Forms of the (taps, K + k_pad, sum N_i) matrix of Conv weights (O_i, I, taps[, 1]) concatenated along the output channels, and
+    of its per-tap transpose (taps, sum N_i, K + k_pad) for the data gradient; the k_pad input channels are zero rows."""
+    o_all = sum(w.shape[0] for w in weights)
+    inner = weights[0].shape[1]
+    taps = weights[0].numel() // (weights[0].shape[0] * inner)
+    fwd, bwd, n0 = [], [], 0
+    for w in weights:
+        o = w.shape[0]
+        fwd.append(Seg(w, st_k=taps, st_n=inner * taps, klen=inner, nlen=o, n0=n0, st_tap=1, tlen=taps))
+        bwd.append(Seg(w, st_k=inner * taps, st_n=taps, klen=o, nlen=inner, k0=n0, st_tap=1, tlen=taps))
+        n0 += o
+    return Form("plain", taps, inner + k_pad, o_all, fwd), Form("plain", taps, o_all, inner + k_pad, bwd)
+
+
+def scale_major_forms(weight: torch.Tensor, num_scales: int, c_pad: int) -> Tuple[Form, Form]:
+    """MLP weight (O, S*C[, 1, 1]) whose input channel is s*C + c, for an aggregate whose per-scale channel groups are C + c_pad wide:
+    the (1, S*(C + c_pad), O) matrix stated as (S, C + c_pad, O) -- one "tap" per scale -- and its transpose (O, S, C + c_pad)."""
+    o = weight.shape[0]
+    c = weight.numel() // (o * num_scales)
+    fwd = Form("plain", num_scales, c + c_pad, o, [Seg(weight, st_k=1, st_n=num_scales * c, klen=c, nlen=o, st_tap=c, tlen=num_scales)],
+               shape=(1, num_scales * (c + c_pad), o))
+    bwd = Form("plain", o, num_scales, c + c_pad, [Seg(weight, st_k=c, st_n=1, klen=num_scales, nlen=c, st_tap=num_scales * c, tlen=o)],
+               shape=(1, o, num_scales * (c + c_pad)))
+    return fwd, bwd
+
+
+def bias_form(biases: Sequence[Optional[torch.Tensor]]) -> Optional[Form]:
+    """The concatenation of the convolutions' biases as one vector (None when no convolution has one)."""
+    if all(b is None for b in biases):
+        return None
+    segs, n0 = [], 0
+    for b in biases:
+        segs.append(Seg(b, st_k=0, st_n=1, klen=1, nlen=b.numel(), n0=n0))
+        n0 += b.numel()
+    return Form("plain", 1, 1, n0, segs, shape=(n0,))
+
+
+def node_mix_forms(a_const: torch.Tensor, a_res: torch.Tensor, num_scales: int) -> Tuple[Form, Form]:
+    """node_mix's matrix a_fm[u, v*S + s] = (A + A_res)[s*V + v, u] (Vp x V*S, see node_mix_matrix) and its transpose, as sums of the
+    constant stack and the learnable residual: (taps, K, N) = (u, v, s) resp. (v, s, u) index the same memory."""
+    SV, V = a_const.shape
+    S = num_scales
+    if SV != S * V or (V * S) % 4:
+        raise ValueError("node_mix_forms: stacked (S*V, V) matrix with V*S a multiple of 4 expected")
+    Vp = (V + 63) // 64 * 64
+    fwd = Form("plain", Vp, V, S, [Seg(t, st_k=V, st_n=V * V, klen=V, nlen=S, st_tap=1, tlen=V) for t in (a_const, a_res)],
+               shape=(Vp, V * S))
+    bwd = Form("plain", V, S, Vp, [Seg(t, st_k=V * V, st_n=1, klen=S, nlen=V, st_tap=V, tlen=V) for t in (a_const, a_res)],
+               shape=(V * S, Vp))
+    return fwd, bwd
+
+
+class _ConvParams(torch.autograd.Function):
+    """_ConvRows on parameters: ``w`` / ``wt`` / ``bias`` are packed forms of ``weights`` / ``biases`` (refresh_forms keeps them current);
+    gradients are returned per parameter, in the parameter's layout, straight from the weight-gradient reduction.
+    ``groups`` > 1: the matrix is `groups` stacked (K/groups x N) blocks whose parameter is laid out (O, groups * k_true) (the
+    scale-major MLPs behind node_mix)."""
+
+    @staticmethod
+    def forward(ctx, x, w, wt, bias, cfg, *params):
+        tmap, T_out, stats, zero_bias_grad, in_coff, k_true, groups, n_w = cfg
+        B, T, V, ld = x.shape
+        taps, K, N = w.shape
+        out = torch.empty((B, T_out, V, N), device=x.device, dtype=torch.float32)
+        fold = _pointwise(tmap) and in_coff == 0
+        xin = x.view(B, T * V, 1, ld) if fold else x
+        part = ops.rows_gemm(xin, w, out.view(B, T * V, 1, N) if fold else out, K=K, N=N, tmap=tmap, bias=bias, stats=stats,
+                             in_coff=in_coff)
+        ctx.save_for_backward(xin, wt)
+        ctx.cfg, ctx.fold, ctx.x_shape = cfg, fold, x.shape
+        ctx.shapes = [tuple(p.shape) for p in params]
+        if part is None:
+            part = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(part)
+        return out, part
+
+    @staticmethod
+    def backward(ctx, d_out, _d_part):
+        xin, wt = ctx.saved_tensors
+        tmap, T_out, stats, zero_bias_grad, in_coff, k_true, groups, n_w = ctx.cfg
+        taps, ta, tb, tc, td = tmap
+        _, N, K = wt.shape
+        B, T, V, ld = ctx.x_shape
+        d_out = d_out.contiguous()
+        if ctx.fold:
+            d_out = d_out.view(B, T * V, 1, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xin)
+            if in_coff != 0 or ld != K:
+                dx.zero_()                                              # channels outside the K window receive nothing
+            ops.rows_gemm(d_out, wt, dx, K=N, N=K, tmap=(taps, td, -tb, -tc, ta), out_coff=in_coff)
+            dx = dx.view(ctx.x_shape)
+        shapes = ctx.shapes
+        grads: List[Optional[torch.Tensor]] = [None] * len(shapes)
+        if any(ctx.needs_input_grad[5:5 + n_w]):
+            gw = ops.rows_wgrad(xin, d_out, K=K, N=N, tmap=tmap, a_coff=in_coff, conv_param=(groups, k_true))
+            if groups > 1:                                              # (groups, N, k_true, 1, 1) -> the parameter's (N, groups * k_true)
+                gw = gw.view(groups, N, k_true).permute(1, 0, 2).reshape(N, groups * k_true)
+            n0 = 0
+            for i in range(n_w):
+                o = shapes[i][0]
+                grads[i] = gw[n0:n0 + o].view(shapes[i])
+                n0 += o
+        if len(shapes) > n_w and any(ctx.needs_input_grad[5 + n_w:]):
+            gb = torch.zeros(N, device=d_out.device, dtype=torch.float32) if zero_bias_grad else ops.col_sum(d_out, N)
+            n0 = 0
+            for i in range(n_w, len(shapes)):
+                o = shapes[i][0]
+                grads[i] = gb[n0:n0 + o]
+                n0 += o
+        return (dx, None, None, None, None, *grads)
+
+
+def conv_params(x: torch.Tensor, forms: ParamForms, name: str, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]],
+                *, tmap=ops.TMAP_POINTWISE, T_out: Optional[int] = None, stats: bool = False, zero_bias_grad: bool = False,
+                in_coff: int = 0, scales: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The convolution(s) ``weights`` (concatenated along their output channels; ``scales`` > 1: ONE scale-major MLP weight) applied to
+    the channel window of x that starts at ``in_coff`` -> (y, BatchNorm partial sums or an empty tensor).  The packed forms live in
+    ``forms`` under ``name``."""
+    weights, biases = list(weights), [b for b in biases if b is not None]
+    x = x.contiguous()
+    if scales > 1 and x.shape[-1] == weights[0].shape[1]:
+        scales = 1                                                      # unpadded scale groups: an ordinary (O, S*C) matrix
+    inner = weights[0].shape[1] // scales
+    k_pad = x.shape[-1] // scales - inner if scales > 1 else 0
+    if scales == 1 and in_coff == 0 and x.shape[-1] != inner:
+        k_pad = x.shape[-1] - inner                                     # zero pad channels of the input (3 -> 4)
+    made: Dict[str, Form] = {}
+
+    def make(which):
+        def build():
+            if not made:
+                made["w"], made["wt"] = (scale_major_forms(weights[0], scales, k_pad) if scales > 1
+                                         else conv_weight_forms(weights, k_pad))
+            return made[which]
+        return build
+    w = forms.get(name + ".w", make("w"), x.device)
+    wt = forms.get(name + ".wt", make("wt"), x.device)
+    bias = forms.get(name + ".b", lambda: bias_form(biases), x.device) if biases else None
+    cfg = (tuple(tmap), x.shape[1] if T_out is None else T_out, stats, zero_bias_grad, in_coff, inner, scales, len(weights))
+    return _ConvParams.apply(x, w, wt, bias, cfg, *weights, *biases)
+
+
+class _NodeMixParams(torch.autograd.Function):
+    """_NodeMix with the packed matrix and its transpose as forms of (A + A_res); returns the gradient of A_res in its own layout."""
+
+    @staticmethod
+    def forward(ctx, x, a_fm, a_fm_t, a_res, S: int):
+        B, T, V, C = x.shape
+        Vp, Np = a_fm.shape
+        x_fm = ops.transpose(x.view(B * T, V, C), Vp)
+        out_fm = torch.empty((B * T, C, Np), device=x.device, dtype=torch.float32)
+        ops.rows_gemm(_rows4(x_fm), a_fm.unsqueeze(0), _rows4(out_fm), K=Vp, N=Np)
+        out = ops.transpose_into(out_fm, V * S)
+        ctx.save_for_backward(x_fm, a_fm_t)
+        ctx.dims = (B, T, V, C, S)
+        return out.view(B, T, V, S * C)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x_fm, a_fm_t = ctx.saved_tensors
+        B, T, V, C, S = ctx.dims
+        Np, Vp = a_fm_t.shape
+        d_fm = ops.transpose(d_out.contiguous().view(B * T, V * S, C), Np)
+        dx = da = None
+        if ctx.needs_input_grad[0]:
+            dx_fm = torch.empty((B * T, C, Vp), device=d_out.device, dtype=torch.float32)
+            ops.rows_gemm(_rows4(d_fm), a_fm_t.unsqueeze(0), _rows4(dx_fm), K=Np, N=Vp)
+            dx = ops.transpose_into(dx_fm, V).view(B, T, V, C)
+        if ctx.needs_input_grad[3]:
+            da_fm = ops.rows_wgrad(_rows4(x_fm), _rows4(d_fm), K=Vp, N=Np, wide=False)[0]        # (Vp, V*S): [u, v*S + s]
+            da = da_fm[:V].view(V, V, S).permute(2, 1, 0).reshape(S * V, V)
+        return dx, None, None, da, None
+
+
+def node_mix_params(x: torch.Tensor, forms: ParamForms, name: str, a_const: torch.Tensor, a_res: torch.Tensor, num_scales: int):
+    """node_mix with the stacked matrix (a_const + a_res); the packed matrix and its transpose are forms when V * S needs no column
+    padding (UTD-MHAD's 20 joints: every case), built with torch ops otherwise (NTU's 25 joints x 13 scales = 325 columns)."""
+    if (a_const.shape[1] * num_scales) % 4:
+        return node_mix(x, node_mix_matrix(a_const + a_res, num_scales), num_scales)
+    made: Dict[str, Form] = {}
+
+    def make(which):
+        def build():
+            if not made:
+                made["a"], made["at"] = node_mix_forms(a_const, a_res, num_scales)
+            return made[which]
+        return build
+    a_fm = forms.get(name + ".a", make("a"), x.device)
+    a_fm_t = forms.get(name + ".at", make("at"), x.device)
+    return _NodeMixParams.apply(x.contiguous(), a_fm, a_fm_t, a_res, num_scales)
+
+
+class _WindowBranchesParams(torch.autograd.Function):
+    """_WindowBranches on parameters: inputs h, the n packed weights, their n transposes, the n packed biases, then the n weight and n
+    bias parameters (for the gradients, which come back in the parameters' layouts)."""
+
+    @staticmethod
+    def forward(ctx, h, cfg, *rest):
+        n, bc, tmaps, stride, T_out, stats, zero_bias_grad = cfg
+        ws, wts, bs = rest[:n], rest[n:2 * n], rest[2 * n:3 * n]
+        B, T, V, ld = h.shape
+        outs, parts = [], []
+        for i in range(n):
+            y = torch.empty((B, T_out, V, bc), device=h.device, dtype=torch.float32)
+            part = ops.rows_gemm(h, ws[i], y, K=bc, N=bc, tmap=tmaps[i], bias=bs[i], stats=stats, in_coff=i * bc)
+            outs.append(y)
+            parts.append(part if part is not None else torch.empty(0, device=h.device))
+        pooled, idx = ops.tmaxpool3_fwd(h, stride, coff=n * bc, C=bc)
+        ctx.save_for_backward(h, idx, *wts)
+        ctx.cfg = cfg
+        ctx.shapes = [tuple(p.shape) for p in rest[3 * n:]]
+        ctx.mark_non_differentiable(*parts)
+        return (*outs, pooled, *parts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        h, idx, *wts = ctx.saved_tensors
+        n, bc, tmaps, stride, T_out, stats, zero_bias_grad = ctx.cfg
+        B, T, V, ld = h.shape
+        d_outs, d_pool = grads[:n], grads[n]
+        dh = torch.empty_like(h)
+        gws, gbs = [], []
+        zeros = torch.zeros(n * bc, device=h.device, dtype=torch.float32) if zero_bias_grad else None
+        for i in range(n):
+            d = d_outs[i].contiguous()
+            taps, ta, tb, tc, td = tmaps[i]
+            ops.rows_gemm(d, wts[i], dh, K=bc, N=bc, tmap=(taps, td, -tb, -tc, ta), out_coff=i * bc)
+            gws.append(ops.rows_wgrad(h, d, K=bc, N=bc, tmap=tmaps[i], a_coff=i * bc, conv_param=(1, bc)).view(ctx.shapes[i]))
+            gbs.append(zeros[i * bc:(i + 1) * bc] if zero_bias_grad else ops.col_sum(d, bc))
+        ops.tmaxpool3_bwd(d_pool.contiguous(), idx, T, stride, din=dh, coff=n * bc)
+        return (dh, None, *([None] * (3 * n)), *gws, *gbs)
+
+
+def window_branches_params(h, forms: ParamForms, name: str, convs, tmaps, bc: int, stride: int, T_out: int, stats: bool,
+                           zero_bias_grad: bool):
+    """``convs``: the n nn.Conv2d of the dilated branches (weights (bc, bc, k, 1))."""
+    n = len(convs)
+    ws, wts, bs = [], [], []
+    for i, conv in enumerate(convs):
+        made: Dict[str, Form] = {}
+
+        def make(which, conv=conv, made=made):
+            def build():
+                if not made:
+                    made["w"], made["wt"] = conv_weight_forms([conv.weight])
+                return made[which]
+            return build
+        ws.append(forms.get(f"{name}.{i}.w", make("w"), h.device))
+        wts.append(forms.get(f"{name}.{i}.wt", make("wt"), h.device))
+        bs.append(forms.get(f"{name}.{i}.b", lambda conv=conv: bias_form([conv.bias]), h.device))
+    cfg = (n, bc, tuple(tuple(t) for t in tmaps), stride, T_out, stats, zero_bias_grad)
+    out = _WindowBranchesParams.apply(h.contiguous(), cfg, *ws, *wts, *bs, *[c.weight for c in convs], *[c.bias for c in convs])
+    return out[:n], out[n], out[n + 1:]

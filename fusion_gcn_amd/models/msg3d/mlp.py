@@ -1,18 +1,12 @@
 """Point-wise MLP of the MS-G3D blocks (reference torch_src/models/msg3d/mlp.py:14-30): per layer Conv2d 1x1 -> BatchNorm2d ->
 activation, registered as ``layers.{0,1,2}`` (+3 per further layer).  The sub-modules hold parameters; the arithmetic is the row
-GEMM with BatchNorm partial sums in its epilogue + the fused BatchNorm / activation kernel (fops.conv_rows, fops.bn_act)."""
+GEMM with BatchNorm partial sums in its epilogue + the fused BatchNorm / activation kernel (fops.conv_params, fops.bn_act); the
+packed forms of the weights live in ``_forms`` and are refreshed with the whole model's (fops.refresh_forms)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import fops
 from .activation import activation_factory, is_relu
-
-
-def pointwise_weight(conv: nn.Module, k_pad: int = 0) -> torch.Tensor:
-    """(O, I, 1, 1[, 1]) -> the packed (1, I + k_pad, O) matrix of the row GEMM (differentiable re-layout of a small tensor)."""
-    w = conv.weight.reshape(conv.weight.shape[0], -1).t()
-    return (F.pad(w, (0, 0, 0, k_pad)) if k_pad else w).unsqueeze(0)
 
 
 class MLP(nn.Module):
@@ -23,13 +17,14 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList()
         for cin, cout in zip([in_channels] + list(out_channels), out_channels):
             self.layers += [nn.Conv2d(cin, cout, kernel_size=1), nn.BatchNorm2d(cout), activation_factory(activation)]
+        self._forms = fops.ParamForms()
 
-    def forward(self, x: torch.Tensor, weights=None) -> torch.Tensor:
-        """x (B, T, V, C) channels-last; ``weights``: per layer an already packed (1, K, N) matrix (callers whose input channels are
-        laid out differently from the reference's pass their own re-layout of layers[3i].weight)."""
+    def forward(self, x: torch.Tensor, scales: int = 1) -> torch.Tensor:
+        """x (B, T, V, C) channels-last.  ``scales`` > 1: x is a multi-scale aggregate (fops.node_mix) whose channel is s * width + c;
+        the first layer's weight (O, scales * C) is read scale-major, `width - C` zero pad channels per scale skipped."""
         for i in range(0, len(self.layers), 3):
             conv, bn, act = self.layers[i:i + 3]
-            w = weights[i // 3] if weights is not None else pointwise_weight(conv, x.shape[-1] - conv.in_channels)
-            y, part = fops.conv_rows(x, w, conv.bias, stats=bn.training, zero_bias_grad=bn.training)
+            y, part = fops.conv_params(x, self._forms, f"layers.{i}", [conv.weight], [conv.bias], stats=bn.training,
+                                       zero_bias_grad=bn.training, scales=scales if i == 0 else 1)
             x = fops.bn_act(y, part, bn, relu=is_relu(act))
         return x

@@ -23,16 +23,6 @@ def k_hop_stack(a: np.ndarray, num_scales: int) -> np.ndarray:
     return np.concatenate([normalize_adjacency_matrix(get_k_adjacency(a, k, with_self=True)) for k in range(num_scales)])
 
 
-def scale_major_weight(conv: nn.Conv2d, num_scales: int, c_pad: int) -> torch.Tensor:
-    """MLP weight (O, S*C) with input channel s*C + c -> packed (1, S*(C + c_pad), O) for an aggregate whose per-scale channel
-    groups are C + c_pad wide (the 3-channel network input travels as 4 channels, the 4th identically zero)."""
-    o = conv.weight.shape[0]
-    w = conv.weight.reshape(o, num_scales, -1)
-    if c_pad:
-        w = torch.nn.functional.pad(w, (0, c_pad))
-    return w.reshape(o, -1).t().unsqueeze(0)
-
-
 class MultiScale_GraphConv(nn.Module):
     def __init__(self, num_scales, in_channels, out_channels, A_binary, disentangled_agg=True, use_mask=True, dropout=0,
                  activation="relu"):
@@ -45,6 +35,7 @@ class MultiScale_GraphConv(nn.Module):
         self.use_mask = use_mask
         self.A_res = nn.init.uniform_(nn.Parameter(torch.empty(self.A_powers.shape)), -1e-6, 1e-6)
         self.mlp = MLP(in_channels * num_scales, [out_channels], dropout=dropout, activation=activation)
+        self._forms = fops.ParamForms()
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -52,6 +43,7 @@ class MultiScale_GraphConv(nn.Module):
         return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        a_fm = fops.node_mix_matrix(self.A_powers.to(x.device) + self.A_res, self.num_scales)
-        agg = fops.node_mix(x, a_fm, self.num_scales)                                  # (B, T, V, S * C)
-        return self.mlp(agg, weights=[scale_major_weight(self.mlp.layers[0], self.num_scales, x.shape[-1] - self.in_channels)])
+        if self.A_powers.device != x.device:
+            self.A_powers = self.A_powers.to(x.device)
+        agg = fops.node_mix_params(x, self._forms, "A", self.A_powers, self.A_res, self.num_scales)       # (B, T, V, S * C)
+        return self.mlp(agg, scales=self.num_scales)

@@ -13,7 +13,7 @@ import torch.nn as nn
 from ... import fops
 from .activation import activation_factory, is_relu
 from .mlp import MLP
-from .ms_gcn import k_hop_stack, scale_major_weight
+from .ms_gcn import k_hop_stack
 
 
 class UnfoldTemporalWindows(nn.Module):
@@ -43,6 +43,7 @@ class SpatialTemporal_MS_GCN(nn.Module):
         self.mlp = MLP(in_channels * num_scales, [out_channels], dropout=dropout, activation="linear")
         self.residual = lambda x: 0
         self.act = activation_factory(activation)
+        self._forms = fops.ParamForms()
 
     @staticmethod
     def build_spatial_temporal_graph(A_binary: np.ndarray, window_size: int) -> np.ndarray:
@@ -56,9 +57,10 @@ class SpatialTemporal_MS_GCN(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x (B, T', window * V, C) -> (B, T', window * V, out)"""
-        a_fm = fops.node_mix_matrix(self.A_scales.to(x.device) + self.A_res, self.num_scales)
-        agg = fops.node_mix(x, a_fm, self.num_scales)
+        if self.A_scales.device != x.device:
+            self.A_scales = self.A_scales.to(x.device)
+        agg = fops.node_mix_params(x, self._forms, "A", self.A_scales, self.A_res, self.num_scales)
         conv, bn, _ = self.mlp.layers
-        w = scale_major_weight(conv, self.num_scales, x.shape[-1] - self.in_channels)
-        y, part = fops.conv_rows(agg, w, conv.bias, stats=bn.training, zero_bias_grad=bn.training)
+        y, part = fops.conv_params(agg, self._forms, "mlp", [conv.weight], [conv.bias], stats=bn.training, zero_bias_grad=bn.training,
+                                   scales=self.num_scales)
         return fops.bn_act(y, part, bn, relu=is_relu(self.act))            # linear MLP, no residual, then the block's activation

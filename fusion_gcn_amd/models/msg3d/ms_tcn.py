@@ -14,12 +14,6 @@ import torch.nn as nn
 
 from ... import fops
 from .activation import activation_factory, is_relu
-from .mlp import pointwise_weight
-
-
-def temporal_weight(conv: nn.Conv2d) -> torch.Tensor:
-    """(O, I, k, 1) -> packed (k, I, O)."""
-    return conv.weight[..., 0].permute(2, 1, 0)
 
 
 def temporal_map(kernel_size: int, stride: int, dilation: int):
@@ -71,13 +65,13 @@ class TemporalConv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(pad, 0), stride=(stride, 1),
                               dilation=(dilation, 1))
         self.bn = nn.BatchNorm2d(out_channels)
+        self._forms = fops.ParamForms()
 
     def pre_bn(self, x: torch.Tensor, coff: int = 0):
         """conv(x[..., coff:coff + in_channels]) with BatchNorm partial sums -> (y, partials)"""
         k, s, d = self.conv.kernel_size[0], self.conv.stride[0], self.conv.dilation[0]
-        xin = x if coff == 0 and x.shape[-1] == self.conv.in_channels else x[..., coff:coff + self.conv.in_channels].contiguous()
-        return fops.conv_rows(xin, temporal_weight(self.conv), self.conv.bias, tmap=temporal_map(k, s, d),
-                              T_out=out_frames(x.shape[1], s), stats=self.bn.training, zero_bias_grad=self.bn.training)
+        return fops.conv_params(x, self._forms, "conv", [self.conv.weight], [self.conv.bias], tmap=temporal_map(k, s, d),
+                                T_out=out_frames(x.shape[1], s), stats=self.bn.training, zero_bias_grad=self.bn.training, in_coff=coff)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y, part = self.pre_bn(x)
@@ -109,30 +103,30 @@ class MultiScale_TemporalConv(nn.Module):
         else:
             self.residual = TemporalConv(in_channels, out_channels, kernel_size=residual_kernel_size, stride=stride)
         self.act = activation_factory(activation)
+        self._forms = fops.ParamForms()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         bc, s = self.branch_channels, self.stride
         lead = self.branches[:-1]                       # the five branches that start with an un-strided 1x1 conv + BN + act
         relu_heads = is_relu(lead[0][2])
         # one GEMM + one BatchNorm/activation pass for the five heads
-        w = torch.cat([pointwise_weight(b[0]) for b in lead], dim=2)                   # (1, Cin, 5 bc)
-        bias = torch.cat([b[0].bias for b in lead])
         joined = _JoinedBatchNorm([b[1] for b in lead])
-        h, part = fops.conv_rows(x, w, bias, stats=joined.training, zero_bias_grad=joined.training)
+        h, part = fops.conv_params(x, self._forms, "heads", [b[0].weight for b in lead], [b[0].bias for b in lead],      # (1, Cin, 5 bc)
+                                   stats=joined.training, zero_bias_grad=joined.training)
         h = fops.bn_act(h, part, joined, relu=relu_heads)
         joined.scatter_running_stats()
         # dilated (3 x 1) convolutions and the max pooling on their channel windows of h, read and differentiated in place
         tconvs = [b[3] for b in lead[:-1]]
         train = tconvs[0].bn.training
-        ys, pooled, parts = fops.window_branches(
-            h, [temporal_weight(t.conv) for t in tconvs], [t.conv.bias for t in tconvs],
+        ys, pooled, parts = fops.window_branches_params(
+            h, self._forms, "windows", [t.conv for t in tconvs],
             [temporal_map(t.conv.kernel_size[0], t.conv.stride[0], t.conv.dilation[0]) for t in tconvs], bc, s, out_frames(x.shape[1], s),
             stats=train, zero_bias_grad=train)
         outs = [fops.bn_act(y, part, t.bn) for y, part, t in zip(ys, parts, tconvs)]
         outs.append(fops.bn_act(pooled, fops.col_stats(pooled) if lead[-1][4].training else pooled.new_empty(0), lead[-1][4]))
         last = self.branches[-1]
-        y, part = fops.conv_rows(x, pointwise_weight(last[0]), last[0].bias, tmap=(1, s, 0, 0, 1), T_out=out_frames(x.shape[1], s),
-                                 stats=last[1].training, zero_bias_grad=last[1].training)
+        y, part = fops.conv_params(x, self._forms, "strided", [last[0].weight], [last[0].bias], tmap=(1, s, 0, 0, 1),
+                                   T_out=out_frames(x.shape[1], s), stats=last[1].training, zero_bias_grad=last[1].training)
         outs.append(fops.bn_act(y, part, last[1]))
         out = torch.cat(outs, dim=-1)
         res = self.residual(x)

@@ -47,6 +47,7 @@ class MS_G3D(nn.Module):
                                    num_scales=num_scales, window_size=window_size, use_Ares=True))
         self.out_conv = nn.Conv3d(self.embed_channels_out, out_channels, kernel_size=(1, window_size, 1))
         self.out_bn = nn.BatchNorm2d(out_channels)
+        self._forms = fops.ParamForms()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, _, V, _ = x.shape
@@ -55,9 +56,8 @@ class MS_G3D(nn.Module):
         # collapse: out[(b, t', v)] = sum_j W_j . h[(b, t', j*V + v)] -- a temporal conv over the frame index t'*window + j with
         # `window` taps and stride `window`
         h = h.view(B, Tw * ws, V, h.shape[-1])
-        w = self.out_conv.weight[:, :, 0, :, 0].permute(2, 1, 0)       # (window, embed_out, out)
-        y, part = fops.conv_rows(h, w, self.out_conv.bias, tmap=(ws, ws, 1, 0, 1), T_out=Tw, stats=self.out_bn.training,
-                                 zero_bias_grad=self.out_bn.training)
+        y, part = fops.conv_params(h, self._forms, "out_conv", [self.out_conv.weight], [self.out_conv.bias], tmap=(ws, ws, 1, 0, 1),
+                                   T_out=Tw, stats=self.out_bn.training, zero_bias_grad=self.out_bn.training)   # (window, embed_out, out)
         return fops.bn_act(y, part, self.out_bn)
 
 
@@ -99,8 +99,18 @@ class Model(nn.Module):
             cin = cout
         self.fc = nn.Linear(cin, num_classes)
 
+    def mark_packed_stale(self) -> None:
+        """Force the re-pack of every weight form at the next forward (what an optimizer step does through the version counters)."""
+        fops.mark_forms_stale(self)
+
+    def prepare_recording(self) -> None:
+        """GraphStep hook: the one-launch re-pack plan is built (device tables, an H2D copy) before the step is recorded."""
+        fops.mark_forms_stale(self)
+        fops.refresh_forms(self)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         N, M, T, V, C = x.size()
+        fops.refresh_forms(self)
         h = self.data_bn(x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T))
         h = h.view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)      # channels-last (B, T, V, C)
         h = F.pad(h, (0, (-C) % 4)).contiguous()                                      # 3 input channels travel as 4 (4th zero)
