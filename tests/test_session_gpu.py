@@ -210,3 +210,94 @@ def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
         else:
             assert torch.equal(sa[k], sb[k]), k
     assert opt.param_groups[0]["lr"] == pytest.approx(sched.get_last_lr()[0])
+
+
+# ---- two data-parallel ranks through the harness (one device shared, gloo: the control flow of the N > 1 path, not a measurement) ----
+def _dp_data(shape, classes):
+    return batches([4, 4, 4], shape, classes, seed=11)
+
+
+def _dp_worker(rank, world, port, out_path, mode):
+    import os
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fusion_gcn_amd import ops
+        from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
+        from fusion_gcn_amd.optim import FlatOptimizer
+        from fusion_gcn_amd.session.procedures import DefaultBatchProcessor, GraphStep
+        from fusion_gcn_amd.session.session import Session
+        shape, classes = (1, 24, 20, 3), 27
+        with ops.math_mode(mode):
+            model = agcn(shape, classes).to(DEV).train()
+            if rank:                                   # replicas start different on purpose: the broadcast must make them equal
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.add_(0.01)
+            broadcast_parameters(model, src=0)
+            grads = FlatGradients(model.parameters())
+            opt = FlatOptimizer(model.parameters(), "SGD", 0.01, momentum=0.9, grads=grads)
+            step = GraphStep(grads=grads)
+            mine = []
+            for x, y, idx in _dp_data(shape, classes):
+                sl = shard_batch(x.shape[0], rank, world)
+                mine.append((x[sl].contiguous(), y[sl].contiguous(), idx[sl]))
+            Session.train_epoch(DefaultBatchProcessor(step), model, F.cross_entropy, mine, opt)
+            torch.cuda.synchronize()
+            assert step.replays == 3 and len(step._recorded) == 1
+        torch.save({k: v.cpu() for k, v in model.state_dict().items()}, f"{out_path}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_graph_step_match_two_sequential_replicas(tmp_path, fgcn_math):
+    import socket
+
+    import torch.multiprocessing as mp
+    from fusion_gcn_amd.dp import FlatGradients, shard_batch
+    from fusion_gcn_amd.optim import FlatOptimizer
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "rank")
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, out, fgcn_math)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = [torch.load(f"{out}.{r}") for r in range(world)]
+    for k in got[0]:                                   # parameters identical on both ranks; BatchNorm statistics are per replica
+        if "running_" not in k and "num_batches" not in k:
+            assert torch.equal(got[0][k], got[1][k]), k
+
+    # the same two shards one after the other in this process: per-replica BatchNorm, averaged gradients, the same update twice
+    shape, classes = (1, 24, 20, 3), 27
+    reps = []
+    for _ in range(world):
+        m = agcn(shape, classes).to(DEV).train()
+        g = FlatGradients(m.parameters())
+        reps.append((m, g, FlatOptimizer(m.parameters(), "SGD", 0.01, momentum=0.9, grads=g)))
+    for x, y, _ in _dp_data(shape, classes):
+        for r, (m, g, opt) in enumerate(reps):
+            sl = shard_batch(x.shape[0], r, world)
+            opt.zero_grad()
+            F.cross_entropy(m(x[sl].contiguous()), y[sl]).backward()
+            g.gather()
+        mean = sum(g.flat for _, g, _ in reps) / world
+        for m, g, opt in reps:
+            g.flat.copy_(mean)
+            opt.step()
+    torch.cuda.synchronize()
+    for r, (m, _, _) in enumerate(reps):
+        want = m.state_dict()
+        for k, v in got[r].items():
+            w = want[k].cpu()
+            if v.is_floating_point():
+                assert float((v - w).abs().max()) <= 2e-6 * max(1e-3, float(w.abs().max())), (r, k)
+            else:
+                assert torch.equal(v, w), (r, k)
