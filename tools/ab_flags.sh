@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of bench.py flag sets (run on the GPU box from the repo root): tools/ab_flags.sh "<flags A>" "<flags B>" ...
+# Boxes of the pool differ by +-2-3 %, so only numbers from ONE call compare.
+mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/ab.log
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-kernel-timing"
+for rep in 1 2; do
+for t in "$@"; do
+    echo "== $t" >> gpurun_out/ab/ab.log
+    $B $t 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['loss'])" >> gpurun_out/ab/ab.log 2>&1 || exit 1
+done
+done
+cat gpurun_out/ab/ab.log
