@@ -815,10 +815,11 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
 using namespace fgcn;
 
 // output rows per workgroup: 128, or 96 in the bf16 math modes when the 128-row tile's halo image (9 taps: 128 + 8 V rows, three
-// 80-byte planes) would not fit twice into LDS (V > 26)
+// planes of unpadded 64-byte rows) would not fit twice into LDS -- with the swizzled image that is V > 36, i.e. never (V <= 32):
+// the 27- and 22-joint shapes of BASELINE configs 3 / 4 run the 128-row tile too (they took the 96-row one with 80-byte rows)
 static int halo_tile_rows(int V) {
     const bool k32 = fgcn::math_mode() == FGCN_MATH_BF16 || (fgcn::math_mode() == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 6));
-    return (k32 && (128 + 8 * V) * XSB * 3 > 80 * 1024) ? 96 : 128;
+    return (k32 && (128 + 8 * V) * 64 * 3 > 80 * 1024) ? 96 : 128;
 }
 
 // 1 when fgcn_tconv_halo can emit the BatchNorm-backward sums in the current math mode / tuning (the 16x16x32 split-bf16 kernel)
