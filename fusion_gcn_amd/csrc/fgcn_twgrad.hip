@@ -182,7 +182,7 @@ constexpr int X3_APASS = 6;              // passes of 64 rows: window <= 128 + 8
 // TN = 128: waves = 4 column tiles x 2 row halves of a 64-row stage; TN = 64: 2 column tiles x 4 row quarters of a 128-row
 // stage (a wave always owns 32 rows = two 16-row steps).  g rows are padded by 64 bytes: 4 consecutive rows then land 64
 // bytes apart modulo 256 = one transposed read touches every bank once.
-constexpr int x3_rows(int tn) { return tn == 128 ? 64 : 128; }
+constexpr int x3_rows(int tn, int wv = 8) { return 32 * (wv / (tn / 32)); }   // 8 waves: 64 (TN 128) / 128 (TN 64); 4 waves: half
 constexpr int x3_sg(int tn) { return tn * 2 + 64; }
 
 __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
@@ -196,12 +196,18 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 // starts X3_R rows further instead of V rows further; everything else is the same kernel.
 // NP = bf16 parts per operand: 3 (FGCN_MATH_BF16X3) or 1 (FGCN_MATH_BF16: operands rounded once as the stage is written, one
 // MFMA per product group).
-template <int NTAP, int TN, bool CH, int NP>
-__global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
+// WV = waves per workgroup: 8 (one workgroup per CU, the next stage's rows prefetched into registers across the MFMAs) or 4 (half
+// the rows per stage, TWO workgroups per CU and no prefetch: one workgroup stages while the other multiplies, as in the halo conv).
+template <int NTAP, int TN, bool CH, int NP, int WV = 8>
+__global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kernel(TWgradP p) {
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int X3_R = x3_rows(TN), X3_SG = x3_sg(TN);
-    constexpr int NSUBS = TN / 32, NPARTS = 8 / NSUBS;
-    constexpr int GT = TN / 4, GRP = 512 / GT;                    // g staging: threads per row, rows per pass (4 passes)
+    constexpr int NT = 64 * WV;
+    constexpr int X3_R = x3_rows(TN, WV), X3_SG = x3_sg(TN);
+    constexpr int NSUBS = TN / 32, NPARTS = WV / NSUBS;
+    constexpr int GT = TN / 4, GRP = NT / GT;                     // g staging: threads per row, rows per pass (4 passes)
+    constexpr int RA = NT / 8;                                    // a staging: 8 threads per row of 32 channels, rows per pass
+    constexpr int APASS = WV == 8 ? X3_APASS : (X3_R + 8 * 32 + RA - 1) / RA;
+    constexpr bool PF = WV == 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nsub = wave % NSUBS, part = wave / NSUBS;
@@ -219,17 +225,17 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
     const bool strided = p.a_s != 1 || p.a_o != 0;
 
-    // staging roles: a: row tid/8 + 64*i, channels k0 + (tid%8)*4;  g: row tid/GT + GRP*i, columns n0 + (tid%GT)*4
+    // staging roles: a: row tid/8 + RA*i, channels k0 + (tid%8)*4;  g: row tid/GT + GRP*i, columns n0 + (tid%GT)*4
     const int a_row = tid >> 3, a_c4 = tid & 7, g_row = tid / GT, g_c4 = tid % GT;
     const bool a_cok = k0 + a_c4 * 4 < p.K, g_cok = n0 + g_c4 * 4 < p.N;
-    f32x4 sa[X3_APASS], sg[4];
+    f32x4 sa[APASS], sg[4];
     auto fetch = [&](int sid) {
         const int n = sid / p.stages_per_sample;
         const int r0 = (sid - n * p.stages_per_sample) * X3_R;
 #pragma unroll
-        for (int i = 0; i < X3_APASS; ++i) {
-            const int wr = a_row + 64 * i;
-            const int chunk = CH ? (64 * i) / X3_R : 0;           // compile-time per pass
+        for (int i = 0; i < APASS; ++i) {
+            const int wr = a_row + RA * i;
+            const int chunk = CH ? (RA * i) / X3_R : 0;           // compile-time per pass
             const int q = CH ? r0 + wr - chunk * X3_R : r0 + p.shift0 * V + wr;   // row of the frame view inside the sample
             const bool ok = (CH ? k0 + chunk * 32 + a_c4 * 4 < p.K : a_cok) && wr < win && q >= 0 && q < p.Th_a * V;
             int row = ok ? q : 0;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
             const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + chunk * 32 + a_c4 * 4) * 4u : OOB;
-            if (i * 64 < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            if (i * RA < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -249,9 +255,9 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
     };
     auto deposit = [&]() {
 #pragma unroll
-        for (int i = 0; i < X3_APASS; ++i) {
-            const int wr = a_row + 64 * i;
-            if (i * 64 < win && wr < win) {
+        for (int i = 0; i < APASS; ++i) {
+            const int wr = a_row + RA * i;
+            if (i * RA < win && wr < win) {
                 u32x2 ph, pm, pl;
                 split3_x4(sa[i], ph, pm, pl);
                 unsigned char* d = Ap + wr * X3_SA + a_c4 * 8;
@@ -300,12 +306,13 @@ __global__ __launch_bounds__(512, 1) void tconv_wgrad_x3_kernel(TWgradP p) {
         }
     };
 
-    if (sbeg < send) fetch(sbeg);
+    if (PF && sbeg < send) fetch(sbeg);
     for (int sid = sbeg; sid < send; ++sid) {
         __syncthreads();                                          // the previous stage's fragment reads are done
+        if constexpr (!PF) fetch(sid);                            // (the CU's other workgroup multiplies meanwhile)
         deposit();
         __syncthreads();
-        if (sid + 1 < send) fetch(sid + 1);                       // lands during the MFMAs below
+        if (PF && sid + 1 < send) fetch(sid + 1);                 // lands during the MFMAs below
         u32x4v gq[2][NP];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) frag(g_lane + nt * 32, g_plane, X3_SG, gq[nt]);
@@ -359,16 +366,24 @@ using namespace fgcn;
 static bool twgrad_use_x3(int N, int chunk_mode) {
     return fgcn::math_mode() != FGCN_MATH_F32 && !(chunk_mode && (fgcn::tuning(6) & 1));   // both bf16 modes (3 parts / 1 part)
 }
+// The split-bf16 kernel as one 8-wave workgroup per CU (next stage prefetched) or two 4-wave ones (half the rows per stage, no
+// prefetch).  Measured at B = 128 (tools/kbench.py wgrad, same box): 1x1 weight gradients -3 .. -9 % with the two small workgroups
+// (K = 64: +3 %), the nine-tap ones +1-2 % (64 channels +32 %: their tap window is re-staged per stage, twice as often with half the
+// rows) -> 1x1: 4 waves, all taps: 8 waves.  (tuning key 6 bit 5 turns the 4-wave form off, bit 6 forces it for the tap kernels.)
+static int twgrad_x3_waves(int chunk_mode) {
+    if (chunk_mode) return (fgcn::tuning(6) & 32) ? 8 : 4;
+    return (fgcn::tuning(6) & 64) ? 4 : 8;
+}
 static int twgrad_parts(int N, int chunk_mode) {
-    if (twgrad_use_x3(N, chunk_mode)) return N <= 64 ? 4 : 2;
+    if (twgrad_use_x3(N, chunk_mode)) return twgrad_x3_waves(chunk_mode) / (N <= 64 ? 2 : 4);
     return N <= 64 ? 2 : 1;
 }
 
 extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 0); }
 extern "C" int fgcn_pw_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 1); }
 /* workgroups of one launch that are resident at once (the row-split count is chosen so that tiles * nsplit fits) */
-extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) ? 256 : 512; }
-extern "C" int fgcn_pw_wgrad_resident(int N) { return twgrad_use_x3(N, 1) ? 256 : 512; }
+extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) && twgrad_x3_waves(0) == 8 ? 256 : 512; }
+extern "C" int fgcn_pw_wgrad_resident(int N) { return twgrad_use_x3(N, 1) && twgrad_x3_waves(1) == 8 ? 256 : 512; }
 
 template <int NTAP>
 static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
@@ -401,9 +416,13 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
     static bool opt_in = false;
     if (!opt_in) {
 #define FGCN_TWX_ATTR(TN_)                                                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3>),         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 8>),      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1>),         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 8>),      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 4>),      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 4>),      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         FGCN_TWX_ATTR(128);
         if constexpr (!CH || NTAP <= 3) { FGCN_TWX_ATTR(64); }
@@ -411,10 +430,16 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
         opt_in = true;
     }
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
+    const bool half = twgrad_x3_waves(CH ? 1 : 0) == 4;
 #define FGCN_TWX_LAUNCH(TN_)                                                                                    \
     do {                                                                                                        \
-        if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1>), grid, dim3(512), lds, s, p);    \
-        else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3>), grid, dim3(512), lds, s, p);        \
+        if (half) {                                                                                             \
+            if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 4>), grid, dim3(256), lds, s, p); \
+            else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 4>), grid, dim3(256), lds, s, p);  \
+        } else {                                                                                                \
+            if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 8>), grid, dim3(512), lds, s, p); \
+            else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 8>), grid, dim3(512), lds, s, p);  \
+        }                                                                                                       \
     } while (0)
     if (N <= 64) {
         if constexpr (!CH || NTAP <= 3) FGCN_TWX_LAUNCH(64);
@@ -446,7 +471,7 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.B = B; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
     p.T_a_full = T_a_full; p.a_s = a_s; p.a_o = a_o; p.Th_a = Th_a;
     p.shift0 = shift0; p.tap0 = tap0; p.tap_step = tap_step; p.taps_total = taps_total;
-    p.stage_rows = N <= 64 ? 128 : 64;
+    p.stage_rows = x3 ? x3_rows(N <= 64 ? 64 : 128, twgrad_x3_waves(chunk_mode)) : (N <= 64 ? 128 : 64);
     p.stages_per_sample = (int)cdiv((long long)T_g * V, p.stage_rows);
     p.total_stages = B * p.stages_per_sample;
     p.stages_per_split = (int)cdiv(p.total_stages, nsplit);
@@ -456,11 +481,13 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
     const int planes = chunk_mode ? nacc : 1;
     const int tn_x3 = N <= 64 ? 64 : 128;
-    const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3) : p.win_rows;
+    const int wv_x3 = twgrad_x3_waves(chunk_mode);
+    const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3, wv_x3) : p.win_rows;
     const size_t lds = x3 ? (size_t)(fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3) *
-                                ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3) * x3_sg(tn_x3))
+                                ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3, wv_x3) * x3_sg(tn_x3))
                           : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
-    FGCN_REQUIRE(!x3 || win_x3 <= 64 * X3_APASS, FGCN_E_BADARG, "%s: window of %d rows too large", what, win_x3);
+    FGCN_REQUIRE(!x3 || win_x3 <= (wv_x3 == 8 ? 64 * X3_APASS : x3_rows(tn_x3, 4) + 8 * 32), FGCN_E_BADARG,
+                 "%s: window of %d rows too large", what, win_x3);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
     const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);
     dim3 grid((unsigned)(tiles_k * p.tiles_n), (unsigned)nsplit);

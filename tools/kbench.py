@@ -16,6 +16,7 @@ from fusion_gcn_amd import _lib, block, ops  # noqa: E402
 
 V = 25
 DEV = torch.device("cuda:0")
+TUNE = {}          # --tune pairs (sections that flip a key for an A/B line restore the requested value)
 
 
 def timeit(fn, reps):
@@ -116,9 +117,9 @@ def bench_wgrad(B, reps):
             report(f"pw_wgrad {name} T{ta} K{K} N{N} (channel chunks)", ms, 2.0 * B * tg * V * K * N,
                    4.0 * B * V * (ta * K + tg * N))
             if ops.get_math_mode() == "bf16x3":
-                _lib.load().fgcn_set_tuning(6, 1)
+                _lib.load().fgcn_set_tuning(6, TUNE.get(6, 0) | 1)
                 ms = timeit(lambda: ops.rows_wgrad(a, g, K=K, N=N, tmap=tm, wide=True), reps)
-                _lib.load().fgcn_set_tuning(6, 0)
+                _lib.load().fgcn_set_tuning(6, TUNE.get(6, 0))
                 report("  same, fragments split as they are read (256-thread kernel)", ms, 2.0 * B * tg * V * K * N,
                        4.0 * B * V * (ta * K + tg * N))
         if kt > 1:
@@ -231,6 +232,7 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         _lib.load().fgcn_set_tuning(int(k), int(v))
+        TUNE[int(k)] = int(v)
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
