@@ -26,6 +26,7 @@ struct TWgradP {
     int stages_per_sample, total_stages, stages_per_split;
     int tiles_n, win_rows, stage_rows;
     int chunk_mode;   // 0: accumulator j = tap j (window rows shifted by j*V); 1: accumulator j = in-channel chunk j (1x1 conv)
+    int ring_rows;    // tap mode of the split-bf16 kernel, RING form: rows of the circular window image (256 or 512)
     unsigned a_bytes, g_bytes, p_bytes;
 };
 
@@ -198,15 +199,21 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 // MFMA per product group).
 // WV = waves per workgroup: 8 (one workgroup per CU, the next stage's rows prefetched into registers across the MFMAs) or 4 (half
 // the rows per stage, TWO workgroups per CU and no prefetch: one workgroup stages while the other multiplies, as in the halo conv).
-template <int NTAP, int TN, bool CH, int NP, int WV = 8>
+// RING (tap mode): consecutive stages of a sample need windows that overlap in all but X3_R rows -- [r0 + sh, r0 + sh + X3_R +
+// (NTAP-1) V) slides by X3_R.  Instead of fetching, splitting and writing the whole window per stage (264 rows for 64 new ones at
+// 9 taps, V = 25) the a planes are a circular image: row q of the sample's frame view lives at slot q & (ring_rows - 1), a stage
+// adds its X3_R new rows (prefetched across the previous stage's MFMAs), and only the first stage of a sample (or of the
+// workgroup's share) fills the (NTAP-1) V older rows, synchronously.  Fragment addresses wrap per read.
+template <int NTAP, int TN, bool CH, int NP, int WV = 8, bool RING = false>
 __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kernel(TWgradP p) {
+    static_assert(!(RING && CH), "the circular window is the tap mode's");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NT = 64 * WV;
     constexpr int X3_R = x3_rows(TN, WV), X3_SG = x3_sg(TN);
     constexpr int NSUBS = TN / 32, NPARTS = WV / NSUBS;
     constexpr int GT = TN / 4, GRP = NT / GT;                     // g staging: threads per row, rows per pass (4 passes)
     constexpr int RA = NT / 8;                                    // a staging: 8 threads per row of 32 channels, rows per pass
-    constexpr int APASS = WV == 8 ? X3_APASS : (X3_R + 8 * 32 + RA - 1) / RA;
+    constexpr int APASS = RING ? X3_R / RA : (WV == 8 ? X3_APASS : (X3_R + 8 * 32 + RA - 1) / RA);
     constexpr bool PF = WV == 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,7 +222,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     const int k0 = tk * (CH ? 32 * NTAP : 32), n0 = tn * TN;
     const int V = p.V, TVg = p.T_g * V;
     const int win = CH ? NTAP * X3_R : p.win_rows;                // tap mode: X3_R + (NTAP - 1) * V
-    const unsigned a_plane = (unsigned)win * X3_SA, g_plane = X3_R * X3_SG;
+    const unsigned a_plane = (unsigned)(RING ? p.ring_rows : win) * X3_SA, g_plane = X3_R * X3_SG;
+    const int rmask = p.ring_rows - 1;
     unsigned char* Ap = lds_raw;                                  // [3][win][32] bf16
     unsigned char* Gp = lds_raw + NP * a_plane;                   // [NP][X3_R][128 (+32 pad)] bf16
     const int sbeg = blockIdx.y * p.stages_per_split;
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
         const int r0 = (sid - n * p.stages_per_sample) * X3_R;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            const int wr = a_row + RA * i;
+            const int wr = (RING ? win - X3_R : 0) + a_row + RA * i;    // RING: only the X3_R newest rows of the window
             const int chunk = CH ? (RA * i) / X3_R : 0;           // compile-time per pass
             const int q = CH ? r0 + wr - chunk * X3_R : r0 + p.shift0 * V + wr;   // row of the frame view inside the sample
             const bool ok = (CH ? k0 + chunk * 32 + a_c4 * 4 < p.K : a_cok) && wr < win && q >= 0 && q < p.Th_a * V;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
             const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + chunk * 32 + a_c4 * 4) * 4u : OOB;
-            if (i * RA < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            if (RING || i * RA < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -253,9 +261,44 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
             sg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
         }
     };
-    auto deposit = [&]() {
+    auto put_a = [&](int slot, f32x4 v) {
+        u32x2 ph, pm, pl;
+        split3_x4(v, ph, pm, pl);
+        unsigned char* d = Ap + slot * X3_SA + a_c4 * 8;
+        *reinterpret_cast<u32x2*>(d) = ph;
+        if constexpr (NP == 3) {
+            *reinterpret_cast<u32x2*>(d + a_plane) = pm;
+            *reinterpret_cast<u32x2*>(d + 2 * a_plane) = pl;
+        }
+    };
+    // RING: the (NTAP - 1) V rows in front of the stage's new ones -- once per sample / per workgroup share, not prefetched
+    auto fill = [&](int sid) {
+        const int n = sid / p.stages_per_sample;
+        const int r0 = (sid - n * p.stages_per_sample) * X3_R;
+        const int cnt = win - X3_R;
+        for (int i = 0; i * RA < cnt; ++i) {
+            const int wr = a_row + RA * i;
+            const int q = r0 + p.shift0 * V + wr;
+            const bool ok = a_cok && wr < cnt && q >= 0 && q < p.Th_a * V;
+            int row = ok ? q : 0;
+            if (strided) {
+                const int f = (int)((unsigned)row / (unsigned)V);
+                row = (f * p.a_s + p.a_o) * V + (row - f * V);
+            }
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + a_c4 * 4) * 4u : OOB;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            if (wr < cnt) put_a(q & rmask, v);
+        }
+    };
+    auto deposit = [&](int sid) {
+        if constexpr (RING) {
+            const int n = sid / p.stages_per_sample;
+            const int q0 = (sid - n * p.stages_per_sample) * X3_R + p.shift0 * V + win - X3_R;
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) {
+            for (int i = 0; i < APASS; ++i) put_a((q0 + a_row + RA * i) & rmask, sa[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < (RING ? 0 : APASS); ++i) {
             const int wr = a_row + RA * i;
             if (i * RA < win && wr < win) {
                 u32x2 ph, pm, pl;
@@ -310,17 +353,37 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     for (int sid = sbeg; sid < send; ++sid) {
         __syncthreads();                                          // the previous stage's fragment reads are done
         if constexpr (!PF) fetch(sid);                            // (the CU's other workgroup multiplies meanwhile)
-        deposit();
+        if constexpr (RING) {
+            if (sid == sbeg || sid % p.stages_per_sample == 0) fill(sid);
+        }
+        deposit(sid);
         __syncthreads();
         if (PF && sid + 1 < send) fetch(sid + 1);                 // lands during the MFMAs below
         u32x4v gq[2][NP];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) frag(g_lane + nt * 32, g_plane, X3_SG, gq[nt]);
+        int lane_q = 0;                                           // RING: this lane's first window row, before the tap shift
+        if constexpr (RING) {
+            const int n = sid / p.stages_per_sample;
+            lane_q = (sid - n * p.stages_per_sample) * X3_R + p.shift0 * V + part * 32 + 8 * g4 + q4;
+        }
 #pragma unroll
         for (int j = 0; j < NTAP; ++j) {
             u32x4v aq[2][NP];
+            if constexpr (RING) {
+                const unsigned char* lo = Ap + ((lane_q + j * V) & rmask) * X3_SA + (4 * c4) * 2;
+                const unsigned char* hi = Ap + ((lane_q + j * V + 4) & rmask) * X3_SA + (4 * c4) * 2;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) frag(a_lane + (j * (CH ? X3_R : V)) * X3_SA + kt * 32, a_plane, X3_SA, aq[kt]);
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const u32x2 l = lds_read_tr16(lo + kt * 32 + pl * a_plane);
+                        const u32x2 h = lds_read_tr16(hi + kt * 32 + pl * a_plane);
+                        aq[kt][pl] = u32x4v{l[0], l[1], h[0], h[1]};
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < (RING ? 0 : 2); ++kt) frag(a_lane + (j * (CH ? X3_R : V)) * X3_SA + kt * 32, a_plane, X3_SA, aq[kt]);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -367,23 +430,28 @@ static bool twgrad_use_x3(int N, int chunk_mode) {
     return fgcn::math_mode() != FGCN_MATH_F32 && !(chunk_mode && (fgcn::tuning(6) & 1));   // both bf16 modes (3 parts / 1 part)
 }
 // The split-bf16 kernel as one 8-wave workgroup per CU (next stage prefetched) or two 4-wave ones (half the rows per stage, no
-// prefetch).  Measured at B = 128 (tools/kbench.py wgrad, same box): 1x1 weight gradients -3 .. -9 % with the two small workgroups
-// (K = 64: +3 %), the nine-tap ones +1-2 % (64 channels +32 %: their tap window is re-staged per stage, twice as often with half the
-// rows) -> 1x1: 4 waves, all taps: 8 waves.  (tuning key 6 bit 5 turns the 4-wave form off, bit 6 forces it for the tap kernels.)
-static int twgrad_x3_waves(int chunk_mode) {
+// prefetch), and in the tap mode with the circular window image (RING).  Measured at B = 128 (tools/kbench.py wgrad, same box):
+//   1x1 weight gradients: two small workgroups -3 .. -9 % (K = 64: +3 %);
+//   all taps, 128 / 256 columns: circular window -10 .. -14 % on 8 waves, another 0-2 % on 4 (without the circular window the
+//     4-wave form re-stages the 8 V-row tap window twice as often: +1-2 %);
+//   all taps, 64 columns (128-row stages): the circular window does not fit beside the g planes on 8 waves and loses 8 % on 4.
+// -> 1x1: 4 waves; all taps: 4 waves + circular window above 64 columns, 8 waves without it at 64.
+// (tuning key 6: bit 5 = 1x1 on 8 waves, bit 6 = flip the tap kernels' wave count, bit 7 = no circular window.)
+static int twgrad_x3_waves(int N, int chunk_mode) {
     if (chunk_mode) return (fgcn::tuning(6) & 32) ? 8 : 4;
-    return (fgcn::tuning(6) & 64) ? 4 : 8;
+    const int w = N > 64 ? 4 : 8;
+    return (fgcn::tuning(6) & 64) ? 12 - w : w;
 }
 static int twgrad_parts(int N, int chunk_mode) {
-    if (twgrad_use_x3(N, chunk_mode)) return twgrad_x3_waves(chunk_mode) / (N <= 64 ? 2 : 4);
+    if (twgrad_use_x3(N, chunk_mode)) return twgrad_x3_waves(N, chunk_mode) / (N <= 64 ? 2 : 4);
     return N <= 64 ? 2 : 1;
 }
 
 extern "C" int fgcn_tconv_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 0); }
 extern "C" int fgcn_pw_wgrad_slabs(int N, int nsplit) { return nsplit * twgrad_parts(N, 1); }
 /* workgroups of one launch that are resident at once (the row-split count is chosen so that tiles * nsplit fits) */
-extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) && twgrad_x3_waves(0) == 8 ? 256 : 512; }
-extern "C" int fgcn_pw_wgrad_resident(int N) { return twgrad_use_x3(N, 1) && twgrad_x3_waves(1) == 8 ? 256 : 512; }
+extern "C" int fgcn_tconv_wgrad_resident(int N) { return twgrad_use_x3(N, 0) && twgrad_x3_waves(N, 0) == 8 ? 256 : 512; }
+extern "C" int fgcn_pw_wgrad_resident(int N) { return twgrad_use_x3(N, 1) && twgrad_x3_waves(N, 1) == 8 ? 256 : 512; }
 
 template <int NTAP>
 static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
@@ -413,32 +481,35 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 template <int NTAP, bool CH>
 static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
     static_assert(!CH || NTAP <= 6, "chunk mode: at most 6 (128 columns) / 3 (64 columns) chunks fit the staging passes");
+    constexpr bool RG = !CH;                          // the circular-window form exists for the tap mode only
     static bool opt_in = false;
     if (!opt_in) {
-#define FGCN_TWX_ATTR(TN_)                                                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 8>),      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 8>),      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 4>),      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 4>),      \
+#define FGCN_TWX_ATTR1(TN_, NP_, WV_, RING_)                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN_, CH, NP_, WV_, RING_>), \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define FGCN_TWX_ATTR(TN_)                                                                                            \
+    FGCN_TWX_ATTR1(TN_, 3, 8, false); FGCN_TWX_ATTR1(TN_, 1, 8, false); FGCN_TWX_ATTR1(TN_, 3, 4, false);            \
+    FGCN_TWX_ATTR1(TN_, 1, 4, false); FGCN_TWX_ATTR1(TN_, 3, 8, RG); FGCN_TWX_ATTR1(TN_, 1, 8, RG);                  \
+    FGCN_TWX_ATTR1(TN_, 3, 4, RG); FGCN_TWX_ATTR1(TN_, 1, 4, RG)
         FGCN_TWX_ATTR(128);
         if constexpr (!CH || NTAP <= 3) { FGCN_TWX_ATTR(64); }
 #undef FGCN_TWX_ATTR
+#undef FGCN_TWX_ATTR1
         opt_in = true;
     }
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
-    const bool half = twgrad_x3_waves(CH ? 1 : 0) == 4;
+    const bool half = twgrad_x3_waves(N, CH ? 1 : 0) == 4;
+    const bool ring = RG && p.ring_rows > 0;
+#define FGCN_TWX_GO(TN_, NP_, WV_, RING_) \
+    hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, NP_, WV_, RING_>), grid, dim3(64 * WV_), lds, s, p)
 #define FGCN_TWX_LAUNCH(TN_)                                                                                    \
     do {                                                                                                        \
-        if (half) {                                                                                             \
-            if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 4>), grid, dim3(256), lds, s, p); \
-            else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 4>), grid, dim3(256), lds, s, p);  \
+        if (ring) {                                                                                             \
+            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, RG); else FGCN_TWX_GO(TN_, 3, 4, RG); }                 \
+            else { if (one) FGCN_TWX_GO(TN_, 1, 8, RG); else FGCN_TWX_GO(TN_, 3, 8, RG); }                      \
         } else {                                                                                                \
-            if (one) hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 1, 8>), grid, dim3(512), lds, s, p); \
-            else hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, 3, 8>), grid, dim3(512), lds, s, p);  \
+            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, false); else FGCN_TWX_GO(TN_, 3, 4, false); }           \
+            else { if (one) FGCN_TWX_GO(TN_, 1, 8, false); else FGCN_TWX_GO(TN_, 3, 8, false); }                \
         }                                                                                                       \
     } while (0)
     if (N <= 64) {
@@ -447,6 +518,7 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
         FGCN_TWX_LAUNCH(128);
     }
 #undef FGCN_TWX_LAUNCH
+#undef FGCN_TWX_GO
 }
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
@@ -471,7 +543,7 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.B = B; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
     p.T_a_full = T_a_full; p.a_s = a_s; p.a_o = a_o; p.Th_a = Th_a;
     p.shift0 = shift0; p.tap0 = tap0; p.tap_step = tap_step; p.taps_total = taps_total;
-    p.stage_rows = x3 ? x3_rows(N <= 64 ? 64 : 128, twgrad_x3_waves(chunk_mode)) : (N <= 64 ? 128 : 64);
+    p.stage_rows = x3 ? x3_rows(N <= 64 ? 64 : 128, twgrad_x3_waves(N, chunk_mode)) : (N <= 64 ? 128 : 64);
     p.stages_per_sample = (int)cdiv((long long)T_g * V, p.stage_rows);
     p.total_stages = B * p.stages_per_sample;
     p.stages_per_split = (int)cdiv(p.total_stages, nsplit);
@@ -481,12 +553,15 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
     const int planes = chunk_mode ? nacc : 1;
     const int tn_x3 = N <= 64 ? 64 : 128;
-    const int wv_x3 = twgrad_x3_waves(chunk_mode);
+    const int wv_x3 = twgrad_x3_waves(N, chunk_mode);
     const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3, wv_x3) : p.win_rows;
-    const size_t lds = x3 ? (size_t)(fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3) *
-                                ((size_t)win_x3 * X3_SA + (size_t)x3_rows(tn_x3, wv_x3) * x3_sg(tn_x3))
+    // tap mode, more than one tap: the circular window image (tuning key 6 bit 7 switches it off)
+    p.ring_rows = (x3 && !chunk_mode && nacc > 1 && !(fgcn::tuning(6) & 128)) ? (win_x3 <= 256 ? 256 : 512) : 0;
+    const size_t np_x3 = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3, g_x3 = (size_t)x3_rows(tn_x3, wv_x3) * x3_sg(tn_x3);
+    if (p.ring_rows && np_x3 * ((size_t)p.ring_rows * X3_SA + g_x3) > 160 * 1024) p.ring_rows = 0;   // (64-column tiles, 128-row stages)
+    const size_t lds = x3 ? np_x3 * ((size_t)(p.ring_rows ? p.ring_rows : win_x3) * X3_SA + g_x3)
                           : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
-    FGCN_REQUIRE(!x3 || win_x3 <= (wv_x3 == 8 ? 64 * X3_APASS : x3_rows(tn_x3, 4) + 8 * 32), FGCN_E_BADARG,
+    FGCN_REQUIRE(!x3 || win_x3 <= (p.ring_rows ? p.ring_rows : (wv_x3 == 8 ? 64 * X3_APASS : x3_rows(tn_x3, 4) + 8 * 32)), FGCN_E_BADARG,
                  "%s: window of %d rows too large", what, win_x3);
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
     const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);

@@ -11,12 +11,12 @@ torch.manual_seed(0)
 worst = 0
 for mode in ("bf16x3", "bf16"):
     with ops.math_mode(mode):
-        for (B, T, V, K, N, kt, s) in [(4, 20, 25, 64, 64, 9, 1), (3, 24, 25, 128, 128, 9, 1), (2, 30, 25, 256, 256, 9, 1), (3, 24, 20, 128, 128, 9, 2),
+        for (B, T, V, K, N, kt, s) in [(4, 20, 25, 64, 64, 9, 1), (3, 70, 25, 64, 64, 9, 1), (2, 300, 25, 64, 64, 9, 1), (3, 24, 25, 128, 128, 9, 1), (3, 40, 32, 128, 128, 9, 1), (2, 75, 27, 128, 128, 9, 2), (2, 30, 25, 256, 256, 9, 1), (3, 24, 20, 128, 128, 9, 2),
                                        (4, 20, 25, 192, 64, 1, 1), (3, 22, 25, 128, 192, 1, 1), (2, 30, 25, 256, 384, 1, 1), (5, 17, 27, 64, 128, 1, 1), (2, 30, 25, 768, 256, 1, 1)]:
             a = torch.randn(B, T, V, K, device=dev); Tg = (T - 1) // s + 1
             g = torch.randn(B, Tg, V, N, device=dev)
             res = []
-            for tune in (32, 64):        # 32: 8 waves everywhere, 64: 4 waves everywhere
+            for tune in (32 + 128, 64 + 128, 32, 64):   # bit 5: 1x1 on 8 waves, bit 6: taps on 4 waves, bit 7: no circular window
                 lib.fgcn_set_tuning(6, tune)
                 if kt > 1:
                     w = ops.tconv_wgrad(a, g, taps=kt, stride=s, all_taps=True)
@@ -24,8 +24,8 @@ for mode in ("bf16x3", "bf16"):
                     w = ops.rows_wgrad(a, g, K=K, N=N, tmap=ops.conv_tmap(kt, s), wide=True)
                 res.append(w.clone())
             lib.fgcn_set_tuning(6, 0)
-            err = float((res[0] - res[1]).abs().max() / res[0].abs().max())
+            err = max(float((res[0] - r).abs().max() / res[0].abs().max()) for r in res[1:])
             worst = max(worst, err)
-            print(mode, (B, T, V, K, N, kt, s), "rel diff 8-wave vs 4-wave", err, flush=True)
+            print(mode, (B, T, V, K, N, kt, s), "largest rel diff between the four forms", err, flush=True)
 print("worst", worst)
 assert worst < 2e-6 if True else None
