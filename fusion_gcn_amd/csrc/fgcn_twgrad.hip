@@ -184,7 +184,7 @@ constexpr int X3_APASS = 6;              // passes of 64 rows: window <= 128 + 8
 // stage (a wave always owns 32 rows = two 16-row steps).  g rows are padded by 64 bytes: 4 consecutive rows then land 64
 // bytes apart modulo 256 = one transposed read touches every bank once.
 constexpr int x3_rows(int tn, int wv = 8) { return 32 * (wv / (tn / 32)); }   // 8 waves: 64 (TN 128) / 128 (TN 64); 4 waves: half
-constexpr int x3_sg(int tn) { return tn * 2 + 64; }
+constexpr int x3_sg(int tn) { return tn == 64 ? 160 : tn * 2 + 64; }   // (64 columns: 32 bytes of padding -- the circular window fits beside 128 g rows)
 
 __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
     using v4s = __attribute__((ext_vector_type(4))) short;
