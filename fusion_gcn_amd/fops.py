@@ -52,6 +52,39 @@ class deferred_batch_counters:
         return False
 
 
+class zero_pool:
+    """``with zero_pool(model): ...`` around a forward: the exactly-zero gradients of the conv biases in front of train-mode BatchNorms
+    (``zero_bias_grad``) are slices of ONE zero-filled allocation per step instead of one fill launch per convolution (the demand
+    of a step sizes the next step's pool; every parameter still gets memory of its own)."""
+    active = None
+
+    def __init__(self, owner: torch.nn.Module):
+        self.owner = owner
+
+    def __enter__(self):
+        size = getattr(self.owner, "_zero_pool_size", 0)
+        self.buf = torch.zeros(size, device=next(self.owner.parameters()).device, dtype=torch.float32) if size else None
+        self.used = self.demand = 0
+        zero_pool.active = self
+        return self
+
+    def __exit__(self, *exc):
+        zero_pool.active = None
+        self.owner._zero_pool_size = self.demand
+        return False
+
+    @staticmethod
+    def take(n: int, device) -> torch.Tensor:
+        pool = zero_pool.active
+        if pool is None:
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        pool.demand += n
+        if pool.buf is not None and pool.used + n <= pool.buf.numel():
+            pool.used += n
+            return pool.buf[pool.used - n:pool.used]
+        return torch.zeros(n, device=device, dtype=torch.float32)
+
+
 def _pointwise(tmap) -> bool:
     taps, ta, _tb, tc, td = tmap
     return taps == 1 and ta == 1 and tc == 0 and td == 1
@@ -448,6 +481,7 @@ class _ConvParams(torch.autograd.Function):
         ctx.save_for_backward(xin, wt)
         ctx.cfg, ctx.fold, ctx.x_shape = cfg, fold, x.shape
         ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.zero_bias = zero_pool.take(N, x.device) if (zero_bias_grad and len(params) > n_w) else None
         if part is None:
             part = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(part)
@@ -482,7 +516,7 @@ class _ConvParams(torch.autograd.Function):
                 grads[i] = gw[n0:n0 + o].view(shapes[i])
                 n0 += o
         if len(shapes) > n_w and any(ctx.needs_input_grad[5 + n_w:]):
-            gb = torch.zeros(N, device=d_out.device, dtype=torch.float32) if zero_bias_grad else ops.col_sum(d_out, N)
+            gb = ctx.zero_bias if zero_bias_grad else ops.col_sum(d_out, N)
             n0 = 0
             for i in range(n_w, len(shapes)):
                 o = shapes[i][0]
@@ -590,6 +624,7 @@ class _WindowBranchesParams(torch.autograd.Function):
         ctx.save_for_backward(h, idx, *wts)
         ctx.cfg = cfg
         ctx.shapes = [tuple(p.shape) for p in rest[3 * n:]]
+        ctx.zero_bias = zero_pool.take(n * bc, h.device) if zero_bias_grad else None
         ctx.mark_non_differentiable(*parts)
         return (*outs, pooled, *parts)
 
@@ -601,7 +636,7 @@ class _WindowBranchesParams(torch.autograd.Function):
         d_outs, d_pool = grads[:n], grads[n]
         dh = torch.empty_like(h)
         gws, gbs = [], []
-        zeros = torch.zeros(n * bc, device=h.device, dtype=torch.float32) if zero_bias_grad else None
+        zeros = ctx.zero_bias
         for i in range(n):
             d = d_outs[i].contiguous()
             taps, ta, tb, tc, td = tmaps[i]
@@ -632,3 +667,26 @@ def window_branches_params(h, forms: ParamForms, name: str, convs, tmaps, bc: in
     cfg = (n, bc, tuple(tuple(t) for t in tmaps), stride, T_out, stats, zero_bias_grad)
     out = _WindowBranchesParams.apply(h.contiguous(), cfg, *ws, *wts, *bs, *[c.weight for c in convs], *[c.bias for c in convs])
     return out[:n], out[n], out[n + 1:]
+
+
+class _JoinedVector(torch.autograd.Function):
+    """The concatenation of 1-D parameters as ONE packed form (bias_form; refreshed with the model's other forms): forward hands
+    out the packed buffer, backward the slices of its gradient -- no cat / split launches."""
+
+    @staticmethod
+    def forward(ctx, packed, *params):
+        ctx.sizes = [p.numel() for p in params]
+        return packed.view_as(packed)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, lo = [], 0
+        for n in ctx.sizes:
+            out.append(g[lo:lo + n])
+            lo += n
+        return (None, *out)
+
+
+def joined_vector(forms: ParamForms, name: str, params: Sequence[torch.Tensor]) -> torch.Tensor:
+    packed = forms.get(name, lambda: bias_form(list(params)), params[0].device)
+    return _JoinedVector.apply(packed, *params)

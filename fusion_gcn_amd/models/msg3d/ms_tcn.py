@@ -27,16 +27,16 @@ def out_frames(T: int, stride: int) -> int:
 
 
 class _JoinedBatchNorm:
-    """Several per-channel BatchNorms applied to the channel-wise concatenation of their inputs as one: the parameters and running
-    statistics are concatenated for the kernel and the updated running statistics are split back.  (Differentiable for gamma / beta:
-    torch.cat of the parameters.)"""
+    """Several per-channel BatchNorms applied to the channel-wise concatenation of their inputs as one: gamma / beta are packed
+    forms of the members' parameters (fops.joined_vector: no cat, gradients come back as slices), the running statistics are
+    concatenated for the kernel and the updated ones written back with one multi-tensor copy."""
 
-    def __init__(self, bns):
+    def __init__(self, bns, forms):
         self.bns = list(bns)
         self.training = self.bns[0].training
         self.eps, self.momentum = self.bns[0].eps, self.bns[0].momentum
-        self.weight = torch.cat([b.weight for b in self.bns])
-        self.bias = torch.cat([b.bias for b in self.bns])
+        self.weight = fops.joined_vector(forms, "heads.gamma", [b.weight for b in self.bns])
+        self.bias = fops.joined_vector(forms, "heads.beta", [b.bias for b in self.bns])
         with torch.no_grad():
             self.running_mean = torch.cat([b.running_mean for b in self.bns])
             self.running_var = torch.cat([b.running_var for b in self.bns])
@@ -46,16 +46,14 @@ class _JoinedBatchNorm:
         if not self.training:
             return
         with torch.no_grad():
-            lo = 0
+            sizes = [b.num_features for b in self.bns]
+            torch._foreach_copy_([b.running_mean for b in self.bns] + [b.running_var for b in self.bns],
+                                 list(self.running_mean.split(sizes)) + list(self.running_var.split(sizes)))
             for b in self.bns:
-                c = b.num_features
-                b.running_mean.copy_(self.running_mean[lo:lo + c])
-                b.running_var.copy_(self.running_var[lo:lo + c])
                 if fops.deferred_batch_counters.active is not None:
                     fops.deferred_batch_counters.active.buffers.append(b.num_batches_tracked)
                 else:
                     b.num_batches_tracked += 1
-                lo += c
 
 
 class TemporalConv(nn.Module):
@@ -110,7 +108,7 @@ class MultiScale_TemporalConv(nn.Module):
         lead = self.branches[:-1]                       # the five branches that start with an un-strided 1x1 conv + BN + act
         relu_heads = is_relu(lead[0][2])
         # one GEMM + one BatchNorm/activation pass for the five heads
-        joined = _JoinedBatchNorm([b[1] for b in lead])
+        joined = _JoinedBatchNorm([b[1] for b in lead], self._forms)
         h, part = fops.conv_params(x, self._forms, "heads", [b[0].weight for b in lead], [b[0].bias for b in lead],      # (1, Cin, 5 bc)
                                    stats=joined.training, zero_bias_grad=joined.training)
         h = fops.bn_act(h, part, joined, relu=relu_heads)

@@ -114,7 +114,7 @@ class Model(nn.Module):
         h = self.data_bn(x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T))
         h = h.view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)      # channels-last (B, T, V, C)
         h = F.pad(h, (0, (-C) % 4)).contiguous()                                      # 3 input channels travel as 4 (4th zero)
-        with fops.deferred_batch_counters():                                          # one multi-tensor add for all BatchNorm counters
+        with fops.deferred_batch_counters(), fops.zero_pool(self):                    # one add for all BatchNorm counters, one fill for all zero bias gradients
             for i in range(1, len(_STAGES) + 1):
                 s = getattr(self, f"sgcn{i}")(h)
                 g = getattr(self, f"gcn3d{i}")(h)

@@ -822,6 +822,9 @@ def unfold_windows_bwd(dout: torch.Tensor, T: int, V: int, window: int, stride: 
     return dx
 
 
+_identity_vecs = {}
+
+
 def col_moments(x: torch.Tensor) -> torch.Tensor:
     """BatchNorm partial sums of a tensor no GEMM epilogue produced: (tiles, 2, C) = per-tile (sum x, sum x*x) per channel, the
     layout ``bn_finalize`` takes.  Runs the BatchNorm-backward reduction kernel with dout = a = x and identity statistics
@@ -832,8 +835,12 @@ def col_moments(x: torch.Tensor) -> torch.Tensor:
     rows = x.numel() // C
     lib = _lib.load()
     tiles = lib.fgcn_elem_tiles(rows)
-    vec = torch.zeros((4, C), device=x.device, dtype=torch.float32)
-    vec[1:3] = 1.0
+    key = (C, str(x.device))
+    vec = _identity_vecs.get(key)
+    if vec is None:                      # {mean 0, rstd 1, scale 1, shift 0}: read-only, cached
+        vec = torch.zeros((4, C), device=x.device, dtype=torch.float32)
+        vec[1:3] = 1.0
+        _identity_vecs[key] = vec
     partials = torch.empty((tiles, 3, C), device=x.device, dtype=torch.float32)
     check(lib.fgcn_bn_act_bwd_reduce(_p(x), None, None, _p(x), _p(vec), None, None, _p(partials), tiles, rows, C, 0, 0, _stream()),
           "fgcn_bn_act_bwd_reduce")
