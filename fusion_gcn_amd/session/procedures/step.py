@@ -117,7 +117,8 @@ class GraphStep(Step):
       * evaluation (``model.eval()`` or under ``torch.no_grad()``) is the eager forward;
       * BatchNorm running statistics / counters advance once per step: the warm-up and the verification replay that precede
         a recording are rolled back.
-    ``grads``: a ``dp.FlatGradients`` to share with ``optim.FlatOptimizer`` / the data-parallel all-reduce (created on first use
+    ``max_shapes`` recordings are kept (a ragged last batch is a second shape); beyond that the oldest is dropped and recorded again
+    when its shape comes back.  ``grads``: a ``dp.FlatGradients`` to share with ``optim.FlatOptimizer`` / the data-parallel all-reduce (created on first use
     otherwise; ``.grads`` afterwards).  ``math``: run in this math mode instead of the current one.  ``verify``: after recording,
     replay once and require the eager step's loss and gradients (1e-6 relative; the kernels are deterministic) -- turns a
     recording invalidated by foreign stream use (see below) into an error instead of wrong gradients.
@@ -129,11 +130,12 @@ class GraphStep(Step):
     """
 
     def __init__(self, grads: Optional[FlatGradients] = None, math: Optional[str] = None, verify: bool = True,
-                 data_parallel: bool = True):
+                 data_parallel: bool = True, max_shapes: int = 4):
         self.grads = grads
         self.math = math
         self.verify = verify
         self.data_parallel = data_parallel
+        self.max_shapes = max_shapes          # recordings kept (each owns the activations of a step in its private pool): oldest dropped
         self._eager = DefaultStep()
         self._recorded: Dict[tuple, _Recorded] = {}
         self._stream: Optional[torch.cuda.Stream] = None
@@ -161,6 +163,9 @@ class GraphStep(Step):
             if rec is not None and rec.homes != self._homes(model):
                 rec = None                  # a parameter / buffer moved (model.to(), a new optimizer's flat home): record again
             if rec is None:
+                self._recorded.pop(key, None)
+                while len(self._recorded) >= max(1, self.max_shapes):
+                    self._recorded.pop(next(iter(self._recorded)))
                 rec = self._recorded[key] = self._record(model, loss_function, features, label, loss_quotient)
             self._load(rec, features, label)
             rec.graph.replay()

@@ -162,6 +162,15 @@ def test_graph_step_rejects_foreign_gradients_and_records_again_after_a_move():
     torch.cuda.synchronize()
     for p, g in zip(model.parameters(), first):
         assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-12)
+    # at most max_shapes recordings are kept: the oldest goes, and is recorded again when its shape returns
+    small = GraphStep(grads=step.grads, max_shapes=1)
+    for n in (2, 1, 2):
+        opt.zero_grad()
+        small.forward(model, F.cross_entropy, x[:n].contiguous(), y[:n].contiguous())
+        assert len(small._recorded) == 1
+    torch.cuda.synchronize()
+    for p, g in zip(model.parameters(), first):
+        assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-12)
 
 
 def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
