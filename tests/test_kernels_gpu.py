@@ -131,6 +131,29 @@ def test_tconv_wgrad_all_taps_in_one_pass(B, T, V, K, N, kt, s):
     assert rel_l2(acc.cpu().numpy(), 2 * dw_want.numpy()) < RED_TOL
 
 
+def test_all_taps_weight_gradient_over_random_shapes():
+    """The all-taps weight gradient over 24 seeded random shapes (joint counts 5..32, 3 / 5 / 9 taps, stride 1 / 2, sample lengths
+    from below one stage of rows to several, tile-filling and ragged channel counts) against float64 sums: the split-bf16 kernel
+    keeps its tap window in a circular LDS image that is filled at the first stage of a sample or of a workgroup's share and
+    extended by the new rows of every later stage."""
+    import random
+    from fusion_gcn_amd import ops
+    rng = random.Random(3)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(24):
+        V = rng.choice([5, 18, 20, 22, 25, 27, 32])
+        B, kt, s = rng.randint(1, 5), rng.choice([9, 9, 5, 3]), rng.choice([1, 1, 2])
+        T = rng.randint(max(2, kt // 2 + 1), 40)
+        K, N = rng.choice([32, 64, 128, 160, 256]), rng.choice([32, 64, 96, 128, 256])
+        Tg, pad = (T - 1) // s + 1, (kt - 1) // 2
+        a, g = torch.randn(B, T, V, K, generator=gen), torch.randn(B, Tg, V, N, generator=gen)
+        ap = torch.zeros(B, T + 2 * pad, V, K, dtype=torch.float64)
+        ap[:, pad:pad + T] = a.double()
+        want = torch.stack([torch.einsum("btvk,btvn->kn", ap[:, j:j + (Tg - 1) * s + 1:s], g.double()) for j in range(kt)])
+        got = ops.tconv_wgrad(to_gpu(a), to_gpu(g), taps=kt, stride=s, all_taps=True)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < RED_TOL, (B, T, V, K, N, kt, s)
+
+
 @pytest.mark.parametrize("B,T,V,C,O,s", [(3, 20, 25, 64, 64, 1), (2, 21, 25, 64, 128, 2), (2, 20, 27, 128, 128, 2),
                                          (2, 13, 18, 128, 256, 1), (3, 7, 32, 32, 96, 1), (2, 1, 25, 64, 64, 2),
                                          (1, 40, 25, 256, 256, 1), (2, 9, 20, 64, 64, 2)])
