@@ -16,7 +16,7 @@ weight and a row softmax on the transposed scores (``fgcn_row_softmax_*``); see 
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn
