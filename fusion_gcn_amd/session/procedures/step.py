@@ -120,7 +120,7 @@ class GraphStep(Step):
     ``max_shapes`` recordings are kept (a ragged last batch is a second shape); beyond that the oldest is dropped and recorded again
     when its shape comes back.  ``grads``: a ``dp.FlatGradients`` to share with ``optim.FlatOptimizer`` / the data-parallel all-reduce (created on first use
     otherwise; ``.grads`` afterwards).  ``math``: run in this math mode instead of the current one.  ``verify``: after recording,
-    replay once and require the eager step's loss and gradients (1e-6 relative; the kernels are deterministic) -- turns a
+    replay once and require the eager step's loss (1e-6) and flat gradient (1e-5 rel-L2; libfgcn's kernels are bitwise reproducible) -- turns a
     recording invalidated by foreign stream use (see below) into an error instead of wrong gradients.
 
     Stream rule: everything runs on one stream owned by the step, joined to the caller's current stream on both sides.  Autograd
@@ -275,11 +275,16 @@ class GraphStep(Step):
         if self.verify:
             g.flat.zero_()
             rec.graph.replay()
-            tol = lambda ref: 1e-6 * float(ref.abs().max()) + 1e-30      # noqa: E731
-            bad = float((rec.loss - want_loss).abs()) > tol(want_loss)
+            # the loss must come back exactly (to float rounding), the flat gradient to 1e-5 in rel-L2: libfgcn's kernels are bitwise
+            # reproducible, but torch's own ops in the step need not be (MIOpen's BatchNorm backward moves data_bn.weight by ~1e-3 of
+            # its size when another process shares the device) -- an invalid recording is off by orders of magnitude, not by that
+            bad = float((rec.loss - want_loss).abs()) > 1e-6 * float(want_loss.abs()) + 1e-30
+            num = den = 0.0
             for v, w in zip(g.views, want):
-                if w is not None and float((v - w).abs().max()) > tol(w):
-                    bad = True
+                if w is not None:
+                    num += float((v - w).double().pow(2).sum())
+                    den += float(w.double().pow(2).sum())
+            bad = bad or not (num <= 1e-10 * den + 1e-60)
             roll_back()
             if bad:
                 raise RuntimeError("GraphStep: the recorded step does not reproduce the eager one (gradient accumulators pinned to "
