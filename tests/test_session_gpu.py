@@ -221,6 +221,31 @@ def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
     assert opt.param_groups[0]["lr"] == pytest.approx(sched.get_last_lr()[0])
 
 
+def test_graph_step_with_dropout_draws_new_masks_per_replay():
+    """nn.Dropout between the blocks (reference agcn.py:166-172): the recorded step is not compared with an eager one (other masks);
+    every replay must draw its own mask (torch advances the generator offset of a recorded graph per replay)."""
+    from fusion_gcn_amd.datasets.utd_mhad import constants as utd
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.session.procedures import GraphStep
+    from fusion_gcn_amd.util import Graph
+    shape, classes = (1, 24, 20, 3), 27
+    model = Model(shape, classes, Graph(utd.skeleton_edges, center_joint=utd.center_joint), dropout=0.3)
+    filler.fill_state_dict(model.state_dict())
+    model = model.to(DEV).train()
+    (x, y, _), = batches([4], shape, classes)
+    step = GraphStep()
+    losses = []
+    for _ in range(4):
+        for p in model.parameters():
+            p.grad = None
+        _, loss = step.forward(model, F.cross_entropy, x, y)
+        step.backward(loss)
+        losses.append(float(loss))
+    assert step.replays == 4 and len(step._recorded) == 1
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    assert len(set(losses)) > 1, losses               # different masks -> different losses
+
+
 # ---- two data-parallel ranks through the harness (one device shared, gloo: the control flow of the N > 1 path, not a measurement) ----
 def _dp_data(shape, classes):
     return batches([4, 4, 4], shape, classes, seed=11)
