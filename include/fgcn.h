@@ -38,9 +38,19 @@ const char* fgcn_last_error(void);
 /* 0 if the current HIP device is gfx950, FGCN_E_ARCH otherwise (message names the arch found). */
 int fgcn_check_device(void);
 
-/* Select a kernel variant (process-wide; for tuning tools and A/B tests — defaults are the measured-best ones).
- * key 0: row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row,
- *        double-buffered LDS.  key 1: wider N: 0 = two barriers per K chunk (default), 1 = double-buffered LDS. */
+/* Select a kernel variant (process-wide; for tuning tools and same-box A/B runs -- value 0 of every key is the measured-best
+ * default, every other form computes the same result in another summation order at most).  Keys 0..7:
+ *   0  row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row, double-buffered LDS
+ *   1  row GEMM, wider N: 0 = two barriers per K chunk, 1 = double-buffered LDS
+ *   4  f32 halo conv: 0 = three workgroups per CU, 1 = two
+ *   5  workgroup orders (bits): 1 row GEMM XCD-aware order on; 8 row GEMM column-tile-fastest off; 4 batched row GEMM XCD-aware off;
+ *      16 spatial forward XCD-aware off; 32 split-bf16 halo conv XCD-aware off; 2 f32 halo conv XCD-aware on
+ *   6  (bits) 1: 1x1 weight gradients of the bf16 modes on the 256-thread kernel that splits fragments as it reads them;
+ *      8: joint_dagg at two workgroups per CU; 16: joint_dagg's gram on the f32 MFMA in every mode;
+ *      32: 1x1 weight gradients on ONE 8-wave workgroup per CU (default: two 4-wave ones); 64: flip the all-taps kernels' wave
+ *      count (default: 4 waves above 64 output columns, 8 at 64); 128: all-taps weight gradient without the circular tap window
+ *   7  split-bf16 kernels (bits) 1: spatial forward, one frame per wave (older form); 2: halo conv on the 32x32x16 MFMA shape;
+ *      4: the same for N <= 64 only */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
