@@ -43,7 +43,7 @@ int fgcn_check_device(void);
  *   0  row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row, double-buffered LDS
  *   1  row GEMM, wider N: 0 = two barriers per K chunk, 1 = double-buffered LDS
  *   4  f32 halo conv: 0 = three workgroups per CU, 1 = two
- *   5  workgroup orders (bits): 1 row GEMM XCD-aware order on; 8 row GEMM column-tile-fastest off; 4 batched row GEMM XCD-aware off;
+ *   5  workgroup orders (bits): 1 row GEMM XCD-aware order on; 8 row GEMM column-tile-fastest off; 4 generic weight gradient (rows_wgrad) XCD-aware off;
  *      16 spatial forward XCD-aware off; 32 split-bf16 halo conv XCD-aware off; 2 f32 halo conv XCD-aware on
  *   6  (bits) 1: 1x1 weight gradients of the bf16 modes on the 256-thread kernel that splits fragments as it reads them;
  *      8: joint_dagg at two workgroups per CU; 16: joint_dagg's gram on the f32 MFMA in every mode;
