@@ -373,6 +373,18 @@ class ParamForms:
             self.generation += 1
         return f.dst
 
+    def get_pair(self, name: str, suffixes: Tuple[str, str], make: Callable[[], Tuple[Form, Form]], device):
+        """Two forms built together (a matrix and its transpose) under ``name + suffix``."""
+        a, b = self.forms.get(name + suffixes[0]), self.forms.get(name + suffixes[1])
+        if a is None or b is None:
+            a, b = make()
+            for key, f in ((name + suffixes[0], a), (name + suffixes[1], b)):
+                f.alloc(device)
+                self.forms[key] = f
+            PackPlan([a, b]).run()
+            self.generation += 1
+        return a.dst, b.dst
+
     def clear(self) -> None:
         self.forms.clear()
         self.generation += 1
@@ -539,17 +551,8 @@ def conv_params(x: torch.Tensor, forms: ParamForms, name: str, weights: Sequence
     k_pad = x.shape[-1] // scales - inner if scales > 1 else 0
     if scales == 1 and in_coff == 0 and x.shape[-1] != inner:
         k_pad = x.shape[-1] - inner                                     # zero pad channels of the input (3 -> 4)
-    made: Dict[str, Form] = {}
-
-    def make(which):
-        def build():
-            if not made:
-                made["w"], made["wt"] = (scale_major_forms(weights[0], scales, k_pad) if scales > 1
-                                         else conv_weight_forms(weights, k_pad))
-            return made[which]
-        return build
-    w = forms.get(name + ".w", make("w"), x.device)
-    wt = forms.get(name + ".wt", make("wt"), x.device)
+    w, wt = forms.get_pair(name, (".w", ".wt"), lambda: (scale_major_forms(weights[0], scales, k_pad) if scales > 1
+                                                          else conv_weight_forms(weights, k_pad)), x.device)
     bias = forms.get(name + ".b", lambda: bias_form(biases), x.device) if biases else None
     cfg = (tuple(tmap), x.shape[1] if T_out is None else T_out, stats, zero_bias_grad, in_coff, inner, scales, len(weights))
     return _ConvParams.apply(x, w, wt, bias, cfg, *weights, *biases)
@@ -592,16 +595,7 @@ def node_mix_params(x: torch.Tensor, forms: ParamForms, name: str, a_const: torc
     padding (UTD-MHAD's 20 joints: every case), built with torch ops otherwise (NTU's 25 joints x 13 scales = 325 columns)."""
     if (a_const.shape[1] * num_scales) % 4:
         return node_mix(x, node_mix_matrix(a_const + a_res, num_scales), num_scales)
-    made: Dict[str, Form] = {}
-
-    def make(which):
-        def build():
-            if not made:
-                made["a"], made["at"] = node_mix_forms(a_const, a_res, num_scales)
-            return made[which]
-        return build
-    a_fm = forms.get(name + ".a", make("a"), x.device)
-    a_fm_t = forms.get(name + ".at", make("at"), x.device)
+    a_fm, a_fm_t = forms.get_pair(name, (".a", ".at"), lambda: node_mix_forms(a_const, a_res, num_scales), x.device)
     return _NodeMixParams.apply(x.contiguous(), a_fm, a_fm_t, a_res, num_scales)
 
 
@@ -653,16 +647,9 @@ def window_branches_params(h, forms: ParamForms, name: str, convs, tmaps, bc: in
     n = len(convs)
     ws, wts, bs = [], [], []
     for i, conv in enumerate(convs):
-        made: Dict[str, Form] = {}
-
-        def make(which, conv=conv, made=made):
-            def build():
-                if not made:
-                    made["w"], made["wt"] = conv_weight_forms([conv.weight])
-                return made[which]
-            return build
-        ws.append(forms.get(f"{name}.{i}.w", make("w"), h.device))
-        wts.append(forms.get(f"{name}.{i}.wt", make("wt"), h.device))
+        w, wt = forms.get_pair(f"{name}.{i}", (".w", ".wt"), lambda conv=conv: conv_weight_forms([conv.weight]), h.device)
+        ws.append(w)
+        wts.append(wt)
         bs.append(forms.get(f"{name}.{i}.b", lambda conv=conv: bias_form([conv.bias]), h.device))
     cfg = (n, bc, tuple(tuple(t) for t in tmaps), stride, T_out, stats, zero_bias_grad)
     out = _WindowBranchesParams.apply(h.contiguous(), cfg, *ws, *wts, *bs, *[c.weight for c in convs], *[c.bias for c in convs])
