@@ -436,11 +436,12 @@ static bool twgrad_use_x3(int N, int chunk_mode) {
 //     4-wave form re-stages the 8 V-row tap window twice as often: +1-2 %);
 //   all taps, 64 columns (128-row stages): the circular window does not fit beside the g planes on 8 waves and loses 8 % on 4.
 // -> 1x1: 4 waves; all taps: 4 waves + circular window above 64 columns, 8 waves without it at 64.
-// (tuning key 6: bit 5 = 1x1 on 8 waves, bit 6 = flip the tap kernels' wave count, bit 7 = no circular window.)
+// (tuning key 6: bit 5 = 1x1 on 8 waves, bit 6 = all taps above 64 columns on 8 waves, bit 8 = all taps at 64 columns on 4 waves,
+// bit 7 = no circular window.  In the step the wave counts of the tap kernels are within the run-to-run noise of each other.)
 static int twgrad_x3_waves(int N, int chunk_mode) {
     if (chunk_mode) return (fgcn::tuning(6) & 32) ? 8 : 4;
-    const int w = N > 64 ? 4 : 8;
-    return (fgcn::tuning(6) & 64) ? 12 - w : w;
+    if (N > 64) return (fgcn::tuning(6) & 64) ? 8 : 4;
+    return (fgcn::tuning(6) & 256) ? 4 : 8;
 }
 static int twgrad_parts(int N, int chunk_mode) {
     if (twgrad_use_x3(N, chunk_mode)) return twgrad_x3_waves(N, chunk_mode) / (N <= 64 ? 2 : 4);

@@ -47,8 +47,8 @@ int fgcn_check_device(void);
  *      16 spatial forward XCD-aware off; 32 split-bf16 halo conv XCD-aware off; 2 f32 halo conv XCD-aware on
  *   6  (bits) 1: 1x1 weight gradients of the bf16 modes on the 256-thread kernel that splits fragments as it reads them;
  *      8: joint_dagg at two workgroups per CU; 16: joint_dagg's gram on the f32 MFMA in every mode;
- *      32: 1x1 weight gradients on ONE 8-wave workgroup per CU (default: two 4-wave ones); 64: flip the all-taps kernels' wave
- *      count (default: 4 waves above 64 output columns, 8 at 64); 128: all-taps weight gradient without the circular tap window
+ *      32: 1x1 weight gradients on ONE 8-wave workgroup per CU (default: two 4-wave ones); 64: all-taps kernels above 64 output
+ *      columns on 8 waves (default 4); 256: at 64 columns on 4 waves (default 8); 128: all-taps weight gradient without the circular tap window
  *   7  split-bf16 kernels (bits) 1: spatial forward, one frame per wave (older form); 2: halo conv on the 32x32x16 MFMA shape;
  *      4: the same for N <= 64 only */
 int fgcn_set_tuning(int key, int value);

@@ -16,7 +16,7 @@ for mode in ("bf16x3", "bf16"):
             a = torch.randn(B, T, V, K, device=dev); Tg = (T - 1) // s + 1
             g = torch.randn(B, Tg, V, N, device=dev)
             res = []
-            for tune in (32 + 128, 64 + 128, 32, 64):   # bit 5: 1x1 on 8 waves, bit 6: taps on 4 waves, bit 7: no circular window
+            for tune in (32 + 64 + 128, 256 + 128, 32 + 64, 256):   # bit 5: 1x1 on 8 waves; bits 6 / 8: taps on 8 / 4 waves everywhere; bit 7: no circular window
                 lib.fgcn_set_tuning(6, tune)
                 if kt > 1:
                     w = ops.tconv_wgrad(a, g, taps=kt, stride=s, all_taps=True)
