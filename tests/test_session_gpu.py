@@ -221,6 +221,24 @@ def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
     assert opt.param_groups[0]["lr"] == pytest.approx(sched.get_last_lr()[0])
 
 
+def test_graph_step_in_the_bf16_mode_is_the_mixed_precision_step():
+    """``GraphStep(math="bf16")`` (what ``get_batch_processor_from_config`` builds for --mixed_precision + hip_graph) trains like the eager
+    ``MixedPrecisionStep``: both passes of every step in the bf16 math mode, whatever mode is current around them."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.session.procedures import DefaultBatchProcessor, GraphStep, MixedPrecisionStep
+    shape, classes = (1, 24, 20, 3), 27
+    data = batches([4, 4, 4], shape, classes)
+    base = agcn(shape, classes)
+    before = ops.get_math_mode()
+    eager, keep_e = train(copy.deepcopy(base), DefaultBatchProcessor(MixedPrecisionStep()), data)
+    graph, keep_g = train(copy.deepcopy(base), DefaultBatchProcessor(GraphStep(math="bf16")), data)
+    assert ops.get_math_mode() == before
+    assert_same_training(graph, eager, keep_g, keep_e)
+    # and it is not the f32 training (the bf16 operands show in the loss from the first step on)
+    f32, keep_f = train(copy.deepcopy(base), DefaultBatchProcessor(GraphStep(math="f32")), data)
+    assert abs(float(keep_f.losses[0]) - float(keep_g.losses[0])) > 1e-6
+
+
 def test_graph_step_with_dropout_draws_new_masks_per_replay():
     """nn.Dropout between the blocks (reference agcn.py:166-172): the recorded step is not compared with an eager one (other masks);
     every replay must draw its own mask (torch advances the generator offset of a recorded graph per replay)."""
