@@ -125,6 +125,13 @@ SIGNATURES = {
     "fgcn_tmaxpool3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_tmaxpool3_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_unfold_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_data_bn_tiles": (_I, [_I, _I]),
+    "fgcn_data_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fgcn_data_bn_apply": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_data_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_data_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_cross_entropy_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fgcn_cross_entropy_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fgcn_optim_step": (_I, [_P, _P, _P, _P, _LL, _I, _F, _F, _F, _F, _F, _F, _F, _F, _I, _LL, _P]),
 }
 

@@ -702,3 +702,60 @@ class GroupMeanFunction(torch.autograd.Function):
     def backward(ctx, d_out: torch.Tensor):
         G, R, C = ctx.shape
         return (d_out / R).unsqueeze(1).expand(G, R, C).contiguous()
+
+
+class DataBNFunction(torch.autograd.Function):
+    """data_bn (nn.BatchNorm1d over the (m, v, c) channels of the network input, statistics across (n, t); reference
+    mmargcn/agcn.py:150,186-188) fused with the layout change the blocks need: (N, M, T, V, C) -> (N*M, T, V, C padded to 4).
+    The nn.BatchNorm1d module is the parameter / buffer container (momentum 0.1-style exponential running statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, train: bool, momentum: float, eps: float):
+        x = x.contiguous()
+        N, M, T, V, C = x.shape
+        if train:
+            vec = ops.bn_finalize(ops.data_bn_stats(x), N * T, weight, bias, running_mean, running_var, momentum, eps)
+        else:
+            vec = ops.bn_eval_coeffs(weight, bias, running_mean, running_var, eps)
+        ctx.save_for_backward(x, vec)
+        ctx.train = train
+        return ops.data_bn_apply(x, vec, _r4(C))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, vec = ctx.saved_tensors
+        dgamma, dbeta, dx = ops.data_bn_bwd(d_out.contiguous(), x, vec, ctx.train, ctx.needs_input_grad[0])
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def data_bn(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> torch.Tensor:
+    """The model's input stage on libfgcn: ``bn`` = the model's ``data_bn`` module; updates its running statistics and batch
+    counter in train mode like the module's own forward would."""
+    if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        raise NotImplementedError("data_bn: affine BatchNorm1d with exponential running statistics (the reference's default) only")
+    if x.shape[1] * x.shape[3] * x.shape[4] != bn.num_features:
+        raise ValueError(f"data_bn: input {tuple(x.shape)} does not have {bn.num_features} (m, v, c) channels")
+    out = DataBNFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return out
+
+
+class CrossEntropyFunction(torch.autograd.Function):
+    """nn.CrossEntropyLoss() / F.cross_entropy(logits, labels), mean reduction (reference session/session.py:53): one
+    fixed-order kernel each way."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, probs = ops.cross_entropy_fwd(logits, labels)
+        ctx.save_for_backward(probs, labels, loss)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        probs, labels, loss = ctx.saved_tensors
+        return ops.cross_entropy_bwd(probs, labels, loss, d_loss.contiguous().view(1)), None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    return CrossEntropyFunction.apply(logits, labels)

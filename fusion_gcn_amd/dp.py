@@ -39,6 +39,13 @@ class FlatGradients:
         for p in self.params:
             p.grad = None
 
+    def zero_in_place(self) -> None:
+        """optimizer.zero_grad(set_to_none=False): every p.grad becomes its (zeroed) view of the flat buffer, whether or not a
+        gradient existed (before the first backward, or after a set_to_none zero, there is none -- that is not an error here)."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
     def gather(self) -> None:
         """Copy this step's gradients into the flat buffer (one multi-tensor copy) and re-point p.grad at it."""
         src, dst = [], []
@@ -58,16 +65,18 @@ class FlatGradients:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None) -> None:
-        """Average gradients across replicas: one collective on the flat buffer."""
+    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, always: bool = False) -> None:
+        """Average gradients across replicas: one collective on the flat buffer.  ``always``: issue the collective for a
+        single-rank group too (what a 1-GPU box can prove about the RCCL path: tests/test_rccl_gpu.py)."""
         self.gather()
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not always:
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.mul_(1.0 / world)
+        if world > 1:
+            self.flat.mul_(1.0 / world)
 
 
 def shard_batch(n_total: int, rank: int, world: int) -> slice:
@@ -82,11 +91,15 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """Make every replica start from rank ``src``'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    # in place on t.detach() under no_grad: that alias shares the tensor's version counter, so everything keyed on parameter
-    # versions (the blocks' cache of packed weights) sees the change; a write through ``t.data`` would not bump it
+    # c10d collectives write through the storage and do NOT bump the tensors' version counters (checked on torch 2.10: _version
+    # is the same before and after), so everything keyed on parameter versions -- the blocks' packed weights, fops.ParamForms --
+    # is told explicitly: versions are incremented (metadata only) and modules with packed forms are marked stale
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
+        tensors = list(module.parameters()) + list(module.buffers())
+        for t in tensors:
             dist.broadcast(t.detach(), src=src, group=group)
+        for t in tensors:
+            torch.autograd.graph.increment_version(t)
     for m in module.modules():
-        if hasattr(m, "_wcache"):
-            m._wcache = None
+        if hasattr(m, "mark_packed_stale"):
+            m.mark_packed_stale()

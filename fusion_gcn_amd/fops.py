@@ -357,31 +357,52 @@ def col_stats(x: torch.Tensor) -> torch.Tensor:
 # the parameter's own layout (ops.rows_wgrad(conv_param=...)): no torch op touches a weight.
 
 class ParamForms:
-    """The packed forms of one module's parameters, created (and packed once on their own) on first use."""
+    """The packed forms of one module's parameters, created (and packed once on their own) on first use.  Every hand-out checks
+    the form against its sources: parameters updated in place since the last pack (an optimizer step, load_state_dict) are
+    re-packed, parameters that moved (module.to()) get a new form -- a module used on its own behaves like one under a Model
+    whose forward runs the batched ``refresh_forms`` (which leaves every form it packs marked fresh)."""
 
     def __init__(self):
         self.forms: Dict[str, Form] = {}
         self.generation = 0
 
+    def _current(self, key: str) -> Optional[Form]:
+        f = self.forms.get(key)
+        if f is None:
+            return None
+        now = f.stamp()
+        if f.packed == now:
+            return f
+        if f.packed is None or any(a[0] != b[0] for a, b in zip(f.packed, now)):
+            del self.forms[key]                      # a source moved: the form's table holds dead addresses
+            self.generation += 1
+            return None
+        solo = getattr(f, "_solo_plan", None)
+        if solo is None:
+            solo = f._solo_plan = PackPlan([f], stamp=True)
+        solo.run()
+        return f
+
     def get(self, name: str, make: Callable[[], Form], device) -> torch.Tensor:
-        f = self.forms.get(name)
+        f = self._current(name)
         if f is None:
             f = make()
             f.alloc(device)
-            PackPlan([f]).run()
+            f._solo_plan = PackPlan([f], stamp=True)
+            f._solo_plan.run()
             self.forms[name] = f
             self.generation += 1
         return f.dst
 
     def get_pair(self, name: str, suffixes: Tuple[str, str], make: Callable[[], Tuple[Form, Form]], device):
         """Two forms built together (a matrix and its transpose) under ``name + suffix``."""
-        a, b = self.forms.get(name + suffixes[0]), self.forms.get(name + suffixes[1])
+        a, b = self._current(name + suffixes[0]), self._current(name + suffixes[1])
         if a is None or b is None:
             a, b = make()
             for key, f in ((name + suffixes[0], a), (name + suffixes[1], b)):
                 f.alloc(device)
                 self.forms[key] = f
-            PackPlan([a, b]).run()
+            PackPlan([a, b], stamp=True).run()
             self.generation += 1
         return a.dst, b.dst
 
@@ -407,12 +428,22 @@ def refresh_forms(model: torch.nn.Module) -> None:
         model._forms_state = None
         return
     if state is None or state["gen"] != gen:
-        state = {"gen": gen, "homes": homes, "plan": PackPlan([f for s_ in sets for f in s_.forms.values()]), "versions": None}
+        state = {"gen": gen, "homes": homes, "plan": PackPlan([f for s_ in sets for f in s_.forms.values()], stamp=True), "versions": None}
         model._forms_state = state
     versions = tuple(p._version for p in params)
     if state["versions"] != versions:
         state["plan"].run()
         state["versions"] = versions
+
+
+def recording_pins(model: torch.nn.Module) -> list:
+    """What a HIP-graph recording of ``model`` reads through raw pointers: every module's forms and the model's re-pack plan
+    (GraphStep keeps them alive with the recording)."""
+    pins = [f for m in model.modules() if isinstance(getattr(m, "_forms", None), ParamForms) for f in m._forms.forms.values()]
+    state = getattr(model, "_forms_state", None)
+    if state is not None:
+        pins.append(state["plan"])
+    return pins
 
 
 def mark_forms_stale(model: torch.nn.Module) -> None:

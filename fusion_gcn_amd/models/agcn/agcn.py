@@ -85,6 +85,7 @@ class Model(nn.Module):
     _blocks_input = _base.Model._blocks_input
     _bump_batch_counters = _base.Model._bump_batch_counters
     prepare_recording = _base.Model.prepare_recording
+    recording_pins = _base.Model.recording_pins
 
     def forward(self, x):
         clips = x.size(0)

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, pack_weights, param_names
+from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, data_bn, pack_weights, param_names
 from ...util.partition_strategy import GraphPartitionStrategy
 
 
@@ -201,6 +201,15 @@ class SpatialTemporalConv(nn.Module):
         """Force a re-pack at the next forward (what an optimizer step does through the version counters)."""
         self._wversions = None
 
+    def drop_packed(self) -> None:
+        """Forget the packed set (parameters rewritten behind the version counters, e.g. by a collective)."""
+        self._wcache = None
+        self._wversions = None
+
+    def recording_pins(self) -> list:
+        """GraphStep hook: the packed set a recording made now reads (kept alive by the recording)."""
+        return [] if self._wcache is None else [self._wcache[1]]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         names = param_names(self.cfg)
         params = [self._tensor(n) for n in names]
@@ -301,18 +310,17 @@ class Model(nn.Module):
 
     def _blocks_input(self, x: torch.Tensor) -> torch.Tensor:
         """(N, M, T, V, C) -> data_bn over the (m, v, c) channels with statistics across (n, t)
-        -> channels-last (N*M, T, V, C padded to 4)."""
-        N, M, T, V, C = x.size()
-        h = x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T)
-        h = self.data_bn(h)
-        h = h.view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)
-        pad = (-C) % 4
-        if pad:
-            h = F.pad(h, (0, pad))
-        return h.contiguous()
+        -> channels-last (N*M, T, V, C padded to 4): one statistics pass + one apply pass of libfgcn (block.data_bn); the
+        reference's permute / view / BatchNorm1d / view / permute (:186-188) is the same function of x."""
+        return data_bn(x, self.data_bn)
 
     def prepare_recording(self) -> None:
         prepare_recording(self)
+
+    def recording_pins(self) -> list:
+        """GraphStep hook: the one-launch re-pack plan (device tables) a recording made now replays."""
+        plan = getattr(self, "_pack_plan", None)
+        return [] if plan is None else [plan[1]]
 
     def _bump_batch_counters(self) -> None:
         """num_batches_tracked += 1 for every block BatchNorm in one launch (26 scalar adds otherwise)."""

@@ -182,6 +182,10 @@ class STGCNGraphConvolution(nn.Module):
             self._adj_cache = (key, forms)
         return self._adj_cache[1]
 
+    def recording_pins(self) -> list:
+        """GraphStep hook: the padded adjacency forms a recording made now reads."""
+        return [] if self._adj_cache is None else [self._adj_cache[1]]
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         res = self.residual
         return _GraphConv1dFunction.apply(

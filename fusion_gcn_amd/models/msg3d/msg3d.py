@@ -13,10 +13,9 @@ loss are torch-ROCm ops, as in the AGCN model.
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ... import fops
-from ...block import GroupMeanFunction, LinearFunction
+from ...block import GroupMeanFunction, LinearFunction, data_bn
 from .mlp import MLP
 from .ms_gcn import MultiScale_GraphConv as MS_GCN
 from .ms_gtcn import SpatialTemporal_MS_GCN, UnfoldTemporalWindows
@@ -108,12 +107,14 @@ class Model(nn.Module):
         fops.mark_forms_stale(self)
         fops.refresh_forms(self)
 
+    def recording_pins(self) -> list:
+        """GraphStep hook: the forms and the re-pack plan a recording made now replays."""
+        return fops.recording_pins(self)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         N, M, T, V, C = x.size()
         fops.refresh_forms(self)
-        h = self.data_bn(x.permute(0, 1, 3, 4, 2).contiguous().view(N, M * V * C, T))
-        h = h.view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)      # channels-last (B, T, V, C)
-        h = F.pad(h, (0, (-C) % 4)).contiguous()                                      # 3 input channels travel as 4 (4th zero)
+        h = data_bn(x, self.data_bn)          # BatchNorm1d over (m, v, c) -> channels-last (B, T, V, 4): 3 channels travel as 4 (4th zero)
         with fops.deferred_batch_counters(), fops.zero_pool(self):                    # one add for all BatchNorm counters, one fill for all zero bias gradients
             for i in range(1, len(_STAGES) + 1):
                 s = getattr(self, f"sgcn{i}")(h)

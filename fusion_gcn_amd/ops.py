@@ -662,6 +662,72 @@ def group_mean(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ---- the two ends of the step: input BatchNorm and loss (fgcn_head.hip) ---------------------------------------------------------
+def data_bn_stats(x: torch.Tensor) -> torch.Tensor:
+    """x (N, M, T, V, C) -> BatchNorm partial sums (tiles, 2, M*V*C) of the (m, v, c) channels over (n, t)."""
+    ensure_device()
+    _chk(x, "data_bn_stats.x")
+    N, M, T, V, C = x.shape
+    lib = _lib.load()
+    part = torch.empty((lib.fgcn_data_bn_tiles(N, T), 2, M * V * C), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_data_bn_stats(_p(x), _p(part), N, M, T, V, C, _stream()), "fgcn_data_bn_stats")
+    return part
+
+
+def data_bn_apply(x: torch.Tensor, vec: torch.Tensor, Cp: int) -> torch.Tensor:
+    """-> (N*M, T, V, Cp) = x * scale + shift per (m, v, c) channel, pad channels zero."""
+    ensure_device()
+    _chk(x, "data_bn_apply.x"), _chk(vec, "data_bn_apply.vec")
+    N, M, T, V, C = x.shape
+    out = torch.empty((N * M, T, V, Cp), device=x.device, dtype=torch.float32)
+    check(_lib.load().fgcn_data_bn_apply(_p(x), _p(vec), _p(out), N, M, T, V, C, Cp, _stream()), "fgcn_data_bn_apply")
+    return out
+
+
+def data_bn_bwd(dout: torch.Tensor, x: torch.Tensor, vec: torch.Tensor, train: bool, need_dx: bool):
+    """dout (N*M, T, V, Cp), x (N, M, T, V, C) -> (d gamma, d beta, dx or None)."""
+    ensure_device()
+    _chk(dout, "data_bn_bwd.dout"), _chk(x, "data_bn_bwd.x")
+    N, M, T, V, C = x.shape
+    Cp = dout.shape[3]
+    lib = _lib.load()
+    part = torch.empty((lib.fgcn_data_bn_tiles(N, T), 2 * M * V * C), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_data_bn_bwd_reduce(_p(dout), _p(x), _p(vec), _p(part), N, M, T, V, C, Cp, _stream()), "fgcn_data_bn_bwd_reduce")
+    sums = torch.empty((2, M * V * C), device=x.device, dtype=torch.float32)
+    reduce_sum(part, sums.view(-1))
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        check(lib.fgcn_data_bn_bwd_apply(_p(dout), _p(x), _p(vec), _p(sums), _p(dx), N, M, T, V, C, Cp, int(train), _stream()),
+              "fgcn_data_bn_bwd_apply")
+    return sums[1], sums[0], dx
+
+
+def cross_entropy_fwd(logits: torch.Tensor, labels: torch.Tensor):
+    """logits (rows, classes) float32 with unit column stride (any row stride), labels int64 -> (loss (2,) = {mean, valid rows},
+    probs (rows, classes))."""
+    ensure_device()
+    rows, classes = logits.shape
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.int64
+            and labels.is_cuda and labels.is_contiguous() and labels.numel() == rows):
+        raise _lib.FgcnError("cross_entropy: float32 logits (rows, classes) with contiguous classes and int64 labels (rows,) on the device")
+    probs = torch.empty((rows, classes), device=logits.device, dtype=torch.float32)
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(2, device=logits.device, dtype=torch.float32)
+    check(_lib.load().fgcn_cross_entropy_fwd(logits.data_ptr(), labels.data_ptr(), _p(probs), _p(row_loss), _p(loss), rows, classes,
+                                             logits.stride(0), _stream()), "fgcn_cross_entropy_fwd")
+    return loss, probs
+
+
+def cross_entropy_bwd(probs: torch.Tensor, labels: torch.Tensor, loss: torch.Tensor, dloss: torch.Tensor) -> torch.Tensor:
+    ensure_device()
+    rows, classes = probs.shape
+    dl = torch.empty((rows, classes), device=probs.device, dtype=torch.float32)
+    check(_lib.load().fgcn_cross_entropy_bwd(_p(probs), labels.data_ptr(), _p(loss), _p(dloss), _p(dl), rows, classes, classes,
+                                             _stream()), "fgcn_cross_entropy_bwd")
+    return dl
+
+
 # ---- fused spatial forward -----------------------------------------------------------------------------------------
 def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
                 Cout: int, stats: bool = True):

@@ -30,10 +30,12 @@ class FlatOptimizer(torch.optim.Optimizer):
     ADAM / ADAMW ``betas, eps, weight_decay`` (AdamW's default decay is 0.01).  ``amsgrad`` / ``maximize`` and more than
     one parameter group are not built (the reference uses neither) and raise.
     ``grads``: an existing ``FlatGradients`` over the same parameters (the data-parallel buffer) to share.
+    ``allow_unused``: a trainable parameter without a gradient in a step counts as a zero gradient instead of an error
+    (forwarded to the FlatGradients this optimizer creates).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], name: str = "ADAM", lr: float = 1e-3, *,
-                 grads: Optional[FlatGradients] = None, **optimizer_args):
+                 grads: Optional[FlatGradients] = None, allow_unused: bool = False, **optimizer_args):
         kind = name.upper()
         if kind not in KINDS:
             raise ValueError("Unsupported optimizer: " + kind + " (SGD | ADAM | ADAMW)")
@@ -57,7 +59,7 @@ class FlatOptimizer(torch.optim.Optimizer):
             raise NotImplementedError("FlatOptimizer takes one parameter group (as the reference's create_optimizer)")
         super().__init__(params, defaults)
         self.kind = kind
-        self.grads = grads if grads is not None else FlatGradients(self.param_groups[0]["params"])
+        self.grads = grads if grads is not None else FlatGradients(self.param_groups[0]["params"], allow_unused=allow_unused)
         self.params = self.grads.params                      # trainable parameters, in order
         if grads is not None and [id(p) for p in self.params] != [id(p) for p in self.param_groups[0]["params"] if p.requires_grad]:
             raise ValueError("the shared FlatGradients must cover the same parameters in the same order")
@@ -79,8 +81,7 @@ class FlatOptimizer(torch.optim.Optimizer):
         if set_to_none:
             self.grads.zero()
         else:
-            self.grads.gather()
-            self.grads.flat.zero_()
+            self.grads.zero_in_place()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -48,6 +48,12 @@ class Form:
     segs: List[Seg]
     shape: Optional[Tuple[int, ...]] = None      # view of the plain / k4 result handed to the consumer (default: by mode)
     dst: Optional[torch.Tensor] = field(default=None, repr=False)
+    packed: Optional[tuple] = field(default=None, repr=False)    # stamp() of the sources when dst was last packed (stamping plans)
+
+    def stamp(self) -> tuple:
+        """Where this form's sources live and which version they hold now (parameters: the Seg keeps the Parameter object, so a
+        moved ``.data`` and an in-place update both show)."""
+        return tuple((s.src.data_ptr(), s.src._version) for s in self.segs)
 
     def alloc(self, device) -> torch.Tensor:
         lib = _lib.load()
@@ -85,9 +91,10 @@ class Form:
 class PackPlan:
     """The device-side work list of a set of forms; ``run()`` rebuilds every one of them in ONE launch on the current stream."""
 
-    def __init__(self, forms: Sequence[Form]):
+    def __init__(self, forms: Sequence[Form], stamp: bool = False):
         self.forms = [f for f in forms if f.dst is not None]
         self.n_wg = 0
+        self.stamp = stamp            # record Form.packed on every run (fops.ParamForms checks it; the AGCN blocks track versions themselves)
         if not self.forms:
             return
         dev = self.forms[0].dst.device
@@ -106,6 +113,9 @@ class PackPlan:
         if self.n_wg:
             _lib.check(_lib.load().fgcn_pack_run(self.items_dev.data_ptr(), self.map_dev.data_ptr(), self.n_wg,
                                                  torch.cuda.current_stream(self.items_dev.device).cuda_stream), "fgcn_pack_run")
+            if self.stamp:
+                for f in self.forms:
+                    f.packed = f.stamp()
 
 
 class PackedWeights:

@@ -20,6 +20,7 @@ import abc
 from typing import Dict, Optional, Union
 
 import torch
+import torch.distributed as dist
 
 from ... import ops
 from ...dp import FlatGradients
@@ -38,7 +39,19 @@ class Step(abc.ABC):
     def backward(self, loss: torch.Tensor) -> None:
         ...
 
+    _dp_grads: Optional[FlatGradients] = None
+
     def run_optimizer_step(self, optimizer):
+        """``optimizer.step()`` -- after ONE all-reduce (mean) of the flat gradient buffer when a process group with more than one
+        rank is active: ``data.ClipBatches`` shards every batch per rank, so without the exchange the replicas would drift apart
+        silently.  The buffer is the optimizer's own (``optim.FlatOptimizer.grads``) or one built lazily over its parameters."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            grads = getattr(optimizer, "grads", None)
+            if not isinstance(grads, FlatGradients):
+                if self._dp_grads is None:
+                    self._dp_grads = FlatGradients([p for g in optimizer.param_groups for p in g["params"]])
+                grads = self._dp_grads
+            grads.all_reduce_mean()
         return optimizer.step()
 
     def reset(self) -> None:
@@ -99,7 +112,7 @@ def _signature(features: Features, label: torch.Tensor):
 
 class _Recorded:
     """One recorded batch shape: the graph, its static inputs / outputs and the fresh gradient tensors it writes."""
-    __slots__ = ("graph", "features", "label", "y_pred", "loss", "fresh", "views", "homes")
+    __slots__ = ("graph", "features", "label", "y_pred", "loss", "fresh", "views", "homes", "pins")
 
 
 class GraphStep(Step):
@@ -211,6 +224,20 @@ class GraphStep(Step):
         return tuple(t.data_ptr() for t in model.parameters()) + tuple(t.data_ptr() for t in model.buffers())
 
     @staticmethod
+    def _pins(model) -> list:
+        """Objects whose device memory the recorded kernels reach through raw pointers without the graph's pool owning it: the
+        packed weight sets and re-pack tables of the modules (``recording_pins`` hook).  A recording holds them for its own
+        lifetime: a later forward in another math mode, a broadcast that drops a block's packed set or a rebuilt re-pack plan
+        then leaves an older recording's buffers alive (and still re-packed from the current parameters by its own recorded
+        launch) instead of freed under it."""
+        pins = []
+        for m in model.modules():
+            hook = getattr(m, "recording_pins", None)
+            if callable(hook):
+                pins.extend(hook())
+        return pins
+
+    @staticmethod
     def _mark_stale(model) -> None:
         """Packed / split weight forms cached per parameter version are rebuilt inside the step (what an optimizer update in
         front of it causes): the re-packing launch becomes part of the recording and every replay packs the CURRENT values."""
@@ -272,6 +299,7 @@ class GraphStep(Step):
             pairs = [(v, p.grad) for p, v in zip(g.params, g.views) if p.grad is not None]
             rec.views, rec.fresh = [v for v, _ in pairs], [f for _, f in pairs]
             torch._foreach_add_(rec.views, rec.fresh)
+        rec.pins = self._pins(model)
         # (a step with active dropout draws other masks on every run -- torch advances the recorded generator offset per replay --
         # so there is nothing to compare it with)
         random_masks = any(isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.p > 0 for m in model.modules())

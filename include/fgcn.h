@@ -443,6 +443,30 @@ int fgcn_tmaxpool3_bwd(const float* dout, const unsigned char* idx, float* din, 
 int fgcn_unfold_windows(const float* in, float* out, int B, int T, int T_out, int V, int C, int window, int stride,
                         int dilation, int backward, void* stream);
 
+/* ---- the two ends of the step: input BatchNorm and loss (fgcn_head.hip) ------------------------------------------------------
+ * `data_bn` = nn.BatchNorm1d(M*V*C) over the network input x (N, M, T, V, C) viewed as (N, M*V*C, T)
+ * (torch_src/models/mmargcn/agcn.py:150,186-188; msg3d.py:93,152-154): channel ch = (m*V + v)*C + c, statistics over (n, t).
+ *   stats:      partials float[fgcn_data_bn_tiles(N, T)][2][M*V*C] (sum x, sum x^2 per tile) -> fgcn_bn_finalize(count = N*T)
+ *               gives vec float[4][M*V*C] and updates the running statistics;
+ *   apply:      out (N*M, T, V, Cp) = x * scale[ch] + shift[ch], channels [C, Cp) zero -- the blocks' input layout, written directly;
+ *   bwd_reduce: partials float[tiles][2][M*V*C] = (sum dout, sum dout * xhat) -> fgcn_reduce_sum -> (d beta, d gamma);
+ *   bwd_apply:  dx (N, M, T, V, C) = scale * (dout - sum0/m - xhat * sum1/m), m = N*T (train) | scale * dout (eval). */
+int fgcn_data_bn_tiles(int N, int T);
+int fgcn_data_bn_stats(const float* x, float* partials, int N, int M, int T, int V, int C, void* stream);
+int fgcn_data_bn_apply(const float* x, const float* vec, float* out, int N, int M, int T, int V, int C, int Cp, void* stream);
+int fgcn_data_bn_bwd_reduce(const float* dout, const float* x, const float* vec, float* partials, int N, int M, int T, int V,
+                            int C, int Cp, void* stream);
+int fgcn_data_bn_bwd_apply(const float* dout, const float* x, const float* vec, const float* sums, float* dx, int N, int M, int T,
+                           int V, int C, int Cp, int train, void* stream);
+/* nn.CrossEntropyLoss() (mean reduction; session/session.py:53, procedures/step.py:38-46) over logits (rows, classes) with row
+ * stride ld and int64 labels: probs float[rows][classes] = softmax (kept for the backward), row_loss float[rows], loss float[2] =
+ * {mean over the rows whose label is in [0, classes) (torch's ignore_index rows do not count), that row count}; one workgroup,
+ * fixed summation order.  bwd: dlogits (rows, ld_out) = (probs - onehot) * dloss[0] / loss[1], columns [classes, ld_out) zero. */
+int fgcn_cross_entropy_fwd(const float* logits, const long long* labels, float* probs, float* row_loss, float* loss, int rows,
+                           int classes, int ld, void* stream);
+int fgcn_cross_entropy_bwd(const float* probs, const long long* labels, const float* loss, const float* dloss, float* dlogits,
+                           int rows, int classes, int ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

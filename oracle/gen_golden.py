@@ -103,6 +103,17 @@ def module_case(mod, prefix, x, tag, store, fwd=lambda m, x: m(x)):
     return store
 
 
+def relu_sign_taps(model):
+    """Forward hooks on the reference Model's blocks: [out > 0] of every gcn1 (G) and block (O) output, in network order; the
+    list fills during the next forward."""
+    signs = []
+    for i in range(10):
+        blk = getattr(model, f"l{i}")
+        blk.gcn1.register_forward_hook(lambda _m, _i, out: signs.append((out.detach() > 0)))
+        blk.register_forward_hook(lambda _m, _i, out: signs.append((out.detach() > 0)))
+    return signs
+
+
 def main():
     gs = graphs()
     # ---- (i) adjacency stacks -------------------------------------------------------------------
@@ -155,6 +166,7 @@ def main():
         model.eval()
         store[f"{tag}.eval.logits"] = model(x).detach().numpy()
         model.train()
+        signs64 = relu_sign_taps(model)
         logits = model(x)
         loss = F.cross_entropy(logits, labels)
         loss.backward()
@@ -173,12 +185,17 @@ def main():
         model32 = ref_agcn.Model((m, t, v, c), classes, gs[gname])
         model32.load_state_dict({k: (v_.float() if v_.is_floating_point() else v_) for k, v_ in before.items()})
         model32.train()
+        signs32 = relu_sign_taps(model32)
         lg32 = model32(x.float())
         F.cross_entropy(lg32, labels).backward()
         store[f"{tag}.train.logits_f32"] = lg32.detach().numpy()
         flat64 = torch.cat([p.grad.flatten() for p in model.parameters()])
         flat32 = torch.cat([p.grad.flatten() for p in model32.parameters()]).double()
         store[f"{tag}.ref_f32_vs_f64_grad_rel"] = ((flat32 - flat64).norm() / flat64.norm()).numpy()
+        # ReLU decisions (the 20 outputs G = relu(gcn) and O = relu(tcn + residual), agcn.py:113-115,135-136) on which the
+        # reference's own float32 run differs from its float64 run: the yardstick for the HIP forward's flip count
+        store[f"{tag}.ref_f32_vs_f64_relu_flips"] = np.array([int((a != b).sum()) for a, b in zip(signs64, signs32)], dtype=np.int64)
+        store[f"{tag}.relu_decisions"] = np.array([a.numel() for a in signs64], dtype=np.int64)
     np.savez(os.path.join(OUT, "model.npz"), **store)
 
     # ---- (vi) mmargcn.Model(mode="skeleton_imu_spatial_fusion"), V = 20 + 2 ---------------------

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- ReLU-decision accounting between the HIP model and the float64 oracle.
 
-Only tests/ and __graft_entry__.smoke() import this.  Why it exists: the end-to-end gradient of the
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py import this.  Why it exists: the end-to-end gradient of the
 10-block model is a discontinuous function of the 20 ReLU sign patterns.  A pre-activation that sits within float32 rounding of
 zero can come out positive in one correct float32 implementation and non-positive in another (or in the float64 oracle); each
 such flip zeroes / un-zeroes one upstream gradient element, and the flat gradient then differs at the 1e-3 level although
@@ -96,18 +96,28 @@ def flat_grads(model) -> torch.Tensor:
     return torch.cat([p.grad.detach().double().flatten().cpu() for _, p in model.named_parameters()])
 
 
-def gradient_parity_report(model, x_dev, labels_dev, x64, labels, sd64):
-    """Runs (i)-(iii) for one case.  Returns a dict: flips (per block, total, decisions), err_plain (HIP backward as is),
-    err_injected (HIP backward gated on the oracle's ReLU decisions), both flat-gradient rel-L2 against the float64 oracle,
-    and logits / loss errors of the forward."""
-    import torch.nn.functional as F
-
+def oracle_side(x, labels, sd, names):
+    """The oracle's half of the report, computed once: logits, loss, the flat gradient in ``names`` order (the HIP model's
+    named_parameters order) and the per-block ReLU sign images.  ``x`` / ``sd`` float64 for the strict comparison; bench.py's
+    cpu_baseline leg hands in the float32 run it times anyway."""
     from oracle import agcn_oracle as O
     cap: Dict[str, torch.Tensor] = {}
-    lo, los, grads_o, _ = O.loss_and_grads(x64, labels, sd64, capture=cap)
-    flat_o = torch.cat([grads_o[n].double().flatten() for n, _ in model.named_parameters()])
+    lo, los, grads_o, _ = O.loss_and_grads(x, labels, sd, capture=cap)
+    flat_o = torch.cat([grads_o[n].double().flatten() for n in names])
     nblocks = sum(1 for k in cap if k.endswith(".g"))
-    ora = oracle_sign_images(cap, nblocks)
+    images = oracle_sign_images(cap, nblocks)
+    return dict(logits=lo.double(), loss=float(los), flat=flat_o, images=images)
+
+
+def gradient_parity_report(model, x_dev, labels_dev, x64=None, labels=None, sd64=None, oracle=None):
+    """Runs (i)-(iii) for one case.  Returns a dict: flips (per block, total, decisions), err_plain (HIP backward as is),
+    err_injected (HIP backward gated on the oracle's ReLU decisions), both flat-gradient rel-L2 against the oracle,
+    and logits / loss errors of the forward.  ``oracle``: a precomputed ``oracle_side`` result (else computed from x64, labels, sd64)."""
+    from fusion_gcn_amd.loss import cross_entropy      # the product's loss (libfgcn), checked against the oracle's F.cross_entropy
+
+    if oracle is None:
+        oracle = oracle_side(x64, labels, sd64, [n for n, _ in model.named_parameters()])
+    lo, los, flat_o, ora = oracle["logits"], oracle["loss"], oracle["flat"], oracle["images"]
     taps = BlockTaps(model)
     out = {}
     try:
@@ -115,7 +125,7 @@ def gradient_parity_report(model, x_dev, labels_dev, x64, labels, sd64):
             taps.reset()
             model.zero_grad(set_to_none=True)
             logits = model(x_dev)
-            loss = F.cross_entropy(logits, labels_dev)
+            loss = cross_entropy(logits, labels_dev)
             if tag == "plain":
                 hip = taps.sign_images()
                 per, total, n = count_flips(hip, ora)
@@ -129,4 +139,5 @@ def gradient_parity_report(model, x_dev, labels_dev, x64, labels, sd64):
             out[f"err_{tag}"] = float((flat_grads(model) - flat_o).norm() / flat_o.norm())
     finally:
         taps.close()
+        model.zero_grad(set_to_none=True)
     return out

@@ -51,6 +51,67 @@ def _worker(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
+def _eager_step_worker(rank, world, port, out_q):
+    """DefaultStep under a 2-rank group: its run_optimizer_step must average the gradients before the update (the base Step does
+    the exchange; only GraphStep used to) and broadcast_parameters must bump the parameters' version counters."""
+    from fusion_gcn_amd.session.procedures.step import DefaultStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = make_model(seed=200 + rank)
+        before = [p._version for p in model.parameters()]
+        broadcast_parameters(model, src=0)
+        bumped = all(p._version > b for p, b in zip(model.parameters(), before))
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        step = DefaultStep()
+        x, y = data()
+        sl = shard_batch(x.shape[0], rank, world)
+        for _ in range(2):
+            opt.zero_grad()
+            _, loss = step.forward(model, F.cross_entropy, x[sl], y[sl])
+            step.backward(loss)
+            step.run_optimizer_step(opt)
+        out_q.put((rank, bumped, [p.detach().clone().numpy() for p in model.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eager_steps_exchange_gradients_too():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eager_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, bumped, params = q.get(timeout=120)
+        assert bumped, "broadcast_parameters must increment the version counters"
+        got[rank] = params
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):              # the replicas stayed in lock step
+        assert (a == b).all()
+    # and they hold what two sequential replicas with averaged gradients hold
+    replicas = [make_model(seed=200) for _ in range(world)]
+    x, y = data()
+    for _ in range(2):
+        grads = []
+        for r, m in enumerate(replicas):
+            m.zero_grad()
+            sl = shard_batch(x.shape[0], r, world)
+            F.cross_entropy(m(x[sl]), y[sl]).backward()
+            grads.append([p.grad.clone() for p in m.parameters()])
+        with torch.no_grad():
+            for m in replicas:
+                for p, ga, gb in zip(m.parameters(), *grads):
+                    p -= 0.1 * (ga + gb) / world
+    for mine, want in zip(got[0], replicas[0].parameters()):
+        torch.testing.assert_close(torch.from_numpy(mine), want.detach(), rtol=1e-5, atol=1e-6)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

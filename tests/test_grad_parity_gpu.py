@@ -64,7 +64,13 @@ def test_flat_gradient_with_relu_flip_accounting(golden, tag, shape, classes, gn
           f"{rep['err_plain']:.2e}, oracle decisions injected {rep['err_injected']:.2e} "
           f"(reference fp32-vs-fp64 on this case: {ref_floor:.2e})")
     assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5
-    # (i) flips are rare: only pre-activations within float32 rounding of zero can flip
+    # (i) flips are rare: only pre-activations within float32 rounding of zero can flip -- and no more frequent than in the
+    # reference's OWN float32 run against its float64 run on this case (tests/golden/model.npz, written by oracle/gen_golden.py from
+    # hooks on the imported reference: 1 / 2 flips).  Counts this small are Poisson noise, hence 3 x + 3
+    ref_flips = int(golden("model.npz")[f"{tag}.ref_f32_vs_f64_relu_flips"].sum())
+    assert int(golden("model.npz")[f"{tag}.relu_decisions"].sum()) == rep["decisions"]
+    print(f"    ReLU flips vs fp64: HIP {rep['flips']}, the reference's own float32 run {ref_flips}")
+    assert rep["flips"] <= 3 * ref_flips + 3, (rep["flips"], ref_flips, rep["flips_per_block"])
     assert frac < 2e-5, rep["flips_per_block"]
     # (ii) arithmetic-only error
     assert rep["err_injected"] < INJECTED_TOL, rep
@@ -73,3 +79,35 @@ def test_flat_gradient_with_relu_flip_accounting(golden, tag, shape, classes, gn
     # the north star's 1e-3 is met with a factor 100 to spare once the decisions agree; without a flip it is met as is
     if rep["flips"] == 0:
         assert rep["err_plain"] < INJECTED_TOL
+
+
+def test_headline_shape_against_the_oracle_at_full_size():
+    """BASELINE configs[1] at its full (C,T,V,M) = (3,300,25,2) and 60 classes, 16 clips (what the CPU oracle affords: ~1 min of
+    float64 work on the box's cores): HIP logits / loss against the float64 oracle, the flat gradient of all 3.47 M parameters with
+    ReLU-flip accounting -- the same three-part statement as above, at the size the benchmark runs (bench.py reports the same
+    comparison against its float32 oracle run as ``parity_at_full_shape``)."""
+    import os
+    from fusion_gcn_amd import ops
+    n = int(os.environ.get("FGCN_FULL_SHAPE_CLIPS", "16"))
+    dev = torch.device("cuda:0")
+    model, x, labels = _case("full", (n, 2, 300, 25, 3), 60, "ntu")
+    with torch.no_grad():                       # O(1) BatchNorm scale in the graph convolutions, as the benchmark sets it
+        for k, p in model.named_parameters():
+            if k.endswith("gcn1.bn.weight"):
+                p.fill_(1.0)
+    sd = {k: (v.detach().double().clone() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oracle = RM.oracle_side(x.double(), labels, sd, [k for k, _ in model.named_parameters()])
+    del sd
+    model = model.to(dev).train()
+    for mode in ("bf16x3", "f32"):
+        with ops.math_mode(mode):
+            rep = RM.gradient_parity_report(model, x.float().to(dev), labels.to(dev), oracle=oracle)
+        frac = rep["flips"] / rep["decisions"]
+        print(f"[full shape, {n} clips, {mode}] logits {rep['logits_err']:.2e} loss {rep['loss_err']:.2e} | ReLU flips {rep['flips']} of "
+              f"{rep['decisions']} ({frac:.2e}) | flat-grad rel-L2: plain {rep['err_plain']:.2e}, oracle decisions injected "
+              f"{rep['err_injected']:.2e}")
+        assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5, rep
+        assert frac < 2e-6, rep["flips_per_block"]          # SURVEY.md section 0: ~3e-7 of the ReLU inputs in the reference's own runs
+        assert rep["err_injected"] < INJECTED_TOL, rep
+        assert rep["err_plain"] <= flip_bound(rep["flips"], rep["decisions"]), rep

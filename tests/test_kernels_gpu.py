@@ -654,3 +654,74 @@ def test_kernels_are_deterministic():
         outs.append((out.clone(), part.clone(), g.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+# ---- the two ends of the step (fgcn_head.hip): data_bn and CrossEntropy ------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,T,V,C", [(4, 2, 37, 25, 3), (3, 1, 100, 20, 3), (2, 2, 16, 27, 3), (5, 2, 33, 18, 2), (2, 1, 8, 22, 9)])
+@pytest.mark.parametrize("train", [True, False])
+def test_data_bn_matches_batchnorm1d(N, M, T, V, C, train):
+    """block.data_bn = the reference's permute / view / nn.BatchNorm1d / view / permute (agcn.py:186-188) + the zero pad channel:
+    output, running statistics, batch counter, gradients of gamma / beta / x, against torch float64 on the CPU."""
+    from fusion_gcn_amd.block import data_bn
+    torch.manual_seed(N * 100 + T)
+    ch = M * V * C
+    ref = torch.nn.BatchNorm1d(ch).double()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5), ref.bias.uniform_(-0.5, 0.5)
+        ref.running_mean.uniform_(-0.3, 0.3), ref.running_var.uniform_(0.5, 2.0)
+    mine = torch.nn.BatchNorm1d(ch)
+    mine.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    mine = mine.to(dev())
+    ref.train(train), mine.train(train)
+    x = (torch.randn(N, M, T, V, C, dtype=torch.float64) * 2 + 0.3)
+    xr = x.clone().requires_grad_(True)
+    h = ref(xr.permute(0, 1, 3, 4, 2).contiguous().view(N, ch, T)).view(N, M, V, C, T).permute(0, 1, 4, 2, 3).reshape(N * M, T, V, C)
+    xm = x.float().to(dev()).requires_grad_(True)
+    got = data_bn(xm, mine)
+    Cp = (C + 3) // 4 * 4
+    assert got.shape == (N * M, T, V, Cp)
+    assert rel_l2(got[..., :C].detach().cpu().numpy(), h.detach().numpy()) < 2e-6
+    assert float(got[..., C:].abs().max()) == 0.0 if Cp > C else True
+    probe = torch.randn(N * M, T, V, Cp, dtype=torch.float64)
+    (h * probe[..., :C]).sum().backward()
+    (got * probe.float().to(dev())).sum().backward()
+    assert rel_l2(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-5
+    assert rel_l2(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 1e-5
+    assert rel_l2(xm.grad.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    for k in ("running_mean", "running_var"):
+        assert rel_l2(getattr(mine, k).cpu().numpy(), getattr(ref, k).numpy()) < 2e-6, k
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
+    # fixed-order sums: a second run gives the same bits
+    mine.zero_grad()
+    xm2 = x.float().to(dev()).requires_grad_(True)
+    got2 = data_bn(xm2, mine) if not train else None
+    if got2 is not None:
+        assert torch.equal(got2, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,classes", [(64, 60), (2, 27), (7, 35), (130, 60), (1, 5), (16, 200)])
+def test_cross_entropy_matches_torch(rows, classes):
+    """fusion_gcn_amd.loss.CrossEntropyLoss = nn.CrossEntropyLoss() (mean; ignore_index rows do not count), on logits that are a
+    column window of a padded matrix (what the classifier hands over), forward and gradient, bitwise repeatable."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd.loss import CrossEntropyLoss
+    torch.manual_seed(rows + classes)
+    npad = (classes + 3) // 4 * 4
+    z = torch.randn(rows, npad, dtype=torch.float64) * 3
+    y = torch.randint(0, classes, (rows,))
+    if rows > 4:
+        y[1] = -100                                              # torch's ignore_index
+    zr = z[:, :classes].clone().requires_grad_(True)
+    want = F.cross_entropy(zr, y)
+    (want * 1.7).backward()
+    base = z.float().to(dev()).requires_grad_(True)
+    loss_fn = CrossEntropyLoss()
+    got = loss_fn(base[:, :classes], y.to(dev()))
+    (got * 1.7).backward()
+    assert abs(float(got) - float(want)) < 2e-6 * max(1.0, abs(float(want)))
+    assert rel_l2(base.grad[:, :classes].cpu().numpy(), zr.grad.numpy()) < 2e-6
+    assert float(base.grad[:, classes:].abs().max()) == 0.0 if npad > classes else True
+    again = loss_fn(base.detach()[:, :classes], y.to(dev()))
+    assert torch.equal(again, got.detach())

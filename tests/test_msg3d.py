@@ -276,3 +276,42 @@ def test_multi_scale_temporal_block_matches_the_oracle(stride, cin, cout, fgcn_m
             assert rel_l2(mine.cpu().numpy(), g.numpy()) < tol, (k, flips)
     for k, v in stats.updates.items():
         assert rel_l2(blk.state_dict()[k[5:]].cpu().numpy(), v.numpy()) < 1e-5, k
+
+
+@pytest.mark.gpu
+def test_standalone_module_repacks_its_weights_after_an_in_place_update(fgcn_math):
+    """A MultiScale_TemporalConv used on its own (no Model.forward to run the batched refresh): after the parameters change in place
+    (an optimizer step, load_state_dict) or move, the next forward must compute with the NEW values -- fops.ParamForms checks every
+    form against its sources' addresses and version counters."""
+    from fusion_gcn_amd.models.msg3d.ms_tcn import MultiScale_TemporalConv
+    B, T, V, cin, cout = 2, 10, 20, 96, 96
+    blk = MultiScale_TemporalConv(cin, cout, stride=1)
+    filler.fill_state_dict(blk.state_dict(), prefix="tcn1.")
+    blk = blk.to(dev()).train()
+    x = torch.from_numpy(filler.bellish("x.mstcn.stale", (B, cin, T, V)))
+    xg = x.float().permute(0, 2, 3, 1).contiguous().to(dev())
+
+    def oracle():
+        sd = {"tcn1." + k: (v.detach().double().cpu().clone() if v.is_floating_point() else v.detach().cpu().clone())
+              for k, v in blk.state_dict().items()}
+        return O.ms_tcn(x.clone(), sd, "tcn1", 1, True, O.Stats()).permute(0, 2, 3, 1).numpy()
+
+    want0 = oracle()
+    got0 = blk(xg).detach().cpu().numpy()
+    assert rel_l2(got0, want0) < 2e-5
+    with torch.no_grad():                                    # in place: versions bump, addresses stay
+        for n, p in blk.named_parameters():
+            if n.endswith("weight") and p.dim() > 1:
+                p.mul_(-0.7)
+            elif n.endswith("bias"):
+                p.add_(0.05)
+    want1 = oracle()
+    assert rel_l2(want1, want0) > 1e-2                       # the update matters
+    got1 = blk(xg).detach().cpu().numpy()
+    assert rel_l2(got1, want1) < 2e-5, "stale packed weights after an in-place parameter update"
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    for p in blk.parameters():                               # moved: new storage for every parameter
+        p.data = p.data.clone() * 1.25
+    want2 = oracle()
+    got2 = blk(xg).detach().cpu().numpy()
+    assert rel_l2(got2, want2) < 2e-5, "stale packed weights after the parameters moved"

@@ -154,3 +154,21 @@ def test_unused_parameter_is_an_error_not_a_silent_zero_gradient():
     with pytest.raises(RuntimeError, match="no gradient"):
         g.gather()
     FlatGradients(m.parameters(), allow_unused=True).gather()
+
+
+def test_zero_grad_in_place_before_any_backward():
+    """opt.zero_grad(set_to_none=False) with no gradient yet (before the first backward, or after a set_to_none zero) points every
+    p.grad at its zeroed view of the flat buffer instead of raising 'received no gradient'; allow_unused reaches the buffer."""
+    from fusion_gcn_amd.optim import FlatOptimizer
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    opt = FlatOptimizer(m.parameters(), "SGD", 0.1, allow_unused=True)
+    assert opt.grads.allow_unused
+    opt.zero_grad(set_to_none=False)
+    for p, v in zip(opt.grads.params, opt.grads.views):
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr() and float(p.grad.abs().sum()) == 0.0
+    m(torch.randn(5, 4)).sum().backward()
+    assert float(opt.grads.flat.abs().sum()) > 0          # backward accumulated into the flat buffer through the views
+    opt.zero_grad()                                          # set_to_none=True
+    assert all(p.grad is None for p in m.parameters())
+    opt.zero_grad(set_to_none=False)
+    assert float(opt.grads.flat.abs().sum()) == 0.0

@@ -173,6 +173,59 @@ def test_graph_step_rejects_foreign_gradients_and_records_again_after_a_move():
         assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-12)
 
 
+def test_recordings_of_two_math_modes_keep_their_packed_weights():
+    """A recording reads the blocks' packed weight buffers and the re-pack tables through raw pointers.  A forward in another
+    math mode replaces every block's packed set and the model's re-pack plan (and broadcast_parameters' / drop_packed drops
+    them): the earlier recording must keep its own alive (GraphStep pins them) and still replay the eager step -- with the
+    CURRENT parameter values, since its recorded re-pack launch reads the parameters' homes."""
+    import gc
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.session.procedures import GraphStep
+    shape, classes = (1, 24, 20, 3), 27
+    (x, y, _), = batches([3], shape, classes)
+    model = agcn(shape, classes).to(DEV).train()
+    step = GraphStep()
+
+    def eager(mode):
+        model.zero_grad()
+        with ops.math_mode(mode):
+            loss = F.cross_entropy(model(x), y)
+            loss.backward()
+        out = float(loss), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+        model.zero_grad()
+        return out
+
+    def replay(mode):
+        with ops.math_mode(mode):
+            _, loss = step.forward(model, F.cross_entropy, x, y)
+        torch.cuda.synchronize()
+        model.zero_grad()                                 # p.grad = None; the flat buffer keeps the step's gradients until the next step
+        return float(loss), None
+
+    replay("bf16x3")                                     # recording 1
+    pinned = [id(o) for rec in step._recorded.values() for o in rec.pins]
+    assert pinned, "the recording must hold the packed sets it reads"
+    replay("f32")                                        # recording 2: every block's packed set and the plan are replaced
+    assert len(step._recorded) == 2
+    for blk in model.modules():
+        if hasattr(blk, "drop_packed"):
+            blk.drop_packed()                            # what a parameter broadcast does
+    model._pack_plan = None
+    gc.collect()
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]     # reuse whatever memory was freed
+    del junk
+    with torch.no_grad():                                # an "optimizer update" behind the recordings
+        for p in model.parameters():
+            p.mul_(1.01)
+    for mode in ("bf16x3", "f32", "bf16x3"):
+        want_loss, want = eager(mode)
+        got_loss, got = replay(mode)
+        assert abs(got_loss - want_loss) <= 1e-6 * abs(want_loss), (mode, got_loss, want_loss)
+        views = torch.cat([v.reshape(-1) for v in step.grads.views])
+        assert float((views - want).norm()) <= 1e-5 * float(want.norm()), mode
+    assert step.replays == 5 and len(step._recorded) == 2     # nothing was recorded again
+
+
 def test_resume_from_a_reference_style_checkpoint(tmp_path, fgcn_math):
     """Two steps, a checkpoint in the layout of the reference's CheckpointManager.save_checkpoint (progress.py:209-226: one
     state_dict per object of ``state_dict_objects`` + "epoch", torch.save), fresh objects, load, two more steps == four steps."""
