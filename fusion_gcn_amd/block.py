@@ -48,8 +48,6 @@ class BlockConfig:
     has_down: bool = False
     static_adjacency: bool = False  # ST-GCN special case: A^ = A + B, no data-dependent C_k
     fused_spatial: bool = True      # north-star fused kernel vs. joint_mix + rows_gemm
-    fused_spatial_bwd: bool = False  # one-kernel dagg + dx + dA^ (fgcn_spatial_bwd): correct, but measured slower than the
-    #                                  row GEMM + joint_mix + joint_gram trio on MI355X (2.1 vs 1.7 ms at 256 ch), so off
 
     @property
     def ic(self) -> int:
@@ -134,7 +132,6 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
         F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
     d_cols = [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, n0=k * cx) for k, w in enumerate(wd)]          # (1, cout, 3cx)
     F["d_t"] = Form("plain", 1, cout, 3 * cx, d_cols)
-    F["dt4"] = Form("k4", NUM_SUBSETS, cout, cx, [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, t0=k) for k, w in enumerate(wd)])
     # the kernel adds the sum of the three biases: overlapping segments are summed
     F["d_b"] = Form("plain", 1, 1, cout, [Seg(P[f"gcn1.conv_d.{k}.bias"].detach(), st_k=0, st_n=1, klen=1, nlen=cout)
                                           for k in range(NUM_SUBSETS)], shape=(cout,))
@@ -487,7 +484,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
-    gate_in_dagg = (GATED_SHORTCUTS and FUSED_DAGG and not cfg.fused_spatial_bwd and not cfg.has_down and cfg.residual == "identity"
+    gate_in_dagg = (GATED_SHORTCUTS and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and d_o.numel() * 4 < 0x7FFF0000)
     gated: List[tuple] = []
@@ -567,17 +564,13 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
-    if cfg.fused_spatial_bwd:
-        # dagg = dy . Wd, dx += dagg . A^^T and dA^ = x^T . dagg in one kernel; dagg never reaches HBM
-        part = ops.spatial_bwd(dy, x, a_hat, W["dt4"], dx, accumulate=dx_live)
+    dagg = new(B, T, V, c3)
+    pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3)
+    if FUSED_DAGG and x.shape[3] == cin:
+        part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:
-        dagg = new(B, T, V, c3)
-        pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3)
-        if FUSED_DAGG and x.shape[3] == cin:
-            part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
-        else:
-            mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
-            part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
+        mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
+        part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     dx_live = True
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
     db = torch.empty_like(P["gcn1.adj_b"])

@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 
 // MINB = workgroups per CU the register allocation aims at (launch-bounds hint; fgcn_set_tuning key 4 picks 2 or 3)
 // MM: math mode -- FGCN_MATH_F32 or FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments
-// are read); FGCN_MATH_BF16X3 is conv_halo_x3_kernel below
+// are read); FGCN_MATH_BF16X3 is conv_halo_x3k32_kernel below
 template <int NT, int MINB, int MM>
 __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     extern __shared__ __attribute__((aligned(16))) float Ah[];
@@ -277,258 +277,19 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
     }
 }
 
-// ---- FGCN_MATH_BF16X3 ------------------------------------------------------------------------------------------------
-// Same halo-tile scheme on the bf16 matrix pipe at f32 accuracy (fgcn_common.hpp): the image is split into its three
-// bf16 parts as it is staged (three planes of [row][32 + 8 pad] bf16: one ds_read_b128 per part = the 8 k of a lane), the
-// weights come pre-split from HBM (fgcn_pack_split3: [part][tap][k/8][n][8]); one step = 16 channels = one
-// v_mfma_f32_32x32x16_bf16 per partial product.  Six bf16 MFMAs move the work of eight f32 ones in 3/8 of the cycles, so
-// the weight stream (6 instead of 4 bytes per weight) would need 4x the L2 bandwidth of the f32 kernel: the waves are
-// therefore arranged 2 x 2 over the (128 rows x 64*NT columns) tile -- a wave owns 64 rows (MT = 2 row tiles) x 32*NT
-// columns and every weight fragment feeds two row tiles (the 4 x 1 arrangement of the f32 kernel measured L2-bound:
-// 64 B/clk/CU).  Weights are prefetched one unit (one column tile of one step) ahead in a ring of two fragment sets,
-// across step and chunk boundaries; past the last unit the address wraps to the first one (a valid, unused load).
-// KC = channels per staged chunk: 32 for the temporal convs (image = tile + halo rows); 64 for 1x1 convolutions (taps = 1:
-// no halo, 128 rows), where a chunk is only KC/16 steps of MFMAs -- there the NEXT chunk's rows are requested before the
-// MFMAs of the current one and parked in registers (PF), so the global latency is not paid between two barriers.
-template <int MT, int NT, int KC>
-__global__ __launch_bounds__(256, 2) void conv_halo_x3_kernel(HaloP p) {
-    static_assert(MT == 2 && (NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
-    constexpr int XS = KC * 2 + 16;                  // LDS row stride of one bf16 part, bytes (conflict-free b128 reads)
-    constexpr int TPR = KC / 4;                      // threads per staged row (16 bytes each)
-    constexpr int RPP = 256 / TPR;                   // rows per staging pass
-    constexpr int SPC = KC / 16;                     // steps per tap and chunk
-    constexpr bool PF = KC == 64;
-    constexpr int NST = PF ? 8 : HALO_MAX_STAGE;     // staging passes (PF: 128 rows, checked by the host)
-    extern __shared__ __attribute__((aligned(16))) float Ah[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int bm = blockIdx.x, bn = blockIdx.y;
-    const long long m0 = (long long)bm * 128;
-    constexpr int BN = 2 * NT * 32;                  // columns of the workgroup tile
-    const int n0 = bn * BN;
-    const int V = p.V, TvV = p.Tv * p.V;
-    const unsigned k4b = (tid % TPR) * 16;
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
-
-    bool row_ok[MT];
-    int th_lane[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const long long mrow = m0 + (wr * MT + mt) * 32 + l31;
-        row_ok[mt] = mrow < p.Mv;
-        th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
-    }
-
-    unsigned src_off[NST];
-    const int nstage = (p.halo_rows + RPP - 1) / RPP;
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        src_off[i] = 0x80000000u;
-        const int r = tid / TPR + RPP * i;
-        const long long hv = m0 + (long long)p.dmin * V + r;
-        if (i < nstage && hv >= 0 && hv < p.Mv) {
-            const unsigned hu = (unsigned)hv;
-            const int n = (int)(hu / (unsigned)TvV);
-            const int rem = (int)(hu - (unsigned)n * (unsigned)TvV);
-            const int th = (int)((unsigned)rem / (unsigned)V);
-            const int v = rem - th * V;
-            const int fr = th * p.in_s + p.in_o;
-            if (th < p.Th_in && fr < p.T_in_full)
-                src_off[i] = (unsigned)(((((long long)n * p.T_in_full + fr) * V + v) * p.ld_in) * 4) + k4b;
-        }
-    }
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero16();
-
-    const int col = n0 + wc * NT * 32 + l31;         // + nt*32
-    unsigned wvoff[NT];                              // per-lane byte offset into one part: (h*N + col) * 8 bf16
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wvoff[nt] = (unsigned)(((long long)h * p.N + col + nt * 32) * 16);
-
-    unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
-    const unsigned plane = (unsigned)p.halo_rows * XS;
-    const unsigned char* xrow = Xh + (wr * MT * 32 + l31) * XS + 16 * h;
-    const int IT2 = p.taps * SPC;                    // (tap, 16-channel group) steps per chunk
-    const int K8 = p.K >> 3;
-    auto load_w = [&](u32x4v (&dst)[3], int nt, int it, int kc) {
-        if (it >= IT2) {                             // (at most two steps past the chunk: IT2 >= 2)
-            it -= IT2;
-            kc += KC;
-        }
-        if (kc >= p.K) {
-            it = 0;
-            kc = 0;
-        }
-        const int j = it / SPC, s2 = it % SPC;
-        const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 2 * s2) * p.N) * 16);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nt], so + pl * p.w_plane_bytes, 0);
-    };
-    auto load_a = [&](u32x4v (&dst)[MT][3], int it) {
-        const int j = it / SPC, s2 = it % SPC;
-        const int d = j * p.tb + p.tc;
-        const unsigned char* src = xrow + (d - p.dmin) * V * XS + 32 * s2;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int ts = th_lane[mt] + d;
-            const bool ok = row_ok[mt] && ts >= 0 && ts < p.Th_in;      // frame mask of this (row, tap)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const u32x4v v = *reinterpret_cast<const u32x4v*>(src + mt * 32 * XS + pl * plane);
-                dst[mt][pl] = ok ? v : u32x4v{0u, 0u, 0u, 0u};
-            }
-        }
-    };
-    u32x4v wq[2][3];
-    load_w(wq[0], 0, 0, 0);
-    // one step: NT units; `odd` = parity of the step (selects the ring slot when NT == 1)
-    auto step = [&](const u32x4v (&a)[MT][3], int it, int kc, auto odd) {
-        if constexpr (NT == 2) {
-            load_w(wq[1], 1, it, kc);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma_x3_k16(a[mt], wq[0], acc[mt][0]);
-            load_w(wq[0], 0, it + 1, kc);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][1] = mfma_x3_k16(a[mt], wq[1], acc[mt][1]);
-        } else {
-            constexpr int cur = decltype(odd)::value;
-            load_w(wq[cur ^ 1], 0, it + 1, kc);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma_x3_k16(a[mt], wq[cur], acc[mt][0]);
-        }
-    };
-    using Even = std::integral_constant<int, 0>;
-    using Odd = std::integral_constant<int, 1>;
-
-    f32x4 stage[NST];
-    auto fetch = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
-    };
-    auto deposit = [&]() {                           // split the staged rows into the three bf16 planes
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int r = tid / TPR + RPP * i;
-            if (i < nstage && r < p.halo_rows) {
-                u32x2 ph, pm, pl;
-                split3_x4(stage[i], ph, pm, pl);
-                unsigned char* dst = Xh + r * XS + (tid % TPR) * 8;
-                *reinterpret_cast<u32x2*>(dst) = ph;
-                *reinterpret_cast<u32x2*>(dst + plane) = pm;
-                *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
-            }
-        }
-    };
-    if constexpr (PF) fetch(0);
-    for (int kc = 0; kc < p.K; kc += KC) {
-        __syncthreads();                             // previous chunk's image reads are done
-        if constexpr (!PF) fetch(kc);
-        deposit();
-        __syncthreads();
-        if constexpr (PF) {
-            if (kc + KC < p.K) fetch(kc + KC);       // lands during the MFMAs below
-        }
-        u32x4v x0[MT][3], x1[MT][3];
-        load_a(x0, 0);
-        for (int it = 0; it < IT2; it += 2) {        // IT2 is even
-            load_a(x1, it + 1);
-            step(x0, it, kc, Even{});
-            if (it + 2 < IT2) load_a(x0, it + 2);
-            step(x1, it + 1, kc, Odd{});
-        }
-    }
-
-    // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums ---------------------------------
-    const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
-    constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
-    float ssum[NT], ssq[NT], bv[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        ssum[nt] = 0.f;
-        ssq[nt] = 0.f;
-        bv[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                               rbias, col + nt * 32 < p.N ? (unsigned)(col + nt * 32) * 4u : OOB, 0, 0));
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        unsigned rowoff[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long m = m0 + (wr * MT + mt) * 32 + acc_row(r, lane);
-            bool ok = m < p.Mv;
-            unsigned orow = (unsigned)(ok ? m : 0);
-            if (!plain_out) {                              // wave-uniform
-                const int n = (int)(orow / (unsigned)TvV);
-                const int rem = (int)(orow - (unsigned)n * (unsigned)TvV);
-                const int th = (int)((unsigned)rem / (unsigned)V);
-                const int v = rem - th * V;
-                ok = ok && th < p.Th_out;
-                orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
-            }
-            rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c = col + nt * 32;
-            const unsigned coff = c < p.N ? (unsigned)c * 4u : OOB;
-            float old[16];
-            if (p.accumulate) {                            // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rout, (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff, 0, 0));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) old[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned off = (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff;
-                const float val = acc[mt][nt][r] + bv[nt] + old[r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
-                const float kept = off != OOB ? val : 0.f;
-                ssum[nt] += kept;
-                ssq[nt] += kept * kept;
-            }
-        }
-    }
-    if (p.stats) {
-        __syncthreads();
-        float* red = Ah;                                   // [which][wr][BN]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float a = ssum[nt] + __shfl_xor(ssum[nt], 32);
-            const float b = ssq[nt] + __shfl_xor(ssq[nt], 32);
-            if (lane < 32) {
-                red[(0 * 2 + wr) * BN + (wc * NT + nt) * 32 + lane] = a;
-                red[(1 * 2 + wr) * BN + (wc * NT + nt) * 32 + lane] = b;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid - which * BN;
-            if (n0 + c < p.N)
-                p.stats[((long long)bm * 2 + which) * p.N + n0 + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
-        }
-    }
-}
-
-
-// ---- the same kernel on v_mfma_f32_16x16x32_bf16 ---------------------------------------------------------------------------
-// Half the accumulator traffic per FLOP of the 32x32x16 form: under this kernel the chip holds ~1.85 GHz with the 32x32 shape
-// and the timing probe gave +4-5 % for the 16x16 one.  A step is one tap x 32 channels (the
+// ---- FGCN_MATH_BF16X3 / FGCN_MATH_BF16: the halo-tile scheme on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16) ----------------
+// The image is split into its bf16 parts as it is staged (planes of unpadded, XOR-swizzled bf16 rows: one ds_read_b128 per part =
+// the 8 k of a lane), the weights come pre-split from HBM (fgcn_pack_split3: [part][tap][k/8][n][8]).  Six bf16 MFMAs move the
+// work of eight f32 ones in 3/8 of the cycles, so the weight stream (6 instead of 4 bytes per weight) would need 4x the L2
+// bandwidth of the f32 kernel: the waves are arranged 2 x 2 over the (128 rows x 64 NT columns) tile -- a wave owns 64 rows x
+// 32 NT columns and every weight fragment feeds all its row tiles (the 4 x 1 arrangement of the f32 kernel measured L2-bound:
+// 64 B/clk/CU).  Weights are prefetched one unit ahead in a ring of two fragment sets, across step and chunk boundaries; past the
+// last unit the address wraps to the first one (a valid, unused load).  KC = channels per staged chunk: 32 for the temporal convs
+// (image = tile + halo rows); 64 for 1x1 convolutions (taps = 1: no halo), where the NEXT chunk's rows are requested before the
+// MFMAs of the current one and parked in registers, so the global latency is not paid between two barriers.
+// (The first build of this kernel issued v_mfma_f32_32x32x16_bf16: 4-10 % slower at equal FLOPs -- half the accumulator traffic per
+// FLOP with the 16x16 shape and the chip holds its clock better; that form was removed in round 3.)
+// A step is one tap x 32 channels (the
 // whole chunk at KC = 32); lane (i = lane & 15, g = lane >> 4) holds k = 8g + j of row / column i.  The wave's 64 x (32 NT)
 // tile is 4 row tiles x 2 NT column tiles of 16 x 16; the four image fragments of a step stay resident and are replaced
 // one by one during the step's last unit (right after each one's last MFMA), the weight fragments ride the same two-slot
@@ -818,14 +579,14 @@ using namespace fgcn;
 // planes of unpadded 64-byte rows) would not fit twice into LDS -- with the swizzled image that is V > 36, i.e. never (V <= 32):
 // the 27- and 22-joint shapes of BASELINE configs 3 / 4 run the 128-row tile too (they took the 96-row one with 80-byte rows)
 static int halo_tile_rows(int V) {
-    const bool k32 = fgcn::math_mode() == FGCN_MATH_BF16 || (fgcn::math_mode() == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 6));
+    const bool k32 = fgcn::math_mode() == FGCN_MATH_BF16 || fgcn::math_mode() == FGCN_MATH_BF16X3;
     return (k32 && (128 + 8 * V) * 64 * 3 > 80 * 1024) ? 96 : 128;
 }
 
 // 1 when fgcn_tconv_halo can emit the BatchNorm-backward sums in the current math mode / tuning (the 16x16x32 split-bf16 kernel)
 extern "C" int fgcn_tconv_halo_bn_sums(void) {
     const int mm = fgcn::math_mode();
-    return (mm == FGCN_MATH_BF16 || (mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 6))) ? 1 : 0;
+    return (mm == FGCN_MATH_BF16 || mm == FGCN_MATH_BF16X3) ? 1 : 0;
 }
 
 extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
@@ -894,14 +655,6 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
         FGCN_HALO_ATTR(2, 2); FGCN_HALO_ATTR(2, 3); FGCN_HALO_ATTR(4, 2); FGCN_HALO_ATTR(4, 3);
 #undef FGCN_HALO_ATTR
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 1, 64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3_kernel<2, 2, 64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         lds_opt_in = true;
     }
     const bool three = fgcn::tuning(4) == 0;   // 3 workgroups per CU measured faster (64 channels: 0.73 -> 0.63 ms)
@@ -909,8 +662,8 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.tiles_n = (int)cdiv(N, N <= 64 ? 64 : 128);
     dim3 grid((unsigned)tiles, (unsigned)p.tiles_n);
     p.per_xcd = 0;
-    if ((mm == FGCN_MATH_BF16X3 && !(fgcn::tuning(7) & 2) && !((fgcn::tuning(7) & 4) && N <= 64)) || mm == FGCN_MATH_BF16) {
-        // 16x16x32 MFMA form (tuning key 7 bit 1: the 32x32x16 one); FGCN_MATH_BF16: the same kernel with one bf16 part
+    if (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) {
+        // split-bf16 kernel (16x16x32 MFMAs); FGCN_MATH_BF16: the same kernel with one bf16 part
         static bool opt_in = false;
         if (!opt_in) {
             const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
@@ -955,17 +708,6 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             else FGCN_K32_LAUNCH(2, 32);
         }
 #undef FGCN_K32_LAUNCH
-        return launch_status("tconv_halo");
-    }
-    if (mm == FGCN_MATH_BF16X3) {
-        if (taps == 1 && K % 64 == 0) {              // 1x1 convolution: 64-channel chunks, next chunk prefetched
-            const size_t lds64 = (size_t)128 * (64 * 2 + 16) * 3;
-            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1, 64>), grid, dim3(256), lds64, s, p);
-            else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2, 64>), grid, dim3(256), lds64, s, p);
-        } else {
-            if (N <= 64) hipLaunchKernelGGL((conv_halo_x3_kernel<2, 1, 32>), grid, dim3(256), lds, s, p);
-            else hipLaunchKernelGGL((conv_halo_x3_kernel<2, 2, 32>), grid, dim3(256), lds, s, p);
-        }
         return launch_status("tconv_halo");
     }
     if ((fgcn::tuning(5) & 2) && tiles * p.tiles_n < (1ll << 30)) {   // measured neutral: off

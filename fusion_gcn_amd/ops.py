@@ -752,27 +752,6 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     return y, part
 
 
-def spatial_bwd(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, wdt4: torch.Tensor, dx: torch.Tensor, *,
-                accumulate: bool) -> torch.Tensor:
-    """Fused backward of the spatial aggregation: dx (+)= sum_k (dy . Wd_k) . A^_k^T and the per-chunk partials of
-    dA^_k = x^T . (dy . Wd_k).  wdt4 = pack_k4 of the (K, Cout, Cin) weight stack.  -> partial (B, nchunk, K, 32, 32)."""
-    ensure_device()
-    _chk(dy, "spatial_bwd.dy"), _chk(x, "spatial_bwd.x"), _chk(a_hat, "spatial_bwd.a_hat"), _chk(wdt4, "spatial_bwd.wdt4")
-    _chk(dx, "spatial_bwd.dx")
-    B, T, V, ld_dy = dy.shape
-    ns, Cout, Cin = wdt4.shape[0], wdt4.shape[1] * 4, wdt4.shape[2]
-    if x.shape[:3] != dy.shape[:3] or dx.shape != x.shape or a_hat.shape[1] != ns or a_hat.shape[0] not in (1, B) or \
-            a_hat.shape[2:] != (V, V) or wdt4.shape[3] != 4 or Cout > ld_dy or Cin > x.shape[3]:
-        raise _lib.FgcnError(f"spatial_bwd: shape mismatch dy={tuple(dy.shape)} x={tuple(x.shape)} "
-                             f"a_hat={tuple(a_hat.shape)} wdt4={tuple(wdt4.shape)}")
-    lib = _lib.load()
-    partial = torch.empty((B, lib.fgcn_spatial_bwd_chunks(B, T), ns, 32, 32), device=dy.device, dtype=torch.float32)
-    check(lib.fgcn_spatial_bwd(_p(dy), _p(x), _p(a_hat), _p(wdt4), _p(dx), _p(partial), B, T, V, Cin, Cout, ld_dy,
-                               x.shape[3], dx.shape[3], ns, int(a_hat.shape[0] != 1), int(accumulate), _stream()),
-          "fgcn_spatial_bwd")
-    return partial
-
-
 def transpose(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
     """(B, R, C) -> (B, C, ld_out) with out[b, c, r] = x[b, r, c] and the columns [R, ld_out) zero-filled (ld_out >= R)."""
     ensure_device()

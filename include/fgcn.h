@@ -379,16 +379,6 @@ int fgcn_spatial_fwd(const float* x, const float* a_hat, const float* wd, const 
                      int n_subsets, int a_hat_batched, void* stream);
 int fgcn_spatial_tiles(int B, int T);
 
-/* ---- fused spatial block backward (input and adjacency gradients) ------------------------------------------ */
-/* dagg_k = dy . Wd_k (kept on chip);  dx (+)= sum_k dagg_k . A^_k^T;  partial[n][chunk][k] = sum_{t in chunk} x_t^T . dagg_k
- *   = the autograd backward of agcn.py:103-111 w.r.t. x (through the aggregation) and w.r.t. A^_k, in one kernel.
- *   wdt4: k-interleaved packed float[K][Cout/4][Cin][4] with wdt4[k][o/4][c][o%4] = Wd_k[o][c]; Cin % 4 == 0,
- *   Cout % 16 == 0.  partial: float[B][fgcn_spatial_bwd_chunks(B,T)][K][32][32] (feed to fgcn_adj_softmax_bwd). */
-int fgcn_spatial_bwd(const float* dy, const float* x, const float* a_hat, const float* wdt4, float* dx, float* partial,
-                     int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx,
-                     int n_subsets, int a_hat_batched, int accumulate, void* stream);
-int fgcn_spatial_bwd_chunks(int B, int T);
-
 /* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
 /* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:
  *     out[b][c][r] = in[b][r][c]  (r < R, c < C);  out rows have stride ld_out >= R, their columns [R, ld_out) are zero-filled.

@@ -109,10 +109,11 @@ def oracle_side(x, labels, sd, names):
     return dict(logits=lo.double(), loss=float(los), flat=flat_o, images=images)
 
 
-def gradient_parity_report(model, x_dev, labels_dev, x64=None, labels=None, sd64=None, oracle=None):
+def gradient_parity_report(model, x_dev, labels_dev, x64=None, labels=None, sd64=None, oracle=None, keep_grads: bool = False):
     """Runs (i)-(iii) for one case.  Returns a dict: flips (per block, total, decisions), err_plain (HIP backward as is),
     err_injected (HIP backward gated on the oracle's ReLU decisions), both flat-gradient rel-L2 against the oracle,
-    and logits / loss errors of the forward.  ``oracle``: a precomputed ``oracle_side`` result (else computed from x64, labels, sd64)."""
+    and logits / loss errors of the forward.  ``oracle``: a precomputed ``oracle_side`` result (else computed from x64, labels, sd64).
+    ``keep_grads``: leave the gradients of the LAST (injected) backward in ``p.grad``."""
     from fusion_gcn_amd.loss import cross_entropy      # the product's loss (libfgcn), checked against the oracle's F.cross_entropy
 
     if oracle is None:
@@ -139,5 +140,6 @@ def gradient_parity_report(model, x_dev, labels_dev, x64=None, labels=None, sd64
             out[f"err_{tag}"] = float((flat_grads(model) - flat_o).norm() / flat_o.norm())
     finally:
         taps.close()
-        model.zero_grad(set_to_none=True)
+        if not keep_grads:
+            model.zero_grad(set_to_none=True)
     return out

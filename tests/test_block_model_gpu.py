@@ -13,6 +13,7 @@ import torch
 from conftest import rel_l2
 from oracle import agcn_oracle as O
 from oracle import filler, graph_oracle
+from oracle import relu_masks as RM
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +53,31 @@ def fill_module(mod, prefix=""):
 def oracle_sd(mod, prefix="", dtype=torch.float64):
     return {prefix + k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu().clone())
             for k, v in mod.state_dict().items()}
+
+
+def check_gradients_with_flip_accounting(model, x_dev, labels_dev, x64, labels, sd64, ref, tag, strip=""):
+    """The end-to-end gradient is a discontinuous function of the 20 ReLU sign patterns (oracle/relu_masks.py), so it is pinned in
+    two parts: (a) with the ORACLE's ReLU decisions injected into the backward's sign images the difference is arithmetic only:
+    flat gradient <= 1e-4 against the float64 oracle AND every parameter-gradient norm within 2e-4 of the REFERENCE's own
+    (tests/golden, written by the imported reference -- whose float64 decisions are the oracle's); (b) as is, the error is bounded
+    by what the counted flips explain.  Replaces the former 'flat gradient < 3e-3, norms within 1 %' bounds, which only said
+    'somewhere near the flip noise'."""
+    import math
+    names = [n.replace(strip, "") if strip else n for n, _ in model.named_parameters()]
+    oracle = RM.oracle_side(x64, labels, sd64, names)
+    rep = RM.gradient_parity_report(model, x_dev, labels_dev, oracle=oracle, keep_grads=True)
+    print(f"[{tag}] logits {rep['logits_err']:.2e} | ReLU flips {rep['flips']} of {rep['decisions']} | flat-grad rel-L2: as is "
+          f"{rep['err_plain']:.2e}, with the oracle's decisions {rep['err_injected']:.2e}")
+    assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5, rep
+    assert rep["err_injected"] < 1e-4, rep
+    assert rep["err_plain"] <= 1e-4 + 2.0 * math.sqrt(rep["flips"] / (rep["decisions"] / 20)), rep
+    for (n_, p), key in zip(model.named_parameters(), names):
+        want = float(ref[f"{tag}.gl2.{key}"]) if f"{tag}.gl2.{key}" in ref else float(ref[f"{tag}.gl2.{n_}"])
+        if key.endswith(ZERO_GRAD_SUFFIXES) or want < 1e-9:
+            continue
+        assert abs(float(p.grad.norm()) - want) <= 2e-4 * want, (n_, float(p.grad.norm()), want)
+    model.zero_grad(set_to_none=True)
+    return rep
 
 
 ZERO_GRAD_SUFFIXES = ("conv_d.0.bias", "conv_d.1.bias", "conv_d.2.bias", "tcn1.conv.bias", "down.0.bias",
@@ -190,26 +216,6 @@ def test_block_random_shapes_vs_oracle(seed):
           f"worst-param {worst} relu-flips {flips}")
 
 
-def test_fused_spatial_backward_block_matches_default_path():
-    """The opt-in one-kernel spatial backward gives the same block gradients as the default kernel trio."""
-    import dataclasses
-    from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv
-    adj = ntu_adj()
-    x = torch.from_numpy(filler.bellish("x.fsb", (2, 64, 10, 25))).float().to(dev())
-    probe = torch.from_numpy(filler.uniform("probe.fsb", (2, 128, 5, 25), -1, 1)).float().to(dev())
-    grads = []
-    for fused in (False, True):
-        blk = SpatialTemporalConv(64, 128, adj, stride=2)
-        fill_module(blk, "l0.")
-        blk.cfg = dataclasses.replace(blk.cfg, fused_spatial_bwd=fused)
-        blk = blk.to(dev()).train()
-        xg = x.clone().requires_grad_(True)
-        (blk.forward_nchw(xg) * probe).sum().backward()
-        grads.append([xg.grad] + [p.grad for p in blk.parameters()])
-    for a, b in zip(*grads):
-        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5 or float(a.abs().max()) < 1e-6
-
-
 def test_static_adjacency_block_is_stgcn_special_case():
     """ST-GCN block = same kernels with the data-dependent C_k switched off."""
     from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv
@@ -273,23 +279,14 @@ def test_full_model_vs_golden_and_oracle(golden, tag, shape, classes, gname):
     e_train = rel_l2(logits.detach().cpu().numpy(), ref[f"{tag}.train.logits"])
     assert e_train < 1e-4, e_train
     assert abs(float(loss) - float(ref[f"{tag}.train.loss"])) < 1e-4
-    # gradients vs reference checksums / oracle
-    lo, los, grads_o, stats = O.loss_and_grads(x.double(), labels, sd)
-    flat_g = torch.cat([p.grad.detach().cpu().double().flatten() for n_, p in model.named_parameters()])
-    flat_o = torch.cat([grads_o[n_].flatten() for n_, p in model.named_parameters()])
-    e_grad = float((flat_g - flat_o).norm() / flat_o.norm())
-    ref_floor = float(ref[f"{tag}.ref_f32_vs_f64_grad_rel"])
-    print(f"[{tag}] eval-logits {e_eval:.2e} train-logits {e_train:.2e} flat-grad {e_grad:.2e} "
-          f"(reference fp32-vs-fp64 floor on this case: {ref_floor:.2e})")
-    assert e_grad < 3e-3, e_grad
-    for n_, p in model.named_parameters():
-        want_l2 = float(ref[f"{tag}.gl2.{n_}"])
-        if n_.endswith(ZERO_GRAD_SUFFIXES) or want_l2 < 1e-9:
-            continue
-        assert abs(float(p.grad.norm()) - want_l2) <= 1e-2 * want_l2, (n_, float(p.grad.norm()), want_l2)
+    # running statistics of that ONE train step vs the oracle's (checked before any further forward moves them)
+    _, _, _, stats = O.loss_and_grads(x.double(), labels, sd)
     for k, v in stats.updates.items():
         if k.endswith(("running_mean", "running_var")):
             assert rel_l2(model.state_dict()[k].cpu().numpy(), v.numpy()) < 1e-4, k
+    # gradients: flip-accounted against the float64 oracle, per-parameter norms against the reference's own
+    model.zero_grad(set_to_none=True)
+    check_gradients_with_flip_accounting(model, x.float().to(dev()), labels.to(dev()), x.double(), labels, sd, ref, tag)
 
 
 def test_agcn_spelling_and_mmargcn_mode(golden):
@@ -357,25 +354,36 @@ def test_other_baseline_shapes_vs_reference(golden, tag, dataset, shape, classes
     loss.backward()
     assert rel_l2(logits.detach().cpu().numpy(), ref[f"{tag}.train.logits"]) < 1e-4
     assert abs(float(loss.detach()) - float(ref[f"{tag}.train.loss"])) < 1e-4
-    for n_, p in model.named_parameters():
-        want = float(ref[f"{tag}.gl2.{n_}"])
-        if n_.endswith(ZERO_GRAD_SUFFIXES) or want < 1e-9:
-            continue
-        assert abs(float(p.grad.norm()) - want) <= 1e-2 * want, (n_, float(p.grad.norm()), want)
+    model.zero_grad(set_to_none=True)
+    sd = {(k.replace(strip, "") if strip else k): (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu().clone())
+          for k, v in model.state_dict().items()}
+    x64 = torch.from_numpy(filler.skeleton_input(f"x.{tag}", shape, empty_second_body=True)).double()
+    check_gradients_with_flip_accounting(model, x, labels, x64, labels.cpu(), sd, ref, tag, strip=strip)
 
 
-def test_size_independent_properties_at_headline_shape():
-    """BASELINE configs[1] shape (T=300, V=25, M=2) at a batch the oracle cannot afford: properties that must hold
-    at any size — clip independence in eval mode (a clip's logits do not depend on its batch mates), permutation
-    equivariance, determinism, and zero second body == same logits as feeding that body's slot with zeros."""
+@pytest.mark.parametrize("joints", [25, 27, 22])
+def test_size_independent_properties_at_headline_shape(joints):
+    """BASELINE configs[1] shape (T=300, V=25, M=2) -- and configs 3 / 4 at their full T = 300 (V = 25 + 2 IMU joints on the NTU
+    graph, V = 18 + 4 on the MMAct graph: the shapes whose 9x1 halo image is largest; the V = 27 LDS-tile cliff of round 1 was found
+    by the benchmark, not by a test) -- at a batch the oracle cannot afford: properties that must hold at any size -- clip
+    independence in eval mode (a clip's logits do not depend on its batch mates), permutation equivariance, determinism -- and a
+    finite train step."""
+    from fusion_gcn_amd.datasets.mmact import constants as mmact
     from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
     from fusion_gcn_amd.models.mmargcn.agcn import Model
     from fusion_gcn_amd.util import Graph
+    from fusion_gcn_amd.util.dynamic_import import import_model
     torch.manual_seed(1)
-    model = Model((2, 300, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=20))
-    fill_module(model)
+    if joints == 25:
+        model, classes = Model((2, 300, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=20)), 60
+        fill_module(model)
+    else:
+        c, n_imu, classes = (ntu, 2, 60) if joints == 27 else (mmact, 4, 35)
+        model = import_model("mmargcn")({"skeleton": (2, 300, joints, 3)}, classes, Graph(c.skeleton_edges, center_joint=c.center_joint),
+                                        mode="skeleton_imu_spatial_fusion", num_imu_joints=n_imu, imu_enhanced_mode="append_center")
+        filler.fill_state_dict(model.state_dict(), rename=lambda k: k.replace("_model.agcn.", ""))
     model = model.to(dev()).eval()
-    x = torch.randn(8, 2, 300, 25, 3, device=dev())
+    x = torch.randn(8, 2, 300, joints, 3, device=dev())
     with torch.no_grad():
         full = model(x)
         again = model(x)
@@ -387,10 +395,15 @@ def test_size_independent_properties_at_headline_shape():
     assert torch.isfinite(full).all()
     # train step at this shape: finite loss / grads, batch statistics make the loss batch-dependent but bounded
     model.train()
-    loss = torch.nn.functional.cross_entropy(model(x), torch.arange(8, device=dev()) % 60)
+    loss = torch.nn.functional.cross_entropy(model(x), torch.arange(8, device=dev()) % classes)
     loss.backward()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    # and a second train step from the same state gives the same gradients bit for bit (fixed-order sums everywhere)
+    first = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    torch.nn.functional.cross_entropy(model(x), torch.arange(8, device=dev()) % classes).backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(first, model.parameters()))
 
 
 @pytest.mark.gpu

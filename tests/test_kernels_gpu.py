@@ -584,64 +584,6 @@ def test_batchnorm_epilogue_forward_backward(C, res_mode):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,T,V,cin,cout,batched", [
-    (2, 10, 25, 64, 64, True), (3, 9, 25, 4, 64, True), (2, 13, 18, 64, 128, True), (2, 6, 22, 128, 128, True),
-    (2, 5, 27, 128, 256, True), (1, 7, 25, 256, 256, True), (2, 10, 20, 64, 64, False)])
-def test_fused_spatial_forward(B, T, V, cin, cout, batched):
-    """y = sum_k conv_d[k](x . A^_k): fused kernel vs the einsum composition and vs the unfused kernel pair."""
-    from fusion_gcn_amd import ops
-    from fusion_gcn_amd.block import spec_agg
-    x = rnd(B, T, V, cin, seed=50)
-    if cin == 4:
-        x[..., 3] = 0
-    a = rnd(B if batched else 1, 3, V, V, seed=51, scale=0.3)
-    wd = rnd(3 * cin, cout, seed=52, scale=(3 * cin) ** -0.5)
-    bias = rnd(cout, seed=53)
-    agg = torch.einsum("btvc,bkvw->btwkc", x, a.expand(B, 3, V, V)).reshape(B, T, V, 3 * cin)
-    want = agg @ wd + bias
-    y, part = ops.spatial_fwd(to_gpu(x), to_gpu(a), ops.pack_spatial(to_gpu(wd), cin), to_gpu(bias), Cin=cin, Cout=cout,
-                              stats=True)
-    assert rel_l2(y.cpu().numpy(), want.numpy()) < FWD_TOL
-    tot = part.double().sum(0).cpu()
-    flat = want.reshape(-1, cout)
-    assert rel_l2(tot[0].numpy(), flat.sum(0).numpy()) < RED_TOL
-    assert rel_l2(tot[1].numpy(), (flat ** 2).sum(0).numpy()) < RED_TOL
-    # unfused pair gives the same tensor (different summation order)
-    agg_g = torch.empty(B, T, V, 3 * cin, device=dev())
-    ops.joint_mix(to_gpu(x), agg_g, to_gpu(a), spec_agg(cin), in_channels=cin, out_channels=3 * cin)
-    y2 = torch.empty(B, T, V, cout, device=dev())
-    ops.rows_gemm(agg_g, to_gpu(wd).unsqueeze(0), y2, K=3 * cin, N=cout, bias=to_gpu(bias))
-    assert rel_l2(y2.cpu().numpy(), y.cpu().numpy()) < FWD_TOL
-
-
-@pytest.mark.parametrize("B,T,V,cin,cout,batched", [
-    (2, 10, 25, 64, 64, True), (3, 9, 25, 4, 64, True), (2, 13, 18, 64, 128, True), (2, 6, 22, 128, 128, True),
-    (2, 5, 27, 128, 256, True), (1, 7, 25, 256, 256, True), (2, 10, 20, 64, 64, False)])
-def test_fused_spatial_backward(B, T, V, cin, cout, batched):
-    """dx (+)= sum_k (dy . Wd_k) . A^_k^T and dA^_k = x^T . (dy . Wd_k): fused kernel vs autograd of the einsum forward."""
-    from fusion_gcn_amd import ops
-    x = rnd(B, T, V, cin, seed=90)
-    if cin == 4:
-        x[..., 3] = 0
-    a = rnd(B if batched else 1, 3, V, V, seed=91, scale=0.3)
-    wd = rnd(3, cout, cin, seed=92, scale=(3 * cin) ** -0.5)          # Wd_k[o][c]
-    dy = rnd(B, T, V, cout, seed=93)
-    xr, ar = x.clone().requires_grad_(True), a.expand(B, 3, V, V).clone().requires_grad_(True)
-    agg = torch.einsum("btvc,bkvw->btwkc", xr, ar)                     # (B,T,W,3,cin)
-    y = torch.einsum("btwkc,koc->btwo", agg, wd)
-    dx_want, da_want = torch.autograd.grad((y * dy).sum(), [xr, ar])
-    base = rnd(B, T, V, cin, seed=94)
-    dx = to_gpu(base)
-    wdt4 = ops.pack_k4(to_gpu(wd))
-    part = ops.spatial_bwd(to_gpu(dy), to_gpu(x), to_gpu(a), wdt4, dx, accumulate=True)
-    assert rel_l2(dx.cpu().numpy(), (base + dx_want).numpy()) < FWD_TOL
-    got_da = part.double().sum(1)[..., :V, :V].cpu()
-    assert rel_l2(got_da.numpy(), da_want.numpy()) < RED_TOL
-    assert float(part.double().sum(1)[..., V:, :].abs().max()) == 0.0 if V < 32 else True
-    ops.spatial_bwd(to_gpu(dy), to_gpu(x), to_gpu(a), wdt4, dx, accumulate=False)
-    assert rel_l2(dx.cpu().numpy(), dx_want.numpy()) < FWD_TOL
-
-
 def test_kernels_are_deterministic():
     """Same inputs, same bits (no atomics anywhere in the path)."""
     from fusion_gcn_amd import ops

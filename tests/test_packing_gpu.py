@@ -51,7 +51,6 @@ def _long_way(P, cfg, mode):
     R["d"] = torch.cat([w.t() for w in d_list], 0).contiguous()
     R["d4"] = ops.pack_spatial(R["d"], cx)
     R["d_t"] = torch.cat(d_list, 1).contiguous().unsqueeze(0)
-    R["dt4"] = ops.pack_k4(torch.stack(d_list, 0).contiguous())
     R["d_b"] = P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]
     if cfg.has_down:
         down = _pad_last(P["gcn1.down.0.weight"].view(cout, cin), cx)

@@ -76,10 +76,9 @@ def bench_tconv(B, reps):
     register budget (2 or 3 workgroups per CU)."""
     lib = _lib.load()
     x3 = ops.get_math_mode() == "bf16x3"
-    for three in (0, 1):
-        lib.fgcn_set_tuning(7, 2 * three if x3 else 0)
+    for three in ((0,) if x3 else (0, 1)):
         lib.fgcn_set_tuning(4, three)
-        print(f"-- conv_halo, " + (f"MFMA shape {('16x16x32', '32x32x16')[three]}" if x3 else f"workgroups per CU hint = {3 - three}"))
+        print("-- conv_halo" + ("" if x3 else f", workgroups per CU hint = {3 - three}"))
         for T, c, s in ((300, 64, 1), (150, 128, 1), (75, 256, 1), (300, 128, 2), (150, 256, 2)):
             Tp = (T - 1) // s + 1
             wt = rnd(9, c, c) * (9 * c) ** -0.5
@@ -98,7 +97,6 @@ def bench_tconv(B, reps):
             ms = timeit(lambda: block.temporal_dgrad(du, dg, W, 9, s), reps)
             report(f"tconv_halo dgrad T{T} s{s} C{c}", ms, fl, 4.0 * B * V * c * (T + Tp))
     lib.fgcn_set_tuning(4, 0)
-    lib.fgcn_set_tuning(7, 0)
 
 
 def bench_wgrad(B, reps):
@@ -160,16 +158,6 @@ def bench_spatial_wgrad(B, reps):
         report(f"mix_agg + rows_wgrad     T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (8 * cin + cout))
 
 
-def bench_spatial_bwd(B, reps):
-    for T, cin, cout in ((300, 4, 64), (300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
-        x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
-        wdt4 = ops.pack_k4(rnd(3, cout, cin) * (3 * cin) ** -0.5)
-        dx = torch.zeros(B, T, V, cin, device=DEV)
-        ms = timeit(lambda: ops.spatial_bwd(dy, x, a, wdt4, dx, accumulate=True), reps)
-        rows = B * T * V
-        report(f"spatial_bwd T{T} {cin}->{cout}", ms, rows * (12.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (3 * cin + cout))
-
-
 def bench_joint(B, reps):
     for order in ((1,), (2, 1)):
         block.MIX_VW_ORDER = order
@@ -225,7 +213,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,joint,elem")
+    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_wgrad,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -236,7 +224,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_bwd=bench_spatial_bwd, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
