@@ -193,6 +193,7 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
+FUSE_BN_INTO_TCONV = True   # identity blocks: BatchNorm + shortcut + ReLU of the graph convolution inside the temporal conv's image fill
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
@@ -264,12 +265,15 @@ def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) 
 
 
 def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], bias: torch.Tensor, kt: int, s: int,
-                 stats: bool):
-    """u = Conv(kt x 1, stride s, pad (kt-1)//2)(g) + bias, with BatchNorm partial sums of u when ``stats``."""
+                 stats: bool, fuse_in=None):
+    """u = Conv(kt x 1, stride s, pad (kt-1)//2)(g) + bias, with BatchNorm partial sums of u when ``stats``.
+    ``fuse_in = (vec, shortcut, g_out, g_sign)`` (stride 1, split-bf16 kernel): the first argument is the BatchNorm input y and
+    g = relu(BatchNorm(y) + shortcut) is formed inside the conv (ops.tconv_halo)."""
     pad = (kt - 1) // 2
     T, Tp = g.shape[1], u.shape[1]
     if s == 1 and "t4" in W:
-        return ops.tconv_halo(g, W["t4"], u, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=stats)
+        return ops.tconv_halo(g, W["t4"], u, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=stats, fuse_in=fuse_in)
+    assert fuse_in is None
     if s == 2 and "t4_e" in W and pad % 2 == 0 and T > 1:
         # output frame to meets tap j = 2j' + par at input frame 2 (to + j' - pad/2) + par: one pass over the even input
         # frames (taps 0, 2, ..), one accumulating pass over the odd ones (which also takes the BatchNorm sums)
@@ -366,13 +370,22 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True)
     else:
         d, vec_d = None, None
+    # identity blocks on the split-bf16 kernels: G = relu(BatchNorm(y) + x) is formed INSIDE the temporal conv while it stages its
+    # image (north-star kernel 2: "temporal 9x1 conv + BN + ReLU"), G and its sign image come out as by-products -- no bn_act pass
+    kt = P["tcn1.conv.weight"].shape[2]
+    fuse_g = (FUSE_BN_INTO_TCONV and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
+              and cx == cout and V <= 32 and (B * T * V * cout) % 8 == 0)
+    if fuse_g:
+        g = new(B, T, V, cout)
+        g_sign = torch.empty((B * T * V * cout) // 8, device=dev, dtype=torch.uint8)
+    elif not cfg.has_down:
         g, g_sign = ops.bn_act(y, vec_y, x, None, relu=True, sign_mask=True)
     S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign)   # *_sign: 1 bit per element, the backward's ReLU gate
 
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
-    kt = P["tcn1.conv.weight"].shape[2]
     u = new(B, Tp, V, cout)
-    part = temporal_fwd(g, u, W, P["tcn1.conv.bias"], kt, s, stats=train)
+    part = temporal_fwd(y if fuse_g else g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
+                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     if cfg.residual == "none":

@@ -45,8 +45,19 @@ struct HaloP {
     const float* bn_a;
     const unsigned char* bn_mask;
     const float* bn_vec;
+    // Input stage fused into the image fill (conv_halo_x3k32_kernel<.., FIN = true>; the 9x1 forward of an identity block): `in` is
+    // the BatchNorm INPUT y and the image is G = relu(y * scale + shift + fin_res) (agcn.py:113-115), formed as the rows are
+    // staged; the workgroups of the first column tile also store their own (non-halo) rows of G to fin_out and its sign image
+    // (fgcn_bn_act's layout) to fin_mask -- what a stand-alone fgcn_bn_act pass in front of this kernel writes.
+    const float* fin_vec;               // float[4][K] of fgcn_bn_finalize (scale at [2K, 3K), shift at [3K, 4K))
+    const float* fin_res;               // the shortcut operand, laid out like `in`
+    float* fin_out;                     // G, laid out like `in`
+    unsigned char* fin_mask;            // rows * K / 8 bytes
 };
 
+#ifndef FGCN_HALO_PF64
+#define FGCN_HALO_PF64 1
+#endif
 constexpr int HAS = 36;                 // LDS row stride of the halo image (32 channels + 4 pad: conflict-free b128)
 constexpr int HALO_MAX_STAGE = 13;      // ceil((128 + 8*32) / 32) + 1
 constexpr int XSB = 80;                 // FGCN_MATH_BF16X3: LDS row stride in bytes of one bf16 part (32 channels + 8 pad)
@@ -299,8 +310,9 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // MFMA per product group: a sixth of the matrix work, a third of the LDS image and of the weight stream).
 // MTW = 16-row tiles per wave: 4 (128 output rows per workgroup) or 3 (96 rows: for more than 25 joints the 128-row tile's halo
 // image -- 128 + 8 V rows x 3 planes -- no longer fits twice into the 160 KB of LDS; the shorter tile keeps two workgroups per CU).
-template <int NT, int KC, int NP, int MTW = 4>
-__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+template <int NT, int KC, int NP, int MTW = 4, bool FIN = false>
+__global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
     static_assert(MTW == 3 || MTW == 4, "wave tile: 48 or 64 rows");
     constexpr int BMR = 32 * MTW;                    // output rows per workgroup
     static_assert(NP == 1 || NP == 3, "one or three bf16 parts per operand");
@@ -316,8 +328,11 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
     constexpr int TPR = KC / 4;
     constexpr int RPP = 256 / TPR;
     constexpr int SPC = KC / 32;                     // steps per tap and chunk
-    constexpr bool PF = KC == 64;
-    constexpr int NST = PF ? 8 : HALO_MAX_STAGE;
+    // PF: the NEXT chunk's rows are requested before the MFMAs of the current one and parked in registers.  Always for the 1x1 form
+    // (KC = 64); for the 9-tap form where the registers allow it: 64 output columns (NT = 1: half the accumulators) -- a 64-channel
+    // tile is only two chunks, so the second chunk's exposed global-load latency was a visible share of it
+    constexpr bool PF = KC == 64 || (NT == 1 && NP == 3 && !FIN && FGCN_HALO_PF64);
+    constexpr int NST = KC == 64 ? 8 : HALO_MAX_STAGE;
     constexpr int NU = 2 * NT;                       // 16-column tiles (units) of a wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float Ah[];
@@ -416,16 +431,59 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
         }
     };
 
-    f32x4 stage[NST];
-    auto fetch = [&](int kc) {
+    f32x4 stage[NST], stage2[FIN ? NST : 1];   // (FIN: only HALF of each live at a time)
+    // (the descriptors of the fused stage's three tensors are built where they are used, from the kernel arguments: kept live
+    // across the MFMA loop they pushed the scalar registers over their limit and the spills landed in vector registers)
+    // (the fused input stage fills the image in two halves -- stages [0, HALF) then [HALF, NST) -- so that the two staged tensors
+    // take 2 x HALF instead of 2 x NST registers: all at once spilled)
+    constexpr int HALF = FIN ? (NST + 1) / 2 : NST;
+    auto fetch = [&](int kc, int lo = 0, int hi = 64) {
 #pragma unroll
         for (int i = 0; i < NST; ++i)
-            if (i < nstage) stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+            if (i >= lo && i < hi && i < nstage) {
+                stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
+                if constexpr (FIN)
+                    stage2[i] = buf_load4(__builtin_amdgcn_make_buffer_rsrc((void*)p.fin_res, 0, p.in_bytes, 0x00020000), src_off[i],
+                                          (unsigned)kc * 4);
+            }
     };
-    auto deposit = [&]() {                           // split the staged rows into the three bf16 planes
+    auto deposit = [&](int kc, int lo = 0, int hi = 64) {   // split the staged rows into the three bf16 planes
+        f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
+        const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc((void*)(FIN ? (void*)p.fin_out : (void*)p.out), 0,
+                                                                             FIN ? p.in_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rgm = __builtin_amdgcn_make_buffer_rsrc((void*)(FIN ? (void*)p.fin_mask : (void*)p.out), 0,
+                                                                             FIN ? p.in_bytes >> 5 : 0u, 0x00020000);
+        const int own0 = -p.dmin * V;                // image row of the tile's first own (non-halo) row
+        if constexpr (FIN) {
+            fsc = *reinterpret_cast<const f32x4*>(p.fin_vec + 2 * p.K + kc + (tid % TPR) * 4);
+            fsh = *reinterpret_cast<const f32x4*>(p.fin_vec + 3 * p.K + kc + (tid % TPR) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
+            if (i < lo || i >= hi) continue;
             const int r = tid / TPR + RPP * i;
+            if constexpr (FIN) {
+                if (i < nstage) {                    // (wave-uniform; the shuffles below need whole 8-lane row groups)
+                    // G = relu(BatchNorm(y) + shortcut) of this row chunk; rows outside the tensor / frame view stay exact zeros
+                    const bool live = src_off[i] != OOB;
+                    f32x4 v = stage[i] * fsc + fsh + stage2[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = live ? fmaxf(v[e], 0.f) : 0.f;
+                    stage[i] = v;
+                    // the first column tile's workgroups keep their own rows of G and its sign image (one dword = this row's 32
+                    // channels of the chunk: the eight 4-bit groups of the row's eight lanes, gathered with three shuffles)
+                    const bool mine = live && bn == 0 && r >= own0 && r < own0 + BMR;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rgo, mine ? src_off[i] : OOB,
+                                                           (unsigned)kc * 4, 0);
+                    unsigned w = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u))
+                                 << (4 * (lane & 7));
+                    w |= (unsigned)__shfl_xor((int)w, 1);
+                    w |= (unsigned)__shfl_xor((int)w, 2);
+                    w |= (unsigned)__shfl_xor((int)w, 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(w, rgm, (mine && (lane & 7) == 0) ? (src_off[i] + (unsigned)kc * 4) >> 5 : OOB,
+                                                          0, 0);
+                }
+            }
             if (i < nstage && r < p.halo_rows) {
                 u32x2 ph, pm, pl;
                 split3_x4(stage[i], ph, pm, pl);
@@ -444,8 +502,15 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void conv_halo_x3k32_kernel(H
     if constexpr (PF) fetch(0);
     for (int kc = 0; kc < p.K; kc += KC) {
         __syncthreads();                             // previous chunk's image reads are done
-        if constexpr (!PF) fetch(kc);
-        deposit();
+        if constexpr (FIN) {
+            fetch(kc, 0, HALF);
+            deposit(kc, 0, HALF);
+            fetch(kc, HALF, NST);
+            deposit(kc, HALF, NST);
+        } else {
+            if constexpr (!PF) fetch(kc);
+            deposit(kc);
+        }
         __syncthreads();
         if constexpr (PF) {
             if (kc + KC < p.K) fetch(kc + KC);       // lands during the MFMAs below
@@ -599,8 +664,15 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                                int T_in_full, int in_s, int in_o, int Th_in,
                                int T_out_full, int out_s, int out_o,
                                int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
-                               const float* bn_vec, void* stream) {
+                               const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
+                               unsigned char* fin_mask, void* stream) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
+    const bool fin = fin_vec || fin_res || fin_out || fin_mask;
+    FGCN_REQUIRE(!fin || (fin_vec && fin_res && fin_out && fin_mask && fgcn_tconv_halo_bn_sums() && !bn_a && !accumulate && taps > 1 &&
+                          ld_in == K && in_s == 1 && in_o == 0 && Th_in == T_in_full && Th_in == Th && aligned16(fin_res) &&
+                          aligned16(fin_out) && aligned16(fin_vec) && ((uintptr_t)fin_mask & 3u) == 0),
+                 FGCN_E_BADARG, "tconv_halo: the fused input stage (BatchNorm + shortcut + ReLU while the image is staged) needs the "
+                 "split-bf16 kernel, all four of (vec, shortcut, G, sign image), a plain contiguous input view (ld_in == K) and taps > 1");
     FGCN_REQUIRE(!bn_a || (bn_mask && bn_vec && stat_partials && fgcn_tconv_halo_bn_sums() && ld_out == N && N % 8 == 0 &&
                            out_s == 1 && out_o == 0 && T_out_full == Th),
                  FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums need the split-bf16 kernel, a contiguous plain output (ld_out == N, "
@@ -635,6 +707,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.T_out_full = T_out_full; p.out_s = out_s; p.out_o = out_o; p.Th_out = Th;
     p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
     p.bn_a = bn_a; p.bn_mask = bn_mask; p.bn_vec = bn_vec;
+    p.fin_vec = fin_vec; p.fin_res = fin_res; p.fin_out = fin_out; p.fin_mask = fin_mask;
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
     const int dmax = d0 < d1 ? d1 : d0;
@@ -678,6 +751,11 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
             FGCN_K32_ATTR(1, 32); FGCN_K32_ATTR(2, 32); FGCN_K32_ATTR(1, 64); FGCN_K32_ATTR(2, 64);
 #undef FGCN_K32_ATTR
+#define FGCN_K32_FIN_ATTR(NT_, NP_)                                                                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, 32, NP_, 4, true>),   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
+            FGCN_K32_FIN_ATTR(1, 1); FGCN_K32_FIN_ATTR(1, 3); FGCN_K32_FIN_ATTR(2, 1); FGCN_K32_FIN_ATTR(2, 3);
+#undef FGCN_K32_FIN_ATTR
             opt_in = true;
         }
         const bool one = mm == FGCN_MATH_BF16;
@@ -700,7 +778,16 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 4>), grid, dim3(256), lds_k, s, p);     \
         }                                                                                                        \
     } while (0)
-        if (pw) {
+        if (fin) {
+            FGCN_REQUIRE(bmr == 128 && !pw, FGCN_E_BADARG, "tconv_halo: the fused input stage runs on the 128-row tap tile (V <= 32)");
+            if (N <= 64) {
+                if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32, 1, 4, true>), grid, dim3(256), lds_k, s, p);
+                else hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32, 3, 4, true>), grid, dim3(256), lds_k, s, p);
+            } else {
+                if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32, 1, 4, true>), grid, dim3(256), lds_k, s, p);
+                else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32, 3, 4, true>), grid, dim3(256), lds_k, s, p);
+            }
+        } else if (pw) {
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
             else FGCN_K32_LAUNCH(2, 64);
         } else {

@@ -152,12 +152,16 @@ def tconv_halo_bn_sums() -> bool:
 
 def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
                in_view=None, out_view=(1, 0), bias: Optional[torch.Tensor] = None, stats: bool = False,
-               accumulate: bool = False, bn_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> Optional[torch.Tensor]:
+               accumulate: bool = False, bn_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+               fuse_in: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> Optional[torch.Tensor]:
     """Halo-tile temporal conv over virtual frames [0, Th): input frame th*in_s + in_o (th < Th_in), output frame
     th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked.
     ``bn_bwd = (a, sign image, vec)``: the call is the data gradient of a conv whose input was relu(BatchNorm(a) + shortcut); the
     returned partials (tiles, 2, N) then hold the BatchNorm-backward sums (sum dp, sum dp * a_hat) of what it writes
-    (``bn_act_bwd(..., partials=)`` takes them instead of running its own reduction pass)."""
+    (``bn_act_bwd(..., partials=)`` takes them instead of running its own reduction pass).
+    ``fuse_in = (vec, shortcut, g, g_sign)``: ``inp`` is the INPUT of a BatchNorm and the conv runs on
+    g = relu(inp * scale + shift + shortcut), formed while the image is staged; g and its sign image (``bn_act``'s layout) are
+    written as by-products -- the block's ``bn_act`` pass in front of the conv folded into it (split-bf16 kernel, taps > 1)."""
     ensure_device()
     _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out")
     B, T_in, V, ld_in = inp.shape
@@ -185,8 +189,17 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
         bn = (_p(a), mask.data_ptr(), _p(vec))
     if stats or bn_bwd is not None:
         part = torch.empty((lib.fgcn_tconv_halo_tiles(B, Th, Th_in, V), 2, N), device=inp.device, dtype=torch.float32)
+    fin = (None, None, None, None)
+    if fuse_in is not None:
+        vec, res, g, g_sign = fuse_in
+        _chk(vec, "tconv_halo.fin_vec"), _chk(res, "tconv_halo.fin_res"), _chk(g, "tconv_halo.fin_out")
+        if tuple(res.shape) != tuple(inp.shape) or tuple(g.shape) != tuple(inp.shape) or vec.shape != (4, K) or ld_in != K or \
+                g_sign.dtype != torch.uint8 or g_sign.numel() * 8 != inp.numel() or not g_sign.is_contiguous():
+            raise _lib.FgcnError("tconv_halo: fuse_in needs the (4, K) BatchNorm vector, a shortcut and an output like the input "
+                                 "(contiguous, K channels) and the uint8 sign image of numel / 8 bytes")
+        fin = (_p(vec), _p(res), _p(g), g_sign.data_ptr())
     check(lib.fgcn_tconv_halo(_p(inp), _p(out), _p(w4), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
-                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, _stream()),
+                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, *fin, _stream()),
           "fgcn_tconv_halo")
     return part
 

@@ -117,12 +117,20 @@ int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
  * fgcn_bn_finalize's vector (mean at [0, N), rstd at [N, 2N)): what fgcn_bn_act_bwd_reduce computes in a pass of its own over dG
  * and a (two activation reads and two launches less per identity block). */
 int fgcn_tconv_halo_bn_sums(void);
+/* fin_vec / fin_res / fin_out / fin_mask (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1; taps > 1, a plain contiguous
+ * input view with ld_in == K, V <= 32): the INPUT STAGE of the temporal conv fused into its image fill -- the north star's "temporal
+ * 9x1 conv + BN + ReLU as one kernel", consumer side.  `in` is then y, the input of the graph convolution's BatchNorm, and the conv
+ * runs on G = relu(y * scale + shift + fin_res) (agcn.py:113-115; fin_vec = fgcn_bn_finalize's float[4][K], fin_res = the identity
+ * shortcut x, laid out like `in`), formed as the rows are staged; G (fin_out, like `in`) and its sign image (fin_mask, fgcn_bn_act's
+ * layout, rows*K/8 bytes) are written once as by-products (the backward's weight gradient and ReLU gate read them): what an
+ * fgcn_bn_act(res_mode = 1, relu = 1) pass in front of this call computes, without that pass. */
 int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
                     int B, int Th, int V, int K, int N, int ld_in, int ld_out,
                     int T_in_full, int in_s, int in_o, int Th_in,
                     int T_out_full, int out_s, int out_o,
                     int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
-                    const float* bn_vec, void* stream);
+                    const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out, unsigned char* fin_mask,
+                    void* stream);
 
 /* partial[s][j][k][n] = sum over the s-th slice of rows m=(n,tg,v) of a[(n,ti(tg,j),v), k] * g[m, n]
  *   (weight gradient of the same convolutions; autograd backward of agcn.py:41-42,71-73,77).

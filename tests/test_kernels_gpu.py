@@ -190,6 +190,42 @@ def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
     assert rel_l2(dg.cpu().numpy(), dx_want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 21, 25, 128), (2, 9, 27, 256), (1, 50, 22, 64), (5, 3, 18, 128), (2, 40, 32, 64)])
+def test_halo_temporal_conv_with_the_input_stage_fused(B, T, V, C):
+    """North-star kernel 2 as the north star states it: G = relu(BatchNorm(y) + x) (agcn.py:113-115) formed INSIDE the 9x1 temporal
+    conv while it stages its image (`fuse_in`), against the two-pass form (bn_act, then the conv on G): the conv output and its
+    BatchNorm partial sums, G and the sign image written as by-products -- all bit for bit, they are the same arithmetic -- plus
+    the conv output against the float64 formula.  Tiles straddle samples; T < the 8-frame halo is included."""
+    from fusion_gcn_amd import ops
+    if not ops.tconv_halo_bn_sums():
+        pytest.skip("the fused input stage is built for the split-bf16 halo kernel")
+    kt = 9
+    wt = rnd(kt, C, C, seed=180, scale=(kt * C) ** -0.5)
+    bias = rnd(C, seed=181)
+    y, x = rnd(B, T, V, C, seed=182), rnd(B, T, V, C, seed=183)
+    vec = torch.stack([rnd(C, seed=184), rnd(C, seed=185).abs() + 0.5, rnd(C, seed=186), rnd(C, seed=187) * 0.3])   # mean, rstd, scale, shift
+    yg, xg, vg = to_gpu(y), to_gpu(x), to_gpu(vec)
+    g64 = torch.relu(y.double() * vec[2].double() + vec[3].double() + x.double())
+    want = ref_rows_conv(g64, wt, ops.conv_tmap(kt, 1), T, bias)
+
+    def both_forms(tol):
+        w4 = ops.pack_conv(to_gpu(wt))                   # the streamed form of the CURRENT math mode
+        g_ref, sign_ref = ops.bn_act(yg, vg, xg, None, relu=True, sign_mask=True)
+        u_ref = torch.empty(B, T, V, C, device=dev())
+        part_ref = ops.tconv_halo(g_ref, w4, u_ref, Th=T, taps=kt, tb=1, tc=-4, bias=to_gpu(bias), stats=True)
+        g = torch.full((B, T, V, C), 7.0, device=dev())
+        sign = torch.full((B * T * V * C // 8,), 0xAA, device=dev(), dtype=torch.uint8)
+        u = torch.full((B, T, V, C), 3.0, device=dev())
+        part = ops.tconv_halo(yg, w4, u, Th=T, taps=kt, tb=1, tc=-4, bias=to_gpu(bias), stats=True, fuse_in=(vg, xg, g, sign))
+        assert torch.equal(g, g_ref) and torch.equal(sign, sign_ref)
+        assert torch.equal(u, u_ref) and torch.equal(part, part_ref)
+        assert rel_l2(u.cpu().numpy(), want.numpy()) < tol
+
+    both_forms(FWD_TOL)
+    with ops.math_mode("bf16"):                          # BASELINE config 5: the same kernel with one bf16 part per operand
+        both_forms(2e-2)
+
+
 @pytest.mark.parametrize("B,T,V,K,N,kt,s", [(2, 40, 25, 64, 64, 9, 1), (2, 41, 25, 64, 128, 9, 2),
                                             (4, 64, 25, 128, 96, 1, 1), (2, 30, 22, 4, 64, 1, 1),
                                             (1, 20, 18, 192, 64, 1, 1), (2, 33, 25, 64, 128, 1, 2)])
