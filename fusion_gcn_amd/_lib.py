@@ -123,6 +123,9 @@ SIGNATURES = {
     "fgcn_tmaxpool3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_tmaxpool3_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_unfold_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_pw_gemm_available": (_I, []),
+    "fgcn_pw_gemm_tiles": (_I, [_LL]),
+    "fgcn_pw_gemm": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_data_bn_tiles": (_I, [_I, _I]),
     "fgcn_data_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fgcn_data_bn_apply": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

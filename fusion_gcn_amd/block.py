@@ -23,6 +23,7 @@ Kernel schedule of one block, train mode (B = N*M samples):
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -160,18 +161,28 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
         F["res"], F["res_t"] = Form("plain", 1, cx, cout, fwd), Form("plain", 1, cout, cx, bwd)
     if x3:                                           # split forms of the 1x1 weights pw_gemm may route to the halo kernel
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
-            if key in F and F[key].K % 64 == 0:
+            if key in F and F[key].K % 32 == 0:
                 F[key + "_s3"] = Form("split3", 1, F[key].K, F[key].N, F[key].segs)
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
+# 1x1 convolutions with a split form go to the persistent split-bf16 row GEMM (ops.pw_gemm, fgcn_pw.hip) from this contraction depth
+# on; below it (and in math mode f32) the exact-f32 row GEMM runs.  Measured on MI355X (tools/kbench.py pw, B = 128,
+# profiles/r03_kbench_pw.log): at K = 64 / 96 the f32 row GEMM is 8-18 % faster (both latency-bound at 3.3-4.0 TB/s), from K = 128 on
+# pw_gemm wins by 2-29 % over it and by 3-22 % over the one-tap halo kernel round 2 used from K = 192; same-box step A/B
+# (profiles/r03_ab_pw_gemm.txt): threshold 128 -> 62.53 / 62.58 ms against 62.82 / 63.10 with round 2's routing, 63.32 with 64
+PW_X3_MIN_K = int(os.environ.get("FGCN_PW_MIN_K", "128"))
+
+
 def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Tensor, *, K: int, N: int,
             bias: Optional[torch.Tensor] = None, stats: bool = False, accumulate: bool = False):
-    """1x1 convolution over all rows: the row GEMM, or -- in math mode bf16x3, where the packed set holds the split form
-    of the weight and the contraction is deep enough to pay for it (measured: K >= 192, or K >= 128 into >= 384 columns:
-    0.86 -> 0.73 ms at 256 -> 768) -- the one-tap split-bf16 halo kernel."""
+    """1x1 convolution over all rows: in the split-bf16 math modes (the packed set then holds the split form of the weight) the
+    persistent split-bf16 row GEMM; the exact-f32 row GEMM otherwise."""
     w3 = W.get(key + "_s3")
-    if w3 is not None and K % 64 == 0 and x.shape[3] == K and (K >= 192 or (K >= 128 and N >= 384)):
+    if w3 is not None and K % 32 == 0 and x.shape[3] == K and K >= PW_X3_MIN_K:
+        return ops.pw_gemm(x, w3, out, bias=bias, stats=stats, accumulate=accumulate)
+    if PW_X3_MIN_K > 4096 and w3 is not None and K % 64 == 0 and x.shape[3] == K and (K >= 192 or (K >= 128 and N >= 384)):
+        # (A/B control, FGCN_PW_MIN_K=100000: round 2's routing -- the one-tap halo kernel from K = 192 on, the f32 row GEMM below)
         return ops.tconv_halo(x, w3, out, Th=x.shape[1], taps=1, tb=1, tc=0, bias=bias, stats=stats, accumulate=accumulate)
     return ops.rows_gemm(x, W[key], out, K=K, N=N, bias=bias, stats=stats, accumulate=accumulate)
 
@@ -193,7 +204,14 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
-FUSE_BN_INTO_TCONV = True   # identity blocks: BatchNorm + shortcut + ReLU of the graph convolution inside the temporal conv's image fill
+# Identity blocks: BatchNorm + shortcut + ReLU of the graph convolution applied INSIDE the temporal conv while it stages its image
+# (ops.tconv_halo(fuse_in=...): the north star's "temporal 9x1 conv + BN + ReLU" kernel, consumer side; G and its sign image come
+# out as by-products and the bn_act pass disappears).  Built, bit-identical to the two-pass form (tests/test_kernels_gpu.py) and
+# MEASURED SLOWER on MI355X: same-box A/B of the step (two pairs) 63.10 / 63.16 -> 64.68 / 64.96 ms at 64 clips, 10.44 / 10.46 ->
+# 10.68 / 10.74 ms at 8 -- the conv's staging phase (two tensors per row, in two halves to fit the registers: 16-52 spilled
+# VGPRs at 64 / 128 output columns otherwise) stops hiding under the other workgroup's MFMAs, which costs 0.35 ms per launch
+# where the bn_act pass took 0.126.  Off by default; FGCN_FUSE_G=1 selects it (profiles/r03_ab_fused_input_stage.txt).
+FUSE_BN_INTO_TCONV = bool(os.environ.get("FGCN_FUSE_G"))
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see

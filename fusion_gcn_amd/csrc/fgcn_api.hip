@@ -8,8 +8,8 @@ char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
-static int g_tuning[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-int tuning(int key) { return (key >= 0 && key < 8) ? g_tuning[key] : 0; }
+static int g_tuning[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
 static int g_math_mode = FGCN_MATH_F32;
 int math_mode() { return g_math_mode; }
 }  // namespace fgcn
@@ -24,7 +24,7 @@ extern "C" int fgcn_set_math_mode(int mode) {
 extern "C" int fgcn_get_math_mode(void) { return fgcn::g_math_mode; }
 
 extern "C" int fgcn_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);
+    if (key < 0 || key >= 16) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);
     fgcn::g_tuning[key] = value;
     return FGCN_OK;
 }

@@ -1,0 +1,278 @@
+// 1x1 convolutions (theta|phi embedding, dY.Wd, down, dEmb.W; reference torch_src/models/mmargcn/agcn.py:71-73,77,104-111 and their
+// data gradients) in the split-bf16 math modes: a PERSISTENT row GEMM  out[m][n] (+)= sum_k in[m][k] W[k][n] + bias[n].
+//
+// Why a kernel of its own.  A 1x1 convolution has K = 64..384: one to six 64-channel chunks per (128 rows x 128 columns) tile.  Run on
+// the halo-tile kernel (fgcn_tconv.hip, one workgroup per tile) such a tile is a staging latency, <= 6 short MFMA phases and a store
+// tail, with nothing of its own to overlap them: 104-140 TFLOP/s where the nine-tap form of the same kernel reaches 210-237, and
+// below K = 192 the exact-f32 row GEMM was the faster choice (3.2-4.3 TB/s, neither matrix- nor HBM-bound).  Here a workgroup walks a
+// list of tiles: the rows of the NEXT chunk -- or of the next tile's first chunk -- are requested before the MFMAs of the current one
+// and parked in registers, so the global latency and the previous tile's store tail lie under matrix work; the weight ring crosses
+// tile boundaries the same way.  MFMA core, LDS image (unpadded 128-byte bf16 rows, 32-byte blocks XOR-swizzled by row bits:
+// conflict-free ds_read_b128), 2 x 2 wave arrangement, weight form (fgcn_pack_split3) and XCD-aware tile order (column tiles of a row
+// tile back to back on one XCD) are the halo kernel's.
+//   NP = bf16 parts per operand: 3 (FGCN_MATH_BF16X3: six partial products, f32 accuracy) or 1 (FGCN_MATH_BF16).
+//   NT = 1 / 2: 64 / 128 output columns per tile.
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct PwP {
+    const float* in;
+    float* out;
+    const void* w3;                     // [part][K/8][N][8] bf16
+    const float* bias;
+    float* stats;                       // float[tiles_m][2][N] or NULL: per row tile, sum and sum of squares of the values written
+    long long M;
+    unsigned in_bytes, w_plane_bytes, out_bytes;
+    int K, N, ld_in, ld_out, accumulate;
+    int tiles_m, tiles_n, per_xcd, wg_per_xcd;
+};
+
+using u32x4p = __attribute__((ext_vector_type(4))) unsigned int;
+
+template <int NT, int NP>
+__global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
+    static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 3), "64 / 128 columns, one or three bf16 parts");
+    constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    constexpr int TPR = KC / 4, RPP = 256 / TPR, NST = BMR / RPP;      // 16 threads per row, 16 rows per pass, 8 passes
+    constexpr unsigned OOB = 0x80000000u;
+    auto swz = [](int r) -> unsigned { return (unsigned)(r & 6) << 4; };
+    extern __shared__ __attribute__((aligned(16))) float Ah[];
+    unsigned char* Xh = reinterpret_cast<unsigned char*>(Ah);
+    constexpr unsigned plane = BMR * XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : p.w3), 0,
+                                                                           p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+
+    // this workgroup's tiles: ids go round-robin over the 8 XCDs, so workgroup b works inside XCD (b & 7)'s share of the virtual tile
+    // list [x * per_xcd, (x + 1) * per_xcd) (column tile fastest), taking every wg_per_xcd-th tile from its local index on
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int v_end = min((xcd + 1) * p.per_xcd, p.tiles_m * p.tiles_n);
+    int vid = xcd * p.per_xcd + local;
+    if (vid >= v_end) return;
+
+    const unsigned k4b = (unsigned)(tid % TPR) * 16u;
+    const int k4 = (tid % TPR) * 4;
+    const int K8 = p.K >> 3;
+    const int xrow = wr * (16 * MTW) + l15;
+
+    unsigned src_off[NST];
+    f32x4 stage[NST];
+    auto set_rows = [&](int bm) {                                    // image row r = tid / 16 + 16 i of tile bm
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const long long m = (long long)bm * BMR + tid / TPR + RPP * i;
+            src_off[i] = m < p.M ? (unsigned)(m * p.ld_in * 4) + k4b : OOB;
+        }
+    };
+    auto fetch = [&](int kc) {
+        const bool kok = kc + k4 < p.K;                              // K % 4 == 0: a 16-byte group is whole or absent
+#pragma unroll
+        for (int i = 0; i < NST; ++i) stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                          rin, kok ? src_off[i] : OOB, (unsigned)kc * 4u, 0));
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int r = tid / TPR + RPP * i;
+            u32x2 ph, pm, pl;
+            split3_x4(stage[i], ph, pm, pl);
+            unsigned char* dst = Xh + r * XS + ((unsigned)((tid % TPR) * 8) ^ swz(r));
+            *reinterpret_cast<u32x2*>(dst) = ph;
+            if constexpr (NP == 3) {
+                *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * plane) = pl;
+            }
+        }
+    };
+    // weight fragment of (column unit nu of column tile bn, 32-channel step at channel k): lane (l15, g4) holds k + 8 g4 + j
+    auto load_w = [&](u32x4v (&dst)[NP], int bn, int nu, int k) {
+        const int col = bn * BN + wc * NT * 32 + nu * 16 + l15;
+        const int kg = (k >> 3) + g4;
+        const unsigned off = (col < p.N && kg < K8) ? (unsigned)(((long long)kg * p.N + col) * 16) : OOB;
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
+    };
+    auto load_a = [&](u32x4v (&dst)[NP], int mt, int s2) {
+        const int r = xrow + mt * 16;
+        const unsigned char* src = Xh + r * XS + ((unsigned)(16 * g4 + 64 * s2) ^ swz(r));
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * plane);
+    };
+
+    int bm = vid / p.tiles_n, bn = vid - bm * p.tiles_n;
+    u32x4v a[MTW][NP], wq[2][NP];
+    set_rows(bm);
+    fetch(0);
+    load_w(wq[0], bn, 0, 0);
+    while (true) {
+        const int vnext = vid + p.wg_per_xcd;
+        const bool more = vnext < v_end;
+        const int bm_n = more ? vnext / p.tiles_n : bm, bn_n = more ? vnext - bm_n * p.tiles_n : bn;
+        f32x4 acc[MTW][NU];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) acc[mt][nu] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < p.K; kc += KC) {
+            __syncthreads();                                         // the previous chunk's (or tile's) LDS reads are done
+            deposit();
+            __syncthreads();
+            const bool last_chunk = kc + KC >= p.K;
+            if (!last_chunk) {
+                fetch(kc + KC);                                      // lands during the MFMAs below
+            } else if (more) {                                       // ... or the next tile's first chunk, across this tile's store tail
+                set_rows(bm_n);
+                fetch(0);
+            }
+            const int nsteps = p.K - kc > 32 ? 2 : 1;                // a 32-channel tail runs one step
+#pragma unroll 1
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) load_a(a[mt], mt, s2);
+                const bool last_step = s2 + 1 == nsteps;
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    // the ring: the next unit's weights -- next column unit, next step, next chunk, or the next tile's first unit
+                    if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], bn, nu + 1, kc + 32 * s2);
+                    else if (!last_step) load_w(wq[0], bn, 0, kc + 32);
+                    else if (!last_chunk) load_w(wq[0], bn, 0, kc + KC);
+                    else load_w(wq[0], bn_n, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                        else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums (accumulator register r of lane
+        // (col l15, g4) = row 4 g4 + r of its 16 x 16 tile) ------------------------------------------------------------------
+        const long long m0 = (long long)bm * BMR;
+        const int col = bn * BN + wc * NT * 32 + l15;
+        float ssum[NU], ssq[NU], bv[NU];
+        unsigned coff[NU];
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            ssum[nu] = 0.f;
+            ssq[nu] = 0.f;
+            coff[nu] = col + nu * 16 < p.N ? (unsigned)(col + nu * 16) * 4u : OOB;
+            bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            unsigned rowoff[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
+                rowoff[r] = m < p.M ? (unsigned)(m * p.ld_out * 4) : OOB;
+            }
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                float old[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    old[r] = 0.f;
+                    if (p.accumulate)                                // wave-uniform
+                        old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rout, (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu], 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
+                    const float val = acc[mt][nu][r] + bv[nu] + old[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+                    const float kept = off != OOB ? val : 0.f;
+                    ssum[nu] += kept;
+                    ssq[nu] += kept * kept;
+                }
+            }
+        }
+        if (p.stats) {                                               // (kernel-uniform)
+            __syncthreads();                                         // every wave has left the tile's last MFMA step: the image is free
+            float* red = Ah;                                         // [which][wr][BN]
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                float sa = ssum[nu] + __shfl_xor(ssum[nu], 16);
+                float sb = ssq[nu] + __shfl_xor(ssq[nu], 16);
+                sa += __shfl_xor(sa, 32);
+                sb += __shfl_xor(sb, 32);
+                if (lane < 16) {
+                    red[(0 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sa;
+                    red[(1 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sb;
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, c = tid - which * BN;
+                if (bn * BN + c < p.N)
+                    p.stats[((long long)bm * 2 + which) * p.N + bn * BN + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
+            }
+        }
+        if (!more) break;
+        vid = vnext;
+        bm = bm_n;
+        bn = bn_n;
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+extern "C" int fgcn_pw_gemm_tiles(long long rows) { return (int)cdiv(rows, 128); }
+
+// 1 when fgcn_pw_gemm runs in the current math mode (the split-bf16 modes)
+extern "C" int fgcn_pw_gemm_available(void) {
+    const int mm = fgcn::math_mode();
+    return (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) ? 1 : 0;
+}
+
+extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                            int K, int N, int ld_in, int ld_out, int accumulate, void* stream) {
+    FGCN_REQUIRE(in && out && w3 && rows > 0, FGCN_E_BADARG, "pw_gemm: null pointer or no rows");
+    FGCN_REQUIRE(fgcn_pw_gemm_available(), FGCN_E_BADARG, "pw_gemm: a split-bf16 math mode (bf16x3 / bf16) only");
+    FGCN_REQUIRE(K > 0 && K % 32 == 0 && N > 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N,
+                 FGCN_E_ALIGN, "pw_gemm: K must be a multiple of 32, N and the row strides multiples of 4 (K=%d N=%d ld_in=%d ld_out=%d)", K,
+                 N, ld_in, ld_out);
+    FGCN_REQUIRE(aligned16(in) && aligned16(w3) && aligned16(out), FGCN_E_ALIGN, "pw_gemm: 16-byte alignment");
+    const long long in_bytes = rows * ld_in * 4, out_bytes = rows * ld_out * 4, plane = (long long)K * N * 2;
+    FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "pw_gemm: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    PwP p;
+    p.in = in; p.out = out; p.w3 = w3; p.bias = bias; p.stats = stat_partials;
+    p.M = rows;
+    p.in_bytes = (unsigned)in_bytes; p.out_bytes = (unsigned)out_bytes; p.w_plane_bytes = (unsigned)plane;
+    p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out; p.accumulate = accumulate;
+    const bool narrow = N <= 64;
+    p.tiles_m = (int)cdiv(rows, 128);
+    p.tiles_n = (int)cdiv(N, narrow ? 64 : 128);
+    const long long total = (long long)p.tiles_m * p.tiles_n;
+    FGCN_REQUIRE(total < (1ll << 30), FGCN_E_BADARG, "pw_gemm: too many tiles");
+    p.per_xcd = (int)cdiv(total, 8);
+    // two workgroups per CU (48 KB of LDS, <= 256 registers): 64 per XCD fill the chip; fewer when there are fewer tiles.  key 8: tiles
+    // per workgroup cap (0 = persistent; 1 = one tile per workgroup, the non-persistent control of the A/B)
+    int per = 64;
+    if (fgcn::tuning(8) == 1) per = p.per_xcd;
+    p.wg_per_xcd = p.per_xcd < per ? p.per_xcd : per;
+    const dim3 grid((unsigned)(p.wg_per_xcd * 8));
+    const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
+    const size_t lds = (size_t)128 * 128 * (one ? 1 : 3);
+    hipStream_t s = (hipStream_t)stream;
+    if (narrow) {
+        if (one) hipLaunchKernelGGL((pw_x3_kernel<1, 1>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((pw_x3_kernel<1, 3>), grid, dim3(256), lds, s, p);
+    } else {
+        if (one) hipLaunchKernelGGL((pw_x3_kernel<2, 1>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((pw_x3_kernel<2, 3>), grid, dim3(256), lds, s, p);
+    }
+    return launch_status("pw_gemm");
+}

@@ -204,6 +204,31 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     return part
 
 
+def pw_gemm_available() -> bool:
+    """Whether ``pw_gemm`` runs in the current math mode (the split-bf16 modes)."""
+    return bool(_lib.load().fgcn_pw_gemm_available())
+
+
+def pw_gemm(inp: torch.Tensor, w3: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None, stats: bool = False,
+            accumulate: bool = False) -> Optional[torch.Tensor]:
+    """1x1 convolution over all rows on the persistent split-bf16 row GEMM: inp (..., ld_in) and out (..., ld_out) contiguous with the
+    same number of rows, w3 = pack_split3 of the (1, K, N) matrix.  Returns the BatchNorm partial sums (tiles, 2, N) when asked."""
+    ensure_device()
+    _chk(inp, "pw_gemm.in"), _chk(out, "pw_gemm.out")
+    if w3.dtype != torch.bfloat16 or w3.dim() != 5 or w3.shape[0] != 3 or w3.shape[1] != 1 or w3.shape[4] != 8 or not w3.is_contiguous():
+        raise _lib.FgcnError(f"pw_gemm: pack_split3 weights of a (1, K, N) matrix expected, got {w3.dtype} {tuple(w3.shape)}")
+    K, N = w3.shape[2] * 8, w3.shape[3]
+    ld_in, ld_out = inp.shape[-1], out.shape[-1]
+    rows = inp.numel() // ld_in
+    if out.numel() // ld_out != rows or K > ld_in or N > ld_out:
+        raise _lib.FgcnError(f"pw_gemm: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} w3={tuple(w3.shape)}")
+    lib = _lib.load()
+    part = torch.empty((lib.fgcn_pw_gemm_tiles(rows), 2, N), device=inp.device, dtype=torch.float32) if stats else None
+    check(lib.fgcn_pw_gemm(_p(inp), _p(out), w3.data_ptr(), _p(bias), _p(part), rows, K, N, ld_in, ld_out, int(accumulate), _stream()),
+          "fgcn_pw_gemm")
+    return part
+
+
 class ReduceBatch:
     """Leaf reductions of a block's backward, collected and issued as ONE fgcn_reduce_multi launch per 8 items.
 

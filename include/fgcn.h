@@ -441,6 +441,18 @@ int fgcn_tmaxpool3_bwd(const float* dout, const unsigned char* idx, float* din, 
 int fgcn_unfold_windows(const float* in, float* out, int B, int T, int T_out, int V, int C, int window, int stride,
                         int dilation, int backward, void* stream);
 
+/* ---- 1x1 convolutions in the split-bf16 math modes: persistent row GEMM (fgcn_pw.hip) ---------------------------------------------
+ * out[m][n] (+)= sum_k in[m][k] * W[k][n] + bias[n] over `rows` contiguous rows (row strides ld_in / ld_out): the theta|phi embedding,
+ * dY.Wd, down and dEmb.W products of the block (agcn.py:71-73,77,104-111) where the row GEMM above has no temporal map.  w3 = the
+ * fgcn_pack_split3 form of the (1, K, N) matrix; K % 32 == 0, N % 4 == 0; stat_partials: float[fgcn_pw_gemm_tiles(rows)][2][N] or NULL
+ * (sum and sum of squares of the values written, per 128-row tile).  A workgroup walks a list of (128 rows x 64 | 128 columns) tiles
+ * and requests the next chunk's -- or the next tile's -- rows before the current MFMAs: the tiles of a 1x1 convolution are too short
+ * (K = 64..384) to hide their own staging latency and store tail.  fgcn_pw_gemm_available() = 1 in FGCN_MATH_BF16X3 / FGCN_MATH_BF16. */
+int fgcn_pw_gemm_available(void);
+int fgcn_pw_gemm_tiles(long long rows);
+int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                 int K, int N, int ld_in, int ld_out, int accumulate, void* stream);
+
 /* ---- the two ends of the step: input BatchNorm and loss (fgcn_head.hip) ------------------------------------------------------
  * `data_bn` = nn.BatchNorm1d(M*V*C) over the network input x (N, M, T, V, C) viewed as (N, M*V*C, T)
  * (torch_src/models/mmargcn/agcn.py:150,186-188; msg3d.py:93,152-154): channel ch = (m*V + v)*C + c, statistics over (n, t).

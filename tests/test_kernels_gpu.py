@@ -190,6 +190,48 @@ def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
     assert rel_l2(dg.cpu().numpy(), dx_want.numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("rows,K,N,ld_in,ld_out", [
+    (3000, 64, 96, 64, 96), (2999, 96, 64, 96, 64), (1283, 128, 384, 128, 384), (517, 192, 128, 192, 128), (4097, 256, 768, 256, 768),
+    (130, 384, 256, 384, 256), (1000, 64, 128, 64, 128), (127, 32, 4, 36, 8), (12000, 64, 192, 64, 192), (70000, 64, 64, 64, 64)])
+def test_persistent_pointwise_gemm(rows, K, N, ld_in, ld_out):
+    """ops.pw_gemm (fgcn_pw.hip): the block's 1x1 convolutions in the split-bf16 modes -- out = in . W + bias with BatchNorm
+    partial sums, and the accumulating form -- against float64; ragged last tile, 32-channel tail chunk (K = 96), one and several
+    column tiles, more tiles than workgroups (the persistent walk), padded row strides; the one-tile-per-workgroup control (tuning
+    key 8) must give the same bits."""
+    from fusion_gcn_amd import _lib, ops
+    if not ops.pw_gemm_available():
+        pytest.skip("pw_gemm runs in the split-bf16 math modes")
+    x = rnd(rows, 1, 1, ld_in, seed=200)
+    w = rnd(1, K, N, seed=201, scale=K ** -0.5)
+    bias = rnd(N, seed=202)
+    base = rnd(rows, 1, 1, ld_out, seed=203)
+    want = x[..., :K].reshape(rows, K) @ w[0] + bias
+    w3 = ops.pack_split3(to_gpu(w))
+    out = to_gpu(base)
+    part = ops.pw_gemm(to_gpu(x), w3, out, bias=to_gpu(bias), stats=True)
+    got = out.view(rows, ld_out).cpu().double()
+    assert rel_l2(got[:, :N].numpy(), want.numpy()) < FWD_TOL
+    assert torch.equal(got[:, N:], base.float().double().view(rows, ld_out)[:, N:])          # columns beyond N untouched
+    tot = part.double().sum(0).cpu()
+    assert rel_l2(tot[0].numpy(), want.sum(0).numpy()) < RED_TOL * 5 + 1e-7 * rows ** 0.5
+    assert rel_l2(tot[1].numpy(), (want ** 2).sum(0).numpy()) < RED_TOL
+    _lib.load().fgcn_set_tuning(8, 1)
+    try:
+        out1 = to_gpu(base)
+        part1 = ops.pw_gemm(to_gpu(x), w3, out1, bias=to_gpu(bias), stats=True)
+    finally:
+        _lib.load().fgcn_set_tuning(8, 0)
+    assert torch.equal(out1, out) and torch.equal(part1, part)
+    acc = to_gpu(base)
+    ops.pw_gemm(to_gpu(x), w3, acc, accumulate=True)
+    want_acc = base.view(rows, ld_out)[:, :N] + x[..., :K].reshape(rows, K) @ w[0]
+    assert rel_l2(acc.view(rows, ld_out)[:, :N].cpu().numpy(), want_acc.numpy()) < FWD_TOL
+    with ops.math_mode("bf16"):
+        outb = to_gpu(base)
+        ops.pw_gemm(to_gpu(x), w3, outb, bias=to_gpu(bias))
+        assert rel_l2(outb.view(rows, ld_out)[:, :N].cpu().numpy(), want.numpy()) < 2e-2
+
+
 @pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 21, 25, 128), (2, 9, 27, 256), (1, 50, 22, 64), (5, 3, 18, 128), (2, 40, 32, 64)])
 def test_halo_temporal_conv_with_the_input_stage_fused(B, T, V, C):
     """North-star kernel 2 as the north star states it: G = relu(BatchNorm(y) + x) (agcn.py:113-115) formed INSIDE the 9x1 temporal

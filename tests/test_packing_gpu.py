@@ -69,7 +69,7 @@ def _long_way(P, cfg, mode):
         R["res"], R["res_t"] = res.t().contiguous().unsqueeze(0), res.contiguous().unsqueeze(0)
     if x3:
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
-            if key in R and R[key].shape[1] % 64 == 0:
+            if key in R and R[key].shape[1] % 32 == 0:
                 R[key + "_s3"] = ops.pack_split3(R[key])
     return R
 

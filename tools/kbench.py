@@ -71,6 +71,36 @@ def bench_gemm(B, reps):
     report("rows_gemm tconv dgrad s2 T150->300 K9x128 N128", ms, 2.0 * B * 150 * V * 9 * 128 * 128, 4.0 * B * 450 * V * 128)
 
 
+def bench_pw(B, reps):
+    """1x1 convolutions of the block at their headline shapes: exact-f32 row GEMM / split-bf16 halo kernel with one tap / the
+    persistent split-bf16 row GEMM (ops.pw_gemm), one tile per workgroup (tuning key 8 = 1) and persistent."""
+    lib = _lib.load()
+    if not ops.pw_gemm_available():
+        print("-- pw: split-bf16 modes only")
+        return
+    cases = [("emb", 300, 64, 96), ("emb", 150, 128, 192), ("emb", 75, 256, 384), ("d_t", 300, 64, 192), ("d_t", 150, 128, 384),
+             ("d_t", 75, 256, 768), ("emb_t", 300, 96, 64), ("emb_t", 150, 192, 128), ("emb_t", 75, 384, 256), ("down", 300, 64, 128),
+             ("down_t", 150, 128, 64), ("down", 150, 128, 256), ("down_t", 75, 256, 128)]
+    for name, T, K, N in cases:
+        x, w, y = rnd(B, T, V, K), rnd(1, K, N) * K ** -0.5, torch.empty(B, T, V, N, device=DEV)
+        rows = B * T * V
+        fl, by = 2.0 * rows * K * N, 4.0 * rows * (K + N)
+        ms = timeit(lambda: ops.rows_gemm(x, w, y, K=K, N=N, stats=True), reps)
+        report(f"{name:7s} K{K:3d} N{N:3d} T{T}: f32 row GEMM", ms, fl, by)
+        w3 = ops.pack_split3(w)
+        if K % 64 == 0:
+            ms = timeit(lambda: ops.tconv_halo(x, w3, y, Th=T, taps=1, tb=1, tc=0, stats=True), reps)
+            report("            halo kernel, one tap", ms, fl, by)
+        lib.fgcn_set_tuning(8, 1)
+        ms = timeit(lambda: ops.pw_gemm(x, w3, y, stats=True), reps)
+        report("            pw_gemm, one tile per workgroup", ms, fl, by)
+        lib.fgcn_set_tuning(8, 0)
+        ms = timeit(lambda: ops.pw_gemm(x, w3, y, stats=True), reps)
+        report("            pw_gemm, persistent", ms, fl, by)
+        ms = timeit(lambda: ops.pw_gemm(x, w3, y, accumulate=True), reps)
+        report("            pw_gemm, persistent, accumulate", ms, fl, by + 4.0 * rows * N)
+
+
 def bench_tconv(B, reps):
     """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2; tuning key 4 picks the
     register budget (2 or 3 workgroups per CU)."""
@@ -213,7 +243,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,tconv,wgrad,spatial,spatial_wgrad,joint,elem")
+    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -224,7 +254,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
