@@ -48,14 +48,17 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA (32x32x16 / 16x16x32), dense
 PEAK_SPLIT3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # float32-equivalent FLOPs when every product costs six bf16 MFMAs
-MATH_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT3_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}
+PEAK_SPLIT2H_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3  # f16 MFMAs run at the bf16 rate; three products per product group
+MATH_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT3_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f16x2": PEAK_SPLIT2H_TFLOPS}
 MATH_DTYPE = {
     "f32": "f32",
     "bf16x3": "f32 (products from exact 3-way bf16 splits of both operands: 6 bf16 MFMAs per product group, f32 accumulate; "
               "f32 storage / statistics; same parity tolerances as the f32 MFMA path)",
-    "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics"}
+    "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics",
+    "f16x2": "f32 (bf16x3, with the temporal and 1x1 convolutions' products from block-scaled 2-way f16 splits of both operands: 3 f16 "
+             "MFMAs per product group, f32 accumulate; f32 storage / statistics; same parity tolerances as the f32 MFMA path)"}
 MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_kernel<{nt},3> (bf16 operands)",
-               "bf16x3": "conv_halo_x3k32_kernel<{nt2},32>"}
+               "bf16x3": "conv_halo_x3k32_kernel<{nt2},32>", "f16x2": "conv_halo_x3k32_kernel<{nt2},32,2> (f16x2 products)"}
 PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
 SHAPE = dict(N=64, M=2, T=300, V=25, C=3, classes=60)
 
@@ -227,7 +230,7 @@ def measured_traffic(dom, samples, math="f32"):
     for name in TRAFFIC_RECORDS:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                rec = json.load(f)[{"f32": "conv_halo_fwd", "bf16x3": "conv_halo_x3_fwd"}[math]]
+                rec = json.load(f)[{"f32": "conv_halo_fwd", "bf16x3": "conv_halo_x3_fwd", "f16x2": "conv_halo_f16x2_fwd"}[math]]
             break
         except (OSError, KeyError, ValueError):
             continue
@@ -299,7 +302,7 @@ def main():
                     help="plumbing check without a GPU: rendezvous, batch sharding, one all-reduce of a gradient-sized buffer "
                          "over FGCN_BENCH_BACKEND (gloo), then the JSON line with value null")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", choices=("f32", "bf16", "bf16x3"), default="bf16x3",
+    ap.add_argument("--math", choices=("f32", "bf16", "bf16x3", "f16x2"), default="bf16x3",
                     help="bf16x3 (default): f32-accurate split-bf16 products; f32: v_mfma_f32 directly; bf16: BASELINE "
                          "config 5 (bf16 MFMA operands, f32 accumulation)")
     ap.add_argument("--no-f32-mode", action="store_true",
@@ -612,7 +615,8 @@ def main():
                                                          "(the chip lowers its clock to ~1.9 GHz under MFMA load); this kernel issues "
                                                          "6 x achieved of bf16 MFMA work",
                                "peak_is": {"f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "v_mfma_f32_32x32x16_bf16 dense",
-                                           "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)"}[args.math],
+                                           "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)",
+                                           "f16x2": "f16 dense peak (= bf16's) / 3 products (f32-equivalent FLOPs)"}[args.math],
                                "frac_of_f32_mfma_peak": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                                "kernel": f"{kname} (9x1 temporal conv forward, "
                                          f"{dom['channels']} channels, {dom['frames']} frames)",

@@ -48,7 +48,7 @@ class PackSeg(C.Structure):
 
 
 PACK_MAX_SEG = 6            # FGCN_PACK_MAX_SEG
-PACK_MODES = {"plain": 0, "k4": 1, "split3": 2, "split3_acc": 3}       # FGCN_PACK_*
+PACK_MODES = {"plain": 0, "k4": 1, "split3": 2, "split3_acc": 3, "split2h": 4}       # FGCN_PACK_*
 
 
 class PackItem(C.Structure):
@@ -75,20 +75,22 @@ SIGNATURES = {
     "fgcn_set_tuning": (_I, [_I, _I]),
     "fgcn_set_math_mode": (_I, [_I]),
     "fgcn_get_math_mode": (_I, []),
+    "fgcn_set_products": (_I, [_I]),
+    "fgcn_get_products": (_I, []),
     "fgcn_rows_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_rows_gemm_batched": (_I, [_P, _P, _P, _I, _LL, _LL, _LL, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_rows_gemm_tiles": (_I, [_LL]),
     "fgcn_tconv_halo_tiles": (_I, [_I, _I, _I, _I]),
-    "fgcn_tconv_halo": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P, _P, _P] + [_P, _P, _P, _P] + [_P]),
+    "fgcn_tconv_halo": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P, _P, _P] + [_P, _P, _P, _P] + [_P, _P]),
     "fgcn_tconv_halo_bn_sums": (_I, []),
     "fgcn_rows_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_tconv_wgrad_slabs": (_I, [_I, _I]),
     "fgcn_pw_wgrad_slabs": (_I, [_I, _I]),
     "fgcn_tconv_wgrad_resident": (_I, [_I]),
     "fgcn_pw_wgrad_resident": (_I, [_I]),
-    "fgcn_tconv_wgrad": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
+    "fgcn_tconv_wgrad": (_I, [_P, _P, _P] + [_I] * 17 + [_P, _P, _P]),
     "fgcn_pw_wgrad_chunks": (_I, [_I, _I]),
-    "fgcn_pw_wgrad": (_I, [_P, _P, _P] + [_I] * 11 + [_P]),
+    "fgcn_pw_wgrad": (_I, [_P, _P, _P] + [_I] * 11 + [_P, _P, _P]),
     "fgcn_reduce_sum": (_I, [_P, _P, _I, _LL, _I, _P]),
     "fgcn_reduce_sum_strided": (_I, [_P, _P, _I, _I, _I, _I, _I, _LL, _LL, _LL, _I, _P]),
     "fgcn_reduce_multi": (_I, [C.POINTER(ReduceItem), _I, _P]),
@@ -99,8 +101,9 @@ SIGNATURES = {
     "fgcn_pack_kgroups": (_I, [_I, _I]),
     "fgcn_pack_units": (_LL, [_I, _I, _I, _I]),
     "fgcn_pack_run": (_I, [_P, _P, _I, _P]),
+    "fgcn_pack_run_scaled": (_I, [_P, _P, _I, _I, _P]),
     "fgcn_joint_mix": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixItem), _I, _I, _P]),
-    "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P, _P]),
+    "fgcn_joint_mix_vec": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(MixVItem), _I, _I, _I, _P, _P, _P]),
     "fgcn_joint_mix_chunks": (_I, [_I, _I]),
     "fgcn_joint_gram": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(GramItem), _I, _P]),
     "fgcn_spatial_wgrad_chunks": (_I, [_I, _I, _I, _I]),
@@ -125,7 +128,7 @@ SIGNATURES = {
     "fgcn_unfold_windows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_pw_gemm_available": (_I, []),
     "fgcn_pw_gemm_tiles": (_I, [_LL]),
-    "fgcn_pw_gemm": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "fgcn_pw_gemm": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P, _P]),
     "fgcn_data_bn_tiles": (_I, [_I, _I]),
     "fgcn_data_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fgcn_data_bn_apply": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -107,7 +107,8 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     cin, cout, ic, cx = cfg.cin, cfg.cout, cfg.ic, cfg.cx
     mode = ops.get_math_mode()
     x3 = mode in ops.SPLIT_MODES                     # modes whose halo kernel takes the split weight form
-    conv_form = "split3" if x3 else "k4"
+    split_form = "split2h" if mode == "f16x2" else "split3"      # f16x2: block-scaled two-way f16 split (FGCN_PACK_SPLIT2H)
+    conv_form = split_form if x3 else "k4"
     F: Dict[str, Form] = {}
     conv = lambda name: P[name].detach()             # noqa: E731  (O, I, kt, 1) contiguous: strides o: I*kt, i: kt, tap: 1
 
@@ -127,7 +128,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     wd = [conv(f"gcn1.conv_d.{k}.weight") for k in range(NUM_SUBSETS)]
     d_rows = [Seg(w, st_k=1, st_n=cin, klen=cin, nlen=cout, k0=k * cx) for k, w in enumerate(wd)]          # (3cx, cout)
     F["d"] = Form("plain", 1, 3 * cx, cout, d_rows, shape=(3 * cx, cout))
-    if mode == "bf16x3" and cx % 32 == 0:            # the fused spatial kernel's form (ops.pack_spatial)
+    if mode in ops.X3_MODES and cx % 32 == 0:        # the fused spatial kernel's form (ops.pack_spatial)
         F["d4"] = Form("split3_acc", 1, 3 * cx, cout, d_rows)
     else:
         F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
@@ -162,7 +163,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     if x3:                                           # split forms of the 1x1 weights pw_gemm may route to the halo kernel
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
             if key in F and F[key].K % 32 == 0:
-                F[key + "_s3"] = Form("split3", 1, F[key].K, F[key].N, F[key].segs)
+                F[key + "_s3"] = Form(split_form, 1, F[key].K, F[key].N, F[key].segs)
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
@@ -174,13 +175,18 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
 PW_X3_MIN_K = int(os.environ.get("FGCN_PW_MIN_K", "128"))
 
 
+def pw_routed(W, key: str, x: torch.Tensor, K: int) -> bool:
+    """Whether pw_gemm sends this 1x1 convolution to the persistent split row GEMM (the kernel that can record max |x|)."""
+    return (key + "_s3") in W and K % 32 == 0 and x.shape[3] == K and K >= PW_X3_MIN_K
+
+
 def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Tensor, *, K: int, N: int,
-            bias: Optional[torch.Tensor] = None, stats: bool = False, accumulate: bool = False):
+            bias: Optional[torch.Tensor] = None, stats: bool = False, accumulate: bool = False, amax_out: Optional[torch.Tensor] = None):
     """1x1 convolution over all rows: in the split-bf16 math modes (the packed set then holds the split form of the weight) the
-    persistent split-bf16 row GEMM; the exact-f32 row GEMM otherwise."""
+    persistent split-bf16 row GEMM; the exact-f32 row GEMM otherwise.  ``amax_out``: see ops.pw_gemm (ignored by the f32 kernel)."""
     w3 = W.get(key + "_s3")
     if w3 is not None and K % 32 == 0 and x.shape[3] == K and K >= PW_X3_MIN_K:
-        return ops.pw_gemm(x, w3, out, bias=bias, stats=stats, accumulate=accumulate)
+        return ops.pw_gemm(x, w3, out, bias=bias, stats=stats, accumulate=accumulate, amax_out=amax_out)
     if PW_X3_MIN_K > 4096 and w3 is not None and K % 64 == 0 and x.shape[3] == K and (K >= 192 or (K >= 128 and N >= 384)):
         # (A/B control, FGCN_PW_MIN_K=100000: round 2's routing -- the one-tap halo kernel from K = 192 on, the f32 row GEMM below)
         return ops.tconv_halo(x, w3, out, Th=x.shape[1], taps=1, tb=1, tc=0, bias=bias, stats=stats, accumulate=accumulate)
@@ -221,7 +227,7 @@ GATED_SHORTCUTS = False
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
-FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 64}
+FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 64, "f16x2": 64}
 MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
 
 
@@ -237,16 +243,18 @@ def _vec_width(c: int, order: Sequence[int] = None) -> int:
     return min(narrow) if narrow else 0
 
 
-def mix_agg(x: torch.Tensor, agg: torch.Tensor, a_hat: torch.Tensor, cin: int) -> None:
-    """agg[(k, c)] = x . A^_k for the three subsets (items of one channel group are adjacent: x is loaded once)."""
+def mix_agg(x: torch.Tensor, agg: torch.Tensor, a_hat: torch.Tensor, cin: int, amax_out=None) -> bool:
+    """agg[(k, c)] = x . A^_k for the three subsets (items of one channel group are adjacent: x is loaded once).  ``amax_out``:
+    records max |agg| (ops.joint_mix_vec); -> whether it was recorded."""
     vw = _vec_width(cin)
     if not vw:
         ops.joint_mix(x, agg, a_hat, spec_agg(cin), in_channels=cin, out_channels=3 * cin)
-        return
+        return False
     g = 32 * vw
     spec = [dict(out_c=k * cin + c0, nch=min(g, cin), terms=[(k, 1, c0)])
             for c0 in range(0, cin, g) for k in range(NUM_SUBSETS)]
-    ops.joint_mix_vec(x, agg, a_hat, spec, vw=vw)
+    ops.joint_mix_vec(x, agg, a_hat, spec, vw=vw, amax_out=amax_out)
+    return amax_out is not None
 
 
 def mix_dx(dagg: torch.Tensor, dx: torch.Tensor, a_hat: torch.Tensor, cin: int, accumulate: bool) -> None:
@@ -283,40 +291,40 @@ def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) 
 
 
 def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], bias: torch.Tensor, kt: int, s: int,
-                 stats: bool, fuse_in=None):
+                 stats: bool, fuse_in=None, amax_out=None):
     """u = Conv(kt x 1, stride s, pad (kt-1)//2)(g) + bias, with BatchNorm partial sums of u when ``stats``.
     ``fuse_in = (vec, shortcut, g_out, g_sign)`` (stride 1, split-bf16 kernel): the first argument is the BatchNorm input y and
     g = relu(BatchNorm(y) + shortcut) is formed inside the conv (ops.tconv_halo)."""
     pad = (kt - 1) // 2
     T, Tp = g.shape[1], u.shape[1]
     if s == 1 and "t4" in W:
-        return ops.tconv_halo(g, W["t4"], u, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=stats, fuse_in=fuse_in)
+        return ops.tconv_halo(g, W["t4"], u, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=stats, fuse_in=fuse_in, amax_out=amax_out)
     assert fuse_in is None
     if s == 2 and "t4_e" in W and pad % 2 == 0 and T > 1:
         # output frame to meets tap j = 2j' + par at input frame 2 (to + j' - pad/2) + par: one pass over the even input
         # frames (taps 0, 2, ..), one accumulating pass over the odd ones (which also takes the BatchNorm sums)
         ops.tconv_halo(g, W["t4_e"], u, Th=Tp, taps=(kt + 1) // 2, tb=1, tc=-(pad // 2), in_view=(2, 0, (T + 1) // 2),
-                       bias=bias)
+                       bias=bias, amax_out=amax_out)
         return ops.tconv_halo(g, W["t4_o"], u, Th=Tp, taps=kt // 2, tb=1, tc=-(pad // 2), in_view=(2, 1, T // 2),
-                              stats=stats, accumulate=True)
+                              stats=stats, accumulate=True, amax_out=amax_out)
     # strided forward in f32: the per-tap row GEMM measures faster than two accumulating halo passes over the even / odd
     # input frames (1.26 vs 1.54 ms at 128 channels, T 300 -> 150); on the split-bf16 kernels (math mode bf16x3: the packed
     # set then holds t4_e / t4_o) the two passes win
     return ops.rows_gemm(g, W["t"], u, K=g.shape[3], N=u.shape[3], tmap=ops.conv_tmap(kt, s), bias=bias, stats=stats)
 
 
-def temporal_dgrad(du: torch.Tensor, dg: torch.Tensor, W: Dict[str, torch.Tensor], kt: int, s: int, bn_bwd=None):
+def temporal_dgrad(du: torch.Tensor, dg: torch.Tensor, W: Dict[str, torch.Tensor], kt: int, s: int, bn_bwd=None, amax_out=None):
     """dg = data gradient of that convolution: dg[t] = sum_j W_j^T du[(t + pad - j) / s].  ``bn_bwd`` (stride 1, split-bf16 kernel):
     the BatchNorm-backward sums of dg against (a, sign image, vec) from the kernel's epilogue -> partials, else None."""
     pad = (kt - 1) // 2
     T, Tp = dg.shape[1], du.shape[1]
     if s == 1 and "t_t4" in W:
-        return ops.tconv_halo(du, W["t_t4"], dg, Th=T, taps=kt, tb=-1, tc=pad, bn_bwd=bn_bwd)
+        return ops.tconv_halo(du, W["t_t4"], dg, Th=T, taps=kt, tb=-1, tc=pad, bn_bwd=bn_bwd, amax_out=amax_out)
     elif s == 2 and "t_t4_e" in W and pad % 2 == 0:
         # frame t = 2*th + par only meets taps j = 2j' + par, at du frame th + pad/2 - j'
-        ops.tconv_halo(du, W["t_t4_e"], dg, Th=(T + 1) // 2, taps=(kt + 1) // 2, tb=-1, tc=pad // 2, out_view=(2, 0))
+        ops.tconv_halo(du, W["t_t4_e"], dg, Th=(T + 1) // 2, taps=(kt + 1) // 2, tb=-1, tc=pad // 2, out_view=(2, 0), amax_out=amax_out)
         if T > 1:
-            ops.tconv_halo(du, W["t_t4_o"], dg, Th=T // 2, taps=kt // 2, tb=-1, tc=pad // 2, out_view=(2, 1))
+            ops.tconv_halo(du, W["t_t4_o"], dg, Th=T // 2, taps=kt // 2, tb=-1, tc=pad // 2, out_view=(2, 1), amax_out=amax_out)
     else:
         ops.rows_gemm(du, W["t_t"], dg, K=du.shape[3], N=dg.shape[3], tmap=ops.conv_dgrad_tmap(kt, s))
 
@@ -359,6 +367,11 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     dev = x.device
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     S: Dict[str, Optional[torch.Tensor]] = {"x": x}
+    # math mode f16x2: the largest magnitudes of x and G, recorded by the kernels that stage them (pw_gemm / tconv_halo), scale the
+    # same tensors in the backward's weight gradients; slot 0 = x (only when the embedding runs on the split row GEMM), 1 = G
+    f16x2 = ops.get_math_mode() == "f16x2"
+    amax = torch.zeros(4, device=dev, dtype=torch.int32) if f16x2 else None
+    S["amax"], S["x_amax"] = amax, False
 
     # -- data-dependent adjacency ------------------------------------------------------------------------------------
     adj_a, adj_b = bufs["gcn1.adj_a"], P["gcn1.adj_b"].detach()
@@ -367,7 +380,8 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
         emb = new(B, T, V, 6 * ic)
-        pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"])
+        S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
+        pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
         part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
         c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_a, B, adj_b=adj_b)
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
@@ -403,7 +417,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
     u = new(B, Tp, V, cout)
     part = temporal_fwd(y if fuse_g else g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
-                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None)
+                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None, amax_out=amax[1:2] if f16x2 else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     if cfg.residual == "none":
@@ -551,10 +565,16 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
     fuse_sums = (BN_SUMS_IN_DGRAD and train and s == 1 and not cfg.has_down and S["g_sign"] is not None and "t_t4" in W
                  and ops.tconv_halo_bn_sums())
-    g_partials = temporal_dgrad(du, dg, W, kt, s, bn_bwd=(S["y"], S["g_sign"], S["vec_y"]) if fuse_sums else None)
+    # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
+    # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
+    f16x2 = S.get("amax") is not None and ops.get_math_mode() == "f16x2" and ("t_t4" in W or "t_t4_e" in W)
+    bamax = torch.zeros(4, device=dev, dtype=torch.int32) if f16x2 else None
+    g_partials = temporal_dgrad(du, dg, W, kt, s, bn_bwd=(S["y"], S["g_sign"], S["vec_y"]) if fuse_sums else None,
+                                amax_out=bamax[0:1] if f16x2 else None)
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
     with wgrad():
-        G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout))
+        G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout),
+                                                amax=(S["amax"][1:2], bamax[0:1]) if f16x2 else None)
     G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
@@ -580,6 +600,10 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
     a_hat = S["a_hat"]
     c3 = 3 * cin
+    # dagg = dy . Wd first: in math mode f16x2 the row GEMM records max |dy| (slot 3), the operand scale of conv_d's weight gradient
+    dagg = new(B, T, V, c3)
+    dy_amax = f16x2 and pw_routed(W, "d_t", dy, cout)
+    pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     with wgrad():
         if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
@@ -587,16 +611,15 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
             gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
         else:
             agg = new(B, T, V, c3)
-            mix_agg(x, agg, a_hat, cin)
-            gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true))   # (3, cout, cin_true, 1, 1)
+            agg_amax = mix_agg(x, agg, a_hat, cin, amax_out=bamax[2:3] if dy_amax else None)
+            gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true),   # (3, cout, cin_true, 1, 1)
+                                amax=(bamax[2:3], bamax[3:4]) if agg_amax else None)
             del agg
     dbias = None if train else ops.col_sum(dy, cout)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
-    dagg = new(B, T, V, c3)
-    pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3)
     if FUSED_DAGG and x.shape[3] == cin:
         part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:
@@ -613,9 +636,11 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         emb = S["emb"]
         demb = new(B, T, V, 6 * ic)
         gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
+        demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)
+        pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live, amax_out=bamax[1:2] if demb_amax else None)
         with wgrad():
-            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true))     # (6ic, cin_true, 1, 1)
-        pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live)
+            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
+                                amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic

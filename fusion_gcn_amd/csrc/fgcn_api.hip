@@ -12,6 +12,8 @@ static int g_tuning[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
 static int g_math_mode = FGCN_MATH_F32;
 int math_mode() { return g_math_mode; }
+static int g_products = FGCN_PRODUCTS_BF16X3;
+int products() { return g_products; }
 }  // namespace fgcn
 
 extern "C" int fgcn_set_math_mode(int mode) {
@@ -22,6 +24,15 @@ extern "C" int fgcn_set_math_mode(int mode) {
 }
 
 extern "C" int fgcn_get_math_mode(void) { return fgcn::g_math_mode; }
+
+extern "C" int fgcn_set_products(int products) {
+    if (products != FGCN_PRODUCTS_BF16X3 && products != FGCN_PRODUCTS_F16X2)
+        return fgcn::fail(FGCN_E_BADARG, "set_products: %d is not FGCN_PRODUCTS_BF16X3 / _F16X2", products);
+    fgcn::g_products = products;
+    return FGCN_OK;
+}
+
+extern "C" int fgcn_get_products(void) { return fgcn::g_products; }
 
 extern "C" int fgcn_set_tuning(int key, int value) {
     if (key < 0 || key >= 16) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);

@@ -45,7 +45,9 @@ inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 // workgroups per CU, 1: 2); key 5: XCD-aware workgroup order, bit 0 row GEMM (off), bit 1 halo conv (off), bit 2
 // disables it for the weight gradient (on by default), bit 3 disables the column-tile-fastest grid of the row GEMM.
 int tuning(int key);
-int math_mode();   // FGCN_MATH_F32 / FGCN_MATH_BF16 (fgcn_set_math_mode)
+int math_mode();   // FGCN_MATH_F32 / FGCN_MATH_BF16 / FGCN_MATH_BF16X3 (fgcn_set_math_mode)
+int products();    // FGCN_PRODUCTS_BF16X3 / FGCN_PRODUCTS_F16X2 inside FGCN_MATH_BF16X3 (fgcn_set_products)
+inline bool f16x2_products() { return math_mode() == FGCN_MATH_BF16X3 && products() == FGCN_PRODUCTS_F16X2; }
 
 // ---- device: MFMA 32x32x2 f32 -----------------------------------------------------------------------------
 // A operand: lane l holds A[i = l & 31][k = l >> 5];  B operand: lane l holds B[k = l >> 5][j = l & 31];
@@ -121,6 +123,49 @@ __device__ __forceinline__ f32x4 mfma_x3_k32(const u32x4v (&a)[3], const u32x4v 
     c = mfma_bf16_k32(a[1], b[0], c);
     c = mfma_bf16_k32(a[0], b[1], c);
     return mfma_bf16_k32(a[0], b[0], c);
+}
+
+// ---- FGCN_MATH_F16X2: f32 products from two-way f16 splits, block-scaled -----------------------------------------------------------
+// x * 2^e = h + l with h = f16(x 2^e), l = f16(x 2^e - h): 11 + 11 significand bits and the sign of l give |x 2^e - h - l| <= 2^-24 |x 2^e|
+// while l stays a normal f16 (|x 2^e| >= 2^-2), an absolute 2^-25 below; a.b from three products (l.h, h.l, h.h; l.l <= 2^-24 |a.b| is
+// dropped) -- half of bf16x3's matrix work.  f16 has 5 exponent bits, so every operand block is scaled by a power of two (exact) that
+// puts its largest magnitude into [2^14, 2^15): activations per staged (tile, channel chunk) inside the kernels, weights per packed
+// form (fgcn_pack_run_scaled); the accumulator carries the scale and the epilogue removes it.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ f32x4 mfma_f16_k32(u32x4v a, u32x4v b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_h2_k32(const u32x4v (&a)[2], const u32x4v (&b)[2], f32x4 c) {
+    c = mfma_f16_k32(a[1], b[0], c);
+    c = mfma_f16_k32(a[0], b[1], c);
+    return mfma_f16_k32(a[0], b[0], c);
+}
+__device__ __forceinline__ void split_f16_pair(float a0, float a1, unsigned& h, unsigned& l) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+    const f16x2 hh = __builtin_convertvector(f32x2{a0, a1}, f16x2);
+    const f32x2 back = __builtin_convertvector(hh, f32x2);
+    const f16x2 ll = __builtin_convertvector(f32x2{a0 - back[0], a1 - back[1]}, f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void split2h_x4(f32x4 a, u32x2& h, u32x2& l) {
+    unsigned h0, l0, h1, l1;
+    split_f16_pair(a[0], a[1], h0, l0);
+    split_f16_pair(a[2], a[3], h1, l1);
+    h = u32x2{h0, h1};
+    l = u32x2{l0, l1};
+}
+
+// power-of-two scale 2^s with amax * 2^s in [2^14, 2^15) from the float bits of amax >= 0 (0, denormals: s = 0); returned as the
+// exponent s (so that callers can take min / differences) -- exp2i(s) is the float
+__device__ __forceinline__ int scale_exp_for(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);           // biased exponent: amax in [2^(e-127), 2^(e-126))
+    return e == 0 ? 0 : 141 - e;                              // 14 - (e - 127)
+}
+__device__ __forceinline__ float exp2i(int s) {               // 2^s for s in [-126, 127]
+    s = s < -126 ? -126 : (s > 127 ? 127 : s);
+    return __builtin_bit_cast(float, (unsigned)(s + 127) << 23);
 }
 
 template <int MM> struct Frag;

@@ -108,6 +108,7 @@ struct MixVP {
     const float* mats;
     int B, T, V, ld_in, ld_out, n_mats, mats_batched, n_items, t_chunk;
     float* colsum;   // optional: per-workgroup column sums of everything this launch writes, [B * chunks][ld_out]
+    unsigned* amax;  // optional: receives max |value written| (integer atomic maximum of the float bits: order-independent)
     unsigned in_bytes, out_bytes;
     struct Item {  // dword fields only: the kernel reads them with scalar loads (16-bit fields went through vector memory)
         int out_c, nterms, img[3], in_c[3];
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
         uoff[s] = (lane_ok && u < V) ? (unsigned)(u * p.ld_out + VW * l31) * 4u : OOB;
     }
     const float* arow = &img[h * 32 + l31];
+    float wmax = 0.f;                                 // (p.amax) largest magnitude this lane wrote; padding rows / lanes hold exact zeros
 
     for (int t = t0 + wave; t < t1; t += 4) {
         const unsigned frame = (unsigned)(n * p.T + t) * (unsigned)V;
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
                 for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
                 if constexpr (ACC) v += __builtin_bit_cast(vec, old[r]);
                 MixVec<VW>::store(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
+#pragma unroll
+                for (int m = 0; m < VW; ++m) wmax = fmaxf(wmax, fabsf(v[m]));
             }
             if constexpr (!ACC) {
                 if (p.colsum) {   // wave-uniform.  Rows >= V and absent channels are exact zeros (zero-padded images / loads)
@@ -224,6 +228,11 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
                 }
             }
         }
+    }
+    if (p.amax) {                                     // (kernel-uniform)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d));
+        if (lane == 0) atomicMax(p.amax, __builtin_bit_cast(unsigned, wmax));
     }
     if (p.colsum) {
         __syncthreads();
@@ -879,7 +888,7 @@ extern "C" int fgcn_adj_softmax_bwd(const float* partial, int nchunk, float scal
 extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
                                   int ld_in, int ld_out, int n_mats, int mats_batched,
                                   const fgcn_mixv_item* items, int n_items, int vw, int accumulate,
-                                  float* colsum_partial, void* stream) {
+                                  float* colsum_partial, unsigned* out_amax, void* stream) {
     FGCN_REQUIRE(in && out && mats && items, FGCN_E_BADARG, "joint_mix_vec: null pointer");
     FGCN_REQUIRE(!(colsum_partial && accumulate), FGCN_E_BADARG, "joint_mix_vec: column sums only without accumulation");
     FGCN_REQUIRE(B > 0 && B <= 65535 && T > 0 && V > 0 && V <= FGCN_MAX_V, FGCN_E_BADARG,
@@ -899,6 +908,7 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     p.n_mats = n_mats; p.mats_batched = mats_batched; p.n_items = n_items;
     p.t_chunk = pick_t_chunk(B, T);
     p.colsum = colsum_partial;
+    p.amax = out_amax;
     for (int i = 0; i < n_items; ++i) {
         const fgcn_mixv_item& it = items[i];
         FGCN_REQUIRE(it.nterms >= 1 && it.nterms <= 3 && it.nch >= vw && it.nch <= 32 * vw && it.nch % vw == 0 &&

@@ -53,12 +53,50 @@ __global__ __launch_bounds__(256) void pack_run_kernel(const fgcn_pack_item* ite
         const int k = it.mode == FGCN_PACK_SPLIT3_ACC ? 16 * (kg >> 1) + 4 * (kg & 1) + (j & 3) + 8 * (j >> 2) : 8 * kg + j;
         v[j] = k < it.K ? pack_fetch(it, tap, k, n) : 0.f;
     }
+    if (it.mode == FGCN_PACK_SPLIT2H) {
+        // high / low f16 parts of W * 2^s, s from the form's maximum (header word 0, written by pack_amax_kernel)
+        const float sc = exp2i(scale_exp_for(*reinterpret_cast<const unsigned*>(it.dst)));
+        u32x2 h0, l0, h1, l1;
+        split2h_x4(f32x4{v[0], v[1], v[2], v[3]} * sc, h0, l0);
+        split2h_x4(f32x4{v[4], v[5], v[6], v[7]} * sc, h1, l1);
+        unsigned short* d2 = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(it.dst) + 16);
+        const long long plane2 = (long long)it.taps * KG * N * 8;
+        *reinterpret_cast<u32x4v*>(d2 + u * 8) = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+        *reinterpret_cast<u32x4v*>(d2 + plane2 + u * 8) = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+        return;
+    }
     u32x4v q[3];
     split3_x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], q);
     unsigned short* dst = reinterpret_cast<unsigned short*>(it.dst);
     const long long plane = (long long)it.taps * KG * N * 8;
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4v*>(dst + p * plane + u * 8) = q[p];
+}
+
+// FGCN_PACK_SPLIT2H, pass 1 and 2: header word 0 of every such form = 0, then = float bits of max |W| (non-negative floats order like
+// their bit patterns, and an integer maximum does not depend on the order of the updates: reproducible)
+__global__ void pack_zero_kernel(const fgcn_pack_item* items, int n_items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items && items[i].mode == FGCN_PACK_SPLIT2H) *reinterpret_cast<unsigned*>(items[i].dst) = 0u;
+}
+
+__global__ __launch_bounds__(256) void pack_amax_kernel(const fgcn_pack_item* items, const int* blockmap) {
+    const fgcn_pack_item& it = items[blockmap[2 * blockIdx.x]];
+    if (it.mode != FGCN_PACK_SPLIT2H) return;                        // (workgroup-uniform)
+    const long long u = (long long)blockmap[2 * blockIdx.x + 1] * 256 + threadIdx.x;
+    const int N = it.N, KG = it.kgroups;
+    float m = 0.f;
+    if (u < (long long)it.taps * KG * N) {
+        const int n = (int)(u % N);
+        const long long tk = u / N;
+        const int kg = (int)(tk % KG), tap = (int)(tk / KG);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (8 * kg + j < it.K) m = fmaxf(m, fabsf(pack_fetch(it, tap, 8 * kg + j, n)));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(it.dst), __builtin_bit_cast(unsigned, m));
 }
 
 }  // namespace fgcn
@@ -70,6 +108,7 @@ extern "C" int fgcn_pack_kgroups(int mode, int K) {
         case FGCN_PACK_PLAIN: return K;
         case FGCN_PACK_K4: return (K + 3) / 4;
         case FGCN_PACK_SPLIT3: return (K + 7) / 8;
+        case FGCN_PACK_SPLIT2H: return (K + 7) / 8;
         case FGCN_PACK_SPLIT3_ACC: return (K + 15) / 16 * 2;
         default: return -1;
     }
@@ -86,4 +125,14 @@ extern "C" int fgcn_pack_run(const fgcn_pack_item* items_dev, const int* blockma
     hipLaunchKernelGGL(pack_run_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, (hipStream_t)stream, items_dev,
                        blockmap_dev);
     return launch_status("pack_run");
+}
+
+extern "C" int fgcn_pack_run_scaled(const fgcn_pack_item* items_dev, const int* blockmap_dev, int n_workgroups, int n_items,
+                                    void* stream) {
+    FGCN_REQUIRE(items_dev && blockmap_dev && n_workgroups > 0 && n_items > 0, FGCN_E_BADARG, "pack_run_scaled: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_zero_kernel, dim3((unsigned)cdiv(n_items, 256)), dim3(256), 0, s, items_dev, n_items);
+    hipLaunchKernelGGL(pack_amax_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, s, items_dev, blockmap_dev);
+    hipLaunchKernelGGL(pack_run_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, s, items_dev, blockmap_dev);
+    return launch_status("pack_run_scaled");
 }

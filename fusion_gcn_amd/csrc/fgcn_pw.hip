@@ -10,7 +10,10 @@
 // tile boundaries the same way.  MFMA core, LDS image (unpadded 128-byte bf16 rows, 32-byte blocks XOR-swizzled by row bits:
 // conflict-free ds_read_b128), 2 x 2 wave arrangement, weight form (fgcn_pack_split3) and XCD-aware tile order (column tiles of a row
 // tile back to back on one XCD) are the halo kernel's.
-//   NP = bf16 parts per operand: 3 (FGCN_MATH_BF16X3: six partial products, f32 accuracy) or 1 (FGCN_MATH_BF16).
+//   NP = parts per operand: 3 (FGCN_MATH_BF16X3: six bf16 partial products, f32 accuracy), 1 (FGCN_MATH_BF16), or 2 = two f16 parts and
+//        three products (FGCN_PRODUCTS_F16X2, fgcn_common.hpp): the rows of a chunk are scaled by 2^ea as they are split, ea from the
+//        chunk's largest magnitude (wave maxima through four LDS words ahead of the barrier that exists anyway); the accumulators are
+//        rescaled (a power of two: exact) whenever the scale moves, and the epilogue multiplies 2^-ea 2^-ew back out.
 //   NT = 1 / 2: 64 / 128 output columns per tile.
 #include "fgcn_common.hpp"
 
@@ -19,20 +22,21 @@ namespace fgcn {
 struct PwP {
     const float* in;
     float* out;
-    const void* w3;                     // [part][K/8][N][8] bf16
+    const void* w3;                     // [part][K/8][N][8] bf16; NP == 2: FGCN_PACK_SPLIT2H (16-byte header, then two f16 parts)
     const float* bias;
     float* stats;                       // float[tiles_m][2][N] or NULL: per row tile, sum and sum of squares of the values written
     long long M;
     unsigned in_bytes, w_plane_bytes, out_bytes;
     int K, N, ld_in, ld_out, accumulate;
     int tiles_m, tiles_n, per_xcd, wg_per_xcd;
+    unsigned* in_amax;                  // NP == 2: receives max |in| over everything staged (integer atomic maximum of the float bits) or NULL
 };
 
 using u32x4p = __attribute__((ext_vector_type(4))) unsigned int;
 
 template <int NT, int NP>
 __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
-    static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 3), "64 / 128 columns, one or three bf16 parts");
+    static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 2 || NP == 3), "64 / 128 columns; one or three bf16 parts, or two f16 parts");
     constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     constexpr int TPR = KC / 4, RPP = 256 / TPR, NST = BMR / RPP;      // 16 threads per row, 16 rows per pass, 8 passes
     constexpr unsigned OOB = 0x80000000u;
@@ -45,7 +49,12 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     const int wr = wave >> 1, wc = wave & 1;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const unsigned char*>(p.w3) + (NP == 2 ? 16 : 0)), 0, p.w_plane_bytes * NP, 0x00020000);
+    constexpr int EA_NONE = 1000;                                    // "no scale yet" (every chunk so far was all zeros)
+    const int ew = NP == 2 ? scale_exp_for(*reinterpret_cast<const unsigned*>(p.w3)) : 0;
+    float* smax = reinterpret_cast<float*>(Xh + NP * plane);         // NP == 2: the four waves' chunk maxima
+    int ea = EA_NONE, abound = 0;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : p.w3), 0,
                                                                            p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
@@ -78,12 +87,19 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                                           rin, kok ? src_off[i] : OOB, (unsigned)kc * 4u, 0));
     };
     auto deposit = [&]() {
+        const float a_scale = ea == EA_NONE ? 1.f : exp2i(ea);
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int r = tid / TPR + RPP * i;
             u32x2 ph, pm, pl;
-            split3_x4(stage[i], ph, pm, pl);
             unsigned char* dst = Xh + r * XS + ((unsigned)((tid % TPR) * 8) ^ swz(r));
+            if constexpr (NP == 2) {
+                split2h_x4(stage[i] * a_scale, ph, pm);
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                continue;
+            }
+            split3_x4(stage[i], ph, pm, pl);
             *reinterpret_cast<u32x2*>(dst) = ph;
             if constexpr (NP == 3) {
                 *reinterpret_cast<u32x2*>(dst + plane) = pm;
@@ -121,8 +137,45 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) acc[mt][nu] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (NP == 2) {
+            ea = EA_NONE;
+            abound = 0;
+        }
         for (int kc = 0; kc < p.K; kc += KC) {
+            if constexpr (NP == 2) {                                 // this wave's largest magnitude of the chunk now parked in registers
+                float m = 0.f;
+#pragma unroll
+                for (int i = 0; i < NST; ++i)
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(stage[i][0]), fabsf(stage[i][1]))), fmaxf(fabsf(stage[i][2]), fabsf(stage[i][3])));
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+                if (lane == 0) smax[wave] = m;
+            }
             __syncthreads();                                         // the previous chunk's (or tile's) LDS reads are done
+            if constexpr (NP == 2) {
+                const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 127));
+                if (p.in_amax && tid == 0 && bn == 0) atomicMax(p.in_amax, mb);   // (the column tiles of a row tile stage the same rows)
+                // the chunk's scale: its own (largest magnitude into [2^14, 2^15)) whenever the accumulators can follow -- down always
+                // (exact), up while their magnitude bound stays below 2^120 (abound: log2 bound of |acc| in units of the scale in
+                // force; a chunk adds at most 2^44 per accumulator) -- so every chunk is split at full f16 resolution unless the
+                // chunks of one tile span more than ~2^75
+                if (ec != EA_NONE && ec != ea) {
+                    int d = ea == EA_NONE ? 0 : ec - ea;
+                    if (d > 120 - abound) d = 120 - abound;
+                    if (ea == EA_NONE) ea = ec;
+                    else if (d != 0) {
+                        const float f = exp2i(d);
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                            for (int nu = 0; nu < NU; ++nu) acc[mt][nu] *= f;
+                        ea += d;
+                        abound += d;
+                    }
+                }
+                abound = (abound > 44 ? abound : 44) + 1;
+            }
             deposit();
             __syncthreads();
             const bool last_chunk = kc + KC >= p.K;
@@ -148,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) {
                         if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                        else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu & 1], acc[mt][nu]);
                         else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
                     }
                 }
@@ -158,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
         // (col l15, g4) = row 4 g4 + r of its 16 x 16 tile) ------------------------------------------------------------------
         const long long m0 = (long long)bm * BMR;
         const int col = bn * BN + wc * NT * 32 + l15;
-        float ssum[NU], ssq[NU], bv[NU];
+        const float un_a = (NP == 2 && ea != EA_NONE) ? exp2i(-ea) : 1.f, un_w = NP == 2 ? exp2i(-ew) : 1.f;   // (two factors: the sum of
+        float ssum[NU], ssq[NU], bv[NU];                                                                        // the exponents may exceed 126)
         unsigned coff[NU];
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) {
@@ -188,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
-                    const float val = acc[mt][nu][r] + bv[nu] + old[r];
+                    const float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu] + old[r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
                     const float kept = off != OOB ? val : 0.f;
                     ssum[nu] += kept;
@@ -237,7 +292,7 @@ extern "C" int fgcn_pw_gemm_available(void) {
 }
 
 extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
-                            int K, int N, int ld_in, int ld_out, int accumulate, void* stream) {
+                            int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream) {
     FGCN_REQUIRE(in && out && w3 && rows > 0, FGCN_E_BADARG, "pw_gemm: null pointer or no rows");
     FGCN_REQUIRE(fgcn_pw_gemm_available(), FGCN_E_BADARG, "pw_gemm: a split-bf16 math mode (bf16x3 / bf16) only");
     FGCN_REQUIRE(K > 0 && K % 32 == 0 && N > 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N,
@@ -252,6 +307,7 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
     p.M = rows;
     p.in_bytes = (unsigned)in_bytes; p.out_bytes = (unsigned)out_bytes; p.w_plane_bytes = (unsigned)plane;
     p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out; p.accumulate = accumulate;
+    p.in_amax = fgcn::f16x2_products() ? in_amax : nullptr;
     const bool narrow = N <= 64;
     p.tiles_m = (int)cdiv(rows, 128);
     p.tiles_n = (int)cdiv(N, narrow ? 64 : 128);
@@ -264,14 +320,16 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
     if (fgcn::tuning(8) == 1) per = p.per_xcd;
     p.wg_per_xcd = p.per_xcd < per ? p.per_xcd : per;
     const dim3 grid((unsigned)(p.wg_per_xcd * 8));
-    const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
-    const size_t lds = (size_t)128 * 128 * (one ? 1 : 3);
+    const bool one = fgcn::math_mode() == FGCN_MATH_BF16, two = fgcn::f16x2_products();
+    const size_t lds = (size_t)128 * 128 * (one ? 1 : (two ? 2 : 3)) + 16;
     hipStream_t s = (hipStream_t)stream;
     if (narrow) {
         if (one) hipLaunchKernelGGL((pw_x3_kernel<1, 1>), grid, dim3(256), lds, s, p);
+        else if (two) hipLaunchKernelGGL((pw_x3_kernel<1, 2>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((pw_x3_kernel<1, 3>), grid, dim3(256), lds, s, p);
     } else {
         if (one) hipLaunchKernelGGL((pw_x3_kernel<2, 1>), grid, dim3(256), lds, s, p);
+        else if (two) hipLaunchKernelGGL((pw_x3_kernel<2, 2>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((pw_x3_kernel<2, 3>), grid, dim3(256), lds, s, p);
     }
     return launch_status("pw_gemm");

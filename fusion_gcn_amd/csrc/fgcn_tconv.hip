@@ -53,6 +53,7 @@ struct HaloP {
     const float* fin_res;               // the shortcut operand, laid out like `in`
     float* fin_out;                     // G, laid out like `in`
     unsigned char* fin_mask;            // rows * K / 8 bytes
+    unsigned* in_amax;                  // NP == 2: receives max |in| over everything staged (integer atomic maximum of the float bits) or NULL
 };
 
 #ifndef FGCN_HALO_PF64
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
     static_assert(MTW == 3 || MTW == 4, "wave tile: 48 or 64 rows");
     constexpr int BMR = 32 * MTW;                    // output rows per workgroup
-    static_assert(NP == 1 || NP == 3, "one or three bf16 parts per operand");
+    static_assert(NP == 1 || NP == 2 || NP == 3, "one or three bf16 parts per operand, or two f16 parts (FGCN_PRODUCTS_F16X2)");
+    static_assert(!(FIN && NP == 2), "the fused input stage is not built for the f16x2 products");
     static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
     // Image rows are KC bf16 = 64 / 128 bytes with NO padding; the 32-byte blocks of a row are XOR-swizzled with row bits instead.
     // A fragment read is ds_read_b128 of (row base + l15, 16-byte chunk g4 [+ 4 per 32-channel step]); its four lane groups are the
@@ -356,7 +358,15 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     const unsigned k4b = (tid % TPR) * 16;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w4, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const unsigned char*>(p.w4) + (NP == 2 ? 16 : 0)), 0, p.w_bytes, 0x00020000);
+    // NP == 2 (f16x2 products, fgcn_common.hpp): block scaling.  The staged chunk (tile + halo rows x KC channels) is scaled by 2^ea as it
+    // is split, ea from its largest magnitude (wave maxima through four LDS words); the accumulators are rescaled (a power of two:
+    // exact) whenever the scale moves, and the epilogue multiplies 2^-ea 2^-ew back out (ew: the packed form's scale, header word of
+    // FGCN_PACK_SPLIT2H).
+    constexpr int EA_NONE = 1000;
+    const int ew = NP == 2 ? scale_exp_for(*reinterpret_cast<const unsigned*>(p.w4)) : 0;
+    int ea = EA_NONE, abound = 0;
 
     bool row_ok[MTW];
     int th_lane[MTW];
@@ -448,6 +458,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             }
     };
     auto deposit = [&](int kc, int lo = 0, int hi = 64) {   // split the staged rows into the three bf16 planes
+        const float a_scale = (NP == 2 && ea != EA_NONE) ? exp2i(ea) : 1.f;
         f32x4 fsc = {0.f, 0.f, 0.f, 0.f}, fsh = fsc;
         const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc((void*)(FIN ? (void*)p.fin_out : (void*)p.out), 0,
                                                                              FIN ? p.in_bytes : 0u, 0x00020000);
@@ -486,8 +497,14 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             }
             if (i < nstage && r < p.halo_rows) {
                 u32x2 ph, pm, pl;
-                split3_x4(stage[i], ph, pm, pl);
                 unsigned char* dst = Xh + r * XS + ((unsigned)((tid % TPR) * 8) ^ swz(r));
+                if constexpr (NP == 2) {
+                    split2h_x4(stage[i] * a_scale, ph, pm);
+                    *reinterpret_cast<u32x2*>(dst) = ph;
+                    *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                    continue;
+                }
+                split3_x4(stage[i], ph, pm, pl);
                 *reinterpret_cast<u32x2*>(dst) = ph;
                 if constexpr (NP == 3) {
                     *reinterpret_cast<u32x2*>(dst + plane) = pm;
@@ -500,7 +517,19 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     u32x4v a[MTW][NP], wq[2][NP];
     load_w(wq[0], 0, 0, 0);
     if constexpr (PF) fetch(0);
+    float* smax = reinterpret_cast<float*>(Xh + NP * plane);      // NP == 2: the four waves' chunk maxima (16 bytes behind the planes)
+    auto chunk_max = [&]() {                         // this wave's largest staged magnitude -> its LDS word
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (i < nstage)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(stage[i][0]), fabsf(stage[i][1]))), fmaxf(fabsf(stage[i][2]), fabsf(stage[i][3])));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0) smax[wave] = m;
+    };
     for (int kc = 0; kc < p.K; kc += KC) {
+        if constexpr (NP == 2 && PF) chunk_max();    // (the chunk is already parked in registers)
         __syncthreads();                             // previous chunk's image reads are done
         if constexpr (FIN) {
             fetch(kc, 0, HALF);
@@ -509,6 +538,34 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             deposit(kc, HALF, NST);
         } else {
             if constexpr (!PF) fetch(kc);
+            if constexpr (NP == 2) {
+                if constexpr (!PF) {
+                    chunk_max();
+                    __syncthreads();
+                }
+                const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 127));
+                if (p.in_amax && tid == 0 && bn == 0) atomicMax(p.in_amax, mb);   // (the column tiles of a row tile stage the same rows)
+                // the chunk's scale: its own (largest magnitude into [2^14, 2^15)) whenever the accumulators can follow -- down always
+                // (exact), up while their magnitude bound stays below 2^120 (abound: log2 bound of |acc| in units of the scale in
+                // force; a chunk adds at most 2^44 per accumulator) -- so every chunk is split at full f16 resolution unless the
+                // chunks of one tile span more than ~2^75
+                if (ec != EA_NONE && ec != ea) {
+                    int d = ea == EA_NONE ? 0 : ec - ea;
+                    if (d > 120 - abound) d = 120 - abound;
+                    if (ea == EA_NONE) ea = ec;
+                    else if (d != 0) {
+                        const float f = exp2i(d);
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                            for (int nu = 0; nu < NU; ++nu) acc[mt][nu] *= f;
+                        ea += d;
+                        abound += d;
+                    }
+                }
+                abound = (abound > 44 ? abound : 44) + 1;
+            }
             deposit(kc);
         }
         __syncthreads();
@@ -527,6 +584,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
                     if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu & 1], acc[mt][nu]);
                     else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
                     if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
                 }
@@ -542,6 +600,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         (void*)(p.bias ? p.bias : p.w4), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NU], ssq[NU], bv[NU];
     unsigned coff[NU];
+    const float un_a = (NP == 2 && ea != EA_NONE) ? exp2i(-ea) : 1.f, un_w = NP == 2 ? exp2i(-ew) : 1.f;
     const bool bnb = p.bn_a != nullptr;                   // wave-uniform: BatchNorm-backward sums instead of the forward moments
     const __amdgpu_buffer_rsrc_t rba = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? p.bn_a : p.out), 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbm = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? (const void*)p.bn_mask : (const void*)p.out), 0,
@@ -599,7 +658,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
-                const float val = acc[mt][nu][r] + bv[nu] + old[r];
+                const float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu] + old[r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
                 const float kept = off != OOB ? val : 0.f;
                 if (bnb) {
@@ -665,9 +724,10 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                                int T_out_full, int out_s, int out_o,
                                int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
                                const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
-                               unsigned char* fin_mask, void* stream) {
+                               unsigned char* fin_mask, unsigned* in_amax, void* stream) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
     const bool fin = fin_vec || fin_res || fin_out || fin_mask;
+    FGCN_REQUIRE(!fin || !fgcn::f16x2_products(), FGCN_E_BADARG, "tconv_halo: the fused input stage is not built for the f16x2 products");
     FGCN_REQUIRE(!fin || (fin_vec && fin_res && fin_out && fin_mask && fgcn_tconv_halo_bn_sums() && !bn_a && !accumulate && taps > 1 &&
                           ld_in == K && in_s == 1 && in_o == 0 && Th_in == T_in_full && Th_in == Th && aligned16(fin_res) &&
                           aligned16(fin_out) && aligned16(fin_vec) && ((uintptr_t)fin_mask & 3u) == 0),
@@ -692,7 +752,8 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     // FGCN_MATH_BF16X3 / FGCN_MATH_BF16: w4 is the split form (fgcn_pack_split3: three bf16 parts of [tap][K/8][N][8]) = 6 bytes
     // per weight; the bf16 mode reads part 0 only (the round-to-nearest-even bf16 of the weight)
     const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4;
-    const long long w_bytes = (long long)taps * K * N * (mm != FGCN_MATH_F32 ? 6 : 4);   // split form in both bf16 modes
+    const bool two = fgcn::f16x2_products();                                                // FGCN_PACK_SPLIT2H weights: two f16 parts
+    const long long w_bytes = (long long)taps * K * N * (mm != FGCN_MATH_F32 ? (two ? 4 : 6) : 4);   // split form in both bf16 modes
     const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
     FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -708,6 +769,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
     p.bn_a = bn_a; p.bn_mask = bn_mask; p.bn_vec = bn_vec;
     p.fin_vec = fin_vec; p.fin_res = fin_res; p.fin_out = fin_out; p.fin_mask = fin_mask;
+    p.in_amax = fgcn::f16x2_products() ? in_amax : nullptr;
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
     const int dmax = d0 < d1 ? d1 : d0;
@@ -745,6 +807,10 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 4>),          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 2, 4>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 2, 3>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3, 3>),          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 3>),          \
@@ -767,14 +833,17 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             grid = dim3((unsigned)(p.per_xcd * 8));
         }
         // image rows: 128 (1x1, 64-channel chunks) / 64 bytes per bf16 part, unpadded (swizzled); the epilogue's 2 KB of partial sums fit
-        const size_t lds_k = pw ? (size_t)bmr * 128 * (one ? 1 : 3) : (size_t)p.halo_rows * 64 * (one ? 1 : 3);
+        const int np = one ? 1 : (two ? 2 : 3);
+        const size_t lds_k = (pw ? (size_t)bmr * 128 * np : (size_t)p.halo_rows * 64 * np) + 16;
 #define FGCN_K32_LAUNCH(NT_, KC_)                                                                                \
     do {                                                                                                         \
         if (bmr == 96) {                                                                                         \
             if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 3>), grid, dim3(256), lds_k, s, p); \
+            else if (two) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 2, 3>), grid, dim3(256), lds_k, s, p); \
             else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 3>), grid, dim3(256), lds_k, s, p);     \
         } else {                                                                                                 \
             if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 4>), grid, dim3(256), lds_k, s, p); \
+            else if (two) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 2, 4>), grid, dim3(256), lds_k, s, p); \
             else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 4>), grid, dim3(256), lds_k, s, p);     \
         }                                                                                                        \
     } while (0)

@@ -28,6 +28,11 @@ struct TWgradP {
     int chunk_mode;   // 0: accumulator j = tap j (window rows shifted by j*V); 1: accumulator j = in-channel chunk j (1x1 conv)
     int ring_rows;    // tap mode of the split-bf16 kernel, RING form: rows of the circular window image (256 or 512)
     unsigned a_bytes, g_bytes, p_bytes;
+    // FGCN_PRODUCTS_F16X2 (tconv_wgrad_x3_kernel<..., NP = 2>): float bits of max |a| and max |g| over the whole tensors, gathered by
+    // the kernels that staged them before (fgcn_tconv_halo / fgcn_pw_gemm `in_amax`); both operands are scaled by the exact power of
+    // two that puts that maximum into [2^14, 2^15) as they are split, the slabs leave with the scales multiplied back out
+    const unsigned* a_amax;
+    const unsigned* g_amax;
 };
 
 // TN = out-channel tile (64: waves = 2 column tiles x 2 row halves of the stage, 128: 4 column tiles).
@@ -196,7 +201,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 // images of the stage's rows, one per 32-channel chunk (window row chunk * X3_R + r), and the fragment of accumulator j
 // starts X3_R rows further instead of V rows further; everything else is the same kernel.
 // NP = bf16 parts per operand: 3 (FGCN_MATH_BF16X3) or 1 (FGCN_MATH_BF16: operands rounded once as the stage is written, one
-// MFMA per product group).
+// MFMA per product group); 2 = two f16 parts, three products (FGCN_PRODUCTS_F16X2; tensor-level scales, see TWgradP).
 // WV = waves per workgroup: 8 (one workgroup per CU, the next stage's rows prefetched into registers across the MFMAs) or 4 (half
 // the rows per stage, TWO workgroups per CU and no prefetch: one workgroup stages while the other multiplies, as in the halo conv).
 // RING (tap mode): consecutive stages of a sample need windows that overlap in all but X3_R rows -- [r0 + sh, r0 + sh + X3_R +
@@ -232,6 +237,12 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
     const bool strided = p.a_s != 1 || p.a_o != 0;
+    int ea = 0, eg = 0;
+    if constexpr (NP == 2) {
+        ea = min(scale_exp_for(*p.a_amax), 127);
+        eg = min(scale_exp_for(*p.g_amax), 127);
+    }
+    const float sc_a = exp2i(ea), sc_g = exp2i(eg);
 
     // staging roles: a: row tid/8 + RA*i, channels k0 + (tid%8)*4;  g: row tid/GT + GRP*i, columns n0 + (tid%GT)*4
     const int a_row = tid >> 3, a_c4 = tid & 7, g_row = tid / GT, g_c4 = tid % GT;
@@ -263,8 +274,14 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     };
     auto put_a = [&](int slot, f32x4 v) {
         u32x2 ph, pm, pl;
-        split3_x4(v, ph, pm, pl);
         unsigned char* d = Ap + slot * X3_SA + a_c4 * 8;
+        if constexpr (NP == 2) {
+            split2h_x4(v * sc_a, ph, pm);
+            *reinterpret_cast<u32x2*>(d) = ph;
+            *reinterpret_cast<u32x2*>(d + a_plane) = pm;
+            return;
+        }
+        split3_x4(v, ph, pm, pl);
         *reinterpret_cast<u32x2*>(d) = ph;
         if constexpr (NP == 3) {
             *reinterpret_cast<u32x2*>(d + a_plane) = pm;
@@ -300,22 +317,19 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
 #pragma unroll
         for (int i = 0; i < (RING ? 0 : APASS); ++i) {
             const int wr = a_row + RA * i;
-            if (i * RA < win && wr < win) {
-                u32x2 ph, pm, pl;
-                split3_x4(sa[i], ph, pm, pl);
-                unsigned char* d = Ap + wr * X3_SA + a_c4 * 8;
-                *reinterpret_cast<u32x2*>(d) = ph;
-                if constexpr (NP == 3) {
-                    *reinterpret_cast<u32x2*>(d + a_plane) = pm;
-                    *reinterpret_cast<u32x2*>(d + 2 * a_plane) = pl;
-                }
-            }
+            if (i * RA < win && wr < win) put_a(wr, sa[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 ph, pm, pl;
-            split3_x4(sg[i], ph, pm, pl);
             unsigned char* d = Gp + (g_row + GRP * i) * X3_SG + g_c4 * 8;
+            if constexpr (NP == 2) {
+                split2h_x4(sg[i] * sc_g, ph, pm);
+                *reinterpret_cast<u32x2*>(d) = ph;
+                *reinterpret_cast<u32x2*>(d + g_plane) = pm;
+                continue;
+            }
+            split3_x4(sg[i], ph, pm, pl);
             *reinterpret_cast<u32x2*>(d) = ph;
             if constexpr (NP == 3) {
                 *reinterpret_cast<u32x2*>(d + g_plane) = pm;
@@ -389,6 +403,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     if constexpr (NP == 3) acc[j][kt][nt] = mfma_x3_k32(aq[kt], gq[nt], acc[j][kt][nt]);
+                    else if constexpr (NP == 2) acc[j][kt][nt] = mfma_h2_k32(aq[kt], gq[nt], acc[j][kt][nt]);
                     else acc[j][kt][nt] = mfma_bf16_k32(aq[kt][0], gq[nt][0], acc[j][kt][nt]);
                 }
         }
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     // ---- partial slabs: [slab = split * NPARTS + part][tap][k][n] -----------------------------------------------------
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
     const int slab = blockIdx.y * NPARTS + part;
+    const float un_a = exp2i(-ea), un_g = exp2i(-eg);               // (NP == 2; 1 otherwise)
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
         const int tap = CH ? 0 : p.tap0 + j * p.tap_step;
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 for (int r = 0; r < 4; ++r) {
                     const int k = kj + 16 * kt + 4 * g4 + r;
                     const unsigned off = (k < p.K && ncol < p.N) ? (base + (unsigned)(k * p.N + ncol)) * 4u : OOB;
-                    const float val = acc[j][kt][nt][r];
+                    const float val = NP == 2 ? acc[j][kt][nt][r] * un_a * un_g : acc[j][kt][nt][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
                 }
             }
@@ -491,7 +507,8 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
 #define FGCN_TWX_ATTR(TN_)                                                                                            \
     FGCN_TWX_ATTR1(TN_, 3, 8, false); FGCN_TWX_ATTR1(TN_, 1, 8, false); FGCN_TWX_ATTR1(TN_, 3, 4, false);            \
     FGCN_TWX_ATTR1(TN_, 1, 4, false); FGCN_TWX_ATTR1(TN_, 3, 8, RG); FGCN_TWX_ATTR1(TN_, 1, 8, RG);                  \
-    FGCN_TWX_ATTR1(TN_, 3, 4, RG); FGCN_TWX_ATTR1(TN_, 1, 4, RG)
+    FGCN_TWX_ATTR1(TN_, 3, 4, RG); FGCN_TWX_ATTR1(TN_, 1, 4, RG);                                                    \
+    FGCN_TWX_ATTR1(TN_, 2, 8, false); FGCN_TWX_ATTR1(TN_, 2, 4, false); FGCN_TWX_ATTR1(TN_, 2, 8, RG); FGCN_TWX_ATTR1(TN_, 2, 4, RG)
         FGCN_TWX_ATTR(128);
         if constexpr (!CH || NTAP <= 3) { FGCN_TWX_ATTR(64); }
 #undef FGCN_TWX_ATTR
@@ -499,6 +516,7 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
         opt_in = true;
     }
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16;
+    const bool two = !one && p.a_amax && p.g_amax;                // f16x2 products (twgrad_launch cleared the pointers otherwise)
     const bool half = twgrad_x3_waves(N, CH ? 1 : 0) == 4;
     const bool ring = RG && p.ring_rows > 0;
 #define FGCN_TWX_GO(TN_, NP_, WV_, RING_) \
@@ -506,11 +524,11 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
 #define FGCN_TWX_LAUNCH(TN_)                                                                                    \
     do {                                                                                                        \
         if (ring) {                                                                                             \
-            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, RG); else FGCN_TWX_GO(TN_, 3, 4, RG); }                 \
-            else { if (one) FGCN_TWX_GO(TN_, 1, 8, RG); else FGCN_TWX_GO(TN_, 3, 8, RG); }                      \
+            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, RG); else if (two) FGCN_TWX_GO(TN_, 2, 4, RG); else FGCN_TWX_GO(TN_, 3, 4, RG); } \
+            else { if (one) FGCN_TWX_GO(TN_, 1, 8, RG); else if (two) FGCN_TWX_GO(TN_, 2, 8, RG); else FGCN_TWX_GO(TN_, 3, 8, RG); }      \
         } else {                                                                                                \
-            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, false); else FGCN_TWX_GO(TN_, 3, 4, false); }           \
-            else { if (one) FGCN_TWX_GO(TN_, 1, 8, false); else FGCN_TWX_GO(TN_, 3, 8, false); }                \
+            if (half) { if (one) FGCN_TWX_GO(TN_, 1, 4, false); else if (two) FGCN_TWX_GO(TN_, 2, 4, false); else FGCN_TWX_GO(TN_, 3, 4, false); } \
+            else { if (one) FGCN_TWX_GO(TN_, 1, 8, false); else if (two) FGCN_TWX_GO(TN_, 2, 8, false); else FGCN_TWX_GO(TN_, 3, 8, false); }      \
         }                                                                                                       \
     } while (0)
     if (N <= 64) {
@@ -524,7 +542,8 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
 
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                          int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a, int nacc, int chunk_mode,
-                         int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream, const char* what) {
+                         int shift0, int tap0, int tap_step, int taps_total, int nsplit, const unsigned* a_amax,
+                         const unsigned* g_amax, void* stream, const char* what) {
     FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "%s: null pointer", what);
     FGCN_REQUIRE(B > 0 && T_g > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0 && nsplit > 0 && nsplit <= 65535,
                  FGCN_E_BADARG, "%s: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", what, B, T_g, V, K, N, nsplit);
@@ -552,13 +571,16 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.chunk_mode = chunk_mode;
     p.win_rows = chunk_mode ? p.stage_rows : p.stage_rows + (nacc - 1) * V;
     p.a_bytes = (unsigned)a_bytes; p.g_bytes = (unsigned)g_bytes; p.p_bytes = (unsigned)p_bytes;
+    const bool two = x3 && fgcn::f16x2_products() && a_amax && g_amax;     // both maxima known: the f16x2 form
+    p.a_amax = two ? a_amax : nullptr;
+    p.g_amax = two ? g_amax : nullptr;
     const int planes = chunk_mode ? nacc : 1;
     const int tn_x3 = N <= 64 ? 64 : 128;
     const int wv_x3 = twgrad_x3_waves(N, chunk_mode);
     const int win_x3 = chunk_mode ? nacc * x3_rows(tn_x3, wv_x3) : p.win_rows;
     // tap mode, more than one tap: the circular window image (tuning key 6 bit 7 switches it off)
     p.ring_rows = (x3 && !chunk_mode && nacc > 1 && !(fgcn::tuning(6) & 128)) ? (win_x3 <= 256 ? 256 : 512) : 0;
-    const size_t np_x3 = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3, g_x3 = (size_t)x3_rows(tn_x3, wv_x3) * x3_sg(tn_x3);
+    const size_t np_x3 = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : (two ? 2 : 3), g_x3 = (size_t)x3_rows(tn_x3, wv_x3) * x3_sg(tn_x3);
     if (p.ring_rows && np_x3 * ((size_t)p.ring_rows * X3_SA + g_x3) > 160 * 1024) p.ring_rows = 0;   // (64-column tiles, 128-row stages)
     const size_t lds = x3 ? np_x3 * ((size_t)(p.ring_rows ? p.ring_rows : win_x3) * X3_SA + g_x3)
                           : (size_t)(((p.win_rows + 7) / 8) * 256 * planes + 8192) * sizeof(float);
@@ -608,11 +630,11 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
 extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                                 int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                                 int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit,
-                                void* stream) {
+                                const unsigned* a_amax, const unsigned* g_amax, void* stream) {
     FGCN_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_step >= 1 && tap0 >= 0 && tap0 + (ntaps - 1) * tap_step < taps_total,
                  FGCN_E_BADARG, "tconv_wgrad: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
     return twgrad_launch(a, g, partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s, a_o, Th_a, ntaps, 0, shift0, tap0,
-                         tap_step, taps_total, nsplit, stream, "tconv_wgrad");
+                         tap_step, taps_total, nsplit, a_amax, g_amax, stream, "tconv_wgrad");
 }
 
 /* in-channel chunks (32 channels each = one accumulator) per wave for a 1x1 weight gradient: a divisor of the chunk
@@ -626,8 +648,9 @@ extern "C" int fgcn_pw_wgrad_chunks(int K, int N) {
 }
 
 extern "C" int fgcn_pw_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
-                             int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream) {
+                             int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, const unsigned* a_amax,
+                             const unsigned* g_amax, void* stream) {
     FGCN_REQUIRE(a_s >= 1 && T_g > 0, FGCN_E_BADARG, "pw_wgrad: bad frame view");
     return twgrad_launch(a, g, partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s, a_o, T_g, fgcn_pw_wgrad_chunks(K, N), 1,
-                         0, 0, 1, 1, nsplit, stream, "pw_wgrad");
+                         0, 0, 1, 1, nsplit, a_amax, g_amax, stream, "pw_wgrad");
 }

@@ -17,21 +17,71 @@ from ._lib import GramItem, MixItem, MixTerm, TMap, check
 TMAP_POINTWISE = (1, 1, 0, 0, 1)
 
 
-MATH_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}     # FGCN_MATH_F32 / _BF16 / _BF16X3 (include/fgcn.h)
+MATH_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 2}     # FGCN_MATH_F32 / _BF16 / _BF16X3 (include/fgcn.h)
+# "f16x2" = FGCN_MATH_BF16X3 with FGCN_PRODUCTS_F16X2 in the convolution / 1x1 kernels: the weight forms built in this mode are
+# FGCN_PACK_SPLIT2H (``ScaledWeights``) and a kernel call takes the product form of the weights it is handed
+X3_MODES = ("bf16x3", "f16x2")        # float32-accurate split modes (every kernel outside the conv / 1x1 family is bf16x3 in both)
+_f16x2 = False
 
 
 def set_math_mode(mode: str) -> None:
     """Arithmetic of the convolution / GEMM kernels, process-wide: "f32" (default, the parity path) or "bf16" (BASELINE
     config 5: operands rounded to bfloat16 as the MFMA fragments are formed, float32 accumulation; everything in HBM,
     BatchNorm statistics, softmax and the joint mixing stay float32) or "bf16x3" (float32-accurate: operands split into
-    three bfloat16 terms, six partial products per MFMA step, float32 accumulation -- same tolerances as "f32")."""
+    three bfloat16 terms, six partial products per MFMA step, float32 accumulation -- same tolerances as "f32") or "f16x2"
+    (float32-accurate as well: bf16x3 whose temporal / 1x1 convolutions form every product from block-scaled two-way f16
+    splits, three MFMAs instead of six; include/fgcn.h FGCN_PRODUCTS_F16X2)."""
+    global _f16x2
     if mode not in MATH_MODES:
-        raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16 | bf16x3)")
+        raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16 | bf16x3 | f16x2)")
     check(_lib.load().fgcn_set_math_mode(MATH_MODES[mode]), "fgcn_set_math_mode")
+    _f16x2 = mode == "f16x2"
+    check(_lib.load().fgcn_set_products(int(_f16x2)), "fgcn_set_products")
 
 
 def get_math_mode() -> str:
-    return {v: k for k, v in MATH_MODES.items()}[_lib.load().fgcn_get_math_mode()]
+    m = _lib.load().fgcn_get_math_mode()
+    return "f16x2" if (m == 2 and _f16x2) else {0: "f32", 1: "bf16", 2: "bf16x3"}[m]
+
+
+class ScaledWeights:
+    """A FGCN_PACK_SPLIT2H form (include/fgcn.h): one device buffer = 16-byte header (float bits of max |W|) + the two f16 parts of
+    W * 2^s in the fragment order of the split kernels; what ``tconv_halo`` / ``pw_gemm`` stream with FGCN_PRODUCTS_F16X2."""
+
+    def __init__(self, taps: int, K: int, N: int, device):
+        self.taps, self.K, self.N = taps, K, N
+        self.kgroups = (K + 7) // 8
+        self.buf = torch.zeros(16 + 2 * taps * self.kgroups * N * 8 * 2, device=device, dtype=torch.uint8)
+
+    device = property(lambda self: self.buf.device)
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def amax(self) -> float:
+        return float(self.buf[:4].view(torch.float32)[0])
+
+    def parts(self) -> torch.Tensor:
+        """(2, taps, K/8, N, 8) float16 view of the two parts (tests)."""
+        return self.buf[16:].view(torch.float16).view(2, self.taps, self.kgroups, self.N, 8)
+
+
+def _use_products_of(w) -> None:
+    """The conv / 1x1 kernels take the product form of the weights they are handed (in math mode bf16x3)."""
+    if _lib.load().fgcn_get_math_mode() == 2:
+        check(_lib.load().fgcn_set_products(int(isinstance(w, ScaledWeights))), "fgcn_set_products")
+
+
+def pack_split2h(w: torch.Tensor) -> ScaledWeights:
+    """(taps, K, N) f32 packed weights -> the FGCN_PACK_SPLIT2H form (two passes on the device: maximum, then the split)."""
+    from .packing import Form, PackPlan, Seg
+    ensure_device()
+    _chk(w, "pack_split2h.w")
+    taps, K, N = w.shape
+    f = Form("split2h", taps, K, N, [Seg(w, st_tap=K * N, st_k=N, st_n=1, klen=K, nlen=N, tlen=taps)])
+    f.alloc(w.device)
+    PackPlan([f]).run()
+    return f.dst
 
 
 @contextlib.contextmanager
@@ -128,19 +178,22 @@ def pack_split3(w: torch.Tensor, acc_order: bool = False) -> torch.Tensor:
     return out
 
 
-SPLIT_MODES = ("bf16x3", "bf16")      # math modes whose halo-tile kernel streams fgcn_pack_split3 weights (bf16: part 0 only)
+SPLIT_MODES = ("bf16x3", "bf16", "f16x2")      # math modes whose halo-tile kernel streams split weights (bf16: part 0 only)
 
 
-def pack_conv(w: torch.Tensor) -> torch.Tensor:
-    """Packed (taps, K, N) weights in the form tconv_halo streams in the current math mode: ``pack_k4`` (f32) or
-    ``pack_split3`` (bf16x3, and bf16, which reads only the rounded high part)."""
-    return pack_split3(w) if get_math_mode() in SPLIT_MODES else pack_k4(w)
+def pack_conv(w: torch.Tensor):
+    """Packed (taps, K, N) weights in the form tconv_halo streams in the current math mode: ``pack_k4`` (f32),
+    ``pack_split3`` (bf16x3, and bf16, which reads only the rounded high part) or ``pack_split2h`` (f16x2)."""
+    mode = get_math_mode()
+    if mode == "f16x2":
+        return pack_split2h(w)
+    return pack_split3(w) if mode in SPLIT_MODES else pack_k4(w)
 
 
 def pack_spatial(wd: torch.Tensor, cin: int) -> torch.Tensor:
     """The stacked (K*Cin, Cout) conv_d matrix in the form spatial_fwd streams in the current math mode: ``pack_k4``
     (K*Cin/4, Cout, 4), or in bf16x3 (whole 32-channel tiles only) the accumulator-ordered three-way split."""
-    if get_math_mode() == "bf16x3" and cin % 32 == 0:
+    if get_math_mode() in X3_MODES and cin % 32 == 0:
         return pack_split3(wd.unsqueeze(0), acc_order=True)
     return pack_k4(wd.unsqueeze(0))[0]
 
@@ -153,12 +206,15 @@ def tconv_halo_bn_sums() -> bool:
 def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: int, taps: int, tb: int, tc: int,
                in_view=None, out_view=(1, 0), bias: Optional[torch.Tensor] = None, stats: bool = False,
                accumulate: bool = False, bn_bwd: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
-               fuse_in: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None) -> Optional[torch.Tensor]:
+               fuse_in: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+               amax_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Halo-tile temporal conv over virtual frames [0, Th): input frame th*in_s + in_o (th < Th_in), output frame
     th*out_s + out_o.  in_view = (in_s, in_o, Th_in); w4 from ``pack_k4``.  Returns stats partials when asked.
     ``bn_bwd = (a, sign image, vec)``: the call is the data gradient of a conv whose input was relu(BatchNorm(a) + shortcut); the
     returned partials (tiles, 2, N) then hold the BatchNorm-backward sums (sum dp, sum dp * a_hat) of what it writes
     (``bn_act_bwd(..., partials=)`` takes them instead of running its own reduction pass).
+    ``amax_out`` (math mode f16x2): a zero-initialised one-element int32 tensor that receives the float bits of max |inp| over
+    what the call stages (integer atomic maximum; several calls may share it) -- ``tconv_wgrad(amax=...)`` takes it.
     ``fuse_in = (vec, shortcut, g, g_sign)``: ``inp`` is the INPUT of a BatchNorm and the conv runs on
     g = relu(inp * scale + shift + shortcut), formed while the image is staged; g and its sign image (``bn_act``'s layout) are
     written as by-products -- the block's ``bn_act`` pass in front of the conv folded into it (split-bf16 kernel, taps > 1)."""
@@ -167,15 +223,20 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
     split = get_math_mode() in SPLIT_MODES       # the weights then are the pack_split3 form
-    if split:
+    if isinstance(w4, ScaledWeights):
+        if not split:
+            raise _lib.FgcnError("tconv_halo: FGCN_PACK_SPLIT2H weights need math mode bf16x3 / f16x2")
+        w_taps, K, N = w4.taps, w4.K, w4.N
+    elif split:
         if w4.dtype != torch.bfloat16 or w4.dim() != 5 or w4.shape[0] != 3 or w4.shape[4] != 8 or not w4.is_contiguous():
             raise _lib.FgcnError(f"tconv_halo: math mode {get_math_mode()} takes pack_split3 weights, got {w4.dtype} {tuple(w4.shape)}")
         w_taps, K, N = w4.shape[1], w4.shape[2] * 8, w4.shape[3]
     else:
         _chk(w4, "tconv_halo.w4")
         w_taps, K, N = w4.shape[0], w4.shape[1] * 4, w4.shape[2]
+    _use_products_of(w4)
     if (Bo, Vo) != (B, V) or w_taps != taps or (not split and w4.shape[3] != 4) or K > ld_in or N > ld_out:
-        raise _lib.FgcnError(f"tconv_halo: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} w4={tuple(w4.shape)}")
+        raise _lib.FgcnError(f"tconv_halo: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} weights (taps, K, N) = {(w_taps, K, N)}")
     in_s, in_o, Th_in = in_view if in_view is not None else (1, 0, T_in)
     out_s, out_o = out_view
     lib = _lib.load()
@@ -198,8 +259,9 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
             raise _lib.FgcnError("tconv_halo: fuse_in needs the (4, K) BatchNorm vector, a shortcut and an output like the input "
                                  "(contiguous, K channels) and the uint8 sign image of numel / 8 bytes")
         fin = (_p(vec), _p(res), _p(g), g_sign.data_ptr())
-    check(lib.fgcn_tconv_halo(_p(inp), _p(out), _p(w4), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
-                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, *fin, _stream()),
+    check(lib.fgcn_tconv_halo(_p(inp), _p(out), w4.data_ptr(), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
+                              T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, *fin,
+                              None if amax_out is None else amax_out.data_ptr(), _stream()),
           "fgcn_tconv_halo")
     return part
 
@@ -209,23 +271,29 @@ def pw_gemm_available() -> bool:
     return bool(_lib.load().fgcn_pw_gemm_available())
 
 
-def pw_gemm(inp: torch.Tensor, w3: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None, stats: bool = False,
-            accumulate: bool = False) -> Optional[torch.Tensor]:
+def pw_gemm(inp: torch.Tensor, w3, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None, stats: bool = False,
+            accumulate: bool = False, amax_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """1x1 convolution over all rows on the persistent split-bf16 row GEMM: inp (..., ld_in) and out (..., ld_out) contiguous with the
     same number of rows, w3 = pack_split3 of the (1, K, N) matrix.  Returns the BatchNorm partial sums (tiles, 2, N) when asked."""
     ensure_device()
     _chk(inp, "pw_gemm.in"), _chk(out, "pw_gemm.out")
-    if w3.dtype != torch.bfloat16 or w3.dim() != 5 or w3.shape[0] != 3 or w3.shape[1] != 1 or w3.shape[4] != 8 or not w3.is_contiguous():
+    if isinstance(w3, ScaledWeights):
+        if w3.taps != 1:
+            raise _lib.FgcnError("pw_gemm: a one-tap FGCN_PACK_SPLIT2H form expected")
+        K, N = w3.K, w3.N
+    elif w3.dtype != torch.bfloat16 or w3.dim() != 5 or w3.shape[0] != 3 or w3.shape[1] != 1 or w3.shape[4] != 8 or not w3.is_contiguous():
         raise _lib.FgcnError(f"pw_gemm: pack_split3 weights of a (1, K, N) matrix expected, got {w3.dtype} {tuple(w3.shape)}")
-    K, N = w3.shape[2] * 8, w3.shape[3]
+    else:
+        K, N = w3.shape[2] * 8, w3.shape[3]
+    _use_products_of(w3)
     ld_in, ld_out = inp.shape[-1], out.shape[-1]
     rows = inp.numel() // ld_in
     if out.numel() // ld_out != rows or K > ld_in or N > ld_out:
-        raise _lib.FgcnError(f"pw_gemm: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} w3={tuple(w3.shape)}")
+        raise _lib.FgcnError(f"pw_gemm: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} weights (K, N) = {(K, N)}")
     lib = _lib.load()
     part = torch.empty((lib.fgcn_pw_gemm_tiles(rows), 2, N), device=inp.device, dtype=torch.float32) if stats else None
-    check(lib.fgcn_pw_gemm(_p(inp), _p(out), w3.data_ptr(), _p(bias), _p(part), rows, K, N, ld_in, ld_out, int(accumulate), _stream()),
-          "fgcn_pw_gemm")
+    check(lib.fgcn_pw_gemm(_p(inp), _p(out), w3.data_ptr(), _p(bias), _p(part), rows, K, N, ld_in, ld_out, int(accumulate),
+                           None if amax_out is None else amax_out.data_ptr(), _stream()), "fgcn_pw_gemm")
     return part
 
 
@@ -321,10 +389,13 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
 
 def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_POINTWISE, a_coff: int = 0,
                g_coff: int = 0, out: Optional[torch.Tensor] = None, accumulate: bool = False,
-               wide: Optional[bool] = None, conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+               wide: Optional[bool] = None, conv_param: Optional[Tuple[int, int]] = None,
+               amax: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """(taps, K, N) weight gradient: sum over rows of a[src(row, tap), k] * g[row, n].  1x1 convolutions with K a multiple
     of 32 take the multi-accumulator kernel (``wide``; False forces the generic per-tap kernel).  ``conv_param`` returns
-    the gradient in the convolution parameter's own layout (see ``_reduce_slabs``)."""
+    the gradient in the convolution parameter's own layout (see ``_reduce_slabs``).  ``amax = (slot of a, slot of g)``: the
+    one-element int32 tensors in which ``tconv_halo`` / ``pw_gemm`` left the operands' largest magnitudes (math mode f16x2: the
+    split kernel then forms its products from two-way f16 splits; without them it runs bf16x3)."""
     ensure_device()
     _chk(a, "rows_wgrad.a"), _chk(g, "rows_wgrad.g")
     B, T_a, V, ld_a = a.shape
@@ -346,8 +417,11 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         nsplit = max(1, min(lib.fgcn_pw_wgrad_resident(N) // max(tiles, 1), stages))   # every workgroup resident at once
         slabs = lib.fgcn_pw_wgrad_slabs(N, nsplit)
         partial = torch.empty((slabs, K, N), device=a.device, dtype=torch.float32)
+        am = (None, None) if amax is None or a_coff or g_coff else (amax[0].data_ptr(), amax[1].data_ptr())
+        if am[0] is not None and lib.fgcn_get_math_mode() == 2:
+            check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
-                                nsplit, _stream()), "fgcn_pw_wgrad")
+                                nsplit, *am, _stream()), "fgcn_pw_wgrad")
         return _reduce_slabs(partial.view(slabs, 1, K, N), 1, K, N, out, accumulate, conv_param)
     nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
     partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
@@ -361,7 +435,8 @@ TWGRAD_TAPS = (1, 2, 3, 4, 5, 6, 9)   # taps per call the multi-tap kernel is in
 
 def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1, out: Optional[torch.Tensor] = None,
                 accumulate: bool = False, all_taps: Optional[bool] = None,
-                conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+                conv_param: Optional[Tuple[int, int]] = None,
+                amax: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """(taps, K, N) weight gradient of the (taps x 1) temporal convolution with stride ``stride`` and padding
     (taps-1)//2: all taps in one pass over the rows (one call per residue class of the tap offset when strided).
     a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` False forces the
@@ -394,8 +469,11 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
     for par, tap0, ntaps, shift0 in calls:
         th_a = (T_a - par + stride - 1) // stride
+        am = (None, None) if amax is None else (amax[0].data_ptr(), amax[1].data_ptr())
+        if am[0] is not None and lib.fgcn_get_math_mode() == 2:
+            check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
         check(lib.fgcn_tconv_wgrad(_p(a), _p(g), _p(partial), B, T_g, V, K, N, K, N, T_a, stride, par, th_a,
-                                   ntaps, shift0, tap0, stride, taps, nsplit, _stream()), "fgcn_tconv_wgrad")
+                                   ntaps, shift0, tap0, stride, taps, nsplit, *am, _stream()), "fgcn_tconv_wgrad")
     return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
@@ -458,7 +536,7 @@ MIX_MAX_ITEMS = 24   # FGCN_MIX_MAX_ITEMS (include/fgcn.h)
 
 
 def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec: Sequence[dict], *, vw: int,
-                  accumulate: bool = False, colsum: bool = False):
+                  accumulate: bool = False, colsum: bool = False, amax_out: Optional[torch.Tensor] = None):
     """Channel-group joint mix; spec: [{out_c, nch, terms: [(mat, transpose, in_c)]}].  ``colsum`` also returns the
     per-channel sums of everything written (ld_out,) -- a bias gradient without another pass over ``out``."""
     ensure_device()
@@ -481,8 +559,8 @@ def joint_mix_vec(inp: torch.Tensor, out: torch.Tensor, mats: torch.Tensor, spec
             for j, (mat, tr, in_c) in enumerate(it["terms"]):
                 arr[i].term[j] = _lib.MixVTerm(mat, tr, in_c)
         check(lib.fgcn_joint_mix_vec(_p(inp), _p(out), _p(mats), B, T, V, ld_in, out.shape[3], mats.shape[1],
-                                     int(mats.shape[0] != 1), arr, len(part), vw, int(accumulate), _p(partial), _stream()),
-              "fgcn_joint_mix_vec")
+                                     int(mats.shape[0] != 1), arr, len(part), vw, int(accumulate), _p(partial),
+                                     None if amax_out is None else amax_out.data_ptr(), _stream()), "fgcn_joint_mix_vec")
     if colsum:
         sums = torch.empty((out.shape[3],), device=inp.device, dtype=torch.float32)
         reduce_sum(partial, sums, leaf=True)          # a bias gradient: a leaf of the backward
@@ -775,7 +853,7 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat")
     B, T, V, ld_x = x.shape
     ns = a_hat.shape[1]
-    if get_math_mode() == "bf16x3" and Cin % 32 == 0:      # weights in the pack_spatial split form
+    if get_math_mode() in X3_MODES and Cin % 32 == 0:      # weights in the pack_spatial split form
         w_ok = wd.dtype == torch.bfloat16 and tuple(wd.shape) == (3, 1, ns * Cin // 8, Cout, 8) and wd.is_contiguous()
     else:
         w_ok = wd.dtype == torch.float32 and tuple(wd.shape) == (ns * Cin // 4, Cout, 4) and wd.is_contiguous()

@@ -58,7 +58,10 @@ class Form:
     def alloc(self, device) -> torch.Tensor:
         lib = _lib.load()
         kg = lib.fgcn_pack_kgroups(PACK_MODES[self.mode], self.K)
-        if self.mode in ("split3", "split3_acc"):
+        if self.mode == "split2h":
+            from .ops import ScaledWeights
+            self.dst = ScaledWeights(self.taps, self.K, self.N, device)
+        elif self.mode in ("split3", "split3_acc"):
             self.dst = torch.empty((3, self.taps, kg, self.N, 8), device=device, dtype=torch.bfloat16)
         elif self.mode == "k4":
             self.dst = torch.empty(self.shape or (self.taps, kg, self.N, 4), device=device, dtype=torch.float32)
@@ -107,12 +110,18 @@ class PackPlan:
         self.items_dev = raw.to(dev)
         self.map_dev = torch.tensor(blockmap, dtype=torch.int32).to(dev)
         self.n_wg = len(blockmap) // 2
+        self.scaled = any(f.mode == "split2h" for f in self.forms)    # FGCN_PACK_SPLIT2H items: per-form maxima first
         self.srcs = [s.src for f in self.forms for s in f.segs]        # the table holds raw pointers: keep the tensors alive
 
     def run(self) -> None:
         if self.n_wg:
-            _lib.check(_lib.load().fgcn_pack_run(self.items_dev.data_ptr(), self.map_dev.data_ptr(), self.n_wg,
-                                                 torch.cuda.current_stream(self.items_dev.device).cuda_stream), "fgcn_pack_run")
+            stream = torch.cuda.current_stream(self.items_dev.device).cuda_stream
+            if self.scaled:
+                _lib.check(_lib.load().fgcn_pack_run_scaled(self.items_dev.data_ptr(), self.map_dev.data_ptr(), self.n_wg,
+                                                            len(self.forms), stream), "fgcn_pack_run_scaled")
+            else:
+                _lib.check(_lib.load().fgcn_pack_run(self.items_dev.data_ptr(), self.map_dev.data_ptr(), self.n_wg, stream),
+                           "fgcn_pack_run")
             if self.stamp:
                 for f in self.forms:
                     f.packed = f.stamp()

@@ -71,6 +71,19 @@ int fgcn_set_tuning(int key, int value);
 #define FGCN_MATH_BF16X3 2
 int fgcn_set_math_mode(int mode);
 int fgcn_get_math_mode(void);
+/* Product form of the convolution / 1x1 kernels inside FGCN_MATH_BF16X3 (every other kernel is unaffected):
+ *   FGCN_PRODUCTS_BF16X3  six bf16 partial products from exact three-way bf16 splits (above);
+ *   FGCN_PRODUCTS_F16X2   three f16 products from two-way f16 splits: x 2^s = h + l (11 + 11 significand bits + the sign of l: within
+ *                         2^-24 |x| while l is a normal f16), l.l dropped (<= 2^-24 |a.b|) -- half the matrix work at float32-class
+ *                         accuracy.  f16 has 5 exponent bits, so every operand BLOCK is scaled by an exact power of two that puts its
+ *                         largest magnitude into [2^14, 2^15): activations per staged (row tile, channel chunk) inside the kernels
+ *                         (the accumulator carries the scale, only ever towards larger magnitudes), weights per packed form
+ *                         (FGCN_PACK_SPLIT2H).  Error model per operand element: max(2^-24 |x|, 2^-40 * block maximum).  Weights must
+ *                         then be FGCN_PACK_SPLIT2H forms. */
+#define FGCN_PRODUCTS_BF16X3 0
+#define FGCN_PRODUCTS_F16X2 1
+int fgcn_set_products(int products);
+int fgcn_get_products(void);
 
 /* Temporal index map shared by the row GEMMs: for output frame `to` and tap `j`
  *     num = to*ta + j*tb + tc ;  valid iff num >= 0, num % td == 0 and num/td < T_in ;  ti = num/td.
@@ -130,7 +143,10 @@ int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* b
                     int T_out_full, int out_s, int out_o,
                     int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
                     const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out, unsigned char* fin_mask,
-                    void* stream);
+                    unsigned* in_amax, void* stream);
+/* in_amax (may be NULL; FGCN_PRODUCTS_F16X2 only): a device word that receives, by integer atomic maximum (order-independent), the
+ * float bits of max |in| over everything this call stages -- zero it before the first call that should count; the weight gradient of
+ * the same tensor takes it as its operand scale (fgcn_tconv_wgrad). */
 
 /* partial[s][j][k][n] = sum over the s-th slice of rows m=(n,tg,v) of a[(n,ti(tg,j),v), k] * g[m, n]
  *   (weight gradient of the same convolutions; autograd backward of agcn.py:41-42,71-73,77).
@@ -155,7 +171,8 @@ int fgcn_tconv_wgrad_resident(int N);
 int fgcn_pw_wgrad_resident(int N);
 int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                      int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
-                     int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
+                     int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit,
+                     const unsigned* a_amax, const unsigned* g_amax, void* stream);
 
 /* Weight gradient of a 1x1 convolution (theta|phi embedding, conv_d on the stacked agg, down, residual): the same
  * kernel with one accumulator per 32-channel chunk of a instead of per tap (each g fragment feeds up to 6 MFMAs):
@@ -163,7 +180,12 @@ int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, int B, int 
  *   partial: float[fgcn_tconv_wgrad_slabs(N, nsplit)][K][N].  Same alignment / size rules as fgcn_tconv_wgrad. */
 int fgcn_pw_wgrad_chunks(int K, int N);
 int fgcn_pw_wgrad(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
-                  int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream);
+                  int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit,
+                  const unsigned* a_amax, const unsigned* g_amax, void* stream);
+/* a_amax / g_amax (both weight-gradient entry points; may be NULL): device words holding the float bits of max |a| / max |g| over
+ * the whole tensors, as fgcn_tconv_halo / fgcn_pw_gemm leave them in `in_amax`.  With both given and FGCN_PRODUCTS_F16X2 selected the
+ * split kernel runs its f16x2 form (operands scaled by the exact powers of two that put those maxima into [2^14, 2^15)); without
+ * them it runs the bf16x3 form. */
 
 /* dst[i] (+)= sum_s src[s*count + i]   (deterministic tree-free column sum; also bias / adj_b gradients) */
 int fgcn_reduce_sum(float* dst, const float* src, int S, long long count, int accumulate, void* stream);
@@ -213,6 +235,11 @@ int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int
 #define FGCN_PACK_K4 1
 #define FGCN_PACK_SPLIT3 2
 #define FGCN_PACK_SPLIT3_ACC 3
+/*   FGCN_PACK_SPLIT2H     FGCN_PRODUCTS_F16X2 weights: a 16-byte header whose first word holds the float bits of max |W| over the
+ *                         form, then _Float16[2][taps][ceil(K/8)][N][8] = the high / low f16 parts of W * 2^s, s = 141 - biased
+ *                         exponent of that maximum (scaled maximum in [2^14, 2^15); s = 0 for an all-zero form).  Needs
+ *                         fgcn_pack_run_scaled (the maximum is a pass of its own). */
+#define FGCN_PACK_SPLIT2H 4
 typedef struct {
     const float* src;
     long long st_tap, st_k, st_n;
@@ -226,6 +253,9 @@ typedef struct {
 int fgcn_pack_kgroups(int mode, int K);
 long long fgcn_pack_units(int mode, int taps, int K, int N);
 int fgcn_pack_run(const fgcn_pack_item* items_dev, const int* blockmap_dev, int n_workgroups, void* stream);
+/* the same for tables that hold FGCN_PACK_SPLIT2H items: three launches -- headers zeroed, per-form maxima (integer atomic max over
+ * the float bits: order-independent, so reproducible), then the pack proper */
+int fgcn_pack_run_scaled(const fgcn_pack_item* items_dev, const int* blockmap_dev, int n_workgroups, int n_items, void* stream);
 
 /* dst[j][k][n] = src[n*st_n + k*st_k + jj*st_tap], jj = flip ? taps-1-j : j ; n >= N_src zero-filled up to N_dst
  * (weight re-layout into the packed [taps][K][N] form; N_dst % 4 == 0). */
@@ -281,10 +311,12 @@ typedef struct {
 int fgcn_joint_mix_vec(const float* in, float* out, const float* mats, int B, int T, int V,
                        int ld_in, int ld_out, int n_mats, int mats_batched,
                        const fgcn_mixv_item* items, int n_items, int vw, int accumulate,
-                       float* colsum_partial, void* stream);
+                       float* colsum_partial, unsigned* out_amax, void* stream);
 /* colsum_partial (optional, only without accumulation): float[B * fgcn_joint_mix_chunks(B, T)][ld_out]; row i receives the
  * column sums of everything workgroup i wrote (the theta|phi bias gradient falls out of the embedding-gradient mix
- * instead of a separate pass over its output); channels no item writes receive 0. */
+ * instead of a separate pass over its output); channels no item writes receive 0.
+ * out_amax (optional): a device word that receives, by integer atomic maximum, the float bits of the largest magnitude written -- the
+ * operand scale of the f16x2 weight gradient that reads `out` (fgcn_pw_wgrad); zero it before the launches that should count. */
 int fgcn_joint_mix_chunks(int B, int T);
 
 typedef struct {
@@ -451,7 +483,8 @@ int fgcn_unfold_windows(const float* in, float* out, int B, int T, int T_out, in
 int fgcn_pw_gemm_available(void);
 int fgcn_pw_gemm_tiles(long long rows);
 int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
-                 int K, int N, int ld_in, int ld_out, int accumulate, void* stream);
+                 int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream);
+/* (w3: the FGCN_PACK_SPLIT2H form with FGCN_PRODUCTS_F16X2 selected; in_amax as for fgcn_tconv_halo) */
 
 /* ---- the two ends of the step: input BatchNorm and loss (fgcn_head.hip) ------------------------------------------------------
  * `data_bn` = nn.BatchNorm1d(M*V*C) over the network input x (N, M, T, V, C) viewed as (N, M*V*C, T)

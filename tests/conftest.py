@@ -43,14 +43,15 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
 
 
-# The kernel / block / model parity modules run twice on the GPU: in the default math mode (exact f32 MFMA) and in
-# "bf16x3" (f32-accurate split-bf16 products, include/fgcn.h) -- the same oracle, the same tolerances.
+# The kernel / block / model parity modules run three times on the GPU: in the default math mode (exact f32 MFMA), in "bf16x3"
+# (f32-accurate split-bf16 products, include/fgcn.h) and in "f16x2" (bf16x3 whose temporal / 1x1 convolutions form their products
+# from block-scaled two-way f16 splits, FGCN_PRODUCTS_F16X2) -- the same oracle, the same tolerances.
 BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu", "test_train_e2e_gpu", "test_imu_gcn", "test_grad_parity_gpu", "test_msg3d", "test_session_gpu"}
 
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split(".")[-1] in BOTH_MATH_MODES and "fgcn_math" in metafunc.fixturenames:
-        metafunc.parametrize("fgcn_math", ["f32", "bf16x3"], indirect=True)
+        metafunc.parametrize("fgcn_math", ["f32", "bf16x3", "f16x2"], indirect=True)
 
 
 @pytest.fixture(autouse=True)

@@ -206,7 +206,7 @@ def test_persistent_pointwise_gemm(rows, K, N, ld_in, ld_out):
     bias = rnd(N, seed=202)
     base = rnd(rows, 1, 1, ld_out, seed=203)
     want = x[..., :K].reshape(rows, K) @ w[0] + bias
-    w3 = ops.pack_split3(to_gpu(w))
+    w3 = ops.pack_conv(to_gpu(w))                       # pack_split3, or the block-scaled two-way f16 split in math mode f16x2
     out = to_gpu(base)
     part = ops.pw_gemm(to_gpu(x), w3, out, bias=to_gpu(bias), stats=True)
     got = out.view(rows, ld_out).cpu().double()
@@ -228,7 +228,7 @@ def test_persistent_pointwise_gemm(rows, K, N, ld_in, ld_out):
     assert rel_l2(acc.view(rows, ld_out)[:, :N].cpu().numpy(), want_acc.numpy()) < FWD_TOL
     with ops.math_mode("bf16"):
         outb = to_gpu(base)
-        ops.pw_gemm(to_gpu(x), w3, outb, bias=to_gpu(bias))
+        ops.pw_gemm(to_gpu(x), ops.pack_conv(to_gpu(w)), outb, bias=to_gpu(bias))
         assert rel_l2(outb.view(rows, ld_out)[:, :N].cpu().numpy(), want.numpy()) < 2e-2
 
 
@@ -239,8 +239,8 @@ def test_halo_temporal_conv_with_the_input_stage_fused(B, T, V, C):
     BatchNorm partial sums, G and the sign image written as by-products -- all bit for bit, they are the same arithmetic -- plus
     the conv output against the float64 formula.  Tiles straddle samples; T < the 8-frame halo is included."""
     from fusion_gcn_amd import ops
-    if not ops.tconv_halo_bn_sums():
-        pytest.skip("the fused input stage is built for the split-bf16 halo kernel")
+    if not ops.tconv_halo_bn_sums() or ops.get_math_mode() == "f16x2":
+        pytest.skip("the fused input stage is built for the split-bf16 halo kernel (bf16x3 / bf16 products)")
     kt = 9
     wt = rnd(kt, C, C, seed=180, scale=(kt * C) ** -0.5)
     bias = rnd(C, seed=181)
@@ -745,3 +745,49 @@ def test_cross_entropy_matches_torch(rows, classes):
     assert float(base.grad[:, classes:].abs().max()) == 0.0 if npad > classes else True
     again = loss_fn(base.detach()[:, :classes], y.to(dev()))
     assert torch.equal(again, got.detach())
+
+
+@pytest.mark.parametrize("B,T,V,K,N,kt,stride", [(2, 40, 25, 64, 64, 9, 1), (3, 33, 25, 128, 128, 9, 1), (2, 21, 25, 128, 128, 9, 2),
+                                                 (2, 16, 27, 256, 256, 9, 1), (2, 30, 25, 128, 192, 1, 1), (2, 24, 22, 256, 384, 1, 1)])
+def test_weight_gradient_from_two_way_f16_splits(B, T, V, K, N, kt, stride):
+    """Math mode f16x2: the all-taps / 1x1 weight gradient with its operands scaled by the maxima that the data-path kernels of the
+    same tensors recorded (tconv_halo / pw_gemm ``amax_out``) -- against float64, at the f32 tolerance; the recorded maxima are
+    the tensors' true maxima; operands spanning 2^-20 .. 2^20 around unit scale keep the accuracy (power-of-two scaling is exact)."""
+    from fusion_gcn_amd import ops
+    if ops.get_math_mode() != "f16x2":
+        pytest.skip("f16x2 products only")
+    for scale_a, scale_g in ((1.0, 1.0), (2.0 ** -20, 2.0 ** 17)):
+        Tg = (T - 1) // stride + 1
+        a, g = rnd(B, T, V, K, seed=300) * scale_a, rnd(B, Tg, V, N, seed=301) * scale_g
+        ag, gg = to_gpu(a), to_gpu(g)
+        slots = torch.zeros(2, device=dev(), dtype=torch.int32)
+        if kt > 1:
+            # what the block does: forward conv stages a (= G), data gradient stages g (= dU)
+            w = rnd(kt, K, N, seed=302, scale=(kt * K) ** -0.5)
+            wf, wb = ops.pack_conv(to_gpu(w)), ops.pack_conv(to_gpu(w.permute(0, 2, 1)))
+            if stride == 1:
+                ops.tconv_halo(ag, wf, torch.empty(B, Tg, V, N, device=dev()), Th=T, taps=kt, tb=1, tc=-4, amax_out=slots[0:1])
+                ops.tconv_halo(gg, wb, torch.empty(B, T, V, K, device=dev()), Th=T, taps=kt, tb=-1, tc=4, amax_out=slots[1:2])
+            else:
+                slots[0] = torch.tensor(float(ag.abs().max())).view(torch.int32)      # (any writer of the true maxima will do)
+                slots[1] = torch.tensor(float(gg.abs().max())).view(torch.int32)
+            got = ops.tconv_wgrad(ag, gg, taps=kt, stride=stride, amax=(slots[0:1], slots[1:2]))
+            tm = ops.conv_tmap(kt, stride)
+        else:
+            wa = ops.pack_conv(to_gpu(rnd(1, K, 64, seed=303, scale=K ** -0.5)))
+            wg_ = ops.pack_conv(to_gpu(rnd(1, N, 64, seed=304, scale=N ** -0.5)))
+            ops.pw_gemm(ag, wa, torch.empty(B, T, V, 64, device=dev()), amax_out=slots[0:1])
+            ops.pw_gemm(gg, wg_, torch.empty(B, Tg, V, 64, device=dev()), amax_out=slots[1:2])
+            got = ops.rows_wgrad(ag, gg, K=K, N=N, amax=(slots[0:1], slots[1:2]))
+            tm = ops.TMAP_POINTWISE
+        rec = slots.view(torch.float32).cpu()
+        assert float(rec[0]) == float(ag.abs().max()) and float(rec[1]) == float(gg.abs().max())
+        want = torch.zeros(kt, K, N, dtype=torch.float64)
+        taps, ta, tb, tc, td = tm
+        for to in range(Tg):
+            for j in range(taps):
+                num = to * ta + j * tb + tc
+                if num < 0 or num % td or num // td >= T:
+                    continue
+                want[j] += torch.einsum("bvk,bvn->kn", a[:, num // td], g[:, to])
+        assert rel_l2(got.cpu().numpy().reshape(kt, K, N), want.numpy()) < RED_TOL, (scale_a, scale_g)

@@ -87,7 +87,7 @@ def bench_pw(B, reps):
         fl, by = 2.0 * rows * K * N, 4.0 * rows * (K + N)
         ms = timeit(lambda: ops.rows_gemm(x, w, y, K=K, N=N, stats=True), reps)
         report(f"{name:7s} K{K:3d} N{N:3d} T{T}: f32 row GEMM", ms, fl, by)
-        w3 = ops.pack_split3(w)
+        w3 = ops.pack_conv(w)
         if K % 64 == 0:
             ms = timeit(lambda: ops.tconv_halo(x, w3, y, Th=T, taps=1, tb=1, tc=0, stats=True), reps)
             report("            halo kernel, one tap", ms, fl, by)
@@ -105,7 +105,7 @@ def bench_tconv(B, reps):
     """Halo-tile temporal conv: forward / data gradient, stride 1 and the parity-split stride 2; tuning key 4 picks the
     register budget (2 or 3 workgroups per CU)."""
     lib = _lib.load()
-    x3 = ops.get_math_mode() == "bf16x3"
+    x3 = ops.get_math_mode() in ops.X3_MODES
     for three in ((0,) if x3 else (0, 1)):
         lib.fgcn_set_tuning(4, three)
         print("-- conv_halo" + ("" if x3 else f", workgroups per CU hint = {3 - three}"))
@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
-    ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3"), help="fgcn_set_math_mode")
+    ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3", "f16x2"), help="fgcn_set_math_mode")
     args = ap.parse_args()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
