@@ -144,11 +144,11 @@ def time_dominant_kernel(device, b_local: int, reps: int = 10, widths=(64, 128, 
     return out
 
 
-def cpu_baseline(n_clips: int = 16, iters: int = 2, device=None, math: str = "bf16x3"):
+def cpu_baseline(n_clips: int = 16, iters: int = 2, device=None, maths=("bf16x3",)):
     """Reported baseline, not the target: the oracle model, fwd+bwd, on the host cores of this box.
     torch's CPU convolutions stop scaling (and then collapse) well below the 256 hardware threads of the GPU box,
     so the thread count is calibrated on one clip first and the best one is used and reported as ``cores``.
-    -> (cpu_baseline dict, parity_at_full_shape dict or None).  With ``device`` the oracle's results on those n_clips clips of the
+    -> (cpu_baseline dict, {math mode: parity_at_full_shape dict} or None).  With ``device`` the oracle's results on those n_clips clips of the
     FULL (C,T,V,M) shape are not thrown away: the HIP model is loaded with the same state and run on the same clips, and logits,
     loss and the flat gradient (with ReLU-flip accounting, oracle/relu_masks.py) are compared -- the oracle as the checker."""
     from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
@@ -198,17 +198,19 @@ def cpu_baseline(n_clips: int = 16, iters: int = 2, device=None, math: str = "bf
         import math as _m
         from fusion_gcn_amd import ops as _ops
         hip = hip.to(device).train()
-        with _ops.math_mode(math):
-            rep = RM.gradient_parity_report(hip, x.to(device), y.to(device), oracle=oracle)
-        bound = 1e-4 + 2.0 * _m.sqrt(rep["flips"] / (rep["decisions"] / 20))
-        parity = {"clips": n_clips, "shape_CTVM": [SHAPE["C"], SHAPE["T"], SHAPE["V"], SHAPE["M"]], "math": math,
-                  "against": "float32 CPU oracle run of cpu_baseline (same state, same clips)",
-                  "logits_rel_l2": float(f"{rep['logits_err']:.3e}"), "loss_abs_err": float(f"{rep['loss_err']:.3e}"),
-                  "relu_flips": rep["flips"], "relu_decisions": rep["decisions"],
-                  "flat_grad_rel_l2_as_is": float(f"{rep['err_plain']:.3e}"),
-                  "flat_grad_rel_l2_with_oracle_relu_decisions": float(f"{rep['err_injected']:.3e}"),
-                  "ok": bool(rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5 and rep["err_injected"] < 1e-4
-                             and rep["err_plain"] <= bound)}
+        parity = {}
+        for math in maths:
+            with _ops.math_mode(math):
+                rep = RM.gradient_parity_report(hip, x.to(device), y.to(device), oracle=oracle)
+            bound = 1e-4 + 2.0 * _m.sqrt(rep["flips"] / (rep["decisions"] / 20))
+            parity[math] = {"clips": n_clips, "shape_CTVM": [SHAPE["C"], SHAPE["T"], SHAPE["V"], SHAPE["M"]], "math": math,
+                            "against": "float32 CPU oracle run of cpu_baseline (same state, same clips)",
+                            "logits_rel_l2": float(f"{rep['logits_err']:.3e}"), "loss_abs_err": float(f"{rep['loss_err']:.3e}"),
+                            "relu_flips": rep["flips"], "relu_decisions": rep["decisions"],
+                            "flat_grad_rel_l2_as_is": float(f"{rep['err_plain']:.3e}"),
+                            "flat_grad_rel_l2_with_oracle_relu_decisions": float(f"{rep['err_injected']:.3e}"),
+                            "ok": bool(rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5 and rep["err_injected"] < 1e-4
+                                       and rep["err_plain"] <= bound)}
         del hip
     return base, parity
 
@@ -307,6 +309,8 @@ def main():
                          "config 5 (bf16 MFMA operands, f32 accumulation)")
     ap.add_argument("--no-f32-mode", action="store_true",
                     help="N = 1 only: skip the secondary timing of the exact-f32-MFMA mode (f32_mfma_mode)")
+    ap.add_argument("--no-f16x2-mode", action="store_true",
+                    help="N = 1 only: skip the secondary timing of the f16x2 products (f16x2_mode)")
     ap.add_argument("--verify-dp", action="store_true",
                     help="N > 1 only: check the exchanged gradient buffer of the (graph) step against an eager step")
     ap.add_argument("--no-other-scaling", action="store_true",
@@ -575,6 +579,25 @@ def main():
                     "ms_per_step": round(1e3 * el_f / args.steps, 3), "loss": round(float(loss_f), 5), "launch": mode_f}
         _ops.set_math_mode(args.math)
         del step_f
+    f16x2_mode = None
+    if world == 1 and args.math == "bf16x3" and not args.no_f16x2_mode:
+        # the same step with the temporal / 1x1 convolutions and their weight gradients on block-scaled two-way f16 splits (three
+        # MFMAs per product group instead of six; float32-class: tests/test_f16x2_edge_gpu.py) -- reported beside
+        # the headline, which stays on the arithmetic the earlier rounds were judged on
+        _ops.set_math_mode("f16x2")
+        step_h, mode_h = make_step(x, y)
+        el_h, loss_h = timed(step_h, args.steps, args.warmup)
+        kern_h = None if args.no_kernel_timing else time_dominant_kernel(device, n_local * SHAPE["M"], widths=(256,))
+        f16x2_mode = {"value": round(n_global * args.steps / el_h, 2), "unit": "clips/s",
+                      "ms_per_step": round(1e3 * el_h / args.steps, 3), "loss": round(float(loss_h), 5), "launch": mode_h,
+                      "dtype": MATH_DTYPE["f16x2"]}
+        if kern_h:
+            f16x2_mode["dominant_kernel"] = {"kernel": MATH_KERNEL["f16x2"].format(nt2=2) + " (9x1 temporal conv forward, 256 channels)",
+                                             "ms_per_launch": round(kern_h[0]["ms"], 4), "achieved_tflops": round(kern_h[0]["tflops"], 2),
+                                             "peak_tflops": round(PEAK_SPLIT2H_TFLOPS, 1),
+                                             "frac": round(kern_h[0]["tflops"] / PEAK_SPLIT2H_TFLOPS, 4)}
+        _ops.set_math_mode(args.math)
+        del step_h
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         clips_per_s = n_global * args.steps / elapsed
@@ -626,13 +649,18 @@ def main():
                                               for d in kern]}
         if f32_mode:
             out["f32_mfma_mode"] = f32_mode
+        if f16x2_mode:
+            out["f16x2_mode"] = f16x2_mode
         if other:
             out["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on the host cores")
-            out["cpu_baseline"], parity = cpu_baseline(device=device, math=args.math)
+            also = ("f16x2",) if f16x2_mode else ()
+            out["cpu_baseline"], parity = cpu_baseline(device=device, maths=(args.math,) + also)
             if parity is not None:
-                out["parity_at_full_shape"] = parity
+                out["parity_at_full_shape"] = parity[args.math]
+                if f16x2_mode:
+                    out["f16x2_mode"]["parity_at_full_shape"] = parity["f16x2"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pack_run_kernel(const fgcn_pack_item* ite
     }
     if (it.mode == FGCN_PACK_SPLIT2H) {
         // high / low f16 parts of W * 2^s, s from the form's maximum (header word 0, written by pack_amax_kernel)
-        const float sc = exp2i(scale_exp_for(*reinterpret_cast<const unsigned*>(it.dst)));
+        const float sc = exp2i(min(scale_exp_for(*reinterpret_cast<const unsigned*>(it.dst)), 126));
         u32x2 h0, l0, h1, l1;
         split2h_x4(f32x4{v[0], v[1], v[2], v[3]} * sc, h0, l0);
         split2h_x4(f32x4{v[4], v[5], v[6], v[7]} * sc, h1, l1);

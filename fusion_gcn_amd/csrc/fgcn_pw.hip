@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(p.w3) + (NP == 2 ? 16 : 0)), 0, p.w_plane_bytes * NP, 0x00020000);
     constexpr int EA_NONE = 1000;                                    // "no scale yet" (every chunk so far was all zeros)
-    const int ew = NP == 2 ? scale_exp_for(*reinterpret_cast<const unsigned*>(p.w3)) : 0;
+    const int ew = NP == 2 ? min(scale_exp_for(*reinterpret_cast<const unsigned*>(p.w3)), 126) : 0;
     float* smax = reinterpret_cast<float*>(Xh + NP * plane);         // NP == 2: the four waves' chunk maxima
     int ea = EA_NONE, abound = 0;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
             __syncthreads();                                         // the previous chunk's (or tile's) LDS reads are done
             if constexpr (NP == 2) {
                 const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
-                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 127));
+                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 126));
                 if (p.in_amax && tid == 0 && bn == 0) atomicMax(p.in_amax, mb);   // (the column tiles of a row tile stage the same rows)
                 // the chunk's scale: its own (largest magnitude into [2^14, 2^15)) whenever the accumulators can follow -- down always
                 // (exact), up while their magnitude bound stays below 2^120 (abound: log2 bound of |acc| in units of the scale in

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     // exact) whenever the scale moves, and the epilogue multiplies 2^-ea 2^-ew back out (ew: the packed form's scale, header word of
     // FGCN_PACK_SPLIT2H).
     constexpr int EA_NONE = 1000;
-    const int ew = NP == 2 ? scale_exp_for(*reinterpret_cast<const unsigned*>(p.w4)) : 0;
+    const int ew = NP == 2 ? min(scale_exp_for(*reinterpret_cast<const unsigned*>(p.w4)), 126) : 0;
     int ea = EA_NONE, abound = 0;
 
     bool row_ok[MTW];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                     __syncthreads();
                 }
                 const unsigned mb = __builtin_bit_cast(unsigned, fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
-                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 127));
+                const int ec = __builtin_amdgcn_readfirstlane((mb >> 23) == 0u ? EA_NONE : min(scale_exp_for(mb), 126));
                 if (p.in_amax && tid == 0 && bn == 0) atomicMax(p.in_amax, mb);   // (the column tiles of a row tile stage the same rows)
                 // the chunk's scale: its own (largest magnitude into [2^14, 2^15)) whenever the accumulators can follow -- down always
                 // (exact), up while their magnitude bound stays below 2^120 (abound: log2 bound of |acc| in units of the scale in

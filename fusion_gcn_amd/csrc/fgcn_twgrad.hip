@@ -239,8 +239,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     const bool strided = p.a_s != 1 || p.a_o != 0;
     int ea = 0, eg = 0;
     if constexpr (NP == 2) {
-        ea = min(scale_exp_for(*p.a_amax), 127);
-        eg = min(scale_exp_for(*p.g_amax), 127);
+        ea = min(scale_exp_for(*p.a_amax), 126);                // (2^-ea must be a normal float too)
+        eg = min(scale_exp_for(*p.g_amax), 126);
     }
     const float sc_a = exp2i(ea), sc_g = exp2i(eg);
 

@@ -2,7 +2,7 @@
 # Same-box A/B of bench.py flag sets (run on the GPU box from the repo root): tools/ab_flags.sh "<flags A>" "<flags B>" ...
 # Boxes of the pool differ by +-2-3 %, so only numbers from ONE call compare.
 mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/ab.log
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-kernel-timing"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing"
 for rep in 1 2; do
 for t in "$@"; do
     echo "== $t" >> gpurun_out/ab/ab.log

@@ -9,7 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 # 1. whole step, every kernel on one stream (true per-kernel durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o step_serial -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline \
-    --no-f32-mode --no-kernel-timing --no-graph --wgrad-stream main > $out/step_serial.log 2>&1
+    --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-graph --wgrad-stream main > $out/step_serial.log 2>&1
 # 2. the dominant kernel alone (22 launches at its dominant shape)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o dominant -- python3 bench.py --kernel-only > $out/dominant.log 2>&1
 # 3. HBM-side traffic of the dominant kernel: FETCH_SIZE and WRITE_SIZE in separate passes
