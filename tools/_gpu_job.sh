@@ -1,9 +1,14 @@
 set -x
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout -k 10 600 python -m pytest tests/test_f16x2_edge_gpu.py -q -s > gpurun_out/t11_edge.log 2>&1; echo "edge tests rc=$?"
-grep -E "passed|failed|^FAILED" gpurun_out/t11_edge.log | tail -8
-timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/t11_all.log 2>&1; echo "gpu tests rc=$?"
-tail -8 gpurun_out/t11_all.log
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/t11_bench.json 2> gpurun_out/t11_bench.err; echo "bench rc=$?"
-tail -2 gpurun_out/t11_bench.err; cut -c1-300 gpurun_out/t11_bench.json
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --math f16x2"
+for rep in 1 2; do
+  for mk in 128 64; do
+    for clips in 64 8; do
+      steps=10; [ $clips = 8 ] && steps=30
+      r=$(FGCN_PW_MIN_K=$mk $B --batch $clips --steps $steps 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['loss'])" 2>&1)
+      echo "f16x2 pw_min_k=$mk clips=$clips : $r" >> gpurun_out/t13_ab.log
+    done
+  done
+done
+cat gpurun_out/t13_ab.log
+timeout -k 10 300 python tools/rccl_world1_check.py --steps 12 > gpurun_out/t13_rccl.json 2> gpurun_out/t13_rccl.err; echo "rccl rc=$?"; cat gpurun_out/t13_rccl.json
