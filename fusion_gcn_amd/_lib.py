@@ -48,7 +48,7 @@ class PackSeg(C.Structure):
 
 
 PACK_MAX_SEG = 6            # FGCN_PACK_MAX_SEG
-PACK_MODES = {"plain": 0, "k4": 1, "split3": 2, "split3_acc": 3, "split2h": 4}       # FGCN_PACK_*
+PACK_MODES = {"plain": 0, "k4": 1, "split3": 2, "split3_acc": 3, "split2h": 4, "split2h_acc": 5}       # FGCN_PACK_*
 
 
 class PackItem(C.Structure):

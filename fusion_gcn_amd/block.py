@@ -129,7 +129,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     d_rows = [Seg(w, st_k=1, st_n=cin, klen=cin, nlen=cout, k0=k * cx) for k, w in enumerate(wd)]          # (3cx, cout)
     F["d"] = Form("plain", 1, 3 * cx, cout, d_rows, shape=(3 * cx, cout))
     if mode in ops.X3_MODES and cx % 32 == 0:        # the fused spatial kernel's form (ops.pack_spatial)
-        F["d4"] = Form("split3_acc", 1, 3 * cx, cout, d_rows)
+        F["d4"] = Form("split2h_acc" if mode == "f16x2" else "split3_acc", 1, 3 * cx, cout, d_rows)
     else:
         F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
     d_cols = [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, n0=k * cx) for k, w in enumerate(wd)]          # (1, cout, 3cx)

@@ -140,6 +140,15 @@ __device__ __forceinline__ f32x4 mfma_h2_k32(const u32x4v (&a)[2], const u32x4v 
     c = mfma_f16_k32(a[0], b[1], c);
     return mfma_f16_k32(a[0], b[0], c);
 }
+// the same three products on v_mfma_f32_32x32x16_f16 (the fused spatial forward's shape)
+__device__ __forceinline__ f32x16 mfma_f16_k16(u32x4v a, u32x4v b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_h2_k16(const u32x4v (&a)[2], const u32x4v (&b)[2], f32x16 c) {
+    c = mfma_f16_k16(a[1], b[0], c);
+    c = mfma_f16_k16(a[0], b[1], c);
+    return mfma_f16_k16(a[0], b[0], c);
+}
 __device__ __forceinline__ void split_f16_pair(float a0, float a1, unsigned& h, unsigned& l) {
     using f32x2 = __attribute__((ext_vector_type(2))) float;
     using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
@@ -166,6 +175,26 @@ __device__ __forceinline__ int scale_exp_for(unsigned amax_bits) {
 __device__ __forceinline__ float exp2i(int s) {               // 2^s for s in [-126, 127]
     s = s < -126 ? -126 : (s > 127 ? 127 : s);
     return __builtin_bit_cast(float, (unsigned)(s + 127) << 23);
+}
+
+// eight values (one lane's fragment) -> the two f16 parts, 16 bytes each
+__device__ __forceinline__ void split2h_x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float sc,
+                                           u32x4v (&q)[2]) {
+    u32x2 h0, l0, h1, l1;
+    split2h_x4(f32x4{v0, v1, v2, v3} * sc, h0, l0);
+    split2h_x4(f32x4{v4, v5, v6, v7} * sc, h1, l1);
+    q[0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+    q[1] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+}
+__device__ __forceinline__ float wave_max_abs16(const float (&v)[16], float m) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(v[i]));
+    return m;
+}
+__device__ __forceinline__ float wave_reduce_max(float m) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    return m;
 }
 
 template <int MM> struct Frag;

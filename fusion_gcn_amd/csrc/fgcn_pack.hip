@@ -24,6 +24,11 @@ __device__ __forceinline__ float pack_fetch(const fgcn_pack_item& it, int tap, i
     return v;
 }
 
+// contraction index of element j of k-group kg: fragment order, or the order in which a 32x32 accumulator enumerates its rows
+__device__ __forceinline__ int pack_k(int mode, int kg, int j) {
+    return (mode == FGCN_PACK_SPLIT3_ACC || mode == FGCN_PACK_SPLIT2H_ACC) ? 16 * (kg >> 1) + 4 * (kg & 1) + (j & 3) + 8 * (j >> 2) : 8 * kg + j;
+}
+
 __global__ __launch_bounds__(256) void pack_run_kernel(const fgcn_pack_item* items, const int* blockmap) {
     const fgcn_pack_item& it = items[blockmap[2 * blockIdx.x]];
     const long long u = (long long)blockmap[2 * blockIdx.x + 1] * 256 + threadIdx.x;
@@ -50,10 +55,10 @@ __global__ __launch_bounds__(256) void pack_run_kernel(const fgcn_pack_item* ite
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = it.mode == FGCN_PACK_SPLIT3_ACC ? 16 * (kg >> 1) + 4 * (kg & 1) + (j & 3) + 8 * (j >> 2) : 8 * kg + j;
+        const int k = pack_k(it.mode, kg, j);
         v[j] = k < it.K ? pack_fetch(it, tap, k, n) : 0.f;
     }
-    if (it.mode == FGCN_PACK_SPLIT2H) {
+    if (it.mode == FGCN_PACK_SPLIT2H || it.mode == FGCN_PACK_SPLIT2H_ACC) {
         // high / low f16 parts of W * 2^s, s from the form's maximum (header word 0, written by pack_amax_kernel)
         const float sc = exp2i(min(scale_exp_for(*reinterpret_cast<const unsigned*>(it.dst)), 126));
         u32x2 h0, l0, h1, l1;
@@ -77,12 +82,13 @@ __global__ __launch_bounds__(256) void pack_run_kernel(const fgcn_pack_item* ite
 // their bit patterns, and an integer maximum does not depend on the order of the updates: reproducible)
 __global__ void pack_zero_kernel(const fgcn_pack_item* items, int n_items) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_items && items[i].mode == FGCN_PACK_SPLIT2H) *reinterpret_cast<unsigned*>(items[i].dst) = 0u;
+    if (i < n_items && (items[i].mode == FGCN_PACK_SPLIT2H || items[i].mode == FGCN_PACK_SPLIT2H_ACC))
+        *reinterpret_cast<unsigned*>(items[i].dst) = 0u;
 }
 
 __global__ __launch_bounds__(256) void pack_amax_kernel(const fgcn_pack_item* items, const int* blockmap) {
     const fgcn_pack_item& it = items[blockmap[2 * blockIdx.x]];
-    if (it.mode != FGCN_PACK_SPLIT2H) return;                        // (workgroup-uniform)
+    if (it.mode != FGCN_PACK_SPLIT2H && it.mode != FGCN_PACK_SPLIT2H_ACC) return;      // (workgroup-uniform)
     const long long u = (long long)blockmap[2 * blockIdx.x + 1] * 256 + threadIdx.x;
     const int N = it.N, KG = it.kgroups;
     float m = 0.f;
@@ -91,8 +97,10 @@ __global__ __launch_bounds__(256) void pack_amax_kernel(const fgcn_pack_item* it
         const long long tk = u / N;
         const int kg = (int)(tk % KG), tap = (int)(tk / KG);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (8 * kg + j < it.K) m = fmaxf(m, fabsf(pack_fetch(it, tap, 8 * kg + j, n)));
+        for (int j = 0; j < 8; ++j) {
+            const int k = pack_k(it.mode, kg, j);
+            if (k < it.K) m = fmaxf(m, fabsf(pack_fetch(it, tap, k, n)));
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
@@ -109,6 +117,7 @@ extern "C" int fgcn_pack_kgroups(int mode, int K) {
         case FGCN_PACK_K4: return (K + 3) / 4;
         case FGCN_PACK_SPLIT3: return (K + 7) / 8;
         case FGCN_PACK_SPLIT2H: return (K + 7) / 8;
+        case FGCN_PACK_SPLIT2H_ACC: return (K + 15) / 16 * 2;
         case FGCN_PACK_SPLIT3_ACC: return (K + 15) / 16 * 2;
         default: return -1;
     }

@@ -311,12 +311,20 @@ __global__ __launch_bounds__(256, ((CT_OUT <= 2 || (CT_OUT == 4 && (CT_IN <= 2 |
 // Same accumulator-as-operand chain, weight format (fgcn_pack_split3, acc_order), epilogue and statistics as above.
 constexpr int AHB = 80;    // bytes per [w] row of a split A^ plane (32 joints x bf16 + 16 pad: conflict-free b128 reads)
 
-template <int CT_IN>
+// NP = 3: three bf16 parts per operand, six products (FGCN_PRODUCTS_BF16X3).  NP = 2: two f16 parts, three products
+// (FGCN_PRODUCTS_F16X2, fgcn_common.hpp) with power-of-two block scales, all of them wave-private because the waves of this kernel are
+// independent: x per (frame pair, channel tile) from the wave's largest |x| (ex), A^ per workgroup as it is written to LDS (eA), the
+// aggregation per (tile, subset) from the wave's largest accumulator of step 1 (e2), the weights per packed form (ew, header of
+// FGCN_PACK_SPLIT2H_ACC).  The step-2 accumulators carry S = ex + eA + e2 + ew; when a tile's natural S differs from the one in
+// force they are rescaled (a power of two: exact; upwards only while a running bound of log2 |acc| stays below 120, the remainder goes
+// into e2) and the epilogue multiplies 2^-S back out.
+template <int CT_IN, int NP = 3>
 __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
+    static_assert(NP == 2 || NP == 3, "three bf16 parts or two f16 parts");
     constexpr int CT_OUT = 2, WROW = CT_OUT * 32;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char* ahs = reinterpret_cast<unsigned char*>(smem);      // [3 subsets][3 parts][32 w][AHB]
+    unsigned char* ahs = reinterpret_cast<unsigned char*>(smem);      // [3 subsets][NP parts][32 w][AHB]
     float* st = smem + (9 * 32 * AHB) / 4;                            // [4 waves][2][WROW]
     float* tt = st + 4 * 2 * WROW;                                    // [4 waves][32][TTS]
     float* bl = tt + 4 * 32 * TTS;                                    // [WROW]
@@ -338,20 +346,42 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
     const int t1 = min(t0 + p.t_chunk, p.T);
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wd, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const unsigned char*>(p.wd) + (NP == 2 ? 16 : 0)), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.y + ((long long)n * p.T + t0) * V * p.ld_y), 0, (unsigned)((t1 - t0) * V * p.ld_y) * 4u, 0x00020000);
 
     const float* asrc = p.a_hat + (p.a_batched ? (long long)n * NS * V * V : 0);
+    int eA = 0;                                                       // NP == 2: scale of this sample's A^ images
+    if constexpr (NP == 2) {
+        float m = 0.f;
+        for (int i = tid; i < 3 * 32 * 32; i += 256) {
+            const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
+            m = fmaxf(m, (k < NS && v < V && w < V) ? fabsf(asrc[(k * V + v) * V + w]) : 0.f);
+        }
+        m = wave_reduce_max(m);
+        if (lane == 0) bl[wave] = m;                                  // (bl is written again below, behind the barrier)
+        __syncthreads();
+        eA = __builtin_amdgcn_readfirstlane(min(scale_exp_for(__builtin_bit_cast(unsigned, fmaxf(fmaxf(bl[0], bl[1]), fmaxf(bl[2], bl[3])))), 126));
+        __syncthreads();
+    }
+    const float scA = exp2i(eA);
     for (int i = tid; i < 3 * 32 * 32; i += 256) {
         const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
         const float a = (k < NS && v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
-        unsigned ph, pm, pl;
-        split_bf16_pair(a, 0.f, ph, pm, pl);
-        unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * 3) * 32 + w) * AHB) + v;
-        d[0] = (unsigned short)ph;
-        d[32 * AHB / 2] = (unsigned short)pm;
-        d[2 * 32 * AHB / 2] = (unsigned short)pl;
+        unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * NP) * 32 + w) * AHB) + v;
+        if constexpr (NP == 2) {
+            unsigned ph, pl;
+            split_f16_pair(a * scA, 0.f, ph, pl);
+            d[0] = (unsigned short)ph;
+            d[32 * AHB / 2] = (unsigned short)pl;
+        } else {
+            unsigned ph, pm, pl;
+            split_bf16_pair(a, 0.f, ph, pm, pl);
+            d[0] = (unsigned short)ph;
+            d[32 * AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * AHB / 2] = (unsigned short)pl;
+        }
     }
     for (int i = tid; i < 4 * 2 * WROW; i += 256) st[i] = 0.f;
     const int ob = bz * WROW;
@@ -377,14 +407,16 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                                                                                    (unsigned)vs * row_b, 0));
         }
     };
-    u32x4v w3[CT_OUT][3];
-    auto load_w3 = [&](int ci, int k, int gp, int ot, u32x4v (&wv)[3]) {
+    u32x4v w3[CT_OUT][NP];
+    auto load_w3 = [&](int ci, int k, int gp, int ot, u32x4v (&wv)[NP]) {
         const unsigned so = (unsigned)((((k * p.Cin + ci * 32) >> 4) + gp) * 2 * p.Cout) * 16u;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
             wv[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[ot], so + pl * p.w_plane_bytes, 0);
     };
-    const unsigned char* af_lane = ahs + l31 * AHB + 16 * h;           // + (k*3 + part) * 32 * AHB + 32 * s
+    const unsigned char* af_lane = ahs + l31 * AHB + 16 * h;           // + (k*NP + part) * 32 * AHB + 32 * s
+    const int ew = NP == 2 ? min(scale_exp_for(*reinterpret_cast<const unsigned*>(p.wd)), 126) : 0;
+    constexpr int S_NONE = 100000;
 
     float xr[2][16];
     load_x(t0 + 2 * wave, 0, xr[0]);
@@ -399,28 +431,47 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int i = 0; i < CT_OUT; ++i) acc[f][i] = zero16();
+        int S = S_NONE, abound = 0;                                   // NP == 2: scale exponent the accumulators carry, log2 bound of |acc|
 
 #pragma unroll 1
         for (int ci = 0; ci < CT_IN; ++ci) {
-            u32x4v xs[2][2][3];                                       // [frame][16-joint step][part]
+            u32x4v xs[2][2][NP];                                      // [frame][16-joint step][part]
+            int ex = 0;
+            if constexpr (NP == 2) {
+                const float m = wave_reduce_max(wave_max_abs16(xr[1], wave_max_abs16(xr[0], 0.f)));
+                ex = __builtin_amdgcn_readfirstlane(min(scale_exp_for(__builtin_bit_cast(unsigned, m)), 126));
+                const float scx = exp2i(ex);
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
+                for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    split3_x8(xr[f][8 * s2], xr[f][8 * s2 + 1], xr[f][8 * s2 + 2], xr[f][8 * s2 + 3], xr[f][8 * s2 + 4],
-                              xr[f][8 * s2 + 5], xr[f][8 * s2 + 6], xr[f][8 * s2 + 7], xs[f][s2]);
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        split2h_x8(xr[f][8 * s2], xr[f][8 * s2 + 1], xr[f][8 * s2 + 2], xr[f][8 * s2 + 3], xr[f][8 * s2 + 4],
+                                   xr[f][8 * s2 + 5], xr[f][8 * s2 + 6], xr[f][8 * s2 + 7], scx, xs[f][s2]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        split3_x8(xr[f][8 * s2], xr[f][8 * s2 + 1], xr[f][8 * s2 + 2], xr[f][8 * s2 + 3], xr[f][8 * s2 + 4],
+                                  xr[f][8 * s2 + 5], xr[f][8 * s2 + 6], xr[f][8 * s2 + 7], xs[f][s2]);
+            }
             // one subset: step 1 for both frames, then step 2; `last` (compile time) = the tile's final subset, after whose
             // step 1 the split x is dead and the next tile's x is requested into the same registers
             auto subset = [&](int k, auto last) {
                 f32x16 agg[2] = {zero16(), zero16()};
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    u32x4v af[3];
+                    u32x4v af[NP];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * 3 + pl) * 32 * AHB + 32 * s2);
-                    agg[0] = mfma_x3_k16(xs[0][s2], af, agg[0]);
-                    agg[1] = mfma_x3_k16(xs[1][s2], af, agg[1]);
+                    for (int pl = 0; pl < NP; ++pl)
+                        af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * NP + pl) * 32 * AHB + 32 * s2);
+                    if constexpr (NP == 2) {
+                        agg[0] = mfma_h2_k16(xs[0][s2], af, agg[0]);
+                        agg[1] = mfma_h2_k16(xs[1][s2], af, agg[1]);
+                    } else {
+                        agg[0] = mfma_x3_k16(xs[0][s2], af, agg[0]);
+                        agg[1] = mfma_x3_k16(xs[1][s2], af, agg[1]);
+                    }
                 }
                 if constexpr (decltype(last)::value) {
                     if (ci + 1 < CT_IN) {
@@ -429,6 +480,36 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                     } else {
                         load_x(tA + 8, 0, xr[0]);
                         load_x(tA + 9, 0, xr[1]);
+                    }
+                }
+                // NP == 2: the aggregation (in units of 2^-(ex + eA)) is split at 2^e2, e2 from the wave's largest accumulator; the
+                // step-2 accumulators then want S = ex + eA + e2 + ew -- they follow (exactly), or e2 gives way where they cannot
+                float sc2 = 1.f;
+                if constexpr (NP == 2) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(fabsf(agg[0][r]), fabsf(agg[1][r])));
+                    const unsigned mb = __builtin_bit_cast(unsigned, wave_reduce_max(m));
+                    if ((mb >> 23) != 0u) {                           // (wave-uniform; an all-zero aggregation adds nothing)
+                        int e2 = __builtin_amdgcn_readfirstlane(min(scale_exp_for(mb), 126));
+                        const int want = ex + eA + e2 + ew;
+                        if (S == S_NONE) S = want;
+                        else if (want != S) {
+                            int d = want - S;
+                            if (d > 120 - abound) d = 120 - abound;
+                            if (d != 0) {
+                                const float fsc = exp2i(d);
+#pragma unroll
+                                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                                    for (int ot = 0; ot < CT_OUT; ++ot) acc[f][ot] *= fsc;
+                                S += d;
+                                abound += d;
+                            }
+                            e2 -= want - S;                           // what the accumulators could not follow
+                        }
+                        sc2 = exp2i(e2);                              // (|e2| <= 126 unless the tiles of one frame pair span > 2^120)
+                        abound = (abound > 44 ? abound : 44) + 1;
                     }
                 }
                 // step 2: registers 8gp..8gp+7 of agg are contraction rows c = 16gp + 4h + (j&3) + 8(j>>2)
@@ -441,20 +522,30 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                         else if (ci + 1 < CT_IN) nci = ci + 1, nk = 0;
                         else nci = 0, nk = 0;
                     }
-                    u32x4v b3[2][3];
+                    u32x4v b3[2][NP];
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
-                        u32x2 h0, m0, l0, h1, m1, l1;
-                        split3_x4(f32x4{agg[f][8 * gp], agg[f][8 * gp + 1], agg[f][8 * gp + 2], agg[f][8 * gp + 3]}, h0, m0, l0);
-                        split3_x4(f32x4{agg[f][8 * gp + 4], agg[f][8 * gp + 5], agg[f][8 * gp + 6], agg[f][8 * gp + 7]}, h1, m1, l1);
-                        b3[f][0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
-                        b3[f][1] = u32x4v{m0[0], m0[1], m1[0], m1[1]};
-                        b3[f][2] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+                        if constexpr (NP == 2) {
+                            split2h_x8(agg[f][8 * gp], agg[f][8 * gp + 1], agg[f][8 * gp + 2], agg[f][8 * gp + 3], agg[f][8 * gp + 4],
+                                       agg[f][8 * gp + 5], agg[f][8 * gp + 6], agg[f][8 * gp + 7], sc2, b3[f]);
+                        } else {
+                            u32x2 h0, m0, l0, h1, m1, l1;
+                            split3_x4(f32x4{agg[f][8 * gp], agg[f][8 * gp + 1], agg[f][8 * gp + 2], agg[f][8 * gp + 3]}, h0, m0, l0);
+                            split3_x4(f32x4{agg[f][8 * gp + 4], agg[f][8 * gp + 5], agg[f][8 * gp + 6], agg[f][8 * gp + 7]}, h1, m1, l1);
+                            b3[f][0] = u32x4v{h0[0], h0[1], h1[0], h1[1]};
+                            b3[f][1] = u32x4v{m0[0], m0[1], m1[0], m1[1]};
+                            b3[f][NP - 1] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
+                        }
                     }
 #pragma unroll
                     for (int ot = 0; ot < CT_OUT; ++ot) {
-                        acc[0][ot] = mfma_x3_k16(w3[ot], b3[0], acc[0][ot]);
-                        acc[1][ot] = mfma_x3_k16(w3[ot], b3[1], acc[1][ot]);
+                        if constexpr (NP == 2) {
+                            acc[0][ot] = mfma_h2_k16(w3[ot], b3[0], acc[0][ot]);
+                            acc[1][ot] = mfma_h2_k16(w3[ot], b3[1], acc[1][ot]);
+                        } else {
+                            acc[0][ot] = mfma_x3_k16(w3[ot], b3[0], acc[0][ot]);
+                            acc[1][ot] = mfma_x3_k16(w3[ot], b3[1], acc[1][ot]);
+                        }
                         load_w3(nci, nk, ngp, ot, w3[ot]);
                     }
                 }
@@ -462,6 +553,15 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
 #pragma unroll 1
             for (int k = 0; k + 1 < NS; ++k) subset(k, std::false_type{});
             subset(NS - 1, std::true_type{});
+        }
+        if constexpr (NP == 2) {                                       // back to true units (two factors: |S| may exceed 126)
+            if (S != S_NONE) {
+                const float u0 = exp2i(-(S / 4)), u1 = exp2i(-(S - 3 * (S / 4)));   // (four factors: S is a sum of four exponents)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int ot = 0; ot < CT_OUT; ++ot) acc[f][ot] = ((acc[f][ot] * u0) * u0) * u0 * u1;
+            }
         }
 
         // ---- epilogue, one frame after the other through the wave-private transpose tile ------------------------------------
@@ -542,7 +642,8 @@ static void launch_spatial_x3(const SpatialP& p, hipStream_t s) {
         q.per_xcd = (int)cdiv(total, 8);
         grid = dim3((unsigned)(q.per_xcd * 8));
     }
-    hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI>), grid, dim3(256), lds, s, q);
+    if (fgcn::f16x2_products()) hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 2>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 3>), grid, dim3(256), lds, s, q);
 }
 
 static int spatial_t_chunk(int B, int T) {
@@ -608,7 +709,7 @@ extern "C" int fgcn_spatial_fwd(const float* x, const float* a_hat, const float*
     FGCN_REQUIRE(ci > 0 && co > 0, FGCN_E_BADARG, "spatial_fwd: at most 256 channels (Cin=%d Cout=%d)", Cin, Cout);
     const bool split = fgcn::math_mode() == FGCN_MATH_BF16X3 && Cin % 32 == 0;   // wd: fgcn_pack_split3(acc_order) form
     const long long x_bytes = (long long)B * T * V * ld_x * 4;
-    const long long w_bytes = (long long)n_subsets * Cin * Cout * (split ? 6 : 4);
+    const long long w_bytes = (long long)n_subsets * Cin * Cout * (split ? (fgcn::f16x2_products() ? 4 : 6) : 4);
     FGCN_REQUIRE(x_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "spatial_fwd: x must be smaller than 2 GiB (32-bit buffer offsets)");
     FGCN_REQUIRE(aligned16(x) || true, FGCN_E_ALIGN, "spatial_fwd: alignment");
     SpatialP p{x, a_hat, wd, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, n_subsets, a_hat_batched,

@@ -48,9 +48,9 @@ class ScaledWeights:
     """A FGCN_PACK_SPLIT2H form (include/fgcn.h): one device buffer = 16-byte header (float bits of max |W|) + the two f16 parts of
     W * 2^s in the fragment order of the split kernels; what ``tconv_halo`` / ``pw_gemm`` stream with FGCN_PRODUCTS_F16X2."""
 
-    def __init__(self, taps: int, K: int, N: int, device):
-        self.taps, self.K, self.N = taps, K, N
-        self.kgroups = (K + 7) // 8
+    def __init__(self, taps: int, K: int, N: int, device, acc_order: bool = False):
+        self.taps, self.K, self.N, self.acc_order = taps, K, N, acc_order
+        self.kgroups = (K + 15) // 16 * 2 if acc_order else (K + 7) // 8
         self.buf = torch.zeros(16 + 2 * taps * self.kgroups * N * 8 * 2, device=device, dtype=torch.uint8)
 
     device = property(lambda self: self.buf.device)
@@ -193,6 +193,13 @@ def pack_conv(w: torch.Tensor):
 def pack_spatial(wd: torch.Tensor, cin: int) -> torch.Tensor:
     """The stacked (K*Cin, Cout) conv_d matrix in the form spatial_fwd streams in the current math mode: ``pack_k4``
     (K*Cin/4, Cout, 4), or in bf16x3 (whole 32-channel tiles only) the accumulator-ordered three-way split."""
+    if get_math_mode() == "f16x2" and cin % 32 == 0:
+        from .packing import Form, PackPlan, Seg
+        K, N = wd.shape
+        f = Form("split2h_acc", 1, K, N, [Seg(wd, st_k=N, st_n=1, klen=K, nlen=N)])
+        f.alloc(wd.device)
+        PackPlan([f]).run()
+        return f.dst
     if get_math_mode() in X3_MODES and cin % 32 == 0:
         return pack_split3(wd.unsqueeze(0), acc_order=True)
     return pack_k4(wd.unsqueeze(0))[0]
@@ -853,17 +860,20 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     _chk(x, "spatial_fwd.x"), _chk(a_hat, "spatial_fwd.a_hat")
     B, T, V, ld_x = x.shape
     ns = a_hat.shape[1]
-    if get_math_mode() in X3_MODES and Cin % 32 == 0:      # weights in the pack_spatial split form
+    if isinstance(wd, ScaledWeights):                      # FGCN_PACK_SPLIT2H_ACC: the f16x2 form of the kernel
+        w_ok = get_math_mode() in X3_MODES and Cin % 32 == 0 and wd.acc_order and (wd.taps, wd.K, wd.N) == (1, ns * Cin, Cout)
+    elif get_math_mode() in X3_MODES and Cin % 32 == 0:    # weights in the pack_spatial split form
         w_ok = wd.dtype == torch.bfloat16 and tuple(wd.shape) == (3, 1, ns * Cin // 8, Cout, 8) and wd.is_contiguous()
     else:
         w_ok = wd.dtype == torch.float32 and tuple(wd.shape) == (ns * Cin // 4, Cout, 4) and wd.is_contiguous()
     if not w_ok or a_hat.shape[0] not in (1, B) or a_hat.shape[2:] != (V, V):
         raise _lib.FgcnError(f"spatial_fwd: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} "
-                             f"wd={wd.dtype} {tuple(wd.shape)} (math mode {get_math_mode()}: weights from pack_spatial)")
+                             f"(math mode {get_math_mode()}: weights from pack_spatial)")
+    _use_products_of(wd)
     lib = _lib.load()
     y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
     part = torch.empty((lib.fgcn_spatial_tiles(B, T), 2, Cout), device=x.device, dtype=torch.float32) if stats else None
-    check(lib.fgcn_spatial_fwd(_p(x), _p(a_hat), _p(wd), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout, ns,
+    check(lib.fgcn_spatial_fwd(_p(x), _p(a_hat), wd.data_ptr(), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout, ns,
                                int(a_hat.shape[0] == B), _stream()), "fgcn_spatial_fwd")
     return y, part
 

@@ -58,9 +58,9 @@ class Form:
     def alloc(self, device) -> torch.Tensor:
         lib = _lib.load()
         kg = lib.fgcn_pack_kgroups(PACK_MODES[self.mode], self.K)
-        if self.mode == "split2h":
+        if self.mode in ("split2h", "split2h_acc"):
             from .ops import ScaledWeights
-            self.dst = ScaledWeights(self.taps, self.K, self.N, device)
+            self.dst = ScaledWeights(self.taps, self.K, self.N, device, acc_order=self.mode == "split2h_acc")
         elif self.mode in ("split3", "split3_acc"):
             self.dst = torch.empty((3, self.taps, kg, self.N, 8), device=device, dtype=torch.bfloat16)
         elif self.mode == "k4":
@@ -110,7 +110,7 @@ class PackPlan:
         self.items_dev = raw.to(dev)
         self.map_dev = torch.tensor(blockmap, dtype=torch.int32).to(dev)
         self.n_wg = len(blockmap) // 2
-        self.scaled = any(f.mode == "split2h" for f in self.forms)    # FGCN_PACK_SPLIT2H items: per-form maxima first
+        self.scaled = any(f.mode in ("split2h", "split2h_acc") for f in self.forms)    # FGCN_PACK_SPLIT2H items: per-form maxima first
         self.srcs = [s.src for f in self.forms for s in f.segs]        # the table holds raw pointers: keep the tensors alive
 
     def run(self) -> None:

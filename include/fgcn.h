@@ -240,6 +240,8 @@ int fgcn_pack_split3(unsigned short* dst, const float* src, int taps, int K, int
  *                         exponent of that maximum (scaled maximum in [2^14, 2^15); s = 0 for an all-zero form).  Needs
  *                         fgcn_pack_run_scaled (the maximum is a pass of its own). */
 #define FGCN_PACK_SPLIT2H 4
+/*   FGCN_PACK_SPLIT2H_ACC the same with the k order of FGCN_PACK_SPLIT3_ACC (fgcn_spatial_fwd's weights with FGCN_PRODUCTS_F16X2) */
+#define FGCN_PACK_SPLIT2H_ACC 5
 typedef struct {
     const float* src;
     long long st_tap, st_k, st_n;

@@ -249,3 +249,26 @@ def test_weight_gradient_at_tensor_scale(C, kt):
         e = pow2((B, T, V, 1), -d, 0, seed=24)
         err = run_case(f32(a * e), f32(g / e), f"wgrad {C}ch {kt}tap, rows over {d} binades, inverse on g", assert_f32_class=(d <= 8))
         assert err["f16x2"] <= max(2.0 ** -22, 2.0 ** -(38 - d)), err      # an element d binades below its tensor's maximum: 2^-(40 - d)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 256)])
+@pytest.mark.parametrize("log2_x,log2_a,log2_w", [(0, 0, 0), (-90, 10, 60), (70, -20, -40)])
+def test_fused_spatial_forward_scales(cin, cout, log2_x, log2_a, log2_w):
+    """y = sum_k (x . A^_k) . Wd_k in the f16x2 form of the fused kernel: x is scaled per (frame pair, channel tile), A^ per sample, the
+    aggregation it forms in registers per (tile, subset), the weights per form, and the step-2 accumulators follow the product of the
+    four -- any overall magnitude of the three operands, and channel tiles of x on different scales, at the f32 contract."""
+    from fusion_gcn_amd import ops
+    B, T, V = 2, 6, 25
+    tile_scale = torch.pow(2.0, torch.tensor([0.0, -9.0, 7.0, -3.0, 5.0, -6.0, 2.0, 8.0])[:cin // 32]).repeat_interleave(32)
+    x = f32(rnd(B, T, V, cin, seed=15) * tile_scale * 2.0 ** log2_x)
+    a = f32(rnd(B, 3, V, V, seed=16, scale=0.3) * 2.0 ** log2_a)
+    wd = f32(rnd(3, cin, cout, seed=17, scale=(3 * cin) ** -0.5) * 2.0 ** log2_w)
+    agg = torch.einsum("btvc,bkvw->btwkc", x, a)
+    want = torch.einsum("btwkc,kco->btwo", agg, wd)
+    mag = torch.einsum("btwkc,kco->btwo", torch.einsum("btvc,bkvw->btwkc", x.abs(), a.abs()), wd.abs())
+
+    def run():
+        y, _ = ops.spatial_fwd(gpu(x), gpu(a), ops.pack_spatial(gpu(wd.reshape(3 * cin, cout)), cin), None, Cin=cin, Cout=cout,
+                               stats=False)
+        return y
+    check(f"spatial_fwd {cin}->{cout} x 2^{log2_x} A 2^{log2_a} W 2^{log2_w}", all_modes(run), want, mag)
