@@ -14,6 +14,7 @@
 //   A/B fragments are single LDS dwords with the channel on the lane.  64x64 output tile per workgroup
 //   (one 32x32 accumulator per wave), rows split across blockIdx.z into deterministic partial slabs.
 #include "fgcn_common.hpp"
+#include <type_traits>
 
 namespace fgcn {
 
@@ -185,40 +186,59 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.bias ? p.bias : p.w), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NT], ssq[NT];
+    // One branch around the whole epilogue (an `if (p.accumulate)` around the loads inside the unrolled loops made hipcc drain vmcnt(0)
+    // -- every earlier store's write acknowledgement -- at each join, on the plain path too).  Accumulating form: the old values of
+    // group g + 1 are requested BEFORE the stores of group g, so a wait for them never includes those stores (vmcnt counts in issue order).
+    const unsigned rstep = (unsigned)p.ld_out * 4u;
+    auto epilogue = [&](auto acc_c) {
+        constexpr bool ACC = decltype(acc_c)::value;
+        constexpr int NG = NT * MT;                        // groups of 16 values: g = nt * MT + mt
+        float bvs[NT];
+        unsigned off0[NG];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        ssum[nt] = 0.f;
-        ssq[nt] = 0.f;
-        const int col = n0 + nt * 32 + (lane & 31);
-        const bool cok = col < p.N;
-        const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, cok ? (unsigned)col * 4u : OOB, 0, 0));
+        for (int nt = 0; nt < NT; ++nt) {
+            ssum[nt] = 0.f;
+            ssq[nt] = 0.f;
+            const int col = n0 + nt * 32 + (lane & 31);
+            const bool cok = col < p.N;
+            bvs[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, cok ? (unsigned)col * 4u : OOB, 0, 0));
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            // register r holds row rel0 + (r & 3) + 8 (r >> 2); rows past the tile's last row are outside the buffer
-            const unsigned rel0 = (unsigned)(wave * 32 * MT + mt * 32 + 4 * (lane >> 5));
-            const unsigned off0 = cok ? (rel0 * (unsigned)p.ld_out + (unsigned)col) * 4u : OOB;
-            const unsigned rstep = (unsigned)p.ld_out * 4u;
-            float old[16];
-            if (p.accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           rout, off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) {
+                // register r holds row rel0 + (r & 3) + 8 (r >> 2); rows past the tile's last row are outside the buffer
+                const unsigned rel0 = (unsigned)(wave * 32 * MT + mt * 32 + 4 * (lane >> 5));
+                off0[nt * MT + mt] = cok ? (rel0 * (unsigned)p.ld_out + (unsigned)col) * 4u : OOB;
             }
+        }
+        float old[ACC ? 2 : 1][16];
+        auto load_old = [&](int g, float (&o)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rout, off0[g] + (unsigned)((r & 3) + 8 * (r >> 2)) * rstep, 0, 0));
+        };
+        if constexpr (ACC) load_old(0, old[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int nt = g / MT, mt = g - nt * MT;
+            if constexpr (ACC) {
+                if (g + 1 < NG) load_old(g + 1, old[(g + 1) & 1]);
+            }
+            const unsigned rel0 = (unsigned)(wave * 32 * MT + mt * 32 + 4 * (lane >> 5));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
-                const float val = acc[mt][nt][r] + bv + old[r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off0 + dr * rstep, 0, 0);
-                const float kept = (cok && rel0 + dr < tile_rows) ? val : 0.f;
+                float val = acc[mt][nt][r] + bvs[nt];
+                if constexpr (ACC) val += old[g & 1][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off0[g] + dr * rstep, 0, 0);
+                const float kept = (off0[g] != OOB && rel0 + dr < tile_rows) ? val : 0.f;
                 ssum[nt] += kept;
                 ssq[nt] += kept * kept;
             }
+            if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);   // (keep the request / store order as written)
         }
-    }
+    };
+    if (p.accumulate) epilogue(std::true_type{});          // wave-uniform
+    else epilogue(std::false_type{});
     if (p.stats) {
         __syncthreads();  // As is free now: reuse as [2][4 waves][BN]
         float* red = As;

@@ -17,6 +17,12 @@
 //   NT = 1 / 2: 64 / 128 output columns per tile.
 #include "fgcn_common.hpp"
 
+// Timing probes (wrong results; tools/probes builds only): bit 0 = no output stores, bit 1 = no MFMAs, bit 2 = the image is deposited
+// once per workgroup (later chunks skip the split + LDS writes), bit 3 = no input fetches after the first
+#ifndef FGCN_PROBE_PW
+#define FGCN_PROBE_PW 0
+#endif
+
 namespace fgcn {
 
 struct PwP {
@@ -34,7 +40,12 @@ struct PwP {
 
 using u32x4p = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <int NT, int NP>
+// ACC (compile time): out += ... (see the epilogue).  A run-time `if (p.accumulate)` around loads of the old values,
+// wave-uniform as it was, made hipcc branch inside the unrolled epilogue and lose count of the outstanding memory operations: it
+// drained vmcnt(0) in front of EVERY group of four stores, i.e. sixteen full write round trips per tile and wave (found with the
+// FGCN_PROBE_PW timing probes: the stores cost 22 % of the kernel, the time the written bytes take at the HBM rate, with nothing
+// overlapping them).
+template <int NT, int NP, bool ACC>
 __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 2 || NP == 3), "64 / 128 columns; one or three bf16 parts, or two f16 parts");
     constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
@@ -80,7 +91,9 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
             src_off[i] = m < p.M ? (unsigned)(m * p.ld_in * 4) + k4b : OOB;
         }
     };
+    bool probe_first = true;
     auto fetch = [&](int kc) {
+        if ((FGCN_PROBE_PW & 8) && !probe_first) return;
         const bool kok = kc + k4 < p.K;                              // K % 4 == 0: a 16-byte group is whole or absent
 #pragma unroll
         for (int i = 0; i < NST; ++i) stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -176,7 +189,8 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                 }
                 abound = (abound > 44 ? abound : 44) + 1;
             }
-            deposit();
+            if (!(FGCN_PROBE_PW & 4) || probe_first) deposit();
+            probe_first = false;
             __syncthreads();
             const bool last_chunk = kc + KC >= p.K;
             if (!last_chunk) {
@@ -200,6 +214,10 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                     else load_w(wq[0], bn_n, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) {
+                        if constexpr ((FGCN_PROBE_PW & 2) != 0) {
+                            acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu & 1][0][0]);
+                            continue;
+                        }
                         if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
                         else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu & 1], acc[mt][nu]);
                         else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
@@ -222,34 +240,52 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
             coff[nu] = col + nu * 16 < p.N ? (unsigned)(col + nu * 16) * 4u : OOB;
             bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
         }
+        // ACC: out += value by load / add / store, the old values of row tile mt + 1 requested BEFORE the stores of row tile mt: vmcnt
+        // counts in issue order, so a load behind a store could only be waited for together with that store's write acknowledgement.
+        // (One no-return float atomic per element -- every element has a single contributor, so it would be deterministic -- was
+        // measured too: the L2 performs them at about one element per clock and channel, 5-40 % slower than this form.)
+        // Addresses: one per-lane register per column unit (row 4 g4 of the wave's first tile + column); the row inside the wave's 64
+        // travels in the instruction's scalar offset, which the hardware does not range-check: rows >= M (last row tile only) are masked
+        // per lane.
+        const unsigned ld_b = (unsigned)p.ld_out * 4u;
+        const long long mrow0 = m0 + wr * (16 * MTW) + 4 * g4;
+        unsigned rmask = 0;                                          // bit 4 mt + r: row mrow0 + 16 mt + r exists
+#pragma unroll
+        for (int i = 0; i < 4 * MTW; ++i) rmask |= (mrow0 + (i >> 2) * 16 + (i & 3) < p.M ? 1u : 0u) << i;
+        unsigned cbase[NU];
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) cbase[nu] = (coff[nu] == OOB || rmask == 0u) ? OOB : (unsigned)mrow0 * ld_b + coff[nu];
+        const bool whole = __builtin_amdgcn_readfirstlane(m0 + BMR <= p.M ? 1 : 0) != 0;   // (uniform: every row of the tile exists)
+        float old[ACC ? 2 : 1][NU][4];
+        auto load_old = [&](int mt, float (&o)[NU][4]) {
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o[nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rout, (whole || ((rmask >> (4 * mt + r)) & 1u)) ? cbase[nu] : OOB, (unsigned)(mt * 16 + r) * ld_b, 0));
+        };
+        if constexpr (ACC) load_old(0, old[0]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            unsigned rowoff[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
-                rowoff[r] = m < p.M ? (unsigned)(m * p.ld_out * 4) : OOB;
+            if constexpr (ACC) {
+                if (mt + 1 < MTW) load_old(mt + 1, old[(mt + 1) & 1]);
             }
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                float old[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    old[r] = 0.f;
-                    if (p.accumulate)                                // wave-uniform
-                        old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rout, (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu], 0, 0));
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
-                    const float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu] + old[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
-                    const float kept = off != OOB ? val : 0.f;
+                    float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
+                    if constexpr (ACC) val += old[mt & 1][nu][r];
+                    if ((FGCN_PROBE_PW & 1) && val != 123.456f) continue;
+                    const unsigned vo = (whole || ((rmask >> (4 * mt + r)) & 1u)) ? cbase[nu] : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, vo, (unsigned)(mt * 16 + r) * ld_b, 0);
+                    const float kept = vo != OOB ? val : 0.f;
                     ssum[nu] += kept;
                     ssq[nu] += kept * kept;
                 }
             }
+            if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);    // (keep the request / store order as written)
         }
         if (p.stats) {                                               // (kernel-uniform)
             __syncthreads();                                         // every wave has left the tile's last MFMA step: the image is free
@@ -323,14 +359,20 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16, two = fgcn::f16x2_products();
     const size_t lds = (size_t)128 * 128 * (one ? 1 : (two ? 2 : 3)) + 16;
     hipStream_t s = (hipStream_t)stream;
+#define FGCN_PW_LAUNCH(NT_, NP_)                                                                                         \
+    do {                                                                                                                 \
+        if (accumulate) hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, true>), grid, dim3(256), lds, s, p);                  \
+        else hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, false>), grid, dim3(256), lds, s, p);                            \
+    } while (0)
     if (narrow) {
-        if (one) hipLaunchKernelGGL((pw_x3_kernel<1, 1>), grid, dim3(256), lds, s, p);
-        else if (two) hipLaunchKernelGGL((pw_x3_kernel<1, 2>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((pw_x3_kernel<1, 3>), grid, dim3(256), lds, s, p);
+        if (one) FGCN_PW_LAUNCH(1, 1);
+        else if (two) FGCN_PW_LAUNCH(1, 2);
+        else FGCN_PW_LAUNCH(1, 3);
     } else {
-        if (one) hipLaunchKernelGGL((pw_x3_kernel<2, 1>), grid, dim3(256), lds, s, p);
-        else if (two) hipLaunchKernelGGL((pw_x3_kernel<2, 2>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((pw_x3_kernel<2, 3>), grid, dim3(256), lds, s, p);
+        if (one) FGCN_PW_LAUNCH(2, 1);
+        else if (two) FGCN_PW_LAUNCH(2, 2);
+        else FGCN_PW_LAUNCH(2, 3);
     }
+#undef FGCN_PW_LAUNCH
     return launch_status("pw_gemm");
 }

@@ -24,6 +24,12 @@
 // A^_k's zero padding makes the 7 idle columns exact zeros, so they drop out of stores and statistics.
 #include "fgcn_common.hpp"
 
+// Timing probes of spatial_fwd_x3_kernel (wrong results; tools/build_probe.py only): bit 0 = no output stores, bit 1 = no step-1 MFMAs,
+// bit 2 = no step-2 MFMAs, bit 3 = the weight fragments are loaded once
+#ifndef FGCN_PROBE_SP
+#define FGCN_PROBE_SP 0
+#endif
+
 namespace fgcn {
 
 constexpr int AHS = 33;
@@ -465,7 +471,10 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
                         af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * NP + pl) * 32 * AHB + 32 * s2);
-                    if constexpr (NP == 2) {
+                    if constexpr ((FGCN_PROBE_SP & 2) != 0) {
+                        agg[0][s2] += __builtin_bit_cast(float, xs[0][s2][0][0] ^ af[0][0]);
+                        agg[1][s2] += __builtin_bit_cast(float, xs[1][s2][0][0] ^ af[0][1]);
+                    } else if constexpr (NP == 2) {
                         agg[0] = mfma_h2_k16(xs[0][s2], af, agg[0]);
                         agg[1] = mfma_h2_k16(xs[1][s2], af, agg[1]);
                     } else {
@@ -539,14 +548,17 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                     }
 #pragma unroll
                     for (int ot = 0; ot < CT_OUT; ++ot) {
-                        if constexpr (NP == 2) {
+                        if constexpr ((FGCN_PROBE_SP & 4) != 0) {
+                            acc[0][ot][gp] += __builtin_bit_cast(float, w3[ot][0][0] ^ b3[0][0][0] ^ b3[0][NP - 1][3]);
+                            acc[1][ot][gp] += __builtin_bit_cast(float, w3[ot][NP - 1][3] ^ b3[1][0][0] ^ b3[1][NP - 1][3]);
+                        } else if constexpr (NP == 2) {
                             acc[0][ot] = mfma_h2_k16(w3[ot], b3[0], acc[0][ot]);
                             acc[1][ot] = mfma_h2_k16(w3[ot], b3[1], acc[1][ot]);
                         } else {
                             acc[0][ot] = mfma_x3_k16(w3[ot], b3[0], acc[0][ot]);
                             acc[1][ot] = mfma_x3_k16(w3[ot], b3[1], acc[1][ot]);
                         }
-                        load_w3(nci, nk, ngp, ot, w3[ot]);
+                        if constexpr ((FGCN_PROBE_SP & 8) == 0) load_w3(nci, nk, ngp, ot, w3[ot]);
                     }
                 }
             };
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                     const int r = rr + 8 * i;
                     const f32x4 val = *reinterpret_cast<const f32x4*>(&T[r * TTS + c4]) + b4;
                     const bool keep = tv && r < V && ook;
-                    const unsigned off = keep ? (unsigned)(((t - t0) * V + r) * p.ld_y + o) * 4u : OOB;
+                    const unsigned off = (keep && (!(FGCN_PROBE_SP & 1) || val[0] == 123.456f)) ? (unsigned)(((t - t0) * V + r) * p.ld_y + o) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, val), ry, off, 0, 0);
                     const f32x4 kept = keep ? val : f32x4{0.f, 0.f, 0.f, 0.f};
                     s1 += kept;

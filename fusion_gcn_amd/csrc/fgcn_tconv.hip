@@ -241,30 +241,35 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
         }
         rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
     }
+    // (one branch around the whole loop: an `if (p.accumulate)` around the loads inside it made hipcc drain vmcnt(0) at every join,
+    // on the plain path too)
+    auto epilogue = [&](auto acc_c) {
+        constexpr bool ACC = decltype(acc_c)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int c = col + nt * 32;
-        const unsigned coff = c < p.N ? (unsigned)c * 4u : OOB;
-        float old[16];
-        if (p.accumulate) {                            // wave-uniform
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = col + nt * 32;
+            const unsigned coff = c < p.N ? (unsigned)c * 4u : OOB;
+            float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rout, (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff, 0, 0));
-        } else {
+            for (int r = 0; r < 16; ++r) {
+                old[r] = 0.f;
+                if constexpr (ACC)
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rout, (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff, 0, 0));
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const unsigned off = (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff;
+                const float val = acc[nt][r] + bv[nt] + old[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+                const float kept = off != OOB ? val : 0.f;
+                ssum[nt] += kept;
+                ssq[nt] += kept * kept;
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned off = (rowoff[r] == OOB || coff == OOB) ? OOB : rowoff[r] + coff;
-            const float val = acc[nt][r] + bv[nt] + old[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
-            const float kept = off != OOB ? val : 0.f;
-            ssum[nt] += kept;
-            ssq[nt] += kept * kept;
-        }
-    }
+    };
+    if (p.accumulate) epilogue(std::true_type{});      // wave-uniform
+    else epilogue(std::false_type{});
     if (p.stats) {
         constexpr int BN = 32 * NT;
         __syncthreads();
@@ -309,12 +314,20 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // NP = bf16 parts per operand: 3 = FGCN_MATH_BF16X3 (six partial products), 1 = FGCN_MATH_BF16 (operands rounded to bf16 once --
 // activations as the image is staged, weights by fgcn_pack_split3, whose part 0 is the round-to-nearest-even bf16 -- and ONE
 // MFMA per product group: a sixth of the matrix work, a third of the LDS image and of the weight stream).
-// MTW = 16-row tiles per wave: 4 (128 output rows per workgroup) or 3 (96 rows: for more than 25 joints the 128-row tile's halo
-// image -- 128 + 8 V rows x 3 planes -- no longer fits twice into the 160 KB of LDS; the shorter tile keeps two workgroups per CU).
-template <int NT, int KC, int NP, int MTW = 4, bool FIN = false>
+// EPI = what the epilogue does besides bias + store (compile time: run-time `if (p.accumulate)` / `if (bnb)` guards around the
+// epilogue's loads, wave-uniform as they were, made hipcc branch inside the unrolled loops and drain vmcnt(0) in front of every
+// group of four stores -- sixteen serialised write round trips per workgroup; found with the timing probes of fgcn_pw.hip):
+//   0  store;  2  store + the BatchNorm-backward sums (bn_a / bn_mask / bn_vec);  3  accumulate: load / add / store with the old
+//   values of a row tile requested one row tile AHEAD of the stores (the second pass of a strided forward convolution; statistics
+//   are those of the final values).  (1 was accumulation by one no-return float atomic per element -- deterministic, every element
+//   has one contributor -- measured 5-40 % slower in fgcn_pw.hip: the L2 performs about one per clock and channel.)
+// (A 96-row tile for images that do not fit LDS twice is not needed: with the swizzled unpadded image the 128-row tile fits up to
+// 36 joints, FGCN_MAX_V is 32.)
+template <int NT, int KC, int NP, int EPI = 0, bool FIN = false>
 __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
-    static_assert(MTW == 3 || MTW == 4, "wave tile: 48 or 64 rows");
+    static_assert((EPI == 0 || EPI == 2 || EPI == 3) && !(FIN && EPI != 0), "epilogue: store / store + BatchNorm-backward sums / accumulate");
+    constexpr int MTW = 4;                           // 16-row tiles per wave (128 output rows per workgroup)
     constexpr int BMR = 32 * MTW;                    // output rows per workgroup
     static_assert(NP == 1 || NP == 2 || NP == 3, "one or three bf16 parts per operand, or two f16 parts (FGCN_PRODUCTS_F16X2)");
     static_assert(!(FIN && NP == 2), "the fused input stage is not built for the f16x2 products");
@@ -592,8 +605,9 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         }
     }
 
-    // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums ---------------------------------
+    // ---- epilogue: bias, (accumulate), branch-free buffer stores, BatchNorm partial sums ---------------------------------
     // accumulator register r of lane (col l15, g4) = row 4 g4 + r of the 16 x 16 tile
+    __builtin_amdgcn_sched_barrier(0);                    // (epilogue loads hoisted into the last MFMA step spilled registers)
     const bool plain_out = p.out_s == 1 && p.out_o == 0 && p.T_out_full == p.Tv && p.Th_out == p.Tv;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     float ssum[NU], ssq[NU], bv[NU];
     unsigned coff[NU];
     const float un_a = (NP == 2 && ea != EA_NONE) ? exp2i(-ea) : 1.f, un_w = NP == 2 ? exp2i(-ew) : 1.f;
-    const bool bnb = p.bn_a != nullptr;                   // wave-uniform: BatchNorm-backward sums instead of the forward moments
+    constexpr bool bnb = EPI == 2;                        // BatchNorm-backward sums instead of the forward moments
     const __amdgpu_buffer_rsrc_t rba = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? p.bn_a : p.out), 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbm = __builtin_amdgcn_make_buffer_rsrc((void*)(bnb ? (const void*)p.bn_mask : (const void*)p.out), 0,
                                                                          p.out_bytes >> 5, 0x00020000);
@@ -614,12 +628,14 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         ssq[nu] = 0.f;
         coff[nu] = col + nu * 16 < p.N ? (unsigned)(col + nu * 16) * 4u : OOB;
         bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
-        bmean[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], 0, 0));
-        brstd[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], (unsigned)p.N * 4u, 0));
+        bmean[nu] = bnb ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], 0, 0)) : 0.f;
+        brstd[nu] = bnb ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbv, coff[nu], (unsigned)p.N * 4u, 0)) : 0.f;
     }
+    // all row offsets first (the frame-view mapping of the strided passes is the only branch of the epilogue, and no memory
+    // operation lies behind it)
+    unsigned rowoff[MTW][4];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        unsigned rowoff[4];
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long long m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
@@ -633,44 +649,63 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                 ok = ok && th < p.Th_out;
                 orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
             }
-            rowoff[r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
+            rowoff[mt][r] = ok ? orow * (unsigned)p.ld_out * 4u : OOB;
+        }
+    // EPI 2: the BatchNorm input and the ReLU sign bits of a row tile's elements are requested one row tile AHEAD of its stores, so a
+    // wait for them never includes the write acknowledgement of stores issued before them (vmcnt counts in issue order)
+    float av[bnb ? 2 : 1][NU][4];
+    unsigned mbits[bnb ? 2 : 1][NU][4];
+    auto load_bn = [&](int mt, float (&a_)[NU][4], unsigned (&m_)[NU][4]) {
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
+                a_[nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rba, off, 0, 0));
+                m_[nu][r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbm, off == OOB ? OOB : off >> 5, 0, 0);
+            }
+    };
+    constexpr bool ldacc = EPI == 3;
+    float oldv[ldacc ? 2 : 1][NU][4];
+    auto load_old = [&](int mt, float (&o_)[NU][4]) {
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o_[nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rout, (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu], 0, 0));
+    };
+    if constexpr (bnb) load_bn(0, av[0], mbits[0]);
+    if constexpr (ldacc) load_old(0, oldv[0]);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        if constexpr (bnb) {
+            if (mt + 1 < MTW) load_bn(mt + 1, av[(mt + 1) & 1], mbits[(mt + 1) & 1]);
+        }
+        if constexpr (ldacc) {
+            if (mt + 1 < MTW) load_old(mt + 1, oldv[(mt + 1) & 1]);
         }
 #pragma unroll
         for (int nu = 0; nu < NU; ++nu) {
-            float old[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                old[r] = 0.f;
-                if (p.accumulate)                          // wave-uniform
-                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rout, (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu], 0, 0));
-            }
-            float av[4];
-            unsigned mb[4];
-            if (bnb) {                                     // wave-uniform: the BatchNorm input and the ReLU sign bits of these elements
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
-                    av[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rba, off, 0, 0));
-                    mb[r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbm, off == OOB ? OOB : off >> 5, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned off = (rowoff[r] == OOB || coff[nu] == OOB) ? OOB : rowoff[r] + coff[nu];
-                const float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu] + old[r];
+                const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
+                float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
+                if constexpr (ldacc) val += oldv[mt & 1][nu][r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
                 const float kept = off != OOB ? val : 0.f;
-                if (bnb) {
-                    const float dp = (mb[r] >> ((off >> 2) & 7u)) & 1u ? kept : 0.f;
+                if constexpr (bnb) {
+                    const float dp = (mbits[mt & 1][nu][r] >> ((off >> 2) & 7u)) & 1u ? kept : 0.f;
                     ssum[nu] += dp;
-                    ssq[nu] += dp * ((av[r] - bmean[nu]) * brstd[nu]);
+                    ssq[nu] = __builtin_fmaf(dp, (av[mt & 1][nu][r] - bmean[nu]) * brstd[nu], ssq[nu]);
                 } else {
                     ssum[nu] += kept;
-                    ssq[nu] += kept * kept;
+                    ssq[nu] = __builtin_fmaf(kept, kept, ssq[nu]);   // (explicit: every instantiation sums the same way, bit for bit)
                 }
             }
         }
+        // (left to itself the scheduler requests all four row tiles' operands first and sums after the last store: 128 live values)
+        if constexpr (bnb || ldacc) __builtin_amdgcn_sched_barrier(0);
     }
     if (p.stats) {
         __syncthreads();
@@ -799,31 +834,6 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.per_xcd = 0;
     if (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) {
         // split-bf16 kernel (16x16x32 MFMAs); FGCN_MATH_BF16: the same kernel with one bf16 part
-        static bool opt_in = false;
-        if (!opt_in) {
-            const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
-#define FGCN_K32_ATTR(NT_, KC_)                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3, 4>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 4>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 2, 4>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 2, 3>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 3, 3>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, 1, 3>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
-            FGCN_K32_ATTR(1, 32); FGCN_K32_ATTR(2, 32); FGCN_K32_ATTR(1, 64); FGCN_K32_ATTR(2, 64);
-#undef FGCN_K32_ATTR
-#define FGCN_K32_FIN_ATTR(NT_, NP_)                                                                              \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, 32, NP_, 4, true>),   \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
-            FGCN_K32_FIN_ATTR(1, 1); FGCN_K32_FIN_ATTR(1, 3); FGCN_K32_FIN_ATTR(2, 1); FGCN_K32_FIN_ATTR(2, 3);
-#undef FGCN_K32_FIN_ATTR
-            opt_in = true;
-        }
         const bool one = mm == FGCN_MATH_BF16;
         const bool pw = taps == 1 && K % 64 == 0;
         // XCD-aware workgroup order (key 5 bit 5 switches it off): measured on MI355X at 256 channels, B = 128: FETCH_SIZE per launch
@@ -835,26 +845,41 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         // image rows: 128 (1x1, 64-channel chunks) / 64 bytes per bf16 part, unpadded (swizzled); the epilogue's 2 KB of partial sums fit
         const int np = one ? 1 : (two ? 2 : 3);
         const size_t lds_k = (pw ? (size_t)bmr * 128 * np : (size_t)p.halo_rows * 64 * np) + 16;
-#define FGCN_K32_LAUNCH(NT_, KC_)                                                                                \
-    do {                                                                                                         \
-        if (bmr == 96) {                                                                                         \
-            if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 3>), grid, dim3(256), lds_k, s, p); \
-            else if (two) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 2, 3>), grid, dim3(256), lds_k, s, p); \
-            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 3>), grid, dim3(256), lds_k, s, p);     \
-        } else {                                                                                                 \
-            if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 1, 4>), grid, dim3(256), lds_k, s, p); \
-            else if (two) hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 2, 4>), grid, dim3(256), lds_k, s, p); \
-            else hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, 3, 4>), grid, dim3(256), lds_k, s, p);     \
-        }                                                                                                        \
+        FGCN_REQUIRE(bmr == 128, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
+        FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
+        const int epi = bn_a ? 2 : (accumulate ? 3 : 0);     // epilogue form (compile time, see the kernel)
+        const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;   // (opt-in beyond the default dynamic-LDS limit, once per instantiation)
+#define FGCN_K32_GO(NT_, KC_, NP_, EPI_, FIN_)                                                                           \
+    do {                                                                                                                 \
+        static bool opted = false;                                                                                       \
+        if (!opted) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
+            opted = true;                                                                                                \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_>), grid, dim3(256), lds_k, s, p);           \
+    } while (0)
+#define FGCN_K32_NP(NT_, KC_, EPI_)                                                                                      \
+    do {                                                                                                                 \
+        if (one) FGCN_K32_GO(NT_, KC_, 1, EPI_, false);                                                                  \
+        else if (two) FGCN_K32_GO(NT_, KC_, 2, EPI_, false);                                                             \
+        else FGCN_K32_GO(NT_, KC_, 3, EPI_, false);                                                                      \
+    } while (0)
+#define FGCN_K32_LAUNCH(NT_, KC_)                                                                                        \
+    do {                                                                                                                 \
+        if (epi == 0) FGCN_K32_NP(NT_, KC_, 0);                                                                          \
+        else if (epi == 3) FGCN_K32_NP(NT_, KC_, 3);                                                                     \
+        else if (epi == 2 && KC_ == 32) FGCN_K32_NP(NT_, 32, 2);                                                         \
+        else return fgcn::fail(FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums are built for the tap kernel only"); \
     } while (0)
         if (fin) {
-            FGCN_REQUIRE(bmr == 128 && !pw, FGCN_E_BADARG, "tconv_halo: the fused input stage runs on the 128-row tap tile (V <= 32)");
+            FGCN_REQUIRE(!pw, FGCN_E_BADARG, "tconv_halo: the fused input stage runs on the 128-row tap tile (V <= 32)");
             if (N <= 64) {
-                if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32, 1, 4, true>), grid, dim3(256), lds_k, s, p);
-                else hipLaunchKernelGGL((conv_halo_x3k32_kernel<1, 32, 3, 4, true>), grid, dim3(256), lds_k, s, p);
+                if (one) FGCN_K32_GO(1, 32, 1, 0, true);
+                else FGCN_K32_GO(1, 32, 3, 0, true);
             } else {
-                if (one) hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32, 1, 4, true>), grid, dim3(256), lds_k, s, p);
-                else hipLaunchKernelGGL((conv_halo_x3k32_kernel<2, 32, 3, 4, true>), grid, dim3(256), lds_k, s, p);
+                if (one) FGCN_K32_GO(2, 32, 1, 0, true);
+                else FGCN_K32_GO(2, 32, 3, 0, true);
             }
         } else if (pw) {
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
@@ -864,6 +889,8 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             else FGCN_K32_LAUNCH(2, 32);
         }
 #undef FGCN_K32_LAUNCH
+#undef FGCN_K32_NP
+#undef FGCN_K32_GO
         return launch_status("tconv_halo");
     }
     if ((fgcn::tuning(5) & 2) && tiles * p.tiles_n < (1ll << 30)) {   // measured neutral: off
