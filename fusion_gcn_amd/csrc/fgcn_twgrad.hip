@@ -33,6 +33,13 @@ struct TWgradP {
     // two that puts that maximum into [2^14, 2^15) as they are split, the slabs leave with the scales multiplied back out
     const unsigned* a_amax;
     const unsigned* g_amax;
+    // tconv_wgrad_x3_kernel, per_xcd > 0: 1-D grid in XCD-aware order.  Workgroup ids go round-robin over the 8 XCDs (each with its
+    // own L2); with the plain (tile, row split) grid the tiles_xy (channel group, column tile) workgroups of one row split -- which
+    // read the SAME rows of a and g -- landed on different XCDs whenever tiles_xy divides 8 (conv_d at 256 channels: 8 tiles, one
+    // per XCD) and every one fetched its rows through the fabric: 1.84 GB per launch against 0.98 GB algorithmic
+    // (profiles/r03_bf16x3_step_traffic_by_kernel.txt).  Id b takes virtual id (b % 8) * per_xcd + b / 8, tile fastest: the tiles of
+    // a row split run side by side on one XCD and share its L2.
+    int per_xcd, tiles_xy, n_split;
 };
 
 // TN = out-channel tile (64: waves = 2 column tiles x 2 row halves of the stage, 128: 4 column tiles).
@@ -223,7 +230,14 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nsub = wave % NSUBS, part = wave / NSUBS;
-    const int tk = blockIdx.x / p.tiles_n, tn = blockIdx.x - tk * p.tiles_n;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.per_xcd > 0) {
+        const int vid = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+        if (vid >= p.tiles_xy * p.n_split) return;
+        by = vid / p.tiles_xy;
+        bx = vid - by * p.tiles_xy;
+    }
+    const int tk = bx / p.tiles_n, tn = bx - tk * p.tiles_n;
     const int k0 = tk * (CH ? 32 * NTAP : 32), n0 = tn * TN;
     const int V = p.V, TVg = p.T_g * V;
     const int win = CH ? NTAP * X3_R : p.win_rows;                // tap mode: X3_R + (NTAP - 1) * V
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     const int rmask = p.ring_rows - 1;
     unsigned char* Ap = lds_raw;                                  // [3][win][32] bf16
     unsigned char* Gp = lds_raw + NP * a_plane;                   // [NP][X3_R][128 (+32 pad)] bf16
-    const int sbeg = blockIdx.y * p.stages_per_split;
+    const int sbeg = by * p.stages_per_split;
     const int send = min(sbeg + p.stages_per_split, p.total_stages);
 
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
 
     // ---- partial slabs: [slab = split * NPARTS + part][tap][k][n] -----------------------------------------------------
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
-    const int slab = blockIdx.y * NPARTS + part;
+    const int slab = by * NPARTS + part;
     const float un_a = exp2i(-ea), un_g = exp2i(-eg);               // (NP == 2; 1 otherwise)
 #pragma unroll
     for (int j = 0; j < NTAP; ++j) {
@@ -589,6 +603,13 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     FGCN_REQUIRE(lds <= 160 * 1024, FGCN_E_BADARG, "%s: stage needs %zu bytes of LDS", what, lds);
     const int tiles_k = (int)cdiv(K, chunk_mode ? 32 * nacc : 32);
     dim3 grid((unsigned)(tiles_k * p.tiles_n), (unsigned)nsplit);
+    p.per_xcd = 0;
+    p.tiles_xy = tiles_k * p.tiles_n;
+    p.n_split = nsplit;
+    if (x3 && p.tiles_xy > 1 && !(fgcn::tuning(5) & 64)) {      // key 5 bit 6: the plain 2-D grid (A/B control)
+        p.per_xcd = (int)cdiv((long long)p.tiles_xy * nsplit, 8);
+        grid = dim3((unsigned)(p.per_xcd * 8));
+    }
     hipStream_t s = (hipStream_t)stream;
     if (x3 && chunk_mode) {
         switch (nacc) {
