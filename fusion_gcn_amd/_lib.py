@@ -120,6 +120,9 @@ SIGNATURES = {
     "fgcn_col_sum": (_I, [_P, _P, _LL, _I, _I, _P]),
     "fgcn_spatial_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_spatial_tiles": (_I, [_I, _I]),
+    "fgcn_spatial_fwd_tile": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_spatial_fwd_tile_tiles": (_I, [_I, _I, _I]),
+    "fgcn_spatial_fwd_tile_available": (_I, [_I, _I, _I]),
     "fgcn_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fgcn_row_softmax_fwd": (_I, [_P, _P, _P, _P, _LL, _I, _I, _I, _F, _P]),
     "fgcn_row_softmax_bwd": (_I, [_P, _P, _P, _LL, _I, _I, _F, _P]),

@@ -132,6 +132,8 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
         F["d4"] = Form("split2h_acc" if mode == "f16x2" else "split3_acc", 1, 3 * cx, cout, d_rows)
     else:
         F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
+    if mode == "bf16x3" and cx % 64 == 0:            # the tile form of the fused spatial kernel (ops.spatial_fwd_tile): plain split form
+        F["d_s3"] = Form("split3", 1, 3 * cx, cout, d_rows)
     d_cols = [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, n0=k * cx) for k, w in enumerate(wd)]          # (1, cout, 3cx)
     F["d_t"] = Form("plain", 1, cout, 3 * cx, d_cols)
     # the kernel adds the sum of the three biases: overlapping segments are summed
@@ -225,6 +227,12 @@ def spec_dx(cin: int) -> List[dict]:
 # VGPRs at 64 / 128 output columns otherwise) stops hiding under the other workgroup's MFMAs, which costs 0.35 ms per launch
 # where the bn_act pass took 0.126.  Off by default; FGCN_FUSE_G=1 selects it (profiles/r03_ab_fused_input_stage.txt).
 FUSE_BN_INTO_TCONV = bool(os.environ.get("FGCN_FUSE_G"))
+# the fused spatial forward in its tile form (fgcn_spatial_tile.hip; bf16x3 products, Cin % 64 == 0, 16 <= V <= 32); FGCN_SPATIAL_TILE=0:
+# the two-frames-per-wave form everywhere (A/B control)
+SPATIAL_TILE = os.environ.get("FGCN_SPATIAL_TILE", "1") != "0"
+# ... from this many output channels on (tools/kbench.py spatial, B = 128, profiles/r03_kbench_spatial_tile.log: 64 -> 64 0.345 vs 0.387 ms for
+# the tile form, 64 -> 128 0.562 vs 0.500, 128 -> 128 0.475 vs 0.433, 128 -> 256 0.927 vs 0.841, 256 -> 256 0.895 vs 0.797)
+SPATIAL_TILE_MIN_COUT = int(os.environ.get("FGCN_SPATIAL_TILE_MIN_COUT", "128"))
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
@@ -394,7 +402,9 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
-    if cfg.fused_spatial:
+    if cfg.fused_spatial and SPATIAL_TILE and cout >= SPATIAL_TILE_MIN_COUT and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
+        y, part = ops.spatial_fwd_tile(x, a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train)
+    elif cfg.fused_spatial:
         y, part = ops.spatial_fwd(x, a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     else:
         agg = new(B, T, V, 3 * cin)

@@ -1,0 +1,334 @@
+// Fused spatial graph convolution, forward, TILE form (north-star kernel 1 in the split-bf16 math mode):
+//
+//     y[(n,t,w), o] = bias[o] + sum_k sum_c Wd_k[o][c] * ( sum_v x[(n,t,v), c] * A^_k[n][v][w] )
+//
+// reference: SpatialGraphConv.forward, torch_src/models/mmargcn/agcn.py:103-111; still ONE kernel and no aggregation tensor in HBM.
+//
+// Why a second form.  spatial_fwd_x3_kernel (fgcn_spatial.hip) gives every wave two frames: its feature GEMM runs on 25 of 32 matrix
+// columns (the joints of ONE frame per 32-column tile), the aggregation is re-formed for every 64-column block of outputs, and each
+// wave streams its own weight fragments from L2 with one unit of MFMAs to cover the load.  Timing probes (tools/build_probe.py,
+// profiles/r03_probe_pw_spatial.txt) put that kernel at 0.92 ms for 256 -> 256 channels with the aggregation (a third of its MFMAs)
+// costing 0.43 ms of it.  Here the feature GEMM is the halo conv's (fgcn_tconv.hip): a workgroup owns F = 128 / V whole frames of
+// one sample -- F V rows, 125 of 128 at V = 25 -- times 64 NT output columns; per pair (32-channel tile ci, subset k) the
+// aggregation tile agg_k[(f, w)][c] is formed ONCE per workgroup on the matrix pipe (split-bf16, as before), split into its three
+// bf16 parts and written to an LDS image [row f V + w][32 channels]; the feature contraction then runs from that image exactly like
+// one tap of the temporal conv: 2 x 2 waves over 128 rows x 64 NT columns, image fragments by ds_read_b128, pre-split weights
+// (fgcn_pack_split3, the (3 Cin) x Cout matrix of the three conv_d weights) streamed from L2 through a two-slot ring, each fragment
+// feeding four row tiles.  Two pairs are staged per barrier pair (the image of all three subsets of a channel tile would not leave
+// room for two workgroups per CU beside the A^ planes).
+//   aggregation units of a chunk = (pair, frame): 2 F units, dealt round-robin to the four waves; a unit is 2 x 6 MFMAs
+//   (v_mfma_f32_32x32x16_bf16: agg^T (32 c x 32 w) = X_t^T . A^_k), its x rows are requested one chunk ahead and parked in registers.
+// Rows of the image beyond the tile's F V rows are never written and never stored (each output row depends on its own image row only).
+#include "fgcn_common.hpp"
+
+// Timing probes (wrong results; tools/build_probe.py only): bit 0 = the image is staged for the first chunk only, bit 1 = no feature
+// MFMAs, bit 2 = x is fetched for the first chunk only, bit 3 = no aggregation MFMAs / splits (the image receives x's split instead)
+#ifndef FGCN_PROBE_ST
+#define FGCN_PROBE_ST 0
+#endif
+
+namespace fgcn {
+
+struct SpTileP {
+    const float* x;
+    const float* a_hat;
+    const void* w3;                     // fgcn_pack_split3 form of the (3 Cin) x Cout matrix: [part][(k Cin + c) / 8][o][8] bf16
+    const float* bias;
+    float* y;
+    float* stats;                       // float[tiles_m][2][Cout] or NULL
+    int B, T, V, Cin, Cout, ld_x, ld_y, a_batched;
+    int F, tiles_t, tiles_m, tiles_n, per_xcd;
+    unsigned x_bytes, y_bytes, w_plane_bytes;
+};
+
+constexpr int ST_AHB = 80;              // bytes per [w] row of a split A^ plane (32 joints x bf16 + 16 pad: conflict-free b128 reads)
+constexpr int ST_XS = 64;               // bytes per image row and part (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
+constexpr int ST_PLANE = 256 * ST_XS;   // one part of the image: two pairs x 128 rows
+
+template <int NT, int MAXU>
+__global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
+    constexpr int NP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    constexpr unsigned OOB = 0x80000000u;
+    auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
+    extern __shared__ __attribute__((aligned(16))) float smem_st[];
+    unsigned char* Xh = reinterpret_cast<unsigned char*>(smem_st);   // [3 parts][2 pairs x 128 rows][64 B]
+    unsigned char* ahs = Xh + NP * ST_PLANE;                         // [3 subsets][3 parts][32 w][ST_AHB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4, l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware order, column tile fastest: the column tiles of a row tile (same x rows, same A^) run back to back on one XCD
+    const int vid = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (vid >= p.tiles_m * p.tiles_n) return;
+    const int bm = vid / p.tiles_n, bn = vid - bm * p.tiles_n;
+    const int n = bm / p.tiles_t, tf = bm - n * p.tiles_t;
+    const int V = p.V, F = p.F;
+    const int t0 = tf * F;
+    const int nf = min(F, p.T - t0);                                 // frames of this tile
+    const int nrows = nf * V;
+    const int n0 = bn * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+
+    // A^_k of this sample, split once per workgroup: [subset][part][w][v] bf16 (one ds_read_b128 = the 8 joints of a lane's fragment)
+    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
+    for (int i = tid; i < 3 * 32 * 32; i += 256) {
+        const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
+        const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+        unsigned ph, pm, pl;
+        split_bf16_pair(a, 0.f, ph, pm, pl);
+        unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * NP) * 32 + w) * ST_AHB) + v;
+        d[0] = (unsigned short)ph;
+        d[32 * ST_AHB / 2] = (unsigned short)pm;
+        d[2 * 32 * ST_AHB / 2] = (unsigned short)pl;
+    }
+
+    // this wave's aggregation units of a chunk: unit u = wave + 4 i -> (pair slot q = u / F, frame f = u % F)
+    int uq[MAXU], uf[MAXU];
+    bool uok[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = wave + 4 * i;
+        uq[i] = __builtin_amdgcn_readfirstlane(u / F);
+        uf[i] = __builtin_amdgcn_readfirstlane(u - uq[i] * F);
+        uok[i] = uq[i] < 2 && uf[i] < nf;                            // (wave-uniform)
+    }
+    const int npairs = 3 * (p.Cin >> 5);                             // (channel tile, subset) pairs; even (Cin % 64 == 0)
+    const int nchunks = npairs >> 1;
+    const unsigned row_b = (unsigned)p.ld_x * 4u;
+    // two register sets: the x rows of chunk c + 1 are requested at the START of chunk c's staging phase (behind the barrier) and have
+    // landed when the feature MFMAs begin.  Requested at the start of the MFMA phase instead, they sat in front of every weight
+    // fragment of that phase in the in-order vmcnt queue -- a wait for a weight load (an L2 hit) then waited for the HBM loads
+    // before it: measured 0.17 ms of a 0.81 ms launch (FGCN_PROBE_ST)
+    float xrA[MAXU][16], xrB[MAXU][16];
+    // x of (frame, channel tile): lane = channel, register 8 s + j = joint 16 s + 8 h + j (the k order of the 32x32x16 fragment); the
+    // joint's row offset splits into a per-lane part (8 h rows) and a scalar part (16 s + j rows, the instruction's soffset)
+    auto fetch_units = [&](int c, float (&xr)[MAXU][16]) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int pq = 2 * c + uq[i];
+            const int ci = pq / 3;
+            const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * h) * p.ld_x + ci * 32 + l31) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int vs = 16 * (r >> 3) + (r & 7);
+                xr[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (uok[i] && vs + 8 * h < V) ? base : OOB,
+                                                                                          (unsigned)vs * row_b, 0));
+            }
+        }
+    };
+    const unsigned char* af_lane = ahs + l31 * ST_AHB + 16 * h;      // + (k * NP + part) * 32 * ST_AHB + 32 * s2
+    auto stage_units = [&](int c, float (&xr)[MAXU][16]) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (!uok[i]) continue;                                   // wave-uniform
+            const int pq = 2 * c + uq[i];
+            const int k = pq - 3 * (pq / 3);
+            f32x16 agg = zero16();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4v xs[NP], af[NP];
+                split3_x8(xr[i][8 * s2], xr[i][8 * s2 + 1], xr[i][8 * s2 + 2], xr[i][8 * s2 + 3], xr[i][8 * s2 + 4], xr[i][8 * s2 + 5],
+                          xr[i][8 * s2 + 6], xr[i][8 * s2 + 7], xs);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * NP + pl) * 32 * ST_AHB + 32 * s2);
+                agg = mfma_x3_k16(xs, af, agg);                      // agg^T (32 c x 32 w): lane = joint w, register r = channel acc_row(r)
+            }
+            // this lane's joint w = l31 of frame uf: image row uq * 128 + uf * V + w, channels 8 g + 4 h + (0..3) per register group
+            const int R = uq[i] * 128 + uf[i] * V + l31;
+            if (l31 < V) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 ph, pm, pl;
+                    split3_x4(f32x4{agg[4 * g], agg[4 * g + 1], agg[4 * g + 2], agg[4 * g + 3]}, ph, pm, pl);
+                    unsigned char* dst = Xh + R * ST_XS + ((unsigned)(16 * g + 8 * h) ^ swz(R));
+                    *reinterpret_cast<u32x2*>(dst) = ph;
+                    *reinterpret_cast<u32x2*>(dst + ST_PLANE) = pm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * ST_PLANE) = pl;
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MTW][NU];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) acc[mt][nu] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int col = n0 + wc * NT * 32 + l15;                         // + nu * 16
+    unsigned wvoff[NU];                                              // per-lane byte offset into one part: (g4 * N + col) * 8 bf16
+#pragma unroll
+    for (int nu = 0; nu < NU; ++nu) wvoff[nu] = col + nu * 16 < p.Cout ? (unsigned)(((long long)g4 * p.Cout + col + nu * 16) * 16) : OOB;
+    // weight fragment of (column unit nu, pair pq): contraction rows k * Cin + 32 ci + 8 g4 + j; past the last pair: pair 0 (a valid, unused load)
+    auto load_w = [&](u32x4v (&dst)[NP], int nu, int pq) {
+        if (pq >= npairs) pq = 0;
+        const int ci = pq / 3, k = pq - 3 * ci;
+        const unsigned so = (unsigned)(((long long)((k * p.Cin + 32 * ci) >> 3) * p.Cout) * 16);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
+    };
+    const int xrow = wr * (16 * MTW) + l15;
+    auto load_a = [&](u32x4v (&dst)[NP], int mt, int q) {
+        const int r = q * 128 + xrow + mt * 16;
+        const unsigned char* src = Xh + r * ST_XS + ((unsigned)(16 * g4) ^ swz(r));
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * ST_PLANE);
+    };
+
+    u32x4v a[MTW][NP], wq[2][NP];
+    auto feature_phase = [&](int c) {                                // the two pairs of chunk c from the image
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) load_a(a[mt], mt, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pq = 2 * c + q;
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], nu + 1, pq);
+                else load_w(wq[0], 0, pq + 1);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) {
+                    if constexpr ((FGCN_PROBE_ST & 2) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu & 1][0][0]);
+                    else acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    if (nu == NU - 1 && q == 0) load_a(a[mt], mt, 1);    // this fragment's last use: fetch the next step's
+                }
+            }
+        }
+    };
+    auto chunk = [&](int c, float (&cur)[MAXU][16], float (&nxt)[MAXU][16]) {
+        __syncthreads();                                             // the previous chunk's image reads are done (first pass: the A^ planes are written)
+        if (c + 1 < nchunks && !(FGCN_PROBE_ST & 4)) fetch_units(c + 1, nxt);
+        if (!(FGCN_PROBE_ST & 1) || c == 0) stage_units(c, cur);
+        __syncthreads();
+        feature_phase(c);
+    };
+    fetch_units(0, xrA);
+    load_w(wq[0], 0, 0);
+    for (int c = 0; c < nchunks; c += 2) {                           // (nchunks = 3 Cin / 64 is a multiple of 3; an odd count ends on the first half)
+        chunk(c, xrA, xrB);
+        if (c + 1 < nchunks) chunk(c + 1, xrB, xrA);
+    }
+
+    // ---- epilogue: bias, branch-free buffer stores, BatchNorm partial sums (accumulator register r of lane (col l15, g4) = row
+    // 4 g4 + r of its 16 x 16 tile); rows beyond the tile's frames carry the out-of-range offset ----------------------------------
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : p.w3), 0,
+                                                                           p.bias ? (unsigned)p.Cout * 4u : 0u, 0x00020000);
+    const long long m0 = ((long long)n * p.T + t0) * V;
+    float ssum[NU], ssq[NU], bv[NU];
+    unsigned coff[NU];
+#pragma unroll
+    for (int nu = 0; nu < NU; ++nu) {
+        ssum[nu] = 0.f;
+        ssq[nu] = 0.f;
+        coff[nu] = col + nu * 16 < p.Cout ? (unsigned)(col + nu * 16) * 4u : OOB;
+        bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
+                const unsigned off = (row < nrows && coff[nu] != OOB) ? (unsigned)((m0 + row) * p.ld_y * 4) + coff[nu] : OOB;
+                const float val = acc[mt][nu][r] + bv[nu];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ry, off, 0, 0);
+                const float kept = off != OOB ? val : 0.f;
+                ssum[nu] += kept;
+                ssq[nu] = __builtin_fmaf(kept, kept, ssq[nu]);
+            }
+        }
+    }
+    if (p.stats) {                                                   // (kernel-uniform)
+        __syncthreads();                                             // every wave has left the last MFMA step: the image is free
+        float* red = smem_st;                                        // [which][wr][BN]
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            float sa = ssum[nu] + __shfl_xor(ssum[nu], 16);
+            float sb = ssq[nu] + __shfl_xor(ssq[nu], 16);
+            sa += __shfl_xor(sa, 32);
+            sb += __shfl_xor(sb, 32);
+            if (lane < 16) {
+                red[(0 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sa;
+                red[(1 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sb;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.Cout)
+                p.stats[((long long)bm * 2 + which) * p.Cout + n0 + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
+        }
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+static int sp_tile_frames(int V) { return 128 / V; }
+
+// 1 when fgcn_spatial_fwd_tile runs these sizes in the current math mode (split-bf16 products, whole 64-channel input groups,
+// 16..32 joints: at most 8 frames per 128-row tile)
+extern "C" int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout) {
+    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && !fgcn::f16x2_products() && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cout % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int fgcn_spatial_fwd_tile_tiles(int B, int T, int V) {
+    return V >= 16 && V <= FGCN_MAX_V ? (int)(B * cdiv(T, sp_tile_frames(V))) : 0;
+}
+
+extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
+                                     float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                                     int a_hat_batched, void* stream) {
+    FGCN_REQUIRE(x && a_hat && w3 && y, FGCN_E_BADARG, "spatial_fwd_tile: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, FGCN_E_BADARG, "spatial_fwd_tile: bad sizes B=%d T=%d Cin=%d Cout=%d", B, T, Cin, Cout);
+    FGCN_REQUIRE(fgcn_spatial_fwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
+                 "spatial_fwd_tile: needs math mode bf16x3 (bf16x3 products), 16 <= V <= %d, Cin %% 64 == 0, Cout %% 4 == 0 (V=%d Cin=%d Cout=%d)",
+                 FGCN_MAX_V, V, Cin, Cout);
+    FGCN_REQUIRE(ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= Cin && ld_y >= Cout, FGCN_E_ALIGN, "spatial_fwd_tile: row strides");
+    FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(y), FGCN_E_ALIGN, "spatial_fwd_tile: 16-byte alignment");
+    const long long x_bytes = (long long)B * T * V * ld_x * 4, y_bytes = (long long)B * T * V * ld_y * 4;
+    const long long plane = (long long)3 * Cin * Cout * 2;
+    FGCN_REQUIRE(x_bytes < 0x7FFF0000ll && y_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "spatial_fwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    SpTileP p;
+    p.x = x; p.a_hat = a_hat; p.w3 = w3; p.bias = bias_sum; p.y = y; p.stats = stat_partials;
+    p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.Cout = Cout; p.ld_x = ld_x; p.ld_y = ld_y; p.a_batched = a_hat_batched;
+    p.F = sp_tile_frames(V);
+    p.tiles_t = (int)cdiv(T, p.F);
+    p.tiles_m = B * p.tiles_t;
+    const bool narrow = Cout <= 64;
+    p.tiles_n = (int)cdiv(Cout, narrow ? 64 : 128);
+    const long long total = (long long)p.tiles_m * p.tiles_n;
+    FGCN_REQUIRE(total < (1ll << 30), FGCN_E_BADARG, "spatial_fwd_tile: too many tiles");
+    p.per_xcd = (int)cdiv(total, 8);
+    p.x_bytes = (unsigned)x_bytes; p.y_bytes = (unsigned)y_bytes; p.w_plane_bytes = (unsigned)plane;
+    const size_t lds = (size_t)3 * ST_PLANE + 9 * 32 * ST_AHB;
+    const dim3 grid((unsigned)(p.per_xcd * 8));
+    hipStream_t s = (hipStream_t)stream;
+    const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
+#define FGCN_ST_GO(NT_, MU_)                                                                                        \
+    do {                                                                                                            \
+        static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
+        if (!opted) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+            opted = true;                                                                                           \
+        }                                                                                                           \
+        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_>), grid, dim3(256), lds, s, p);                         \
+    } while (0)
+    if (narrow) {
+        if (four) FGCN_ST_GO(1, 4);
+        else FGCN_ST_GO(1, 3);
+    } else {
+        if (four) FGCN_ST_GO(2, 4);
+        else FGCN_ST_GO(2, 3);
+    }
+#undef FGCN_ST_GO
+    return launch_status("spatial_fwd_tile");
+}

@@ -878,6 +878,30 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
     return y, part
 
 
+def spatial_fwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
+    """Whether ``spatial_fwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, 16 <= V <= 32)."""
+    return bool(_lib.load().fgcn_spatial_fwd_tile_available(V, Cin, Cout))
+
+
+def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
+                     Cout: int, stats: bool = True):
+    """y = sum_k conv_d[k](x . A^_k), the tile form of the fused kernel (fgcn_spatial_tile.hip): w3 = ``pack_split3`` of the stacked
+    (1, 3 Cin, Cout) matrix.  -> (y (B,T,V,Cout), stats partials or None)."""
+    ensure_device()
+    _chk(x, "spatial_fwd_tile.x"), _chk(a_hat, "spatial_fwd_tile.a_hat")
+    B, T, V, ld_x = x.shape
+    if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, 3 * Cin // 8, Cout, 8) or not w3.is_contiguous()
+            or a_hat.shape[0] not in (1, B) or tuple(a_hat.shape[1:]) != (3, V, V)):
+        raise _lib.FgcnError(f"spatial_fwd_tile: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} w3={tuple(w3.shape)} "
+                             "(weights: pack_split3 of the (1, 3 Cin, Cout) matrix)")
+    lib = _lib.load()
+    y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
+    part = torch.empty((lib.fgcn_spatial_fwd_tile_tiles(B, T, V), 2, Cout), device=x.device, dtype=torch.float32) if stats else None
+    check(lib.fgcn_spatial_fwd_tile(_p(x), _p(a_hat), w3.data_ptr(), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout,
+                                    int(a_hat.shape[0] == B), _stream()), "fgcn_spatial_fwd_tile")
+    return y, part
+
+
 def transpose(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
     """(B, R, C) -> (B, C, ld_out) with out[b, c, r] = x[b, r, c] and the columns [R, ld_out) zero-filled (ld_out >= R)."""
     ensure_device()

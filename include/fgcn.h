@@ -420,6 +420,18 @@ int fgcn_spatial_fwd(const float* x, const float* a_hat, const float* wd, const 
                      float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
                      int n_subsets, int a_hat_batched, void* stream);
 int fgcn_spatial_tiles(int B, int T);
+/* The same product in its TILE form (split-bf16 math mode, bf16x3 products; fgcn_spatial_tile.hip): a workgroup owns 128 / V whole
+ *   frames of one sample (125 of 128 matrix rows at V = 25 instead of 25 of 32 columns per frame) times 64 / 128 output columns; the
+ *   aggregation x . A^_k of a (32-channel tile, subset) pair is formed once per workgroup on the matrix pipe and written to an LDS
+ *   image, from which the feature contraction runs like one tap of fgcn_tconv_halo.
+ *   w3: fgcn_pack_split3 form (acc_order 0) of the (3 Cin) x Cout matrix [k * Cin + c][o] = Wd_k[o][c] (one tap, K = 3 Cin); three
+ *   subsets; Cin %% 64 == 0; 16 <= V <= 32.  stat_partials: float[fgcn_spatial_fwd_tile_tiles(B, T, V)][2][Cout] or NULL.
+ *   fgcn_spatial_fwd_tile_available: 1 when the current math mode / products and these sizes run on this kernel. */
+int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
+                          float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                          int a_hat_batched, void* stream);
+int fgcn_spatial_fwd_tile_tiles(int B, int T, int V);
+int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout);
 
 /* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
 /* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:

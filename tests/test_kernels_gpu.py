@@ -462,6 +462,35 @@ def test_spatial_wgrad_fused_agg_recompute(V, T, cin, cout, B):
     assert rel_l2(shared[0].cpu().numpy(), want1.numpy()) < RED_TOL
 
 
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
+                                             (16, 8, 128, 128, 1), (32, 5, 64, 96, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1)])
+def test_spatial_forward_tile_form(V, T, cin, cout, B):
+    """The fused spatial forward in its tile form (fgcn_spatial_tile.hip: 128 / V whole frames per workgroup, the aggregation of a
+    (channel tile, subset) pair formed once per workgroup into an LDS image): y = sum_k (x . A^_k) . Wd_k + bias against the float64
+    einsums, its BatchNorm partial sums against the output it wrote, per-sample and shared adjacency, ragged last frame group
+    (T % F != 0), 4 .. 8 frames per tile, a partial column tile; bitwise reproducible; agrees with the two-frames-per-wave form."""
+    from fusion_gcn_amd import ops
+    if not ops.spatial_fwd_tile_available(V, cin, cout):
+        pytest.skip("the tile form runs with the bf16x3 products")
+    x, a = rnd(B, T, V, cin, seed=300), rnd(B, 3, V, V, seed=301, scale=0.3)
+    wd, bias = rnd(3, cin, cout, seed=302, scale=(3 * cin) ** -0.5), rnd(cout, seed=303)
+    want = torch.einsum("btwkc,kco->btwo", torch.einsum("btvc,bkvw->btwkc", x.double(), a.double()), wd.double()) + bias.double()
+    w3 = ops.pack_split3(to_gpu(wd.reshape(1, 3 * cin, cout)))
+    y, part = ops.spatial_fwd_tile(to_gpu(x), to_gpu(a), w3, to_gpu(bias), Cin=cin, Cout=cout, stats=True)
+    assert rel_l2(y.cpu().numpy(), want.numpy()) < FWD_TOL
+    s = part.double().sum(0).cpu()
+    assert rel_l2(s[0].numpy(), y.double().sum((0, 1, 2)).cpu().numpy()) < RED_TOL
+    assert rel_l2(s[1].numpy(), (y.double() ** 2).sum((0, 1, 2)).cpu().numpy()) < RED_TOL
+    y2, part2 = ops.spatial_fwd_tile(to_gpu(x), to_gpu(a), w3, to_gpu(bias), Cin=cin, Cout=cout, stats=True)
+    assert torch.equal(y, y2) and torch.equal(part, part2)
+    y_old, _ = ops.spatial_fwd(to_gpu(x), to_gpu(a), ops.pack_spatial(to_gpu(wd.reshape(3 * cin, cout)), cin), to_gpu(bias), Cin=cin,
+                               Cout=cout, stats=False)
+    assert rel_l2(y.cpu().numpy(), y_old.cpu().numpy()) < FWD_TOL
+    shared, _ = ops.spatial_fwd_tile(to_gpu(x), to_gpu(a[:1]), w3, None, Cin=cin, Cout=cout, stats=False)
+    want1 = torch.einsum("btwkc,kco->btwo", torch.einsum("btvc,kvw->btwkc", x.double(), a[0].double()), wd.double())
+    assert rel_l2(shared.cpu().numpy(), want1.numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("V,T,C,B", [(25, 30, 64, 3), (18, 33, 128, 2), (27, 12, 256, 2), (22, 9, 4, 2), (32, 5, 96, 1), (25, 300, 64, 2)])
 def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     """One pass over dagg gives both dx (+)= sum_k dagg_k . A^_k^T and dA^_k = x^T dagg_k (float64 einsums), with and without

@@ -50,6 +50,8 @@ def _long_way(P, cfg, mode):
     d_list = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(3)]
     R["d"] = torch.cat([w.t() for w in d_list], 0).contiguous()
     R["d4"] = ops.pack_spatial(R["d"], cx)
+    if mode == "bf16x3" and cx % 64 == 0:          # the tile form of the fused spatial kernel takes the plain split form
+        R["d_s3"] = ops.pack_split3(R["d"].unsqueeze(0))
     R["d_t"] = torch.cat(d_list, 1).contiguous().unsqueeze(0)
     R["d_b"] = P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]
     if cfg.has_down:

@@ -163,6 +163,11 @@ def bench_spatial(B, reps):
         ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
         rows = B * T * V
         report(f"spatial_fwd T{T} {cin}->{cout}", ms, rows * (6.0 * V * cin + 6.0 * cin * cout), 4.0 * rows * (cin + cout))
+        if ops.spatial_fwd_tile_available(V, cin, cout):
+            w3 = ops.pack_split3(rnd(1, 3 * cin, cout) * (3 * cin) ** -0.5)
+            ms = timeit(lambda: ops.spatial_fwd_tile(x, a, w3, bias, Cin=cin, Cout=cout, stats=True), reps)
+            report("  tile form (128 / V frames per workgroup, aggregation image in LDS)", ms, rows * (6.0 * V * cin + 6.0 * cin * cout),
+                   4.0 * rows * (cin + cout))
         if ops.get_math_mode() == "bf16x3" and cin % 32 == 0:
             _lib.load().fgcn_set_tuning(7, 1)
             ms = timeit(lambda: ops.spatial_fwd(x, a, wd, bias, Cin=cin, Cout=cout, stats=True), reps)
