@@ -235,6 +235,8 @@ SPATIAL_TILE = os.environ.get("FGCN_SPATIAL_TILE", "1") != "0"
 SPATIAL_TILE_MIN_COUT = int(os.environ.get("FGCN_SPATIAL_TILE_MIN_COUT", "128"))
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
+# ... up to this many channels (FGCN_BN_SUMS_MAX_C; see the measurement at its use in block_backward)
+BN_SUMS_MAX_C = int(os.environ.get("FGCN_BN_SUMS_MAX_C", "4096"))
 # identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
 # block_backward).  Measured neutral on MI355X (tools/probes/gated_dagg_probe.py, B = 128: the two apply kernels save 0.16 ms per
 # block, the two extra tensor reads cost joint_dagg 0.15 ms; slower at 8 clips), so off; the kernel form stays tested.
@@ -580,8 +582,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     dg = new(B, T, V, cout)
     # identity blocks in the split-bf16 modes: the data-gradient kernel sums dg * [g > 0] and dg * [g > 0] * y_hat in its epilogue,
     # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
-    fuse_sums = (BN_SUMS_IN_DGRAD and train and s == 1 and not cfg.has_down and S["g_sign"] is not None and "t_t4" in W
-                 and ops.tconv_halo_bn_sums())
+    fuse_sums = (BN_SUMS_IN_DGRAD and cout <= BN_SUMS_MAX_C and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
+                 and "t_t4" in W and ops.tconv_halo_bn_sums())
     # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
     # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
     f16x2 = S.get("amax") is not None and ops.get_math_mode() == "f16x2" and ("t_t4" in W or "t_t4_e" in W)
