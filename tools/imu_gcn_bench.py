@@ -48,11 +48,18 @@ def main():
     flops *= 3
     out = {"nodes": V, "batch": args.batch, "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
     from steptime import time_step
-    for mode in ("f32", "bf16x3", "bf16"):
+    # dense matrix peaks (MI355X_MICROARCH.md) per arithmetic: exact f32 MFMA, bf16 / 6 products, f16 / 3 products, bf16
+    peaks = {"f32": 157.3, "bf16x3": 2500.0 / 6, "f16x2": 2500.0 / 3, "bf16": 2500.0}
+    for mode in ("f32", "bf16x3", "f16x2", "bf16"):
         with ops.math_mode(mode):
             t = time_step(model, x, y, args.steps, graph=args.graph)
+        best = min(t["eager"]["ms_per_step"], t["graph"]["ms_per_step"]) if args.graph else t["eager"]["ms_per_step"]
         out[mode] = {"ms_per_step": t["eager"]["ms_per_step"], "samples_per_s": t["eager"]["per_s"],
-                     "tflops": round(flops / t["eager"]["ms_per_step"] / 1e9, 1), "loss": t["eager"]["loss"]}
+                     "tflops": round(flops / t["eager"]["ms_per_step"] / 1e9, 1), "loss": t["eager"]["loss"],
+                     # the whole step against the matrix roof of its arithmetic (the step is matrix-bound: 1956 x 1956 adjacency products
+                     # and 512..4096-wide feature GEMMs; algorithmic FLOPs = 3 x forward)
+                     "roofline": {"bound": "mfma", "achieved": round(flops / best / 1e9, 1), "peak": round(peaks[mode], 1),
+                                  "unit": "TFLOP/s", "frac": round(flops / best / 1e9 / peaks[mode], 3), "what": "whole fwd+bwd step"}}
         if args.graph:
             out[mode]["graph"] = dict(t["graph"], tflops=round(flops / t["graph"]["ms_per_step"] / 1e9, 1))
     if args.cpu:

@@ -50,6 +50,34 @@ def main():
         loss.backward()
         return loss                                   # the caller must not hold it across a capture (see --graph below)
 
+    # algorithmic FLOPs of one forward pass, counted at the C-ABI boundary: every GEMM-shaped launch of a no-grad forward (row GEMMs
+    # incl. the dilated temporal convolutions and the stacked-adjacency products, the halo conv, the persistent 1x1 GEMM); fwd+bwd = 3x
+    counted = [0.0]
+
+    def counting(name, flop_of):
+        real = getattr(ops, name)
+
+        def wrapper(*a, **kw):
+            counted[0] += flop_of(*a, **kw)
+            return real(*a, **kw)
+        setattr(ops, name, wrapper)
+        return real
+    rows_of = lambda t: t.shape[0] * t.shape[1] * t.shape[2]                       # noqa: E731
+    saved = {"rows_gemm": counting("rows_gemm", lambda x, w, out, *, K, N, **kw: 2.0 * rows_of(out) * (kw["tmap"][0] if kw.get("tmap") else 1) * K * N),
+             "pw_gemm": counting("pw_gemm", lambda x, w3, out, **kw: 2.0 * rows_of(out) * x.shape[3] * out.shape[3]),
+             "tconv_halo": counting("tconv_halo", lambda x, w, out, *, taps, **kw: 2.0 * rows_of(out) * taps * x.shape[3] * out.shape[3])}
+    with torch.no_grad():
+        model(x)
+    for k, v in saved.items():
+        setattr(ops, k, v)
+    flops = 3.0 * counted[0]
+    out["algorithmic_gflop_per_step"] = round(flops / 1e9, 1)
+    peaks = {"f32": 157.3, "bf16x3": 2500.0 / 6, "f16x2": 2500.0 / 3, "bf16": 2500.0}     # dense matrix peak of each arithmetic, TFLOP/s
+
+    def roofline(ms):
+        return {"bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": round(peaks[mode], 1), "unit": "TFLOP/s",
+                "frac": round(flops / ms / 1e9 / peaks[mode], 3), "what": "whole fwd+bwd step (3 x the forward's GEMM FLOPs)"}
+
     for mode in args.modes.split(","):
         with ops.math_mode(mode):
             for _ in range(2):
@@ -62,7 +90,8 @@ def main():
             dt = (time.perf_counter() - t0) / args.steps
             eager_loss = float(loss.detach())
             del loss
-            out[mode] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(eager_loss, 5)}
+            out[mode] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(eager_loss, 5),
+                         "roofline": roofline(1e3 * dt)}
             if args.graph:
                 # Every lazily built buffer exists after the eager steps: record forward + backward once and replay.  No reference
                 # to an earlier step's autograd graph may be alive here (tools/probes/msg3d_graph_probe.py: it pins the
@@ -89,7 +118,8 @@ def main():
                 got = float(gloss.detach())
                 if got != eager_loss:
                     raise RuntimeError(f"{mode}: graph replay loss {got} != eager loss {eager_loss} after the timed replays")
-                out[mode]["graph"] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(got, 5)}
+                out[mode]["graph"] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(args.batch / dt, 1), "loss": round(got, 5),
+                                      "roofline": roofline(1e3 * dt)}
     if args.cpu:
         from oracle import msg3d_oracle as O
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
