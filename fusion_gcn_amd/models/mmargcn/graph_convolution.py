@@ -29,6 +29,27 @@ def _r(c: int, m: int) -> int:
     return (c + m - 1) // m * m
 
 
+def _split_form(mod, name: str, w: torch.Tensor):
+    """The split form of a (1, K, N) matrix that is rebuilt every call (a transposed / padded weight) in the products of the current math
+    mode.  bf16x3 / bf16: one ``fgcn_pack_split3`` launch.  f16x2: the FGCN_PACK_SPLIT2H form goes through a pack plan whose device-side
+    table is uploaded when it is built -- not allowed inside a HIP-graph capture -- so the module keeps one staging buffer + plan per
+    name (built by the eager warm-up steps); a call copies into the staging buffer and runs the plan: two launches, capture-safe."""
+    if ops.get_math_mode() != "f16x2":
+        return ops.pack_split3(w)
+    from ...packing import Form, PackPlan, Seg
+    cache = mod.__dict__.setdefault("_split_cache", {})
+    ent = cache.get(name)
+    if ent is None or ent[0].shape != w.shape or ent[0].device != w.device:
+        stage = torch.empty_like(w)
+        _, K, N = w.shape
+        f = Form("split2h", 1, K, N, [Seg(stage, st_tap=K * N, st_k=N, st_n=1, klen=K, nlen=N, tlen=1)])
+        f.alloc(w.device)
+        ent = cache[name] = (stage, f, PackPlan([f]))
+    ent[0].copy_(w)
+    ent[2].run()
+    return ent[1].dst
+
+
 def _rows4(t: torch.Tensor) -> torch.Tensor:
     """(B, R, C) -> the (B, R, 1, C) view the row kernels index as (sample, frame, joint, channel)."""
     return t.view(t.shape[0], t.shape[1], 1, t.shape[2])
@@ -56,7 +77,7 @@ class _GraphConv1dFunction(torch.autograd.Function):
             w[0, :Fin] = weight.view(O, Fin).t()
         W: Dict[str, torch.Tensor] = {"w": w}
         if ops.get_math_mode() in ops.SPLIT_MODES and Fp % 64 == 0:
-            W["w_s3"] = ops.pack_split3(w)
+            W["w_s3"] = _split_form(mod, "w", w)        # split form of the current products (bf16x3 / f16x2)
         support = torch.empty((B, V, O), device=dev, dtype=torch.float32)
         pw_gemm(_rows4(x), W, "w", _rows4(support), K=Fp, N=O, bias=bias)
         sup_fm = ops.transpose(support, Vp)                                   # (B, O, Vp), zero padding columns
@@ -75,7 +96,7 @@ class _GraphConv1dFunction(torch.autograd.Function):
                 wr[0, :Fin] = res_w.view(O, Fin).t()
             W["wr"] = wr
             if "w_s3" in W:
-                W["wr_s3"] = ops.pack_split3(wr)
+                W["wr_s3"] = _split_form(mod, "wr", wr)
             r = torch.empty((B, V, O), device=dev, dtype=torch.float32)
             part = pw_gemm(_rows4(x), W, "wr", _rows4(r), K=Fp, N=O, bias=res_b, stats=train)
             bn = mod.residual[1]
@@ -114,8 +135,10 @@ class _GraphConv1dFunction(torch.autograd.Function):
             g_res_w = ops.rows_wgrad(_rows4(x), _rows4(dr), K=Fp, N=O, conv_param=(1, Fin)).view(O, Fin, 1)
             g_res_b = torch.zeros(O, device=dev, dtype=torch.float32) if train else ops.col_sum(_rows4(dr), O)
             dx = torch.empty_like(x)
-            wr_t = W["wr"][0].t().contiguous().unsqueeze(0)                      # (1, O, Fp)
-            ops.rows_gemm(_rows4(dr), wr_t, _rows4(dx), K=O, N=Fp)
+            Wt = {"wr_t": W["wr"][0].t().contiguous().unsqueeze(0)}           # (1, O, Fp)
+            if "wr_s3" in W and O % 32 == 0:
+                Wt["wr_t_s3"] = _split_form(mod, "wr_t", Wt["wr_t"])
+            pw_gemm(_rows4(dr), Wt, "wr_t", _rows4(dx), K=O, N=Fp)
         # main path: d_support = d_main . adj  (feature-major), then the conv's data and weight gradients
         dm_fm = ops.transpose(d_main, Vp)
         ds_fm = torch.empty((B, O, Vp), device=dev, dtype=torch.float32)
@@ -124,12 +147,13 @@ class _GraphConv1dFunction(torch.autograd.Function):
         g_w = ops.rows_wgrad(_rows4(x), _rows4(d_support), K=Fp, N=O, conv_param=(1, Fin)).view(O, Fin, 1)
         g_b = ops.col_sum(_rows4(d_support), O)
         if ctx.needs_input_grad[0]:
-            w_t = W["w"][0].t().contiguous().unsqueeze(0)                        # (1, O, Fp)
+            Wt = {"w_t": W["w"][0].t().contiguous().unsqueeze(0)}              # (1, O, Fp)
+            if "w_s3" in W and O % 32 == 0:
+                Wt["w_t_s3"] = _split_form(mod, "w_t", Wt["w_t"])
+            acc = dx is not None
             if dx is None:
                 dx = torch.empty_like(x)
-                ops.rows_gemm(_rows4(d_support), w_t, _rows4(dx), K=O, N=Fp)
-            else:
-                ops.rows_gemm(_rows4(d_support), w_t, _rows4(dx), K=O, N=Fp, accumulate=True)
+            pw_gemm(_rows4(d_support), Wt, "w_t", _rows4(dx), K=O, N=Fp, accumulate=acc)
         else:
             dx = None
         return dx, None, None, g_w, g_b, g_res_w, g_res_b, g_res_g, g_res_beta
@@ -177,8 +201,8 @@ class STGCNGraphConvolution(nn.Module):
                 a[:V, :V] = self.adj
                 forms = {"Vp": Vp, "adjT": a.t().contiguous().unsqueeze(0), "adj": a.contiguous().unsqueeze(0)}
                 if ops.get_math_mode() in ops.SPLIT_MODES:
-                    forms["adjT_s3"] = ops.pack_split3(forms["adjT"])
-                    forms["adj_s3"] = ops.pack_split3(forms["adj"])
+                    forms["adjT_s3"] = ops.pack_conv(forms["adjT"])
+                    forms["adj_s3"] = ops.pack_conv(forms["adj"])
             self._adj_cache = (key, forms)
         return self._adj_cache[1]
 
