@@ -605,12 +605,23 @@ struct SWgradP {
 };
 
 constexpr int YTS = 68;   // dy tile row stride (64 channels + 4)
+constexpr int SW_AHB = 80; // MM == 2: bytes per [w] row of a split A^ plane (32 joints x bf16 + 16 pad: conflict-free b128 reads)
 
-template <int KS, bool BF>
+// MM: 0 = exact f32 MFMAs; 1 = FGCN_MATH_BF16 (operands rounded once, one bf16 MFMA per product group); 2 = FGCN_MATH_BF16X3: the
+// weight-gradient contraction from exact three-way bf16 splits (six v_mfma_f32_32x32x16_bf16 per 16 joints, 384 cycles instead of
+// 13 x 2 x 64 on the f32 pipe): the aggregation's accumulator registers 8 gp .. 8 gp + 7 of lane half h ARE a 16-deep k fragment
+// (joints (j & 3) + 8 (j >> 2) + 4 h + 16 gp), split in registers; the dy fragments in the same joint order are split once per frame and
+// serve the three subsets.  The joint mixing itself stays on the f32 MFMA (13 of the frame's 91 f32-equivalent steps).
+template <int KS, int MM>
 __global__ __launch_bounds__(256, 2) void spatial_wgrad_kernel(SWgradP p) {
+    constexpr bool BF = MM == 1;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     float* img = wsm;                                  // [3][kk = in joint v][i = out joint w] = A^_k[v][w]
-    float* tiles = wsm + 3 * IMG;                      // [4 waves][32 * DTS + 32 * YTS]
+    // MM == 2: instead, the three bf16 parts of A^_k as planes [subset][part][w][SW_AHB bytes] (v contiguous: one ds_read_b128 = the 8
+    // joints of a lane's fragment of the split joint mixing)
+    constexpr int IMG_FLOATS = MM == 2 ? 9 * 32 * SW_AHB / 4 : 3 * IMG;
+    unsigned char* ahs = reinterpret_cast<unsigned char*>(wsm);
+    float* tiles = wsm + IMG_FLOATS;                   // [4 waves][32 * DTS + 32 * YTS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int tile = blockIdx.x, chunk = blockIdx.y, n = blockIdx.z;
@@ -624,8 +635,19 @@ __global__ __launch_bounds__(256, 2) void spatial_wgrad_kernel(SWgradP p) {
 
     const float* msrc = p.mats + (p.mats_batched ? (long long)n * NS * V * V : 0);
     for (int e = tid; e < 3 * IMG; e += 256) {
-        const int k = e >> 10, v = (e >> 5) & 31, w = e & 31;
-        img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+        if constexpr (MM == 2) {
+            const int k = e >> 10, w = (e >> 5) & 31, v = e & 31;
+            const float a = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+            unsigned ph, pm, pl;
+            split_bf16_pair(a, 0.f, ph, pm, pl);
+            unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * 3) * 32 + w) * SW_AHB) + v;
+            d[0] = (unsigned short)ph;
+            d[32 * SW_AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * SW_AHB / 2] = (unsigned short)pl;
+        } else {
+            const int k = e >> 10, v = (e >> 5) & 31, w = e & 31;
+            img[e] = (k < NS && v < V && w < V) ? msrc[(k * V + v) * V + w] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -662,13 +684,52 @@ __global__ __launch_bounds__(256, 2) void spatial_wgrad_kernel(SWgradP p) {
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) *reinterpret_cast<f32x4*>(&yt[(4 * ps + yr) * YTS + 4 * yg]) = yv[ps];
         }
+        u32x4v yb3[MM == 2 ? 2 : 1][2][3];                 // MM == 2: dy fragments of this frame, [16-joint group][32-column tile][part]
+        u32x4v xf3[MM == 2 ? 2 : 1][3];                    // MM == 2: x fragments of the joint mixing (lane = channel, joints 16 s2 + 8 h + j)
+        if constexpr (MM == 2) {
+            const float* xq = xt + 8 * h * DTS + l31;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                split3_x8(xq[(16 * s2) * DTS], xq[(16 * s2 + 1) * DTS], xq[(16 * s2 + 2) * DTS], xq[(16 * s2 + 3) * DTS], xq[(16 * s2 + 4) * DTS],
+                          xq[(16 * s2 + 5) * DTS], xq[(16 * s2 + 6) * DTS], xq[(16 * s2 + 7) * DTS], xf3[s2]);
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                if (16 * gp >= 2 * KS) continue;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const float* yq = yb + 16 * gp * YTS + ot * 32;
+                    split3_x8(yq[0], yq[YTS], yq[2 * YTS], yq[3 * YTS], yq[8 * YTS], yq[9 * YTS], yq[10 * YTS], yq[11 * YTS], yb3[gp][ot]);
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k < NS) {                              // wave-uniform
                 f32x16 agg = zero16();                 // agg_k chunk: rows = out joint, lanes = channel
+                if constexpr (MM == 2) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) agg = mfma32(am[k * IMG + s * 64], xb[2 * s * DTS], agg);
-                if constexpr (BF) {
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4v af[3];
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            af[pl] = *reinterpret_cast<const u32x4v*>(ahs + ((k * 3 + pl) * 32 + l31) * SW_AHB + 16 * h + 32 * s2);
+                        agg = mfma_x3_k16(af, xf3[s2], agg);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) agg = mfma32(am[k * IMG + s * 64], xb[2 * s * DTS], agg);
+                }
+                if constexpr (MM == 2) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        if (16 * gp >= 2 * KS) continue;
+                        u32x4v a3[3];
+                        split3_x8(agg[8 * gp], agg[8 * gp + 1], agg[8 * gp + 2], agg[8 * gp + 3], agg[8 * gp + 4], agg[8 * gp + 5],
+                                  agg[8 * gp + 6], agg[8 * gp + 7], a3);
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) accw[k][ot] = mfma_x3_k16(a3, yb3[gp][ot], accw[k][ot]);
+                    }
+                } else if constexpr (BF) {
                     // 8 joints per bf16 MFMA: registers 4g..4g+3 of lane half h are joints 8g + 4h + (0..3)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -1028,22 +1089,29 @@ extern "C" int fgcn_spatial_wgrad(const float* x, const float* dy, const float* 
     p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.Cout = Cout; p.ld_x = ld_x; p.ld_dy = ld_dy; p.n_sub = n_subsets;
     p.mats_batched = mats_batched; p.t_chunk = (int)cdiv(T, nchunk); p.tiles_o = (int)cdiv(Cout, 64);
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)yb; p.p_bytes = (unsigned)pb;
-    const size_t lds = (size_t)(3 * IMG + 4 * (32 * DTS + 32 * YTS)) * sizeof(float);   // 65,536 bytes: two workgroups per CU
+    const bool x3m = fgcn::math_mode() == FGCN_MATH_BF16X3 && !(fgcn::tuning(6) & 512);
+    // 65,536 bytes (76,288 with the split A^ planes of the bf16x3 form): two workgroups per CU
+    const size_t lds = (size_t)((x3m ? 9 * 32 * SW_AHB / 4 : 3 * IMG) + 4 * (32 * DTS + 32 * YTS)) * sizeof(float);
     dim3 grid((unsigned)(cdiv(Cin, 32) * p.tiles_o), (unsigned)nchunk, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
+    const bool x3 = fgcn::math_mode() == FGCN_MATH_BF16X3 && !(fgcn::tuning(6) & 512);   // key 6 bit 9: the exact-f32 form (A/B control)
     const int ks = (V + 3) / 4 * 2;
     static bool lds_opt_in = false;   // once per process; not a stream operation (stays out of graph captures)
 #define FGCN_SW(KS_)                                                                                                   \
     do {                                                                                                               \
-        if (bf) hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, true>), grid, dim3(256), lds, s, p);                     \
-        else hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, false>), grid, dim3(256), lds, s, p);                       \
+        if (bf) hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, 1>), grid, dim3(256), lds, s, p);                        \
+        else if (x3) hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, 2>), grid, dim3(256), lds, s, p);                   \
+        else hipLaunchKernelGGL((spatial_wgrad_kernel<KS_, 0>), grid, dim3(256), lds, s, p);                           \
     } while (0)
+    const int max_lds = (int)((9 * 32 * SW_AHB / 4 + 4 * (32 * DTS + 32 * YTS)) * sizeof(float));   // the larger (bf16x3) form
 #define FGCN_SW_ATTR(KS_)                                                                                             \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, false>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, true>),                       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, 0>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, 2>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_kernel<KS_, 1>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
     if (!lds_opt_in) {
         FGCN_SW_ATTR(10); FGCN_SW_ATTR(12); FGCN_SW_ATTR(14); FGCN_SW_ATTR(16);
         lds_opt_in = true;
