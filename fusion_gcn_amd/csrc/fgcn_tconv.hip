@@ -54,6 +54,8 @@ struct HaloP {
     float* fin_out;                     // G, laid out like `in`
     unsigned char* fin_mask;            // rows * K / 8 bytes
     unsigned* in_amax;                  // NP == 2: receives max |in| over everything staged (integer atomic maximum of the float bits) or NULL
+    int stats_rows;                     // rows of `stats` the caller allocated (fgcn_tconv_halo_tiles: 128-row tiles); a kernel form with larger
+                                        // row tiles fills tiles_m of them and zeroes the rest
 };
 
 #ifndef FGCN_HALO_PF64
@@ -323,12 +325,16 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 //   has one contributor -- measured 5-40 % slower in fgcn_pw.hip: the L2 performs about one per clock and channel.)
 // (A 96-row tile for images that do not fit LDS twice is not needed: with the swizzled unpadded image the 128-row tile fits up to
 // 36 joints, FGCN_MAX_V is 32.)
-template <int NT, int KC, int NP, int EPI = 0, bool FIN = false>
+// WR = wave rows: 2 = waves 2 x 2 over (128 rows x 64 NT columns); 4 = waves 4 x 1 over (192 rows x 32 NT columns), the form for 64
+// output columns (NT = 2): every image fragment then feeds FOUR 16-column units instead of two (half the LDS fragment reads per MFMA --
+// the 2 x 2 form at 64 columns reads 12 KB of fragments per 48 MFMAs and wave) and the halo image is re-staged 2.04x instead of 2.56x.
+template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2>
 __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(WR == 2 || (WR == 4 && KC == 32 && !FIN), "wave arrangement: 2 x 2, or 4 x 1 for the tap form");
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
     static_assert((EPI == 0 || EPI == 2 || EPI == 3) && !(FIN && EPI != 0), "epilogue: store / store + BatchNorm-backward sums / accumulate");
-    constexpr int MTW = 4;                           // 16-row tiles per wave (128 output rows per workgroup)
-    constexpr int BMR = 32 * MTW;                    // output rows per workgroup
+    constexpr int MTW = WR == 4 ? 3 : 4;             // 16-row tiles per wave
+    constexpr int BMR = WR * 16 * MTW;               // output rows per workgroup: 128 (2 x 2 waves) or 192 (4 x 1)
     static_assert(NP == 1 || NP == 2 || NP == 3, "one or three bf16 parts per operand, or two f16 parts (FGCN_PRODUCTS_F16X2)");
     static_assert(!(FIN && NP == 2), "the fused input stage is not built for the f16x2 products");
     static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = WR == 4 ? wave : wave >> 1, wc = WR == 4 ? 0 : wave & 1;
     // per_xcd > 0: 1-D grid in XCD-aware order -- consecutive workgroup ids go round-robin over the 8 XCDs, so id b takes virtual
     // tile (b % 8) * per_xcd + b / 8, column tile fastest: the column tiles of a row tile (same image) and neighbouring row tiles
     // (shared halo rows) run back to back on ONE XCD and find each other's rows in its L2 instead of fetching them again
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         bn = vid - bm * p.tiles_n;
     }
     const long long m0 = (long long)bm * BMR;
-    constexpr int BN = 2 * NT * 32;
+    constexpr int BN = (4 / WR) * NT * 32;
     const int n0 = bn * BN;
     const int V = p.V, TvV = p.Tv * p.V;
     const unsigned k4b = (tid % TPR) * 16;
@@ -717,15 +723,22 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             sa += __shfl_xor(sa, 32);
             sb += __shfl_xor(sb, 32);
             if (lane < 16) {
-                red[(0 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sa;
-                red[(1 * 2 + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sb;
+                red[(0 * WR + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sa;
+                red[(1 * WR + wr) * BN + wc * NT * 32 + nu * 16 + lane] = sb;
             }
         }
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid - which * BN;
-            if (n0 + c < p.N)
-                p.stats[((long long)bm * 2 + which) * p.N + n0 + c] = red[(which * 2 + 0) * BN + c] + red[(which * 2 + 1) * BN + c];
+            if (n0 + c < p.N) {
+                float t = red[(which * WR + 0) * BN + c] + red[(which * WR + 1) * BN + c];
+                if constexpr (WR == 4) t = (t + red[(which * WR + 2) * BN + c]) + red[(which * WR + 3) * BN + c];
+                p.stats[((long long)bm * 2 + which) * p.N + n0 + c] = t;
+                if constexpr (WR == 4) {                   // the partial rows of the 128-row tiling that this tiling does not fill
+                    const long long extra = (long long)bm + p.tiles_m;
+                    if (extra < p.stats_rows) p.stats[(extra * 2 + which) * p.N + n0 + c] = 0.f;
+                }
+            }
         }
     }
 }
@@ -808,7 +821,14 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
     const int dmax = d0 < d1 ? d1 : d0;
-    const int bmr = halo_tile_rows(V);
+    int bmr = halo_tile_rows(V);
+    p.stats_rows = (int)cdiv(p.Mv, bmr);
+    // split kernels, <= 64 output columns, tap form: waves 4 x 1 over 192-row tiles (see the kernel; key 7 bit 3 keeps the 2 x 2 form)
+    const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && N <= 64 && N > 32 && !(taps == 1 && K % 64 == 0) &&
+                           !(fin_vec || fin_res || fin_out || fin_mask) && !(fgcn::tuning(7) & 8) &&
+                           192 + (dmax - p.dmin) * V <= 32 * HALO_MAX_STAGE && (size_t)(192 + (dmax - p.dmin) * V) * 64 * 3 + 16 <= 80 * 1024 &&
+                           cdiv(p.Mv, 192) >= 1536;   // (three rounds of 512 workgroups: below, the coarser tiling quantises worse -- 8-clip step +0.07 ms)
+    if (wide_rows) bmr = 192;
     p.halo_rows = bmr + (dmax - p.dmin) * V;
     FGCN_REQUIRE(p.halo_rows <= 32 * HALO_MAX_STAGE, FGCN_E_BADARG, "tconv_halo: halo of %d rows too large", p.halo_rows);
     const size_t lds = mm == FGCN_MATH_BF16X3 ? (size_t)p.halo_rows * XSB * 3 : (size_t)p.halo_rows * HAS * sizeof(float);
@@ -845,19 +865,26 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         // image rows: 128 (1x1, 64-channel chunks) / 64 bytes per bf16 part, unpadded (swizzled); the epilogue's 2 KB of partial sums fit
         const int np = one ? 1 : (two ? 2 : 3);
         const size_t lds_k = (pw ? (size_t)bmr * 128 * np : (size_t)p.halo_rows * 64 * np) + 16;
-        FGCN_REQUIRE(bmr == 128, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
+        FGCN_REQUIRE(bmr == 128 || wide_rows, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
         const int epi = bn_a ? 2 : (accumulate ? 3 : 0);     // epilogue form (compile time, see the kernel)
         const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;   // (opt-in beyond the default dynamic-LDS limit, once per instantiation)
-#define FGCN_K32_GO(NT_, KC_, NP_, EPI_, FIN_)                                                                           \
+#define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
     do {                                                                                                                 \
         static bool opted = false;                                                                                       \
         if (!opted) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
             opted = true;                                                                                                \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_>), grid, dim3(256), lds_k, s, p);           \
+        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_>), grid, dim3(256), lds_k, s, p);      \
+    } while (0)
+#define FGCN_K32_GO(NT_, KC_, NP_, EPI_, FIN_) FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, 2)
+#define FGCN_K32_WIDE_NP(EPI_)                                                                                           \
+    do {                                                                                                                 \
+        if (one) FGCN_K32_GO6(2, 32, 1, EPI_, false, 4);                                                                 \
+        else if (two) FGCN_K32_GO6(2, 32, 2, EPI_, false, 4);                                                            \
+        else FGCN_K32_GO6(2, 32, 3, EPI_, false, 4);                                                                     \
     } while (0)
 #define FGCN_K32_NP(NT_, KC_, EPI_)                                                                                      \
     do {                                                                                                                 \
@@ -885,12 +912,18 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
             else FGCN_K32_LAUNCH(2, 64);
         } else {
-            if (N <= 64) FGCN_K32_LAUNCH(1, 32);
+            if (wide_rows) {
+                if (epi == 0) FGCN_K32_WIDE_NP(0);
+                else if (epi == 3) FGCN_K32_WIDE_NP(3);
+                else FGCN_K32_WIDE_NP(2);
+            } else if (N <= 64) FGCN_K32_LAUNCH(1, 32);
             else FGCN_K32_LAUNCH(2, 32);
         }
 #undef FGCN_K32_LAUNCH
 #undef FGCN_K32_NP
 #undef FGCN_K32_GO
+#undef FGCN_K32_GO6
+#undef FGCN_K32_WIDE_NP
         return launch_status("tconv_halo");
     }
     if ((fgcn::tuning(5) & 2) && tiles * p.tiles_n < (1ll << 30)) {   // measured neutral: off

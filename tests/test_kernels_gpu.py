@@ -260,7 +260,10 @@ def test_halo_temporal_conv_with_the_input_stage_fused(B, T, V, C):
         u = torch.full((B, T, V, C), 3.0, device=dev())
         part = ops.tconv_halo(yg, w4, u, Th=T, taps=kt, tb=1, tc=-4, bias=to_gpu(bias), stats=True, fuse_in=(vg, xg, g, sign))
         assert torch.equal(g, g_ref) and torch.equal(sign, sign_ref)
-        assert torch.equal(u, u_ref) and torch.equal(part, part_ref)
+        assert torch.equal(u, u_ref)
+        # (the partial sums are per row tile, and the two-pass form may run another row tiling -- 192-row tiles at 64 columns: their
+        # totals agree to rounding)
+        assert rel_l2(part.double().sum(0).cpu().numpy(), part_ref.double().sum(0).cpu().numpy()) < 1e-6
         assert rel_l2(u.cpu().numpy(), want.numpy()) < tol
 
     both_forms(FWD_TOL)
