@@ -44,13 +44,15 @@ int fgcn_check_device(void);
  *   1  row GEMM, wider N: 0 = two barriers per K chunk, 1 = double-buffered LDS
  *   4  f32 halo conv: 0 = three workgroups per CU, 1 = two
  *   5  workgroup orders (bits): 1 row GEMM XCD-aware order on; 8 row GEMM column-tile-fastest off; 4 generic weight gradient (rows_wgrad) XCD-aware off;
- *      16 spatial forward XCD-aware off; 32 split-bf16 halo conv XCD-aware off; 2 f32 halo conv XCD-aware on
+ *      16 spatial forward XCD-aware off; 32 split-bf16 halo conv XCD-aware off; 2 f32 halo conv XCD-aware on; 64 split weight gradient XCD-aware off
  *   6  (bits) 1: 1x1 weight gradients of the bf16 modes on the 256-thread kernel that splits fragments as it reads them;
  *      8: joint_dagg at two workgroups per CU; 16: joint_dagg's gram on the f32 MFMA in every mode;
  *      32: 1x1 weight gradients on ONE 8-wave workgroup per CU (default: two 4-wave ones); 64: all-taps kernels above 64 output
- *      columns on 8 waves (default 4); 256: at 64 columns on 4 waves (default 8); 128: all-taps weight gradient without the circular tap window
+ *      columns on 8 waves (default 4); 256: at 64 columns on 4 waves (default 8); 128: all-taps weight gradient without the circular tap window;
+ *      512: fgcn_spatial_wgrad on exact-f32 MFMAs in math mode bf16x3 (default there: the split-bf16 form)
  *   7  split-bf16 kernels (bits) 1: spatial forward, one frame per wave (older form); 2: halo conv on the 32x32x16 MFMA shape;
- *      4: the same for N <= 64 only */
+ *      4: the same for N <= 64 only; 8: split-bf16 halo conv at <= 64 output columns as 2 x 2 waves over 128-row tiles (default: 4 x 1 waves
+ *      over 192-row tiles from 1536 tiles on) */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
