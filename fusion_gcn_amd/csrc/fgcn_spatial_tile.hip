@@ -84,29 +84,34 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
         d[2 * 32 * ST_AHB / 2] = (unsigned short)pl;
     }
 
-    // this wave's aggregation units of a chunk: unit u = wave + 4 i -> (pair slot q = u / F, frame f = u % F)
+    // this wave's aggregation units of a chunk: the 2 F units in frame-major order (f0 q0, f0 q1, f1 q0, ...) are dealt to the waves in
+    // contiguous blocks, so the two pairs of a frame mostly land on ONE wave -- when they share the channel tile (two chunks of three) that
+    // wave loads and splits the frame's x rows once for both
     int uq[MAXU], uf[MAXU];
-    bool uok[MAXU];
+    bool uok[MAXU], ushare[MAXU];
+    const int u_lo = __builtin_amdgcn_readfirstlane((wave * 2 * F) >> 2), u_hi = __builtin_amdgcn_readfirstlane(((wave + 1) * 2 * F) >> 2);
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
-        const int u = wave + 4 * i;
-        uq[i] = __builtin_amdgcn_readfirstlane(u / F);
-        uf[i] = __builtin_amdgcn_readfirstlane(u - uq[i] * F);
-        uok[i] = uq[i] < 2 && uf[i] < nf;                            // (wave-uniform)
+        const int u = u_lo + i;
+        uq[i] = u & 1;
+        uf[i] = u >> 1;
+        uok[i] = u < u_hi && uf[i] < nf;                             // (wave-uniform)
+        ushare[i] = i > 0 && uok[i] && uok[i - 1] && uf[i] == uf[i - 1];   // same frame as the previous unit (then q = 1 after q = 0)
     }
     const int npairs = 3 * (p.Cin >> 5);                             // (channel tile, subset) pairs; even (Cin % 64 == 0)
     const int nchunks = npairs >> 1;
     const unsigned row_b = (unsigned)p.ld_x * 4u;
-    // two register sets: the x rows of chunk c + 1 are requested at the START of chunk c's staging phase (behind the barrier) and have
-    // landed when the feature MFMAs begin.  Requested at the start of the MFMA phase instead, they sat in front of every weight
-    // fragment of that phase in the in-order vmcnt queue -- a wait for a weight load (an L2 hit) then waited for the HBM loads
-    // before it: measured 0.17 ms of a 0.81 ms launch (FGCN_PROBE_ST)
-    float xrA[MAXU][16], xrB[MAXU][16];
+    // the x rows of chunk c + 1 are requested at the start of chunk c's feature phase and parked in registers.  (A second register set,
+    // requested a phase earlier so that the loads are not queued in front of the phase's weight fragments in the in-order vmcnt queue,
+    // measured the same and cost 48 registers: FGCN_PROBE_ST puts the fetches at 0.12-0.17 ms of a 0.8 ms launch either way.)
+    float xrA[MAXU][16];
     // x of (frame, channel tile): lane = channel, register 8 s + j = joint 16 s + 8 h + j (the k order of the 32x32x16 fragment); the
     // joint's row offset splits into a per-lane part (8 h rows) and a scalar part (16 s + j rows, the instruction's soffset)
     auto fetch_units = [&](int c, float (&xr)[MAXU][16]) {
+        const bool same_ci = (2 * c + 1) % 3 != 0;                   // both pairs of chunk c read the same channel tile
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
+            if (ushare[i] && same_ci) continue;                      // (wave-uniform) the previous unit's rows serve this one too
             const int pq = 2 * c + uq[i];
             const int ci = pq / 3;
             const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * h) * p.ld_x + ci * 32 + l31) * 4u;
@@ -120,21 +125,27 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     };
     const unsigned char* af_lane = ahs + l31 * ST_AHB + 16 * h;      // + (k * NP + part) * 32 * ST_AHB + 32 * s2
     auto stage_units = [&](int c, float (&xr)[MAXU][16]) {
+        const bool same_ci = (2 * c + 1) % 3 != 0;
+        u32x4v xs[2][NP];                                            // the split x rows of the current frame (kept across a shared pair)
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
             if (!uok[i]) continue;                                   // wave-uniform
             const int pq = 2 * c + uq[i];
             const int k = pq - 3 * (pq / 3);
             f32x16 agg = zero16();
+            if (!(ushare[i] && same_ci)) {                           // wave-uniform
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    split3_x8(xr[i][8 * s2], xr[i][8 * s2 + 1], xr[i][8 * s2 + 2], xr[i][8 * s2 + 3], xr[i][8 * s2 + 4], xr[i][8 * s2 + 5],
+                              xr[i][8 * s2 + 6], xr[i][8 * s2 + 7], xs[s2]);
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4v xs[NP], af[NP];
-                split3_x8(xr[i][8 * s2], xr[i][8 * s2 + 1], xr[i][8 * s2 + 2], xr[i][8 * s2 + 3], xr[i][8 * s2 + 4], xr[i][8 * s2 + 5],
-                          xr[i][8 * s2 + 6], xr[i][8 * s2 + 7], xs);
+                u32x4v af[NP];
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * NP + pl) * 32 * ST_AHB + 32 * s2);
-                agg = mfma_x3_k16(xs, af, agg);                      // agg^T (32 c x 32 w): lane = joint w, register r = channel acc_row(r)
+                agg = mfma_x3_k16(xs[s2], af, agg);                  // agg^T (32 c x 32 w): lane = joint w, register r = channel acc_row(r)
             }
             // this lane's joint w = l31 of frame uf: image row uq * 128 + uf * V + w, channels 8 g + 4 h + (0..3) per register group
             const int R = uq[i] * 128 + uf[i] * V + l31;
@@ -198,18 +209,14 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
             }
         }
     };
-    auto chunk = [&](int c, float (&cur)[MAXU][16], float (&nxt)[MAXU][16]) {
-        __syncthreads();                                             // the previous chunk's image reads are done (first pass: the A^ planes are written)
-        if (c + 1 < nchunks && !(FGCN_PROBE_ST & 4)) fetch_units(c + 1, nxt);
-        if (!(FGCN_PROBE_ST & 1) || c == 0) stage_units(c, cur);
-        __syncthreads();
-        feature_phase(c);
-    };
     fetch_units(0, xrA);
     load_w(wq[0], 0, 0);
-    for (int c = 0; c < nchunks; c += 2) {                           // (nchunks = 3 Cin / 64 is a multiple of 3; an odd count ends on the first half)
-        chunk(c, xrA, xrB);
-        if (c + 1 < nchunks) chunk(c + 1, xrB, xrA);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                             // the previous chunk's image reads are done (first pass: the A^ planes are written)
+        if (!(FGCN_PROBE_ST & 1) || c == 0) stage_units(c, xrA);
+        __syncthreads();
+        if (c + 1 < nchunks && !(FGCN_PROBE_ST & 4)) fetch_units(c + 1, xrA);   // lands during the MFMAs below
+        feature_phase(c);
     }
 
     // ---- epilogue: bias, branch-free buffer stores, BatchNorm partial sums (accumulator register r of lane (col l15, g4) = row
