@@ -7,7 +7,8 @@
 namespace fgcn {
 
 constexpr int ELEM_ROWS_PER_TILE = 64;    // small tiles keep >= 8 workgroups per CU busy even at 8 clips per GPU
-constexpr int ELEM_MAX_TILES = 2048;
+constexpr int ELEM_MAX_TILES = 1024;    // partial rows of the reduction kernels (summed by reduce_sum, 22 launches per step whose time follows the
+                                        // row count): same-box step A/B 2048 -> 1024: 60.95 -> 60.66 ms; 512: 61.4-61.7 (the reduce kernels lose bandwidth)
 
 // ---- BatchNorm finalize ------------------------------------------------------------------------------------
 // block = 8 channels x 128 partial-groups (C/8 workgroups, 4 loads in flight per thread: the 7500-tile partial arrays
