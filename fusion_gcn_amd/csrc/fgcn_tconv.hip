@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     constexpr int BMR = WR * 16 * MTW;               // output rows per workgroup: 128 (2 x 2 waves) or 192 (4 x 1)
     static_assert(NP == 1 || NP == 2 || NP == 3, "one or three bf16 parts per operand, or two f16 parts (FGCN_PRODUCTS_F16X2)");
     static_assert(!(FIN && NP == 2), "the fused input stage is not built for the f16x2 products");
-    static_assert((NT == 1 || NT == 2) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns");
+    static_assert((NT == 1 || NT == 2 || (NT == 4 && WR == 4)) && (KC == 32 || KC == 64), "wave tile is 64 rows x 32 or 64 columns (48 x 128 as 4 x 1 waves)");
     // Image rows are KC bf16 = 64 / 128 bytes with NO padding; the 32-byte blocks of a row are XOR-swizzled with row bits instead.
     // A fragment read is ds_read_b128 of (row base + l15, 16-byte chunk g4 [+ 4 per 32-channel step]); its four lane groups are the
     // NON-contiguous sets {0-3,12-15,20-27}, ... (MI355X_MICROARCH.md, LDS): each holds 8 rows at chunk c and 8 other rows at
@@ -824,7 +824,11 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     int bmr = halo_tile_rows(V);
     p.stats_rows = (int)cdiv(p.Mv, bmr);
     // split kernels, <= 64 output columns, tap form: waves 4 x 1 over 192-row tiles (see the kernel; key 7 bit 3 keeps the 2 x 2 form)
-    const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && N <= 64 && N > 32 && !(taps == 1 && K % 64 == 0) &&
+    // the same arrangement for ONE 128-column tile (64 < N <= 128): a wave owns 48 rows x 128 columns, every image fragment feeds eight
+    // units: -5 % (bf16x3) / -9 % (f16x2) at 128 channels, nothing at 256 (two column tiles; key 7 bit 4 forces it there, bit 5 switches it
+    // off); epilogue forms 0 and 3 only -- the BatchNorm-sums epilogue would spill at 255 registers
+    const bool wide128 = ((fgcn::tuning(7) & 16) || (N <= 128 && !(fgcn::tuning(7) & 32))) && N > 64 && !bn_a;
+    const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && ((N <= 64 && N > 32) || wide128) && !(taps == 1 && K % 64 == 0) &&
                            !(fin_vec || fin_res || fin_out || fin_mask) && !(fgcn::tuning(7) & 8) &&
                            192 + (dmax - p.dmin) * V <= 32 * HALO_MAX_STAGE && (size_t)(192 + (dmax - p.dmin) * V) * 64 * 3 + 16 <= 80 * 1024 &&
                            cdiv(p.Mv, 192) >= 1536;   // (three rounds of 512 workgroups: below, the coarser tiling quantises worse -- 8-clip step +0.07 ms)
@@ -912,7 +916,10 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
             else FGCN_K32_LAUNCH(2, 64);
         } else {
-            if (wide_rows) {
+            if (wide_rows && N > 64) {
+                if (epi == 0) { if (one) FGCN_K32_GO6(4, 32, 1, 0, false, 4); else if (two) FGCN_K32_GO6(4, 32, 2, 0, false, 4); else FGCN_K32_GO6(4, 32, 3, 0, false, 4); }
+                else { if (one) FGCN_K32_GO6(4, 32, 1, 3, false, 4); else if (two) FGCN_K32_GO6(4, 32, 2, 3, false, 4); else FGCN_K32_GO6(4, 32, 3, 3, false, 4); }
+            } else if (wide_rows) {
                 if (epi == 0) FGCN_K32_WIDE_NP(0);
                 else if (epi == 3) FGCN_K32_WIDE_NP(3);
                 else FGCN_K32_WIDE_NP(2);
