@@ -60,7 +60,7 @@ def test_host_side_validation(lib):
     assert lib.fgcn_spatial_fwd(p16, p16, p16, None, p16, None, 1, 1, 25, 3, 64, 4, 64, 3, 1, None) == -2   # Cin % 4
     # bn reduce with a wrong tile count
     assert lib.fgcn_bn_act_bwd_reduce(p16, p16, None, p16, p16, None, None, p16, 7, 1000, 64, 0, 1, None) == -1   # needs 16 tiles
-    assert lib.fgcn_elem_tiles(1000) == 16 and lib.fgcn_elem_tiles(10 ** 7) == 2048 and lib.fgcn_rows_gemm_tiles(129) == 2
+    assert lib.fgcn_elem_tiles(1000) == 16 and lib.fgcn_elem_tiles(10 ** 7) == 1024 and lib.fgcn_rows_gemm_tiles(129) == 2
     assert lib.fgcn_spatial_tiles(128, 300) == 128 * 10
 
 
