@@ -831,7 +831,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && ((N <= 64 && N > 32) || wide128) && !(taps == 1 && K % 64 == 0) &&
                            !(fin_vec || fin_res || fin_out || fin_mask) && !(fgcn::tuning(7) & 8) &&
                            192 + (dmax - p.dmin) * V <= 32 * HALO_MAX_STAGE && (size_t)(192 + (dmax - p.dmin) * V) * 64 * 3 + 16 <= 80 * 1024 &&
-                           cdiv(p.Mv, 192) >= 1536;   // (three rounds of 512 workgroups: below, the coarser tiling quantises worse -- 8-clip step +0.07 ms)
+                           (cdiv(p.Mv, 192) >= 1536 || (fgcn::tuning(7) & 64));   // (three rounds of 512 workgroups: below, the coarser tiling quantises worse -- 8-clip step +0.07 ms)
     if (wide_rows) bmr = 192;
     p.halo_rows = bmr + (dmax - p.dmin) * V;
     FGCN_REQUIRE(p.halo_rows <= 32 * HALO_MAX_STAGE, FGCN_E_BADARG, "tconv_halo: halo of %d rows too large", p.halo_rows);

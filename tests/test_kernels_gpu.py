@@ -465,6 +465,44 @@ def test_spatial_wgrad_fused_agg_recompute(V, T, cin, cout, B):
     assert rel_l2(shared[0].cpu().numpy(), want1.numpy()) < RED_TOL
 
 
+@pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 20, 27, 64), (2, 9, 25, 128), (1, 5, 28, 64)])
+def test_halo_conv_wave_arrangements_agree(B, T, V, C):
+    """The nine-tap halo conv as 4 x 1 waves over 192-row tiles (64 output columns: used from 1536 tiles on, forced here by tuning key 7
+    bit 6; one 128-column tile: the default for 64 < N <= 128) against 2 x 2 waves over 128-row tiles (key 7 bits 3 / 5): the outputs
+    bit for bit (each output element is the same sum in the same order), the BatchNorm partial sums in total; forward, data gradient
+    with the BatchNorm-backward sums in its epilogue, and the accumulating second pass of a strided forward."""
+    from fusion_gcn_amd import _lib, ops
+    if not ops.tconv_halo_bn_sums():
+        pytest.skip("the split-bf16 halo kernel")
+    lib = _lib.load()
+    kt = 9
+    wt = rnd(kt, C, C, seed=400, scale=(kt * C) ** -0.5)
+    g, bias = to_gpu(rnd(B, T, V, C, seed=401)), to_gpu(rnd(C, seed=402))
+    y = to_gpu(rnd(B, T, V, C, seed=403))
+    vec = to_gpu(torch.stack([rnd(C, seed=404), rnd(C, seed=405).abs() + 0.5, rnd(C, seed=406), rnd(C, seed=407)]))
+    _, sign = ops.bn_act(y, vec, g, None, relu=True, sign_mask=True)
+
+    def run(bn_bwd):
+        w4 = ops.pack_conv(to_gpu(wt))
+        u = torch.full((B, T, V, C), 3.0, device=dev())
+        part = ops.tconv_halo(g, w4, u, Th=T, taps=kt, tb=1, tc=-4, bias=bias, stats=not bn_bwd, bn_bwd=(y, sign, vec) if bn_bwd else None)
+        acc = u.clone()
+        ops.tconv_halo(g, w4, acc, Th=T, taps=kt, tb=1, tc=-4, accumulate=True, stats=True)
+        return u, part, acc
+    try:
+        outs = {}
+        for name, key in (("2x2", 8 | 32), ("4x1", 64)):
+            lib.fgcn_set_tuning(7, key)
+            outs[name] = [run(False), run(True) if C <= 64 else None]
+    finally:
+        lib.fgcn_set_tuning(7, 0)
+    for a, b in zip(outs["2x2"], outs["4x1"]):
+        if a is None:
+            continue
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        assert rel_l2(a[1].double().sum(0).cpu().numpy(), b[1].double().sum(0).cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
                                              (16, 8, 128, 128, 1), (32, 5, 64, 96, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1)])
 def test_spatial_forward_tile_form(V, T, cin, cout, B):
