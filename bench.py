@@ -316,9 +316,9 @@ def main():
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--wgrad-stream", choices=("auto", "side", "main", "side-high", "side-low"), default="auto",
-                    help="weight-gradient kernels on a second HIP stream beside the HBM-bound chain (side), in line (main), or by the "
-                         "size of the block's tensors (auto, the library default: side from ~24 clips per GPU upwards)")
+    ap.add_argument("--wgrad-stream", choices=("auto", "side", "main", "side-high", "side-low"), default="main",
+                    help="weight-gradient kernels in line (main, the library default since the end of round 3), on a second HIP stream "
+                         "beside the HBM-bound chain (side), or by the size of the block's tensors (auto: side from ~24 clips per GPU upwards)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--joints", type=int, choices=(25, 27, 22), default=25,
                     help="25: the headline (BASELINE config 2); 27: config 3 (NTU graph + 2 IMU joints); 22: config 4 (MMAct COCO-18 + "

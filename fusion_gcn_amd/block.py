@@ -463,7 +463,10 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 # returns.  WGRAD_SIDE_STREAM: "auto" (side stream from WGRAD_SIDE_MIN_WORK output elements per block upwards -- B*T'*V*cout is
 # the same for all ten blocks of the model: 480,000 per sample), True, False.  WGRAD_STREAM_PRIORITY: 0 normal, -1 high (torch
 # convention; high priority measured 1.5x SLOWER at 8 clips).
-WGRAD_SIDE_STREAM = "auto"
+# Final state of round 3 (same-box A/B, profiles/r03_ab_wgrad_stream.txt): with the XCD-aware weight-gradient order and the shorter
+# epilogues the side stream no longer pays -- 64 clips 59.33 / 59.39 ms in line vs 59.37 / 59.51 (auto = side) / 59.61 / 59.43 (side), 32 clips
+# 31.14 / 31.15 vs 31.28 / 31.31 -- so the default is in line (one stream, no cross-stream edges in the recorded graph); "auto" keeps the old rule.
+WGRAD_SIDE_STREAM = False
 WGRAD_SIDE_MIN_WORK = 48 * 480_000
 WGRAD_STREAM_PRIORITY = 0
 _side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
