@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,9 @@ def _r(c: int, m: int) -> int:
     return (c + m - 1) // m * m
 
 
+_SPLIT_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 def _split_form(mod, name: str, w: torch.Tensor):
     """The split form of a (1, K, N) matrix that is rebuilt every call (a transposed / padded weight) in the products of the current math
     mode.  bf16x3 / bf16: one ``fgcn_pack_split3`` launch.  f16x2: the FGCN_PACK_SPLIT2H form goes through a pack plan whose device-side
@@ -37,7 +42,7 @@ def _split_form(mod, name: str, w: torch.Tensor):
     if ops.get_math_mode() != "f16x2":
         return ops.pack_split3(w)
     from ...packing import Form, PackPlan, Seg
-    cache = mod.__dict__.setdefault("_split_cache", {})
+    cache = _SPLIT_CACHE.setdefault(mod, {})          # (kept beside the module, not in it: state_dict / pickling never see it)
     ent = cache.get(name)
     if ent is None or ent[0].shape != w.shape or ent[0].device != w.device:
         stage = torch.empty_like(w)
