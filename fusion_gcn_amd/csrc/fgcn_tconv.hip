@@ -58,6 +58,9 @@ struct HaloP {
                                         // row tiles fills tiles_m of them and zeroes the rest
 };
 
+#ifndef FGCN_HALO_RING
+#define FGCN_HALO_RING 4                // 2: the two-slot weight ring everywhere (A/B builds)
+#endif
 #ifndef FGCN_HALO_PF64
 #define FGCN_HALO_PF64 1
 #endif
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     constexpr bool PF = KC == 64 || (NT == 1 && NP == 3 && !FIN && FGCN_HALO_PF64);
     constexpr int NST = KC == 64 ? 8 : HALO_MAX_STAGE;
     constexpr int NU = 2 * NT;                       // 16-column tiles (units) of a wave
+    constexpr int RS = (FGCN_HALO_RING == 4 && NU == 4 && NP >= 2 && (EPI != 2 || WR == 4) && !FIN) ? 4 : 2;   // weight ring slots (requested RS - 1 units ahead)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -533,8 +537,9 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         }
     };
 
-    u32x4v a[MTW][NP], wq[2][NP];
-    load_w(wq[0], 0, 0, 0);
+    u32x4v a[MTW][NP], wq[RS][NP];
+#pragma unroll
+    for (int nu = 0; nu < RS - 1; ++nu) load_w(wq[nu], nu, 0, 0);
     if constexpr (PF) fetch(0);
     float* smax = reinterpret_cast<float*>(Xh + NP * plane);      // NP == 2: the four waves' chunk maxima (16 bytes behind the planes)
     auto chunk_max = [&]() {                         // this wave's largest staged magnitude -> its LDS word
@@ -598,13 +603,14 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             const int itn = it + 1 < IT2 ? it + 1 : it;                  // the chunk's last step re-reads itself (unused)
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], nu + 1, it, kc);
-                else load_w(wq[0], 0, it + 1, kc);
+                const int t = nu + RS - 1;                               // the ring: the unit RS - 1 ahead (this step's, or the next's)
+                if (t < NU) load_w(wq[t % RS], t, it, kc);
+                else load_w(wq[t % RS], t - NU, it + 1, kc);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
-                    else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu & 1], acc[mt][nu]);
-                    else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
+                    if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
+                    else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu % RS], acc[mt][nu]);
+                    else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu % RS][0], acc[mt][nu]);
                     if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
                 }
             }

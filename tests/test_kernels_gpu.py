@@ -192,11 +192,13 @@ def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
 
 @pytest.mark.parametrize("rows,K,N,ld_in,ld_out", [
     (3000, 64, 96, 64, 96), (2999, 96, 64, 96, 64), (1283, 128, 384, 128, 384), (517, 192, 128, 192, 128), (4097, 256, 768, 256, 768),
-    (130, 384, 256, 384, 256), (1000, 64, 128, 64, 128), (127, 32, 4, 36, 8), (12000, 64, 192, 64, 192), (70000, 64, 64, 64, 64)])
+    (130, 384, 256, 384, 256), (1000, 64, 128, 64, 128), (127, 32, 4, 36, 8), (12000, 64, 192, 64, 192), (70000, 64, 64, 64, 64),
+    (700, 96, 192, 96, 192), (300, 32, 128, 32, 128), (513, 160, 132, 160, 136)])
 def test_persistent_pointwise_gemm(rows, K, N, ld_in, ld_out):
     """ops.pw_gemm (fgcn_pw.hip): the block's 1x1 convolutions in the split-bf16 modes -- out = in . W + bias with BatchNorm
     partial sums, and the accumulating form -- against float64; ragged last tile, 32-channel tail chunk (K = 96), one and several
-    column tiles, more tiles than workgroups (the persistent walk), padded row strides; the one-tile-per-workgroup control (tuning
+    column tiles, more tiles than workgroups (the persistent walk), padded row strides, the four-slot weight ring of the 128-column form
+    across a one-step chunk, a single step per tile and a partial column tile; the one-tile-per-workgroup control (tuning
     key 8) must give the same bits."""
     from fusion_gcn_amd import _lib, ops
     if not ops.pw_gemm_available():

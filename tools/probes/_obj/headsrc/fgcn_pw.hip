@@ -18,11 +18,7 @@
 #include "fgcn_common.hpp"
 
 // Timing probes (wrong results; tools/probes builds only): bit 0 = no output stores, bit 1 = no MFMAs, bit 2 = the image is deposited
-// once per workgroup (later chunks skip the split + LDS writes), bit 3 = no input fetches after the first, bit 4 = weight fragments
-// loaded for the first chunk only
-#ifndef FGCN_PW_RING
-#define FGCN_PW_RING 4                  // 2: the two-slot ring everywhere (A/B builds)
-#endif
+// once per workgroup (later chunks skip the split + LDS writes), bit 3 = no input fetches after the first
 #ifndef FGCN_PROBE_PW
 #define FGCN_PROBE_PW 0
 #endif
@@ -53,12 +49,6 @@ template <int NT, int NP, bool ACC>
 __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 2 || NP == 3), "64 / 128 columns; one or three bf16 parts, or two f16 parts");
     constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
-    // Weight ring: fragments are requested RS - 1 units (of 24 MFMAs) ahead.  One unit is 384 matrix cycles, less than an L2 round trip
-    // under load: the FGCN_PROBE_PW bit 4 probe (weights loaded once) ran 16-29 % faster than the kernel with a two-slot ring.  Four
-    // slots (three units of cover) where the registers are there -- 128-column tiles without the accumulating epilogue (256 VGPRs, no
-    // scratch): -3 .. -18 % per launch (profiles/r03_ab_pw_ring.txt); the accumulating form would spill (and its old-value loads shrunk
-    // to half row tiles to make room cost more than the ring wins), the 64-column form has two units per step.
-    constexpr int RS = (FGCN_PW_RING == 4 && NU == 4 && !ACC) ? 4 : 2;
     constexpr int TPR = KC / 4, RPP = 256 / TPR, NST = BMR / RPP;      // 16 threads per row, 16 rows per pass, 8 passes
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 6) << 4; };
@@ -135,7 +125,6 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
         const int col = bn * BN + wc * NT * 32 + nu * 16 + l15;
         const int kg = (k >> 3) + g4;
         const unsigned off = (col < p.N && kg < K8) ? (unsigned)(((long long)kg * p.N + col) * 16) : OOB;
-        if ((FGCN_PROBE_PW & 16) && !probe_first) return;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
     };
@@ -147,11 +136,10 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     };
 
     int bm = vid / p.tiles_n, bn = vid - bm * p.tiles_n;
-    u32x4v a[MTW][NP], wq[RS][NP];
+    u32x4v a[MTW][NP], wq[2][NP];
     set_rows(bm);
     fetch(0);
-#pragma unroll
-    for (int nu = 0; nu < RS - 1; ++nu) load_w(wq[nu], bn, nu, 0);
+    load_w(wq[0], bn, 0, 0);
     while (true) {
         const int vnext = vid + p.wg_per_xcd;
         const bool more = vnext < v_end;
@@ -202,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                 abound = (abound > 44 ? abound : 44) + 1;
             }
             if (!(FGCN_PROBE_PW & 4) || probe_first) deposit();
+            probe_first = false;
             __syncthreads();
             const bool last_chunk = kc + KC >= p.K;
             if (!last_chunk) {
@@ -218,26 +207,23 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                 const bool last_step = s2 + 1 == nsteps;
 #pragma unroll
                 for (int nu = 0; nu < NU; ++nu) {
-                    // the ring: the weights of the unit RS - 1 ahead -- a later column unit of this step, or a unit of the next step, the
-                    // next chunk, or the next tile's first step
-                    const int t = nu + RS - 1;
-                    if (t < NU) load_w(wq[t % RS], bn, t, kc + 32 * s2);
-                    else if (!last_step) load_w(wq[t % RS], bn, t - NU, kc + 32);
-                    else if (!last_chunk) load_w(wq[t % RS], bn, t - NU, kc + KC);
-                    else load_w(wq[t % RS], bn_n, t - NU, 0);
+                    // the ring: the next unit's weights -- next column unit, next step, next chunk, or the next tile's first unit
+                    if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], bn, nu + 1, kc + 32 * s2);
+                    else if (!last_step) load_w(wq[0], bn, 0, kc + 32);
+                    else if (!last_chunk) load_w(wq[0], bn, 0, kc + KC);
+                    else load_w(wq[0], bn_n, 0, 0);
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) {
                         if constexpr ((FGCN_PROBE_PW & 2) != 0) {
-                            acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu % RS][0][0]);
+                            acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu & 1][0][0]);
                             continue;
                         }
-                        if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
-                        else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu % RS], acc[mt][nu]);
-                        else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu % RS][0], acc[mt][nu]);
+                        if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                        else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                        else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu & 1][0], acc[mt][nu]);
                     }
                 }
             }
-            probe_first = false;
         }
 
         // ---- epilogue: bias, accumulate, branch-free buffer stores, BatchNorm partial sums (accumulator register r of lane
