@@ -78,12 +78,18 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     out[3 * C + c] = beta[c] - rmean[c] * scale;
 }
 
+// 16 bytes per lane, plain or non-temporal (`stream`: a kernel argument, fgcn_common.hpp stream_out -- large activations are streamed
+// past L2: the backward apply pass -9 .. -12 % at the 64-clip step's sizes)
+__device__ __forceinline__ void store4(float* ptr, f32x4 val, int stream) {
+    if (stream) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(ptr));
+    else *reinterpret_cast<f32x4*>(ptr) = val;
+}
 // ---- forward epilogue ----------------------------------------------------------------------------------------
 // MASK: also writes the sign bits of the result (bit e%8 of byte e/8 = [out[e] > 0]) for the backward passes, which then
 // read 1/32 of an activation instead of `out`; a lane pair shares a byte (n4 is even, host check).
 template <int RES, bool MASK>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
-                                                     float* out, unsigned char* mask, long long n4, int C, int relu) {
+                                                     float* out, unsigned char* mask, long long n4, int C, int relu, int stream) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = y;
+        store4(out + i * 4, y, stream);
         if (MASK) {
             const int nib = (y[0] > 0.f ? 1 : 0) | (y[1] > 0.f ? 2 : 0) | (y[2] > 0.f ? 4 : 0) | (y[3] > 0.f ? 8 : 0);
             const int other = __shfl_xor(nib, 1);
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                                                                const float* va, const float* b, const float* vb,
                                                                const float* sums, float* da, float* db, long long n4,
                                                                int C, int relu, int train, float inv_m,
-                                                               int db_accumulate) {
+                                                               int db_accumulate, int stream) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
             ga = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
                  ah * (*reinterpret_cast<const f32x4*>(sums + C + c) * inv_m);
         }
-        *reinterpret_cast<f32x4*>(da + i * 4) = ga * sc_a;
+        store4(da + i * 4, ga * sc_a, stream);
         if (RES != 0 && db) {
             f32x4 gb = dp;
             if (RES == 2) {
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                 gb = gb * sc_b;
             }
             if (db_accumulate) gb += *reinterpret_cast<const f32x4*>(db + i * 4);
-            *reinterpret_cast<f32x4*>(db + i * 4) = gb;
+            store4(db + i * 4, gb, db_accumulate ? 0 : stream);
         }
     }
 }
@@ -319,12 +325,13 @@ extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, c
     hipStream_t s = (hipStream_t)stream;
     FGCN_REQUIRE(!sign_mask || n4 % 2 == 0, FGCN_E_BADARG, "bn_act: a sign mask needs rows*C to be a multiple of 8");
     dim3 g(stream_blocks(n4)), blk(256);
+    const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_ACT(RES_)                                                                                         \
     do {                                                                                                          \
         if (sign_mask)                                                                                            \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu); \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str); \
         else                                                                                                      \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu); \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str); \
     } while (0)
     if (res_mode == 0) FGCN_BN_ACT(0);
     else if (res_mode == 1) FGCN_BN_ACT(1);
@@ -387,9 +394,10 @@ extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const 
     const float inv_m = 1.f / (float)rows;
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
+    const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_APP(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                       da, db, n4, C, relu, train, inv_m, db_accumulate)
+                       da, db, n4, C, relu, train, inv_m, db_accumulate, str)
     if (res_mode == 0 || !db) {
         if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
     } else if (res_mode == 1) {

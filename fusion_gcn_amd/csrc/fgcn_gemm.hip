@@ -32,6 +32,7 @@ struct RowsGemmP {
     unsigned w_bytes;
     int tiles_m, tiles_n, per_xcd;  // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
     long long in_bs, out_bs, w_bs;  // fgcn_rows_gemm_batched: element strides of blockIdx.z's problem (0 otherwise)
+    int stream;                     // non-temporal output stores (fgcn_common.hpp, stream_out)
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
@@ -190,8 +191,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     // -- every earlier store's write acknowledgement -- at each join, on the plain path too).  Accumulating form: the old values of
     // group g + 1 are requested BEFORE the stores of group g, so a wait for them never includes those stores (vmcnt counts in issue order).
     const unsigned rstep = (unsigned)p.ld_out * 4u;
-    auto epilogue = [&](auto acc_c) {
-        constexpr bool ACC = decltype(acc_c)::value;
+    auto epilogue = [&](auto mode_c) {                     // 0 store, 1 accumulate, 2 store non-temporally (fgcn_common.hpp, stream_out)
+        constexpr bool ACC = decltype(mode_c)::value == 1;
+        constexpr int AUX = decltype(mode_c)::value == 2 ? FGCN_STORE_AUX : 0;
         constexpr int NG = NT * MT;                        // groups of 16 values: g = nt * MT + mt
         float bvs[NT];
         unsigned off0[NG];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
                 const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
                 float val = acc[mt][nt][r] + bvs[nt];
                 if constexpr (ACC) val += old[g & 1][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off0[g] + dr * rstep, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off0[g] + dr * rstep, 0, AUX);
                 const float kept = (off0[g] != OOB && rel0 + dr < tile_rows) ? val : 0.f;
                 ssum[nt] += kept;
                 ssq[nt] += kept * kept;
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
             if constexpr (ACC) __builtin_amdgcn_sched_barrier(0);   // (keep the request / store order as written)
         }
     };
-    if (p.accumulate) epilogue(std::true_type{});          // wave-uniform
-    else epilogue(std::false_type{});
+    if (p.accumulate) epilogue(std::integral_constant<int, 1>{});          // (kernel-uniform)
+    else if (p.stream) epilogue(std::integral_constant<int, 2>{});
+    else epilogue(std::integral_constant<int, 0>{});
     if (p.stats) {
         __syncthreads();  // As is free now: reuse as [2][4 waves][BN]
         float* red = As;
@@ -638,7 +641,8 @@ static int rows_gemm_launch(const float* in, float* out, const float* w, const f
     if (int e = check_tmap(map)) return e;
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
                 map.taps, map.ta, map.tb, map.tc, map.td, accumulate,
-                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0, in_bs, out_bs, w_bs};
+                (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0, in_bs, out_bs, w_bs,
+                (!accumulate && fgcn::stream_out((long long)batch * B * T_out * V * N * 4)) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;

@@ -49,8 +49,9 @@ using u32x4p = __attribute__((ext_vector_type(4))) unsigned int;
 // drained vmcnt(0) in front of EVERY group of four stores, i.e. sixteen full write round trips per tile and wave (found with the
 // FGCN_PROBE_PW timing probes: the stores cost 22 % of the kernel, the time the written bytes take at the HBM rate, with nothing
 // overlapping them).
-template <int NT, int NP, bool ACC>
+template <int NT, int NP, bool ACC, bool STR = false>          // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
 __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
+    static_assert(!(ACC && STR), "an accumulating epilogue stores plainly");
     static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 2 || NP == 3), "64 / 128 columns; one or three bf16 parts, or two f16 parts");
     constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     // Weight ring: fragments are requested RS - 1 units (of 24 MFMAs) ahead.  One unit is 384 matrix cycles, less than an L2 round trip
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                     if constexpr (ACC) val += old[mt & 1][nu][r];
                     if ((FGCN_PROBE_PW & 1) && val != 123.456f) continue;
                     const unsigned vo = (whole || ((rmask >> (4 * mt + r)) & 1u)) ? cbase[nu] : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, vo, (unsigned)(mt * 16 + r) * ld_b, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, vo, (unsigned)(mt * 16 + r) * ld_b, STR ? FGCN_STORE_AUX : 0);
                     const float kept = vo != OOB ? val : 0.f;
                     ssum[nu] += kept;
                     ssq[nu] += kept * kept;
@@ -342,7 +343,7 @@ extern "C" int fgcn_pw_gemm_available(void) {
 }
 
 extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
-                            int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream) {
+                            int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream_) {
     FGCN_REQUIRE(in && out && w3 && rows > 0, FGCN_E_BADARG, "pw_gemm: null pointer or no rows");
     FGCN_REQUIRE(fgcn_pw_gemm_available(), FGCN_E_BADARG, "pw_gemm: a split-bf16 math mode (bf16x3 / bf16) only");
     FGCN_REQUIRE(K > 0 && K % 32 == 0 && N > 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N,
@@ -372,10 +373,12 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
     const dim3 grid((unsigned)(p.wg_per_xcd * 8));
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16, two = fgcn::f16x2_products();
     const size_t lds = (size_t)128 * 128 * (one ? 1 : (two ? 2 : 3)) + 16;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = (hipStream_t)stream_;
+    const bool stream = fgcn::stream_out(rows * (long long)N * 4);
 #define FGCN_PW_LAUNCH(NT_, NP_)                                                                                         \
     do {                                                                                                                 \
         if (accumulate) hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, true>), grid, dim3(256), lds, s, p);                  \
+        else if (stream) hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, false, true>), grid, dim3(256), lds, s, p);         \
         else hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, false>), grid, dim3(256), lds, s, p);                            \
     } while (0)
     if (narrow) {

@@ -324,7 +324,7 @@ constexpr int AHB = 80;    // bytes per [w] row of a split A^ plane (32 joints x
 // FGCN_PACK_SPLIT2H_ACC).  The step-2 accumulators carry S = ex + eA + e2 + ew; when a tile's natural S differs from the one in
 // force they are rescaled (a power of two: exact; upwards only while a running bound of log2 |acc| stays below 120, the remainder goes
 // into e2) and the epilogue multiplies 2^-S back out.
-template <int CT_IN, int NP = 3>
+template <int CT_IN, int NP = 3, bool STR = false>              // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
 __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
     static_assert(NP == 2 || NP == 3, "three bf16 parts or two f16 parts");
     constexpr int CT_OUT = 2, WROW = CT_OUT * 32;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void spatial_fwd_x3_kernel(SpatialP p) {
                     const f32x4 val = *reinterpret_cast<const f32x4*>(&T[r * TTS + c4]) + b4;
                     const bool keep = tv && r < V && ook;
                     const unsigned off = (keep && (!(FGCN_PROBE_SP & 1) || val[0] == 123.456f)) ? (unsigned)(((t - t0) * V + r) * p.ld_y + o) * 4u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, val), ry, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, val), ry, off, 0, STR ? FGCN_STORE_AUX : 0);
                     const f32x4 kept = keep ? val : f32x4{0.f, 0.f, 0.f, 0.f};
                     s1 += kept;
                     s2 += kept * kept;
@@ -654,8 +654,14 @@ static void launch_spatial_x3(const SpatialP& p, hipStream_t s) {
         q.per_xcd = (int)cdiv(total, 8);
         grid = dim3((unsigned)(q.per_xcd * 8));
     }
-    if (fgcn::f16x2_products()) hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 2>), grid, dim3(256), lds, s, q);
-    else hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 3>), grid, dim3(256), lds, s, q);
+    const bool str = fgcn::stream_out((long long)p.B * p.T * p.V * p.Cout * 4);
+    if (fgcn::f16x2_products()) {
+        if (str) hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 2, true>), grid, dim3(256), lds, s, q);
+        else hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 2>), grid, dim3(256), lds, s, q);
+    } else {
+        if (str) hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 3, true>), grid, dim3(256), lds, s, q);
+        else hipLaunchKernelGGL((spatial_fwd_x3_kernel<CI, 3>), grid, dim3(256), lds, s, q);
+    }
 }
 
 static int spatial_t_chunk(int B, int T) {

@@ -45,7 +45,7 @@ constexpr int ST_AHB = 80;              // bytes per [w] row of a split A^ plane
 constexpr int ST_XS = 64;               // bytes per image row and part (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
 constexpr int ST_PLANE = 256 * ST_XS;   // one part of the image: two pairs x 128 rows
 
-template <int NT, int MAXU>
+template <int NT, int MAXU, bool STR = false>                   // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
 __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     constexpr int NP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     constexpr unsigned OOB = 0x80000000u;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
                 const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
                 const unsigned off = (row < nrows && coff[nu] != OOB) ? (unsigned)((m0 + row) * p.ld_y * 4) + coff[nu] : OOB;
                 const float val = acc[mt][nu][r] + bv[nu];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ry, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ry, off, 0, STR ? FGCN_STORE_AUX : 0);
                 const float kept = off != OOB ? val : 0.f;
                 ssum[nu] += kept;
                 ssq[nu] = __builtin_fmaf(kept, kept, ssq[nu]);
@@ -319,15 +319,21 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
     const dim3 grid((unsigned)(p.per_xcd * 8));
     hipStream_t s = (hipStream_t)stream;
     const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
-#define FGCN_ST_GO(NT_, MU_)                                                                                        \
+    const bool str = fgcn::stream_out(y_bytes);
+#define FGCN_ST_GO3(NT_, MU_, STR_)                                                                                 \
     do {                                                                                                            \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_>),             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             opted = true;                                                                                           \
         }                                                                                                           \
-        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_>), grid, dim3(256), lds, s, p);                         \
+        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_>), grid, dim3(256), lds, s, p);                   \
+    } while (0)
+#define FGCN_ST_GO(NT_, MU_)                                                                                        \
+    do {                                                                                                            \
+        if (str) FGCN_ST_GO3(NT_, MU_, true);                                                                       \
+        else FGCN_ST_GO3(NT_, MU_, false);                                                                          \
     } while (0)
     if (narrow) {
         if (four) FGCN_ST_GO(1, 4);
@@ -337,5 +343,6 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
         else FGCN_ST_GO(2, 3);
     }
 #undef FGCN_ST_GO
+#undef FGCN_ST_GO3
     return launch_status("spatial_fwd_tile");
 }

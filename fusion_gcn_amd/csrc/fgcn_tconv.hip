@@ -331,8 +331,9 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // WR = wave rows: 2 = waves 2 x 2 over (128 rows x 64 NT columns); 4 = waves 4 x 1 over (192 rows x 32 NT columns), the form for 64
 // output columns (NT = 2): every image fragment then feeds FOUR 16-column units instead of two (half the LDS fragment reads per MFMA --
 // the 2 x 2 form at 64 columns reads 12 KB of fragments per 48 MFMAs and wave) and the halo image is re-staged 2.04x instead of 2.56x.
-template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2>
+template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false>   // STR: non-temporal output stores (stream_out)
 __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(!(STR && EPI == 3), "an accumulating epilogue stores plainly");
     static_assert(WR == 2 || (WR == 4 && KC == 32 && !FIN), "wave arrangement: 2 x 2, or 4 x 1 for the tap form");
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
     static_assert((EPI == 0 || EPI == 2 || EPI == 3) && !(FIN && EPI != 0), "epilogue: store / store + BatchNorm-backward sums / accumulate");
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                 const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
                 float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
                 if constexpr (ldacc) val += oldv[mt & 1][nu][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, STR ? FGCN_STORE_AUX : 0);
                 const float kept = off != OOB ? val : 0.f;
                 if constexpr (bnb) {
                     const float dp = (mbits[mt & 1][nu][r] >> ((off >> 2) & 7u)) & 1u ? kept : 0.f;
@@ -878,16 +879,22 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         FGCN_REQUIRE(bmr == 128 || wide_rows, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
         const int epi = bn_a ? 2 : (accumulate ? 3 : 0);     // epilogue form (compile time, see the kernel)
+        const bool stream_k = fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes
         const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;   // (opt-in beyond the default dynamic-LDS limit, once per instantiation)
-#define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
+#define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_)                                                               \
     do {                                                                                                                 \
         static bool opted = false;                                                                                       \
         if (!opted) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
             opted = true;                                                                                                \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_>), grid, dim3(256), lds_k, s, p);      \
+        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>), grid, dim3(256), lds_k, s, p); \
+    } while (0)
+#define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
+    do {                                                                                                                 \
+        if (EPI_ != 3 && stream_k) FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, (EPI_ != 3));                            \
+        else FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, false);                                                        \
     } while (0)
 #define FGCN_K32_GO(NT_, KC_, NP_, EPI_, FIN_) FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, 2)
 #define FGCN_K32_WIDE_NP(EPI_)                                                                                           \
@@ -936,6 +943,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
 #undef FGCN_K32_NP
 #undef FGCN_K32_GO
 #undef FGCN_K32_GO6
+#undef FGCN_K32_GO7
 #undef FGCN_K32_WIDE_NP
         return launch_status("tconv_halo");
     }

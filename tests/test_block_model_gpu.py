@@ -411,6 +411,38 @@ def test_size_independent_properties_at_headline_shape(joints):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fgcn_math_mode", ["bf16x3", "f16x2", "f32"])
+def test_streamed_output_stores_change_no_bit(fgcn_math_mode):
+    """Every kernel that writes an activation has two store forms -- plain, and non-temporal for tensors from 48 MiB on (fgcn_common.hpp
+    stream_out; the launchers choose per call) -- that must be the same computation: one training step of the headline model with the
+    streamed form forced everywhere (tuning key 10 = 2) against the step with it forbidden (= 1): loss and every gradient bit for bit."""
+    from fusion_gcn_amd import _lib, ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    lib = _lib.load()
+    torch.manual_seed(3)
+    with ops.math_mode(fgcn_math_mode):
+        model = Model((2, 64, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=20))
+        fill_module(model)
+        model = model.to(dev()).train()
+        x = torch.randn(3, 2, 64, 25, 3, device=dev())
+        labels = torch.arange(3, device=dev()) % 60
+        runs = {}
+        try:
+            for key in (1, 2):
+                lib.fgcn_set_tuning(10, key)
+                model.zero_grad(set_to_none=True)
+                loss = torch.nn.functional.cross_entropy(model(x), labels)
+                loss.backward()
+                runs[key] = (loss.detach().clone(), [p.grad.clone() for p in model.parameters()])
+        finally:
+            lib.fgcn_set_tuning(10, 0)
+    assert torch.isfinite(runs[1][0]) and torch.equal(runs[1][0], runs[2][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[1][1], runs[2][1]))
+
+
+@pytest.mark.gpu
 def test_pool_and_classifier_kernels_and_graph_replay():
     """Global average pooling and fc run on libfgcn (equal to torch.mean / nn.Linear incl. gradients), and a captured
     forward+backward of the 8-clip headline shard replays to the same logits every time (with torch's multi-block mean
