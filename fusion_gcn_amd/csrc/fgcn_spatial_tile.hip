@@ -23,6 +23,9 @@
 
 // Timing probes (wrong results; tools/build_probe.py only): bit 0 = the image is staged for the first chunk only, bit 1 = no feature
 // MFMAs, bit 2 = x is fetched for the first chunk only, bit 3 = no aggregation MFMAs / splits (the image receives x's split instead)
+#ifndef FGCN_ST_RING
+#define FGCN_ST_RING 4
+#endif
 #ifndef FGCN_PROBE_ST
 #define FGCN_PROBE_ST 0
 #endif
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
         for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * ST_PLANE);
     };
 
-    u32x4v a[MTW][NP], wq[2][NP];
+    constexpr int RS = (FGCN_ST_RING == 4 && NU == 4) ? 4 : 2;      // weight ring slots: fragments requested RS - 1 units ahead (see fgcn_pw.hip)
+    u32x4v a[MTW][NP], wq[RS][NP];
     auto feature_phase = [&](int c) {                                // the two pairs of chunk c from the image
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) load_a(a[mt], mt, 0);
@@ -198,19 +202,21 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
             const int pq = 2 * c + q;
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                if (nu + 1 < NU) load_w(wq[(nu + 1) & 1], nu + 1, pq);
-                else load_w(wq[0], 0, pq + 1);
+                const int t = nu + RS - 1;
+                if (t < NU) load_w(wq[t % RS], t, pq);
+                else load_w(wq[t % RS], t - NU, pq + 1);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    if constexpr ((FGCN_PROBE_ST & 2) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu & 1][0][0]);
-                    else acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu & 1], acc[mt][nu]);
+                    if constexpr ((FGCN_PROBE_ST & 2) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu % RS][0][0]);
+                    else acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
                     if (nu == NU - 1 && q == 0) load_a(a[mt], mt, 1);    // this fragment's last use: fetch the next step's
                 }
             }
         }
     };
     fetch_units(0, xrA);
-    load_w(wq[0], 0, 0);
+#pragma unroll
+    for (int nu = 0; nu < RS - 1; ++nu) load_w(wq[nu], nu, 0);
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();                                             // the previous chunk's image reads are done (first pass: the A^ planes are written)
         if (!(FGCN_PROBE_ST & 1) || c == 0) stage_units(c, xrA);
