@@ -80,6 +80,11 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // 16 bytes per lane, plain or non-temporal (`stream`: a kernel argument, fgcn_common.hpp stream_out -- large activations are streamed
 // past L2: the backward apply pass -9 .. -12 % at the 64-clip step's sizes)
+// ... and the same for an input that is read here for the last time in a long while (bn_act's operands: -15 % per launch with both;
+// bn_act_bwd_apply re-reads what the reduce pass in front of it has just brought in and is better off with plain loads)
+__device__ __forceinline__ f32x4 load4(const float* ptr, int stream) {
+    return stream ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : *reinterpret_cast<const f32x4*>(ptr);
+}
 __device__ __forceinline__ void store4(float* ptr, f32x4 val, int stream) {
     if (stream) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(ptr));
     else *reinterpret_cast<f32x4*>(ptr) = val;
@@ -93,14 +98,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
-        const f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
+        const f32x4 x = load4(a + i * 4, stream);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(va + 3 * C + c);
         f32x4 y = x * sc + sh;
         if (RES == 1) {
-            y += *reinterpret_cast<const f32x4*>(b + i * 4);
+            y += load4(b + i * 4, stream);
         } else if (RES == 2) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(b + i * 4);
+            const f32x4 r = load4(b + i * 4, stream);
             y += r * *reinterpret_cast<const f32x4*>(vb + 2 * C + c) + *reinterpret_cast<const f32x4*>(vb + 3 * C + c);
         }
         if (relu) {

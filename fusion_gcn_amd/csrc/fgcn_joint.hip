@@ -7,6 +7,11 @@
 // stores are 128-byte contiguous per half-wave.  These ops are HBM-bound (each activation element feeds one
 // 32x32x2 step); the fused spatial kernel (fgcn_spatial.hip) removes them from the forward pass.
 #include "fgcn_common.hpp"
+// joint_dagg reads every operand tile exactly once: its tile loads carry the non-temporal hint (-6 % per launch in kbench, -0.03 .. -0.2 ms on the step;
+// the same hint on joint_gram's and joint_mix_vec's loads, whose rows are read by several subsets / waves, cost 20-50 %: profiles/r03_ab_store_nt.txt)
+#ifndef FGCN_DAGG_LDAUX
+#define FGCN_DAGG_LDAUX 2
+#endif
 
 namespace fgcn {
 
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
             const int row = 8 * ps + srow;
             const bool ok = valid && row < V && 4 * sg < cw;
             v[ps] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  r, ok ? frow_bytes + (unsigned)(row * ld + c + 4 * sg) * 4u : OOB, 0, 0));
+                                                  r, ok ? frow_bytes + (unsigned)(row * ld + c + 4 * sg) * 4u : OOB, 0, FGCN_DAGG_LDAUX));
         }
     };
     auto storet = [&](float* tile, const f32x4 (&v)[4]) {
