@@ -36,8 +36,9 @@ inline int launch_status(const char* what) {
 // the 64-clip step is 245 MB, written once and read by a later kernel after as much other traffic: a plain store allocates its line
 // in L2 (the matrix kernels write 64-byte row pieces per instruction, i.e. partial lines) and costs the kernel its full HBM write time
 // on top of the matrix work; the non-temporal form streams them out (pw_gemm -7 .. -22 % per launch, the joint mixing -19 .. -31 %,
-// the spatial forward -3 .. -11 %, the halo conv -0.3 .. -6 %; profiles/r03_ab_store_nt.txt).  A SMALL activation (the 8-clip shard's
-// 31 MB) is still in L2 / Infinity Cache when its consumer starts, and the streamed form loses that (+0.08 ms on the 10 ms step): the
+// the spatial forward -3 .. -11 %, the halo conv -0.3 .. -6 % in loops of identical launches; inside the step less, -0.55 ms of 59 in
+// all: profiles/r03_ab_store_nt.txt).  A SMALL tensor (the 8-clip shard's 31 MB activations, its 92 MB three-wide 1x1 outputs) is
+// still in L2 / Infinity Cache when its consumer starts, and the streamed form loses that (+0.04 .. +0.08 ms on the 9.7 ms step): the
 // launchers choose per call from the bytes written (stream_out) between two instantiations of the kernel (template parameter STR; a
 // run-time branch around the epilogue cost the tightest kernels spills).  Stores of a load-add-store (accumulating epilogues: the line is resident from the load) and of partial-sum
 // rows stay plain.
@@ -57,10 +58,10 @@ inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 // workgroups per CU, 1: 2); key 5: XCD-aware workgroup order, bit 0 row GEMM (off), bit 1 halo conv (off), bit 2
 // disables it for the weight gradient (on by default), bit 3 disables the column-tile-fastest grid of the row GEMM.
 int tuning(int key);
-// true when a call that writes `bytes` of output should stream it (tuning key 10: 0 = from 48 MiB on, 1 = never, 2 = always)
+// true when a call that writes `bytes` of output should stream it (tuning key 10: 0 = from 96 MiB on, 1 = never, 2 = always)
 inline bool stream_out(long long bytes) {
     const int k = tuning(10);
-    return k == 2 || (k == 0 && bytes >= (48ll << 20));
+    return k == 2 || (k == 0 && bytes >= (96ll << 20));
 }
 int math_mode();   // FGCN_MATH_F32 / FGCN_MATH_BF16 / FGCN_MATH_BF16X3 (fgcn_set_math_mode)
 int products();    // FGCN_PRODUCTS_BF16X3 / FGCN_PRODUCTS_F16X2 inside FGCN_MATH_BF16X3 (fgcn_set_products)

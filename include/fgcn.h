@@ -53,7 +53,7 @@ int fgcn_check_device(void);
  *   7  split-bf16 kernels (bits) 1: spatial forward, one frame per wave (older form); 2: halo conv on the 32x32x16 MFMA shape;
  *      4: the same for N <= 64 only; 8: split-bf16 halo conv at <= 64 output columns as 2 x 2 waves over 128-row tiles (default: 4 x 1 waves
  *      over 192-row tiles from 1536 tiles on); 16: the 4 x 1 form with a 128-column tile for every N > 64 (default: 64 < N <= 128 only); 32: never; 64: the 4 x 1 form at <= 64 columns whatever the tile count (tests)
- *   10 output stores of the activation-writing kernels: 0 = non-temporal (streamed past L2) when the call writes 48 MiB or more, plain below;
+ *   10 output stores of the activation-writing kernels: 0 = non-temporal (streamed past L2) when the call writes 96 MiB or more, plain below;
  *      1 = always plain; 2 = always non-temporal (same results in every setting: tests/test_block_model_gpu.py) */
 int fgcn_set_tuning(int key, int value);
 

@@ -413,7 +413,7 @@ def test_size_independent_properties_at_headline_shape(joints):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fgcn_math_mode", ["bf16x3", "f16x2", "f32"])
 def test_streamed_output_stores_change_no_bit(fgcn_math_mode):
-    """Every kernel that writes an activation has two store forms -- plain, and non-temporal for tensors from 48 MiB on (fgcn_common.hpp
+    """Every kernel that writes an activation has two store forms -- plain, and non-temporal for tensors from 96 MiB on (fgcn_common.hpp
     stream_out; the launchers choose per call) -- that must be the same computation: one training step of the headline model with the
     streamed form forced everywhere (tuning key 10 = 2) against the step with it forbidden (= 1): loss and every gradient bit for bit."""
     from fusion_gcn_amd import _lib, ops

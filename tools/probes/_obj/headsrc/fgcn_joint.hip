@@ -125,23 +125,21 @@ template <int VW> struct MixVec;
 template <> struct MixVec<1> {
     using raw = unsigned;
     static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b32(r, v, so, 0); }
-    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b32(d, r, v, so, 0); }
+    template <int AUX> static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b32(d, r, v, so, AUX); }
 };
 template <> struct MixVec<2> {
     using raw = __attribute__((ext_vector_type(2))) unsigned;
     static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b64(r, v, so, 0); }
-    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b64(d, r, v, so, 0); }
+    template <int AUX> static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b64(d, r, v, so, AUX); }
 };
 constexpr int IMG = 32 * 32;  // one A-operand image, [k][i]
 
 // KS = MFMA k-steps (joint pairs) covered: ceil(V / 2) rounded up to even; the padding steps multiply zeros (the images
 // are zero-padded and absent joints load as zeros).  Compile-time so that the MFMA chains carry no branches: with a
 // runtime step count hipcc moved all accumulators between AGPRs and VGPRs around every conditional step.
-// (Output stores stay plain at every size: streamed (fgcn_common.hpp, stream_out) this kernel won 19-31 % in a loop of identical launches -- its
-// input then survives in the Infinity Cache from one repetition to the next -- and LOST 5-13 % per launch inside the step, same box:
-// profiles/r03_ab_store_nt.txt section 7.)
-template <int VW, bool ACC, int KS>
+template <int VW, bool ACC, int KS, bool STR = false>           // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
 __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
+    static_assert(!(ACC && STR), "an accumulating call stores plainly");
     using vec = __attribute__((ext_vector_type(VW))) float;
     using raw = typename MixVec<VW>::raw;
     __shared__ float img[2 * MIX_MAX_MATS * IMG];
@@ -219,7 +217,7 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
 #pragma unroll
                 for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
                 if constexpr (ACC) v += __builtin_bit_cast(vec, old[r]);
-                MixVec<VW>::store(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
+                MixVec<VW>::template store<(STR ? FGCN_STORE_AUX : 0)>(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
 #pragma unroll
                 for (int m = 0; m < VW; ++m) wmax = fmaxf(wmax, fabsf(v[m]));
             }
@@ -1000,18 +998,20 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     const int ks = (V + 3) / 4 * 2;  // k-steps, rounded up to even
     const size_t cs_lds = colsum_partial ? (size_t)4 * ld_out * sizeof(float) : 0;
     FGCN_REQUIRE(cs_lds <= 32 * 1024, FGCN_E_BADARG, "joint_mix_vec: ld_out=%d too wide for the column-sum scratch", ld_out);
-#define FGCN_MIXV_KS(VW_, ACC_)                                                                                   \
-    do {                                                                                                          \
-        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10>), grid, dim3(256), cs_lds, st, p);      \
-        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12>), grid, dim3(256), cs_lds, st, p); \
-        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14>), grid, dim3(256), cs_lds, st, p); \
-        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16>), grid, dim3(256), cs_lds, st, p);               \
+#define FGCN_MIXV_KS(VW_, ACC_, STR_)                                                                                   \
+    do {                                                                                                                \
+        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10, STR_>), grid, dim3(256), cs_lds, st, p);      \
+        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12, STR_>), grid, dim3(256), cs_lds, st, p); \
+        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14, STR_>), grid, dim3(256), cs_lds, st, p); \
+        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16, STR_>), grid, dim3(256), cs_lds, st, p);               \
     } while (0)
-#define FGCN_MIXV(VW_)                            \
-    do {                                          \
-        if (accumulate) FGCN_MIXV_KS(VW_, true);  \
-        else FGCN_MIXV_KS(VW_, false);            \
+#define FGCN_MIXV(VW_)                                   \
+    do {                                                 \
+        if (accumulate) FGCN_MIXV_KS(VW_, true, false);  \
+        else if (str) FGCN_MIXV_KS(VW_, false, true);    \
+        else FGCN_MIXV_KS(VW_, false, false);            \
     } while (0)
+    const bool str = fgcn::stream_out((long long)B * T * V * ld_out * 4);
     if (vw == 2) FGCN_MIXV(2);
     else FGCN_MIXV(1);
 #undef FGCN_MIXV
