@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Promote gpurun_out/prof_r03e{,_f16x2} + bench_r03e*.json into profiles/ (scratch helper)."""
+import csv, glob, json, os, shutil, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(R, "profiles")
+def find(tag, name):
+    f = glob.glob(os.path.join(R, "gpurun_out", f"prof_{tag}", "**", name), recursive=True)
+    assert f, (tag, name)
+    return f[0]
+def pmc(tag, which, counter, kname="conv_halo_x3k32_kernel"):
+    vals = []; dur = []
+    for r in csv.DictReader(open(find(tag, f"pmc_{which}_counter_collection.csv"))):
+        if kname in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.append(float(r["Counter_Value"])); dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return sum(vals) / len(vals), sum(dur) / len(dur), len(vals)
+traffic = json.load(open(os.path.join(P, "r03_traffic.json")))
+for tag, mode, key in (("r03e", "bf16x3", "conv_halo_x3_fwd"), ("r03e_f16x2", "f16x2", "conv_halo_f16x2_fwd")):
+    shutil.copy(find(tag, "step_serial_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_step_serial_kernel_stats.csv"))
+    shutil.copy(find(tag, "step8_serial_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_8clips_step_serial_kernel_stats.csv"))
+    shutil.copy(find(tag, "dominant_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_dominant_kernel_stats.csv"))
+    shutil.copy(os.path.join(R, "gpurun_out", f"prof_{tag}", "step_traffic_by_kernel.txt"), os.path.join(P, f"r03e_{mode}_step_traffic_by_kernel.txt"))
+    log = open(os.path.join(R, "gpurun_out", f"prof_{tag}", "dominant.log")).read().strip().split("\n")
+    live = [l for l in log if l.startswith("{")]
+    if live:
+        open(os.path.join(P, f"r03e_{mode}_dominant_kernel_live.json"), "w").write(live[-1] + "\n")
+    fetch, _, n = pmc(tag, "fetch", "FETCH_SIZE")
+    write, _, _ = pmc(tag, "write", "WRITE_SIZE")
+    busy, durm, _ = pmc(tag, "mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui, _, _ = pmc(tag, "mfma", "GRBM_GUI_ACTIVE")
+    stats = [r for r in csv.DictReader(open(find(tag, "dominant_kernel_stats.csv"))) if "conv_halo_x3k32_kernel" in r["Name"]][0]
+    ns = float(stats["AverageNs"])
+    t = traffic[key]
+    tb = int(2 * fetch * 1024 + write * 1024)
+    clock = gui / 8 / durm
+    # MFMA busy: counter is summed over SIMDs?  keep the r03d convention: busy fraction = busy / (4 * 256 * gui/8) is what the old method line states
+    frac = busy / (4 * 256 * (gui / 8))
+    t.update({"fetch_size_kib_raw": fetch, "write_size_kib": write, "traffic_bytes": tb, "mfma_busy_cycles_per_launch": busy,
+              "grbm_gui_active_per_launch_all_xcds": gui, "ns_per_launch_under_rocprofv3": ns, "launches": n})
+    t["kernel"] = t["kernel"].replace("false>", "false,2,true>") if "true>" not in t["kernel"] else t["kernel"]
+    t["method"] = (f"tools/collect_profiles.sh {tag} (round 3, FINAL state: four-slot weight ring, streamed output stores): rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / "
+                   f"--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE in three separate runs of `python3 bench.py --kernel-only{'' if mode == 'bf16x3' else ' --math f16x2'}` ({n} launches each); "
+                   f"traffic = 2*FETCH_SIZE + WRITE_SIZE = {tb / 1e9:.2f} GB per launch = {tb / t['algorithmic_bytes']:.2f}x the algorithmic bytes; effective clock GRBM_GUI_ACTIVE / 8 / duration = {clock:.2f} GHz; "
+                   f"matrix pipe busy {100 * frac:.0f} % of the launch")
+    print(key, tb, ns, clock, frac)
+json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
+for a, b in (("bench_r03e.json", "r03e_bench.json"), ("bench_r03e_8clips.json", "r03e_bench_8clips.json")):
+    shutil.copy(os.path.join(R, "gpurun_out", a), os.path.join(P, b))
