@@ -176,17 +176,23 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
 # (profiles/r03_ab_pw_gemm.txt): threshold 128 -> 62.53 / 62.58 ms against 62.82 / 63.10 with round 2's routing, 63.32 with 64
 # Round 3, after the epilogue fix of pw_gemm (-4..-26 %, profiles/r03_ab_epilogues.txt): in bf16x3 K = 64 / 96 is now even (-6..+9 %
 # over the four shapes: threshold stays 128); with the f16x2 products pw_gemm wins there too (-5..-19 %): threshold 64.
+# End of round 3 (four-slot weight ring, streamed stores; profiles/r03_ab_pw_min_k_small.txt): at 64 clips K = 64 is still even in bf16x3
+# (58.0-58.4 vs 58.3-58.5 ms), but on the 8-clip shard pw_gemm wins there (9.65-9.67 -> 9.61-9.62 ms: the f32 row GEMM's one tile per
+# workgroup quantises worse on few rows): below PW_X3_SMALL_ROWS rows the threshold is 64 in bf16x3 too.
 PW_X3_MIN_K = int(os.environ.get("FGCN_PW_MIN_K", "128"))
 PW_X3_MIN_K_F16X2 = int(os.environ.get("FGCN_PW_MIN_K_F16X2", os.environ.get("FGCN_PW_MIN_K", "64")))
+PW_X3_SMALL_ROWS = int(os.environ.get("FGCN_PW_SMALL_ROWS", "300000"))
 
 
-def _pw_min_k() -> int:
-    return PW_X3_MIN_K_F16X2 if ops.get_math_mode() == "f16x2" else PW_X3_MIN_K
+def _pw_min_k(rows: int) -> int:
+    if ops.get_math_mode() == "f16x2":
+        return PW_X3_MIN_K_F16X2
+    return min(PW_X3_MIN_K, 64) if rows < PW_X3_SMALL_ROWS else PW_X3_MIN_K
 
 
 def pw_routed(W, key: str, x: torch.Tensor, K: int) -> bool:
     """Whether pw_gemm sends this 1x1 convolution to the persistent split row GEMM (the kernel that can record max |x|)."""
-    return (key + "_s3") in W and K % 32 == 0 and x.shape[3] == K and K >= _pw_min_k()
+    return (key + "_s3") in W and K % 32 == 0 and x.shape[3] == K and K >= _pw_min_k(x.numel() // x.shape[3])
 
 
 def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Tensor, *, K: int, N: int,
@@ -194,7 +200,7 @@ def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Te
     """1x1 convolution over all rows: in the split-bf16 math modes (the packed set then holds the split form of the weight) the
     persistent split-bf16 row GEMM; the exact-f32 row GEMM otherwise.  ``amax_out``: see ops.pw_gemm (ignored by the f32 kernel)."""
     w3 = W.get(key + "_s3")
-    if w3 is not None and K % 32 == 0 and x.shape[3] == K and K >= _pw_min_k():
+    if w3 is not None and K % 32 == 0 and x.shape[3] == K and K >= _pw_min_k(x.numel() // x.shape[3]):
         return ops.pw_gemm(x, w3, out, bias=bias, stats=stats, accumulate=accumulate, amax_out=amax_out)
     if PW_X3_MIN_K > 4096 and w3 is not None and K % 64 == 0 and x.shape[3] == K and (K >= 192 or (K >= 128 and N >= 384)):
         # (A/B control, FGCN_PW_MIN_K=100000: round 2's routing -- the one-tap halo kernel from K = 192 on, the f32 row GEMM below)
