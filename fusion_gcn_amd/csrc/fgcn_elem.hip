@@ -286,9 +286,15 @@ extern "C" int fgcn_elem_tiles(long long rows) {
 
 static long long rows_per_tile_for(long long rows) { return cdiv(rows, fgcn_elem_tiles(rows)); }
 
+// One 16-byte group per thread (the cap only bounds the grid): with 8192 blocks a thread of the 64-clip step walked seven groups, and every
+// trip of that loop waits for its loads behind the previous trip's store (vmcnt counts in issue order) -- in-step, per kernel, same box
+// (profiles/r03_ab_elem_blocks.txt): bn_act 1.80 -> 1.62 ms per step, bn_act_bwd_apply 2.72 -> 2.51 (identity residual), 1.62 -> 1.49 (down).
+#ifndef FGCN_ELEM_BLOCKS
+#define FGCN_ELEM_BLOCKS (1 << 22)
+#endif
 static unsigned stream_blocks(long long n4) {
     const long long b = cdiv(n4, 256);
-    return (unsigned)(b < 8192 ? b : 8192);
+    return (unsigned)(b < FGCN_ELEM_BLOCKS ? b : FGCN_ELEM_BLOCKS);
 }
 
 extern "C" int fgcn_bn_finalize(const float* partials, int n_partials, long long count, const float* gamma,
