@@ -125,21 +125,23 @@ template <int VW> struct MixVec;
 template <> struct MixVec<1> {
     using raw = unsigned;
     static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b32(r, v, so, 0); }
-    template <int AUX> static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b32(d, r, v, so, AUX); }
+    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b32(d, r, v, so, 0); }
 };
 template <> struct MixVec<2> {
     using raw = __attribute__((ext_vector_type(2))) unsigned;
     static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b64(r, v, so, 0); }
-    template <int AUX> static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b64(d, r, v, so, AUX); }
+    static __device__ __forceinline__ void store(raw d, __amdgpu_buffer_rsrc_t r, unsigned v, unsigned so) { __builtin_amdgcn_raw_buffer_store_b64(d, r, v, so, 0); }
 };
 constexpr int IMG = 32 * 32;  // one A-operand image, [k][i]
 
 // KS = MFMA k-steps (joint pairs) covered: ceil(V / 2) rounded up to even; the padding steps multiply zeros (the images
 // are zero-padded and absent joints load as zeros).  Compile-time so that the MFMA chains carry no branches: with a
 // runtime step count hipcc moved all accumulators between AGPRs and VGPRs around every conditional step.
-template <int VW, bool ACC, int KS, bool STR = false>           // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
+// (Output stores stay plain at every size: streamed (fgcn_common.hpp, stream_out) this kernel won 19-31 % in a loop of identical launches -- its
+// input then survives in the Infinity Cache from one repetition to the next -- and LOST 5-13 % per launch inside the step, same box:
+// profiles/r03_ab_store_nt.txt section 7.)
+template <int VW, bool ACC, int KS>
 __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
-    static_assert(!(ACC && STR), "an accumulating call stores plainly");
     using vec = __attribute__((ext_vector_type(VW))) float;
     using raw = typename MixVec<VW>::raw;
     __shared__ float img[2 * MIX_MAX_MATS * IMG];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void joint_mix_vec_kernel(MixVP p) {
 #pragma unroll
                 for (int m = 0; m < VW; ++m) v[m] = acc[m][r];
                 if constexpr (ACC) v += __builtin_bit_cast(vec, old[r]);
-                MixVec<VW>::template store<(STR ? FGCN_STORE_AUX : 0)>(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
+                MixVec<VW>::store(__builtin_bit_cast(raw, v), rout, uoff[r], so_out);
 #pragma unroll
                 for (int m = 0; m < VW; ++m) wmax = fmaxf(wmax, fabsf(v[m]));
             }
@@ -394,7 +396,11 @@ constexpr int DTS = 36;   // tile row stride: 16-byte reads of 8 consecutive row
 // per (frame, chunk) into its three bf16 parts in registers (lane = joint, 8 consecutive channels per fragment), each dagg chunk
 // once per subset, and a 32-channel contraction is 2 x 6 v_mfma_f32_32x32x16_bf16 (384 cycles) instead of 16 f32 MFMAs (1024):
 // the f32 form of this kernel runs at about half the rate its matrix work allows and the gram is more than half of that work.
-template <int KS, int NE, int MB = 3, bool X3 = false>
+// NSC / ACCM: the subset count and the accumulate flag as compile-time constants (0 / -1: run-time values).  Both sit in wave-uniform guards
+// around loads inside the chunk loop; as run-time values they made hipcc branch there and, having lost count of the outstanding memory
+// operations at every join, drain vmcnt(0) eight or nine times per chunk -- each one a full round trip of the chunk's dx stores
+// (vmcnt counts loads and stores in issue order; DESIGN.md section 3.8 found the same in the GEMM epilogues).
+template <int KS, int NE, int MB = 3, bool X3 = false, int NSC = 0, int ACCM = -1>
 __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     constexpr int NIMG = NE > 0 ? 4 : 3;               // + the identity (slot 3): gated addends ride the mix MFMAs
@@ -405,7 +411,8 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int t0 = chunk * p.t_chunk;
     const int t1 = min(t0 + p.t_chunk, p.T);
-    const int V = p.V, C = p.C, NS = p.n_sub;
+    const int V = p.V, C = p.C, NS = NSC ? NSC : p.n_sub;
+    const bool accumulate = ACCM < 0 ? p.accumulate != 0 : ACCM != 0;
     float* xt = tiles + wave * 2 * 32 * DTS;
     float* dt = xt + 32 * DTS;
 
@@ -482,11 +489,20 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
     const float* am = img + h * 32 + l31;              // mix A operand: image row k = w = 2s + h, lane = out joint v
     const int u0 = 4 * h;                              // accumulator register r holds out joint (r&3) + 8(r>>2) + 4h
     auto frame_bytes = [&](int t, int ld) { return (unsigned)((n * p.T + t) * V) * (unsigned)ld * 4u; };
-    f32x4 vx[4], vd[4];
+    // PF3: one register set per subset, each refilled with the NEXT chunk's tile of its subset as soon as it has been written to LDS:
+    // every load of chunk i + 1 is requested during chunk i, in front of chunk i's dx stores, and dx's old values at the top of the
+    // chunk -- so no wait of the chunk loop ever includes a store's write acknowledgement (two workgroups per CU: 48 registers more).
+    constexpr bool PF3 = NSC == 3 && NE == 0 && MB == 2;
+    f32x4 vx[4], vd[4], vd3[PF3 ? 3 : 1][4];
     {
         const int t = t0 + wave;
         loadt(rx, frame_bytes(t, p.ld_x), p.ld_x, 0, min(32, C), t < t1, vx);
-        loadt(rd, frame_bytes(t, p.ld_d), p.ld_d, 0, min(32, C), t < t1, vd);
+        if constexpr (PF3) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) loadt(rd, frame_bytes(t, p.ld_d), p.ld_d, k * C, min(32, C), t < t1, vd3[k]);
+        } else {
+            loadt(rd, frame_bytes(t, p.ld_d), p.ld_d, 0, min(32, C), t < t1, vd);
+        }
     }
     for (int t = t0 + wave; t < t1; t += 4) {
         const unsigned fd = frame_bytes(t, p.ld_d);
@@ -498,7 +514,25 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
             const int cwn = min(32, C - cn);
             const bool nvalid = tn < t1;
             storet(xt, vx);
-            loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, cn, cwn, nvalid, vx);
+            if constexpr (PF3) loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, nvalid ? cn : c0, nvalid ? cwn : cw, true, vx);
+            else loadt(rx, frame_bytes(nvalid ? tn : t, p.ld_x), p.ld_x, cn, cwn, nvalid, vx);
+            // dx chunk: rows v in the registers, 32 channels on the lanes
+            const int c = c0 + l31;
+            const unsigned coff = c < C ? (unsigned)(((t - t0) * V + u0) * p.ld_dx + c) * 4u : OOB;
+            const unsigned rstep = (unsigned)p.ld_dx * 4u;
+            float old[16];
+            auto load_old = [&]() {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    old[r] = 0.f;
+                    if (dr < 2 * KS)                   // compile-time: register r only holds padding joints otherwise
+                        old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                               rdx, (coff != OOB && u0 + dr < V) ? coff + dr * rstep : OOB, 0, 0));
+                }
+            };
+            if constexpr (PF3 && ACCM == 1) load_old();
+            if constexpr (PF3) __builtin_amdgcn_sched_barrier(0);
             f32x16 accx = zero16();
             unsigned gm[4] = {0u, 0u, 0u, 0u};
             u32x4v xs3[2][3];                           // X3: the x chunk's gram fragments (channels 16s + 8h + j of joint l31)
@@ -513,10 +547,18 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < NS) {                          // wave-uniform
-                    storet(dt, vd);
-                    if (k + 1 < NS) loadt(rd, fd, p.ld_d, (k + 1) * C + c0, cw, true, vd);
-                    else if (NE > 0) loadg(0, t, c0, cw, true, vd, gm);
-                    else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
+                    if constexpr (PF3) {
+                        // (past the workgroup's last chunk the current tile is requested again, unused: a wave-uniform "no next
+                        // chunk" condition on the request would come back as a branch around the loads and cost the wait counts)
+                        storet(dt, vd3[k]);
+                        loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, k * C + (nvalid ? cn : c0), nvalid ? cwn : cw, true, vd3[k]);
+                        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the requests to the end of the chunk, next to the stores)
+                    } else {
+                        storet(dt, vd);
+                        if (k + 1 < NS) loadt(rd, fd, p.ld_d, (k + 1) * C + c0, cw, true, vd);
+                        else if (NE > 0) loadg(0, t, c0, cw, true, vd, gm);
+                        else loadt(rd, frame_bytes(nvalid ? tn : t, p.ld_d), p.ld_d, cn, cwn, nvalid, vd);
+                    }
                     if constexpr (X3) {                // dA^_k += x chunk . dagg_k chunk^T, split-bf16 (channels 16s + 8h + j)
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) {
@@ -548,21 +590,13 @@ __global__ __launch_bounds__(256, MB) void joint_dagg_kernel(DaggP p) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) accx = mfma32(am[3 * IMG + s * 64], dm[2 * s * DTS], accx);
             }
-            // dx chunk: rows v in the registers, 32 channels on the lanes
-            const int c = c0 + l31;
-            const unsigned coff = c < C ? (unsigned)(((t - t0) * V + u0) * p.ld_dx + c) * 4u : OOB;
-            const unsigned rstep = (unsigned)p.ld_dx * 4u;
-            float old[16];
-            if (p.accumulate) {
+            if constexpr (!(PF3 && ACCM == 1)) {
+                if (accumulate) {
+                    load_old();
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                           rdx, (coff != OOB && u0 + dr < V) ? coff + dr * rstep : OOB, 0, 0));
+                    for (int r = 0; r < 16; ++r) old[r] = 0.f;
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) old[r] = 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -998,20 +1032,18 @@ extern "C" int fgcn_joint_mix_vec(const float* in, float* out, const float* mats
     const int ks = (V + 3) / 4 * 2;  // k-steps, rounded up to even
     const size_t cs_lds = colsum_partial ? (size_t)4 * ld_out * sizeof(float) : 0;
     FGCN_REQUIRE(cs_lds <= 32 * 1024, FGCN_E_BADARG, "joint_mix_vec: ld_out=%d too wide for the column-sum scratch", ld_out);
-#define FGCN_MIXV_KS(VW_, ACC_, STR_)                                                                                   \
-    do {                                                                                                                \
-        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10, STR_>), grid, dim3(256), cs_lds, st, p);      \
-        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12, STR_>), grid, dim3(256), cs_lds, st, p); \
-        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14, STR_>), grid, dim3(256), cs_lds, st, p); \
-        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16, STR_>), grid, dim3(256), cs_lds, st, p);               \
+#define FGCN_MIXV_KS(VW_, ACC_)                                                                                   \
+    do {                                                                                                          \
+        if (ks <= 10) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 10>), grid, dim3(256), cs_lds, st, p);      \
+        else if (ks <= 12) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 12>), grid, dim3(256), cs_lds, st, p); \
+        else if (ks <= 14) hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 14>), grid, dim3(256), cs_lds, st, p); \
+        else hipLaunchKernelGGL((joint_mix_vec_kernel<VW_, ACC_, 16>), grid, dim3(256), cs_lds, st, p);               \
     } while (0)
-#define FGCN_MIXV(VW_)                                   \
-    do {                                                 \
-        if (accumulate) FGCN_MIXV_KS(VW_, true, false);  \
-        else if (str) FGCN_MIXV_KS(VW_, false, true);    \
-        else FGCN_MIXV_KS(VW_, false, false);            \
+#define FGCN_MIXV(VW_)                            \
+    do {                                          \
+        if (accumulate) FGCN_MIXV_KS(VW_, true);  \
+        else FGCN_MIXV_KS(VW_, false);            \
     } while (0)
-    const bool str = fgcn::stream_out((long long)B * T * V * ld_out * 4);
     if (vw == 2) FGCN_MIXV(2);
     else FGCN_MIXV(1);
 #undef FGCN_MIXV
@@ -1050,11 +1082,21 @@ extern "C" int fgcn_joint_dagg(const float* x, const float* dagg, const float* m
     const int ks = (V + 3) / 4 * 2;
     const bool three = (fgcn::tuning(6) & 8) != 0;
     const bool x3 = fgcn::math_mode() != FGCN_MATH_F32 && !(fgcn::tuning(6) & 16);   // key 6 bit 4: the f32-MFMA gram in every mode
+    const bool mb3_form = (fgcn::tuning(6) & 2048) != 0;                              // key 6 bit 11: the compile-time form at three workgroups per CU, one tile set (A/B)
+    const bool plain_form = (fgcn::tuning(6) & 1024) != 0;                            // key 6 bit 10: run-time subset count / accumulate flag (A/B)
 #define FGCN_DAGG(KS_)                                                                                    \
     do {                                                                                                  \
         if (n_extra == 2 && three) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 3>), grid, dim3(256), lds, s, p); \
         else if (n_extra == 2) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 2, 2>), grid, dim3(256), lds, s, p); \
         else if (n_extra == 1) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 1, 2>), grid, dim3(256), lds, s, p); \
+        else if (x3 && !three && n_subsets == 3 && !plain_form && !mb3_form) {                            \
+            if (accumulate) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 2, true, 3, 1>), grid, dim3(256), lds, s, p); \
+            else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 2, true, 3, 0>), grid, dim3(256), lds, s, p); \
+        }                                                                                                 \
+        else if (x3 && !three && n_subsets == 3 && !plain_form) {                                         \
+            if (accumulate) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 3, true, 3, 1>), grid, dim3(256), lds, s, p); \
+            else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 3, true, 3, 0>), grid, dim3(256), lds, s, p); \
+        }                                                                                                 \
         else if (x3 && !three) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 3, true>), grid, dim3(256), lds, s, p); \
         else if (x3) hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0, 2, true>), grid, dim3(256), lds, s, p); \
         else hipLaunchKernelGGL((joint_dagg_kernel<KS_, 0>), grid, dim3(256), lds, s, p);                 \
