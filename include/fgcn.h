@@ -50,6 +50,8 @@ int fgcn_check_device(void);
  *      32: 1x1 weight gradients on ONE 8-wave workgroup per CU (default: two 4-wave ones); 64: all-taps kernels above 64 output
  *      columns on 8 waves (default 4); 256: at 64 columns on 4 waves (default 8); 128: all-taps weight gradient without the circular tap window;
  *      512: fgcn_spatial_wgrad on exact-f32 MFMAs in math mode bf16x3 (default there: the split-bf16 form)
+ *      1024: joint_dagg with its subset count / accumulate flag as run-time values (the form before the end of round 3); 2048: both at compile time,
+ *      three workgroups per CU, one tile register set (default: one set per subset refilled a chunk ahead, two workgroups per CU)
  *   7  split-bf16 kernels (bits) 1: spatial forward, one frame per wave (older form); 2: halo conv on the 32x32x16 MFMA shape;
  *      4: the same for N <= 64 only; 8: split-bf16 halo conv at <= 64 output columns as 2 x 2 waves over 128-row tiles (default: 4 x 1 waves
  *      over 192-row tiles from 1536 tiles on); 16: the 4 x 1 form with a 128-column tile for every N > 64 (default: 64 < N <= 128 only); 32: never; 64: the 4 x 1 form at <= 64 columns whatever the tile count (tests)
