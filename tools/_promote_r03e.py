@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Promote gpurun_out/prof_r03e{,_f16x2} + bench_r03e*.json into profiles/ (scratch helper)."""
+"""Promote gpurun_out/prof_r03f{,_f16x2} + bench_r03f*.json into profiles/ (scratch helper)."""
 import csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(R, "profiles")
@@ -14,15 +14,15 @@ def pmc(tag, which, counter, kname="conv_halo_x3k32_kernel"):
             vals.append(float(r["Counter_Value"])); dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return sum(vals) / len(vals), sum(dur) / len(dur), len(vals)
 traffic = json.load(open(os.path.join(P, "r03_traffic.json")))
-for tag, mode, key in (("r03e", "bf16x3", "conv_halo_x3_fwd"), ("r03e_f16x2", "f16x2", "conv_halo_f16x2_fwd")):
-    shutil.copy(find(tag, "step_serial_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_step_serial_kernel_stats.csv"))
-    shutil.copy(find(tag, "step8_serial_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_8clips_step_serial_kernel_stats.csv"))
-    shutil.copy(find(tag, "dominant_kernel_stats.csv"), os.path.join(P, f"r03e_{mode}_dominant_kernel_stats.csv"))
-    shutil.copy(os.path.join(R, "gpurun_out", f"prof_{tag}", "step_traffic_by_kernel.txt"), os.path.join(P, f"r03e_{mode}_step_traffic_by_kernel.txt"))
+for tag, mode, key in (("r03f", "bf16x3", "conv_halo_x3_fwd"), ("r03f_f16x2", "f16x2", "conv_halo_f16x2_fwd")):
+    shutil.copy(find(tag, "step_serial_kernel_stats.csv"), os.path.join(P, f"r03f_{mode}_step_serial_kernel_stats.csv"))
+    shutil.copy(find(tag, "step8_serial_kernel_stats.csv"), os.path.join(P, f"r03f_{mode}_8clips_step_serial_kernel_stats.csv"))
+    shutil.copy(find(tag, "dominant_kernel_stats.csv"), os.path.join(P, f"r03f_{mode}_dominant_kernel_stats.csv"))
+    shutil.copy(os.path.join(R, "gpurun_out", f"prof_{tag}", "step_traffic_by_kernel.txt"), os.path.join(P, f"r03f_{mode}_step_traffic_by_kernel.txt"))
     log = open(os.path.join(R, "gpurun_out", f"prof_{tag}", "dominant.log")).read().strip().split("\n")
     live = [l for l in log if l.startswith("{")]
     if live:
-        open(os.path.join(P, f"r03e_{mode}_dominant_kernel_live.json"), "w").write(live[-1] + "\n")
+        open(os.path.join(P, f"r03f_{mode}_dominant_kernel_live.json"), "w").write(live[-1] + "\n")
     fetch, _, n = pmc(tag, "fetch", "FETCH_SIZE")
     write, _, _ = pmc(tag, "write", "WRITE_SIZE")
     busy, durm, _ = pmc(tag, "mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
@@ -43,5 +43,5 @@ for tag, mode, key in (("r03e", "bf16x3", "conv_halo_x3_fwd"), ("r03e_f16x2", "f
                    f"matrix pipe busy {100 * frac:.0f} % of the launch")
     print(key, tb, ns, clock, frac)
 json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
-for a, b in (("bench_r03e.json", "r03e_bench.json"), ("bench_r03e_8clips.json", "r03e_bench_8clips.json")):
+for a, b in (("bench_r03f.json", "r03f_bench.json"), ("bench_r03f_8clips.json", "r03f_bench_8clips.json")):
     shutil.copy(os.path.join(R, "gpurun_out", a), os.path.join(P, b))
