@@ -7,6 +7,7 @@ here computes anything in torch: a missing library or a non-gfx950 device raises
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -94,6 +95,10 @@ def math_mode(mode: str):
         yield
     finally:
         set_math_mode(prev)
+
+
+# weight-gradient kernels: stages (64 / 128 rows) a workgroup should at least walk before the rows are split further (small batches)
+WGRAD_MIN_STAGES = int(os.environ.get("FGCN_WGRAD_MIN_STAGES", "16"))
 
 
 def conv_tmap(kt: int, stride: int) -> Tuple[int, int, int, int, int]:
@@ -471,7 +476,7 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     # at most 512 workgroups (two per CU, all resident at once; 256 for the one-workgroup-per-CU split-bf16 kernel); small
     # batches: >= 16 stages per workgroup while that still leaves a workgroup per CU -- fewer slabs for the reduction
     cap = max(1, lib.fgcn_tconv_wgrad_resident(N) // max(tiles, 1))
-    nsplit = max(1, min(cap, max(stages // 16, min(stages, max(1, 256 // max(tiles, 1))))))
+    nsplit = max(1, min(cap, max(stages // WGRAD_MIN_STAGES, min(stages, max(1, 256 // max(tiles, 1))))))
     slabs = lib.fgcn_tconv_wgrad_slabs(N, nsplit)
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
     for par, tap0, ntaps, shift0 in calls:
