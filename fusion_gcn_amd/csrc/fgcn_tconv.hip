@@ -58,6 +58,11 @@ struct HaloP {
                                         // row tiles fills tiles_m of them and zeroes the rest
 };
 
+// Timing probes (wrong results; tools/probes builds only): bit 0 = no output stores, bit 1 = no MFMAs, bit 2 = the image of the first chunk
+// only (later chunks skip fetch, split and LDS writes), bit 4 = weight fragments loaded once
+#ifndef FGCN_PROBE_HALO
+#define FGCN_PROBE_HALO 0
+#endif
 #ifndef FGCN_HALO_RING
 #define FGCN_HALO_RING 4                // 2: the two-slot weight ring everywhere (A/B builds)
 #endif
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     const int xrow = wr * (16 * MTW) + l15;          // this lane's image row before the tap shift and the tile index
     const int IT2 = p.taps * SPC;                    // (tap, 32-channel group) steps per chunk
     const int K8 = p.K >> 3;
+    bool probe_started = false;                      // (FGCN_PROBE_HALO: set after the first chunk)
     auto load_w = [&](u32x4v (&dst)[NP], int nu, int it, int kc) {
         if (it >= IT2) {                             // (at most one step past the chunk)
             it -= IT2;
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         }
         const int j = it / SPC, s2 = it - j * SPC;
         const unsigned so = (unsigned)(((long long)(j * K8 + (kc >> 3) + 4 * s2) * p.N) * 16);
+        if ((FGCN_PROBE_HALO & 16) && probe_started) return;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
             dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
@@ -561,6 +568,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             deposit(kc, 0, HALF);
             fetch(kc, HALF, NST);
             deposit(kc, HALF, NST);
+        } else if ((FGCN_PROBE_HALO & 4) && probe_started) {
+            // (probe: the first chunk's image stays)
         } else {
             if constexpr (!PF) fetch(kc);
             if constexpr (NP == 2) {
@@ -609,13 +618,15 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                 else load_w(wq[t % RS], t - NU, it + 1, kc);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
+                    if constexpr ((FGCN_PROBE_HALO & 2) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu % RS][0][0] ^ a[mt][NP - 1][3] ^ wq[nu % RS][NP - 1][3]);
+                    else if constexpr (NP == 3) acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
                     else if constexpr (NP == 2) acc[mt][nu] = mfma_h2_k32(a[mt], wq[nu % RS], acc[mt][nu]);
                     else acc[mt][nu] = mfma_bf16_k32(a[mt][0], wq[nu % RS][0], acc[mt][nu]);
                     if (nu == NU - 1) load_a(a[mt], mt, itn);            // this fragment's last use: fetch the next step's
                 }
             }
         }
+        probe_started = true;
     }
 
     // ---- epilogue: bias, (accumulate), branch-free buffer stores, BatchNorm partial sums ---------------------------------
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                 const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
                 float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
                 if constexpr (ldacc) val += oldv[mt & 1][nu][r];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, off, 0, STR ? FGCN_STORE_AUX : 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, ((FGCN_PROBE_HALO & 1) && val != 123.456f) ? OOB : off, 0, STR ? FGCN_STORE_AUX : 0);
                 const float kept = off != OOB ? val : 0.f;
                 if constexpr (bnb) {
                     const float dp = (mbits[mt & 1][nu][r] >> ((off >> 2) & 7u)) & 1u ? kept : 0.f;
