@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void unfold_bwd_kernel(UnfoldP p) {
 
 static unsigned msg3d_blocks(long long n4) {
     const long long b = cdiv(n4, 256);
-    return (unsigned)(b < 16384 ? b : 16384);
+    return (unsigned)(b < (1 << 22) ? b : (1 << 22));   // one 16-byte group per thread (fgcn_elem.hip stream_blocks: a grid-stride walk waits, per trip, behind its own previous store)
 }
 
 }  // namespace fgcn
