@@ -528,6 +528,7 @@ class _ConvParams(torch.autograd.Function):
         if part is None:
             part = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)     # (no zero tensor for `part` in the backward: one fill launch per convolution and step)
         return out, part
 
     @staticmethod
@@ -537,6 +538,8 @@ class _ConvParams(torch.autograd.Function):
         taps, ta, tb, tc, td = tmap
         _, N, K = wt.shape
         B, T, V, ld = ctx.x_shape
+        if d_out is None:                        # (unused output; gradients are not materialised, see forward)
+            d_out = torch.zeros((B, T_out, V, N), device=xin.device, dtype=torch.float32)
         d_out = d_out.contiguous()
         if ctx.fold:
             d_out = d_out.view(B, T * V, 1, N)
@@ -651,6 +654,7 @@ class _WindowBranchesParams(torch.autograd.Function):
         ctx.shapes = [tuple(p.shape) for p in rest[3 * n:]]
         ctx.zero_bias = zero_pool.take(n * bc, h.device) if zero_bias_grad else None
         ctx.mark_non_differentiable(*parts)
+        ctx.set_materialize_grads(False)     # (no zero tensors for the partial sums in the backward)
         return (*outs, pooled, *parts)
 
     @staticmethod
@@ -658,16 +662,20 @@ class _WindowBranchesParams(torch.autograd.Function):
         h, idx, *wts = ctx.saved_tensors
         n, bc, tmaps, stride, T_out, stats, zero_bias_grad = ctx.cfg
         B, T, V, ld = h.shape
-        d_outs, d_pool = grads[:n], grads[n]
+        d_outs, d_pool = list(grads[:n]), grads[n]
         dh = torch.empty_like(h)
         gws, gbs = [], []
         zeros = ctx.zero_bias
         for i in range(n):
+            if d_outs[i] is None:                # (unused output; gradients are not materialised, see forward)
+                d_outs[i] = torch.zeros((B, T_out, V, bc), device=h.device, dtype=torch.float32)
             d = d_outs[i].contiguous()
             taps, ta, tb, tc, td = tmaps[i]
             ops.rows_gemm(d, wts[i], dh, K=bc, N=bc, tmap=(taps, td, -tb, -tc, ta), out_coff=i * bc)
             gws.append(ops.rows_wgrad(h, d, K=bc, N=bc, tmap=tmaps[i], a_coff=i * bc, conv_param=(1, bc)).view(ctx.shapes[i]))
             gbs.append(zeros[i * bc:(i + 1) * bc] if zero_bias_grad else ops.col_sum(d, bc))
+        if d_pool is None:
+            d_pool = torch.zeros((B, T_out, V, bc), device=h.device, dtype=torch.float32)
         ops.tmaxpool3_bwd(d_pool.contiguous(), idx, T, stride, din=dh, coff=n * bc)
         return (dh, None, *([None] * (3 * n)), *gws, *gbs)
 

@@ -28,19 +28,28 @@ def out_frames(T: int, stride: int) -> int:
 
 class _JoinedBatchNorm:
     """Several per-channel BatchNorms applied to the channel-wise concatenation of their inputs as one: gamma / beta are packed
-    forms of the members' parameters (fops.joined_vector: no cat, gradients come back as slices), the running statistics are
-    concatenated for the kernel and the updated ones written back with one multi-tensor copy."""
+    forms of the members' parameters (fops.joined_vector: no cat, gradients come back as slices).  The running statistics live
+    concatenated in ``cache`` (kept by the owning module): they are gathered from the members only when a member's buffer was
+    replaced or written by someone else since the last hand-back (load_state_dict, .to(): address / version stamps) -- two cat
+    launches less per block and step -- and the updated ones are written back with one multi-tensor copy."""
 
-    def __init__(self, bns, forms):
+    def __init__(self, bns, forms, cache: dict):
         self.bns = list(bns)
         self.training = self.bns[0].training
         self.eps, self.momentum = self.bns[0].eps, self.bns[0].momentum
         self.weight = fops.joined_vector(forms, "heads.gamma", [b.weight for b in self.bns])
         self.bias = fops.joined_vector(forms, "heads.beta", [b.bias for b in self.bns])
-        with torch.no_grad():
-            self.running_mean = torch.cat([b.running_mean for b in self.bns])
-            self.running_var = torch.cat([b.running_var for b in self.bns])
+        self._cache = cache
+        if cache.get("stamp") != self._stamp():
+            with torch.no_grad():
+                cache["mean"] = torch.cat([b.running_mean for b in self.bns])
+                cache["var"] = torch.cat([b.running_var for b in self.bns])
+            cache["stamp"] = self._stamp()
+        self.running_mean, self.running_var = cache["mean"], cache["var"]
         self.num_batches_tracked = 0        # counted on the members below
+
+    def _stamp(self):
+        return tuple((b.running_mean.data_ptr(), b.running_mean._version, b.running_var.data_ptr(), b.running_var._version) for b in self.bns)
 
     def scatter_running_stats(self) -> None:
         if not self.training:
@@ -49,6 +58,7 @@ class _JoinedBatchNorm:
             sizes = [b.num_features for b in self.bns]
             torch._foreach_copy_([b.running_mean for b in self.bns] + [b.running_var for b in self.bns],
                                  list(self.running_mean.split(sizes)) + list(self.running_var.split(sizes)))
+            self._cache["stamp"] = self._stamp()     # (the members now hold what the concatenation holds)
             for b in self.bns:
                 if fops.deferred_batch_counters.active is not None:
                     fops.deferred_batch_counters.active.buffers.append(b.num_batches_tracked)
@@ -102,13 +112,14 @@ class MultiScale_TemporalConv(nn.Module):
             self.residual = TemporalConv(in_channels, out_channels, kernel_size=residual_kernel_size, stride=stride)
         self.act = activation_factory(activation)
         self._forms = fops.ParamForms()
+        self._joined_stats = {}                  # concatenated running statistics of the five heads' BatchNorms (_JoinedBatchNorm)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         bc, s = self.branch_channels, self.stride
         lead = self.branches[:-1]                       # the five branches that start with an un-strided 1x1 conv + BN + act
         relu_heads = is_relu(lead[0][2])
         # one GEMM + one BatchNorm/activation pass for the five heads
-        joined = _JoinedBatchNorm([b[1] for b in lead], self._forms)
+        joined = _JoinedBatchNorm([b[1] for b in lead], self._forms, self._joined_stats)
         h, part = fops.conv_params(x, self._forms, "heads", [b[0].weight for b in lead], [b[0].bias for b in lead],      # (1, Cin, 5 bc)
                                    stats=joined.training, zero_bias_grad=joined.training)
         h = fops.bn_act(h, part, joined, relu=relu_heads)
