@@ -117,6 +117,9 @@ SIGNATURES = {
     "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
     "fgcn_bn_act_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_elem_tiles": (_I, [_LL]),
+    "fgcn_bn_apply_ld": (_I, [_P, _P, _P, _LL, _I, _I, _P]),
+    "fgcn_bn_bwd_reduce_ld": (_I, [_P, _I, _P, _P, _P, _I, _LL, _I, _P]),
+    "fgcn_bn_bwd_apply_ld": (_I, [_P, _I, _P, _P, _P, _P, _LL, _I, _I, _P]),
     "fgcn_col_sum": (_I, [_P, _P, _LL, _I, _I, _P]),
     "fgcn_spatial_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_spatial_tiles": (_I, [_I, _I]),

@@ -94,7 +94,7 @@ __device__ __forceinline__ void store4(float* ptr, f32x4 val, int stream) {
 // read 1/32 of an activation instead of `out`; a lane pair shares a byte (n4 is even, host check).
 template <int RES, bool MASK>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
-                                                     float* out, unsigned char* mask, long long n4, int C, int relu, int stream) {
+                                                     float* out, unsigned char* mask, long long n4, int C, int relu, int stream, int ld_out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
         }
-        store4(out + i * 4, y, stream);
+        // (ld_out != C: the result goes into a channel window of a wider tensor -- MS-G3D's branch concatenation)
+        store4(ld_out == C ? out + i * 4 : out + (i * 4 / C) * ld_out + c, y, stream);
         if (MASK) {
             const int nib = (y[0] > 0.f ? 1 : 0) | (y[1] > 0.f ? 2 : 0) | (y[2] > 0.f ? 4 : 0) | (y[3] > 0.f ? 8 : 0);
             const int other = __shfl_xor(nib, 1);
@@ -140,7 +141,7 @@ __device__ __forceinline__ void relu_gate(f32x4& dp, const float* out, const uns
 template <int RES, bool MASKED>
 __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const unsigned char* mask, const float* a,
                                          const float* va, const float* b, const float* vb, float* partials,
-                                         long long rows, long long rows_per_tile, int C, int relu) {
+                                         long long rows, long long rows_per_tile, int C, int relu, int ld_dout) {
     extern __shared__ float red[];  // [ny][3][Cw], Cw = the channel window of this block: 4 * blockDim.x channels from c0
     const int Cw = blockDim.x * 4, c0 = blockIdx.y * Cw, cl = threadIdx.x * 4;
     const int c = c0 + cl;
@@ -160,7 +161,7 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
     if (cok)
         for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
             const long long o = r * C + c;
-            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + o);
+            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + r * ld_dout + c);   // (ld_dout > C: a channel window of a wider gradient)
             if (relu) relu_gate<MASKED>(dp, out, mask, o);
             const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
             s1 += dp;
@@ -189,11 +190,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                                                                const float* va, const float* b, const float* vb,
                                                                const float* sums, float* da, float* db, long long n4,
                                                                int C, int relu, int train, float inv_m,
-                                                               int db_accumulate, int stream) {
+                                                               int db_accumulate, int stream, int ld_dout) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
-        f32x4 dp = *reinterpret_cast<const f32x4*>(dout + i * 4);
+        f32x4 dp = *reinterpret_cast<const f32x4*>(ld_dout == C ? dout + i * 4 : dout + (i * 4 / C) * ld_dout + c);
         if (relu) relu_gate<MASKED>(dp, out, mask, i * 4);
         const f32x4 sc_a = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         f32x4 ga = dp;
@@ -325,8 +326,8 @@ static int check_elem(const char* what, long long rows, int C, int res_mode, con
     return FGCN_OK;
 }
 
-extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
-                           unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream) {
+static int bn_act_impl(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
+                       unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, int ld_out, void* stream) {
     FGCN_REQUIRE(a && vec_a && out, FGCN_E_BADARG, "bn_act: null pointer");
     if (int e = check_elem("bn_act", rows, C, res_mode, b, vec_b)) return e;
     FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
@@ -340,9 +341,9 @@ extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, c
 #define FGCN_BN_ACT(RES_)                                                                                         \
     do {                                                                                                          \
         if (sign_mask)                                                                                            \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str); \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
         else                                                                                                      \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str); \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
     } while (0)
     if (res_mode == 0) FGCN_BN_ACT(0);
     else if (res_mode == 1) FGCN_BN_ACT(1);
@@ -361,10 +362,10 @@ static int reduce_block(int C, dim3* blk) {
     return 0;
 }
 
-extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const unsigned char* sign_mask,
-                                      const float* a, const float* vec_a, const float* b, const float* vec_b,
-                                      float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
-                                      void* stream) {
+static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const unsigned char* sign_mask,
+                                  const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                  float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
+                                  int ld_dout, void* stream) {
     FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out || sign_mask), FGCN_E_BADARG,
                  "bn_act_bwd_reduce: null pointer");
     if (int e = check_elem("bn_act_bwd_reduce", rows, C, res_mode, b, vec_b)) return e;
@@ -379,7 +380,7 @@ extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const
     dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
 #define FGCN_BN_RED(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
-                       partials, rows, rpt, C, relu)
+                       partials, rows, rpt, C, relu, ld_dout)
     if (res_mode == 2) {
         if (sign_mask) FGCN_BN_RED(2, true); else FGCN_BN_RED(2, false);
     } else {
@@ -389,11 +390,11 @@ extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const
     return launch_status("bn_act_bwd_reduce");
 }
 
-extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned char* sign_mask,
-                                     const float* a, const float* vec_a, const float* b, const float* vec_b,
-                                     const float* sums, float* da, float* db,
-                                     long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
-                                     void* stream) {
+static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsigned char* sign_mask,
+                                 const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                 const float* sums, float* da, float* db,
+                                 long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
+                                 int ld_dout, void* stream) {
     FGCN_REQUIRE(dout && vec_a && da && (!relu || out || sign_mask) && (!train || (a && sums)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: null pointer");
     FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG,
@@ -408,7 +409,7 @@ extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const 
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_APP(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                       da, db, n4, C, relu, train, inv_m, db_accumulate, str)
+                       da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout)
     if (res_mode == 0 || !db) {
         if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
     } else if (res_mode == 1) {
@@ -553,4 +554,42 @@ extern "C" int fgcn_row_softmax_bwd(const float* da, const float* c, float* ds, 
     hipLaunchKernelGGL(fgcn::row_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, da, c, ds,
                        rows, V, ld, scale);
     return fgcn::launch_status("row_softmax_bwd");
+}
+
+extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
+                           unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream) {
+    return bn_act_impl(a, vec_a, b, vec_b, out, sign_mask, rows, C, res_mode, relu, C, stream);
+}
+extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const unsigned char* sign_mask,
+                                      const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                      float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
+                                      void* stream) {
+    return bn_act_bwd_reduce_impl(dout, out, sign_mask, a, vec_a, b, vec_b, partials, n_tiles, rows, C, res_mode, relu, C, stream);
+}
+extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned char* sign_mask,
+                                     const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                     const float* sums, float* da, float* db,
+                                     long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
+                                     void* stream) {
+    return bn_act_bwd_apply_impl(dout, out, sign_mask, a, vec_a, b, vec_b, sums, da, db, rows, C, res_mode, relu, train, db_accumulate, C,
+                                 stream);
+}
+
+// The same three passes for a plain BatchNorm (no residual, no activation) whose RESULT is a channel window of a wider tensor -- one
+// of the six branches of MS-G3D's multi-scale temporal convolution, concatenated on the channel axis (ms_tcn.py:88-109): the forward
+// writes rows of stride ld_out >= C into the window (out = window base), the backward reads the window of the concatenation's
+// gradient (dout = window base, stride ld_dout) -- no torch.cat, no contiguous copies of its backward slices.
+extern "C" int fgcn_bn_apply_ld(const float* a, const float* vec_a, float* out, long long rows, int C, int ld_out, void* stream) {
+    FGCN_REQUIRE(ld_out >= C && ld_out % 4 == 0, FGCN_E_ALIGN, "bn_apply_ld: ld_out=%d must cover C=%d and be a multiple of 4", ld_out, C);
+    return bn_act_impl(a, vec_a, nullptr, nullptr, out, nullptr, rows, C, 0, 0, ld_out, stream);
+}
+extern "C" int fgcn_bn_bwd_reduce_ld(const float* dout, int ld_dout, const float* a, const float* vec_a, float* partials, int n_tiles,
+                                     long long rows, int C, void* stream) {
+    FGCN_REQUIRE(ld_dout >= C && ld_dout % 4 == 0 && aligned16(dout), FGCN_E_ALIGN, "bn_bwd_reduce_ld: ld_dout=%d must cover C=%d, multiples of 4", ld_dout, C);
+    return bn_act_bwd_reduce_impl(dout, nullptr, nullptr, a, vec_a, nullptr, nullptr, partials, n_tiles, rows, C, 0, 0, ld_dout, stream);
+}
+extern "C" int fgcn_bn_bwd_apply_ld(const float* dout, int ld_dout, const float* a, const float* vec_a, const float* sums, float* da,
+                                    long long rows, int C, int train, void* stream) {
+    FGCN_REQUIRE(ld_dout >= C && ld_dout % 4 == 0 && aligned16(dout), FGCN_E_ALIGN, "bn_bwd_apply_ld: ld_dout=%d must cover C=%d, multiples of 4", ld_dout, C);
+    return bn_act_bwd_apply_impl(dout, nullptr, nullptr, a, vec_a, nullptr, nullptr, sums, da, nullptr, rows, C, 0, 0, train, 0, ld_dout, stream);
 }

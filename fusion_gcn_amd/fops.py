@@ -182,6 +182,63 @@ def bn_act(a: torch.Tensor, part: torch.Tensor, bn: torch.nn.Module, res: Option
                         0.1 if bn.momentum is None else bn.momentum)
 
 
+class _BnCat(torch.autograd.Function):
+    """cat_i BatchNorm_i(a_i) on the channel axis as ONE node: every branch's BatchNorm writes its channel window of the result
+    (ops.bn_apply_window) and, in the backward, reads its window of the result's gradient in place (ops.bn_bwd_window) -- no
+    torch.cat, no contiguous copies of the cat's backward slices.  args: n tensors a_i, n partials, n gammas, n betas, n running
+    means, n running variances (all branches: C channels, no residual, no activation)."""
+
+    @staticmethod
+    def forward(ctx, n: int, train: bool, eps: float, momentum: float, *args):
+        a, part, gamma, beta, rmean, rvar = (args[i * n:(i + 1) * n] for i in range(6))
+        C = a[0].shape[-1]
+        count = a[0].numel() // C
+        out = torch.empty((*a[0].shape[:-1], n * C), device=a[0].device, dtype=torch.float32)
+        vecs = []
+        for i in range(n):
+            if train:
+                vec = ops.bn_finalize(part[i], count, gamma[i], beta[i], rmean[i], rvar[i], momentum=momentum, eps=eps)
+            else:
+                vec = ops.bn_eval_coeffs(gamma[i], beta[i], rmean[i], rvar[i], eps=eps)
+            ops.bn_apply_window(a[i], vec, out, i * C)
+            vecs.append(vec)
+        ctx.n, ctx.train, ctx.C = n, train, C
+        ctx.save_for_backward(*a, *vecs)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n, C = ctx.n, ctx.C
+        saved = ctx.saved_tensors
+        a, vecs = saved[:n], saved[n:]
+        if d_out is None:
+            return (None,) * (4 + 6 * n)
+        d_out = d_out.contiguous()
+        das, dgs, dbs = [], [], []
+        for i in range(n):
+            da, sums = ops.bn_bwd_window(d_out, i * C, a[i], vecs[i], train=ctx.train)
+            das.append(da), dgs.append(sums[1]), dbs.append(sums[0])
+        return (None, None, None, None, *das, *([None] * n), *dgs, *dbs, *([None] * (2 * n)))
+
+
+def bn_cat(branches) -> torch.Tensor:
+    """``branches``: [(a_i, partials_i, bn_i)] with equal channel counts, BatchNorm parameters and mode -> cat_i bn_i(a_i) on the
+    channel axis (the six branches of MS-G3D's multi-scale temporal convolution, ms_tcn.py:88-109)."""
+    bns = [b for _, _, b in branches]
+    train = bns[0].training
+    for bn in bns:
+        if train and isinstance(bn.num_batches_tracked, torch.Tensor):
+            if deferred_batch_counters.active is not None:
+                deferred_batch_counters.active.buffers.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
+    n = len(branches)
+    mom = 0.1 if bns[0].momentum is None else bns[0].momentum
+    return _BnCat.apply(n, train, bns[0].eps, mom, *[a.contiguous() for a, _, _ in branches], *[p for _, p, _ in branches],
+                        *[b.weight for b in bns], *[b.bias for b in bns], *[b.running_mean for b in bns], *[b.running_var for b in bns])
+
+
 class _AddRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, relu: bool):

@@ -131,13 +131,18 @@ class MultiScale_TemporalConv(nn.Module):
             h, self._forms, "windows", [t.conv for t in tconvs],
             [temporal_map(t.conv.kernel_size[0], t.conv.stride[0], t.conv.dilation[0]) for t in tconvs], bc, s, out_frames(x.shape[1], s),
             stats=train, zero_bias_grad=train)
-        outs = [fops.bn_act(y, part, t.bn) for y, part, t in zip(ys, parts, tconvs)]
-        outs.append(fops.bn_act(pooled, fops.col_stats(pooled) if lead[-1][4].training else pooled.new_empty(0), lead[-1][4]))
+        # the six branches' BatchNorms write their channel windows of one tensor (fops.bn_cat: no torch.cat, and the backward reads
+        # the windows of its gradient in place)
+        same = len({t.bn.eps for t in tconvs} | {lead[-1][4].eps, self.branches[-1][1].eps}) == 1 and bc % 4 == 0
         last = self.branches[-1]
-        y, part = fops.conv_params(x, self._forms, "strided", [last[0].weight], [last[0].bias], tmap=(1, s, 0, 0, 1),
-                                   T_out=out_frames(x.shape[1], s), stats=last[1].training, zero_bias_grad=last[1].training)
-        outs.append(fops.bn_act(y, part, last[1]))
-        out = torch.cat(outs, dim=-1)
+        y_last, part_last = fops.conv_params(x, self._forms, "strided", [last[0].weight], [last[0].bias], tmap=(1, s, 0, 0, 1),
+                                             T_out=out_frames(x.shape[1], s), stats=last[1].training, zero_bias_grad=last[1].training)
+        pooled_part = fops.col_stats(pooled) if lead[-1][4].training else pooled.new_empty(0)
+        branches = [(y, part, t.bn) for y, part, t in zip(ys, parts, tconvs)] + [(pooled, pooled_part, lead[-1][4]), (y_last, part_last, last[1])]
+        if same:
+            out = fops.bn_cat(branches)
+        else:
+            out = torch.cat([fops.bn_act(y, part, bn) for y, part, bn in branches], dim=-1)
         res = self.residual(x)
         relu_out = is_relu(self.act)
         if isinstance(res, torch.Tensor):

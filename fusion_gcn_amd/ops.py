@@ -761,6 +761,38 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     return da, db, sums
 
 
+def bn_apply_window(a: torch.Tensor, vec_a: torch.Tensor, out: torch.Tensor, coff: int) -> None:
+    """out[..., coff:coff + C] = a * scale + shift (vec_a = bn_finalize's / bn_eval_coeffs' vector): a plain BatchNorm whose result is a
+    channel window of the wider contiguous tensor ``out`` (fgcn_bn_apply_ld)."""
+    ensure_device()
+    _chk(a, "bn_apply_window.a"), _chk(out, "bn_apply_window.out")
+    C, ld = a.shape[-1], out.shape[-1]
+    rows = a.numel() // C
+    if out.numel() // ld != rows or coff < 0 or coff + C > ld or coff % 4:
+        raise _lib.FgcnError(f"bn_apply_window: window [{coff}, {coff + C}) of {tuple(out.shape)} for {tuple(a.shape)}")
+    check(_lib.load().fgcn_bn_apply_ld(_p(a), _p(vec_a), _p(out, coff), rows, C, ld, _stream()), "fgcn_bn_apply_ld")
+
+
+def bn_bwd_window(dout: torch.Tensor, coff: int, a: torch.Tensor, vec_a: torch.Tensor, train: bool = True):
+    """Backward of bn_apply_window from the gradient of the WIDE tensor: -> (da contiguous like ``a``, sums (3, C): [0] = d beta,
+    [1] = d gamma); dout[..., coff:coff + C] is read in place (fgcn_bn_bwd_reduce_ld / _apply_ld)."""
+    ensure_device()
+    _chk(dout, "bn_bwd_window.dout"), _chk(a, "bn_bwd_window.a")
+    C, ld = a.shape[-1], dout.shape[-1]
+    rows = a.numel() // C
+    if dout.numel() // ld != rows or coff < 0 or coff + C > ld or coff % 4:
+        raise _lib.FgcnError(f"bn_bwd_window: window [{coff}, {coff + C}) of {tuple(dout.shape)} for {tuple(a.shape)}")
+    lib = _lib.load()
+    tiles = lib.fgcn_elem_tiles(rows)
+    partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
+    check(lib.fgcn_bn_bwd_reduce_ld(_p(dout, coff), ld, _p(a), _p(vec_a), _p(partials), tiles, rows, C, _stream()), "fgcn_bn_bwd_reduce_ld")
+    sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
+    reduce_sum(partials.view(tiles, -1), sums.view(-1))
+    da = torch.empty_like(a)
+    check(lib.fgcn_bn_bwd_apply_ld(_p(dout, coff), ld, _p(a), _p(vec_a), _p(sums), _p(da), rows, C, int(train), _stream()), "fgcn_bn_bwd_apply_ld")
+    return da, sums
+
+
 def col_sum(x: torch.Tensor, C: int, coff: int = 0) -> torch.Tensor:
     """Per-channel sum over all rows of x[..., coff:coff+C] -> (C,)."""
     ensure_device()

@@ -411,6 +411,17 @@ int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned ch
                           void* stream);
 /* number of row tiles the reduce kernel uses for `rows` rows (leading dim of its partials) */
 int fgcn_elem_tiles(long long rows);
+/* The same three passes for a plain BatchNorm (no residual, no activation) whose result is a CHANNEL WINDOW of a wider tensor: one of the
+ * six branches of MS-G3D's multi-scale temporal convolution, concatenated on the channel axis (reference torch_src/models/msg3d/ms_tcn.py:88-109).
+ *   fgcn_bn_apply_ld:      out[r * ld_out + c] = a[r * C + c] * scale[c] + shift[c]     (out = window base; ld_out >= C, both multiples of 4)
+ *   fgcn_bn_bwd_reduce_ld: partials as fgcn_bn_act_bwd_reduce with res_mode = relu = 0, dout read as dout[r * ld_dout + c] (dout = window base)
+ *   fgcn_bn_bwd_apply_ld:  da (contiguous, float[rows][C]) as fgcn_bn_act_bwd_apply with res_mode = relu = 0, dout read the same way
+ * -- no torch.cat of the branches and no contiguous copies of its backward slices. */
+int fgcn_bn_apply_ld(const float* a, const float* vec_a, float* out, long long rows, int C, int ld_out, void* stream);
+int fgcn_bn_bwd_reduce_ld(const float* dout, int ld_dout, const float* a, const float* vec_a, float* partials, int n_tiles,
+                          long long rows, int C, void* stream);
+int fgcn_bn_bwd_apply_ld(const float* dout, int ld_dout, const float* a, const float* vec_a, const float* sums, float* da,
+                         long long rows, int C, int train, void* stream);
 
 /* partials[tile][c] = sum over the tile's rows of x[row][c]   (bias gradients); n_tiles = fgcn_elem_tiles(rows) */
 int fgcn_col_sum(const float* x, float* partials, long long rows, int C, int ld, void* stream);

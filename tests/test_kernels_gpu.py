@@ -467,6 +467,44 @@ def test_spatial_wgrad_fused_agg_recompute(V, T, cin, cout, B):
     assert rel_l2(shared[0].cpu().numpy(), want1.numpy()) < RED_TOL
 
 
+@pytest.mark.parametrize("rows,C,n", [(1000, 16, 6), (777, 32, 6), (4100, 64, 3), (130, 4, 2)])
+def test_batchnorm_into_channel_windows(rows, C, n):
+    """ops.bn_apply_window / ops.bn_bwd_window (fgcn_bn_apply_ld, fgcn_bn_bwd_reduce_ld / _apply_ld): n plain BatchNorms whose results are
+    the channel windows of one wide tensor (MS-G3D's branch concatenation, ms_tcn.py:88-109) against torch: forward = cat of the
+    normalised branches, backward from the wide gradient read in place = the per-branch BatchNorm backward of its slice."""
+    from fusion_gcn_amd import ops
+    torch.manual_seed(7)
+    a = [rnd(1, rows, 1, C, seed=500 + i, scale=1.0 + 0.3 * i) + 0.2 * i for i in range(n)]
+    gamma = [rnd(C, seed=520 + i).abs() + 0.5 for i in range(n)]
+    beta = [rnd(C, seed=540 + i) for i in range(n)]
+    dwide = rnd(1, rows, 1, n * C, seed=560)
+    out = torch.full((1, rows, 1, n * C), 7.0, device=dev())
+    vecs = []
+    for i in range(n):
+        ag = to_gpu(a[i])
+        part = ops.col_moments(ag)
+        vec = ops.bn_finalize(part, rows, to_gpu(gamma[i]), to_gpu(beta[i]), None, None)
+        ops.bn_apply_window(ag, vec, out, i * C)
+        vecs.append(vec)
+    want_parts, leaves = [], []
+    for i in range(n):
+        x = a[i].double().requires_grad_(True)
+        g, b = gamma[i].double().requires_grad_(True), beta[i].double().requires_grad_(True)
+        mean, var = x.mean((0, 1, 2)), x.var((0, 1, 2), unbiased=False)
+        want_parts.append((x - mean) / torch.sqrt(var + 1e-5) * g + b)
+        leaves.append((x, g, b))
+    want = torch.cat(want_parts, dim=-1)
+    assert rel_l2(out.cpu().numpy(), want.detach().numpy()) < FWD_TOL
+    want.backward(dwide.double())
+    dw = to_gpu(dwide)
+    for i in range(n):
+        da, sums = ops.bn_bwd_window(dw, i * C, to_gpu(a[i]), vecs[i], train=True)
+        x, g, b = leaves[i]
+        assert rel_l2(da.cpu().numpy(), x.grad.numpy()) < 5 * FWD_TOL
+        assert rel_l2(sums[1].cpu().numpy(), g.grad.numpy()) < RED_TOL * 5
+        assert rel_l2(sums[0].cpu().numpy(), b.grad.numpy()) < RED_TOL * 5
+
+
 @pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 20, 27, 64), (2, 9, 25, 128), (1, 5, 28, 64)])
 def test_halo_conv_wave_arrangements_agree(B, T, V, C):
     """The nine-tap halo conv as 4 x 1 waves over 192-row tiles (64 output columns: used from 1536 tiles on, forced here by tuning key 7
