@@ -110,10 +110,13 @@ class _ConvRows(torch.autograd.Function):
         if part is None:
             part = torch.empty(0, device=x.device)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)     # (no zero tensor for `part` in the backward)
         return out, part
 
     @staticmethod
     def backward(ctx, d_out, _d_part):
+        if d_out is None:                        # (unused output)
+            return (None,) * 7
         x, w = ctx.saved_tensors
         taps, ta, tb, tc, td = ctx.tmap
         _, K, N = w.shape
