@@ -239,6 +239,10 @@ SPATIAL_TILE = os.environ.get("FGCN_SPATIAL_TILE", "1") != "0"
 # ... from this many output channels on (tools/kbench.py spatial, B = 128, profiles/r03_kbench_spatial_tile.log: 64 -> 64 0.345 vs 0.387 ms for
 # the tile form, 64 -> 128 0.562 vs 0.500, 128 -> 128 0.475 vs 0.433, 128 -> 256 0.927 vs 0.841, 256 -> 256 0.895 vs 0.797)
 SPATIAL_TILE_MIN_COUT = int(os.environ.get("FGCN_SPATIAL_TILE_MIN_COUT", "128"))
+# the backward of the spatial stage in ONE launch (fgcn_spatial_bwd_tile.hip): dagg = dy . Wd never leaves the chip -- replaces
+# pw_gemm(dy . Wd) + joint_dagg and their three-activation-wide round trip through HBM; FGCN_SPATIAL_BWD_TILE=0: the unfused pair
+SPATIAL_BWD_TILE = os.environ.get("FGCN_SPATIAL_BWD_TILE", "1") != "0"
+SPATIAL_BWD_TILE_MIN_CIN = int(os.environ.get("FGCN_SPATIAL_BWD_TILE_MIN_CIN", "64"))
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # ... up to this many channels (FGCN_BN_SUMS_MAX_C; see the measurement at its use in block_backward)
@@ -311,6 +315,18 @@ def mix_demb(emb: torch.Tensor, demb: torch.Tensor, d_s: torch.Tensor, ic: int) 
         return ops.col_sum(demb, 6 * ic)
     _, sums = ops.joint_mix_vec(emb, demb, d_s, spec, vw=vw, colsum=True)
     return sums
+
+
+def temporal_fwd_records_amax(W, kt: int, s: int, T: int) -> bool:
+    """Whether temporal_fwd takes a halo-kernel route for these sizes (the only routes that record max |g| in math mode f16x2)."""
+    pad = (kt - 1) // 2
+    return (s == 1 and "t4" in W) or (s == 2 and "t4_e" in W and pad % 2 == 0 and T > 1)
+
+
+def temporal_dgrad_records_amax(W, kt: int, s: int) -> bool:
+    """The same for temporal_dgrad and max |du|."""
+    pad = (kt - 1) // 2
+    return (s == 1 and "t_t4" in W) or (s == 2 and "t_t4_e" in W and pad % 2 == 0)
 
 
 def temporal_fwd(g: torch.Tensor, u: torch.Tensor, W: Dict[str, torch.Tensor], bias: torch.Tensor, kt: int, s: int,
@@ -394,7 +410,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     # same tensors in the backward's weight gradients; slot 0 = x (only when the embedding runs on the split row GEMM), 1 = G
     f16x2 = ops.get_math_mode() == "f16x2"
     amax = torch.zeros(4, device=dev, dtype=torch.int32) if f16x2 else None
-    S["amax"], S["x_amax"] = amax, False
+    S["amax"], S["x_amax"], S["g_amax"] = amax, False, False   # *_amax: the slot was really recorded (a row-GEMM fallback records nothing)
 
     # -- data-dependent adjacency ------------------------------------------------------------------------------------
     adj_a, adj_b = bufs["gcn1.adj_a"], P["gcn1.adj_b"].detach()
@@ -441,8 +457,9 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
     u = new(B, Tp, V, cout)
+    S["g_amax"] = f16x2 and temporal_fwd_records_amax(W, kt, s, T)
     part = temporal_fwd(y if fuse_g else g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
-                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None, amax_out=amax[1:2] if f16x2 else None)
+                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None, amax_out=amax[1:2] if S["g_amax"] else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     if cfg.residual == "none":
@@ -595,14 +612,17 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
                  and "t_t4" in W and ops.tconv_halo_bn_sums())
     # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
     # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
-    f16x2 = S.get("amax") is not None and ops.get_math_mode() == "f16x2" and ("t_t4" in W or "t_t4_e" in W)
+    f16x2 = S.get("amax") is not None and ops.get_math_mode() == "f16x2"
     bamax = torch.zeros(4, device=dev, dtype=torch.int32) if f16x2 else None
+    # (a slot only counts when the kernel that ran really recorded it: the row-GEMM fallbacks of odd paddings / T == 1 record
+    # nothing, and a weight gradient scaled by a zero-initialised slot would silently leave the f16 range)
+    du_amax = f16x2 and temporal_dgrad_records_amax(W, kt, s)
     g_partials = temporal_dgrad(du, dg, W, kt, s, bn_bwd=(S["y"], S["g_sign"], S["vec_y"]) if fuse_sums else None,
-                                amax_out=bamax[0:1] if f16x2 else None)
+                                amax_out=bamax[0:1] if du_amax else None)
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
     with wgrad():
         G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout),
-                                                amax=(S["amax"][1:2], bamax[0:1]) if f16x2 else None)
+                                                amax=(S["amax"][1:2], bamax[0:1]) if du_amax and S.get("g_amax") else None)
     G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
@@ -628,10 +648,14 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
     a_hat = S["a_hat"]
     c3 = 3 * cin
-    # dagg = dy . Wd first: in math mode f16x2 the row GEMM records max |dy| (slot 3), the operand scale of conv_d's weight gradient
-    dagg = new(B, T, V, c3)
-    dy_amax = f16x2 and pw_routed(W, "d_t", dy, cout)
-    pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
+    bwd_tile = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and not gated and x.shape[3] == cin and "d_t_s3" in W
+                and ops.spatial_bwd_tile_available(V, cin, cout))
+    dagg, dy_amax = None, False
+    if not bwd_tile:
+        # dagg = dy . Wd first: in math mode f16x2 the row GEMM records max |dy| (slot 3), the operand scale of conv_d's weight gradient
+        dagg = new(B, T, V, c3)
+        dy_amax = f16x2 and pw_routed(W, "d_t", dy, cout)
+        pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     with wgrad():
         if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
@@ -648,7 +672,9 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
-    if FUSED_DAGG and x.shape[3] == cin:
+    if bwd_tile:
+        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_s3"], dx, accumulate=dx_live)   # dagg on chip: dx and dA^ in one launch
+    elif FUSED_DAGG and x.shape[3] == cin:
         part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:
         mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)

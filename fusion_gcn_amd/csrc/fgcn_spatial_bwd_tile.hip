@@ -1,0 +1,408 @@
+// Fused spatial graph convolution, BACKWARD, tile form (north-star kernel 1, data-gradient side, split-bf16 math mode):
+//
+//     dagg_k[(n,t,w), c] = sum_o dy[(n,t,w), o] Wd_k[o][c]                      (never written to HBM)
+//     dx[(n,t,v), c]    (+)= sum_k sum_w dagg_k[(n,t,w), c] A^_k[n][v][w]
+//     dA^_k[n][v][w]      = sum_{t,c} x[(n,t,v), c] dagg_k[(n,t,w), c]          (partial sums per workgroup)
+//
+// reference: the autograd backward of SpatialGraphConv.forward, torch_src/models/mmargcn/agcn.py:103-111.
+//
+// The unfused chain wrote the three-activation-wide dagg with a 1x1 row GEMM (fgcn_pw_gemm) and read it back in fgcn_joint_dagg:
+// 1.47 GB of HBM round trip per 245 MB activation.  Here a workgroup (8 waves, one per CU) owns F = 128 / V whole frames of one
+// sample -- the forward tile kernel's geometry (fgcn_spatial_tile.hip) -- and walks the input channels in groups of 64:
+//   1. dagg^T tile (192 = 3 subsets x 64 channels, by 128 rows) = Wd^T . dY^T on the matrix pipe, the dY tile staged through LDS in
+//      32-channel steps as three bf16 planes (split once), the pre-split weights (fgcn_pack_split3 of the Cout x 3 Cin matrix)
+//      streamed from L2.  The product is formed TRANSPOSED (weights = A operand): an accumulator lane then holds four consecutive
+//      channels of one row, i.e. 8-byte pieces of a row-major image.
+//   2. per 32-channel half: the owners split their accumulators and write the all-subset image [k][row][32 ch] (three bf16 planes);
+//      * gram: wave f < frames takes frame f: dA^_k (v x w) += x_f (registers, split once) . dagg_kf^T (image rows, ds_read_b128);
+//      * mix:  (frame, 16-channel tile) units dealt to the waves by a host-made table: dx^T (c x v) = sum_k dagg_kf^T (transposing
+//        LDS reads, ds_read_b64_tr_b16: the contraction runs along image rows) . A^_k^T (split planes in LDS), stored (or added) to dx
+//        as 16-byte row pieces.
+// Every sum has a fixed order (bitwise reproducible); rows / joints beyond the tile or V are staged as zeros or meet zero columns
+// of the A^ planes.
+#include <algorithm>
+#include <type_traits>
+
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct SpBwdP {
+    const float* dy;
+    const float* x;
+    const float* a_hat;
+    const void* w3;                     // fgcn_pack_split3 form of the Cout x (3 Cin) matrix [o][k * Cin + c] = Wd_k[o][c]
+    float* dx;
+    float* partial;                     // float[B][nseg][3][32][32]
+    int B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, a_batched;
+    int F, tiles_t, tps, nseg;          // frames per tile, tiles per sample, tiles per segment, segments per sample
+    unsigned dy_bytes, x_bytes, dx_bytes, w_plane_bytes;
+    int mix_wave[16];                   // mix unit u = 2 f + (16-channel tile of the 32-channel half) -> wave
+};
+
+constexpr int SB_ROWS = 144;            // 128 tile rows + the rows a 32-joint fragment of the last frame reaches past them (V = 16: 143)
+constexpr int SB_XS = 64;               // bytes per image row and part (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
+constexpr int SB_PL = SB_ROWS * SB_XS;  // one plane
+constexpr int SB_AHB = 80;              // bytes per [v] row of a split A^ plane (32 joints w x bf16 + 16 pad)
+constexpr int SB_IM = 3 * SB_PL;        // staging planes [3] first, then the image [3 subsets][3 parts]
+constexpr int SB_AH = SB_IM + 9 * SB_PL;
+constexpr int SB_LDS = SB_AH + 9 * 32 * SB_AHB;   // 133632 bytes
+
+__device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
+    using v4s = __attribute__((ext_vector_type(4))) short;
+    const v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
+    constexpr int NP = 3, MAXS = 4;
+    constexpr unsigned OOB = 0x80000000u;
+    auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+    unsigned char* St = sb_lds;
+    unsigned char* Im = sb_lds + SB_IM;
+    unsigned char* Ah = sb_lds + SB_AH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4, q4 = l15 >> 2, c4 = lane & 3;
+    const int wm = wave >> 1, wc = wave & 1;
+    const int n = blockIdx.x / p.nseg, seg = blockIdx.x - n * p.nseg;
+    const int V = p.V, F = p.F, Cin = p.Cin, N3 = 3 * p.Cin;
+    const int tile_lo = seg * p.tps, tile_hi = min(tile_lo + p.tps, p.tiles_t);
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
+
+    // A^_k of this sample, split once per workgroup: planes [subset][part][v][w] bf16 (one ds_read_b128 = 8 joints w of row v)
+    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
+    for (int i = tid; i < 3 * 32 * 32; i += 512) {
+        const int k = i >> 10, v = (i >> 5) & 31, w = i & 31;
+        const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+        unsigned ph, pm, pl;
+        split_bf16_pair(a, 0.f, ph, pm, pl);
+        unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + v) * SB_AHB) + w;
+        d[0] = (unsigned short)ph;
+        d[32 * SB_AHB / 2] = (unsigned short)pm;
+        d[2 * 32 * SB_AHB / 2] = (unsigned short)pl;
+    }
+    // rows 128 .. 143 of every staging / image plane are never written again: zero them (a fragment of the last frame reads them)
+    for (int i = tid; i < 12 * 256; i += 512) {
+        const int pl = i >> 8, o = i & 255;
+        *reinterpret_cast<unsigned*>(sb_lds + pl * SB_PL + 128 * SB_XS + o * 4) = 0u;
+    }
+
+    // this wave's mix units of a 32-channel half (wave-uniform; the table comes from the host: fgcn_spatial_bwd_tile)
+    int sf[MAXS], sct[MAXS];
+    bool sok[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        sf[s] = 0;
+        sct[s] = 0;
+        sok[s] = false;
+    }
+    {
+        int cnt = 0;
+        for (int u = 0; u < 2 * F; ++u) {
+            const bool mine = p.mix_wave[u] == wave;
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s)
+                if (mine && cnt == s) {
+                    sf[s] = u >> 1;
+                    sct[s] = u & 1;
+                    sok[s] = true;
+                }
+            cnt += mine ? 1 : 0;
+        }
+    }
+
+    f32x4 gacc[3][2][2];                 // dA^_k (v tile, w tile) of this wave's frame, summed over the workgroup's tiles and channels
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) gacc[k][vt][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 3, sg = tid & 7;                          // staging: rows srow, srow + 64; 16-byte group sg
+    const int nks = p.Cout >> 5;                                     // 32-channel steps of the contraction (even: Cout % 64 == 0)
+
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int t0 = tile * F;
+        const int nf = min(F, p.T - t0);
+        const int nrows = nf * V;
+        const long long row0 = ((long long)n * p.T + t0) * V;        // first row of the tile
+        for (int cg = 0; cg < (Cin >> 6); ++cg) {
+            // ---- 1. dagg^T = Wd^T . dY^T ---------------------------------------------------------------------------------------
+            f32x4 acc[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 stg[2];
+            auto fetch = [&](int kc) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = srow + 64 * i;
+                    const unsigned off = r < nrows ? (unsigned)((row0 + r) * p.ld_dy * 4) + (unsigned)(kc + 4 * sg) * 4u : OOB;
+                    stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+                }
+            };
+            auto deposit = [&]() {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = srow + 64 * i;
+                    u32x2 ph, pm, pl;
+                    split3_x4(stg[i], ph, pm, pl);
+                    unsigned char* dst = St + r * SB_XS + ((unsigned)(sg * 8) ^ swz(r));
+                    *reinterpret_cast<u32x2*>(dst) = ph;
+                    *reinterpret_cast<u32x2*>(dst + SB_PL) = pm;
+                    *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
+                }
+            };
+            // weight fragment of this wave's tile i (16 dagg channels) at contraction channel kc: lane (l15, g4) holds k = kc + 8 g4 + j
+            // tile m = 3 wm + i of the group's 12: half m / 6, subset (m % 6) / 2, 16-channel tile m % 2 of the half
+            auto load_w = [&](u32x4v (&dst)[NP], int i, int kc) {
+                const int m = 3 * wm + i;
+                const int hf = m / 6, mm = m - 6 * hf;
+                const int col = (mm >> 1) * Cin + cg * 64 + hf * 32 + (mm & 1) * 16 + l15;
+                const unsigned off = (unsigned)((((kc >> 3) + g4) * N3 + col) * 16);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
+            };
+            auto load_a = [&](u32x4v (&dst)[NP], int j) {
+                const int r = wc * 64 + j * 16 + l15;
+                const unsigned char* src = St + r * SB_XS + ((unsigned)(16 * g4) ^ swz(r));
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
+            };
+            u32x4v a[4][NP], wq[2][NP];
+            // one 32-channel step; PB: ring slot of its first weight fragment (three fragments per step: the parity flips every step)
+            auto step = [&](int ks, auto pb_tag) {
+                constexpr int PB = decltype(pb_tag)::value;
+                __syncthreads();                                     // the previous step's (or round's) LDS reads are done
+                deposit();
+                __syncthreads();
+                if (ks + 1 < nks) fetch((ks + 1) * 32);              // lands during the MFMAs below
+#pragma unroll
+                for (int j = 0; j < 4; ++j) load_a(a[j], j);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // the next fragment: a later tile of this step, or the first one of the next step (past the last step: step 0 again, unused)
+                    if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32);
+                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
+                }
+            };
+            fetch(0);
+            load_w(wq[0], 0, 0);
+            for (int ks = 0; ks < nks; ks += 2) {
+                step(ks, std::integral_constant<int, 0>{});
+                step(ks + 1, std::integral_constant<int, 1>{});
+            }
+
+            // ---- 2. the two 32-channel halves of the group ------------------------------------------------------------------------
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int cbase = cg * 64 + hf * 32;                 // first input channel of the half
+                // x rows of this wave's frame (gram A operand: lane = joint v, k = 8 g4 + j channels), split once
+                u32x4v xs[2][NP];
+                if (wave < nf) {
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) {
+                        const int v = 16 * vt + l15;
+                        const unsigned off = v < V ? (unsigned)(((row0 + wave * V + v) * p.ld_x + cbase + 8 * g4) * 4) : OOB;
+                        const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                        const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+                        split3_x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3], xs[vt]);
+                    }
+                }
+                // the owners of this half's tiles write the image: row R = 64 wc + 16 j + l15, channels 16 (mm & 1) + 4 g4 .. + 3 of subset mm >> 1
+                if ((wm >> 1) == hf) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int mm = 3 * (wm & 1) + i;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int R = wc * 64 + j * 16 + l15;
+                            u32x2 ph, pm, pl;
+                            split3_x4(acc[i][j], ph, pm, pl);
+                            unsigned char* dst = Im + ((mm >> 1) * NP) * SB_PL + R * SB_XS + ((unsigned)(((mm & 1) * 16 + 4 * g4) * 2) ^ swz(R));
+                            *reinterpret_cast<u32x2*>(dst) = ph;
+                            *reinterpret_cast<u32x2*>(dst + SB_PL) = pm;
+                            *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
+                        }
+                    }
+                }
+                __syncthreads();
+                // gram: dA^_k (v x w) += x_f . dagg_kf^T over the half's 32 channels
+                if (wave < nf) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+#pragma unroll
+                        for (int wt = 0; wt < 2; ++wt) {
+                            const int R = wave * V + 16 * wt + l15;
+                            const unsigned char* src = Im + (k * NP) * SB_PL + R * SB_XS + ((unsigned)(16 * g4) ^ swz(R));
+                            u32x4v bf[NP];
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) bf[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
+#pragma unroll
+                            for (int vt = 0; vt < 2; ++vt) gacc[k][vt][wt] = mfma_x3_k32(xs[vt], bf, gacc[k][vt][wt]);
+                        }
+                }
+                // mix: dx^T (16 channels x 32 joints v) = sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
+                f32x4 dxa[MAXS][2];
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s) dxa[s][0] = dxa[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u32x4v af[2][NP];
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+                            af[vt][pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * vt + l15) * SB_AHB + 16 * g4);
+#pragma unroll
+                    for (int s = 0; s < MAXS; ++s) {
+                        if (!(sok[s] && sf[s] < nf)) continue;       // wave-uniform
+                        // transposed reads: the 16-lane group g4 reads rows 8 g4 + q4 (+ 4) x 16 channels, every lane receives the 8 joints
+                        // w = 8 g4 .. 8 g4 + 7 of channel l15 of the tile
+                        const int r_lo = sf[s] * V + 8 * g4 + q4, r_hi = r_lo + 4;
+                        const unsigned cb = (unsigned)(sct[s] * 32 + 8 * c4);
+                        u32x4v df[NP];
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) {
+                            const unsigned char* base = Im + (k * NP + pl) * SB_PL;
+                            const u32x2 lo = sb_read_tr16(base + r_lo * SB_XS + (cb ^ swz(r_lo)));
+                            const u32x2 hi = sb_read_tr16(base + r_hi * SB_XS + (cb ^ swz(r_hi)));
+                            df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+                        }
+#pragma unroll
+                        for (int vt = 0; vt < 2; ++vt) dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
+                    }
+                }
+                // dx rows (frame, joint v = 16 vt + l15), channels 16 ct + 4 g4 .. + 3 of the half: 16-byte pieces
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s) {
+                    if (!(sok[s] && sf[s] < nf)) continue;
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) {
+                        const int v = 16 * vt + l15;
+                        const unsigned off = v < V ? (unsigned)(((row0 + sf[s] * V + v) * p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * 4) : OOB;
+                        f32x4 val = dxa[s][vt];
+                        if constexpr (ACC) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, off, 0, 0));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, val), rdx, off, 0, 0);
+                    }
+                }
+                __syncthreads();                                     // the image is free for the next half / the next group
+            }
+        }
+    }
+
+    // ---- the workgroup's dA^ partial: fixed-order sum of the eight waves' frames --------------------------------------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sb_lds);                   // [8 waves][3][32 v][32 w]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[(wave * 3 + k) * 1024 + (16 * vt + 4 * g4 + r) * 32 + 16 * wt + l15] = gacc[k][vt][wt][r];
+    __syncthreads();
+    float* dst = p.partial + ((long long)n * p.nseg + seg) * 3 * 1024;
+    for (int e = tid; e < 3 * 1024; e += 512) {
+        const int k = e >> 10, idx = e & 1023;
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) s += red[(wv * 3 + k) * 1024 + idx];
+        dst[e] = ((idx >> 5) < V && (idx & 31) < V) ? s : 0.f;
+    }
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+// 1 when fgcn_spatial_bwd_tile runs these sizes in the current math mode (bf16x3 products; whole 64-channel input groups, 64-channel
+// steps of the contraction; 16..32 joints: at most 8 frames per 128-row tile, one per wave)
+extern "C" int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout) {
+    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && !fgcn::f16x2_products() && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 &&
+            Cout % 64 == 0 && Cout > 0) ? 1 : 0;
+}
+
+// segments per sample = partial matrices per sample: enough workgroups to fill 256 CUs a few times over
+extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
+    if (V < 16 || V > FGCN_MAX_V || B <= 0 || T <= 0) return 0;
+    const int tiles_t = (int)cdiv(T, 128 / V);
+    const int want = (int)std::max<long long>(1, cdiv(1024, B));
+    const int tps = (int)cdiv(tiles_t, std::min(tiles_t, want));
+    return (int)cdiv(tiles_t, tps);
+}
+
+extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                                     int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
+                                     int accumulate, void* stream) {
+    FGCN_REQUIRE(dy && x && a_hat && w3 && dx && partial, FGCN_E_BADARG, "spatial_bwd_tile: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "spatial_bwd_tile: bad sizes B=%d T=%d", B, T);
+    FGCN_REQUIRE(fgcn_spatial_bwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
+                 "spatial_bwd_tile: needs math mode bf16x3 (bf16x3 products), 16 <= V <= %d, Cin %% 64 == 0, Cout %% 64 == 0 (V=%d Cin=%d Cout=%d)",
+                 FGCN_MAX_V, V, Cin, Cout);
+    FGCN_REQUIRE(ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && ld_dy >= Cout && ld_x >= Cin && ld_dx >= Cin, FGCN_E_ALIGN,
+                 "spatial_bwd_tile: row strides");
+    FGCN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w3) && aligned16(dx), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte alignment");
+    const long long rows = (long long)B * T * V;
+    const long long dy_bytes = rows * ld_dy * 4, x_bytes = rows * ld_x * 4, dx_bytes = rows * ld_dx * 4;
+    const long long plane = (long long)3 * Cin * Cout * 2;
+    FGCN_REQUIRE(dy_bytes < 0x7FFF0000ll && x_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "spatial_bwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    SpBwdP p;
+    p.dy = dy; p.x = x; p.a_hat = a_hat; p.w3 = w3; p.dx = dx; p.partial = partial;
+    p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.Cout = Cout; p.ld_dy = ld_dy; p.ld_x = ld_x; p.ld_dx = ld_dx; p.a_batched = a_hat_batched;
+    p.F = 128 / V;
+    p.tiles_t = (int)cdiv(T, p.F);
+    p.nseg = fgcn_spatial_bwd_tile_segments(B, T, V);
+    p.tps = (int)cdiv(p.tiles_t, p.nseg);
+    FGCN_REQUIRE((long long)B * p.nseg < (1ll << 30), FGCN_E_BADARG, "spatial_bwd_tile: too many workgroups");
+    p.dy_bytes = (unsigned)dy_bytes; p.x_bytes = (unsigned)x_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
+    // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave f < F already carries frame f's gram (24 MFMA groups per
+    // half, a mix unit is 12); greedy on the lightest wave, the later wave on ties (waves >= F carry no gram)
+    {
+        int load[8], cnt[8];
+        for (int w = 0; w < 8; ++w) {
+            load[w] = w < p.F ? 2 : 0;
+            cnt[w] = 0;
+        }
+        for (int u = 0; u < 16; ++u) p.mix_wave[u] = -1;
+        for (int u = 0; u < 2 * p.F; ++u) {
+            int best = -1;
+            for (int w = 7; w >= 0; --w)
+                if (cnt[w] < 4 && (best < 0 || load[w] < load[best])) best = w;
+            FGCN_REQUIRE(best >= 0, FGCN_E_BADARG, "spatial_bwd_tile: no wave left for mix unit %d", u);
+            p.mix_wave[u] = best;
+            load[best] += 1;
+            cnt[best] += 1;
+        }
+    }
+    const dim3 grid((unsigned)(B * p.nseg));
+    hipStream_t s = (hipStream_t)stream;
+#define FGCN_SB_GO(ACC_)                                                                                               \
+    do {                                                                                                                \
+        static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
+        if (!opted) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_LDS);                         \
+            opted = true;                                                                                               \
+        }                                                                                                               \
+        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_>), grid, dim3(512), SB_LDS, s, p);                          \
+    } while (0)
+    if (accumulate) FGCN_SB_GO(true);
+    else FGCN_SB_GO(false);
+#undef FGCN_SB_GO
+    return launch_status("spatial_bwd_tile");
+}

@@ -939,6 +939,34 @@ def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bia
     return y, part
 
 
+def spatial_bwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
+    """Whether ``spatial_bwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, Cout % 64 == 0,
+    16 <= V <= 32)."""
+    return bool(_lib.load().fgcn_spatial_bwd_tile_available(V, Cin, Cout))
+
+
+def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, dx: torch.Tensor, *,
+                     accumulate: bool) -> torch.Tensor:
+    """The fused backward of the spatial stage (fgcn_spatial_bwd_tile.hip): dagg = dy . Wd stays on chip,
+    dx (+)= sum_k dagg_k . A^_k^T, and the partial grams dA^_k = x^T dagg_k come back as (B, nseg, 3, 32, 32) -- joint_dagg's output
+    format.  w3 = ``pack_split3`` of the (1, Cout, 3 Cin) matrix [o][k Cin + c] = Wd_k[o][c]."""
+    ensure_device()
+    _chk(dy, "spatial_bwd_tile.dy"), _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
+    B, T, V, Cin = x.shape
+    Cout = dy.shape[3]
+    if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, Cout // 8, 3 * Cin, 8) or not w3.is_contiguous()
+            or tuple(dy.shape[:3]) != (B, T, V) or tuple(dx.shape[:3]) != (B, T, V) or dx.shape[3] < Cin
+            or a_hat.shape[0] not in (1, B) or tuple(a_hat.shape[1:]) != (3, V, V)):
+        raise _lib.FgcnError(f"spatial_bwd_tile: shape mismatch dy={tuple(dy.shape)} x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} "
+                             f"dx={tuple(dx.shape)} w3={tuple(w3.shape)} (weights: pack_split3 of the (1, Cout, 3 Cin) matrix)")
+    lib = _lib.load()
+    nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
+    partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_spatial_bwd_tile(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
+                                    dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), _stream()), "fgcn_spatial_bwd_tile")
+    return partial
+
+
 def transpose(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
     """(B, R, C) -> (B, C, ld_out) with out[b, c, r] = x[b, r, c] and the columns [R, ld_out) zero-filled (ld_out >= R)."""
     ensure_device()

@@ -450,6 +450,21 @@ int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, co
 int fgcn_spatial_fwd_tile_tiles(int B, int T, int V);
 int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout);
 
+/* The backward of the same stage in tile form (fgcn_spatial_bwd_tile.hip; reference: the autograd backward of agcn.py:103-111,
+ * SURVEY.md Appendix A.2) -- ONE launch for what fgcn_pw_gemm (dagg = dy . Wd) + fgcn_joint_dagg did through a three-activation-wide
+ * tensor in HBM:
+ *     dagg_k = dy . Wd_k (on chip only);  dx (+)= sum_k dagg_k . A^_k^T;  partial = per-workgroup sums of dA^_k = x^T . dagg_k.
+ *   dy (B,T,V,>=Cout), x (B,T,V,>=Cin), a_hat (B or 1, 3, V, V), dx (B,T,V,>=Cin);
+ *   w3: fgcn_pack_split3 form (acc_order 0) of the Cout x (3 Cin) matrix [o][k * Cin + c] = Wd_k[o][c] (one tap, K = Cout);
+ *   partial: float[B][fgcn_spatial_bwd_tile_segments(B, T, V)][3][32][32] (rows v, columns w; entries beyond V are zero) -- the layout
+ *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin %% 64 == 0, Cout %% 64 == 0; 16 <= V <= 32; math mode bf16x3 with bf16x3 products
+ *   (fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order. */
+int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial, int B,
+                          int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                          void* stream);
+int fgcn_spatial_bwd_tile_segments(int B, int T, int V);
+int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout);
+
 /* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
 /* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:
  *     out[b][c][r] = in[b][r][c]  (r < R, c < C);  out rows have stride ld_out >= R, their columns [R, ld_out) are zero-filled.

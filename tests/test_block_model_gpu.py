@@ -220,6 +220,43 @@ def test_block_random_shapes_vs_oracle(seed):
           f"worst-param {worst} relu-flips {flips}")
 
 
+@pytest.mark.parametrize("kt,stride,T", [(3, 2, 12), (7, 2, 9), (9, 2, 1), (3, 1, 6)])
+def test_block_with_other_temporal_kernels_vs_oracle(kt, stride, T):
+    """Temporal kernels the model never uses (kt = 3 / 7 with stride 2: odd padding; a single frame): temporal_fwd / temporal_dgrad
+    fall back to the row GEMM there, which records no operand maxima -- in math mode f16x2 the weight gradient must then run its
+    bf16x3 form instead of scaling by a zero-initialised slot (block.py: g_amax / du_amax).  Forward and all gradients vs float64."""
+    from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv, TemporalConv
+    V, B, cin, cout = 25, 2, 64, 128 if stride == 2 else 64
+    blk = SpatialTemporalConv(cin, cout, ntu_adj(), stride=stride, residual=True)
+    blk.tcn1 = TemporalConv(cout, cout, kernel_size=kt, stride=stride)
+    fill_module(blk, "l0.")
+    sd = oracle_sd(blk, "l0.")
+    blk = blk.to(dev()).train()
+    x = torch.from_numpy(filler.bellish(f"x.kt.{kt}.{stride}.{T}", (B, cin, T, V))).double()
+    Tp = (T - 1) // stride + 1
+    # gradients on a scale where an unscaled f16 split would lose them (2^-20) and one where it would overflow (2^18)
+    for scale in (2.0 ** -20, 2.0 ** 18):
+        probe = torch.from_numpy(filler.uniform(f"probe.kt.{kt}", (B, cout, Tp, V), -1, 1)).double() * scale
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "adj_a"))}
+        live = dict(sd)
+        live.update(params)
+        xo = x.clone().requires_grad_(True)
+        out_o, _ = O.st_block(xo, live, "l0", stride, True, True, O.Stats())
+        grads_o = torch.autograd.grad((out_o * probe).sum(), [xo] + list(params.values()), allow_unused=True)
+        want = {k[3:]: g.numpy() for k, g in zip(params.keys(), grads_o[1:]) if g is not None}
+        blk.zero_grad()
+        xg = x.float().to(dev()).requires_grad_(True)
+        out_g = blk.forward_nchw(xg)
+        assert rel_l2(out_g.detach().cpu().numpy(), out_o.detach().numpy()) < 2e-5
+        flips = int(((out_g.detach().cpu() > 0) != (out_o.detach() > 0)).sum())
+        (out_g * probe.float().to(dev())).sum().backward()
+        tol = 2e-4 if flips == 0 else 5e-3
+        assert rel_l2(xg.grad.cpu().numpy(), grads_o[0].numpy()) < tol, (scale, flips)
+        got = {n: p.grad.detach().cpu().numpy() for n, p in blk.named_parameters()}
+        compare_grads(got, want, tol, max(float(np.abs(v).max()) for v in want.values()))
+
+
 def test_static_adjacency_block_is_stgcn_special_case():
     """ST-GCN block = same kernels with the data-dependent C_k switched off."""
     from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv

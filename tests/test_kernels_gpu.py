@@ -596,6 +596,50 @@ def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", d4, a[0]).numpy()) < FWD_TOL
 
 
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
+                                             (16, 8, 128, 128, 1), (32, 5, 64, 64, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1),
+                                             (17, 23, 64, 128, 2), (21, 12, 128, 64, 3)])
+def test_spatial_backward_tile_form(V, T, cin, cout, B):
+    """The fused backward of the spatial stage in tile form (fgcn_spatial_bwd_tile.hip: dagg = dy . Wd on chip only): dx (+)=
+    sum_k dagg_k . A^_k^T and the partial grams dA^_k = x^T dagg_k against the float64 einsums (backward of agcn.py:103-111), with and
+    without accumulation, per-sample and shared adjacency, ragged last frame group (T % F != 0), 4 .. 8 frames per tile, several
+    64-channel input groups; bitwise reproducible; agrees with the unfused pair pw_gemm + joint_dagg."""
+    from fusion_gcn_amd import ops
+    if not ops.spatial_bwd_tile_available(V, cin, cout):
+        pytest.skip("the tile form runs with the bf16x3 products")
+    x, a = rnd(B, T, V, cin, seed=310), rnd(B, 3, V, V, seed=311, scale=0.3)
+    dy, base = rnd(B, T, V, cout, seed=312), rnd(B, T, V, cin, seed=313)
+    wd = rnd(3, cout, cin, seed=314, scale=cout ** -0.5)                       # Wd_k[o][c]
+    dagg = torch.einsum("btwo,koc->btwkc", dy, wd)
+    want_dx = torch.einsum("btwkc,bkvw->btvc", dagg, a)
+    want_g = torch.einsum("btvc,btwkc->bkvw", x, dagg)
+    wt = wd.permute(1, 0, 2).reshape(1, cout, 3 * cin)                         # [o][k cin + c]
+    w3 = ops.pack_split3(to_gpu(wt))
+    parts = []
+    for acc in (False, True):
+        dx = to_gpu(base)
+        part = ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a), w3, dx, accumulate=acc)
+        assert rel_l2(dx.cpu().numpy(), (want_dx + (base if acc else 0)).numpy()) < FWD_TOL, acc
+        got_g = part.double().sum(1)[:, :, :V, :V].cpu()
+        assert rel_l2(got_g.numpy(), want_g.numpy()) < RED_TOL
+        if V < 32:
+            assert float(part[:, :, :, V:, :].abs().max()) == 0.0 and float(part[:, :, :, :, V:].abs().max()) == 0.0   # padding stays zero
+        parts.append((dx, part))
+    dx2 = to_gpu(base)
+    part2 = ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a), w3, dx2, accumulate=True)
+    assert torch.equal(dx2, parts[1][0]) and torch.equal(part2, parts[1][1])
+    # the unfused pair on the same data
+    dagg_g = torch.empty(B, T, V, 3 * cin, device=dev())
+    ops.pw_gemm(to_gpu(dy), w3, dagg_g)
+    dx_old = to_gpu(base)
+    part_old = ops.joint_dagg(to_gpu(x), dagg_g, to_gpu(a), dx_old, accumulate=True)
+    assert rel_l2(dx2.cpu().numpy(), dx_old.cpu().numpy()) < FWD_TOL
+    assert rel_l2(part2.sum(1).cpu().numpy()[:, :, :V, :V], part_old.sum(1).cpu().numpy()[:, :, :V, :V]) < RED_TOL
+    dx = to_gpu(base)
+    ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a[:1]), w3, dx, accumulate=False)     # static (shared) adjacency
+    assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", dagg, a[0]).numpy()) < FWD_TOL
+
+
 @pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
 def test_halo_data_gradient_emits_the_batchnorm_backward_sums(B, T, V, C, fgcn_math):
     """fgcn_tconv_halo with bn_a / bn_mask / bn_vec: the data gradient dG and, from its epilogue, sum dP and sum dP * a_hat with

@@ -193,6 +193,30 @@ def bench_spatial_wgrad(B, reps):
         report(f"mix_agg + rows_wgrad     T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (8 * cin + cout))
 
 
+def bench_spatial_bwd(B, reps):
+    """Backward of the spatial stage: the fused tile kernel (dagg on chip) vs pw_gemm(dy . Wd) / rows_gemm + joint_dagg."""
+    for T, cin, cout in ((300, 64, 64), (300, 64, 128), (150, 128, 128), (150, 128, 256), (75, 256, 256)):
+        x, a, dy = rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2, rnd(B, T, V, cout)
+        dx = rnd(B, T, V, cin)
+        rows = B * T * V
+        fl = rows * (12.0 * V * cin + 6.0 * cin * cout)
+        wt = rnd(1, cout, 3 * cin) * cout ** -0.5
+        if ops.spatial_bwd_tile_available(V, cin, cout):
+            w3 = ops.pack_split3(wt)
+            ms = timeit(lambda: ops.spatial_bwd_tile(dy, x, a, w3, dx, accumulate=True), reps)
+            report(f"spatial_bwd_tile (fused) T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (3 * cin + cout))
+        dagg = torch.empty(B, T, V, 3 * cin, device=DEV)
+        if ops.pw_gemm_available():
+            w3 = ops.pack_split3(wt)
+            ms1 = timeit(lambda: ops.pw_gemm(dy, w3, dagg), reps)
+        else:
+            ms1 = timeit(lambda: ops.rows_gemm(dy, wt, dagg, K=cout, N=3 * cin), reps)
+        ms1r = timeit(lambda: ops.rows_gemm(dy, wt, dagg, K=cout, N=3 * cin), reps)
+        ms2 = timeit(lambda: ops.joint_dagg(x, dagg, a, dx, accumulate=True), reps)
+        report(f"  pw_gemm {ms1:.3f} (f32 row GEMM {ms1r:.3f}) + joint_dagg {ms2:.3f}  T{T} {cin}->{cout}", min(ms1, ms1r) + ms2, fl,
+               4.0 * rows * (9 * cin + cout))
+
+
 def bench_joint(B, reps):
     for order in ((1,), (2, 1)):
         block.MIX_VW_ORDER = order
@@ -248,7 +272,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,joint,elem")
+    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3", "f16x2"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -259,7 +283,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
