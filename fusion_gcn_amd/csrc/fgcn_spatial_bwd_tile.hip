@@ -54,9 +54,10 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-template <bool ACC>
+// MAXS: mix units per wave and half (three up to six frames per tile, four for seven / eight)
+template <bool ACC, int MAXS>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
-    constexpr int NP = 3, MAXS = 4;
+    constexpr int NP = 3;
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
@@ -116,6 +117,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 }
             cnt += mine ? 1 : 0;
         }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            sf[s] = __builtin_amdgcn_readfirstlane(sf[s]);
+            sct[s] = __builtin_amdgcn_readfirstlane(sct[s]);
+            sok[s] = __builtin_amdgcn_readfirstlane(sok[s] ? 1 : 0) != 0;
+        }
     }
 
     f32x4 gacc[3][2][2];                 // dA^_k (v tile, w tile) of this wave's frame, summed over the workgroup's tiles and channels
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
         const int t0 = tile * F;
         const int nf = min(F, p.T - t0);
         const int nrows = nf * V;
-        const long long row0 = ((long long)n * p.T + t0) * V;        // first row of the tile
+        const unsigned row0 = (unsigned)((n * p.T + t0) * V);        // first row of the tile (byte offsets fit 31 bits: checked by the launcher)
         for (int cg = 0; cg < (Cin >> 6); ++cg) {
             // ---- 1. dagg^T = Wd^T . dY^T ---------------------------------------------------------------------------------------
             f32x4 acc[3][4];
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
-                    const unsigned off = r < nrows ? (unsigned)((row0 + r) * p.ld_dy * 4) + (unsigned)(kc + 4 * sg) * 4u : OOB;
+                    const unsigned off = r < nrows ? ((row0 + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
                     stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
                 }
             };
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 for (int i = 0; i < 3; ++i) {
                     // the next fragment: a later tile of this step, or the first one of the next step (past the last step: step 0 again, unused)
                     if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32);
-                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0);
+                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0);   // (a select, not a branch, around the request)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
                 }
@@ -210,15 +217,13 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 const int cbase = cg * 64 + hf * 32;                 // first input channel of the half
                 // x rows of this wave's frame (gram A operand: lane = joint v, k = 8 g4 + j channels), split once
                 u32x4v xs[2][NP];
-                if (wave < nf) {
+                f32x4 xr[2][2];
 #pragma unroll
-                    for (int vt = 0; vt < 2; ++vt) {
-                        const int v = 16 * vt + l15;
-                        const unsigned off = v < V ? (unsigned)(((row0 + wave * V + v) * p.ld_x + cbase + 8 * g4) * 4) : OOB;
-                        const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-                        const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
-                        split3_x8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3], xs[vt]);
-                    }
+                for (int vt = 0; vt < 2; ++vt) {                     // (branch-free: a wave without a frame requests nothing)
+                    const int v = 16 * vt + l15;
+                    const unsigned off = (wave < nf && v < V) ? ((row0 + wave * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * 4u : OOB;
+                    xr[vt][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                    xr[vt][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
                 }
                 // the owners of this half's tiles write the image: row R = 64 wc + 16 j + l15, channels 16 (mm & 1) + 4 g4 .. + 3 of subset mm >> 1
                 if ((wm >> 1) == hf) {
@@ -238,6 +243,22 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     }
                 }
                 __syncthreads();
+                // dx's old values (or zeros) are the mix accumulators' start: rows (frame, joint v = 16 vt + l15), channels 16 ct + 4 g4 .. + 3
+                f32x4 dxa[MAXS][2];
+                auto dx_off = [&](int s, int vt) -> unsigned {
+                    const int v = 16 * vt + l15;
+                    return (sok[s] && sf[s] < nf && v < V) ? ((row0 + sf[s] * V + v) * (unsigned)p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * 4u : OOB;
+                };
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+                    for (int vt = 0; vt < 2; ++vt) {
+                        if constexpr (ACC) dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
+                        else dxa[s][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int vt = 0; vt < 2; ++vt)
+                    split3_x8(xr[vt][0][0], xr[vt][0][1], xr[vt][0][2], xr[vt][0][3], xr[vt][1][0], xr[vt][1][1], xr[vt][1][2], xr[vt][1][3], xs[vt]);
                 // gram: dA^_k (v x w) += x_f . dagg_kf^T over the half's 32 channels
                 if (wave < nf) {
 #pragma unroll
@@ -253,10 +274,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                             for (int vt = 0; vt < 2; ++vt) gacc[k][vt][wt] = mfma_x3_k32(xs[vt], bf, gacc[k][vt][wt]);
                         }
                 }
-                // mix: dx^T (16 channels x 32 joints v) = sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
-                f32x4 dxa[MAXS][2];
-#pragma unroll
-                for (int s = 0; s < MAXS; ++s) dxa[s][0] = dxa[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // mix: dx^T (16 channels x 32 joints v) += sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     u32x4v af[2][NP];
@@ -284,19 +302,11 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                         for (int vt = 0; vt < 2; ++vt) dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
                     }
                 }
-                // dx rows (frame, joint v = 16 vt + l15), channels 16 ct + 4 g4 .. + 3 of the half: 16-byte pieces
 #pragma unroll
-                for (int s = 0; s < MAXS; ++s) {
-                    if (!(sok[s] && sf[s] < nf)) continue;
+                for (int s = 0; s < MAXS; ++s)
 #pragma unroll
-                    for (int vt = 0; vt < 2; ++vt) {
-                        const int v = 16 * vt + l15;
-                        const unsigned off = v < V ? (unsigned)(((row0 + sf[s] * V + v) * p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * 4) : OOB;
-                        f32x4 val = dxa[s][vt];
-                        if constexpr (ACC) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, off, 0, 0));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, val), rdx, off, 0, 0);
-                    }
-                }
+                    for (int vt = 0; vt < 2; ++vt)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, dx_off(s, vt), 0, 0);
                 __syncthreads();                                     // the image is free for the next half / the next group
             }
         }
@@ -391,18 +401,29 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     }
     const dim3 grid((unsigned)(B * p.nseg));
     hipStream_t s = (hipStream_t)stream;
-#define FGCN_SB_GO(ACC_)                                                                                               \
+#define FGCN_SB_GO(ACC_, MS_)                                                                                          \
     do {                                                                                                                \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_>),                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_>),            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_LDS);                         \
             opted = true;                                                                                               \
         }                                                                                                               \
-        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_>), grid, dim3(512), SB_LDS, s, p);                          \
+        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_>), grid, dim3(512), SB_LDS, s, p);                     \
     } while (0)
-    if (accumulate) FGCN_SB_GO(true);
-    else FGCN_SB_GO(false);
+    int max_units = 0;
+    for (int w = 0; w < 8; ++w) {
+        int c = 0;
+        for (int u = 0; u < 2 * p.F; ++u) c += p.mix_wave[u] == w ? 1 : 0;
+        max_units = std::max(max_units, c);
+    }
+    if (max_units <= 3) {
+        if (accumulate) FGCN_SB_GO(true, 3);
+        else FGCN_SB_GO(false, 3);
+    } else {
+        if (accumulate) FGCN_SB_GO(true, 4);
+        else FGCN_SB_GO(false, 4);
+    }
 #undef FGCN_SB_GO
     return launch_status("spatial_bwd_tile");
 }
