@@ -442,7 +442,8 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
     return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
-TWGRAD_TAPS = (1, 2, 3, 4, 5, 6, 9)   # taps per call the multi-tap kernel is instantiated for
+TWGRAD_TAPS = (1, 2, 3, 4, 5, 6, 9)   # taps per call the multi-tap kernel is instantiated for (math mode f32)
+TWGRAD_TAPS_SPLIT = (1, 2, 3, 4, 5, 9)   # ... in the split-bf16 modes (tap mode of tconv_wgrad_x3_kernel: fgcn_twgrad.hip)
 
 
 def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1, out: Optional[torch.Tensor] = None,
@@ -467,7 +468,8 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
             calls.append((par, js[0], len(js), (js[0] - pad - par) // stride))
     if all_taps is None:
         all_taps = True
-    if not all_taps or any(n not in TWGRAD_TAPS for _, _, n, _ in calls):
+    ok_taps = TWGRAD_TAPS if get_math_mode() == "f32" else TWGRAD_TAPS_SPLIT
+    if not all_taps or any(n not in ok_taps for _, _, n, _ in calls):
         return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate, wide=False,
                           conv_param=conv_param)
     lib = _lib.load()
