@@ -57,6 +57,8 @@ MATH_DTYPE = {
     "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics",
     "f16x2": "f32 (bf16x3, with the temporal and 1x1 convolutions' products from block-scaled 2-way f16 splits of both operands: 3 f16 "
              "MFMAs per product group, f32 accumulate; f32 storage / statistics; same parity tolerances as the f32 MFMA path)"}
+MATH_DTYPE_SHORT = {"f32": "f32", "bf16x3": "f32 (products from exact 3-way bf16 splits; see notes.dtype)", "bf16": "bf16 operands, f32 accumulate",
+                    "f16x2": "f32 (products from block-scaled 2-way f16 splits; see notes.dtype)"}
 MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_kernel<{nt},3> (bf16 operands)",
                "bf16x3": "conv_halo_x3k32_kernel<{nt2},32>", "f16x2": "conv_halo_x3k32_kernel<{nt2},32,2> (f16x2 products)"}
 PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
@@ -320,6 +322,8 @@ def main():
                     help="weight-gradient kernels in line (main, the library default since the end of round 3), on a second HIP stream "
                          "beside the HBM-bound chain (side), or by the size of the block's tensors (auto: side from ~24 clips per GPU upwards)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--allow-eager", action="store_true",
+                    help="if the HIP-graph capture of the step fails, time the eagerly launched step instead of exiting non-zero")
     ap.add_argument("--joints", type=int, choices=(25, 27, 22), default=25,
                     help="25: the headline (BASELINE config 2); 27: config 3 (NTU graph + 2 IMU joints); 22: config 4 (MMAct COCO-18 + "
                          "4 IMU joints, 35 classes) -- parity-test shapes timed for the record, not the headline")
@@ -472,8 +476,11 @@ def main():
                     opt.step()
                 return static_loss
             return step_graph, "hipgraph"
-        except Exception as e:  # noqa: BLE001 - report and fall back to eager launches
-            log(f"graph capture failed ({type(e).__name__}: {e}); running eager")
+        except Exception as e:  # noqa: BLE001 - a bench that silently changes its launch mode measures something else
+            log(f"graph capture failed ({type(e).__name__}: {e})")
+            if not args.allow_eager:
+                raise SystemExit("bench.py: HIP-graph capture of the step failed (see the message above); --allow-eager runs the "
+                                 "eagerly launched step instead, --no-graph asks for it from the start")
             torch.cuda.synchronize()
             return step_eager, "eager"
 
@@ -602,29 +609,29 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         clips_per_s = n_global * args.steps / elapsed
         flops, byts = algorithmic_costs(n_global)
+        # Key order: a reader (or a record that keeps only the head of the line) gets every NUMBER first -- headline, the two side
+        # modes, whole-step fractions, roofline, CPU baseline -- then the short descriptors, and the long prose last.
         out = {
             "metric": "clips/sec (N,C,T,V,M)=(64,3,300,%d,2) fwd+bwd" % SHAPE["V"],
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": MATH_DTYPE[args.math],
-            "data": "synthetic",
-            "config": {"workload": "AGCN 10-block fwd+bwd, %s, synthetic (N,C,T,V,M)=(%d,3,300,%d,2), "
-                                   "%d classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
-                                   % ({25: "NTU-RGB-D graph", 27: "NTU-RGB-D graph + 2 IMU joints", 22: "MMAct COCO-18 graph + 4 IMU joints"}
-                                      [SHAPE["V"]], n_global, SHAPE["V"], SHAPE["classes"]),
-                       "global_batch": n_global, "per_gpu_batch": n_local,
-                       "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5),
-                       "optimizer_step_in_timed_region": args.optimizer, "input_pipeline": pipeline or "one HBM-resident batch",
-                       "init_override": "gcn1.bn.weight=1.0 in all ten blocks (the reference initialises it to 1e-6, agcn.py:86-94; O(1) "
-                                        "values give every kernel realistic magnitudes; everything else torch.manual_seed(1) reference init)"},
-            "step_fractions": {
-                "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-                "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
-                "hbm": round(byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4),
-                "algorithmic_gflop_per_clip": round(flops / n_global / 1e9, 2),
-                "algorithmic_mb_per_clip": round(byts / n_global / 1e6, 2)},
         }
+        modes = {}
+        if f32_mode:
+            modes["f32_mfma"] = {"clips_s": f32_mode["value"], "ms": f32_mode["ms_per_step"]}
+        if f16x2_mode:
+            modes["f16x2"] = {"clips_s": f16x2_mode["value"], "ms": f16x2_mode["ms_per_step"]}
+        if modes:
+            out["modes"] = modes
+        out["step_fractions"] = {
+            "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+            "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
+            "hbm": round(byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4),
+            "algorithmic_gflop_per_clip": round(flops / n_global / 1e9, 2),
+            "algorithmic_mb_per_clip": round(byts / n_global / 1e6, 2)}
+        notes = {}
+        roofline_detail = None
         if kern:
             dom = max(kern, key=lambda k: k["channels"])      # the 256-channel launch: the longest one of the step
             peak = MATH_PEAK[args.math]
@@ -632,35 +639,51 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(dom["tflops"], 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(dom["tflops"] / peak, 4),
                                "traffic": measured_traffic(dom, n_local * SHAPE["M"], args.math),
-                               "traffic_is": "stored rocprofv3 PMC record of this kernel at this shape (profiles/r0*_traffic.json: "
-                                             "2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run",
-                               "practical_ceiling_note": "MI355X_MICROARCH.md: tuned bf16 MFMA loops reach 1.25-1.48 PFLOP/s on random data "
-                                                         "(the chip lowers its clock to ~1.9 GHz under MFMA load); this kernel issues "
-                                                         "6 x achieved of bf16 MFMA work",
-                               "peak_is": {"f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "v_mfma_f32_32x32x16_bf16 dense",
-                                           "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)",
-                                           "f16x2": "f16 dense peak (= bf16's) / 3 products (f32-equivalent FLOPs)"}[args.math],
-                               "frac_of_f32_mfma_peak": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
-                               "kernel": f"{kname} (9x1 temporal conv forward, "
-                                         f"{dom['channels']} channels, {dom['frames']} frames)",
                                "ms_per_launch": round(dom["ms"], 4),
                                "flop_per_launch": dom["flops"],
-                               "all_widths": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
-                                              for d in kern]}
-        if f32_mode:
-            out["f32_mfma_mode"] = f32_mode
-        if f16x2_mode:
-            out["f16x2_mode"] = f16x2_mode
-        if other:
-            out["other_scaling"] = other
+                               "frac_of_f32_mfma_peak": round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                               "kernel": f"{kname} (9x1 temporal conv forward, "
+                                         f"{dom['channels']} channels, {dom['frames']} frames)"}
+            notes["roofline.traffic"] = ("stored rocprofv3 PMC record of this kernel at this shape (profiles/r0*_traffic.json: "
+                                         "2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run")
+            notes["roofline.practical_ceiling"] = ("MI355X_MICROARCH.md: tuned bf16 MFMA loops reach 1.25-1.48 PFLOP/s on random data "
+                                                   "(the chip lowers its clock to ~1.9 GHz under MFMA load); this kernel issues "
+                                                   "6 x achieved of bf16 MFMA work")
+            notes["roofline.peak"] = {"f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "v_mfma_f32_32x32x16_bf16 dense",
+                                      "bf16x3": "bf16 dense peak / 6 partial products (f32-equivalent FLOPs)",
+                                      "f16x2": "f16 dense peak (= bf16's) / 3 products (f32-equivalent FLOPs)"}[args.math]
+            roofline_detail = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in kern]
+        parity = None
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle on the host cores")
             also = ("f16x2",) if f16x2_mode else ()
             out["cpu_baseline"], parity = cpu_baseline(device=device, maths=(args.math,) + also)
-            if parity is not None:
-                out["parity_at_full_shape"] = parity[args.math]
-                if f16x2_mode:
-                    out["f16x2_mode"]["parity_at_full_shape"] = parity["f16x2"]
+        out["dtype"] = MATH_DTYPE_SHORT[args.math]
+        out["data"] = "synthetic"
+        out["config"] = {"workload": "AGCN 10-block fwd+bwd, %s, synthetic (N,C,T,V,M)=(%d,3,300,%d,2), "
+                                     "%d classes, train-mode BatchNorm, CrossEntropy, all parameter gradients"
+                                     % ({25: "NTU-RGB-D graph", 27: "NTU-RGB-D graph + 2 IMU joints", 22: "MMAct COCO-18 graph + 4 IMU joints"}
+                                        [SHAPE["V"]], n_global, SHAPE["V"], SHAPE["classes"]),
+                         "global_batch": n_global, "per_gpu_batch": n_local,
+                         "parallelism": f"dp{world}", "launch": mode, "loss": round(loss_val, 5),
+                         "optimizer_step_in_timed_region": args.optimizer, "input_pipeline": pipeline or "one HBM-resident batch",
+                         "init_override": "gcn1.bn.weight=1.0 (reference: 1e-6); see notes"}
+        if other:
+            out["other_scaling"] = other
+        if parity is not None:
+            out["parity_at_full_shape"] = parity[args.math]
+            if f16x2_mode:
+                f16x2_mode["parity_at_full_shape"] = parity["f16x2"]
+        if f32_mode:
+            out["f32_mfma_mode"] = f32_mode
+        if f16x2_mode:
+            out["f16x2_mode"] = f16x2_mode
+        if roofline_detail:
+            out["roofline_all_widths"] = roofline_detail
+        notes["dtype"] = MATH_DTYPE[args.math]
+        notes["init_override"] = ("gcn1.bn.weight=1.0 in all ten blocks (the reference initialises it to 1e-6, agcn.py:86-94; O(1) "
+                                  "values give every kernel realistic magnitudes; everything else torch.manual_seed(1) reference init)")
+        out["notes"] = notes
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

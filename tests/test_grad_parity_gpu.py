@@ -100,7 +100,7 @@ def test_headline_shape_against_the_oracle_at_full_size():
     oracle = RM.oracle_side(x.double(), labels, sd, [k for k, _ in model.named_parameters()])
     del sd
     model = model.to(dev).train()
-    for mode in ("bf16x3", "f32"):
+    for mode in ("bf16x3", "f16x2", "f32"):
         with ops.math_mode(mode):
             rep = RM.gradient_parity_report(model, x.float().to(dev), labels.to(dev), oracle=oracle)
         frac = rep["flips"] / rep["decisions"]
@@ -109,5 +109,51 @@ def test_headline_shape_against_the_oracle_at_full_size():
               f"{rep['err_injected']:.2e}")
         assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5, rep
         assert frac < 2e-6, rep["flips_per_block"]          # ~3e-7 of the ReLU inputs in the reference's own runs
+        assert rep["err_injected"] < INJECTED_TOL, rep
+        assert rep["err_plain"] <= flip_bound(rep["flips"], rep["decisions"]), rep
+
+
+@pytest.mark.parametrize("tag,dataset,joints,classes,n_imu", [("ntu27_T300", "ntu", 27, 60, 2), ("mmact22_T300", "mmact", 22, 35, 4)])
+def test_other_baseline_shapes_against_the_oracle_at_full_length(tag, dataset, joints, classes, n_imu):
+    """BASELINE configs 3 and 4 at their full T = 300 (NTU graph + 2 IMU joints, V = 27; MMAct COCO-18 graph + 4 IMU joints, V = 22;
+    M = 2), 4 clips -- the fixture-size comparison of tests/test_block_model_gpu.py::test_other_baseline_shapes_vs_reference runs T = 16:
+    logits / loss against the float64 oracle, the flat gradient with ReLU-flip accounting, in the three float32-class math modes.  The
+    network is built on the fused skeleton + IMU graph the mmargcn mode builds (models/mmargcn/fusion.py:52-65; reference
+    fusion.py:65-89); the IMU joints carry uniform [0, 1) signals like the reference's min-max normalised ones."""
+    import os
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.mmact import constants as mmact
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.models.mmargcn.fusion import get_skeleton_imu_fusion_graph
+    from fusion_gcn_amd.util import Graph
+    c = {"ntu": ntu, "mmact": mmact}[dataset]
+    n = int(os.environ.get("FGCN_FULL_LENGTH_CLIPS", "4"))
+    dev = torch.device("cuda:0")
+    graph = get_skeleton_imu_fusion_graph(Graph(c.skeleton_edges, center_joint=c.center_joint), "append_center", n_imu)
+    shape = (n, 2, 300, joints, 3)
+    model = Model(shape[1:], classes, graph)
+    filler.fill_state_dict(model.state_dict())
+    with torch.no_grad():                       # O(1) BatchNorm scale in the graph convolutions, as the benchmark sets it
+        for k, p in model.named_parameters():
+            if k.endswith("gcn1.bn.weight"):
+                p.fill_(1.0)
+    x = torch.from_numpy(filler.skeleton_input(f"x.{tag}", shape, empty_second_body=True))
+    x[..., joints - n_imu:, :] = torch.from_numpy(filler.uniform(f"imu.{tag}", (n, 2, 300, n_imu, 3), 0, 1)).to(x.dtype)
+    labels = torch.from_numpy(filler.uniform(f"y.{tag}", (n,), 0, classes).astype(np.int64))
+    sd = {k: (v.detach().double().clone() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    oracle = RM.oracle_side(x.double(), labels, sd, [k for k, _ in model.named_parameters()])
+    del sd
+    model = model.to(dev).train()
+    for mode in ("bf16x3", "f16x2", "f32"):
+        with ops.math_mode(mode):
+            rep = RM.gradient_parity_report(model, x.float().to(dev), labels.to(dev), oracle=oracle)
+        frac = rep["flips"] / rep["decisions"]
+        print(f"[{tag}, {n} clips, {mode}] logits {rep['logits_err']:.2e} loss {rep['loss_err']:.2e} | ReLU flips {rep['flips']} of "
+              f"{rep['decisions']} ({frac:.2e}) | flat-grad rel-L2: plain {rep['err_plain']:.2e}, oracle decisions injected "
+              f"{rep['err_injected']:.2e}")
+        assert rep["logits_err"] < 1e-5 and rep["loss_err"] < 1e-5, rep
+        assert frac < 2e-6, rep["flips_per_block"]
         assert rep["err_injected"] < INJECTED_TOL, rep
         assert rep["err_plain"] <= flip_bound(rep["flips"], rep["decisions"]), rep
