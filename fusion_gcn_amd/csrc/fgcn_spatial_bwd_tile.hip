@@ -25,6 +25,13 @@
 
 #include "fgcn_common.hpp"
 
+// Timing probes (wrong results; tools/build_probe.py only): bit 0 = no gram MFMAs, bit 1 = no mix MFMAs, bit 2 = no MFMAs in the
+// contraction steps, bit 3 = x rows / old dx values not requested, bit 4 = the dY rows requested for the first step only,
+// bit 5 = no image writes (the compiler then drops the contraction too), bit 6 = no dx stores
+#ifndef FGCN_PROBE_SB
+#define FGCN_PROBE_SB 0
+#endif
+
 namespace fgcn {
 
 struct SpBwdP {
@@ -54,7 +61,7 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-// MAXS: mix units per wave and half (three up to six frames per tile, four for seven / eight)
+// MAXS: mix units per wave and half (the host's table: two for four to six frames per tile, up to four for seven / eight)
 template <bool ACC, int MAXS>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     constexpr int NP = 3;
@@ -125,13 +132,11 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
         }
     }
 
-    f32x4 gacc[3][2][2];                 // dA^_k (v tile, w tile) of this wave's frame, summed over the workgroup's tiles and channels
+    f32x4 gacc[3][2];                    // dA^_k (this wave's v tile, w tile), summed over its frames and the workgroup's tiles and channels
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-            for (int wt = 0; wt < 2; ++wt) gacc[k][vt][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int wt = 0; wt < 2; ++wt) gacc[k][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int srow = tid >> 3, sg = tid & 7;                          // staging: rows srow, srow + 64; 16-byte group sg
     const int nks = p.Cout >> 5;                                     // 32-channel steps of the contraction (even: Cout % 64 == 0)
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 __syncthreads();                                     // the previous step's (or round's) LDS reads are done
                 deposit();
                 __syncthreads();
-                if (ks + 1 < nks) fetch((ks + 1) * 32);              // lands during the MFMAs below
+                if (ks + 1 < nks && !(FGCN_PROBE_SB & 16)) fetch((ks + 1) * 32);   // lands during the MFMAs below
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_a(a[j], j);
 #pragma unroll
@@ -201,7 +206,10 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32);
                     else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0);   // (a select, not a branch, around the request)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr ((FGCN_PROBE_SB & 4) != 0) acc[i][j][0] += __builtin_bit_cast(float, wq[(PB + i) & 1][0][0] ^ a[j][0][0]);
+                        else acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
+                    }
                 }
             };
             fetch(0);
@@ -216,17 +224,19 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
             for (int hf = 0; hf < 2; ++hf) {
                 const int cbase = cg * 64 + hf * 32;                 // first input channel of the half
                 // x rows of this wave's frame (gram A operand: lane = joint v, k = 8 g4 + j channels), split once
-                u32x4v xs[2][NP];
+                // gram units (frame f, v tile vt): wave 2 (f % 4) + vt takes frames f0 = wave / 2 and f0 + 4 -- its accumulators (one v tile,
+                // both w tiles, three subsets: 24 registers) sum over its frames.  x rows of a unit (A operand: lane = joint v, k = 8 g4 + j
+                // channels) are requested here, ahead of the image barrier (branch-free: a unit without a frame requests nothing)
                 f32x4 xr[2][2];
 #pragma unroll
-                for (int vt = 0; vt < 2; ++vt) {                     // (branch-free: a wave without a frame requests nothing)
-                    const int v = 16 * vt + l15;
-                    const unsigned off = (wave < nf && v < V) ? ((row0 + wave * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * 4u : OOB;
-                    xr[vt][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-                    xr[vt][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+                for (int u = 0; u < 2; ++u) {
+                    const int f = (wave >> 1) + 4 * u, v = 16 * (wave & 1) + l15;
+                    const unsigned off = (f < nf && v < V && !(FGCN_PROBE_SB & 8)) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * 4u : OOB;
+                    xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                    xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
                 }
                 // the owners of this half's tiles write the image: row R = 64 wc + 16 j + l15, channels 16 (mm & 1) + 4 g4 .. + 3 of subset mm >> 1
-                if ((wm >> 1) == hf) {
+                if ((wm >> 1) == hf && !(FGCN_PROBE_SB & 32)) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const int mm = 3 * (wm & 1) + i;
@@ -253,25 +263,27 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 for (int s = 0; s < MAXS; ++s)
 #pragma unroll
                     for (int vt = 0; vt < 2; ++vt) {
-                        if constexpr (ACC) dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
+                        if constexpr (ACC && !(FGCN_PROBE_SB & 8)) dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
                         else dxa[s][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                // gram: dA^_k (v tile x w) += x_f . dagg_kf^T over the half's 32 channels
 #pragma unroll
-                for (int vt = 0; vt < 2; ++vt)
-                    split3_x8(xr[vt][0][0], xr[vt][0][1], xr[vt][0][2], xr[vt][0][3], xr[vt][1][0], xr[vt][1][1], xr[vt][1][2], xr[vt][1][3], xs[vt]);
-                // gram: dA^_k (v x w) += x_f . dagg_kf^T over the half's 32 channels
-                if (wave < nf) {
+                for (int u = 0; u < 2; ++u) {
+                    const int f = (wave >> 1) + 4 * u;
+                    if (f >= nf) continue;                           // wave-uniform
+                    u32x4v xs[NP];
+                    split3_x8(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
                         for (int wt = 0; wt < 2; ++wt) {
-                            const int R = wave * V + 16 * wt + l15;
+                            const int R = f * V + 16 * wt + l15;
                             const unsigned char* src = Im + (k * NP) * SB_PL + R * SB_XS + ((unsigned)(16 * g4) ^ swz(R));
                             u32x4v bf[NP];
 #pragma unroll
                             for (int pl = 0; pl < NP; ++pl) bf[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
-#pragma unroll
-                            for (int vt = 0; vt < 2; ++vt) gacc[k][vt][wt] = mfma_x3_k32(xs[vt], bf, gacc[k][vt][wt]);
+                            if constexpr ((FGCN_PROBE_SB & 1) != 0) gacc[k][wt][0] += __builtin_bit_cast(float, xs[0][0] ^ bf[0][0]);
+                            else gacc[k][wt] = mfma_x3_k32(xs, bf, gacc[k][wt]);
                         }
                 }
                 // mix: dx^T (16 channels x 32 joints v) += sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
@@ -299,14 +311,17 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                             df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
                         }
 #pragma unroll
-                        for (int vt = 0; vt < 2; ++vt) dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
+                        for (int vt = 0; vt < 2; ++vt) {
+                            if constexpr ((FGCN_PROBE_SB & 2) != 0) dxa[s][vt][0] += __builtin_bit_cast(float, df[0][0] ^ af[vt][0][0]);
+                            else dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
+                        }
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < MAXS; ++s)
 #pragma unroll
                     for (int vt = 0; vt < 2; ++vt)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, dx_off(s, vt), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, (FGCN_PROBE_SB & 64) ? OOB : dx_off(s, vt), 0, 0);
                 __syncthreads();                                     // the image is free for the next half / the next group
             }
         }
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
             for (int wt = 0; wt < 2; ++wt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    red[(wave * 3 + k) * 1024 + (16 * vt + 4 * g4 + r) * 32 + 16 * wt + l15] = gacc[k][vt][wt][r];
+                    red[(wave * 3 + k) * 1024 + (16 * vt + 4 * g4 + r) * 32 + 16 * wt + l15] = vt == (wave & 1) ? gacc[k][wt][r] : 0.f;
     __syncthreads();
     float* dst = p.partial + ((long long)n * p.nseg + seg) * 3 * 1024;
     for (int e = tid; e < 3 * 1024; e += 512) {
@@ -385,7 +400,7 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     {
         int load[8], cnt[8];
         for (int w = 0; w < 8; ++w) {
-            load[w] = w < p.F ? 2 : 0;
+            load[w] = (w >> 1) < p.F ? ((w >> 1) + 4 < p.F ? 2 : 1) : 0;
             cnt[w] = 0;
         }
         for (int u = 0; u < 16; ++u) p.mix_wave[u] = -1;
@@ -417,7 +432,10 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
         for (int u = 0; u < 2 * p.F; ++u) c += p.mix_wave[u] == w ? 1 : 0;
         max_units = std::max(max_units, c);
     }
-    if (max_units <= 3) {
+    if (max_units <= 2) {
+        if (accumulate) FGCN_SB_GO(true, 2);
+        else FGCN_SB_GO(false, 2);
+    } else if (max_units <= 3) {
         if (accumulate) FGCN_SB_GO(true, 3);
         else FGCN_SB_GO(false, 3);
     } else {
