@@ -153,16 +153,18 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 stg[2];
-            auto fetch = [&](int kc) {
+            // the dY rows of a step are requested TWO steps ahead (two register sets: one step of MFMAs, ~1.2 us, is less than an HBM round
+            // trip under load -- the FGCN_PROBE_SB bit 4 probe put the exposed wait at 0.18 of 0.90 ms)
+            f32x4 stg2[2][2];
+            auto fetch = [&](f32x4 (&stg)[2], int kc) {              // kc >= Cout: nothing (branch-free)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
-                    const unsigned off = r < nrows ? ((row0 + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
+                    const unsigned off = (r < nrows && kc < p.Cout) ? ((row0 + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
                     stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
                 }
             };
-            auto deposit = [&]() {
+            auto deposit = [&](const f32x4 (&stg)[2]) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
             auto step = [&](int ks, auto pb_tag) {
                 constexpr int PB = decltype(pb_tag)::value;
                 __syncthreads();                                     // the previous step's (or round's) LDS reads are done
-                deposit();
+                deposit(stg2[PB]);
                 __syncthreads();
-                if (ks + 1 < nks && !(FGCN_PROBE_SB & 16)) fetch((ks + 1) * 32);   // lands during the MFMAs below
+                if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB], (ks + 2) * 32);   // lands during this step's and the next one's MFMAs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_a(a[j], j);
 #pragma unroll
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     }
                 }
             };
-            fetch(0);
+            fetch(stg2[0], 0);
+            fetch(stg2[1], 32);
             load_w(wq[0], 0, 0);
             for (int ks = 0; ks < nks; ks += 2) {
                 step(ks, std::integral_constant<int, 0>{});
