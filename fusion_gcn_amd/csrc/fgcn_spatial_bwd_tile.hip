@@ -141,29 +141,49 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     const int srow = tid >> 3, sg = tid & 7;                          // staging: rows srow, srow + 64; 16-byte group sg
     const int nks = p.Cout >> 5;                                     // 32-channel steps of the contraction (even: Cout % 64 == 0)
 
+    // The dY rows of a step are requested TWO steps ahead (two register sets: one step of MFMAs, ~1.2 us, is less than an HBM round trip
+    // under load -- the FGCN_PROBE_SB bit 4 probe put the exposed wait at 0.18 of 0.90 ms), across group and tile boundaries: the first
+    // two steps of the NEXT group are requested before the current group's halves (gram / mix) run.
+    f32x4 stg2[2][2];
+    u32x4v wq[2][NP];
+    auto fetch = [&](f32x4 (&stg)[2], int tile_, int kc) {       // kc >= Cout or no such tile: nothing (branch-free)
+        const int t0_ = tile_ * F;
+        const int nrows_ = (tile_ < tile_hi && kc < p.Cout) ? min(F, p.T - t0_) * V : 0;
+        const unsigned row0_ = (unsigned)((n * p.T + t0_) * V);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = srow + 64 * i;
+            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+        }
+    };
+    // weight fragment of this wave's tile i (16 dagg channels) of group cg at contraction channel kc: lane (l15, g4) holds k = kc + 8 g4 + j
+    // tile m = 3 wm + i of the group's 12: half m / 6, subset (m % 6) / 2, 16-channel tile m % 2 of the half
+    auto load_w = [&](u32x4v (&dst)[NP], int i, int kc, int cg_) {
+        const int m = 3 * wm + i;
+        const int hf = m / 6, mm = m - 6 * hf;
+        const int col = (mm >> 1) * Cin + cg_ * 64 + hf * 32 + (mm & 1) * 16 + l15;
+        const unsigned off = (unsigned)((((kc >> 3) + g4) * N3 + col) * 16);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
+    };
+    fetch(stg2[0], tile_lo, 0);
+    fetch(stg2[1], tile_lo, 32);
+    load_w(wq[0], 0, 0, 0);
+
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int t0 = tile * F;
         const int nf = min(F, p.T - t0);
         const int nrows = nf * V;
         const unsigned row0 = (unsigned)((n * p.T + t0) * V);        // first row of the tile (byte offsets fit 31 bits: checked by the launcher)
         for (int cg = 0; cg < (Cin >> 6); ++cg) {
+            const int cg_n = cg + 1 < (Cin >> 6) ? cg + 1 : 0, tile_n = cg_n ? tile : tile + 1;     // the group after this one
             // ---- 1. dagg^T = Wd^T . dY^T ---------------------------------------------------------------------------------------
             f32x4 acc[3][4];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // the dY rows of a step are requested TWO steps ahead (two register sets: one step of MFMAs, ~1.2 us, is less than an HBM round
-            // trip under load -- the FGCN_PROBE_SB bit 4 probe put the exposed wait at 0.18 of 0.90 ms)
-            f32x4 stg2[2][2];
-            auto fetch = [&](f32x4 (&stg)[2], int kc) {              // kc >= Cout: nothing (branch-free)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int r = srow + 64 * i;
-                    const unsigned off = (r < nrows && kc < p.Cout) ? ((row0 + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
-                    stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
-                }
-            };
             auto deposit = [&](const f32x4 (&stg)[2]) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -176,37 +196,27 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
                 }
             };
-            // weight fragment of this wave's tile i (16 dagg channels) at contraction channel kc: lane (l15, g4) holds k = kc + 8 g4 + j
-            // tile m = 3 wm + i of the group's 12: half m / 6, subset (m % 6) / 2, 16-channel tile m % 2 of the half
-            auto load_w = [&](u32x4v (&dst)[NP], int i, int kc) {
-                const int m = 3 * wm + i;
-                const int hf = m / 6, mm = m - 6 * hf;
-                const int col = (mm >> 1) * Cin + cg * 64 + hf * 32 + (mm & 1) * 16 + l15;
-                const unsigned off = (unsigned)((((kc >> 3) + g4) * N3 + col) * 16);
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
-            };
             auto load_a = [&](u32x4v (&dst)[NP], int j) {
                 const int r = wc * 64 + j * 16 + l15;
                 const unsigned char* src = St + r * SB_XS + ((unsigned)(16 * g4) ^ swz(r));
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
             };
-            u32x4v a[4][NP], wq[2][NP];
+            u32x4v a[4][NP];
             // one 32-channel step; PB: ring slot of its first weight fragment (three fragments per step: the parity flips every step)
             auto step = [&](int ks, auto pb_tag) {
                 constexpr int PB = decltype(pb_tag)::value;
                 __syncthreads();                                     // the previous step's (or round's) LDS reads are done
                 deposit(stg2[PB]);
                 __syncthreads();
-                if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB], (ks + 2) * 32);   // lands during this step's and the next one's MFMAs
+                if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB], tile, (ks + 2) * 32);   // lands during this step's and the next one's MFMAs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_a(a[j], j);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     // the next fragment: a later tile of this step, or the first one of the next step (past the last step: step 0 again, unused)
-                    if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32);
-                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0);   // (a select, not a branch, around the request)
+                    if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32, cg);
+                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0, ks + 1 < nks ? cg : cg_n);   // (selects, not branches)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if constexpr ((FGCN_PROBE_SB & 4) != 0) acc[i][j][0] += __builtin_bit_cast(float, wq[(PB + i) & 1][0][0] ^ a[j][0][0]);
@@ -214,13 +224,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     }
                 }
             };
-            fetch(stg2[0], 0);
-            fetch(stg2[1], 32);
-            load_w(wq[0], 0, 0);
             for (int ks = 0; ks < nks; ks += 2) {
                 step(ks, std::integral_constant<int, 0>{});
                 step(ks + 1, std::integral_constant<int, 1>{});
             }
+            fetch(stg2[0], tile_n, 0);                               // (the last step left the next group's first weight fragment in wq[0])
+            fetch(stg2[1], tile_n, 32);
 
             // ---- 2. the two 32-channel halves of the group ------------------------------------------------------------------------
 #pragma unroll
