@@ -27,7 +27,8 @@
 
 // Timing probes (wrong results; tools/build_probe.py only): bit 0 = no gram MFMAs, bit 1 = no mix MFMAs, bit 2 = no MFMAs in the
 // contraction steps, bit 3 = x rows / old dx values not requested, bit 4 = the dY rows requested for the first step only,
-// bit 5 = no image writes (the compiler then drops the contraction too), bit 6 = no dx stores
+// bit 5 = no image writes (the compiler then drops the contraction too), bit 6 = no dx stores, bit 7 = weight fragments requested
+// once per workgroup
 #ifndef FGCN_PROBE_SB
 #define FGCN_PROBE_SB 0
 #endif
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     // two steps of the NEXT group are requested before the current group's halves (gram / mix) run.
     f32x4 stg2[2][2];
     u32x4v wq[2][NP];
+    bool probe_w_loaded = false;
     auto fetch = [&](f32x4 (&stg)[2], int tile_, int kc) {       // kc >= Cout or no such tile: nothing (branch-free)
         const int t0_ = tile_ * F;
         const int nrows_ = (tile_ < tile_hi && kc < p.Cout) ? min(F, p.T - t0_) * V : 0;
@@ -164,12 +166,17 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
         const int hf = m / 6, mm = m - 6 * hf;
         const int col = (mm >> 1) * Cin + cg_ * 64 + hf * 32 + (mm & 1) * 16 + l15;
         const unsigned off = (unsigned)((((kc >> 3) + g4) * N3 + col) * 16);
+        if ((FGCN_PROBE_SB & 128) && probe_w_loaded) return;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
     };
     fetch(stg2[0], tile_lo, 0);
     fetch(stg2[1], tile_lo, 32);
     load_w(wq[0], 0, 0, 0);
+    if (FGCN_PROBE_SB & 128) {
+        load_w(wq[1], 1, 0, 0);
+        probe_w_loaded = true;
+    }
 
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int t0 = tile * F;
