@@ -615,6 +615,15 @@ def test_spatial_backward_tile_form(V, T, cin, cout, B):
     want_g = torch.einsum("btvc,btwkc->bkvw", x, dagg)
     wt = wd.permute(1, 0, 2).reshape(1, cout, 3 * cin)                         # [o][k cin + c]
     w3 = ops.pack_split3(to_gpu(wt))
+    from fusion_gcn_amd import _lib
+    try:                                        # the other arrangement of the same kernel (two four-wave workgroups per CU, tuning key 11 = 2)
+        _lib.load().fgcn_set_tuning(11, 2)
+        dx4 = to_gpu(base)
+        part4 = ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a), w3, dx4, accumulate=True)
+    finally:
+        _lib.load().fgcn_set_tuning(11, 0)
+    assert rel_l2(dx4.cpu().numpy(), (want_dx + base).numpy()) < FWD_TOL
+    assert rel_l2(part4.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_g.numpy()) < RED_TOL
     parts = []
     for acc in (False, True):
         dx = to_gpu(base)
