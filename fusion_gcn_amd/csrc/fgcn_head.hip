@@ -99,7 +99,9 @@ __device__ __forceinline__ float wsum(float v) {
 }
 
 // ONE workgroup (the row count is the clip batch): wave w takes rows w, w + 4, ...; probs = softmax(logits) is kept for the
-// backward, row_loss[i] = logsumexp - logit[label] (0 for rows whose label is outside [0, classes): torch's ignore_index rows);
+// backward, row_loss[i] = logsumexp - logit[label]; rows labelled -100 (torch's ignore_index) do not count; any OTHER label outside
+// [0, classes) -- torch raises a device assert there -- makes the row's loss, hence the batch loss and every gradient, NaN: a corrupt
+// label fails loudly instead of being dropped from the mean;
 // loss[0] = sum row_loss / n_valid, loss[1] = n_valid -- summed by wave 0 in a fixed order (lane l: rows l, l + 64, ...; then the
 // butterfly): bitwise reproducible.
 __global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* logits, const long long* labels, float* probs,
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* log
         for (int c = lane; c < classes; c += 64) probs[(long long)i * classes + c] = expf(z[c] - mx) * inv;
         if (lane == 0) {
             const long long y = labels[i];
-            row_loss[i] = (y >= 0 && y < classes) ? (mx + logf(s)) - z[y] : 0.f;
+            row_loss[i] = (y >= 0 && y < classes) ? (mx + logf(s)) - z[y] : (y == -100 ? 0.f : NAN);
         }
     }
     __syncthreads();
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* log
         float a = 0.f, cnt = 0.f;
         for (int i = lane; i < rows; i += 64) {
             const long long y = labels[i];
-            const bool ok = y >= 0 && y < classes;
+            const bool ok = y != -100;
             a += ok ? row_loss[i] : 0.f;
             cnt += ok ? 1.f : 0.f;
         }
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void cross_entropy_bwd_kernel(const float* pro
         const long long y = labels[i];
         float d = 0.f;
         if (c < classes && y >= 0 && y < classes) d = (probs[(long long)i * classes + c] - (c == y ? 1.f : 0.f)) * g;
+        else if (c < classes && y != -100) d = NAN;             // a label outside [0, classes) that is not ignore_index
         dlogits[e] = d;
     }
 }

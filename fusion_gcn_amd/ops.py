@@ -67,6 +67,13 @@ class ScaledWeights:
         return self.buf[16:].view(torch.float16).view(2, self.taps, self.kgroups, self.N, 8)
 
 
+def _mode_products() -> None:
+    """The product form of the current math mode (f16x2: two-way f16 splits) -- for entry points that take no weight form of their
+    own to read it from, and after a wrapper that switched the form for one call (the library's product form is process-global)."""
+    if _lib.load().fgcn_get_math_mode() == 2:
+        check(_lib.load().fgcn_set_products(int(_f16x2)), "fgcn_set_products")
+
+
 def _use_products_of(w) -> None:
     """The conv / 1x1 kernels take the product form of the weights they are handed (in math mode bf16x3)."""
     if _lib.load().fgcn_get_math_mode() == 2:
@@ -434,6 +441,7 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
             check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
                                 nsplit, *am, _stream()), "fgcn_pw_wgrad")
+        _mode_products()
         return _reduce_slabs(partial.view(slabs, 1, K, N), 1, K, N, out, accumulate, conv_param)
     nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
     partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
@@ -488,6 +496,7 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
             check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
         check(lib.fgcn_tconv_wgrad(_p(a), _p(g), _p(partial), B, T_g, V, K, N, K, N, T_a, stride, par, th_a,
                                    ntaps, shift0, tap0, stride, taps, nsplit, *am, _stream()), "fgcn_tconv_wgrad")
+    _mode_products()
     return _reduce_slabs(partial, taps, K, N, out, accumulate, conv_param)
 
 
@@ -919,6 +928,7 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
 
 def spatial_fwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
     """Whether ``spatial_fwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, 16 <= V <= 32)."""
+    _mode_products()
     return bool(_lib.load().fgcn_spatial_fwd_tile_available(V, Cin, Cout))
 
 
@@ -934,6 +944,7 @@ def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bia
         raise _lib.FgcnError(f"spatial_fwd_tile: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} w3={tuple(w3.shape)} "
                              "(weights: pack_split3 of the (1, 3 Cin, Cout) matrix)")
     lib = _lib.load()
+    _mode_products()
     y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
     part = torch.empty((lib.fgcn_spatial_fwd_tile_tiles(B, T, V), 2, Cout), device=x.device, dtype=torch.float32) if stats else None
     check(lib.fgcn_spatial_fwd_tile(_p(x), _p(a_hat), w3.data_ptr(), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout,
@@ -944,6 +955,7 @@ def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bia
 def spatial_bwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
     """Whether ``spatial_bwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, Cout % 64 == 0,
     16 <= V <= 32)."""
+    _mode_products()
     return bool(_lib.load().fgcn_spatial_bwd_tile_available(V, Cin, Cout))
 
 
@@ -962,6 +974,7 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
         raise _lib.FgcnError(f"spatial_bwd_tile: shape mismatch dy={tuple(dy.shape)} x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} "
                              f"dx={tuple(dx.shape)} w3={tuple(w3.shape)} (weights: pack_split3 of the (1, Cout, 3 Cin) matrix)")
     lib = _lib.load()
+    _mode_products()
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
     check(lib.fgcn_spatial_bwd_tile(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,

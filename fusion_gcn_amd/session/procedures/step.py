@@ -40,6 +40,7 @@ class Step(abc.ABC):
         ...
 
     _dp_grads: Optional[FlatGradients] = None
+    _dp_key: Optional[tuple] = None
 
     def run_optimizer_step(self, optimizer):
         """``optimizer.step()`` -- after ONE all-reduce (mean) of the flat gradient buffer when a process group with more than one
@@ -48,14 +49,17 @@ class Step(abc.ABC):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             grads = getattr(optimizer, "grads", None)
             if not isinstance(grads, FlatGradients):
-                if self._dp_grads is None:
-                    self._dp_grads = FlatGradients([p for g in optimizer.param_groups for p in g["params"]])
+                params = [p for g in optimizer.param_groups for p in g["params"]]
+                key = (id(optimizer),) + tuple((id(p), p.device) for p in params)
+                if self._dp_grads is None or self._dp_key != key:   # another optimizer / model on this Step object, or moved parameters
+                    # (torch.optim skips parameters without a gradient; so does the exchange: they travel as zeros)
+                    self._dp_grads, self._dp_key = FlatGradients(params, allow_unused=True), key
                 grads = self._dp_grads
             grads.all_reduce_mean()
         return optimizer.step()
 
     def reset(self) -> None:
-        pass
+        self._dp_grads, self._dp_key = None, None
 
     def get_state_dict_objects(self, object_container: dict) -> None:
         """Objects whose state belongs into a checkpoint are added to ``object_container`` (name -> object with state_dict())."""

@@ -549,8 +549,9 @@ int fgcn_data_bn_bwd_apply(const float* dout, const float* x, const float* vec, 
                            int V, int C, int Cp, int train, void* stream);
 /* nn.CrossEntropyLoss() (mean reduction; session/session.py:53, procedures/step.py:38-46) over logits (rows, classes) with row
  * stride ld and int64 labels: probs float[rows][classes] = softmax (kept for the backward), row_loss float[rows], loss float[2] =
- * {mean over the rows whose label is in [0, classes) (torch's ignore_index rows do not count), that row count}; one workgroup,
- * fixed summation order.  bwd: dlogits (rows, ld_out) = (probs - onehot) * dloss[0] / loss[1], columns [classes, ld_out) zero. */
+ * {mean over the rows whose label is not -100 (torch's ignore_index rows do not count), that row count}; any OTHER label outside
+ * [0, classes) -- a device assert in torch -- makes the loss and, in the backward, its row's gradient NaN; one workgroup, fixed
+ * summation order.  bwd: dlogits (rows, ld_out) = (probs - onehot) * dloss[0] / loss[1], columns [classes, ld_out) zero. */
 int fgcn_cross_entropy_fwd(const float* logits, const long long* labels, float* probs, float* row_loss, float* loss, int rows,
                            int classes, int ld, void* stream);
 int fgcn_cross_entropy_bwd(const float* probs, const long long* labels, const float* loss, const float* dloss, float* dlogits,

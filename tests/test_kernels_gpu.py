@@ -908,6 +908,13 @@ def test_cross_entropy_matches_torch(rows, classes):
     assert float(base.grad[:, classes:].abs().max()) == 0.0 if npad > classes else True
     again = loss_fn(base.detach()[:, :classes], y.to(dev()))
     assert torch.equal(again, got.detach())
+    # a label outside [0, classes) that is not ignore_index (torch: a device assert) fails loudly: NaN loss and gradients
+    bad = y.clone()
+    bad[0] = classes + 3
+    z2 = z.float().to(dev()).requires_grad_(True)
+    lb = loss_fn(z2[:, :classes], bad.to(dev()))
+    lb.backward()
+    assert torch.isnan(lb) and torch.isnan(z2.grad[0, :classes]).all()
 
 
 @pytest.mark.parametrize("B,T,V,K,N,kt,stride", [(2, 40, 25, 64, 64, 9, 1), (3, 33, 25, 128, 128, 9, 1), (2, 21, 25, 128, 128, 9, 2),
