@@ -20,6 +20,11 @@
 //        as 16-byte row pieces.
 // Every sum has a fixed order (bitwise reproducible); rows / joints beyond the tile or V are staged as zeros or meet zero columns
 // of the A^ planes.
+// One workgroup per CU runs its waves in lockstep, so every request is made a phase or more ahead: the dY rows of a contraction step two
+// steps before (two register sets; 0.18 of 0.90 ms were exposed waits with one), the next group's first two steps and first weight
+// fragment before the current group's halves, dx's old values before the gram (they are the mix accumulators' start), the x rows ahead of
+// the image barrier.  Measured and not adopted (profiles/r04_kbench_spatial_bwd_tile.log): a second staging buffer with ONE barrier per
+// step (the rows are then requested one step less ahead: 0-6 % slower); the four-wave form below.
 #include <algorithm>
 #include <type_traits>
 
@@ -32,9 +37,6 @@
 #ifndef FGCN_PROBE_SB
 #define FGCN_PROBE_SB 0
 #endif
-#ifndef FGCN_SB_DB
-#define FGCN_SB_DB 0                   // 1: two staging buffers in LDS, ONE barrier per contraction step (the next step's rows are split and
-#endif                                 //    written while this step multiplies); the rows are then requested one step less ahead
 
 namespace fgcn {
 
@@ -58,8 +60,7 @@ constexpr int SB_PL = SB_ROWS * SB_XS;  // one plane
 constexpr int SB_AHB = 80;              // bytes per [v] row of a split A^ plane (32 joints w x bf16 + 16 pad)
 constexpr int SB_IM = 3 * SB_PL;        // staging planes [3] first, then the image [3 subsets][3 parts]
 constexpr int SB_AH = SB_IM + 9 * SB_PL;
-constexpr int SB_ST1 = SB_AH + 9 * 32 * SB_AHB;   // FGCN_SB_DB: the second staging buffer sits behind everything else
-constexpr int SB_LDS = SB_ST1 + (FGCN_SB_DB ? 3 * SB_PL : 0);   // 133632 bytes (161280 with the second buffer)
+constexpr int SB_LDS = SB_AH + 9 * 32 * SB_AHB;   // 133632 bytes
 
 __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
     using v4s = __attribute__((ext_vector_type(4))) short;
@@ -218,19 +219,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
             // one 32-channel step; PB: ring slot of its first weight fragment (three fragments per step: the parity flips every step)
             auto step = [&](int ks, auto pb_tag) {
                 constexpr int PB = decltype(pb_tag)::value;
-#if FGCN_SB_DB
-                deposit(stg2[PB ^ 1], sb_lds + (PB ^ 1) * SB_ST1);    // the next step's rows (past the last step: zeros, unused)
-                if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB ^ 1], tile, (ks + 3) * 32);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) load_a(a[j], j, sb_lds + PB * SB_ST1);
-#else
                 __syncthreads();                                     // the previous step's (or round's) LDS reads are done
                 deposit(stg2[PB], sb_lds);
                 __syncthreads();
                 if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB], tile, (ks + 2) * 32);   // lands during this step's and the next one's MFMAs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_a(a[j], j, sb_lds);
-#endif
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     // the next fragment: a later tile of this step, or the first one of the next step (past the last step: step 0 again, unused)
@@ -242,15 +236,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                         else acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
                     }
                 }
-#if FGCN_SB_DB
-                __syncthreads();                                     // this buffer may be refilled, the other one is complete
-#endif
             };
-#if FGCN_SB_DB
-            deposit(stg2[0], sb_lds);                                // step 0 (requested before the previous group's halves)
-            fetch(stg2[0], tile, 64);
-            __syncthreads();
-#endif
             for (int ks = 0; ks < nks; ks += 2) {
                 step(ks, std::integral_constant<int, 0>{});
                 step(ks + 1, std::integral_constant<int, 1>{});
