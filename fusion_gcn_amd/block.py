@@ -254,7 +254,10 @@ GATED_SHORTCUTS = False
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
-FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 64, "f16x2": 64}
+# Round 4, in-step (same-box A/B of the 64-clip step, bench.py --agg-wgrad-max-cout, profiles/r04_ab_agg_wgrad_max_cout.txt): bf16x3 64 -> 55.75 /
+# 55.80 ms, 128 -> 55.51 / 55.58, 256 -> 56.22 / 56.27 -- inside the step the three-activation-wide agg of the unfused pair is written and read
+# through HBM, which the loop of identical launches of tools/kbench.py (agg resident in the Infinity Cache) does not charge: 128 now.
+FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 128, "f16x2": 64}
 MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
 
 
