@@ -261,6 +261,74 @@ struct GramP {
     } items[FGCN_GRAM_MAX_ITEMS];
 };
 
+// The block's affinity gram (three items = three subsets, theta_k against phi_k, equal widths 8 NQ = ic): item count and width as
+// compile-time constants.  In the generic kernel below both are run-time values in wave-uniform guards around loads and MFMAs inside
+// the frame loop; hipcc branched there and drained vmcnt(0) at the joins (tools/kres.py: 14 full drains) -- the pattern DESIGN.md
+// section 3.8 of Appendix A found in the GEMM epilogues and section 3.9 in joint_dagg.  Here a frame is 6 NQ / 4 x 4 branch-free loads, then its MFMAs,
+// and the NEXT frame's first item is requested before the current frame's last MFMAs.
+template <int NQ>
+__global__ __launch_bounds__(256, 3) void joint_gram3_kernel(GramP p) {
+    __shared__ float red[4 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * p.t_chunk;
+    const int t1 = min(t0 + p.t_chunk, p.T);
+    const int V = p.V;
+    const bool row_ok = l31 < V;
+    const int vv = row_ok ? l31 : 0;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.in1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, p.in2_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    int ic1[3], ic2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ic1[i] = __builtin_amdgcn_readfirstlane(p.items[i].c1);
+        ic2[i] = __builtin_amdgcn_readfirstlane(p.items[i].c2);
+    }
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};
+    // lane (joint l31, half h) holds channels 8 q + 4 h .. + 3 of its row, q = 0 .. NQ - 1
+    auto loadq = [&](const __amdgpu_buffer_rsrc_t& r, int ld, int t, int c, f32x4 (&a)[NQ]) {
+        const unsigned o = (row_ok && t < t1) ? ((unsigned)((n * p.T + t) * V + vv) * (unsigned)ld + c + 4 * h) * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o, 32u * q, 0));
+    };
+    f32x4 ac[NQ], bc[NQ];
+    loadq(r1, p.ld1, t0 + wave, ic1[0], ac);
+    loadq(r2, p.ld2, t0 + wave, ic2[0], bc);
+    for (int t = t0 + wave; t < t1; t += 4) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            f32x4 an[NQ], bn[NQ];                                    // the next item's rows (the next frame's first item after the last)
+            loadq(r1, p.ld1, it < 2 ? t : t + 4, ic1[it < 2 ? it + 1 : 0], an);
+            loadq(r2, p.ld2, it < 2 ? t : t + 4, ic2[it < 2 ? it + 1 : 0], bn);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[it] = mfma32(ac[q][e], bc[q][e], acc[it]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                ac[q] = an[q];
+                bc[q] = bn[q];
+            }
+        }
+    }
+    const int nchunk = gridDim.x;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[it][r];
+        __syncthreads();
+        float* dst = p.partial + (((long long)n * nchunk + chunk) * 3 + it) * 1024;
+        for (int e = tid; e < 1024; e += 256) {
+            const float s = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+            const int r = e >> 6, l = e & 63;
+            dst[acc_row(r, l) * 32 + (l & 31)] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 3) void joint_gram_kernel(GramP p) {
     __shared__ float red[4 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -962,7 +1030,14 @@ extern "C" int fgcn_joint_gram(const float* in1, const float* in2, float* partia
     for (int i = 1; i < n_items; ++i)
         if (items[i].c1 != items[0].c1 || items[i].width != items[0].width) p.share1 = 0;
     dim3 grid((unsigned)cdiv(T, t_chunk), (unsigned)B);
-    hipLaunchKernelGGL(joint_gram_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    // three items of one width 16 / 32 / 64 that do not share their first operand (the affinity gram theta_k^T phi_k): the specialised kernel;
+    // tuning key 12 = 1 keeps the generic one (A/B)
+    const int w0 = items[0].width;
+    const bool three = n_items == 3 && !p.share1 && items[1].width == w0 && items[2].width == w0 && fgcn::tuning(12) != 1;
+    if (three && w0 == 16) hipLaunchKernelGGL(joint_gram3_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (three && w0 == 32) hipLaunchKernelGGL(joint_gram3_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (three && w0 == 64) hipLaunchKernelGGL(joint_gram3_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(joint_gram_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return launch_status("joint_gram");
 }
 
