@@ -23,6 +23,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
     double a = 0.0, b = 0.0;
     if (c < C) {
         int i = g;
+        for (; i + 896 < P; i += 1024) {                 // eight row groups (sixteen loads) in flight: the walk is latency-bound
+            float x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x0[u] = partials[((long long)(i + 128 * u) * 2 + 0) * C + c];
+                x1[u] = partials[((long long)(i + 128 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += (double)x0[u];
+                b += (double)x1[u];
+            }
+        }
         for (; i + 384 < P; i += 512) {
             float x0[4], x1[4];
 #pragma unroll

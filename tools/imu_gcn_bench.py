@@ -88,11 +88,39 @@ def late(args):
     x = {k: torch.randn(args.batch, *v, device=dev) for k, v in shapes.items()}
     y = torch.randint(0, classes, (args.batch,), device=dev)
     out = {"mode": "skeleton_imu_gcn_late_fusion", "imu_nodes": args.frames * 2, "batch": args.batch}
+    # algorithmic FLOPs of fwd + bwd (= 3 x forward), counted from the module tree: every AGCN block of the skeleton branch by SURVEY.md
+    # section 8d's formula (M = 1, T = 128, V = 20), every AGCNGraphConvolution of the IMU branch (graph_convolution.py:56-113: theta | phi
+    # embeddings, V x V scores and aggregation per subset, conv_d, down) -- the classifier and the poolings are < 0.1 %
+    from fusion_gcn_amd.models.mmargcn.agcn import SpatialTemporalConv
+    from fusion_gcn_amd.models.mmargcn.graph_convolution import AGCNGraphConvolution
+    B = args.batch
+    flops = 0.0
+    T, V = shapes["skeleton"][1], shapes["skeleton"][2]
+    for m in model.modules():
+        if isinstance(m, SpatialTemporalConv):
+            c = m.cfg
+            ic, Tp = c.cout // 4, (T - 1) // c.stride + 1
+            f = B * T * V * (12 * c.cin * ic + 6 * V * c.cin + 6 * c.cin * c.cout + (2 * c.cin * c.cout if c.has_down else 0))
+            f += 6 * V * V * ic * T * B + B * Tp * V * (18 * c.cout * c.cout + (2 * c.cin * c.cout if c.residual == "conv" else 0))
+            flops += 3 * f
+            T = Tp
+        elif isinstance(m, AGCNGraphConvolution):
+            n, f_in, f_out, ic, K = args.frames * 2, m.in_features, m.out_features, m.inter_c, m.num_subset
+            f = B * K * (4.0 * n * f_in * ic + 2.0 * n * n * ic + 2.0 * n * n * f_in + 2.0 * n * f_in * f_out)
+            f += 2.0 * B * n * f_in * f_out if m.has_down else 0.0
+            flops += 3 * f
+    out["algorithmic_gflop_per_step"] = round(flops / 1e9, 1)
+    peaks = {"f32": 157.3, "bf16x3": 2500.0 / 6}
     from steptime import time_step
     for mode in ("f32", "bf16x3"):
         with ops.math_mode(mode):
             t = time_step(model, x, y, args.steps, graph=args.graph)
-        out[mode] = {"ms_per_step": t["eager"]["ms_per_step"], "samples_per_s": t["eager"]["per_s"], "loss": t["eager"]["loss"]}
+        best = min(t["eager"]["ms_per_step"], t["graph"]["ms_per_step"]) if args.graph else t["eager"]["ms_per_step"]
+        out[mode] = {"ms_per_step": t["eager"]["ms_per_step"], "samples_per_s": t["eager"]["per_s"], "loss": t["eager"]["loss"],
+                     # the whole step against the matrix roof of its arithmetic; in bf16x3 the per-sample V x V products of the IMU branch
+                     # still run on exact-f32 row GEMMs (fgcn_rows_gemm_batched), so the bf16x3 roof overstates what this step can reach
+                     "roofline": {"bound": "mfma", "achieved": round(flops / best / 1e9, 1), "peak": round(peaks[mode], 1),
+                                  "unit": "TFLOP/s", "frac": round(flops / best / 1e9 / peaks[mode], 3), "what": "whole fwd+bwd step"}}
         if args.graph:
             out[mode]["graph"] = t["graph"]
     print(json.dumps(out))
