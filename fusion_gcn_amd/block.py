@@ -15,8 +15,10 @@ Kernel schedule of one block, train mode (B = N*M samples):
             [rows_gemm(residual 1x1 stride s) -> bn_finalize] -> bn_act (BN + residual + ReLU = O)
   backward  bn_act_bwd (O)  -> tconv_halo(data gradient 9x1; two parity passes when strided) / tconv_wgrad(all taps)
             -> bn_act_bwd (G)
-            rows_gemm(dY.Wd) -> joint_mix_vec(agg recompute) -> rows_wgrad / pw_wgrad(conv_d) -> joint_mix_vec(dx)
-            -> joint_gram(dA^) -> adj_softmax_bwd -> joint_mix_vec(dtheta, dphi) -> rows_gemm(dx) / rows_wgrad(theta|phi)
+            spatial_wgrad (conv_d, aggregation recomputed on chip; beyond 128 outputs: joint_mix_vec(agg) -> pw_wgrad)
+            -> spatial_bwd_tile [bf16x3, >= 64 inputs: dagg = dY.Wd on chip, dx and dA^ in one launch]
+               (else: pw_gemm / rows_gemm(dY.Wd) -> joint_dagg(dx, dA^))
+            -> adj_softmax_bwd -> joint_mix_vec(dtheta, dphi) -> pw_gemm / rows_gemm(dx) / rows_wgrad(theta|phi)
             + down / residual conv dgrad & wgrad, bias gradients by col_sum; every weight gradient is reduced from its
             slabs straight into the parameter's (out, in, taps, 1) layout (reduce_sum_strided).
 """

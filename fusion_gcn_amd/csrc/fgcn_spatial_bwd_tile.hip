@@ -14,7 +14,8 @@
 //      streamed from L2.  The product is formed TRANSPOSED (weights = A operand): an accumulator lane then holds four consecutive
 //      channels of one row, i.e. 8-byte pieces of a row-major image.
 //   2. per 32-channel half: the owners split their accumulators and write the all-subset image [k][row][32 ch] (three bf16 planes);
-//      * gram: wave f < frames takes frame f: dA^_k (v x w) += x_f (registers, split once) . dagg_kf^T (image rows, ds_read_b128);
+//      * gram units (frame f, 16-joint tile vt of v) -> wave 2 (f mod 4) + vt: dA^_k (v tile x w) += x_f (registers, requested ahead of
+//        the image barrier, split once) . dagg_kf^T (image rows, ds_read_b128); 24 accumulator registers per wave, summed over its frames;
 //      * mix:  (frame, 16-channel tile) units dealt to the waves by a host-made table: dx^T (c x v) = sum_k dagg_kf^T (transposing
 //        LDS reads, ds_read_b64_tr_b16: the contraction runs along image rows) . A^_k^T (split planes in LDS), stored (or added) to dx
 //        as 16-byte row pieces.
@@ -699,8 +700,8 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     p.tps = (int)cdiv(p.tiles_t, p.nseg);
     FGCN_REQUIRE((long long)B * p.nseg < (1ll << 30), FGCN_E_BADARG, "spatial_bwd_tile: too many workgroups");
     p.dy_bytes = (unsigned)dy_bytes; p.x_bytes = (unsigned)x_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
-    // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave f < F already carries frame f's gram (24 MFMA groups per
-    // half, a mix unit is 12); greedy on the lightest wave, the later wave on ties (waves >= F carry no gram)
+    // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave 2 (f mod 4) + vt already carries the gram units (f, vt) -- one or
+    // two per half, 12 MFMA groups each like a mix unit; greedy on the lightest wave, the later wave on ties
     {
         int load[8], cnt[8];
         for (int w = 0; w < 8; ++w) {
