@@ -126,7 +126,7 @@ SIGNATURES = {
     "fgcn_spatial_fwd_tile": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_spatial_fwd_tile_tiles": (_I, [_I, _I, _I]),
     "fgcn_spatial_fwd_tile_available": (_I, [_I, _I, _I]),
-    "fgcn_spatial_bwd_tile": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_spatial_bwd_tile": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fgcn_spatial_bwd_tile_segments": (_I, [_I, _I, _I]),
     "fgcn_spatial_bwd_tile_available": (_I, [_I, _I, _I]),
     "fgcn_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

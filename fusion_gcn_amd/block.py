@@ -253,6 +253,11 @@ BN_SUMS_MAX_C = int(os.environ.get("FGCN_BN_SUMS_MAX_C", "4096"))
 # block_backward).  Measured neutral on MI355X (tools/probes/gated_dagg_probe.py, B = 128: the two apply kernels save 0.16 ms per
 # block, the two extra tensor reads cost joint_dagg 0.15 ms; slower at 8 clips), so off; the kernel form stays tested.
 GATED_SHORTCUTS = False
+# ... the same in the fused spatial backward (fgcn_spatial_bwd_tile: the gated addends are requested ahead of the image barrier and are the
+# mix accumulators' start, so the two BatchNorm-backward apply kernels neither write nor read-modify-write dx and the fused kernel has no
+# old values to fetch): same-box step A/B 55.31 / 55.37 -> 55.20 / 55.20 ms at 64 clips, 9.45 / 9.44 -> 9.46 / 9.43 at 8
+# (profiles/r04_ab_gated_tile.txt); on.  FGCN_GATED_TILE=0: the BatchNorm-backward kernels carry the shortcut gradients.
+GATED_SHORTCUTS_TILE = bool(int(os.environ.get("FGCN_GATED_TILE", "1")))
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
@@ -579,7 +584,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
-    gate_in_dagg = (GATED_SHORTCUTS and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
+    tile_ok = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and "d_t_s3" in W and ops.spatial_bwd_tile_available(V, cin, cout))
+    gate_in_dagg = ((GATED_SHORTCUTS_TILE if tile_ok else GATED_SHORTCUTS) and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and d_o.numel() * 4 < 0x7FFF0000)
     gated: List[tuple] = []
@@ -653,8 +659,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
     a_hat = S["a_hat"]
     c3 = 3 * cin
-    bwd_tile = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and not gated and x.shape[3] == cin and "d_t_s3" in W
-                and ops.spatial_bwd_tile_available(V, cin, cout))
+    bwd_tile = tile_ok and x.shape[3] == cin and (not gated or len(gated) == 2)
     dagg, dy_amax = None, False
     if not bwd_tile:
         # dagg = dy . Wd first: in math mode f16x2 the row GEMM records max |dy| (slot 3), the operand scale of conv_d's weight gradient
@@ -678,7 +683,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
     if bwd_tile:
-        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_s3"], dx, accumulate=dx_live)   # dagg on chip: dx and dA^ in one launch
+        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_s3"], dx, accumulate=dx_live, gated=gated)   # dagg on chip: dx and dA^ in one launch
     elif FUSED_DAGG and x.shape[3] == cin:
         part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:

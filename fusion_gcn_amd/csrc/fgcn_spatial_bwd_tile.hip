@@ -51,6 +51,12 @@ struct SpBwdP {
     int B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, a_batched;
     int F, tiles_t, tps, nseg;          // frames per tile, tiles per sample, tiles per segment, segments per sample
     unsigned dy_bytes, x_bytes, dx_bytes, w_plane_bytes;
+    // two gated addends of dx (eight-wave form, not accumulating): dx = mix + e[0] * [bit of m[0]] + e[1] * [bit of m[1]] -- contiguous
+    // (B, T, V, Cin) tensors with fgcn_bn_act's sign images: the ReLU-gated gradients that reach x through the block's two identity
+    // shortcuts (agcn.py:114,135), which the BatchNorm-backward kernels then neither write nor read-modify-write into dx
+    const float* e[2];
+    const unsigned char* m[2];
+    unsigned e_bytes;
     int mix_wave[16];                   // mix unit u = 2 f + (16-channel tile of the 32-channel half) -> wave (eight-wave form)
     int mix_wave4[16];                  // ... four-wave form
 };
@@ -70,8 +76,10 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
 }
 
 // MAXS: mix units per wave and half (the host's table: two for four to six frames per tile, up to four for seven / eight)
-template <bool ACC, int MAXS>
+// NE: gated addends of dx (0 or 2; 2 only without accumulation)
+template <bool ACC, int MAXS, int NE = 0>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
+    static_assert(NE == 0 || (NE == 2 && !ACC), "gated addends: both identity shortcuts, dx not live before");
     constexpr int NP = 3;
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -91,6 +99,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rge[2], rgm[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rge[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.e[i] : (const void*)p.dx), 0, NE ? p.e_bytes : 0u, 0x00020000);
+        rgm[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.m[i] : (const void*)p.dx), 0, NE ? p.e_bytes >> 5 : 0u, 0x00020000);
+    }
 
     // A^_k of this sample, split once per workgroup: planes [subset][part][v][w] bf16 (one ds_read_b128 = 8 joints w of row v)
     const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
@@ -261,6 +275,25 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
                     xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
                 }
+                // gated addends of this wave's mix units (element index of the lane's four channels; the sign image holds one bit per element:
+                // a nibble per lane), requested here as well
+                f32x4 ge[NE ? MAXS : 1][2][2];
+                unsigned gm[NE ? MAXS : 1][2][2];
+                if constexpr (NE == 2) {
+#pragma unroll
+                    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+                        for (int vt = 0; vt < 2; ++vt) {
+                            const int v = 16 * vt + l15;
+                            const unsigned el = (row0 + sf[s] * V + v) * (unsigned)Cin + cbase + sct[s] * 16 + 4 * g4;
+                            const bool ok = sok[s] && sf[s] < nf && v < V;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                ge[s][vt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[i], ok ? el * 4u : OOB, 0, 0));
+                                gm[s][vt][i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rgm[i], ok ? el >> 3 : OOB, 0, 0) >> (el & 4u);
+                            }
+                        }
+                }
                 // the owners of this half's tiles write the image: row R = 64 wc + 16 j + l15, channels 16 (mm & 1) + 4 g4 .. + 3 of subset mm >> 1
                 if ((wm >> 1) == hf && !(FGCN_PROBE_SB & 32)) {
 #pragma unroll
@@ -311,6 +344,15 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                             if constexpr ((FGCN_PROBE_SB & 1) != 0) gacc[k][wt][0] += __builtin_bit_cast(float, xs[0][0] ^ bf[0][0]);
                             else gacc[k][wt] = mfma_x3_k32(xs, bf, gacc[k][wt]);
                         }
+                }
+                if constexpr (NE == 2) {                             // the gated addends are the mix accumulators' start
+#pragma unroll
+                    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+                        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                dxa[s][vt][e] = (((gm[s][vt][0] >> e) & 1u) ? ge[s][vt][0][e] : 0.f) + (((gm[s][vt][1] >> e) & 1u) ? ge[s][vt][1][e] : 0.f);
                 }
                 // mix: dx^T (16 channels x 32 joints v) += sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
 #pragma unroll
@@ -677,7 +719,12 @@ extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
 
 extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                      int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
-                                     int accumulate, void* stream) {
+                                     int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
+                                     const unsigned char* mask2, void* stream) {
+    const bool gated = extra1 != nullptr;
+    FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0 && fgcn::tuning(11) != 2), FGCN_E_BADARG,
+                 "spatial_bwd_tile: gated addends come in pairs with their sign images, without accumulation, on contiguous (B, T, V, Cin) tensors");
+    FGCN_REQUIRE(!gated || (aligned16(extra1) && aligned16(extra2)), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte aligned addends");
     FGCN_REQUIRE(dy && x && a_hat && w3 && dx && partial, FGCN_E_BADARG, "spatial_bwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "spatial_bwd_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_spatial_bwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
@@ -700,6 +747,7 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     p.tps = (int)cdiv(p.tiles_t, p.nseg);
     FGCN_REQUIRE((long long)B * p.nseg < (1ll << 30), FGCN_E_BADARG, "spatial_bwd_tile: too many workgroups");
     p.dy_bytes = (unsigned)dy_bytes; p.x_bytes = (unsigned)x_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
+    p.e[0] = extra1; p.e[1] = extra2; p.m[0] = mask1; p.m[1] = mask2; p.e_bytes = (unsigned)(rows * Cin * 4);
     // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave 2 (f mod 4) + vt already carries the gram units (f, vt) -- one or
     // two per half, 12 MFMA groups each like a mix unit; greedy on the lightest wave, the later wave on ties
     {
@@ -764,15 +812,20 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
 #undef FGCN_SB4_GO
         return launch_status("spatial_bwd_tile");
     }
-#define FGCN_SB_GO(ACC_, MS_)                                                                                          \
+#define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
     do {                                                                                                                \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_LDS);                         \
             opted = true;                                                                                               \
         }                                                                                                               \
-        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_>), grid, dim3(512), SB_LDS, s, p);                     \
+        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_>), grid, dim3(512), SB_LDS, s, p);                \
+    } while (0)
+#define FGCN_SB_GO(ACC_, MS_)                                                                                          \
+    do {                                                                                                                \
+        if (gated) FGCN_SB_GO3(false, MS_, 2);                                                                          \
+        else FGCN_SB_GO3(ACC_, MS_, 0);                                                                                 \
     } while (0)
     int max_units = 0;
     for (int w = 0; w < 8; ++w) {
@@ -791,5 +844,6 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
         else FGCN_SB_GO(false, 4);
     }
 #undef FGCN_SB_GO
+#undef FGCN_SB_GO3
     return launch_status("spatial_bwd_tile");
 }

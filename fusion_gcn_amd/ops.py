@@ -960,11 +960,19 @@ def spatial_bwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
 
 
 def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, dx: torch.Tensor, *,
-                     accumulate: bool) -> torch.Tensor:
+                     accumulate: bool, gated: Sequence[Tuple[torch.Tensor, torch.Tensor]] = ()) -> torch.Tensor:
     """The fused backward of the spatial stage (fgcn_spatial_bwd_tile.hip): dagg = dy . Wd stays on chip,
     dx (+)= sum_k dagg_k . A^_k^T, and the partial grams dA^_k = x^T dagg_k come back as (B, nseg, 3, 32, 32) -- joint_dagg's output
-    format.  w3 = ``pack_split3`` of the (1, Cout, 3 Cin) matrix [o][k Cin + c] = Wd_k[o][c]."""
+    format.  w3 = ``pack_split3`` of the (1, Cout, 3 Cin) matrix [o][k Cin + c] = Wd_k[o][c].  ``gated``: none or exactly two
+    (tensor, sign image) pairs added to dx where the image's bit is set (as in ``joint_dagg``; not with ``accumulate``)."""
     ensure_device()
+    if len(gated) not in (0, 2) or (gated and accumulate):
+        raise _lib.FgcnError("spatial_bwd_tile: gated addends come as the pair of identity shortcuts, without accumulation")
+    for e, m in gated:
+        _chk(e, "spatial_bwd_tile.gated")
+        if tuple(e.shape) != tuple(x.shape) or m.dtype != torch.uint8 or m.numel() * 8 != e.numel() or not m.is_cuda:
+            raise _lib.FgcnError(f"spatial_bwd_tile: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
+    ex = [(_p(e), m.data_ptr()) for e, m in gated] + [(None, None)] * (2 - len(gated))
     _chk(dy, "spatial_bwd_tile.dy"), _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
     B, T, V, Cin = x.shape
     Cout = dy.shape[3]
@@ -978,7 +986,8 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
     check(lib.fgcn_spatial_bwd_tile(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
-                                    dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), _stream()), "fgcn_spatial_bwd_tile")
+                                    dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], ex[0][1], ex[1][0], ex[1][1], _stream()),
+          "fgcn_spatial_bwd_tile")
     return partial
 
 

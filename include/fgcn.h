@@ -458,9 +458,13 @@ int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout);
  *   w3: fgcn_pack_split3 form (acc_order 0) of the Cout x (3 Cin) matrix [o][k * Cin + c] = Wd_k[o][c] (one tap, K = Cout);
  *   partial: float[B][fgcn_spatial_bwd_tile_segments(B, T, V)][3][32][32] (rows v, columns w; entries beyond V are zero) -- the layout
  *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin %% 64 == 0, Cout %% 64 == 0; 16 <= V <= 32; math mode bf16x3 with bf16x3 products
- *   (fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order. */
+ *   (fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order.
+ *   extra1 / mask1, extra2 / mask2 (all four or none; not with accumulate; ld_x == Cin): dx = ... + extra_i * [bit of mask_i] -- contiguous
+ *   (B, T, V, Cin) tensors with fgcn_bn_act's one-bit sign images: the ReLU-gated gradients of the block's two identity shortcuts
+ *   (agcn.py:114,135), as in fgcn_joint_dagg. */
 int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial, int B,
                           int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                          const float* extra1, const unsigned char* mask1, const float* extra2, const unsigned char* mask2,
                           void* stream);
 int fgcn_spatial_bwd_tile_segments(int B, int T, int V);
 int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout);

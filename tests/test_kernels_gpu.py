@@ -647,6 +647,19 @@ def test_spatial_backward_tile_form(V, T, cin, cout, B):
     dx = to_gpu(base)
     ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a[:1]), w3, dx, accumulate=False)     # static (shared) adjacency
     assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", dagg, a[0]).numpy()) < FWD_TOL
+    # the ReLU-gated gradients of the block's two identity shortcuts (agcn.py:114,135) as the mix accumulators' start: dx = mix +
+    # sum_i e_i * [bit of mask_i], the sign images from the real bn_act kernel
+    ident = torch.stack([torch.zeros(cin), torch.ones(cin), torch.ones(cin), torch.zeros(cin)]).float().to(dev())
+    want_gated, gated = want_dx.clone(), []
+    for i in range(2):
+        e, pre = rnd(B, T, V, cin, seed=320 + i), rnd(B, T, V, cin, seed=330 + i)
+        _, mask = ops.bn_act(to_gpu(pre), ident, relu=True, sign_mask=True)
+        want_gated = want_gated + e * (pre.float() > 0)
+        gated.append((to_gpu(e), mask))
+    dx = torch.full_like(to_gpu(base), float("nan"))                                         # every element is written
+    part_g = ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a), w3, dx, accumulate=False, gated=gated)
+    assert rel_l2(dx.cpu().numpy(), want_gated.numpy()) < FWD_TOL
+    assert torch.equal(part_g, parts[0][1])
 
 
 @pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
