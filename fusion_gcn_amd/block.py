@@ -168,6 +168,10 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
             if key in F and F[key].K % 32 == 0:
                 F[key + "_s3"] = Form(split_form, 1, F[key].K, F[key].N, F[key].segs)
+    # the fused spatial backward (ops.spatial_bwd_tile) multiplies three-way bf16 splits in every float32-class mode: with the f16x2
+    # products the block keeps that form of d_t beside the two-way f16 one
+    if mode in ("bf16x3", "f16x2") and cx % 64 == 0 and cout % 64 == 0:
+        F["d_t_b3"] = Form("split3", 1, cout, 3 * cx, d_cols)      # (a form of its own: forms are materialised per key)
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
@@ -245,6 +249,9 @@ SPATIAL_TILE_MIN_COUT = int(os.environ.get("FGCN_SPATIAL_TILE_MIN_COUT", "128"))
 # pw_gemm(dy . Wd) + joint_dagg and their three-activation-wide round trip through HBM; FGCN_SPATIAL_BWD_TILE=0: the unfused pair
 SPATIAL_BWD_TILE = os.environ.get("FGCN_SPATIAL_BWD_TILE", "1") != "0"
 SPATIAL_BWD_TILE_MIN_CIN = int(os.environ.get("FGCN_SPATIAL_BWD_TILE_MIN_CIN", "64"))
+# ... also with the f16x2 products (the kernel itself always multiplies three-way bf16 splits: at least as accurate); FGCN_SPATIAL_BWD_TILE_F16X2=0:
+# there, dagg = dy . Wd by pw_gemm on two-way f16 splits + joint_dagg
+SPATIAL_BWD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_BWD_TILE_F16X2", "1") != "0"
 FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
 BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
 # ... up to this many channels (FGCN_BN_SUMS_MAX_C; see the measurement at its use in block_backward)
@@ -584,7 +591,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
-    tile_ok = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and "d_t_s3" in W and ops.spatial_bwd_tile_available(V, cin, cout))
+    tile_ok = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and "d_t_b3" in W and ops.spatial_bwd_tile_available(V, cin, cout)
+               and (ops.get_math_mode() == "bf16x3" or SPATIAL_BWD_TILE_F16X2))
     gate_in_dagg = ((GATED_SHORTCUTS_TILE if tile_ok else GATED_SHORTCUTS) and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and d_o.numel() * 4 < 0x7FFF0000)
@@ -683,7 +691,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
     if bwd_tile:
-        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_s3"], dx, accumulate=dx_live, gated=gated)   # dagg on chip: dx and dA^ in one launch
+        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_b3"], dx, accumulate=dx_live, gated=gated)   # dagg on chip: dx and dA^ in one launch
     elif FUSED_DAGG and x.shape[3] == cin:
         part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:

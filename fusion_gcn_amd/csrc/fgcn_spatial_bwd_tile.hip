@@ -701,11 +701,11 @@ __global__ __launch_bounds__(256, 2) void spatial_bwd_tile4_x3_kernel(SpBwdP p) 
 
 using namespace fgcn;
 
-// 1 when fgcn_spatial_bwd_tile runs these sizes in the current math mode (bf16x3 products; whole 64-channel input groups, 64-channel
-// steps of the contraction; 16..32 joints: at most 8 frames per 128-row tile, one per wave)
+// 1 when fgcn_spatial_bwd_tile runs these sizes in the current math mode (FGCN_MATH_BF16X3 with either product form: the kernel always
+// multiplies three-way bf16 splits and takes the fgcn_pack_split3 form of the weights; whole 64-channel input groups, 64-channel steps of the
+// contraction; 16..32 joints: at most 8 frames per 128-row tile)
 extern "C" int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout) {
-    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && !fgcn::f16x2_products() && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 &&
-            Cout % 64 == 0 && Cout > 0) ? 1 : 0;
+    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 && Cout % 64 == 0 && Cout > 0) ? 1 : 0;
 }
 
 // segments per sample = partial matrices per sample: enough workgroups to fill 256 CUs a few times over
@@ -728,7 +728,7 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     FGCN_REQUIRE(dy && x && a_hat && w3 && dx && partial, FGCN_E_BADARG, "spatial_bwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "spatial_bwd_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_spatial_bwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
-                 "spatial_bwd_tile: needs math mode bf16x3 (bf16x3 products), 16 <= V <= %d, Cin %% 64 == 0, Cout %% 64 == 0 (V=%d Cin=%d Cout=%d)",
+                 "spatial_bwd_tile: needs math mode bf16x3, 16 <= V <= %d, Cin %% 64 == 0, Cout %% 64 == 0 (V=%d Cin=%d Cout=%d)",
                  FGCN_MAX_V, V, Cin, Cout);
     FGCN_REQUIRE(ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && ld_dy >= Cout && ld_x >= Cin && ld_dx >= Cin, FGCN_E_ALIGN,
                  "spatial_bwd_tile: row strides");

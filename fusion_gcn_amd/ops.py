@@ -953,9 +953,8 @@ def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bia
 
 
 def spatial_bwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
-    """Whether ``spatial_bwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, Cout % 64 == 0,
-    16 <= V <= 32)."""
-    _mode_products()
+    """Whether ``spatial_bwd_tile`` runs these sizes in the current math mode (bf16x3 or f16x2: the kernel multiplies three-way bf16
+    splits in both; Cin % 64 == 0, Cout % 64 == 0, 16 <= V <= 32)."""
     return bool(_lib.load().fgcn_spatial_bwd_tile_available(V, Cin, Cout))
 
 

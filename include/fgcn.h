@@ -457,8 +457,8 @@ int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout);
  *   dy (B,T,V,>=Cout), x (B,T,V,>=Cin), a_hat (B or 1, 3, V, V), dx (B,T,V,>=Cin);
  *   w3: fgcn_pack_split3 form (acc_order 0) of the Cout x (3 Cin) matrix [o][k * Cin + c] = Wd_k[o][c] (one tap, K = Cout);
  *   partial: float[B][fgcn_spatial_bwd_tile_segments(B, T, V)][3][32][32] (rows v, columns w; entries beyond V are zero) -- the layout
- *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin %% 64 == 0, Cout %% 64 == 0; 16 <= V <= 32; math mode bf16x3 with bf16x3 products
- *   (fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order.
+ *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin %% 64 == 0, Cout %% 64 == 0; 16 <= V <= 32; math mode bf16x3 with either product form (the
+ *   kernel always multiplies three-way bf16 splits: fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order.
  *   extra1 / mask1, extra2 / mask2 (all four or none; not with accumulate; ld_x == Cin): dx = ... + extra_i * [bit of mask_i] -- contiguous
  *   (B, T, V, Cin) tensors with fgcn_bn_act's one-bit sign images: the ReLU-gated gradients of the block's two identity shortcuts
  *   (agcn.py:114,135), as in fgcn_joint_dagg. */

@@ -73,6 +73,8 @@ def _long_way(P, cfg, mode):
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
             if key in R and R[key].shape[1] % 32 == 0:
                 R[key + "_s3"] = ops.pack_split3(R[key])
+    if mode in ("bf16x3", "f16x2") and cx % 64 == 0 and cout % 64 == 0:     # the fused spatial backward's weights: three-way bf16 splits in both modes
+        R["d_t_b3"] = ops.pack_split3(R["d_t"])
     return R
 
 
