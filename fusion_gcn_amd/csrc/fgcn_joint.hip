@@ -1188,7 +1188,11 @@ extern "C" int fgcn_joint_mix_chunks(int B, int T) { return (int)cdiv(T, pick_t_
 
 extern "C" int fgcn_spatial_wgrad_chunks(int B, int T, int Cin, int Cout) {
     const long long tiles = cdiv(Cin, 32) * cdiv(Cout, 64);
-    long long nchunk = cdiv(1024, tiles * B);          // about a thousand workgroups, at least 4 frames (one per wave) each
+    // about a thousand workgroups, at least 4 frames (one per wave) each; half as many for small batches, where a workgroup's fixed work (the
+    // split A^ planes, six cross-wave sums) outweighs its frames (same-box A/B of the 8-clip step, tuning key 13: 512 -> 9.31 / 9.33 ms,
+    // 1024 -> 9.40 / 9.40, 2048 -> 9.52 / 9.53, 256 -> +0.12; at 64 clips 512 and 2048 read the same)
+    const int target = fgcn::tuning(13) > 0 ? fgcn::tuning(13) : (B <= 32 ? 512 : 1024);
+    long long nchunk = cdiv(target, tiles * B);
     if (nchunk < 1) nchunk = 1;
     if (nchunk > cdiv(T, 4)) nchunk = cdiv(T, 4);
     return (int)cdiv(T, cdiv(T, nchunk));
