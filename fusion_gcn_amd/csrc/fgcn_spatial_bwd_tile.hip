@@ -708,11 +708,14 @@ extern "C" int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout) {
     return (fgcn::math_mode() == FGCN_MATH_BF16X3 && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 && Cout % 64 == 0 && Cout > 0) ? 1 : 0;
 }
 
-// segments per sample = partial matrices per sample: enough workgroups to fill 256 CUs a few times over
+// segments per sample = partial matrices per sample: one workgroup per CU (256 in all) when the batch allows it -- every workgroup pays the
+// split of the adjacency and the cross-wave sum of its partial matrices once, and a single round of workgroups measured fastest at every
+// batch size (8 clips 9.41 -> 9.18 ms a step, 16: 16.23 -> 16.03, 32: 29.41 -> 29.21, 64 within noise; profiles/r04_ab_spatial_bwd_segments.txt);
+// tuning key 15 overrides the target
 extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
     if (V < 16 || V > FGCN_MAX_V || B <= 0 || T <= 0) return 0;
     const int tiles_t = (int)cdiv(T, 128 / V);
-    const int want = (int)std::max<long long>(1, cdiv(1024, B));
+    const int want = (int)std::max<long long>(1, cdiv(fgcn::tuning(15) > 0 ? fgcn::tuning(15) : 256, B));
     const int tps = (int)cdiv(tiles_t, std::min(tiles_t, want));
     return (int)cdiv(tiles_t, tps);
 }

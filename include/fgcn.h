@@ -56,7 +56,11 @@ int fgcn_check_device(void);
  *      4: the same for N <= 64 only; 8: split-bf16 halo conv at <= 64 output columns as 2 x 2 waves over 128-row tiles (default: 4 x 1 waves
  *      over 192-row tiles from 1536 tiles on); 16: the 4 x 1 form with a 128-column tile for every N > 64 (default: 64 < N <= 128 only); 32: never; 64: the 4 x 1 form at <= 64 columns whatever the tile count (tests)
  *   10 output stores of the activation-writing kernels: 0 = non-temporal (streamed past L2) when the call writes 96 MiB or more, plain below;
- *      1 = always plain; 2 = always non-temporal (same results in every setting: tests/test_block_model_gpu.py) */
+ *      1 = always plain; 2 = always non-temporal (same results in every setting: tests/test_block_model_gpu.py)
+ *   11 fgcn_spatial_bwd_tile: 2 = two four-wave workgroups per CU (8-22 % slower; parity-tested)
+ *   12 joint gram of three equal-width items: 1 = the generic kernel (default: joint_gram3_kernel)
+ *   13 fgcn_spatial_wgrad: workgroups to aim for (0 = 512 up to 32 samples, 1024 above)
+ *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`) */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
