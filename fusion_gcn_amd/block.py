@@ -15,7 +15,8 @@ Kernel schedule of one block, train mode (B = N*M samples):
             [rows_gemm(residual 1x1 stride s) -> bn_finalize] -> bn_act (BN + residual + ReLU = O)
   backward  bn_act_bwd (O)  -> tconv_halo(data gradient 9x1; two parity passes when strided) / tconv_wgrad(all taps)
             -> bn_act_bwd (G)
-            spatial_wgrad (conv_d, aggregation recomputed on chip; beyond 128 outputs: joint_mix_vec(agg) -> pw_wgrad)
+            spatial_wgrad_tile [bf16x3, channels in 64s: conv_d's weight gradient, aggregation on chip, whole frame tiles]
+               (else: spatial_wgrad up to 128 outputs; beyond: joint_mix_vec(agg) -> pw_wgrad)
             -> spatial_bwd_tile [bf16x3, >= 64 inputs: dagg = dY.Wd on chip, dx and dA^ in one launch]
                (else: pw_gemm / rows_gemm(dY.Wd) -> joint_dagg(dx, dA^))
             -> adj_softmax_bwd -> joint_mix_vec(dtheta, dphi) -> pw_gemm / rows_gemm(dx) / rows_wgrad(theta|phi)
@@ -265,6 +266,12 @@ GATED_SHORTCUTS = False
 # old values to fetch): same-box step A/B 55.31 / 55.37 -> 55.20 / 55.20 ms at 64 clips, 9.45 / 9.44 -> 9.46 / 9.43 at 8
 # (profiles/r04_ab_gated_tile.txt); on.  FGCN_GATED_TILE=0: the BatchNorm-backward kernels carry the shortcut gradients.
 GATED_SHORTCUTS_TILE = bool(int(os.environ.get("FGCN_GATED_TILE", "1")))
+# conv_d's weight gradient in tile form (fgcn_spatial_wgrad_tile: a workgroup owns a 64/128 x 64/128 tile of all three subsets and walks
+# whole frame tiles; the aggregation is formed per frame on the matrix pipe and its accumulators are the contraction's operand) for every
+# channel count in 64s -- replaces fgcn_spatial_wgrad up to 128 outputs and joint_mix_vec(agg) + the row weight-gradient GEMM beyond.
+# FGCN_SPATIAL_WGRAD_TILE=0: the older forms.  Also with the f16x2 products (the kernel always multiplies three-way bf16 splits).
+SPATIAL_WGRAD_TILE = os.environ.get("FGCN_SPATIAL_WGRAD_TILE", "1") != "0"
+SPATIAL_WGRAD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_WGRAD_TILE_F16X2", "1") != "0"
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
 # tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
@@ -676,7 +683,10 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     with wgrad():
-        if FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
+        if (SPATIAL_WGRAD_TILE and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout)
+                and (ops.get_math_mode() == "bf16x3" or SPATIAL_WGRAD_TILE_F16X2)):
+            gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
+        elif FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
             # agg = x . A^ is formed in registers and contracted with dy at once: never written
             gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
         else:

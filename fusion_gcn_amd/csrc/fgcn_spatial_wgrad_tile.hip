@@ -1,0 +1,303 @@
+// conv_d weight gradient with the joint aggregation on chip, tile form (north-star kernel 1, weight-gradient side, split-bf16 math mode):
+//
+//     agg_k[(n,t,w), c] = sum_v x[(n,t,v), c] A^_k[n][v][w]                      (never written to HBM)
+//     dWd_k[c][o]       = sum_{n,t,w} agg_k[(n,t,w), c] dy[(n,t,w), o]           (partial sums per workgroup; the caller adds the slabs)
+//
+// reference: the autograd backward of SpatialGraphConv.forward with respect to conv_d's weights, torch_src/models/mmargcn/agcn.py:103-111
+// (SURVEY.md Appendix A.2).
+//
+// fgcn_spatial_wgrad (fgcn_joint.hip) gives a wave a frame and a workgroup a 32 x 64 tile of the gradient, so x is read Cout / 64 times and dy
+// Cin / 32 times: beyond 128 outputs the step fell back to joint_mix_vec (agg, three activations wide, through HBM) + the 1x1 weight-gradient
+// GEMM.  Here a workgroup (8 waves, one per CU) owns a (16 CT input channels) x (16 NT output channels) tile of all three subsets and walks
+// a contiguous range of (sample, frame tile) pairs:
+//   * the dY tile (F frames, <= 160 rows x 16 NT channels) goes through registers (requested one tile ahead) into LDS as three bf16 planes,
+//     split once;
+//   * wave (ct, fp) takes input channels 16 ct .. + 15 and the frames fp, fp + FP, .. of the tile (FP = 8 / CT).  Per frame: the x values
+//     x[(f, v = 8 g + j)][c = lane % 16] arrive as eight strided dword loads per lane (requested one frame ahead; this IS the B fragment of the
+//     joint mixing, no LDS), split once; agg_k^T... agg_k (32 joints w x 16 channels) = A^_k^T . x_f on the matrix pipe (A^ planes in LDS); the
+//     accumulator registers of lane (c, g) hold w = 4 g + r and 16 + 4 g + r: after an in-register split they ARE the A fragment of the
+//     contraction over rows (k slot j <-> joint w(g, j)), whose B fragments are transposing LDS reads (ds_read_b64_tr_b16) of the dY planes in
+//     the same joint order: dWd_k (16 c x 16 o) += agg_kf^T . dY_f.
+//   * joints w >= V meet zero rows of the A^ planes (their agg is exactly zero), so the rows of the next frame that a 32-joint fragment
+//     reaches cost nothing but must be finite: rows past the tile are staged as zeros.
+// Every sum has a fixed order (bitwise reproducible).
+#include <algorithm>
+#include <type_traits>
+
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct SwTileP {
+    const float* x;
+    const float* dy;
+    const float* a_hat;
+    float* partial;                     // float[nseg][3 Cin][Cout]
+    int B, T, V, Cin, Cout, ld_x, ld_dy, a_batched;
+    int F, tiles_t, gtiles, tps, nseg;  // frames per tile, tiles per sample, B * tiles_t, (sample, tile) pairs per segment, segments
+    int n_cg, n_og;                     // input-channel / output-channel groups of a workgroup tile
+    unsigned x_bytes, dy_bytes, p_bytes;
+};
+
+constexpr int SWT_ROWS = 160;           // rows of a dY plane: (F - 1) V + 32 <= 160
+constexpr int SWT_AHB = 80;             // bytes per [w] row of a split A^ plane (32 joints v x bf16 + 16 pad)
+// row stride of a dY plane: the channels' bytes + 32 -- eight consecutive rows then start 32 bytes apart modulo 256, which is what a
+// transposing read's half wave touches (8 rows x 32 bytes)
+template <int NT> constexpr int swt_rs() { return NT * 32 + 32; }
+template <int NT> constexpr int swt_lds() { return 3 * SWT_ROWS * swt_rs<NT>() + 9 * 32 * SWT_AHB; }
+
+__device__ __forceinline__ u32x2 swt_read_tr16(const unsigned char* p) {
+    using v4s = __attribute__((ext_vector_type(4))) short;
+    const v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+// CT: 16-channel input tiles of the workgroup (8: every wave walks all frames; 4: two waves per tile take alternate frames and their
+// accumulators are added at the end); NT: 16-channel output tiles (4 or 8)
+template <int CT, int NT>
+__global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p) {
+    constexpr int NP = 3, FP = 8 / CT;
+    constexpr int RS = swt_rs<NT>(), PL = SWT_ROWS * RS;
+    constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = SWT_ROWS / RPP;    // 16-byte groups per row, rows per pass, passes
+    static_assert(SWT_ROWS % RPP == 0, "staging passes");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sw_lds[];
+    unsigned char* Im = sw_lds;
+    unsigned char* Ah = sw_lds + NP * PL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4, q4 = l15 >> 2, c4 = lane & 3;
+    const int ct = wave % CT, fp = wave / CT;
+    const int combos = p.n_cg * p.n_og;
+    const int seg = blockIdx.x / combos, combo = blockIdx.x - seg * combos;
+    const int cgi = combo / p.n_og, ogi = combo - cgi * p.n_og;
+    const int c0 = cgi * 16 * CT + 16 * ct, o0 = ogi * 16 * NT;
+    const int V = p.V, F = p.F;
+    const int g_lo = seg * p.tps, g_hi = min(g_lo + p.tps, p.gtiles);
+    const int nslot = ((F + FP - 1) / FP + 1) & ~1;                    // frame slots of a wave per tile, even (two per loop trip)
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    f32x4 acc[3][NT];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[k][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid / GPR, sg = tid % GPR;
+    f32x4 stg[NPASS];
+    // the dY rows of (sample, tile) pair g (nothing past the segment: branch-free)
+    auto fetch = [&](int g) {
+        const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
+        const int t0_ = tile_ * F;
+        const int nrows_ = g < g_hi ? min(F, p.T - t0_) * V : 0;
+        const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = srow + RPP * i;
+            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(o0 + 4 * sg)) * 4u : OOB;
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+        }
+    };
+    // x values of frame slot s of pair g for this wave: lane (c = l15, g4) <- x[(f, v = 8 g4 + j)][c0 + l15], j = 0 .. 7
+    float xr[8];
+    auto xfetch = [&](int g, int s) {
+        const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
+        const int t0_ = tile_ * F, f = fp + FP * s;
+        const bool ok = g < g_hi && f < min(F, p.T - t0_);
+        const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_x + (unsigned)(c0 + l15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned off = (ok && 8 * g4 + j < V) ? (base + (unsigned)(j * p.ld_x)) * 4u : OOB;
+            xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+        }
+    };
+    fetch(g_lo);
+    xfetch(g_lo, 0);
+
+    int n_prev = -1;
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int n = g / p.tiles_t, tile = g - n * p.tiles_t;
+        const int nf = min(F, p.T - tile * F);
+        __syncthreads();                                             // the previous tile's fragment reads are done
+        if (n != n_prev && (p.a_batched || n_prev < 0)) {
+            // A^_k of this sample, split once: planes [subset][part][w][v] bf16 (one ds_read_b128 = the 8 joints v of a lane's fragment)
+            const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
+            for (int i = tid; i < 3 * 32 * 32; i += 512) {
+                const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
+                const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+                unsigned ph, pm, pl;
+                split_bf16_pair(a, 0.f, ph, pm, pl);
+                unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + w) * SWT_AHB) + v;
+                d[0] = (unsigned short)ph;
+                d[32 * SWT_AHB / 2] = (unsigned short)pm;
+                d[2 * 32 * SWT_AHB / 2] = (unsigned short)pl;
+            }
+        }
+        n_prev = n;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = srow + RPP * i;
+            u32x2 ph, pm, pl;
+            split3_x4(stg[i], ph, pm, pl);
+            unsigned char* dst = Im + r * RS + sg * 8;
+            *reinterpret_cast<u32x2*>(dst) = ph;
+            *reinterpret_cast<u32x2*>(dst + PL) = pm;
+            *reinterpret_cast<u32x2*>(dst + 2 * PL) = pl;
+        }
+        __syncthreads();
+        fetch(g + 1);                                                // lands during this tile's frames
+
+        auto slot = [&](int s) {
+            const int f = fp + FP * s;
+            u32x4v xs[NP];
+            split3_x8(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
+            if (s + 1 < nslot) xfetch(g, s + 1);                     // (wave-uniform) the next slot's values: this tile's, or the next tile's first
+            else xfetch(g + 1, 0);
+            if (f >= nf) return;                                     // wave-uniform: no such frame in this tile
+            u32x4v a3[3][NP];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                f32x4 m[2];
+#pragma unroll
+                for (int wt = 0; wt < 2; ++wt) {
+                    u32x4v af[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+                        af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * wt + l15) * SWT_AHB + 16 * g4);
+                    m[wt] = mfma_x3_k32(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                split3_x8(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3[k]);
+            }
+            const int r_lo = f * V + 4 * g4 + q4, r_hi = r_lo + 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4v df[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const unsigned char* base = Im + pl * PL + nt * 32 + 8 * c4;
+                    const u32x2 lo = swt_read_tr16(base + r_lo * RS);
+                    const u32x2 hi = swt_read_tr16(base + r_hi * RS);
+                    df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[k][nt] = mfma_x3_k32(a3[k], df, acc[k][nt]);
+            }
+        };
+        for (int s = 0; s < nslot; s += 2) {
+            slot(s);
+            slot(s + 1);
+        }
+    }
+
+    // ---- the workgroup's slab: partial[seg][k Cin + c][o] -------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+    if constexpr (FP == 2) {                                         // fixed order: frames of the even slots + frames of the odd slots
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sw_lds);               // [ct][k][nt][r][lane]
+        if (fp == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(((ct * 3 + k) * NT + nt) * 4 + r) * 64 + lane] = acc[k][nt][r];
+        }
+        __syncthreads();
+        if (fp == 1) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[k][nt][r] += red[(((ct * 3 + k) * NT + nt) * 4 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned off = (((unsigned)seg * 3u + k) * (unsigned)p.Cin + (unsigned)(c0 + 4 * g4 + r)) * (unsigned)p.Cout + (unsigned)(o0 + 16 * nt + l15);
+                const float val = acc[k][nt][r];                     // (a bit_cast of the vector-element lvalue itself reads element 0: hipcc 7.2)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off * 4u, 0, 0);
+            }
+}
+
+// frames per tile: as many whole frames as keep a 32-joint fragment of the last one inside SWT_ROWS rows, at most 8
+static int swt_frames(int V) { return std::max(1, std::min(8, (SWT_ROWS - 32) / V + 1)); }
+
+struct SwtGeom {
+    int CT, NT, F, tiles_t, gtiles, tps, nseg, n_cg, n_og;
+};
+static SwtGeom swt_geom(int B, int T, int V, int Cin, int Cout) {
+    SwtGeom g;
+    g.CT = Cin % 128 == 0 ? 8 : 4;
+    g.NT = Cout % 128 == 0 ? 8 : 4;
+    g.F = swt_frames(V);
+    g.tiles_t = (int)cdiv(T, g.F);
+    g.gtiles = B * g.tiles_t;
+    g.n_cg = Cin / (16 * g.CT);
+    g.n_og = Cout / (16 * g.NT);
+    // one workgroup per CU (tuning key 16 overrides the target)
+    const int want = std::max(1, (fgcn::tuning(16) > 0 ? fgcn::tuning(16) : 256) / (g.n_cg * g.n_og));
+    g.tps = (int)cdiv(g.gtiles, std::min(g.gtiles, want));
+    g.nseg = (int)cdiv(g.gtiles, g.tps);
+    return g;
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+// 1 when fgcn_spatial_wgrad_tile runs these sizes in the current math mode (FGCN_MATH_BF16X3 with either product form: the kernel always
+// multiplies three-way bf16 splits; whole 64-channel groups on both sides; 16..32 joints)
+extern "C" int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout) {
+    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 && Cout % 64 == 0 && Cout > 0) ? 1 : 0;
+}
+
+// slabs of `partial` (0: sizes the kernel does not take)
+extern "C" int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int Cout) {
+    if (V < 16 || V > FGCN_MAX_V || B <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64) return 0;
+    return swt_geom(B, T, V, Cin, Cout).nseg;
+}
+
+extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                                       int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream) {
+    FGCN_REQUIRE(x && dy && a_hat && partial, FGCN_E_BADARG, "spatial_wgrad_tile: null pointer");
+    FGCN_REQUIRE(fgcn_spatial_wgrad_tile_available(V, Cin, Cout), FGCN_E_BADARG,
+                 "spatial_wgrad_tile: V=%d Cin=%d Cout=%d in math mode %d not supported (split-bf16 mode, 16 <= V <= %d, channels in 64s)", V,
+                 Cin, Cout, fgcn::math_mode(), FGCN_MAX_V);
+    FGCN_REQUIRE(B > 0 && T > 0 && ld_x >= Cin && ld_dy >= Cout && ld_dy % 4 == 0, FGCN_E_BADARG,
+                 "spatial_wgrad_tile: bad sizes B=%d T=%d ld_x=%d ld_dy=%d", B, T, ld_x, ld_dy);
+    const long long rows = (long long)B * T * V;
+    FGCN_REQUIRE(rows * ld_x * 4 < (1ll << 31) && rows * ld_dy * 4 < (1ll << 31), FGCN_E_BADARG,
+                 "spatial_wgrad_tile: tensors must be smaller than 2 GiB");
+    const SwtGeom g = swt_geom(B, T, V, Cin, Cout);
+    FGCN_REQUIRE((long long)g.nseg * 3 * Cin * Cout * 4 < (1ll << 31), FGCN_E_BADARG, "spatial_wgrad_tile: partial slabs must be smaller than 2 GiB");
+    SwTileP p;
+    p.x = x, p.dy = dy, p.a_hat = a_hat, p.partial = partial;
+    p.B = B, p.T = T, p.V = V, p.Cin = Cin, p.Cout = Cout, p.ld_x = ld_x, p.ld_dy = ld_dy, p.a_batched = a_hat_batched;
+    p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
+    p.x_bytes = (unsigned)(rows * ld_x * 4), p.dy_bytes = (unsigned)(rows * ld_dy * 4);
+    p.p_bytes = (unsigned)((long long)g.nseg * 3 * Cin * Cout * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
+#define FGCN_SWT(CT_, NT_)                                                                                                        \
+    do {                                                                                                                          \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, swt_lds<NT_>());                                \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_>), grid, dim3(512), swt_lds<NT_>(), s, p);                     \
+    } while (0)
+    if (g.CT == 8 && g.NT == 8) FGCN_SWT(8, 8);
+    else if (g.CT == 8) FGCN_SWT(8, 4);
+    else if (g.NT == 8) FGCN_SWT(4, 8);
+    else FGCN_SWT(4, 4);
+#undef FGCN_SWT
+    return launch_status("spatial_wgrad_tile");
+}

@@ -635,6 +635,30 @@ def spatial_wgrad(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *, out:
     return _reduce_slabs(partial, 1, ns * Cin, Cout, out, accumulate, conv_param)
 
 
+def spatial_wgrad_tile_available(V: int, cin: int, cout: int) -> bool:
+    return bool(_lib.load().fgcn_spatial_wgrad_tile_available(int(V), int(cin), int(cout)))
+
+
+def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+                       accumulate: bool = False, conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """``spatial_wgrad`` in tile form (fgcn_spatial_wgrad_tile: channels in 64s, split-bf16 math mode, three subsets): the same
+    result layout.  x (B,T,V,>=Cin) with Cin = mats-independent ``conv_param``-free width x.shape[3], dy (B,T,V,Cout), mats (B or 1, 3, V, V)."""
+    ensure_device()
+    _chk(x, "spatial_wgrad_tile.x"), _chk(dy, "spatial_wgrad_tile.dy"), _chk(mats, "spatial_wgrad_tile.mats")
+    B, T, V, Cin = x.shape
+    Cout = dy.shape[3]
+    if dy.shape[:3] != (B, T, V) or mats.shape[0] not in (1, B) or tuple(mats.shape[1:]) != (3, V, V):
+        raise _lib.FgcnError(f"spatial_wgrad_tile: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} mats={tuple(mats.shape)}")
+    lib = _lib.load()
+    slabs = lib.fgcn_spatial_wgrad_tile_slabs(B, T, V, Cin, Cout)
+    if slabs <= 0:
+        raise _lib.FgcnError(f"spatial_wgrad_tile: sizes not supported: V={V} Cin={Cin} Cout={Cout}")
+    partial = torch.empty((slabs, 1, 3 * Cin, Cout), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_spatial_wgrad_tile(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, Cin, Cout,
+                                      int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile")
+    return _reduce_slabs(partial, 1, 3 * Cin, Cout, out, accumulate, conv_param)
+
+
 def joint_dagg(x: torch.Tensor, dagg: torch.Tensor, mats: torch.Tensor, dx: torch.Tensor, *, accumulate: bool,
                gated: Sequence[Tuple[torch.Tensor, torch.Tensor]] = ()) -> torch.Tensor:
     """dx (+)= sum_k dagg_k . A^_k^T and the partial grams dA^_k = x^T dagg_k in one pass over dagg.

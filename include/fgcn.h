@@ -60,7 +60,8 @@ int fgcn_check_device(void);
  *   11 fgcn_spatial_bwd_tile: 2 = two four-wave workgroups per CU (8-22 % slower; parity-tested)
  *   12 joint gram of three equal-width items: 1 = the generic kernel (default: joint_gram3_kernel)
  *   13 fgcn_spatial_wgrad: workgroups to aim for (0 = 512 up to 32 samples, 1024 above)
- *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`) */
+ *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`)
+ *   16 fgcn_spatial_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count) */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
@@ -472,6 +473,21 @@ int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, c
                           void* stream);
 int fgcn_spatial_bwd_tile_segments(int B, int T, int V);
 int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout);
+
+/* conv_d's weight gradient of the same stage in tile form (fgcn_spatial_wgrad_tile.hip; reference: the autograd backward of
+ * agcn.py:103-111 with respect to conv_d[k].weight): fgcn_spatial_wgrad's sum,
+ *     partial[slab][k*Cin + c][o] = sum over the slab's (n, t) and joints w of (sum_v x[(n,t,v), c] * A^_k[n][v][w]) * dy[(n,t,w), o],
+ *   for every channel count in 64s: a workgroup owns a (64 or 128) x (64 or 128) tile of all three subsets and walks whole frame
+ *   tiles, so x and dy are read Cout/128 and Cin/128 times instead of Cout/64 and Cin/32 times, and the 3-wide aggregation that
+ *   wider layers wrote with fgcn_joint_mix_vec and read back in the row weight-gradient GEMM never exists.
+ *   a_hat: float[B or 1][3][V][V] (a_hat_batched: one per sample).  partial: float[fgcn_spatial_wgrad_tile_slabs(B, T, V, Cin, Cout)]
+ *   [3 * Cin][Cout]; the caller sums the slabs (fgcn_reduce_multi).  Math mode FGCN_MATH_BF16X3 only (either product form; the kernel
+ *   always multiplies three-way bf16 splits, the mixing included): fgcn_spatial_wgrad_tile_available.  Every sum has a fixed order.
+ *   Tuning key 16: workgroups to aim for (0 = 256, one per CU; sets the slab count). */
+int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                            int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream);
+int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int Cout);
+int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
 
 /* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
 /* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:

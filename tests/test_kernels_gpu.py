@@ -662,6 +662,42 @@ def test_spatial_backward_tile_form(V, T, cin, cout, B):
     assert torch.equal(part_g, parts[0][1])
 
 
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
+                                             (16, 8, 128, 128, 1), (32, 5, 64, 64, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1),
+                                             (17, 23, 64, 128, 2), (21, 12, 128, 64, 3), (25, 20, 192, 64, 5), (19, 2, 64, 192, 3)])
+def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
+    """conv_d's weight gradient in tile form (fgcn_spatial_wgrad_tile.hip: agg = x . A^ on chip only) against the float64 einsum
+    (backward of agcn.py:103-111 with respect to conv_d[k].weight): per-sample and shared adjacency, ragged last frame group,
+    4 .. 8 frames per tile, both wave arrangements (64 / 128 input channels per workgroup) and both tile widths, segments that span
+    samples and segments shorter than a sample (tuning key 16), the parameter layout; bitwise reproducible; agrees with
+    fgcn_spatial_wgrad."""
+    from fusion_gcn_amd import _lib, ops
+    if not ops.spatial_wgrad_tile_available(V, cin, cout):
+        pytest.skip("the tile form runs with the bf16x3 products")
+    x, a, dy = rnd(B, T, V, cin, seed=340), rnd(B, 3, V, V, seed=341, scale=0.3), rnd(B, T, V, cout, seed=342)
+    want = torch.einsum("btvc,bkvw,btwo->kco", x.double(), a.double(), dy.double()).reshape(1, 3 * cin, cout)
+    got = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a))
+    assert tuple(got.shape) == (1, 3 * cin, cout)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < RED_TOL
+    assert torch.equal(got, ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a)))
+    old = ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a))
+    assert rel_l2(got.cpu().numpy(), old.cpu().numpy()) < RED_TOL
+    for target in (8, 100000):                  # few long segments (several samples each) / one (sample, tile) pair per workgroup
+        try:
+            _lib.load().fgcn_set_tuning(16, target)
+            g2 = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a))
+        finally:
+            _lib.load().fgcn_set_tuning(16, 0)
+        assert rel_l2(g2.cpu().numpy(), want.numpy()) < RED_TOL, target
+    shared = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a[:1]))                    # static (shared) adjacency
+    want_s = torch.einsum("btvc,kvw,btwo->kco", x.double(), a[0].double(), dy.double()).reshape(1, 3 * cin, cout)
+    assert rel_l2(shared.cpu().numpy(), want_s.numpy()) < RED_TOL
+    par = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a), conv_param=(3, cin - 3))  # (3, cout, cin_true, 1, 1)
+    want_p = want.reshape(3, cin, cout)[:, :cin - 3].permute(0, 2, 1)
+    assert tuple(par.shape) == (3, cout, cin - 3, 1, 1)
+    assert rel_l2(par.cpu().numpy().reshape(3, cout, cin - 3), want_p.numpy()) < RED_TOL
+
+
 @pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
 def test_halo_data_gradient_emits_the_batchnorm_backward_sums(B, T, V, C, fgcn_math):
     """fgcn_tconv_halo with bn_a / bn_mask / bn_vec: the data gradient dG and, from its epilogue, sum dP and sum dP * a_hat with

@@ -183,6 +183,9 @@ def bench_spatial_wgrad(B, reps):
         agg = torch.empty(B, T, V, 3 * cin, device=DEV)
         rows = B * T * V
         fl = rows * (6.0 * V * cin + 6.0 * cin * cout)
+        if ops.spatial_wgrad_tile_available(V, cin, cout):
+            ms = timeit(lambda: ops.spatial_wgrad_tile(x, dy, a), reps)
+            report(f"spatial_wgrad_tile       T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (cin + cout))
         ms = timeit(lambda: ops.spatial_wgrad(x, dy, a), reps)
         report(f"spatial_wgrad fused T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (cin + cout))
 
