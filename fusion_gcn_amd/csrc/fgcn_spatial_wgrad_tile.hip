@@ -13,7 +13,7 @@
 //   * the dY tile (F frames, <= 160 rows x 16 NT channels) goes through registers (requested one tile ahead) into LDS as three bf16 planes,
 //     split once;
 //   * wave (ct, fp) takes input channels 16 ct .. + 15 and the frames fp, fp + FP, .. of the tile (FP = 8 / CT).  Per frame: the x values
-//     x[(f, v = 8 g + j)][c = lane % 16] arrive as eight strided dword loads per lane (requested one frame ahead; this IS the B fragment of the
+//     x[(f, v = 8 g + j)][c = lane % 16] arrive as eight strided dword loads per lane (requested two frames ahead; this IS the B fragment of the
 //     joint mixing, no LDS), split once; agg_k^T... agg_k (32 joints w x 16 channels) = A^_k^T . x_f on the matrix pipe (A^ planes in LDS); the
 //     accumulator registers of lane (c, g) hold w = 4 g + r and 16 + 4 g + r: after an in-register split they ARE the A fragment of the
 //     contraction over rows (k slot j <-> joint w(g, j)), whose B fragments are transposing LDS reads (ds_read_b64_tr_b16) of the dY planes in
@@ -23,8 +23,19 @@
 // Every sum has a fixed order (bitwise reproducible).
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "fgcn_common.hpp"
+
+// Timing probes (wrong results; tools/build_probe.py only): bit 0 = no contraction MFMAs, bit 1 = no mixing MFMAs, bit 2 = x values requested
+// for the first slot only, bit 3 = dY rows requested for the first tile only, bit 4 = no deposit of the dY tile (first tile only),
+// bit 5 = no transposing reads (one fragment per slot), bit 6 = no in-register splits of the aggregation
+#ifndef FGCN_PROBE_SW
+#define FGCN_PROBE_SW 0
+#endif
+#ifndef FGCN_SWT_PF
+#define FGCN_SWT_PF 1                   // slots the x values are requested ahead (1 or 2; 2 measured equal in the kernel loop, 0.1 ms behind in the step)
+#endif
 
 namespace fgcn {
 
@@ -52,14 +63,25 @@ __device__ __forceinline__ u32x2 swt_read_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
+template <class Fn, int... S>
+__device__ __forceinline__ void swt_for_slots(Fn&& fn, std::integer_sequence<int, S...>) {
+    (fn(std::integral_constant<int, S>{}), ...);
+}
+
 // CT: 16-channel input tiles of the workgroup (8: every wave walks all frames; 4: two waves per tile take alternate frames and their
-// accumulators are added at the end); NT: 16-channel output tiles (4 or 8)
-template <int CT, int NT>
+// accumulators are added at the end); NT: 16-channel output tiles (4 or 8); NSLOT: frame slots of a wave per tile (ceil(F / FP) rounded up to
+// even -- compile time: the slots of a tile are straight-line code, so that the compiler counts the outstanding requests exactly (a run-time
+// slot loop put an s_waitcnt vmcnt(0) and register copies on its back edge: every request made ahead was waited for one slot later))
+template <int CT, int NT, int NSLOT>
 __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p) {
     constexpr int NP = 3, FP = 8 / CT;
     constexpr int RS = swt_rs<NT>(), PL = SWT_ROWS * RS;
     constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = SWT_ROWS / RPP;    // 16-byte groups per row, rows per pass, passes
-    static_assert(SWT_ROWS % RPP == 0, "staging passes");
+    static_assert(SWT_ROWS % RPP == 0 && NSLOT % 2 == 0, "staging passes / slot pairs");
+    constexpr int PF = FGCN_SWT_PF;
+    // the dY rows of the NEXT tile are requested in pieces, pass i in slot i * SPREAD / NPASS: in one burst at the start of the tile (80 KB per
+    // CU, all CUs at once) the x values requested right after it came back behind the whole burst (requests return in order)
+    constexpr int SPREAD = NSLOT > 2 ? NSLOT - 2 : 1;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_lds[];
     unsigned char* Im = sw_lds;
@@ -74,7 +96,6 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
     const int c0 = cgi * 16 * CT + 16 * ct, o0 = ogi * 16 * NT;
     const int V = p.V, F = p.F;
     const int g_lo = seg * p.tps, g_hi = min(g_lo + p.tps, p.gtiles);
-    const int nslot = ((F + FP - 1) / FP + 1) & ~1;                    // frame slots of a wave per tile, even (two per loop trip)
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -87,55 +108,46 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
 
     const int srow = tid / GPR, sg = tid % GPR;
     f32x4 stg[NPASS];
-    // the dY rows of (sample, tile) pair g (nothing past the segment: branch-free)
-    auto fetch = [&](int g) {
+    // pass i of the dY rows of (sample, tile) pair g (nothing past the segment: branch-free)
+    auto fetch_pass = [&](int g, int i) {
         const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
         const int t0_ = tile_ * F;
         const int nrows_ = g < g_hi ? min(F, p.T - t0_) * V : 0;
         const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int r = srow + RPP * i;
-            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(o0 + 4 * sg)) * 4u : OOB;
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
-        }
+        const int r = srow + RPP * i;
+        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(o0 + 4 * sg)) * 4u : OOB;
+        stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
     };
-    // x values of frame slot s of pair g for this wave: lane (c = l15, g4) <- x[(f, v = 8 g4 + j)][c0 + l15], j = 0 .. 7
-    float xr[8];
-    auto xfetch = [&](int g, int s) {
+    // x values of frame slot s of pair g for this wave: lane (c = l15, g4) <- x[(f, v = 8 g4 + j)][c0 + l15], j = 0 .. 7; requested PF slots
+    // ahead (PF = 2: two register sets, by slot parity)
+    float xr2[2][8];
+    auto xfetch = [&](float (&xr)[8], int g, int s) {
         const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
         const int t0_ = tile_ * F, f = fp + FP * s;
-        const bool ok = g < g_hi && f < min(F, p.T - t0_);
+        const int vlim = (g < g_hi && f < min(F, p.T - t0_)) ? V : 0;      // (a scalar select: no frame, no joints -- branch-free loads)
         const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_x + (unsigned)(c0 + l15);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned off = (ok && 8 * g4 + j < V) ? (base + (unsigned)(j * p.ld_x)) * 4u : OOB;
+            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_x)) * 4u : OOB;
             xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
         }
     };
-    fetch(g_lo);
-    xfetch(g_lo, 0);
-
-    int n_prev = -1;
-    for (int g = g_lo; g < g_hi; ++g) {
-        const int n = g / p.tiles_t, tile = g - n * p.tiles_t;
-        const int nf = min(F, p.T - tile * F);
-        __syncthreads();                                             // the previous tile's fragment reads are done
-        if (n != n_prev && (p.a_batched || n_prev < 0)) {
-            // A^_k of this sample, split once: planes [subset][part][w][v] bf16 (one ds_read_b128 = the 8 joints v of a lane's fragment)
-            const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
-            for (int i = tid; i < 3 * 32 * 32; i += 512) {
-                const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
-                const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
-                unsigned ph, pm, pl;
-                split_bf16_pair(a, 0.f, ph, pm, pl);
-                unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + w) * SWT_AHB) + v;
-                d[0] = (unsigned short)ph;
-                d[32 * SWT_AHB / 2] = (unsigned short)pm;
-                d[2 * 32 * SWT_AHB / 2] = (unsigned short)pl;
-            }
+    // the A^ planes of sample n -> LDS (between two barriers): A^_k split once, planes [subset][part][w][v] bf16 (one ds_read_b128 = the 8
+    // joints v of a lane's fragment)
+    auto planes = [&](int n) {
+        const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
+        for (int i = tid; i < 3 * 32 * 32; i += 512) {
+            const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
+            const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
+            unsigned ph, pm, pl;
+            split_bf16_pair(a, 0.f, ph, pm, pl);
+            unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + w) * SWT_AHB) + v;
+            d[0] = (unsigned short)ph;
+            d[32 * SWT_AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * SWT_AHB / 2] = (unsigned short)pl;
         }
-        n_prev = n;
+    };
+    auto deposit = [&]() {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int r = srow + RPP * i;
@@ -146,15 +158,33 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
             *reinterpret_cast<u32x2*>(dst + PL) = pm;
             *reinterpret_cast<u32x2*>(dst + 2 * PL) = pl;
         }
-        __syncthreads();
-        fetch(g + 1);                                                // lands during this tile's frames
+    };
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) fetch_pass(g_lo, i);
+    xfetch(xr2[0], g_lo, 0);
+    if (PF == 2) xfetch(xr2[1], g_lo, 1);
+    if (g_lo < g_hi) planes(g_lo / p.tiles_t);
+    deposit();
+    __syncthreads();
 
-        auto slot = [&](int s) {
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int n = g / p.tiles_t, tile = g - n * p.tiles_t;
+        const int nf = min(F, p.T - tile * F);
+        auto slot = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            float (&xr)[8] = xr2[PF == 2 ? (s & 1) : 0];
             const int f = fp + FP * s;
             u32x4v xs[NP];
             split3_x8(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
-            if (s + 1 < nslot) xfetch(g, s + 1);                     // (wave-uniform) the next slot's values: this tile's, or the next tile's first
-            else xfetch(g + 1, 0);
+            if (!(FGCN_PROBE_SW & 4)) {
+                if constexpr (s + PF < NSLOT) xfetch(xr, g, s + PF);  // a later slot of this tile, or of the next tile
+                else xfetch(xr, g + 1, s + PF - NSLOT);
+            }
+            if (!(FGCN_PROBE_SW & 8)) {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i)
+                    if (i * SPREAD / NPASS == s) fetch_pass(g + 1, i);
+            }
             if (f >= nf) return;                                     // wave-uniform: no such frame in this tile
             u32x4v a3[3][NP];
 #pragma unroll
@@ -166,29 +196,42 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
                         af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * wt + l15) * SWT_AHB + 16 * g4);
-                    m[wt] = mfma_x3_k32(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
+                    if constexpr ((FGCN_PROBE_SW & 2) != 0) m[wt] = __builtin_bit_cast(f32x4, af[0] ^ xs[0] ^ af[1] ^ xs[1] ^ af[2] ^ xs[2]);
+                    else m[wt] = mfma_x3_k32(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
                 }
-                split3_x8(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3[k]);
+                if constexpr ((FGCN_PROBE_SW & 64) != 0) {
+                    a3[k][0] = __builtin_bit_cast(u32x4v, m[0]);
+                    a3[k][1] = __builtin_bit_cast(u32x4v, m[1]);
+                    a3[k][2] = a3[k][0] ^ a3[k][1];
+                } else
+                    split3_x8(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3[k]);
             }
             const int r_lo = f * V + 4 * g4 + q4, r_hi = r_lo + 16;
+            u32x4v df[NP];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                u32x4v df[NP];
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
+                    if ((FGCN_PROBE_SW & 32) && nt > 0) break;
                     const unsigned char* base = Im + pl * PL + nt * 32 + 8 * c4;
                     const u32x2 lo = swt_read_tr16(base + r_lo * RS);
                     const u32x2 hi = swt_read_tr16(base + r_hi * RS);
                     df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
                 }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k][nt] = mfma_x3_k32(a3[k], df, acc[k][nt]);
+                for (int k = 0; k < 3; ++k) {
+                    if constexpr ((FGCN_PROBE_SW & 1) != 0) acc[k][nt][0] += __builtin_bit_cast(float, a3[k][0][0] ^ a3[k][1][1] ^ a3[k][2][2] ^ df[0][0] ^ df[1][1] ^ df[2][2]);
+                    else acc[k][nt] = mfma_x3_k32(a3[k], df, acc[k][nt]);
+                }
             }
         };
-        for (int s = 0; s < nslot; s += 2) {
-            slot(s);
-            slot(s + 1);
-        }
+        swt_for_slots(slot, std::make_integer_sequence<int, NSLOT>{});
+        // the next tile's dY rows (and its sample's A^ planes) replace this one's
+        __syncthreads();                                             // this tile's fragment reads are done
+        const int n1 = (g + 1) / p.tiles_t;
+        if (g + 1 < g_hi && n1 != n && p.a_batched) planes(n1);
+        if (!((FGCN_PROBE_SW & 16))) deposit();
+        __syncthreads();
     }
 
     // ---- the workgroup's slab: partial[seg][k Cin + c][o] -------------------------------------------------------------------------
@@ -284,20 +327,32 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
     p.p_bytes = (unsigned)((long long)g.nseg * 3 * Cin * Cout * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
-#define FGCN_SWT(CT_, NT_)                                                                                                        \
+#define FGCN_SWT(CT_, NT_, NS_)                                                                                                  \
     do {                                                                                                                          \
         static bool attr = false;                                                                                                 \
         if (!attr) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_>),                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_>),              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, swt_lds<NT_>());                                \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_>), grid, dim3(512), swt_lds<NT_>(), s, p);                     \
+        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_>), grid, dim3(512), swt_lds<NT_>(), s, p);                \
     } while (0)
-    if (g.CT == 8 && g.NT == 8) FGCN_SWT(8, 8);
-    else if (g.CT == 8) FGCN_SWT(8, 4);
-    else if (g.NT == 8) FGCN_SWT(4, 8);
-    else FGCN_SWT(4, 4);
+    // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
+    const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;
+#define FGCN_SWT_NT(CT_, NS_)                  \
+    do {                                       \
+        if (g.NT == 8) FGCN_SWT(CT_, 8, NS_);  \
+        else FGCN_SWT(CT_, 4, NS_);            \
+    } while (0)
+    // (5 .. 8 frames per tile for 16 .. 32 joints: 6 or 8 slots with one wave per channel tile, 4 with two)
+    FGCN_REQUIRE(nslot == (g.CT == 8 ? (g.F > 6 ? 8 : 6) : 4), FGCN_E_BADARG, "spatial_wgrad_tile: %d frames per tile: no such kernel form", g.F);
+    if (g.CT == 8) {
+        if (nslot == 8) FGCN_SWT_NT(8, 8);
+        else FGCN_SWT_NT(8, 6);
+    } else {
+        FGCN_SWT_NT(4, 4);
+    }
+#undef FGCN_SWT_NT
 #undef FGCN_SWT
     return launch_status("spatial_wgrad_tile");
 }

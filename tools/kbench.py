@@ -186,6 +186,18 @@ def bench_spatial_wgrad(B, reps):
         if ops.spatial_wgrad_tile_available(V, cin, cout):
             ms = timeit(lambda: ops.spatial_wgrad_tile(x, dy, a), reps)
             report(f"spatial_wgrad_tile       T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (cin + cout))
+            # the same with operands that are NOT resident in the Infinity Cache (what the step sees): a ring of input sets > 256 MB
+            nset = max(2, int(1.2e9 / (4.0 * rows * (cin + cout))))
+            ring = [(rnd(B, T, V, cin), rnd(B, T, V, cout)) for _ in range(nset)]
+            it = [0]
+
+            def cold():
+                xs, dys = ring[it[0] % nset]
+                it[0] += 1
+                ops.spatial_wgrad_tile(xs, dys, a)
+            ms = timeit(cold, max(reps, 2 * nset))
+            report(f"  ... operands from HBM (ring of {nset} sets)", ms, fl, 4.0 * rows * (cin + cout))
+            del ring
         ms = timeit(lambda: ops.spatial_wgrad(x, dy, a), reps)
         report(f"spatial_wgrad fused T{T} {cin}->{cout}", ms, fl, 4.0 * rows * (cin + cout))
 
