@@ -222,7 +222,7 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-TRAFFIC_RECORDS = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")      # newest first
+TRAFFIC_RECORDS = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")      # newest first
 
 
 def measured_traffic(dom, samples, math="f32"):
