@@ -65,5 +65,9 @@ def test_round2_traffic_record_shows_the_fetch_reduction():
         assert r["traffic_bytes"] == int(2 * r["fetch_size_kib_raw"] * 1024 + r["write_size_kib"] * 1024)
         assert r["algorithmic_bytes"] == 4 * 128 * 75 * 25 * 2 * 256 and r["traffic_bytes"] < 2 * r["algorithmic_bytes"]
     assert r3["conv_halo_f16x2_fwd"]["traffic_bytes"] < r3["conv_halo_x3_fwd"]["traffic_bytes"]      # 4 instead of 6 bytes per weight
-    assert bench.measured_traffic(dict(channels=256, frames=75), 128, "bf16x3") == r3["conv_halo_x3_fwd"]["traffic_bytes"]
+    # round 4 re-collected the bf16x3 record (same kernel: within 0.5 % of round 3's); the f16x2 one still comes from round 3's file
+    r4 = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))["conv_halo_x3_fwd"]
+    assert r4["traffic_bytes"] == int(round((2 * r4["fetch_size_kib_raw"] + r4["write_size_kib"]) * 1024))
+    assert abs(r4["traffic_bytes"] - r3["conv_halo_x3_fwd"]["traffic_bytes"]) < 0.005 * r4["traffic_bytes"]
+    assert bench.measured_traffic(dict(channels=256, frames=75), 128, "bf16x3") == r4["traffic_bytes"]
     assert bench.measured_traffic(dict(channels=256, frames=75), 128, "f16x2") == r3["conv_halo_f16x2_fwd"]["traffic_bytes"]
