@@ -8,8 +8,8 @@ char* error_buffer() {
     static thread_local char buf[512] = {0};
     return buf;
 }
-static int g_tuning[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-int tuning(int key) { return (key >= 0 && key < 16) ? g_tuning[key] : 0; }
+static int g_tuning[32] = {1};            // key 0 defaults to 1, every other key to 0
+int tuning(int key) { return (key >= 0 && key < 32) ? g_tuning[key] : 0; }
 static int g_math_mode = FGCN_MATH_F32;
 int math_mode() { return g_math_mode; }
 static int g_products = FGCN_PRODUCTS_BF16X3;
@@ -35,7 +35,7 @@ extern "C" int fgcn_set_products(int products) {
 extern "C" int fgcn_get_products(void) { return fgcn::g_products; }
 
 extern "C" int fgcn_set_tuning(int key, int value) {
-    if (key < 0 || key >= 16) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);
+    if (key < 0 || key >= 32) return fgcn::fail(FGCN_E_BADARG, "set_tuning: key %d out of range", key);
     fgcn::g_tuning[key] = value;
     return FGCN_OK;
 }

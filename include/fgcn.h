@@ -39,7 +39,7 @@ const char* fgcn_last_error(void);
 int fgcn_check_device(void);
 
 /* Select a kernel variant (process-wide; for tuning tools and same-box A/B runs -- value 0 of every key is the measured-best
- * default, every other form computes the same result in another summation order at most).  Keys 0..7:
+ * default, every other form computes the same result in another summation order at most).  Keys 0..31 (others: FGCN_E_BADARG):
  *   0  row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row, double-buffered LDS
  *   1  row GEMM, wider N: 0 = two barriers per K chunk, 1 = double-buffered LDS
  *   4  f32 halo conv: 0 = three workgroups per CU, 1 = two

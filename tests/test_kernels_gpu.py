@@ -682,13 +682,19 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert torch.equal(got, ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a)))
     old = ops.spatial_wgrad(to_gpu(x), to_gpu(dy), to_gpu(a))
     assert rel_l2(got.cpu().numpy(), old.cpu().numpy()) < RED_TOL
-    for target in (8, 100000):                  # few long segments (several samples each) / one (sample, tile) pair per workgroup
+    lib = _lib.load()
+    slabs = {0: lib.fgcn_spatial_wgrad_tile_slabs(B, T, V, cin, cout)}
+    for target in (2, 100000):                  # one or two long segments (several samples each) / one (sample, tile) pair per workgroup
         try:
-            _lib.load().fgcn_set_tuning(16, target)
+            assert lib.fgcn_set_tuning(16, target) == 0
+            slabs[target] = lib.fgcn_spatial_wgrad_tile_slabs(B, T, V, cin, cout)
             g2 = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a))
         finally:
-            _lib.load().fgcn_set_tuning(16, 0)
+            assert lib.fgcn_set_tuning(16, 0) == 0
         assert rel_l2(g2.cpu().numpy(), want.numpy()) < RED_TOL, target
+    assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs                  # the setting really changed the segmentation
+    frames = min(8, 128 // V + 1)                                                          # frames per tile: (F - 1) V + 32 <= 160 rows
+    assert slabs[100000] == B * ((T + frames - 1) // frames), slabs
     shared = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a[:1]))                    # static (shared) adjacency
     want_s = torch.einsum("btvc,kvw,btwo->kco", x.double(), a[0].double(), dy.double()).reshape(1, 3 * cin, cout)
     assert rel_l2(shared.cpu().numpy(), want_s.numpy()) < RED_TOL
