@@ -640,13 +640,18 @@ def spatial_wgrad_tile_available(V: int, cin: int, cout: int) -> bool:
 
 
 def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *, out: Optional[torch.Tensor] = None,
-                       accumulate: bool = False, conv_param: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+                       accumulate: bool = False, conv_param: Optional[Tuple[int, int]] = None, cin: Optional[int] = None,
+                       cout: Optional[int] = None) -> torch.Tensor:
     """``spatial_wgrad`` in tile form (fgcn_spatial_wgrad_tile: channels in 64s, split-bf16 math mode, three subsets): the same
-    result layout.  x (B,T,V,>=Cin) with Cin = mats-independent ``conv_param``-free width x.shape[3], dy (B,T,V,Cout), mats (B or 1, 3, V, V)."""
+    result layout.  x (B,T,V,ld_x), dy (B,T,V,ld_dy), mats (B or 1, 3, V, V); ``cin`` / ``cout``: the leading channels of wider
+    rows that take part (default: all)."""
     ensure_device()
     _chk(x, "spatial_wgrad_tile.x"), _chk(dy, "spatial_wgrad_tile.dy"), _chk(mats, "spatial_wgrad_tile.mats")
-    B, T, V, Cin = x.shape
-    Cout = dy.shape[3]
+    B, T, V, ld_x = x.shape
+    ld_dy = dy.shape[3]
+    Cin, Cout = ld_x if cin is None else int(cin), ld_dy if cout is None else int(cout)
+    if not (0 < Cin <= ld_x and 0 < Cout <= ld_dy):
+        raise _lib.FgcnError(f"spatial_wgrad_tile: cin={Cin} / cout={Cout} outside the rows ({ld_x}, {ld_dy})")
     if dy.shape[:3] != (B, T, V) or mats.shape[0] not in (1, B) or tuple(mats.shape[1:]) != (3, V, V):
         raise _lib.FgcnError(f"spatial_wgrad_tile: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} mats={tuple(mats.shape)}")
     lib = _lib.load()
@@ -654,7 +659,7 @@ def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *,
     if slabs <= 0:
         raise _lib.FgcnError(f"spatial_wgrad_tile: sizes not supported: V={V} Cin={Cin} Cout={Cout}")
     partial = torch.empty((slabs, 1, 3 * Cin, Cout), device=x.device, dtype=torch.float32)
-    check(lib.fgcn_spatial_wgrad_tile(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, Cin, Cout,
+    check(lib.fgcn_spatial_wgrad_tile(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
                                       int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile")
     return _reduce_slabs(partial, 1, 3 * Cin, Cout, out, accumulate, conv_param)
 

@@ -698,6 +698,10 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     shared = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a[:1]))                    # static (shared) adjacency
     want_s = torch.einsum("btvc,kvw,btwo->kco", x.double(), a[0].double(), dy.double()).reshape(1, 3 * cin, cout)
     assert rel_l2(shared.cpu().numpy(), want_s.numpy()) < RED_TOL
+    # rows wider than the channels that take part (row strides of the C ABI): 64 of the inputs / outputs only
+    sub = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a), cin=64, cout=64)
+    want_sub = want.reshape(3, cin, cout)[:, :64, :64].reshape(1, 192, 64)
+    assert rel_l2(sub.cpu().numpy(), want_sub.numpy()) < RED_TOL
     par = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a), conv_param=(3, cin - 3))  # (3, cout, cin_true, 1, 1)
     want_p = want.reshape(3, cin, cout)[:, :cin - 3].permute(0, 2, 1)
     assert tuple(par.shape) == (3, cout, cin - 3, 1, 1)
