@@ -59,7 +59,8 @@ struct HaloP {
 };
 
 // Timing probes (wrong results; tools/probes builds only): bit 0 = no output stores, bit 1 = no MFMAs, bit 2 = the image of the first chunk
-// only (later chunks skip fetch, split and LDS writes), bit 4 = weight fragments loaded once
+// only (later chunks skip fetch, split and LDS writes), bit 3 = image fragments read for the first step of a chunk only, bit 4 = weight
+// fragments loaded once, bit 5 = no statistics in the epilogue
 #ifndef FGCN_PROBE_HALO
 #define FGCN_PROBE_HALO 0
 #endif
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
     };
     auto load_a = [&](u32x4v (&dst)[NP], int mt, int it) {
+        if ((FGCN_PROBE_HALO & 8) && it > 0) return;                     // (probe: the first step's image fragments only)
         const int j = it / SPC, s2 = it - j * SPC;
         const int d = j * p.tb + p.tc;
         const int r = xrow + (d - p.dmin) * V + mt * 16;
