@@ -64,6 +64,32 @@ def test_host_side_validation(lib):
     assert lib.fgcn_spatial_tiles(128, 300) == 128 * 10
 
 
+def test_tile_kernel_geometry_and_tuning_keys(lib):
+    """Host-side geometry of the two round-4 tile kernels (no launch): one workgroup per CU at the headline shapes, fewer when the
+    batch is small, zero slabs / segments for sizes the kernels do not take; fgcn_set_tuning takes keys 0..31 and says so otherwise
+    (keys 16..18 had been rejected unnoticed)."""
+    B, V = 128, 25
+    for T, cin, cout, combos in ((300, 64, 64, 1), (300, 64, 128, 1), (150, 128, 128, 1), (150, 128, 256, 2), (75, 256, 256, 4)):
+        slabs = lib.fgcn_spatial_wgrad_tile_slabs(B, T, V, cin, cout)
+        assert 0 < slabs * combos <= 256 and slabs * combos > 192, (T, cin, cout, slabs)   # one round of (almost) 256 workgroups
+        segs = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
+        assert 0 < B * segs <= 256 and B * segs >= 128, (T, segs)
+    assert lib.fgcn_spatial_wgrad_tile_slabs(2, 13, 25, 64, 64) == 2 * 3                # 6 frames per tile at V = 25: 3 tiles per sample
+    assert lib.fgcn_spatial_bwd_tile_segments(2, 13, 25) == 3                           # 5 frames per tile there
+    for bad in ((2, 13, 25, 96, 64), (2, 13, 25, 64, 32), (2, 13, 15, 64, 64), (2, 13, 33, 64, 64), (0, 13, 25, 64, 64)):
+        assert lib.fgcn_spatial_wgrad_tile_slabs(*bad) == 0, bad
+    assert lib.fgcn_spatial_bwd_tile_segments(2, 13, 15) == 0 and lib.fgcn_spatial_bwd_tile_segments(2, 0, 25) == 0
+    try:
+        assert lib.fgcn_set_tuning(16, 2) == 0 and lib.fgcn_spatial_wgrad_tile_slabs(B, 75, V, 256, 256) == 1
+        assert lib.fgcn_set_tuning(15, 128) == 0 and lib.fgcn_spatial_bwd_tile_segments(B, 75, V) == 1
+        assert lib.fgcn_set_tuning(31, 7) == 0
+    finally:
+        for k in (15, 16, 31):
+            assert lib.fgcn_set_tuning(k, 0) == 0
+    assert lib.fgcn_set_tuning(32, 1) == -1 and b"out of range" in lib.fgcn_last_error()
+    assert lib.fgcn_set_tuning(-1, 1) == -1
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under fusion_gcn_amd/ may import it."""
     pkg = os.path.join(ROOT, "fusion_gcn_amd")
