@@ -314,6 +314,8 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
                  Cin, Cout, fgcn::math_mode(), FGCN_MAX_V);
     FGCN_REQUIRE(B > 0 && T > 0 && ld_x >= Cin && ld_dy >= Cout && ld_dy % 4 == 0, FGCN_E_BADARG,
                  "spatial_wgrad_tile: bad sizes B=%d T=%d ld_x=%d ld_dy=%d", B, T, ld_x, ld_dy);
+    FGCN_REQUIRE(aligned16(dy) && (reinterpret_cast<uintptr_t>(x) & 3u) == 0 && (reinterpret_cast<uintptr_t>(partial) & 3u) == 0, FGCN_E_ALIGN,
+                 "spatial_wgrad_tile: dy must be 16-byte aligned (x, partial: 4)");
     const long long rows = (long long)B * T * V;
     FGCN_REQUIRE(rows * ld_x * 4 < (1ll << 31) && rows * ld_dy * 4 < (1ll << 31), FGCN_E_BADARG,
                  "spatial_wgrad_tile: tensors must be smaller than 2 GiB");

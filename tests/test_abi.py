@@ -86,6 +86,17 @@ def test_tile_kernel_geometry_and_tuning_keys(lib):
     finally:
         for k in (15, 16, 31):
             assert lib.fgcn_set_tuning(k, 0) == 0
+    # the launcher validates on the host before any HIP call: null pointers, channel counts outside the 64s, a misaligned dY
+    one = C.c_void_p(16)
+    assert lib.fgcn_spatial_wgrad_tile(None, one, one, one, 2, 13, 25, 64, 64, 64, 64, 1, None) == -1
+    assert lib.fgcn_set_math_mode(2) == 0
+    try:
+        assert lib.fgcn_spatial_wgrad_tile(one, one, one, one, 2, 13, 25, 96, 64, 96, 64, 1, None) == -1
+        assert lib.fgcn_spatial_wgrad_tile(one, C.c_void_p(20), one, one, 2, 13, 25, 64, 64, 64, 64, 1, None) == -2
+        assert b"aligned" in lib.fgcn_last_error()
+        assert lib.fgcn_spatial_wgrad_tile(one, one, one, one, 2, 13, 25, 64, 64, 32, 64, 1, None) == -1     # ld_x < Cin
+    finally:
+        assert lib.fgcn_set_math_mode(0) == 0
     assert lib.fgcn_set_tuning(32, 1) == -1 and b"out of range" in lib.fgcn_last_error()
     assert lib.fgcn_set_tuning(-1, 1) == -1
 
