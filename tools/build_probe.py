@@ -4,7 +4,8 @@
     python tools/build_probe.py <name> <source.hip> -DFGCN_PROBE_PW=1 [...]     ->  tools/probes/libfgcn_<name>.so
 
 Run a tool against it with FGCN_LIB=$PWD/tools/probes/libfgcn_<name>.so (fusion_gcn_amd/_lib.py).  The in-tree library is built
-first (incrementally) so that the other objects are current.  Probe libraries are git-ignored and travel to the GPU box.
+first (incrementally) so that the other objects are current.  Probe libraries are git-ignored and travel to the GPU box: delete
+tools/probes/libfgcn_*.so and tools/probes/_obj/ when the measurement is done (every snapshot ships them otherwise).
 """
 import os
 import subprocess
