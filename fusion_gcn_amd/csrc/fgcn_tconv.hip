@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         // (left to itself the scheduler requests all four row tiles' operands first and sums after the last store: 128 live values)
         if constexpr (bnb || ldacc) __builtin_amdgcn_sched_barrier(0);
     }
-    if (p.stats) {
+    if (p.stats && !((FGCN_PROBE_HALO & 32) && ssum[0] != 123.456f)) {
         __syncthreads();
         float* red = Ah;                                   // [which][wr][BN]
 #pragma unroll
