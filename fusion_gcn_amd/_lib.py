@@ -111,6 +111,10 @@ SIGNATURES = {
     "fgcn_spatial_wgrad_tile": (_I, [_P] * 4 + [_I] * 8 + [_P]),
     "fgcn_spatial_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_spatial_wgrad_tile_available": (_I, [_I] * 3),
+    "fgcn_emb_dx_tile": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "fgcn_emb_wgrad_tile": (_I, [_P] * 5 + [_I] * 8 + [_P]),
+    "fgcn_emb_wgrad_tile_slabs": (_I, [_I] * 5),
+    "fgcn_emb_tile_available": (_I, [_I] * 3),
     "fgcn_joint_dagg": (_I, [_P] * 5 + [_I] * 11 + [_P] * 5),
     "fgcn_adj_softmax_fwd": (_I, [_P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_adj_softmax_bwd": (_I, [_P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),

@@ -19,7 +19,8 @@ Kernel schedule of one block, train mode (B = N*M samples):
                (else: spatial_wgrad up to 128 outputs; beyond: joint_mix_vec(agg) -> pw_wgrad)
             -> spatial_bwd_tile [bf16x3, >= 64 inputs: dagg = dY.Wd on chip, dx and dA^ in one launch]
                (else: pw_gemm / rows_gemm(dY.Wd) -> joint_dagg(dx, dA^))
-            -> adj_softmax_bwd -> joint_mix_vec(dtheta, dphi) -> pw_gemm / rows_gemm(dx) / rows_wgrad(theta|phi)
+            -> adj_softmax_bwd -> emb_dx_tile + emb_wgrad_tile [split modes, channels in 64s: the embedding gradient on chip]
+               (else: joint_mix_vec(dtheta, dphi) -> pw_gemm / rows_gemm(dx) / rows_wgrad(theta|phi))
             + down / residual conv dgrad & wgrad, bias gradients by col_sum; every weight gradient is reduced from its
             slabs straight into the parameter's (out, in, taps, 1) layout (reduce_sum_strided).
 """
@@ -173,6 +174,10 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     # products the block keeps that form of d_t beside the two-way f16 one
     if mode in ("bf16x3", "f16x2") and cx % 64 == 0 and cout % 64 == 0:
         F["d_t_b3"] = Form("split3", 1, cout, 3 * cx, d_cols)      # (a form of its own: forms are materialised per key)
+    # the embedding backward in tile form (ops.emb_dx_tile: the embedding gradient on chip) streams the three-way bf16 split of emb_t in
+    # every split mode (bf16: its part 0)
+    if "emb_t" in F and mode in ops.SPLIT_MODES and cx % 64 == 0:
+        F["emb_t_b3"] = Form("split3", 1, 6 * ic, cx, F["emb_t"].segs)
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
@@ -271,6 +276,10 @@ GATED_SHORTCUTS_TILE = bool(int(os.environ.get("FGCN_GATED_TILE", "1")))
 # channel count in 64s -- replaces fgcn_spatial_wgrad up to 128 outputs and joint_mix_vec(agg) + the row weight-gradient GEMM beyond.
 # FGCN_SPATIAL_WGRAD_TILE=0: the older forms.  Also with the f16x2 products (the kernel always multiplies three-way bf16 splits).
 SPATIAL_WGRAD_TILE = os.environ.get("FGCN_SPATIAL_WGRAD_TILE", "1") != "0"
+# the backward of the attention embeddings (agcn.py:104-106) in tile form (fgcn_emb_tile.hip): the embedding gradient demb is formed per
+# frame on the matrix pipe inside the two kernels that consume it (dx += demb . Wemb; dWemb = demb^T . x, dbemb) and never exists in HBM --
+# replaces joint_mix_vec(demb) + the 1x1 data-gradient GEMM + the 1x1 weight-gradient GEMM.  FGCN_EMB_TILE=0: that chain.
+EMB_TILE = os.environ.get("FGCN_EMB_TILE", "1") != "0"
 SPATIAL_WGRAD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_WGRAD_TILE_F16X2", "1") != "0"
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
@@ -716,13 +725,21 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        demb = new(B, T, V, 6 * ic)
-        gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
-        demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)
-        pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live, amax_out=bamax[1:2] if demb_amax else None)
-        with wgrad():
-            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
-                                amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
+        if (EMB_TILE and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
+                and emb.numel() * 4 < 0x7FFF0000 and dx.numel() * 4 < 0x7FFF0000):
+            # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
+            ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
+            with wgrad():
+                gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
+            gw = gw.view(6 * ic, cin_true, 1, 1)
+        else:
+            demb = new(B, T, V, 6 * ic)
+            gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
+            demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)
+            pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live, amax_out=bamax[1:2] if demb_amax else None)
+            with wgrad():
+                gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
+                                    amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic

@@ -250,6 +250,29 @@ __device__ __forceinline__ void split3_x8(float v0, float v1, float v2, float v3
     q[2] = u32x4v{l0[0], l0[1], l1[0], l1[1]};
 }
 
+// The same helpers with the number of bf16 parts as a template parameter: NP = 3 is the exact three-way split above (FGCN_MATH_BF16X3),
+// NP = 1 one bfloat16 per value, round-to-nearest-even (FGCN_MATH_BF16: part 0 of the split IS the rounded value) -- one kernel source
+// for both modes (the tile kernels of fgcn_emb_tile.hip).
+template <int NP>
+__device__ __forceinline__ void splitn_x4(f32x4 a, u32x2 (&q)[NP]) {
+    if constexpr (NP == 3) split3_x4(a, q[0], q[1], q[2]);
+    else q[0] = __builtin_bit_cast(u32x2, pack_bf16(a));
+}
+template <int NP>
+__device__ __forceinline__ void splitn_x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, u32x4v (&q)[NP]) {
+    if constexpr (NP == 3) {
+        split3_x8(v0, v1, v2, v3, v4, v5, v6, v7, q);
+    } else {
+        const u32x2 lo = __builtin_bit_cast(u32x2, pack_bf16(v0, v1, v2, v3)), hi = __builtin_bit_cast(u32x2, pack_bf16(v4, v5, v6, v7));
+        q[0] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+template <int NP>
+__device__ __forceinline__ f32x4 mfma_np_k32(const u32x4v (&a)[NP], const u32x4v (&b)[NP], f32x4 c) {
+    if constexpr (NP == 3) return mfma_x3_k32(a, b, c);
+    else return mfma_bf16_k32(a[0], b[0], c);
+}
+
 template <int MM>
 __device__ __forceinline__ Frag<MM> make_frag(float a0, float a1, float a2, float a3) {
     Frag<MM> f;

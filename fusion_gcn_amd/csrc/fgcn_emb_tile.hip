@@ -1,0 +1,632 @@
+// Backward of the attention embeddings with the embedding gradient on chip, tile form (split-bf16 math modes).
+//
+// reference: the autograd backward of SpatialGraphConv.forward through
+//     A1 = conv_a[k](x) (theta_k),  A2 = conv_b[k](x) (phi_k),  S_k = softmax_v(theta_k^T phi_k / (ic T))     torch_src/models/mmargcn/agcn.py:104-106
+// (SURVEY.md Appendix A.2).  With dS_k (B, 3, V, V) the gradient in front of the softmax (fgcn_adj_softmax_bwd, scale folded in) and the
+// embedding tensor emb (B, T, V, 6 ic) = [th0 ph0 th1 ph1 th2 ph2]:
+//
+//     demb[(n,t,v), th_k + e] = sum_w dS_k[n][v][w] emb[(n,t,w), ph_k + e]           (d theta_k = dS_k . phi_k)
+//     demb[(n,t,w), ph_k + e] = sum_v dS_k[n][v][w] emb[(n,t,v), th_k + e]           (d phi_k  = dS_k^T . theta_k)
+//     dx[(n,t,v), c]   (+)= sum_j demb[(n,t,v), j] Wemb[j][c]                         (fgcn_emb_dx_tile)
+//     dWemb[j][c]        = sum_{n,t,v} demb[(n,t,v), j] x[(n,t,v), c],  dbemb[j] = sum_{n,t,v} demb[(n,t,v), j]     (fgcn_emb_wgrad_tile)
+//
+// Until round 5 demb (1.5 activations wide) was written by joint_mix_vec and read back by a 1x1 data-gradient GEMM and a 1x1 weight-gradient
+// GEMM: three launches and four HBM passes of the wide tensor per block.  Here demb never exists in HBM: both consumers form it per frame
+// on the matrix pipe from emb and dS -- a joint mixing in which every 16-channel tile has ONE matrix (dS_k^T for a theta tile, dS_k for a
+// phi tile) and reads the PARTNER group's channels -- the two tile kernels of the spatial stage (fgcn_spatial_tile.hip,
+// fgcn_spatial_wgrad_tile.hip) with that change:
+//
+//   * emb_dx_tile_kernel: a workgroup owns F = 128 / V whole frames of one sample times 64 NT columns of dx.  Per chunk of 64 demb channels
+//     the mixing units (frame, 16-channel tile) are dealt to the four waves: demb_f^T (16 c x 32 w) = emb_f^T (A operand: eight strided
+//     dwords per lane, requested a chunk ahead, split once) . M (B operand: split planes [w][v] in LDS), so that an accumulator lane holds
+//     four consecutive channels of one joint = 8-byte pieces of the row-major image [row f V + w][32 channels] (three bf16 planes); the
+//     contraction with the pre-split weights (fgcn_pack_split3 of the (6 ic) x Cin matrix) then runs from that image exactly like the
+//     forward tile kernel's.  The accumulators START from dx's old values (accumulating form), requested before the first chunk.
+//   * emb_wgrad_tile_kernel: one 8-wave workgroup per CU owns a (16 CT demb channels) x (16 NT input channels) tile of dWemb and walks a
+//     contiguous range of (sample, frame tile) pairs.  The x tile goes through registers into LDS as bf16 planes; per frame the wave's
+//     demb tile (32 joints x 16 channels) is formed in accumulator registers, which after an in-register split ARE the A fragment of the
+//     contraction over rows against transposing LDS reads of the x planes (fgcn_spatial_wgrad_tile.hip's scheme with one accumulator set
+//     per channel tile instead of three).  The bias gradient is the sum of the same accumulators.
+// NP = 3: exact three-way bf16 splits (FGCN_MATH_BF16X3, either product form); NP = 1: operands rounded to bfloat16 once (FGCN_MATH_BF16).
+// Every sum has a fixed order (bitwise reproducible).
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+constexpr unsigned ET_OOB = 0x80000000u;
+constexpr int ET_AHB = 80;              // bytes per [w] row of a split matrix plane (32 joints v x bf16 + 16 pad: conflict-free b128 reads)
+
+// split matrix planes of `nm` consecutive (subset, side) groups starting at group g_lo -> LDS [slot][part][w][v]: the plane of group g holds
+// M[v_in][w_out] at [w_out][v_in] -- g even (theta_k): M = dS_k^T, g odd (phi_k): M = dS_k
+template <int NP, int NTHREADS>
+__device__ __forceinline__ void et_stage_planes(unsigned char* Ah, const float* src, int V, int g_lo, int nm, int tid) {
+    for (int i = tid; i < nm * 1024; i += NTHREADS) {
+        const int m = i >> 10, w = (i >> 5) & 31, v = i & 31;
+        const int g = g_lo + m, k = g >> 1;
+        float a = 0.f;
+        if (g < 6 && v < V && w < V) a = (g & 1) ? src[(k * V + v) * V + w] : src[(k * V + w) * V + v];
+        unsigned ph, pm, pl;
+        split_bf16_pair(a, 0.f, ph, pm, pl);
+        unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((m * NP) * 32 + w) * ET_AHB) + v;
+        d[0] = (unsigned short)ph;
+        if constexpr (NP == 3) {
+            d[32 * ET_AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * ET_AHB / 2] = (unsigned short)pl;
+        }
+    }
+}
+
+// =====================================================================================================================================
+// dx (+)= demb . Wemb
+// =====================================================================================================================================
+struct EmbDxP {
+    const float* emb;
+    const float* d_s;
+    const void* w3;                     // fgcn_pack_split3 form of the (6 ic) x Cout matrix: [part][j / 8][c][8] bf16
+    float* dx;
+    int B, T, V, ic, Ce, Cout, ld_e, ld_dx, s_batched;
+    int F, tiles_t, tiles_m, tiles_n, per_xcd;
+    unsigned e_bytes, dx_bytes, w_plane_bytes;
+};
+
+constexpr int ED_XS = 64;               // bytes per image row and part (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
+constexpr int ED_PLANE = 128 * ED_XS;   // one part of the image: one 32-channel pair x 128 rows
+constexpr int ED_NMAT = 6;              // matrix slots: all (subset, side) groups stay resident
+template <int NP> constexpr int ed_lds() { return NP * ED_PLANE + ED_NMAT * NP * 32 * ET_AHB; }
+
+// One chunk = one 32-channel pair of demb (the image of two pairs beside six resident matrices would not leave room for two workgroups
+// per CU; re-staging the matrices per chunk cost 16 prefetch registers and spilled).  MAXU: mixing units (frame, 16-channel half) of a
+// wave per chunk = ceil(2 F / 4).
+template <int NP, int NT, int MAXU, bool ACC>
+__global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
+    constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char ed_lds_raw[];
+    unsigned char* Xh = ed_lds_raw;                                  // [NP parts][128 rows][64 B]
+    unsigned char* ahs = Xh + NP * ED_PLANE;                         // [6 groups][NP parts][32 w][ET_AHB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int vid = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);    // XCD-aware order, column tile fastest
+    if (vid >= p.tiles_m * p.tiles_n) return;
+    const int bm = vid / p.tiles_n, bn = vid - bm * p.tiles_n;
+    const int n = bm / p.tiles_t, tf = bm - n * p.tiles_t;
+    const int V = p.V, F = p.F, ic = p.ic;
+    const int t0 = tf * F;
+    const int nf = min(F, p.T - t0);
+    const int nrows = nf * V;
+    const int n0 = bn * BN;
+
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)p.emb, 0, p.e_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
+
+    // the six matrices of this sample, split once per workgroup
+    et_stage_planes<NP, 256>(ahs, p.d_s + (p.s_batched ? (long long)n * 3 * V * V : 0), V, 0, ED_NMAT, tid);
+
+    // ---- accumulators: dx's old values (accumulating form) or zero; register r of lane (col l15, g4) = row 4 g4 + r of its 16 x 16 tile.
+    // Address of element (mt, r, nu) = one per-lane offset + a scalar row part + a constant column part.  The LOADS carry no masks: rows past
+    // the tile and columns past Cout read other valid memory (or zeros past the tensor) into accumulators that are never stored -- every
+    // output element depends on its own image row and weight column only.
+    const unsigned m0 = (unsigned)((n * p.T + t0) * V);              // (32-bit row math: the launcher bounds the tensors by 2 GiB)
+    const int col = n0 + wc * NT * 32 + l15;                         // + nu * 16
+    const unsigned lane_base = ((m0 + (unsigned)(wr * (16 * MTW) + 4 * g4)) * (unsigned)p.ld_dx + (unsigned)col) * 4u;
+    const unsigned dx_row_b = (unsigned)p.ld_dx * 4u;
+    f32x4 acc[MTW][NU];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                if constexpr (ACC)
+                    acc[mt][nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdx, lane_base + nu * 64, (unsigned)(mt * 16 + r) * dx_row_b, 0));
+                else
+                    acc[mt][nu][r] = 0.f;
+            }
+
+    // ---- mixing units of a chunk: (frame f, 16-channel half hh of the pair); the 2 F units in frame-major order are dealt to the waves in
+    // contiguous blocks
+    int uf[MAXU], uh[MAXU];
+    bool uok[MAXU];
+    const int u_lo = __builtin_amdgcn_readfirstlane((wave * 2 * F) >> 2), u_hi = __builtin_amdgcn_readfirstlane(((wave + 1) * 2 * F) >> 2);
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = u_lo + i;
+        uf[i] = u >> 1;
+        uh[i] = u & 1;
+        uok[i] = u < u_hi && uf[i] < nf;                             // (wave-uniform)
+    }
+    const int nchunks = p.Ce >> 5;                                   // 32-channel pairs of demb
+    const unsigned row_b = (unsigned)p.ld_e * 4u;
+    // emb values of a unit: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][partner channel + l15], j = 0 .. 7 (the A fragment of the mixing)
+    float xr[MAXU][8];
+    auto fetch_units = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int d0 = 32 * c + 16 * uh[i];                      // the unit's demb channels; their group -> the partner group's channels
+            const int g = d0 / ic;
+            const int csrc = d0 + ((g & 1) ? -ic : ic);
+            const bool ok = uok[i] && c < nchunks;
+            const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * g4) * p.ld_e + (ok ? csrc : 0) + l15) * 4u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, (ok && 8 * g4 + j < V) ? base : ET_OOB, (unsigned)j * row_b, 0));
+        }
+    };
+    auto stage_units = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (!uok[i]) continue;                                   // wave-uniform
+            const int g = (32 * c + 16 * uh[i]) / ic;                // the unit's group = its matrix
+            u32x4v xs[NP];
+            splitn_x8<NP>(xr[i][0], xr[i][1], xr[i][2], xr[i][3], xr[i][4], xr[i][5], xr[i][6], xr[i][7], xs);
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) {
+                u32x4v af[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const u32x4v*>(ahs + ((g * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
+                // demb_f^T (16 c x 16 w): lane (w = 16 wt + l15, g4) holds channels 4 g4 .. + 3 of the half
+                const f32x4 m = mfma_np_k32<NP>(xs, af, f32x4{0.f, 0.f, 0.f, 0.f});
+                const int w = 16 * wt + l15;
+                if (w < V) {
+                    const int R = uf[i] * V + w;
+                    u32x2 parts[NP];
+                    splitn_x4<NP>(m, parts);
+                    unsigned char* dst = Xh + R * ED_XS + ((unsigned)(32 * uh[i] + 8 * g4) ^ swz(R));
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * ED_PLANE) = parts[pl];
+                }
+            }
+        }
+    };
+
+    unsigned wvoff[NU];                                              // per-lane byte offset into one part: (g4 * Cout + col) * 8 bf16
+#pragma unroll
+    for (int nu = 0; nu < NU; ++nu) wvoff[nu] = col + nu * 16 < p.Cout ? (unsigned)(((long long)g4 * p.Cout + col + nu * 16) * 16) : ET_OOB;
+    // weight fragment of (column unit nu, pair pq): contraction rows 32 pq + 8 g4 + j; past the last pair: pair 0 (a valid, unused load)
+    auto load_w = [&](u32x4v (&dst)[NP], int nu, int pq) {
+        if (pq >= nchunks) pq = 0;
+        const unsigned so = (unsigned)(((long long)(4 * pq) * p.Cout) * 16);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
+    };
+    const int xrow = wr * (16 * MTW) + l15;
+    auto load_a = [&](u32x4v (&dst)[NP], int mt) {
+        const int r = xrow + mt * 16;
+        const unsigned char* src = Xh + r * ED_XS + ((unsigned)(16 * g4) ^ swz(r));
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * ED_PLANE);
+    };
+    constexpr int RS = NU == 4 ? 4 : 2;                              // weight ring slots (fragments requested RS - 1 units ahead)
+    u32x4v a[MTW][NP], wq[RS][NP];
+    auto feature_phase = [&](int c) {                                // pair c from the image
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) load_a(a[mt], mt);
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            const int t = nu + RS - 1;
+            if (t < NU) load_w(wq[t % RS], t, c);
+            else load_w(wq[t % RS], t - NU, c + 1);
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) acc[mt][nu] = mfma_np_k32<NP>(a[mt], wq[nu % RS], acc[mt][nu]);
+        }
+    };
+
+    fetch_units(0);
+#pragma unroll
+    for (int nu = 0; nu < RS - 1; ++nu) load_w(wq[nu], nu, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                             // the previous chunk's image reads are done (first pass: the matrices are written)
+        stage_units(c);
+        __syncthreads();
+        fetch_units(c + 1);                                          // lands during the MFMAs below (past the last chunk: nothing is read)
+        feature_phase(c);
+    }
+
+    // ---- epilogue: branch-free buffer stores; rows beyond the tile's frames and columns beyond Cout carry the out-of-range offset
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool rowok = wr * (16 * MTW) + mt * 16 + 4 * g4 + r < nrows;
+#pragma unroll
+            for (int nu = 0; nu < NU; ++nu) {
+                const unsigned off = (rowok && col + nu * 16 < p.Cout) ? lane_base + nu * 64 : ET_OOB;
+                const float val = acc[mt][nu][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdx, off, (unsigned)(mt * 16 + r) * dx_row_b, 0);
+            }
+        }
+}
+
+// =====================================================================================================================================
+// dWemb = demb^T . x,  dbemb = column sums of demb
+// =====================================================================================================================================
+struct EmbWgP {
+    const float* emb;
+    const float* x;
+    const float* d_s;
+    float* partial;                     // float[nseg][Ce][Cx]
+    float* bias_partial;                // float[nseg][Ce]
+    int B, T, V, ic, Ce, Cx, ld_e, ld_x, s_batched;
+    int F, tiles_t, gtiles, tps, nseg, n_cg, n_og;
+    unsigned e_bytes, x_bytes, p_bytes, b_bytes;
+};
+
+constexpr int EW_ROWS = 160;            // rows of an x plane: (F - 1) V + 32 <= 160
+// row stride of an x plane: the channels' bytes + 32 -- eight consecutive rows then start 32 bytes apart modulo 256 (a transposing read's
+// half wave touches 8 rows x 32 bytes)
+template <int NT> constexpr int ew_rs() { return NT * 32 + 32; }
+template <int NP, int NT, int NM> constexpr int ew_lds() { return NP * EW_ROWS * ew_rs<NT>() + NM * NP * 32 * ET_AHB; }
+
+__device__ __forceinline__ u32x2 ew_read_tr16(const unsigned char* p) {
+    using v4s = __attribute__((ext_vector_type(4))) short;
+    const v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <class Fn, int... S>
+__device__ __forceinline__ void ew_for_slots(Fn&& fn, std::integer_sequence<int, S...>) {
+    (fn(std::integral_constant<int, S>{}), ...);
+}
+
+// CT: 16-channel demb tiles of the workgroup (8: every wave walks all frames; 4: two waves per tile take alternate frames, added at the
+// end); NT: 16-channel tiles of x (4 or 8); NSLOT: frame slots of a wave per tile, compile time (straight-line code: exact request counts);
+// NM: matrix slots in LDS (the (subset, side) groups the workgroup's channels touch: 2, or 6 for ic = 16)
+template <int NP, int CT, int NT, int NSLOT, int NM>
+__global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
+    constexpr int FP = 8 / CT;
+    constexpr int RS = ew_rs<NT>(), PL = EW_ROWS * RS;
+    constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = EW_ROWS / RPP;      // 16-byte groups per row, rows per pass, passes
+    static_assert(EW_ROWS % RPP == 0 && NSLOT % 2 == 0, "staging passes / slot pairs");
+    constexpr int SPREAD = NSLOT > 2 ? NSLOT - 2 : 1;                // the next tile's x rows are requested in pieces over the slots
+    extern __shared__ __attribute__((aligned(16))) unsigned char ew_lds_raw[];
+    unsigned char* Im = ew_lds_raw;
+    unsigned char* Ah = ew_lds_raw + NP * PL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4, q4 = l15 >> 2, c4 = lane & 3;
+    const int ct = wave % CT, fp = wave / CT;
+    const int combos = p.n_cg * p.n_og;
+    const int seg = blockIdx.x / combos, combo = blockIdx.x - seg * combos;
+    const int cgi = combo / p.n_og, ogi = combo - cgi * p.n_og;
+    const int cg0 = cgi * 16 * CT;                                   // first demb channel of the workgroup
+    const int c0 = cg0 + 16 * ct, o0 = ogi * 16 * NT;
+    const bool active = c0 < p.Ce;                                   // (wave-uniform) this wave's channel tile exists
+    const int g_lo = cg0 / p.ic, gq = (active ? c0 : cg0) / p.ic;
+    const int ms = gq - g_lo;                                        // matrix slot (< NM: checked by the launcher)
+    const int csrc = c0 + ((gq & 1) ? -p.ic : p.ic);                 // the partner group's channels
+    const int V = p.V, F = p.F;
+    const int t_lo = seg * p.tps, t_hi = min(t_lo + p.tps, p.gtiles);
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)p.emb, 0, p.e_bytes, 0x00020000);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int srow = tid / GPR, sg = tid % GPR;
+    f32x4 stg[NPASS];
+    // pass i of the x rows of (sample, tile) pair g (nothing past the segment: branch-free)
+    auto fetch_pass = [&](int g, int i) {
+        const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
+        const int t0_ = tile_ * F;
+        const int nrows_ = g < t_hi ? min(F, p.T - t0_) * V : 0;
+        const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
+        const int r = srow + RPP * i;
+        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_x + (unsigned)(o0 + 4 * sg)) * 4u : ET_OOB;
+        stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    };
+    // emb values of frame slot s of pair g for this wave: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][csrc + l15], j = 0 .. 7
+    float xr[8];
+    auto xfetch = [&](int g, int s) {
+        const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
+        const int t0_ = tile_ * F, f = fp + FP * s;
+        const int vlim = (active && g < t_hi && f < min(F, p.T - t0_)) ? V : 0;      // (a scalar select: no frame, no joints)
+        const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_e + (unsigned)((active ? csrc : 0) + l15);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_e)) * 4u : ET_OOB;
+            xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, off, 0, 0));
+        }
+    };
+    auto planes = [&](int n) { et_stage_planes<NP, 512>(Ah, p.d_s + (p.s_batched ? (long long)n * 3 * V * V : 0), V, g_lo, NM, tid); };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = srow + RPP * i;
+            u32x2 parts[NP];
+            splitn_x4<NP>(stg[i], parts);
+            unsigned char* dst = Im + r * RS + sg * 8;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PL) = parts[pl];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) fetch_pass(t_lo, i);
+    xfetch(t_lo, 0);
+    if (t_lo < t_hi) planes(t_lo / p.tiles_t);
+    deposit();
+    __syncthreads();
+
+    for (int g = t_lo; g < t_hi; ++g) {
+        const int n = g / p.tiles_t, tile = g - n * p.tiles_t;
+        const int nf = min(F, p.T - tile * F);
+        auto slot = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            const int f = fp + FP * s;
+            u32x4v xs[NP];
+            splitn_x8<NP>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
+            if constexpr (s + 1 < NSLOT) xfetch(g, s + 1);           // the next slot of this tile, or the first of the next tile
+            else xfetch(g + 1, s + 1 - NSLOT);
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i)
+                if (i * SPREAD / NPASS == s) fetch_pass(g + 1, i);
+            if (f >= nf || !active) return;                          // wave-uniform: no such frame in this tile / no such channel tile
+            f32x4 m[2];
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) {
+                u32x4v af[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((ms * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
+                // demb_f (32 joints w x 16 channels): lane (c = l15, g4) holds joints w = 4 g4 + r (wt = 0) and 16 + 4 g4 + r (wt = 1)
+                m[wt] = mfma_np_k32<NP>(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            bsum += ((m[0][0] + m[0][1]) + (m[0][2] + m[0][3])) + ((m[1][0] + m[1][1]) + (m[1][2] + m[1][3]));   // joints >= V are exact zeros
+            u32x4v a3[NP];
+            splitn_x8<NP>(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3);
+            const int r_lo = f * V + 4 * g4 + q4, r_hi = r_lo + 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4v df[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const unsigned char* base = Im + pl * PL + nt * 32 + 8 * c4;
+                    const u32x2 lo = ew_read_tr16(base + r_lo * RS);
+                    const u32x2 hi = ew_read_tr16(base + r_hi * RS);
+                    df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+                }
+                acc[nt] = mfma_np_k32<NP>(a3, df, acc[nt]);
+            }
+        };
+        ew_for_slots(slot, std::make_integer_sequence<int, NSLOT>{});
+        // the next tile's x rows (and its sample's matrix planes) replace this one's
+        __syncthreads();                                             // this tile's fragment reads are done
+        const int n1 = (g + 1) / p.tiles_t;
+        if (g + 1 < t_hi && n1 != n && p.s_batched) planes(n1);
+        deposit();
+        __syncthreads();
+    }
+
+    // ---- the workgroup's slabs: partial[seg][c][o], bias_partial[seg][c] ---------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias_partial, 0, p.b_bytes, 0x00020000);
+    float bs = bsum + __shfl_xor(bsum, 16);                          // the four joint groups of a channel, fixed order
+    bs += __shfl_xor(bs, 32);
+    if constexpr (FP == 2) {                                         // fixed order: frames of the even slots + frames of the odd slots
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ew_lds_raw);           // [ct][nt][r][lane], then [ct][16]
+        float* redb = red + CT * NT * 4 * 64;
+        if (fp == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((ct * NT + nt) * 4 + r) * 64 + lane] = acc[nt][r];
+            if (lane < 16) redb[ct * 16 + lane] = bs;
+        }
+        __syncthreads();
+        if (fp == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] += red[((ct * NT + nt) * 4 + r) * 64 + lane];
+        bs += redb[ct * 16 + l15];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned off = active ? (((unsigned)seg * (unsigned)p.Ce + (unsigned)(c0 + 4 * g4 + r)) * (unsigned)p.Cx + (unsigned)(o0 + 16 * nt + l15)) * 4u : ET_OOB;
+            const float val = acc[nt][r];                            // (a bit_cast of the vector-element lvalue itself reads element 0: hipcc 7.2)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
+        }
+    {
+        const unsigned off = (active && ogi == 0 && lane < 16) ? ((unsigned)seg * (unsigned)p.Ce + (unsigned)(c0 + l15)) * 4u : ET_OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bs), rb, off, 0, 0);
+    }
+}
+
+// frames per tile of the weight-gradient kernel: as many whole frames as keep a 32-joint fragment of the last one inside EW_ROWS rows, at most 8
+static int ew_frames(int V) { return std::max(1, std::min(8, (EW_ROWS - 32) / V + 1)); }
+
+struct EwGeom {
+    int CT, NT, NM, F, tiles_t, gtiles, tps, nseg, n_cg, n_og;
+    bool ok;
+};
+static EwGeom ew_geom(int B, int T, int V, int ic, int Cx) {
+    EwGeom g;
+    const int Ce = 6 * ic;
+    if (ic < 32) {                                                   // ic = 16: all six groups in one 128-channel workgroup (two idle waves)
+        g.CT = 8, g.NM = 6, g.NT = 4;
+    } else {
+        g.CT = (Ce % 128 == 0 && ic % 64 == 0) ? 8 : 4;
+        g.NM = 2;
+        g.NT = Cx % 128 == 0 ? 8 : 4;
+    }
+    g.F = ew_frames(V);
+    g.tiles_t = (int)cdiv(T, g.F);
+    g.gtiles = B * g.tiles_t;
+    g.n_cg = (int)cdiv(Ce, 16 * g.CT);
+    g.n_og = Cx / (16 * g.NT);
+    // every workgroup's channels must touch at most NM (subset, side) groups
+    g.ok = true;
+    for (int cg = 0; cg < g.n_cg; ++cg) {
+        const int lo = cg * 16 * g.CT, hi = std::min(lo + 16 * g.CT, Ce) - 1;
+        if (hi / ic - lo / ic + 1 > g.NM) g.ok = false;
+    }
+    const int want = std::max(1, (fgcn::tuning(17) > 0 ? fgcn::tuning(17) : 256) / (g.n_cg * g.n_og));   // one workgroup per CU
+    g.tps = (int)cdiv(g.gtiles, std::min(g.gtiles, want));
+    g.nseg = (int)cdiv(g.gtiles, g.tps);
+    return g;
+}
+
+static bool emb_tile_mode_ok() { return fgcn::math_mode() == FGCN_MATH_BF16X3 || fgcn::math_mode() == FGCN_MATH_BF16; }
+static bool emb_tile_sizes_ok(int V, int ic, int Cx) {
+    return V >= 16 && V <= FGCN_MAX_V && ic >= 16 && ic % 16 == 0 && Cx >= 64 && Cx % 64 == 0;
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+// 1 when fgcn_emb_dx_tile / fgcn_emb_wgrad_tile run these sizes in the current math mode (FGCN_MATH_BF16X3 with either product form -- the
+// kernels always multiply three-way bf16 splits there -- or FGCN_MATH_BF16; 16 .. 32 joints; ic a multiple of 16; Cx in 64s)
+extern "C" int fgcn_emb_tile_available(int V, int ic, int Cx) {
+    if (!emb_tile_mode_ok() || !emb_tile_sizes_ok(V, ic, Cx)) return 0;
+    return ew_geom(1, 1, V, ic, Cx).ok ? 1 : 0;
+}
+
+extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, int B, int T, int V, int ic, int Cx, int ld_e,
+                                int ld_dx, int d_s_batched, int accumulate, void* stream) {
+    FGCN_REQUIRE(emb && d_s && w3 && dx, FGCN_E_BADARG, "emb_dx_tile: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_dx_tile: bad sizes B=%d T=%d", B, T);
+    FGCN_REQUIRE(emb_tile_mode_ok() && emb_tile_sizes_ok(V, ic, Cx), FGCN_E_BADARG,
+                 "emb_dx_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx %% 64 == 0 (V=%d ic=%d Cx=%d, mode %d)", FGCN_MAX_V, V,
+                 ic, Cx, fgcn::math_mode());
+    const int Ce = 6 * ic;
+    FGCN_REQUIRE(ld_e % 4 == 0 && ld_dx % 4 == 0 && ld_e >= Ce && ld_dx >= Cx, FGCN_E_ALIGN, "emb_dx_tile: row strides");
+    FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
+                 "emb_dx_tile: 16-byte alignment");
+    const long long e_bytes = (long long)B * T * V * ld_e * 4, dx_bytes = (long long)B * T * V * ld_dx * 4;
+    const long long plane = (long long)Ce * Cx * 2;
+    FGCN_REQUIRE(e_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "emb_dx_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    const int np = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3;
+    EmbDxP p;
+    p.emb = emb; p.d_s = d_s; p.w3 = w3; p.dx = dx;
+    p.B = B; p.T = T; p.V = V; p.ic = ic; p.Ce = Ce; p.Cout = Cx; p.ld_e = ld_e; p.ld_dx = ld_dx; p.s_batched = d_s_batched;
+    p.F = 128 / V;
+    p.tiles_t = (int)cdiv(T, p.F);
+    p.tiles_m = B * p.tiles_t;
+    const bool narrow = Cx <= 64;
+    p.tiles_n = (int)cdiv(Cx, narrow ? 64 : 128);
+    const long long total = (long long)p.tiles_m * p.tiles_n;
+    FGCN_REQUIRE(total < (1ll << 30), FGCN_E_BADARG, "emb_dx_tile: too many tiles");
+    p.per_xcd = (int)cdiv(total, 8);
+    p.e_bytes = (unsigned)e_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
+    const dim3 grid((unsigned)(p.per_xcd * 8));
+    hipStream_t s = (hipStream_t)stream;
+    const bool big = 2 * p.F > 12;                                   // mixing units per wave and chunk: ceil(2 F / 4)
+#define FGCN_ED_GO4(NP_, NT_, MU_, ACC_)                                                                             \
+    do {                                                                                                             \
+        static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
+        if (!opted) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP_, NT_, MU_, ACC_>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP_>());                    \
+            opted = true;                                                                                            \
+        }                                                                                                            \
+        hipLaunchKernelGGL((emb_dx_tile_kernel<NP_, NT_, MU_, ACC_>), grid, dim3(256), ed_lds<NP_>(), s, p);          \
+    } while (0)
+#define FGCN_ED_GO3(NP_, NT_, MU_)                     \
+    do {                                               \
+        if (accumulate) FGCN_ED_GO4(NP_, NT_, MU_, true); \
+        else FGCN_ED_GO4(NP_, NT_, MU_, false);        \
+    } while (0)
+#define FGCN_ED_GO2(NP_, NT_)                  \
+    do {                                       \
+        if (big) FGCN_ED_GO3(NP_, NT_, 4);     \
+        else FGCN_ED_GO3(NP_, NT_, 3);         \
+    } while (0)
+#define FGCN_ED_GO(NP_)                        \
+    do {                                       \
+        if (narrow) FGCN_ED_GO2(NP_, 1);       \
+        else FGCN_ED_GO2(NP_, 2);              \
+    } while (0)
+    if (np == 3) FGCN_ED_GO(3);
+    else FGCN_ED_GO(1);
+#undef FGCN_ED_GO
+#undef FGCN_ED_GO2
+#undef FGCN_ED_GO3
+#undef FGCN_ED_GO4
+    return launch_status("emb_dx_tile");
+}
+
+// slabs of `partial` / `bias_partial` (0: sizes the kernel does not take)
+extern "C" int fgcn_emb_wgrad_tile_slabs(int B, int T, int V, int ic, int Cx) {
+    if (B <= 0 || T <= 0 || !emb_tile_sizes_ok(V, ic, Cx)) return 0;
+    const EwGeom g = ew_geom(B, T, V, ic, Cx);
+    return g.ok ? g.nseg : 0;
+}
+
+extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
+                                   int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream) {
+    FGCN_REQUIRE(emb && x && d_s && partial && bias_partial, FGCN_E_BADARG, "emb_wgrad_tile: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_wgrad_tile: bad sizes B=%d T=%d", B, T);
+    FGCN_REQUIRE(fgcn_emb_tile_available(V, ic, Cx), FGCN_E_BADARG,
+                 "emb_wgrad_tile: V=%d ic=%d Cx=%d in math mode %d not supported (bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx in 64s)", V, ic,
+                 Cx, fgcn::math_mode(), FGCN_MAX_V);
+    const int Ce = 6 * ic;
+    FGCN_REQUIRE(ld_e >= Ce && ld_x >= Cx && ld_x % 4 == 0, FGCN_E_BADARG, "emb_wgrad_tile: bad row strides ld_e=%d ld_x=%d", ld_e, ld_x);
+    FGCN_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(emb) & 3u) == 0 && (reinterpret_cast<uintptr_t>(partial) & 3u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(bias_partial) & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0,
+                 FGCN_E_ALIGN, "emb_wgrad_tile: x must be 16-byte aligned (emb, d_s, partial, bias_partial: 4)");
+    const long long rows = (long long)B * T * V;
+    FGCN_REQUIRE(rows * ld_e * 4 < (1ll << 31) && rows * ld_x * 4 < (1ll << 31), FGCN_E_BADARG, "emb_wgrad_tile: tensors must be smaller than 2 GiB");
+    const EwGeom g = ew_geom(B, T, V, ic, Cx);
+    FGCN_REQUIRE((long long)g.nseg * Ce * Cx * 4 < (1ll << 31), FGCN_E_BADARG, "emb_wgrad_tile: partial slabs must be smaller than 2 GiB");
+    const int np = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3;
+    EmbWgP p;
+    p.emb = emb, p.x = x, p.d_s = d_s, p.partial = partial, p.bias_partial = bias_partial;
+    p.B = B, p.T = T, p.V = V, p.ic = ic, p.Ce = Ce, p.Cx = Cx, p.ld_e = ld_e, p.ld_x = ld_x, p.s_batched = d_s_batched;
+    p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
+    p.e_bytes = (unsigned)(rows * ld_e * 4), p.x_bytes = (unsigned)(rows * ld_x * 4);
+    p.p_bytes = (unsigned)((long long)g.nseg * Ce * Cx * 4), p.b_bytes = (unsigned)((long long)g.nseg * Ce * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
+#define FGCN_EW(NP_, CT_, NT_, NS_, NM_)                                                                                          \
+    do {                                                                                                                          \
+        static bool attr = false;                                                                                                 \
+        constexpr int lds_ = ew_lds<NP_, NT_, NM_>();                                                                             \
+        if (!attr) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                          \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_>), grid, dim3(512), lds_, s, p);                        \
+    } while (0)
+    // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
+    const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;
+    FGCN_REQUIRE(nslot == (g.CT == 8 ? (g.F > 6 ? 8 : 6) : 4), FGCN_E_BADARG, "emb_wgrad_tile: %d frames per tile: no such kernel form", g.F);
+#define FGCN_EW_NP(CT_, NT_, NS_, NM_)                     \
+    do {                                                   \
+        if (np == 3) FGCN_EW(3, CT_, NT_, NS_, NM_);       \
+        else FGCN_EW(1, CT_, NT_, NS_, NM_);               \
+    } while (0)
+    if (g.NM == 6) {                                                 // ic = 16
+        if (nslot == 8) FGCN_EW_NP(8, 4, 8, 6);
+        else FGCN_EW_NP(8, 4, 6, 6);
+    } else if (g.CT == 8) {
+        if (g.NT == 8) {
+            if (nslot == 8) FGCN_EW_NP(8, 8, 8, 2);
+            else FGCN_EW_NP(8, 8, 6, 2);
+        } else {
+            if (nslot == 8) FGCN_EW_NP(8, 4, 8, 2);
+            else FGCN_EW_NP(8, 4, 6, 2);
+        }
+    } else {
+        if (g.NT == 8) FGCN_EW_NP(4, 8, 4, 2);
+        else FGCN_EW_NP(4, 4, 4, 2);
+    }
+#undef FGCN_EW_NP
+#undef FGCN_EW
+    return launch_status("emb_wgrad_tile");
+}

@@ -1019,6 +1019,62 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     return partial
 
 
+def emb_tile_available(V: int, ic: int, cx: int) -> bool:
+    """Whether ``emb_dx_tile`` / ``emb_wgrad_tile`` run these sizes in the current math mode (bf16x3, f16x2 -- the kernels multiply
+    three-way bf16 splits in both -- or bf16; 16 <= V <= 32, ic % 16 == 0, cx % 64 == 0)."""
+    return bool(_lib.load().fgcn_emb_tile_available(int(V), int(ic), int(cx)))
+
+
+def _chk_emb(name: str, emb: torch.Tensor, d_s: torch.Tensor, ic: int) -> None:
+    _chk(emb, f"{name}.emb"), _chk(d_s, f"{name}.d_s")
+    B, T, V, ld_e = emb.shape
+    if ld_e < 6 * ic or d_s.shape[0] not in (1, B) or tuple(d_s.shape[1:]) != (3, V, V):
+        raise _lib.FgcnError(f"{name}: shape mismatch emb={tuple(emb.shape)} d_s={tuple(d_s.shape)} ic={ic}")
+
+
+def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torch.Tensor, *, ic: int, accumulate: bool,
+                cx: Optional[int] = None) -> torch.Tensor:
+    """dx (+)= demb . Wemb^T with the embedding gradient demb (d theta_k = dS_k . phi_k, d phi_k = dS_k^T . theta_k) formed on chip
+    (fgcn_emb_tile.hip; backward of agcn.py:104-106).  emb (B,T,V,>=6 ic) = [th0 ph0 th1 ph1 th2 ph2], d_s (B or 1, 3, V, V),
+    w3 = ``pack_split3`` of the (1, 6 ic, cx) matrix [j][c] = Wemb[j][c], dx (B,T,V,>=cx)."""
+    ensure_device()
+    _chk_emb("emb_dx_tile", emb, d_s, ic)
+    _chk(dx, "emb_dx_tile.dx")
+    B, T, V, ld_e = emb.shape
+    cx = dx.shape[3] if cx is None else int(cx)
+    if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, 6 * ic // 8, cx, 8) or not w3.is_contiguous()
+            or tuple(dx.shape[:3]) != (B, T, V) or dx.shape[3] < cx):
+        raise _lib.FgcnError(f"emb_dx_tile: shape mismatch emb={tuple(emb.shape)} dx={tuple(dx.shape)} w3={tuple(w3.shape)} "
+                             f"(weights: pack_split3 of the (1, 6 ic, cx) matrix)")
+    check(_lib.load().fgcn_emb_dx_tile(_p(emb), _p(d_s), w3.data_ptr(), _p(dx), B, T, V, ic, cx, ld_e, dx.shape[3],
+                                       int(d_s.shape[0] != 1), int(accumulate), _stream()), "fgcn_emb_dx_tile")
+    return dx
+
+
+def emb_wgrad_tile(emb: torch.Tensor, x: torch.Tensor, d_s: torch.Tensor, *, ic: int, cx: Optional[int] = None):
+    """-> (dWemb (6 ic, cx) = demb^T . x in the parameters' (out, in) order, dbemb (6 ic,) = column sums of demb), demb formed on chip
+    (see ``emb_dx_tile``).  x (B,T,V,>=cx): the embedding convolutions' input."""
+    ensure_device()
+    _chk_emb("emb_wgrad_tile", emb, d_s, ic)
+    _chk(x, "emb_wgrad_tile.x")
+    B, T, V, ld_e = emb.shape
+    cx = x.shape[3] if cx is None else int(cx)
+    if tuple(x.shape[:3]) != (B, T, V) or x.shape[3] < cx:
+        raise _lib.FgcnError(f"emb_wgrad_tile: shape mismatch emb={tuple(emb.shape)} x={tuple(x.shape)} cx={cx}")
+    lib = _lib.load()
+    slabs = lib.fgcn_emb_wgrad_tile_slabs(B, T, V, ic, cx)
+    if slabs <= 0:
+        raise _lib.FgcnError(f"emb_wgrad_tile: sizes not supported: V={V} ic={ic} cx={cx}")
+    partial = torch.empty((slabs, 1, 6 * ic, cx), device=x.device, dtype=torch.float32)
+    bpart = torch.empty((slabs, 6 * ic), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_emb_wgrad_tile(_p(emb), _p(x), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
+                                  int(d_s.shape[0] != 1), _stream()), "fgcn_emb_wgrad_tile")
+    gw = _reduce_slabs(partial, 1, 6 * ic, cx, None, False, None)[0]
+    gb = torch.empty((6 * ic,), device=x.device, dtype=torch.float32)
+    reduce_sum(bpart, gb, leaf=True)
+    return gw, gb
+
+
 def transpose(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
     """(B, R, C) -> (B, C, ld_out) with out[b, c, r] = x[b, r, c] and the columns [R, ld_out) zero-filled (ld_out >= R)."""
     ensure_device()

@@ -61,7 +61,8 @@ int fgcn_check_device(void);
  *   12 joint gram of three equal-width items: 1 = the generic kernel (default: joint_gram3_kernel)
  *   13 fgcn_spatial_wgrad: workgroups to aim for (0 = 512 up to 32 samples, 1024 above)
  *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`)
- *   16 fgcn_spatial_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count) */
+ *   16 fgcn_spatial_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
+ *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count) */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
@@ -488,6 +489,29 @@ int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat,
                             int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream);
 int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int Cout);
 int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
+
+/* Backward of the attention embeddings with the embedding gradient on chip (fgcn_emb_tile.hip; reference: the autograd backward of
+ * SpatialGraphConv.forward through A1 = conv_a[k](x), A2 = conv_b[k](x), softmax(A1^T A2 / (ic T)), torch_src/models/mmargcn/agcn.py:104-106).
+ *   emb: (B, T, V, ld_e) rows [th0 ph0 th1 ph1 th2 ph2], each `ic` channels wide (the 6 ic outputs of the stacked 1x1 embedding);
+ *   d_s: float[B or 1][3][V][V], the gradient in front of the column softmax (fgcn_adj_softmax_bwd's dS, scale folded in);
+ *   demb[(n,t,v), th_k + e] = sum_w dS_k[v][w] emb[(n,t,w), ph_k + e],  demb[(n,t,w), ph_k + e] = sum_v dS_k[v][w] emb[(n,t,v), th_k + e]
+ * is formed per frame on the matrix pipe inside both kernels and never written:
+ *   fgcn_emb_dx_tile     dx[(n,t,v), 0:Cx] (+)= demb[(n,t,v), :] . Wemb^T, w3 = fgcn_pack_split3 of the (1, 6 ic, Cx) matrix [j][c] = Wemb[j][c]
+ *                        (accumulate: dx += ...);
+ *   fgcn_emb_wgrad_tile  partial[s][j][c] = sum over the rows of slab s of demb[row, j] x[row, c]  (float[slabs][6 ic][Cx]: already the
+ *                        parameters' (out, in) order) and bias_partial[s][j] = sum of demb[row, j] (float[slabs][6 ic]); the caller adds the
+ *                        fgcn_emb_wgrad_tile_slabs(B, T, V, ic, Cx) slabs (fgcn_reduce_multi).
+ * Sizes: 16 <= V <= FGCN_MAX_V, ic a multiple of 16, Cx a multiple of 64; math modes FGCN_MATH_BF16X3 (either product form: the kernels
+ * always multiply exact three-way bf16 splits, the mixing included) and FGCN_MATH_BF16 (operands rounded to bfloat16 once):
+ * fgcn_emb_tile_available.  Replaces fgcn_joint_mix_vec(demb) + fgcn_pw_gemm / fgcn_rows_gemm(demb . W) + fgcn_pw_wgrad(x, demb) and the
+ * 1.5-activation-wide demb tensor between them.  Every sum has a fixed order.
+ * Tuning key 17: fgcn_emb_wgrad_tile workgroups to aim for (0 = 256; sets the slab count). */
+int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, int B, int T, int V, int ic, int Cx, int ld_e, int ld_dx,
+                     int d_s_batched, int accumulate, void* stream);
+int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T, int V, int ic,
+                        int Cx, int ld_e, int ld_x, int d_s_batched, void* stream);
+int fgcn_emb_wgrad_tile_slabs(int B, int T, int V, int ic, int Cx);
+int fgcn_emb_tile_available(int V, int ic, int Cx);
 
 /* ---- 1-D graph convolutions on IMU graphs --------------------------------------------------- */
 /* Batched transpose between the node-major (B, V, F) and feature-major (B, F, V) images of an activation:

@@ -208,3 +208,33 @@ def test_spatial_wgrad_bf16(V, cin, cout):
     want = torch.einsum("btwkc,btwo->kco", bf(agg), bf(dy)).reshape(3 * cin, cout)
     got = ops.spatial_wgrad(gpu(x), gpu(dy), gpu(a))
     assert rel_l2(got[0].cpu().numpy(), want.numpy()) < 2e-3      # a few agg values round to the neighbouring bf16
+
+
+@pytest.mark.parametrize("V,T,ic,cx,B", [(25, 13, 16, 64, 2), (25, 7, 64, 256, 2), (27, 9, 32, 64, 1), (18, 10, 32, 128, 2), (22, 31, 64, 128, 1)])
+def test_embedding_backward_tile_form_bf16(V, T, ic, cx, B):
+    """fgcn_emb_dx_tile / fgcn_emb_wgrad_tile with ONE bf16 part (FGCN_MATH_BF16; reference agcn.py:104-106 under the mixed-precision
+    step, session/procedures/step.py:55-78): emb, dS, the on-chip embedding gradient, x and the weights are each rounded to bfloat16
+    once, products accumulate in float32 -- against the float64 formulas on operands rounded the same way."""
+    from fusion_gcn_amd import ops
+    assert ops.emb_tile_available(V, ic, cx)
+    emb, ds = rnd(B, T, V, 6 * ic, seed=350), rnd(B, 3, V, V, seed=351, scale=0.3)
+    x, base = rnd(B, T, V, cx, seed=352), rnd(B, T, V, cx, seed=353)
+    w = rnd(6 * ic, cx, seed=354, scale=(6 * ic) ** -0.5)
+    e = bf(emb).reshape(B, T, V, 3, 2, ic)
+    theta, phi = e[..., 0, :], e[..., 1, :]
+    dtheta = torch.einsum("bkvw,btwke->btvke", bf(ds), phi)
+    dphi = torch.einsum("bkvw,btvke->btwke", bf(ds), theta)
+    demb = torch.stack([dtheta, dphi], dim=4).reshape(B, T, V, 6 * ic)
+    # the kernel rounds the float32 mixing result; the float64 one rounds differently in a few last bits: 2^-9 relative per element
+    want_dx = base + bf(demb) @ bf(w)
+    want_w = torch.einsum("btvj,btvc->jc", bf(demb), bf(x))
+    w3 = ops.pack_split3(gpu(w.reshape(1, 6 * ic, cx)))
+    dx = gpu(base)
+    ops.emb_dx_tile(gpu(emb), gpu(ds), w3, dx, ic=ic, accumulate=True)
+    assert rel_l2(dx.cpu().numpy(), want_dx.numpy()) < 2e-4
+    gw, gb = ops.emb_wgrad_tile(gpu(emb), gpu(x), gpu(ds), ic=ic)
+    assert rel_l2(gw.cpu().numpy(), want_w.numpy()) < 2e-4
+    assert rel_l2(gb.cpu().numpy(), demb.sum((0, 1, 2)).numpy()) < TOL       # the bias gradient sums the float32 mixing result itself
+    dx2 = gpu(base)
+    ops.emb_dx_tile(gpu(emb), gpu(ds), w3, dx2, ic=ic, accumulate=True)
+    assert torch.equal(dx, dx2)

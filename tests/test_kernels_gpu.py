@@ -708,6 +708,91 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert rel_l2(par.cpu().numpy().reshape(3, cout, cin - 3), want_p.numpy()) < RED_TOL
 
 
+def emb_backward_reference(emb, ds, x, w, ic):
+    """float64 backward of the attention embeddings (agcn.py:104-106): -> demb, demb . W, demb^T . x, column sums of demb."""
+    B, T, V, _ = emb.shape
+    e = emb.reshape(B, T, V, 3, 2, ic)
+    theta, phi = e[..., 0, :], e[..., 1, :]                                  # (B,T,V,3,ic)
+    dtheta = torch.einsum("bkvw,btwke->btvke", ds, phi)
+    dphi = torch.einsum("bkvw,btvke->btwke", ds, theta)
+    demb = torch.stack([dtheta, dphi], dim=4).reshape(B, T, V, 6 * ic)
+    return demb, demb @ w, torch.einsum("btvj,btvc->jc", demb, x), demb.sum((0, 1, 2))
+
+
+EMB_TILE_SHAPES = [(25, 13, 16, 64, 2), (25, 7, 64, 256, 2), (27, 9, 32, 64, 1), (18, 10, 16, 64, 2), (16, 8, 32, 128, 1), (32, 5, 64, 128, 1),
+                   (22, 31, 64, 256, 1), (25, 300, 16, 64, 1), (17, 23, 48, 128, 2), (21, 12, 32, 128, 3), (25, 20, 16, 128, 3),
+                   (19, 2, 128, 64, 2)]
+
+
+@pytest.mark.parametrize("V,T,ic,cx,B", EMB_TILE_SHAPES)
+def test_embedding_backward_tile_form(V, T, ic, cx, B):
+    """The backward of the attention embeddings with demb on chip (fgcn_emb_tile.hip; reference agcn.py:104-106): dx (+)= demb . Wemb and
+    dWemb = demb^T . x, dbemb = column sums of demb against the float64 formulas -- ic = 16 / 32 / 48 / 64 / 128 (one, two or four
+    (subset, side) groups per 64 channels, a partial last channel group), ragged last frame groups, 4 .. 8 frames per tile, one and two
+    column tiles, per-sample and shared dS, with and without accumulation, other segmentations of the weight gradient (tuning key 17);
+    bitwise reproducible; agrees with the unfused chain joint_mix_vec + row GEMM + row weight gradient."""
+    from fusion_gcn_amd import _lib, block, ops
+    if not ops.emb_tile_available(V, ic, cx):
+        pytest.skip("the tile form runs in the split-bf16 math modes")
+    emb, ds = rnd(B, T, V, 6 * ic, seed=350), rnd(B, 3, V, V, seed=351, scale=0.3)
+    x, base = rnd(B, T, V, cx, seed=352), rnd(B, T, V, cx, seed=353)
+    w = rnd(6 * ic, cx, seed=354, scale=(6 * ic) ** -0.5)                        # Wemb[j][c]
+    demb, want_dx, want_w, want_b = emb_backward_reference(emb, ds, x, w, ic)
+    w3 = ops.pack_split3(to_gpu(w.reshape(1, 6 * ic, cx)))
+    outs = []
+    for acc in (False, True):
+        dx = to_gpu(base) if acc else torch.full((B, T, V, cx), float("nan"), device=dev())   # without accumulation every element is written
+        ops.emb_dx_tile(to_gpu(emb), to_gpu(ds), w3, dx, ic=ic, accumulate=acc)
+        assert rel_l2(dx.cpu().numpy(), (want_dx + (base if acc else 0)).numpy()) < FWD_TOL, acc
+        outs.append(dx)
+    dx2 = to_gpu(base)
+    ops.emb_dx_tile(to_gpu(emb), to_gpu(ds), w3, dx2, ic=ic, accumulate=True)
+    assert torch.equal(dx2, outs[1])
+    gw, gb = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds), ic=ic)
+    assert tuple(gw.shape) == (6 * ic, cx) and tuple(gb.shape) == (6 * ic,)
+    assert rel_l2(gw.cpu().numpy(), want_w.numpy()) < RED_TOL
+    assert rel_l2(gb.cpu().numpy(), want_b.numpy()) < RED_TOL
+    gw2, gb2 = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds), ic=ic)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    lib = _lib.load()
+    slabs = {0: lib.fgcn_emb_wgrad_tile_slabs(B, T, V, ic, cx)}
+    for target in (2, 100000):                  # one or two long segments (several samples each) / one (sample, tile) pair per workgroup
+        try:
+            assert lib.fgcn_set_tuning(17, target) == 0
+            slabs[target] = lib.fgcn_emb_wgrad_tile_slabs(B, T, V, ic, cx)
+            g2, b2 = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds), ic=ic)
+        finally:
+            assert lib.fgcn_set_tuning(17, 0) == 0
+        assert rel_l2(g2.cpu().numpy(), want_w.numpy()) < RED_TOL, target
+        assert rel_l2(b2.cpu().numpy(), want_b.numpy()) < RED_TOL, target
+    assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs
+    # shared dS (one matrix set for every sample)
+    _, sh_dx, sh_w, sh_b = emb_backward_reference(emb, ds[:1].expand(B, 3, V, V), x, w, ic)
+    dx = torch.empty(B, T, V, cx, device=dev())
+    ops.emb_dx_tile(to_gpu(emb), to_gpu(ds[:1]), w3, dx, ic=ic, accumulate=False)
+    assert rel_l2(dx.cpu().numpy(), sh_dx.numpy()) < FWD_TOL
+    gws, gbs = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds[:1]), ic=ic)
+    assert rel_l2(gws.cpu().numpy(), sh_w.numpy()) < RED_TOL and rel_l2(gbs.cpu().numpy(), sh_b.numpy()) < RED_TOL
+    # the unfused chain on the same data
+    demb_g = torch.empty(B, T, V, 6 * ic, device=dev())
+    sums = block.mix_demb(to_gpu(emb), demb_g, to_gpu(ds), ic)
+    dx_old = to_gpu(base)
+    ops.rows_gemm(demb_g, to_gpu(w.reshape(1, 6 * ic, cx)), dx_old, K=6 * ic, N=cx, accumulate=True)
+    assert rel_l2(outs[1].cpu().numpy(), dx_old.cpu().numpy()) < FWD_TOL
+    assert rel_l2(gb.cpu().numpy(), sums.cpu().numpy()) < RED_TOL
+    gw_old = ops.rows_wgrad(to_gpu(x), demb_g, K=cx, N=6 * ic)[0]               # (cx, 6 ic)
+    assert rel_l2(gw.cpu().numpy(), gw_old.t().cpu().numpy()) < RED_TOL
+    # rows wider than the channels that take part (row strides of the C ABI)
+    wide_e, wide_x = torch.zeros(B, T, V, 6 * ic + 8, device=dev()), torch.zeros(B, T, V, cx + 4, device=dev())
+    wide_e[..., :6 * ic], wide_x[..., :cx] = to_gpu(emb), to_gpu(x)
+    wide_dx = torch.zeros(B, T, V, cx + 4, device=dev())
+    wide_dx[..., :cx] = to_gpu(base)
+    ops.emb_dx_tile(wide_e, to_gpu(ds), w3, wide_dx, ic=ic, accumulate=True, cx=cx)
+    assert torch.equal(wide_dx[..., :cx].contiguous(), outs[1]) and float(wide_dx[..., cx:].abs().max()) == 0.0
+    gww, gbw = ops.emb_wgrad_tile(wide_e, wide_x, to_gpu(ds), ic=ic, cx=cx)
+    assert torch.equal(gww, gw) and torch.equal(gbw, gb)
+
+
 @pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
 def test_halo_data_gradient_emits_the_batchnorm_backward_sums(B, T, V, C, fgcn_math):
     """fgcn_tconv_halo with bn_a / bn_mask / bn_vec: the data gradient dG and, from its epilogue, sum dP and sum dP * a_hat with

@@ -232,6 +232,48 @@ def bench_spatial_bwd(B, reps):
                4.0 * rows * (9 * cin + cout))
 
 
+def bench_emb_bwd(B, reps):
+    """Backward of the attention embeddings: the two tile kernels (demb on chip) vs joint_mix_vec(demb) + the 1x1 data gradient + the 1x1
+    weight gradient, at the headline model's (T, cin, ic) of blocks l1-l3, l4, l5-l6, l7, l8-l9."""
+    for T, cin, ic in ((300, 64, 16), (300, 64, 32), (150, 128, 32), (150, 128, 64), (75, 256, 64)):
+        ce = 6 * ic
+        emb, x, ds = rnd(B, T, V, ce), rnd(B, T, V, cin), rnd(B, 3, V, V) * 0.2
+        dx, demb = rnd(B, T, V, cin), torch.empty(B, T, V, ce, device=DEV)
+        wt = rnd(1, ce, cin) * ce ** -0.5
+        rows = B * T * V
+        fl_mix, fl_mm = rows * 2.0 * V * ce, rows * 2.0 * ce * cin
+        tag = f"T{T} cin {cin} ic {ic}"
+        if ops.emb_tile_available(V, ic, cin):
+            w3 = ops.pack_split3(wt)
+            ms_a = timeit(lambda: ops.emb_dx_tile(emb, ds, w3, dx, ic=ic, accumulate=True), reps)
+            report(f"emb_dx_tile              {tag}", ms_a, fl_mix + fl_mm, 4.0 * rows * (ce + 2 * cin))
+            ms_b = timeit(lambda: ops.emb_wgrad_tile(emb, x, ds, ic=ic), reps)
+            report(f"emb_wgrad_tile           {tag}", ms_b, fl_mix + fl_mm, 4.0 * rows * (ce + cin))
+            # operands that are NOT resident in the Infinity Cache (what the step sees): a ring of input sets > 256 MB
+            nset = max(2, int(1.2e9 / (4.0 * rows * (ce + 2 * cin))))
+            ring = [(rnd(B, T, V, ce), rnd(B, T, V, cin), rnd(B, T, V, cin)) for _ in range(nset)]
+            it = [0]
+
+            def cold():
+                e_, x_, d_ = ring[it[0] % nset]
+                it[0] += 1
+                ops.emb_dx_tile(e_, ds, w3, d_, ic=ic, accumulate=True)
+                ops.emb_wgrad_tile(e_, x_, ds, ic=ic)
+            ms_c = timeit(cold, max(reps, 2 * nset))
+            report(f"  both, operands from HBM (ring of {nset} sets; warm {ms_a + ms_b:.3f})", ms_c, 2 * (fl_mix + fl_mm), 4.0 * rows * (2 * ce + 3 * cin))
+            del ring
+        ms1 = timeit(lambda: block.mix_demb(emb, demb, ds, ic), reps)
+        if ops.pw_gemm_available():
+            w3 = ops.pack_split3(wt)
+            ms2 = min(timeit(lambda: ops.pw_gemm(demb, w3, dx, accumulate=True), reps),
+                      timeit(lambda: ops.rows_gemm(demb, wt, dx, K=ce, N=cin, accumulate=True), reps))
+        else:
+            ms2 = timeit(lambda: ops.rows_gemm(demb, wt, dx, K=ce, N=cin, accumulate=True), reps)
+        ms3 = timeit(lambda: ops.rows_wgrad(x, demb, K=cin, N=ce), reps)
+        report(f"  mix_demb {ms1:.3f} + 1x1 dgrad {ms2:.3f} + 1x1 wgrad {ms3:.3f}  {tag}", ms1 + ms2 + ms3, fl_mix + 2 * fl_mm,
+               4.0 * rows * (4 * ce + 3 * cin))
+
+
 def bench_joint(B, reps):
     for order in ((1,), (2, 1)):
         block.MIX_VW_ORDER = order
@@ -287,7 +329,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,joint,elem")
+    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,emb_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3", "f16x2"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -298,7 +340,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, spatial_bwd=bench_spatial_bwd, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, spatial_bwd=bench_spatial_bwd, emb_bwd=bench_emb_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
