@@ -111,7 +111,8 @@ SIGNATURES = {
     "fgcn_spatial_wgrad_tile": (_I, [_P] * 4 + [_I] * 8 + [_P]),
     "fgcn_spatial_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_spatial_wgrad_tile_available": (_I, [_I] * 3),
-    "fgcn_emb_dx_tile": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "fgcn_emb_dx_tile": (_I, [_P] * 5 + [_I] * 9 + [_P]),
+    "fgcn_emb_dx_tile_workspace": (_LL, [_I, _I]),
     "fgcn_emb_wgrad_tile": (_I, [_P] * 5 + [_I] * 8 + [_P]),
     "fgcn_emb_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_emb_tile_available": (_I, [_I] * 3),

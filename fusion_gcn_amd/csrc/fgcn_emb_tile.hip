@@ -35,6 +35,15 @@
 
 #include "fgcn_common.hpp"
 
+// Timing probes (wrong results; tools/build_probe.py only).  dx kernel: bit 0 = no contraction MFMAs, 1 = no mixing (the image stays unwritten),
+// 2 = emb values requested for the first chunk only, 3 = no matrix planes, 4 = accumulators start from zero, 5 = no stores, 6 = no weight
+// requests past the prologue, 7 = no image fragment reads past the first.  Weight-gradient kernel: bit 8 = no contraction MFMAs, 9 = no mixing
+// MFMAs, 10 = emb values requested for the first slot only, 11 = x rows requested / deposited for the first tile only, 12 = one transposing
+// read per slot
+#ifndef FGCN_PROBE_EMB
+#define FGCN_PROBE_EMB 0
+#endif
+
 namespace fgcn {
 
 constexpr unsigned ET_OOB = 0x80000000u;
@@ -59,16 +68,56 @@ __device__ __forceinline__ void et_stage_planes(unsigned char* Ah, const float* 
         }
     }
 }
+// The same for all six groups ONCE per sample, into global memory in the LDS image's own layout [group][part][w][ET_AHB bytes]
+// (fgcn_emb_dx_tile's workspace): a workgroup of the dx kernel -- one per 128-row tile -- then copies 16-byte pieces instead of splitting
+// 24 values per thread (300 of its 1500 vector instructions per tile and 72 two-byte LDS writes; SQ counters, profiles/r05_pmc_emb_dx.txt).
+template <int NP> constexpr int et_planes_bytes() { return 6 * NP * 32 * ET_AHB; }
+template <int NP>
+__global__ __launch_bounds__(256) void emb_planes_kernel(const float* __restrict__ d_s, unsigned char* __restrict__ planes, int V) {
+    const float* src = d_s + (long long)blockIdx.x * 3 * V * V;
+    unsigned char* dst = planes + (long long)blockIdx.x * et_planes_bytes<NP>();
+    for (int i = threadIdx.x; i < 6 * 1024; i += 256) {
+        const int g = i >> 10, k = g >> 1, w = (i >> 5) & 31, v = i & 31;
+        float a = 0.f;
+        if (v < V && w < V) a = (g & 1) ? src[(k * V + v) * V + w] : src[(k * V + w) * V + v];
+        unsigned ph, pm, pl;
+        split_bf16_pair(a, 0.f, ph, pm, pl);
+        unsigned short* d = reinterpret_cast<unsigned short*>(dst + ((g * NP) * 32 + w) * ET_AHB) + v;
+        d[0] = (unsigned short)ph;
+        if constexpr (NP == 3) {
+            d[32 * ET_AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * ET_AHB / 2] = (unsigned short)pl;
+        }
+        if (v < 8) d[32] = 0;                                        // the 16 pad bytes of the row (copied, never read as operands)
+        if constexpr (NP == 3) {
+            if (v < 8) d[32 * ET_AHB / 2 + 32] = 0, d[2 * 32 * ET_AHB / 2 + 32] = 0;
+        }
+    }
+}
+// one sample's planes, global -> LDS, every request in flight at once (the last pass is whole waves: the piece count is a multiple of 64)
+template <int NP, int NTHREADS>
+__device__ __forceinline__ void et_copy_planes(unsigned char* Ah, const unsigned char* src, int tid) {
+    constexpr int PIECES = et_planes_bytes<NP>() / 16, NE = (PIECES + NTHREADS - 1) / NTHREADS;
+    static_assert(PIECES % 64 == 0, "whole waves");
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)et_planes_bytes<NP>(), 0x00020000);
+    u32x4v v[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(tid + NTHREADS * e) * 16u, 0, 0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        if (tid + NTHREADS * e < PIECES) *reinterpret_cast<u32x4v*>(Ah + (tid + NTHREADS * e) * 16) = v[e];     // (wave-uniform)
+}
 
 // =====================================================================================================================================
 // dx (+)= demb . Wemb
 // =====================================================================================================================================
 struct EmbDxP {
     const float* emb;
-    const float* d_s;
+    const unsigned char* planes;        // the split matrix planes of every sample (emb_planes_kernel)
     const void* w3;                     // fgcn_pack_split3 form of the (6 ic) x Cout matrix: [part][j / 8][c][8] bf16
     float* dx;
     int B, T, V, ic, Ce, Cout, ld_e, ld_dx, s_batched;
+    unsigned ic_inv;                    // ceil(2^32 / ic): d / ic = the high word of d * ic_inv for d < 6 ic
     int F, tiles_t, tiles_m, tiles_n, per_xcd;
     unsigned e_bytes, dx_bytes, w_plane_bytes;
 };
@@ -81,9 +130,13 @@ template <int NP> constexpr int ed_lds() { return NP * ED_PLANE + ED_NMAT * NP *
 // One chunk = one 32-channel pair of demb (the image of two pairs beside six resident matrices would not leave room for two workgroups
 // per CU; re-staging the matrices per chunk cost 16 prefetch registers and spilled).  MAXU: mixing units (frame, 16-channel half) of a
 // wave per chunk = ceil(2 F / 4).
-template <int NP, int NT, int MAXU, bool ACC>
+// PD: chunks the emb values are requested ahead (the chunk loop is unrolled PD times; 6 ic / 32 is a multiple of 3); RSN: weight ring slots
+// (Measured and not kept, profiles/r05_kbench_emb_bwd_variants.txt: the emb values of all three chunks requested at once -- 215-244 registers,
+// 3-10 % slower; eight waves per workgroup, 4 x 2 over the tile, four waves per SIMD at 104-122 registers -- bit-identical, 6-14 % slower.)
+template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN>
 __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
-    constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT, NW = 4;
+    static_assert(PD == 1 || PD == 3, "the chunk count is a multiple of three");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) unsigned char ed_lds_raw[];
     unsigned char* Xh = ed_lds_raw;                                  // [NP parts][128 rows][64 B]
@@ -107,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
 
     // the six matrices of this sample, split once per workgroup
-    et_stage_planes<NP, 256>(ahs, p.d_s + (p.s_batched ? (long long)n * 3 * V * V : 0), V, 0, ED_NMAT, tid);
+    if (!(FGCN_PROBE_EMB & 8)) et_copy_planes<NP, 64 * NW>(ahs, p.planes + (p.s_batched ? (long long)n * et_planes_bytes<NP>() : 0), tid);
 
     // ---- accumulators: dx's old values (accumulating form) or zero; register r of lane (col l15, g4) = row 4 g4 + r of its 16 x 16 tile.
     // Address of element (mt, r, nu) = one per-lane offset + a scalar row part + a constant column part.  The LOADS carry no masks: rows past
@@ -124,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                if constexpr (ACC)
+                if constexpr (ACC && !(FGCN_PROBE_EMB & 16))
                     acc[mt][nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdx, lane_base + nu * 64, (unsigned)(mt * 16 + r) * dx_row_b, 0));
                 else
                     acc[mt][nu][r] = 0.f;
@@ -134,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     // contiguous blocks
     int uf[MAXU], uh[MAXU];
     bool uok[MAXU];
-    const int u_lo = __builtin_amdgcn_readfirstlane((wave * 2 * F) >> 2), u_hi = __builtin_amdgcn_readfirstlane(((wave + 1) * 2 * F) >> 2);
+    const int u_lo = __builtin_amdgcn_readfirstlane((wave * 2 * F) / NW), u_hi = __builtin_amdgcn_readfirstlane(((wave + 1) * 2 * F) / NW);
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
         const int u = u_lo + i;
@@ -144,47 +197,79 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     }
     const int nchunks = p.Ce >> 5;                                   // 32-channel pairs of demb
     const unsigned row_b = (unsigned)p.ld_e * 4u;
-    // emb values of a unit: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][partner channel + l15], j = 0 .. 7 (the A fragment of the mixing)
-    float xr[MAXU][8];
-    auto fetch_units = [&](int c) {
+    // emb values of a unit: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][partner channel + l15], j = 0 .. 7 (the A fragment of the mixing).
+    // Per request: per-lane offset = the unit's row base | the joint's out-of-range bit (both fixed for the kernel), scalar offset = the
+    // joint's rows + the chunk's partner channels; past the last chunk the requests go to an empty descriptor (zeros, no traffic).
+    const __amdgpu_buffer_rsrc_t re_none = __builtin_amdgcn_make_buffer_rsrc((void*)p.emb, 0, 0, 0x00020000);
+    unsigned ubase[MAXU], jinv[8];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+        ubase[i] = uok[i] ? (((unsigned)((n * p.T + t0 + uf[i]) * V) + 8u * g4) * (unsigned)p.ld_e + (unsigned)l15) * 4u : ET_OOB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) jinv[j] = 8 * g4 + j < V ? 0u : ET_OOB;
+    auto group_of = [&](int d0) -> int { return (int)__umulhi((unsigned)d0, p.ic_inv); };
+    float xr[PD][MAXU][8];
+    auto fetch_units = [&](int c, float (&xr)[MAXU][8]) {
+        const bool live = c < nchunks && (!(FGCN_PROBE_EMB & 4) || c == 0);
+        const __amdgpu_buffer_rsrc_t rc = live ? re : re_none;
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
             const int d0 = 32 * c + 16 * uh[i];                      // the unit's demb channels; their group -> the partner group's channels
-            const int g = d0 / ic;
-            const int csrc = d0 + ((g & 1) ? -ic : ic);
-            const bool ok = uok[i] && c < nchunks;
-            const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * g4) * p.ld_e + (ok ? csrc : 0) + l15) * 4u;
+            const int csrc = d0 + ((group_of(d0) & 1) ? -ic : ic);
+            if constexpr ((FGCN_PROBE_EMB & 65536) != 0) {           // the same bytes in a quarter of the requests (wrong values)
+#pragma unroll
+                for (int j = 0; j < 8; j += 4) {
+                    const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (ubase[i] | jinv[j]) & ~15u, (unsigned)j * row_b + (unsigned)csrc * 4u, 0));
+                    xr[i][j] = q[0], xr[i][j + 1] = q[1], xr[i][j + 2] = q[2], xr[i][j + 3] = q[3];
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, (ok && 8 * g4 + j < V) ? base : ET_OOB, (unsigned)j * row_b, 0));
+                xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, ubase[i] | jinv[j], (unsigned)j * row_b + (unsigned)csrc * 4u, 0));
         }
     };
-    auto stage_units = [&](int c) {
+    // Branch-free over the wave's units: a unit that does not exist mixes the zeros its requests returned and writes nothing, so that the
+    // 2 MAXU independent MFMA chains of a chunk are ONE basic block (a wave-uniform `continue` per unit made every unit its own block:
+    // six dependent MFMAs, then the splits that wait for them, one unit after the other -- half of the kernel's time).
+    auto stage_units = [&](int c, float (&xr)[MAXU][8]) {
+        if ((FGCN_PROBE_EMB & 2)) return;
+        u32x4v xs[MAXU][NP];
+        int g[MAXU];
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
-            if (!uok[i]) continue;                                   // wave-uniform
-            const int g = (32 * c + 16 * uh[i]) / ic;                // the unit's group = its matrix
-            u32x4v xs[NP];
-            splitn_x8<NP>(xr[i][0], xr[i][1], xr[i][2], xr[i][3], xr[i][4], xr[i][5], xr[i][6], xr[i][7], xs);
+            g[i] = group_of(32 * c + 16 * uh[i]);                    // the unit's group = its matrix
+            splitn_x8<NP>(xr[i][0], xr[i][1], xr[i][2], xr[i][3], xr[i][4], xr[i][5], xr[i][6], xr[i][7], xs[i]);
+        }
+        f32x4 m[MAXU][2];
 #pragma unroll
-            for (int wt = 0; wt < 2; ++wt) {
+        for (int wt = 0; wt < 2; ++wt)
+#pragma unroll
+            for (int i = 0; i < MAXU; ++i) {
                 u32x4v af[NP];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    af[pl] = *reinterpret_cast<const u32x4v*>(ahs + ((g * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
+                for (int pl = 0; pl < NP; ++pl) {
+                    if constexpr ((FGCN_PROBE_EMB & 32768) != 0) af[pl] = xs[i][pl] + (unsigned)(wt + 1);
+                    else af[pl] = *reinterpret_cast<const u32x4v*>(ahs + ((g[i] * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
+                }
                 // demb_f^T (16 c x 16 w): lane (w = 16 wt + l15, g4) holds channels 4 g4 .. + 3 of the half
-                const f32x4 m = mfma_np_k32<NP>(xs, af, f32x4{0.f, 0.f, 0.f, 0.f});
+                if constexpr ((FGCN_PROBE_EMB & 8192) != 0) m[i][wt] = __builtin_bit_cast(f32x4, xs[i][0] ^ af[0] ^ xs[i][NP - 1] ^ af[NP - 1]);
+                else m[i][wt] = mfma_np_k32<NP>(xs[i], af, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i)
+#pragma unroll
+            for (int wt = 0; wt < 2; ++wt) {
                 const int w = 16 * wt + l15;
-                if (w < V) {
-                    const int R = uf[i] * V + w;
-                    u32x2 parts[NP];
-                    splitn_x4<NP>(m, parts);
+                const int R = uf[i] * V + w;
+                u32x2 parts[NP];
+                splitn_x4<NP>(m[i][wt], parts);
+                if (w < V && uok[i] && !((FGCN_PROBE_EMB & 16384) && parts[0][0] != 0x12345u)) {
                     unsigned char* dst = Xh + R * ED_XS + ((unsigned)(32 * uh[i] + 8 * g4) ^ swz(R));
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * ED_PLANE) = parts[pl];
                 }
             }
-        }
     };
 
     unsigned wvoff[NU];                                              // per-lane byte offset into one part: (g4 * Cout + col) * 8 bf16
@@ -192,19 +277,24 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     for (int nu = 0; nu < NU; ++nu) wvoff[nu] = col + nu * 16 < p.Cout ? (unsigned)(((long long)g4 * p.Cout + col + nu * 16) * 16) : ET_OOB;
     // weight fragment of (column unit nu, pair pq): contraction rows 32 pq + 8 g4 + j; past the last pair: pair 0 (a valid, unused load)
     auto load_w = [&](u32x4v (&dst)[NP], int nu, int pq) {
+        if ((FGCN_PROBE_EMB & 64) && pq > 0) return;
         if (pq >= nchunks) pq = 0;
         const unsigned so = (unsigned)(((long long)(4 * pq) * p.Cout) * 16);
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[nu], so + pl * p.w_plane_bytes, 0);
     };
     const int xrow = wr * (16 * MTW) + l15;
+    bool first_a = true;
     auto load_a = [&](u32x4v (&dst)[NP], int mt) {
+        if ((FGCN_PROBE_EMB & 128) && !first_a) return;
+        if (mt == MTW - 1) first_a = false;
         const int r = xrow + mt * 16;
         const unsigned char* src = Xh + r * ED_XS + ((unsigned)(16 * g4) ^ swz(r));
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * ED_PLANE);
     };
-    constexpr int RS = NU == 4 ? 4 : 2;                              // weight ring slots (fragments requested RS - 1 units ahead)
+    constexpr int RS = RSN;                                          // weight ring slots (fragments requested RS - 1 units ahead)
+    static_assert(RS >= 2 && RS <= NU, "ring slots");
     u32x4v a[MTW][NP], wq[RS][NP];
     auto feature_phase = [&](int c) {                                // pair c from the image
 #pragma unroll
@@ -215,21 +305,30 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
             if (t < NU) load_w(wq[t % RS], t, c);
             else load_w(wq[t % RS], t - NU, c + 1);
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) acc[mt][nu] = mfma_np_k32<NP>(a[mt], wq[nu % RS], acc[mt][nu]);
+            for (int mt = 0; mt < MTW; ++mt) {
+                if constexpr ((FGCN_PROBE_EMB & 1) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu % RS][0][0]);
+                else acc[mt][nu] = mfma_np_k32<NP>(a[mt], wq[nu % RS], acc[mt][nu]);
+            }
         }
     };
 
-    fetch_units(0);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch_units(d, xr[d]);
 #pragma unroll
     for (int nu = 0; nu < RS - 1; ++nu) load_w(wq[nu], nu, 0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();                                             // the previous chunk's image reads are done (first pass: the matrices are written)
-        stage_units(c);
-        __syncthreads();
-        fetch_units(c + 1);                                          // lands during the MFMAs below (past the last chunk: nothing is read)
-        feature_phase(c);
+    for (int c0 = 0; c0 < nchunks; c0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int c = c0 + d;
+            __syncthreads();                                         // the previous chunk's image reads are done (first pass: the matrices are written)
+            stage_units(c, xr[d]);
+            __syncthreads();
+            fetch_units(c + PD, xr[d]);                              // lands during the MFMAs below (past the last chunk: nothing is read)
+            feature_phase(c);
+        }
     }
 
+    auto val_guard = [](float v) { return v != 1.2345e-30f; };      // (probe bit 5: the stores depend on the values, nothing is written)
     // ---- epilogue: branch-free buffer stores; rows beyond the tile's frames and columns beyond Cout carry the out-of-range offset
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -238,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
             const bool rowok = wr * (16 * MTW) + mt * 16 + 4 * g4 + r < nrows;
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                const unsigned off = (rowok && col + nu * 16 < p.Cout) ? lane_base + nu * 64 : ET_OOB;
+                const unsigned off = (rowok && col + nu * 16 < p.Cout && !((FGCN_PROBE_EMB & 32) && val_guard(acc[mt][nu][r]))) ? lane_base + nu * 64 : ET_OOB;
                 const float val = acc[mt][nu][r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rdx, off, (unsigned)(mt * 16 + r) * dx_row_b, 0);
             }
@@ -279,9 +378,11 @@ __device__ __forceinline__ void ew_for_slots(Fn&& fn, std::integer_sequence<int,
 // CT: 16-channel demb tiles of the workgroup (8: every wave walks all frames; 4: two waves per tile take alternate frames, added at the
 // end); NT: 16-channel tiles of x (4 or 8); NSLOT: frame slots of a wave per tile, compile time (straight-line code: exact request counts);
 // NM: matrix slots in LDS (the (subset, side) groups the workgroup's channels touch: 2, or 6 for ic = 16)
-template <int NP, int CT, int NT, int NSLOT, int NM>
+// PF: frame slots the emb values are requested ahead (a ring of PF register sets, by slot index modulo PF: NSLOT % PF == 0)
+template <int NP, int CT, int NT, int NSLOT, int NM, int PF>
 __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
     constexpr int FP = 8 / CT;
+    static_assert(PF >= 1 && NSLOT % PF == 0, "the slot ring must close over a tile");
     constexpr int RS = ew_rs<NT>(), PL = EW_ROWS * RS;
     constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = EW_ROWS / RPP;      // 16-byte groups per row, rows per pass, passes
     static_assert(EW_ROWS % RPP == 0 && NSLOT % 2 == 0, "staging passes / slot pairs");
@@ -319,18 +420,18 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
     auto fetch_pass = [&](int g, int i) {
         const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
         const int t0_ = tile_ * F;
-        const int nrows_ = g < t_hi ? min(F, p.T - t0_) * V : 0;
+        const int nrows_ = (g < t_hi && (!(FGCN_PROBE_EMB & 2048) || g == t_lo)) ? min(F, p.T - t0_) * V : 0;
         const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
         const int r = srow + RPP * i;
         const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_x + (unsigned)(o0 + 4 * sg)) * 4u : ET_OOB;
         stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     };
     // emb values of frame slot s of pair g for this wave: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][csrc + l15], j = 0 .. 7
-    float xr[8];
-    auto xfetch = [&](int g, int s) {
+    float xr_ring[PF][8];
+    auto xfetch = [&](float (&xr)[8], int g, int s) {
         const int n_ = g / p.tiles_t, tile_ = g - n_ * p.tiles_t;
         const int t0_ = tile_ * F, f = fp + FP * s;
-        const int vlim = (active && g < t_hi && f < min(F, p.T - t0_)) ? V : 0;      // (a scalar select: no frame, no joints)
+        const int vlim = (active && g < t_hi && f < min(F, p.T - t0_) && (!(FGCN_PROBE_EMB & 1024) || (g == t_lo && s == 0))) ? V : 0;   // (a scalar select: no frame, no joints)
         const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_e + (unsigned)((active ? csrc : 0) + l15);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -352,7 +453,8 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
     };
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) fetch_pass(t_lo, i);
-    xfetch(t_lo, 0);
+#pragma unroll
+    for (int d = 0; d < PF; ++d) xfetch(xr_ring[d], t_lo, d);
     if (t_lo < t_hi) planes(t_lo / p.tiles_t);
     deposit();
     __syncthreads();
@@ -360,50 +462,61 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
     for (int g = t_lo; g < t_hi; ++g) {
         const int n = g / p.tiles_t, tile = g - n * p.tiles_t;
         const int nf = min(F, p.T - tile * F);
-        auto slot = [&](auto s_tag) {
+        // Branch-free per slot: a frame past the tile's last mixes the zeros its requests returned (vlim = 0) against rows of frame 0 --
+        // finite values, so the product is an exact zero -- and the slots of a tile are ONE basic block for the waves that own a channel
+        // tile: slot s + 1's mixing chains can issue under slot s's contraction chains (with one matrix per channel tile a slot has a third
+        // of the independent work of the conv_d kernel's).  Waves without a channel tile (ic = 16: two of eight) only take part in the staging.
+        auto slot = [&](auto s_tag, auto act_tag) {
             constexpr int s = decltype(s_tag)::value;
+            constexpr bool ACT = decltype(act_tag)::value;
             const int f = fp + FP * s;
+            float (&xr)[8] = xr_ring[s % PF];
             u32x4v xs[NP];
-            splitn_x8<NP>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
-            if constexpr (s + 1 < NSLOT) xfetch(g, s + 1);           // the next slot of this tile, or the first of the next tile
-            else xfetch(g + 1, s + 1 - NSLOT);
+            if constexpr (ACT) splitn_x8<NP>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
+            if constexpr (s + PF < NSLOT) xfetch(xr, g, s + PF);     // a later slot of this tile, or of the next tile
+            else xfetch(xr, g + 1, s + PF - NSLOT);
 #pragma unroll
             for (int i = 0; i < NPASS; ++i)
                 if (i * SPREAD / NPASS == s) fetch_pass(g + 1, i);
-            if (f >= nf || !active) return;                          // wave-uniform: no such frame in this tile / no such channel tile
-            f32x4 m[2];
+            if constexpr (ACT) {
+                f32x4 m[2];
 #pragma unroll
-            for (int wt = 0; wt < 2; ++wt) {
-                u32x4v af[NP];
+                for (int wt = 0; wt < 2; ++wt) {
+                    u32x4v af[NP];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl)
-                    af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((ms * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
-                // demb_f (32 joints w x 16 channels): lane (c = l15, g4) holds joints w = 4 g4 + r (wt = 0) and 16 + 4 g4 + r (wt = 1)
-                m[wt] = mfma_np_k32<NP>(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
-            }
-            bsum += ((m[0][0] + m[0][1]) + (m[0][2] + m[0][3])) + ((m[1][0] + m[1][1]) + (m[1][2] + m[1][3]));   // joints >= V are exact zeros
-            u32x4v a3[NP];
-            splitn_x8<NP>(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3);
-            const int r_lo = f * V + 4 * g4 + q4, r_hi = r_lo + 16;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                u32x4v df[NP];
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    const unsigned char* base = Im + pl * PL + nt * 32 + 8 * c4;
-                    const u32x2 lo = ew_read_tr16(base + r_lo * RS);
-                    const u32x2 hi = ew_read_tr16(base + r_hi * RS);
-                    df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+                    for (int pl = 0; pl < NP; ++pl)
+                        af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((ms * NP + pl) * 32 + 16 * wt + l15) * ET_AHB + 16 * g4);
+                    // demb_f (32 joints w x 16 channels): lane (c = l15, g4) holds joints w = 4 g4 + r (wt = 0) and 16 + 4 g4 + r (wt = 1)
+                    if constexpr ((FGCN_PROBE_EMB & 512) != 0) m[wt] = __builtin_bit_cast(f32x4, af[0] ^ xs[0]);
+                    else m[wt] = mfma_np_k32<NP>(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
                 }
-                acc[nt] = mfma_np_k32<NP>(a3, df, acc[nt]);
+                bsum += ((m[0][0] + m[0][1]) + (m[0][2] + m[0][3])) + ((m[1][0] + m[1][1]) + (m[1][2] + m[1][3]));   // joints >= V are exact zeros
+                u32x4v a3[NP];
+                splitn_x8<NP>(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3);
+                const int r_lo = (f < nf ? f : 0) * V + 4 * g4 + q4, r_hi = r_lo + 16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    u32x4v df[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        if ((FGCN_PROBE_EMB & 4096) && nt > 0) break;
+                        const unsigned char* base = Im + pl * PL + nt * 32 + 8 * c4;
+                        const u32x2 lo = ew_read_tr16(base + r_lo * RS);
+                        const u32x2 hi = ew_read_tr16(base + r_hi * RS);
+                        df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                    if constexpr ((FGCN_PROBE_EMB & 256) != 0) acc[nt][0] += __builtin_bit_cast(float, a3[0][0] ^ df[0][0]);
+                    else acc[nt] = mfma_np_k32<NP>(a3, df, acc[nt]);
+                }
             }
         };
-        ew_for_slots(slot, std::make_integer_sequence<int, NSLOT>{});
+        if (active) ew_for_slots([&](auto s_tag) { slot(s_tag, std::true_type{}); }, std::make_integer_sequence<int, NSLOT>{});
+        else ew_for_slots([&](auto s_tag) { slot(s_tag, std::false_type{}); }, std::make_integer_sequence<int, NSLOT>{});
         // the next tile's x rows (and its sample's matrix planes) replace this one's
         __syncthreads();                                             // this tile's fragment reads are done
         const int n1 = (g + 1) / p.tiles_t;
         if (g + 1 < t_hi && n1 != n && p.s_batched) planes(n1);
-        deposit();
+        if (!(FGCN_PROBE_EMB & 2048)) deposit();
         __syncthreads();
     }
 
@@ -495,16 +608,22 @@ extern "C" int fgcn_emb_tile_available(int V, int ic, int Cx) {
     return ew_geom(1, 1, V, ic, Cx).ok ? 1 : 0;
 }
 
-extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, int B, int T, int V, int ic, int Cx, int ld_e,
-                                int ld_dx, int d_s_batched, int accumulate, void* stream) {
-    FGCN_REQUIRE(emb && d_s && w3 && dx, FGCN_E_BADARG, "emb_dx_tile: null pointer");
+// bytes of fgcn_emb_dx_tile's workspace (the split matrix planes of every sample) in the current math mode
+extern "C" long long fgcn_emb_dx_tile_workspace(int B, int d_s_batched) {
+    const long long per = fgcn::math_mode() == FGCN_MATH_BF16 ? et_planes_bytes<1>() : et_planes_bytes<3>();
+    return (d_s_batched ? (long long)B : 1ll) * per;
+}
+
+extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
+                                int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
+    FGCN_REQUIRE(emb && d_s && w3 && dx && workspace, FGCN_E_BADARG, "emb_dx_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_dx_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(emb_tile_mode_ok() && emb_tile_sizes_ok(V, ic, Cx), FGCN_E_BADARG,
                  "emb_dx_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx %% 64 == 0 (V=%d ic=%d Cx=%d, mode %d)", FGCN_MAX_V, V,
                  ic, Cx, fgcn::math_mode());
     const int Ce = 6 * ic;
     FGCN_REQUIRE(ld_e % 4 == 0 && ld_dx % 4 == 0 && ld_e >= Ce && ld_dx >= Cx, FGCN_E_ALIGN, "emb_dx_tile: row strides");
-    FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
+    FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && aligned16(workspace) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_dx_tile: 16-byte alignment");
     const long long e_bytes = (long long)B * T * V * ld_e * 4, dx_bytes = (long long)B * T * V * ld_dx * 4;
     const long long plane = (long long)Ce * Cx * 2;
@@ -512,8 +631,9 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
                  "emb_dx_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     const int np = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3;
     EmbDxP p;
-    p.emb = emb; p.d_s = d_s; p.w3 = w3; p.dx = dx;
+    p.emb = emb; p.planes = static_cast<const unsigned char*>(workspace); p.w3 = w3; p.dx = dx;
     p.B = B; p.T = T; p.V = V; p.ic = ic; p.Ce = Ce; p.Cout = Cx; p.ld_e = ld_e; p.ld_dx = ld_dx; p.s_batched = d_s_batched;
+    p.ic_inv = (unsigned)(((1ull << 32) + (unsigned)ic - 1) / (unsigned)ic);
     p.F = 128 / V;
     p.tiles_t = (int)cdiv(T, p.F);
     p.tiles_m = B * p.tiles_t;
@@ -525,16 +645,26 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
     p.e_bytes = (unsigned)e_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
     const dim3 grid((unsigned)(p.per_xcd * 8));
     hipStream_t s = (hipStream_t)stream;
+    // the split matrix planes, once per sample
+    if (np == 3) hipLaunchKernelGGL((emb_planes_kernel<3>), dim3(d_s_batched ? B : 1), dim3(256), 0, s, d_s, static_cast<unsigned char*>(workspace), V);
+    else hipLaunchKernelGGL((emb_planes_kernel<1>), dim3(d_s_batched ? B : 1), dim3(256), 0, s, d_s, static_cast<unsigned char*>(workspace), V);
     const bool big = 2 * p.F > 12;                                   // mixing units per wave and chunk: ceil(2 F / 4)
-#define FGCN_ED_GO4(NP_, NT_, MU_, ACC_)                                                                             \
+#define FGCN_ED_GO6(NP_, NT_, MU_, ACC_, PD_, RS_)                                                                   \
     do {                                                                                                             \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP_, NT_, MU_, ACC_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP_, NT_, MU_, ACC_, PD_, RS_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP_>());                    \
             opted = true;                                                                                            \
         }                                                                                                            \
-        hipLaunchKernelGGL((emb_dx_tile_kernel<NP_, NT_, MU_, ACC_>), grid, dim3(256), ed_lds<NP_>(), s, p);          \
+        hipLaunchKernelGGL((emb_dx_tile_kernel<NP_, NT_, MU_, ACC_, PD_, RS_>), grid, dim3(256), ed_lds<NP_>(), s, p); \
+    } while (0)
+    /* tuning key 18 = 1: 128-column tiles with a two-slot weight ring (default four; 64-column tiles always two) */
+#define FGCN_ED_GO4(NP_, NT_, MU_, ACC_)                                   \
+    do {                                                                   \
+        if (NT_ == 1) FGCN_ED_GO6(NP_, 1, MU_, ACC_, 1, 2);                \
+        else if (variant == 1) FGCN_ED_GO6(NP_, 2, MU_, ACC_, 1, 2);       \
+        else FGCN_ED_GO6(NP_, 2, MU_, ACC_, 1, 4);                         \
     } while (0)
 #define FGCN_ED_GO3(NP_, NT_, MU_)                     \
     do {                                               \
@@ -551,13 +681,29 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
         if (narrow) FGCN_ED_GO2(NP_, 1);       \
         else FGCN_ED_GO2(NP_, 2);              \
     } while (0)
+    const int variant = fgcn::tuning(18);
     if (np == 3) FGCN_ED_GO(3);
     else FGCN_ED_GO(1);
 #undef FGCN_ED_GO
 #undef FGCN_ED_GO2
 #undef FGCN_ED_GO3
 #undef FGCN_ED_GO4
+#undef FGCN_ED_GO6
     return launch_status("emb_dx_tile");
+}
+
+// (tools only, not in include/fgcn.h) resident workgroups per CU of the 64-column / 128-column dx kernels as the runtime computes them
+extern "C" int fgcn_debug_emb_dx_occupancy(int nt) {
+    int n = -1;
+    hipError_t e;
+    if (nt == 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<3, 1, 3, true, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<3>());
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emb_dx_tile_kernel<3, 1, 3, true, 1, 2>, 256, ed_lds<3>());
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<3, 2, 3, true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<3>());
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emb_dx_tile_kernel<3, 2, 3, true, 1, 4>, 256, ed_lds<3>());
+    }
+    return e == hipSuccess ? n : -1;
 }
 
 // slabs of `partial` / `bias_partial` (0: sizes the kernel does not take)
@@ -592,17 +738,24 @@ extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float
     p.p_bytes = (unsigned)((long long)g.nseg * Ce * Cx * 4), p.b_bytes = (unsigned)((long long)g.nseg * Ce * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
-#define FGCN_EW(NP_, CT_, NT_, NS_, NM_)                                                                                          \
+#define FGCN_EW6(NP_, CT_, NT_, NS_, NM_, PF_)                                                                                    \
     do {                                                                                                                          \
         static bool attr = false;                                                                                                 \
         constexpr int lds_ = ew_lds<NP_, NT_, NM_>();                                                                             \
         if (!attr) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_, PF_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                          \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_>), grid, dim3(512), lds_, s, p);                        \
+        hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_, PF_>), grid, dim3(512), lds_, s, p);                   \
     } while (0)
+    /* tuning key 19: slots the emb values are requested ahead (0 = two, 1 = one) */
+#define FGCN_EW(NP_, CT_, NT_, NS_, NM_)                           \
+    do {                                                           \
+        if (pf1) FGCN_EW6(NP_, CT_, NT_, NS_, NM_, 1);             \
+        else FGCN_EW6(NP_, CT_, NT_, NS_, NM_, 2);                 \
+    } while (0)
+    const bool pf1 = fgcn::tuning(19) == 1;
     // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
     const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;
     FGCN_REQUIRE(nslot == (g.CT == 8 ? (g.F > 6 ? 8 : 6) : 4), FGCN_E_BADARG, "emb_wgrad_tile: %d frames per tile: no such kernel form", g.F);
@@ -628,5 +781,6 @@ extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float
     }
 #undef FGCN_EW_NP
 #undef FGCN_EW
+#undef FGCN_EW6
     return launch_status("emb_wgrad_tile");
 }

@@ -1046,8 +1046,11 @@ def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torc
             or tuple(dx.shape[:3]) != (B, T, V) or dx.shape[3] < cx):
         raise _lib.FgcnError(f"emb_dx_tile: shape mismatch emb={tuple(emb.shape)} dx={tuple(dx.shape)} w3={tuple(w3.shape)} "
                              f"(weights: pack_split3 of the (1, 6 ic, cx) matrix)")
-    check(_lib.load().fgcn_emb_dx_tile(_p(emb), _p(d_s), w3.data_ptr(), _p(dx), B, T, V, ic, cx, ld_e, dx.shape[3],
-                                       int(d_s.shape[0] != 1), int(accumulate), _stream()), "fgcn_emb_dx_tile")
+    lib = _lib.load()
+    batched = int(d_s.shape[0] != 1)
+    ws = torch.empty(lib.fgcn_emb_dx_tile_workspace(B, batched), device=emb.device, dtype=torch.uint8)      # the split planes of dS, dS^T
+    check(lib.fgcn_emb_dx_tile(_p(emb), _p(d_s), w3.data_ptr(), _p(dx), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
+                               int(accumulate), _stream()), "fgcn_emb_dx_tile")
     return dx
 
 

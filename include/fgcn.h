@@ -62,7 +62,9 @@ int fgcn_check_device(void);
  *   13 fgcn_spatial_wgrad: workgroups to aim for (0 = 512 up to 32 samples, 1024 above)
  *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`)
  *   16 fgcn_spatial_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
- *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count) */
+ *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
+ *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
+ *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two) */
 int fgcn_set_tuning(int key, int value);
 
 /* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
@@ -506,8 +508,11 @@ int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
  * fgcn_emb_tile_available.  Replaces fgcn_joint_mix_vec(demb) + fgcn_pw_gemm / fgcn_rows_gemm(demb . W) + fgcn_pw_wgrad(x, demb) and the
  * 1.5-activation-wide demb tensor between them.  Every sum has a fixed order.
  * Tuning key 17: fgcn_emb_wgrad_tile workgroups to aim for (0 = 256; sets the slab count). */
-int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, int B, int T, int V, int ic, int Cx, int ld_e, int ld_dx,
-                     int d_s_batched, int accumulate, void* stream);
+int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx, int ld_e,
+                     int ld_dx, int d_s_batched, int accumulate, void* stream);
+/* bytes of fgcn_emb_dx_tile's caller-owned workspace (16-byte aligned; the split bf16 planes of dS and dS^T of every sample, written by a
+ * small first launch and read by every workgroup of the main one) in the current math mode */
+long long fgcn_emb_dx_tile_workspace(int B, int d_s_batched);
 int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T, int V, int ic,
                         int Cx, int ld_e, int ld_x, int d_s_batched, void* stream);
 int fgcn_emb_wgrad_tile_slabs(int B, int T, int V, int ic, int Cx);
