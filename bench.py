@@ -245,6 +245,49 @@ def measured_traffic(dom, samples, math="f32"):
     return rec["traffic_bytes"]
 
 
+def metric_name(n_global: int) -> str:
+    return "clips/sec (N,C,T,V,M)=(%d,3,300,%d,2) fwd+bwd" % (n_global, SHAPE["V"])
+
+
+def collective_report(world: int, rank: int, backend: str, device=None, numel: int = 3_469_510, reps: int = 20):
+    """What the N > 1 line carries so that it proves which collective ran where: backend name, world size, every rank's local device
+    index and device name (gathered), the library version (RCCL's, as torch reports it for the "nccl" backend), and the time of ONE
+    all-reduce of a buffer of the gradient exchange's size, timed alone (barrier + synchronize on both sides, max over ranks, `reps`
+    repetitions).  Collective calls: every rank must call this.  -> dict on every rank (rank 0 prints it)."""
+    on_gpu = device is not None and device.type == "cuda"
+    if on_gpu:
+        me = {"rank": rank, "local_device": device.index, "name": torch.cuda.get_device_name(device),
+              "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+    else:
+        me = {"rank": rank, "local_device": None, "name": "cpu", "uuid": ""}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    buf = torch.ones(numel, device=device if on_gpu else "cpu", dtype=torch.float32)
+
+    def fence():
+        dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+    for _ in range(3):
+        dist.all_reduce(buf)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    fence()
+    t = torch.tensor([(time.perf_counter() - t0) / reps], device=device if on_gpu else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001 - the version string is a label, not a result
+            version = f"unavailable ({type(e).__name__})"
+    return {"backend": backend, "library": "RCCL (torch.distributed backend \"nccl\" on ROCm)" if backend == "nccl" else backend,
+            "rccl_version": version, "world": world, "devices": everyone, "distinct_devices": len({(d["name"], d["local_device"], d["uuid"]) for d in everyone}),
+            "allreduce_bytes": numel * 4, "allreduce_ms": round(1e3 * float(t), 4), "allreduce_reps": reps}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no launcher around it: run the same command line under torch.distributed.run (one rank
     per GPU, rendezvous on 127.0.0.1) as a CHILD process and pass its output and exit code through.  This process never
@@ -283,12 +326,18 @@ def dry_run(args, world: int, rank: int) -> None:
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(flat[0]) == world * (world + 1) / 2
+    coll = collective_report(world, rank, os.environ.get("FGCN_BENCH_BACKEND", "gloo"), reps=3) if world > 1 else None
     if rank == 0:
-        print(json.dumps({"metric": "clips/sec (N,C,T,V,M)=(64,3,300,%d,2) fwd+bwd" % SHAPE["V"], "value": None, "unit": "clips/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
-                          "scaling": args.scaling, "vs_baseline": None, "dry_run": True, "data": "synthetic",
-                          "config": {"global_batch": n_global, "per_gpu_batch": shard.stop - shard.start,
-                                     "parallelism": f"dp{world}", "exchange_s": round(float(t), 4)}}), flush=True)
+        line = {"metric": metric_name(n_global), "value": None, "unit": "clips/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": args.scaling, "vs_baseline": None, "dry_run": True, "data": "synthetic",
+                "config": {"global_batch": n_global, "per_gpu_batch": shard.stop - shard.start,
+                           "parallelism": f"dp{world}", "exchange_s": round(float(t), 4)}}
+        if coll:
+            line["collective"] = coll
+        if world > 1 and not args.no_cpu_baseline:      # the N > 1 line carries the CPU baseline too (rank 0 times it, the others wait)
+            line["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": None, "kind": "port", "sample": "dry run: not timed"}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -575,6 +624,7 @@ def main():
         if err != 0.0:      # data_bn and the loss run on libfgcn too: every gradient of the step is a fixed-order sum
             raise SystemExit("verify-dp failed: the replayed step's gradient buffer must equal the eager step's bit for bit")
 
+    coll = collective_report(world, rank, backend, device=device, numel=int(grads.flat.numel())) if world > 1 else None
     kern = None if args.no_kernel_timing else time_dominant_kernel(device, n_local * SHAPE["M"])
     f32_mode = None
     if world == 1 and args.math == "bf16x3" and not args.no_f32_mode:
@@ -612,7 +662,7 @@ def main():
         # Key order: a reader (or a record that keeps only the head of the line) gets every NUMBER first -- headline, the two side
         # modes, whole-step fractions, roofline, CPU baseline -- then the short descriptors, and the long prose last.
         out = {
-            "metric": "clips/sec (N,C,T,V,M)=(64,3,300,%d,2) fwd+bwd" % SHAPE["V"],
+            "metric": metric_name(n_global),
             "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
@@ -624,6 +674,8 @@ def main():
             modes["f16x2"] = {"clips_s": f16x2_mode["value"], "ms": f16x2_mode["ms_per_step"]}
         if modes:
             out["modes"] = modes
+        if coll:
+            out["collective"] = coll
         out["step_fractions"] = {
             "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
@@ -654,7 +706,8 @@ def main():
                                       "f16x2": "f16 dense peak (= bf16's) / 3 products (f32-equivalent FLOPs)"}[args.math]
             roofline_detail = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in kern]
         parity = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0 only, after every timed region (N > 1: the other ranks wait at the barrier below; nothing here is a collective)
             log("timing the CPU oracle on the host cores")
             also = ("f16x2",) if f16x2_mode else ()
             out["cpu_baseline"], parity = cpu_baseline(device=device, maths=(args.math,) + also)

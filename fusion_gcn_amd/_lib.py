@@ -72,7 +72,12 @@ SIGNATURES = {
     "fgcn_version": (_I, []),
     "fgcn_last_error": (C.c_char_p, []),
     "fgcn_check_device": (_I, []),
+    "fgcn_ctx_create": (_I, [C.POINTER(C.c_void_p)]),
+    "fgcn_ctx_destroy": (_I, [_P]),
+    "fgcn_ctx_set_current": (_I, [_P]),
+    "fgcn_ctx_get_current": (_P, []),
     "fgcn_set_tuning": (_I, [_I, _I]),
+    "fgcn_get_tuning": (_I, [_I]),
     "fgcn_set_math_mode": (_I, [_I]),
     "fgcn_get_math_mode": (_I, []),
     "fgcn_set_products": (_I, [_I]),

@@ -136,7 +136,7 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
         F["d4"] = Form("split2h_acc" if mode == "f16x2" else "split3_acc", 1, 3 * cx, cout, d_rows)
     else:
         F["d4"] = Form("k4", 1, 3 * cx, cout, d_rows, shape=(3 * cx // 4, cout, 4))
-    if mode == "bf16x3" and cx % 64 == 0:            # the tile form of the fused spatial kernel (ops.spatial_fwd_tile): plain split form
+    if mode in ("bf16x3", "bf16") and cx % 64 == 0:  # the tile form of the fused spatial kernel (ops.spatial_fwd_tile): plain split form (bf16: its part 0)
         F["d_s3"] = Form("split3", 1, 3 * cx, cout, d_rows)
     d_cols = [Seg(w, st_k=cin, st_n=1, klen=cout, nlen=cin, n0=k * cx) for k, w in enumerate(wd)]          # (1, cout, 3cx)
     F["d_t"] = Form("plain", 1, cout, 3 * cx, d_cols)
@@ -172,8 +172,8 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
                 F[key + "_s3"] = Form(split_form, 1, F[key].K, F[key].N, F[key].segs)
     # the fused spatial backward (ops.spatial_bwd_tile) multiplies three-way bf16 splits in every float32-class mode: with the f16x2
     # products the block keeps that form of d_t beside the two-way f16 one
-    if mode in ("bf16x3", "f16x2") and cx % 64 == 0 and cout % 64 == 0:
-        F["d_t_b3"] = Form("split3", 1, cout, 3 * cx, d_cols)      # (a form of its own: forms are materialised per key)
+    if mode in ("bf16x3", "f16x2", "bf16") and cx % 64 == 0 and cout % 64 == 0:
+        F["d_t_b3"] = Form("split3", 1, cout, 3 * cx, d_cols)      # (a form of its own: forms are materialised per key; bf16 reads its part 0)
     # the embedding backward in tile form (ops.emb_dx_tile: the embedding gradient on chip) streams the three-way bf16 split of emb_t in
     # every split mode (bf16: its part 0)
     if "emb_t" in F and mode in ops.SPLIT_MODES and cx % 64 == 0:
@@ -607,8 +607,9 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
+    small = lambda width: B * max(T, Tp) * V * width * 4 < 0x7FFF0000      # noqa: E731  the tile kernels address with 32-bit byte offsets
     tile_ok = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and "d_t_b3" in W and ops.spatial_bwd_tile_available(V, cin, cout)
-               and (ops.get_math_mode() == "bf16x3" or SPATIAL_BWD_TILE_F16X2))
+               and (ops.get_math_mode() in ("bf16x3", "bf16") or SPATIAL_BWD_TILE_F16X2) and small(max(cin, cout)))
     gate_in_dagg = ((GATED_SHORTCUTS_TILE if tile_ok else GATED_SHORTCUTS) and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and d_o.numel() * 4 < 0x7FFF0000)
@@ -692,8 +693,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     with wgrad():
-        if (SPATIAL_WGRAD_TILE and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout)
-                and (ops.get_math_mode() == "bf16x3" or SPATIAL_WGRAD_TILE_F16X2)):
+        if (SPATIAL_WGRAD_TILE and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
+                and (ops.get_math_mode() in ("bf16x3", "bf16") or SPATIAL_WGRAD_TILE_F16X2)):
             gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
         elif FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
             # agg = x . A^ is formed in registers and contracted with dy at once: never written
@@ -726,7 +727,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     if not cfg.static_adjacency:
         emb = S["emb"]
         if (EMB_TILE and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
-                and emb.numel() * 4 < 0x7FFF0000 and dx.numel() * 4 < 0x7FFF0000):
+                and small(max(6 * ic, cx))):
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
             with wgrad():
@@ -907,3 +908,6 @@ class CrossEntropyFunction(torch.autograd.Function):
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return CrossEntropyFunction.apply(logits, labels)
+
+
+ops.bind_all_functions(globals())     # every Function's backward runs in its forward's library context (ops.Context)

@@ -272,6 +272,11 @@ __device__ __forceinline__ f32x4 mfma_np_k32(const u32x4v (&a)[NP], const u32x4v
     if constexpr (NP == 3) return mfma_x3_k32(a, b, c);
     else return mfma_bf16_k32(a[0], b[0], c);
 }
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_np_k16(const u32x4v (&a)[NP], const u32x4v (&b)[NP], f32x16 c) {
+    if constexpr (NP == 3) return mfma_x3_k16(a, b, c);
+    else return mfma_bf16_k16(a[0], b[0], c);
+}
 
 template <int MM>
 __device__ __forceinline__ Frag<MM> make_frag(float a0, float a1, float a2, float a3) {

@@ -578,6 +578,11 @@ static EwGeom ew_geom(int B, int T, int V, int ic, int Cx) {
     g.F = ew_frames(V);
     g.tiles_t = (int)cdiv(T, g.F);
     g.gtiles = B * g.tiles_t;
+    if (ic >= 32) {                                                  // small batches: 64 x 64 tiles, fewer and smaller slabs (fgcn_spatial_wgrad_tile.hip, swt_geom)
+        const int combos = (int)cdiv(Ce, 16 * g.CT) * (Cx / (16 * g.NT));
+        const int segs = std::max(1, (fgcn::tuning(17) > 0 ? fgcn::tuning(17) : 256) / combos);
+        if (fgcn::tuning(21) == 2 || (fgcn::tuning(21) == 0 && g.gtiles < 8 * segs)) g.CT = 4, g.NT = 4;
+    }
     g.n_cg = (int)cdiv(Ce, 16 * g.CT);
     g.n_og = Cx / (16 * g.NT);
     // every workgroup's channels must touch at most NM (subset, side) groups
@@ -690,20 +695,6 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
 #undef FGCN_ED_GO4
 #undef FGCN_ED_GO6
     return launch_status("emb_dx_tile");
-}
-
-// (tools only, not in include/fgcn.h) resident workgroups per CU of the 64-column / 128-column dx kernels as the runtime computes them
-extern "C" int fgcn_debug_emb_dx_occupancy(int nt) {
-    int n = -1;
-    hipError_t e;
-    if (nt == 1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<3, 1, 3, true, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<3>());
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emb_dx_tile_kernel<3, 1, 3, true, 1, 2>, 256, ed_lds<3>());
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<3, 2, 3, true, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<3>());
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, emb_dx_tile_kernel<3, 2, 3, true, 1, 4>, 256, ed_lds<3>());
-    }
-    return e == hipSuccess ? n : -1;
 }
 
 // slabs of `partial` / `bias_partial` (0: sizes the kernel does not take)

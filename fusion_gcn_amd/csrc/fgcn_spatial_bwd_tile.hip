@@ -77,10 +77,13 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
 
 // MAXS: mix units per wave and half (the host's table: two for four to six frames per tile, up to four for seven / eight)
 // NE: gated addends of dx (0 or 2; 2 only without accumulation)
-template <bool ACC, int MAXS, int NE = 0>
+// NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3), 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS
+// layout keeps room for three parts, the first is used)
+template <bool ACC, int MAXS, int NE = 0, int NP = 3>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     static_assert(NE == 0 || (NE == 2 && !ACC), "gated addends: both identity shortcuts, dx not live before");
-    constexpr int NP = 3;
+    static_assert(NP == 1 || NP == 3, "parts");
+    constexpr int LP = 3;                                            // parts the LDS layout has room for
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
@@ -113,10 +116,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
         const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
         unsigned ph, pm, pl;
         split_bf16_pair(a, 0.f, ph, pm, pl);
-        unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + v) * SB_AHB) + w;
+        unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * LP) * 32 + v) * SB_AHB) + w;
         d[0] = (unsigned short)ph;
-        d[32 * SB_AHB / 2] = (unsigned short)pm;
-        d[2 * 32 * SB_AHB / 2] = (unsigned short)pl;
+        if constexpr (NP == 3) {
+            d[32 * SB_AHB / 2] = (unsigned short)pm;
+            d[2 * 32 * SB_AHB / 2] = (unsigned short)pl;
+        }
     }
     // rows 128 .. 143 of every staging / image plane are never written again: zero them (a fragment of the last frame reads them)
     for (int i = tid; i < 12 * 256; i += 512) {
@@ -216,12 +221,11 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
-                    u32x2 ph, pm, pl;
-                    split3_x4(stg[i], ph, pm, pl);
+                    u32x2 parts[NP];
+                    splitn_x4<NP>(stg[i], parts);
                     unsigned char* dst = St + r * SB_XS + ((unsigned)(sg * 8) ^ swz(r));
-                    *reinterpret_cast<u32x2*>(dst) = ph;
-                    *reinterpret_cast<u32x2*>(dst + SB_PL) = pm;
-                    *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * SB_PL) = parts[pl];
                 }
             };
             auto load_a = [&](u32x4v (&dst)[NP], int j, const unsigned char* St) {
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if constexpr ((FGCN_PROBE_SB & 4) != 0) acc[i][j][0] += __builtin_bit_cast(float, wq[(PB + i) & 1][0][0] ^ a[j][0][0]);
-                        else acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
+                        else acc[i][j] = mfma_np_k32<NP>(wq[(PB + i) & 1], a[j], acc[i][j]);
                     }
                 }
             };
@@ -302,12 +306,11 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int R = wc * 64 + j * 16 + l15;
-                            u32x2 ph, pm, pl;
-                            split3_x4(acc[i][j], ph, pm, pl);
-                            unsigned char* dst = Im + ((mm >> 1) * NP) * SB_PL + R * SB_XS + ((unsigned)(((mm & 1) * 16 + 4 * g4) * 2) ^ swz(R));
-                            *reinterpret_cast<u32x2*>(dst) = ph;
-                            *reinterpret_cast<u32x2*>(dst + SB_PL) = pm;
-                            *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
+                            u32x2 parts[NP];
+                            splitn_x4<NP>(acc[i][j], parts);
+                            unsigned char* dst = Im + ((mm >> 1) * LP) * SB_PL + R * SB_XS + ((unsigned)(((mm & 1) * 16 + 4 * g4) * 2) ^ swz(R));
+#pragma unroll
+                            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * SB_PL) = parts[pl];
                         }
                     }
                 }
@@ -331,18 +334,18 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     const int f = (wave >> 1) + 4 * u;
                     if (f >= nf) continue;                           // wave-uniform
                     u32x4v xs[NP];
-                    split3_x8(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
+                    splitn_x8<NP>(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
 #pragma unroll
                         for (int wt = 0; wt < 2; ++wt) {
                             const int R = f * V + 16 * wt + l15;
-                            const unsigned char* src = Im + (k * NP) * SB_PL + R * SB_XS + ((unsigned)(16 * g4) ^ swz(R));
+                            const unsigned char* src = Im + (k * LP) * SB_PL + R * SB_XS + ((unsigned)(16 * g4) ^ swz(R));
                             u32x4v bf[NP];
 #pragma unroll
                             for (int pl = 0; pl < NP; ++pl) bf[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
                             if constexpr ((FGCN_PROBE_SB & 1) != 0) gacc[k][wt][0] += __builtin_bit_cast(float, xs[0][0] ^ bf[0][0]);
-                            else gacc[k][wt] = mfma_x3_k32(xs, bf, gacc[k][wt]);
+                            else gacc[k][wt] = mfma_np_k32<NP>(xs, bf, gacc[k][wt]);
                         }
                 }
                 if constexpr (NE == 2) {                             // the gated addends are the mix accumulators' start
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     for (int vt = 0; vt < 2; ++vt)
 #pragma unroll
                         for (int pl = 0; pl < NP; ++pl)
-                            af[vt][pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * vt + l15) * SB_AHB + 16 * g4);
+                            af[vt][pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * LP + pl) * 32 + 16 * vt + l15) * SB_AHB + 16 * g4);
 #pragma unroll
                     for (int s = 0; s < MAXS; ++s) {
                         if (!(sok[s] && sf[s] < nf)) continue;       // wave-uniform
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                         u32x4v df[NP];
 #pragma unroll
                         for (int pl = 0; pl < NP; ++pl) {
-                            const unsigned char* base = Im + (k * NP + pl) * SB_PL;
+                            const unsigned char* base = Im + (k * LP + pl) * SB_PL;
                             const u32x2 lo = sb_read_tr16(base + r_lo * SB_XS + (cb ^ swz(r_lo)));
                             const u32x2 hi = sb_read_tr16(base + r_hi * SB_XS + (cb ^ swz(r_hi)));
                             df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                         for (int vt = 0; vt < 2; ++vt) {
                             if constexpr ((FGCN_PROBE_SB & 2) != 0) dxa[s][vt][0] += __builtin_bit_cast(float, df[0][0] ^ af[vt][0][0]);
-                            else dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
+                            else dxa[s][vt] = mfma_np_k32<NP>(df, af[vt], dxa[s][vt]);
                         }
                     }
                 }
@@ -705,7 +708,8 @@ using namespace fgcn;
 // multiplies three-way bf16 splits and takes the fgcn_pack_split3 form of the weights; whole 64-channel input groups, 64-channel steps of the
 // contraction; 16..32 joints: at most 8 frames per 128-row tile)
 extern "C" int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout) {
-    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 && Cout % 64 == 0 && Cout > 0) ? 1 : 0;
+    return ((fgcn::math_mode() == FGCN_MATH_BF16X3 || fgcn::math_mode() == FGCN_MATH_BF16) && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 &&
+            Cout % 64 == 0 && Cout > 0) ? 1 : 0;
 }
 
 // segments per sample = partial matrices per sample: one workgroup per CU (256 in all) when the batch allows it -- every workgroup pays the
@@ -725,13 +729,13 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
                                      int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
                                      const unsigned char* mask2, void* stream) {
     const bool gated = extra1 != nullptr;
-    FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0 && fgcn::tuning(11) != 2), FGCN_E_BADARG,
+    FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0), FGCN_E_BADARG,
                  "spatial_bwd_tile: gated addends come in pairs with their sign images, without accumulation, on contiguous (B, T, V, Cin) tensors");
     FGCN_REQUIRE(!gated || (aligned16(extra1) && aligned16(extra2)), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte aligned addends");
     FGCN_REQUIRE(dy && x && a_hat && w3 && dx && partial, FGCN_E_BADARG, "spatial_bwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "spatial_bwd_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_spatial_bwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
-                 "spatial_bwd_tile: needs math mode bf16x3, 16 <= V <= %d, Cin %% 64 == 0, Cout %% 64 == 0 (V=%d Cin=%d Cout=%d)",
+                 "spatial_bwd_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, Cin %% 64 == 0, Cout %% 64 == 0 (V=%d Cin=%d Cout=%d)",
                  FGCN_MAX_V, V, Cin, Cout);
     FGCN_REQUIRE(ld_dy % 4 == 0 && ld_x % 4 == 0 && ld_dx % 4 == 0 && ld_dy >= Cout && ld_x >= Cin && ld_dx >= Cin, FGCN_E_ALIGN,
                  "spatial_bwd_tile: row strides");
@@ -794,7 +798,8 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     const dim3 grid((unsigned)(B * p.nseg));
     hipStream_t s = (hipStream_t)stream;
     // tuning key 11 = 2: two four-wave workgroups per CU (measured 8-22 % slower than the eight-wave form: see the kernel's comment)
-    if (fgcn::tuning(11) == 2) {
+    const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once (the eight-wave form only)
+    if (fgcn::tuning(11) == 2 && !gated && !one_part) {          // (the four-wave form takes no gated addends: such a call runs the eight-wave form)
 #define FGCN_SB4_GO(ACC_, MX_)                                                                                         \
     do {                                                                                                                \
         static bool opted = false;                                                                                      \
@@ -815,15 +820,20 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
 #undef FGCN_SB4_GO
         return launch_status("spatial_bwd_tile");
     }
-#define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
+#define FGCN_SB_GO4(ACC_, MS_, NE_, NP_)                                                                               \
     do {                                                                                                                \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_LDS);                         \
             opted = true;                                                                                               \
         }                                                                                                               \
-        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_>), grid, dim3(512), SB_LDS, s, p);                \
+        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_>), grid, dim3(512), SB_LDS, s, p);           \
+    } while (0)
+#define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
+    do {                                                                                                                \
+        if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1);                                                                   \
+        else FGCN_SB_GO4(ACC_, MS_, NE_, 3);                                                                            \
     } while (0)
 #define FGCN_SB_GO(ACC_, MS_)                                                                                          \
     do {                                                                                                                \
@@ -848,5 +858,6 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     }
 #undef FGCN_SB_GO
 #undef FGCN_SB_GO3
+#undef FGCN_SB_GO4
     return launch_status("spatial_bwd_tile");
 }

@@ -48,14 +48,17 @@ constexpr int ST_AHB = 80;              // bytes per [w] row of a split A^ plane
 constexpr int ST_XS = 64;               // bytes per image row and part (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
 constexpr int ST_PLANE = 256 * ST_XS;   // one part of the image: two pairs x 128 rows
 
-template <int NT, int MAXU, bool STR = false>                   // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
+// STR: non-temporal output stores (fgcn_common.hpp, stream_out); NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3),
+// 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout keeps room for three parts, the first is used)
+template <int NT, int MAXU, bool STR = false, int NP = 3>
 __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
-    constexpr int NP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    constexpr int LP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
+    static_assert(NP == 1 || NP == 3, "parts");
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) float smem_st[];
     unsigned char* Xh = reinterpret_cast<unsigned char*>(smem_st);   // [3 parts][2 pairs x 128 rows][64 B]
-    unsigned char* ahs = Xh + NP * ST_PLANE;                         // [3 subsets][3 parts][32 w][ST_AHB]
+    unsigned char* ahs = Xh + LP * ST_PLANE;                         // [3 subsets][3 parts][32 w][ST_AHB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4, l31 = lane & 31, h = lane >> 5;
@@ -74,17 +77,33 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
 
-    // A^_k of this sample, split once per workgroup: [subset][part][w][v] bf16 (one ds_read_b128 = the 8 joints of a lane's fragment)
-    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
-    for (int i = tid; i < 3 * 32 * 32; i += 256) {
-        const int k = i >> 10, w = (i >> 5) & 31, v = i & 31;
-        const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
-        unsigned ph, pm, pl;
-        split_bf16_pair(a, 0.f, ph, pm, pl);
-        unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * NP) * 32 + w) * ST_AHB) + v;
-        d[0] = (unsigned short)ph;
-        d[32 * ST_AHB / 2] = (unsigned short)pm;
-        d[2 * 32 * ST_AHB / 2] = (unsigned short)pl;
+    // A^_k of this sample, split once per workgroup: [subset][part][w][v] bf16 (one ds_read_b128 = the 8 joints of a lane's fragment).
+    // All twelve requests of a thread are in flight at once (branch-free buffer loads; absent joints carry the out-of-range offset): as a
+    // loop of conditional loads they were twelve dependent round trips at the start of EVERY 128-row tile (round 5: the same pattern cost
+    // the embedding-backward kernel 22 % of its time, profiles/r05_kbench_emb_bwd_variants.txt).
+    {
+        const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)asrc, 0, (unsigned)(3 * V * V) * 4u, 0x00020000);
+        float av[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int i = tid + 256 * e;
+            const int k = e >> 2, w = (i >> 5) & 31, v = i & 31;       // (256 threads: subset = e / 4)
+            av[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (v < V && w < V) ? (unsigned)((k * V + v) * V + w) * 4u : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int i = tid + 256 * e;
+            const int k = e >> 2, w = (i >> 5) & 31, v = i & 31;
+            unsigned ph, pm, pl;
+            split_bf16_pair(av[e], 0.f, ph, pm, pl);
+            unsigned short* d = reinterpret_cast<unsigned short*>(ahs + ((k * LP) * 32 + w) * ST_AHB) + v;
+            d[0] = (unsigned short)ph;
+            if constexpr (NP == 3) {
+                d[32 * ST_AHB / 2] = (unsigned short)pm;
+                d[2 * 32 * ST_AHB / 2] = (unsigned short)pl;
+            }
+        }
     }
 
     // this wave's aggregation units of a chunk: the 2 F units in frame-major order (f0 q0, f0 q1, f1 q0, ...) are dealt to the waves in
@@ -139,28 +158,27 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
             if (!(ushare[i] && same_ci)) {                           // wave-uniform
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    split3_x8(xr[i][8 * s2], xr[i][8 * s2 + 1], xr[i][8 * s2 + 2], xr[i][8 * s2 + 3], xr[i][8 * s2 + 4], xr[i][8 * s2 + 5],
-                              xr[i][8 * s2 + 6], xr[i][8 * s2 + 7], xs[s2]);
+                    splitn_x8<NP>(xr[i][8 * s2], xr[i][8 * s2 + 1], xr[i][8 * s2 + 2], xr[i][8 * s2 + 3], xr[i][8 * s2 + 4], xr[i][8 * s2 + 5],
+                                  xr[i][8 * s2 + 6], xr[i][8 * s2 + 7], xs[s2]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4v af[NP];
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * NP + pl) * 32 * ST_AHB + 32 * s2);
-                agg = mfma_x3_k16(xs[s2], af, agg);                  // agg^T (32 c x 32 w): lane = joint w, register r = channel acc_row(r)
+                    af[pl] = *reinterpret_cast<const u32x4v*>(af_lane + (k * LP + pl) * 32 * ST_AHB + 32 * s2);
+                agg = mfma_np_k16<NP>(xs[s2], af, agg);                  // agg^T (32 c x 32 w): lane = joint w, register r = channel acc_row(r)
             }
             // this lane's joint w = l31 of frame uf: image row uq * 128 + uf * V + w, channels 8 g + 4 h + (0..3) per register group
             const int R = uq[i] * 128 + uf[i] * V + l31;
             if (l31 < V) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    u32x2 ph, pm, pl;
-                    split3_x4(f32x4{agg[4 * g], agg[4 * g + 1], agg[4 * g + 2], agg[4 * g + 3]}, ph, pm, pl);
+                    u32x2 parts[NP];
+                    splitn_x4<NP>(f32x4{agg[4 * g], agg[4 * g + 1], agg[4 * g + 2], agg[4 * g + 3]}, parts);
                     unsigned char* dst = Xh + R * ST_XS + ((unsigned)(16 * g + 8 * h) ^ swz(R));
-                    *reinterpret_cast<u32x2*>(dst) = ph;
-                    *reinterpret_cast<u32x2*>(dst + ST_PLANE) = pm;
-                    *reinterpret_cast<u32x2*>(dst + 2 * ST_PLANE) = pl;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * ST_PLANE) = parts[pl];
                 }
             }
         }
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
                     if constexpr ((FGCN_PROBE_ST & 2) != 0) acc[mt][nu][0] += __builtin_bit_cast(float, a[mt][0][0] ^ wq[nu % RS][0][0]);
-                    else acc[mt][nu] = mfma_x3_k32(a[mt], wq[nu % RS], acc[mt][nu]);
+                    else acc[mt][nu] = mfma_np_k32<NP>(a[mt], wq[nu % RS], acc[mt][nu]);
                     if (nu == NU - 1 && q == 0) load_a(a[mt], mt, 1);    // this fragment's last use: fetch the next step's
                 }
             }
@@ -288,7 +306,8 @@ static int sp_tile_frames(int V) { return 128 / V; }
 // 1 when fgcn_spatial_fwd_tile runs these sizes in the current math mode (split-bf16 products, whole 64-channel input groups,
 // 16..32 joints: at most 8 frames per 128-row tile)
 extern "C" int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout) {
-    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && !fgcn::f16x2_products() && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cout % 4 == 0) ? 1 : 0;
+    return (((fgcn::math_mode() == FGCN_MATH_BF16X3 && !fgcn::f16x2_products()) || fgcn::math_mode() == FGCN_MATH_BF16) && V >= 16 && V <= FGCN_MAX_V &&
+            Cin % 64 == 0 && Cout % 4 == 0) ? 1 : 0;
 }
 
 extern "C" int fgcn_spatial_fwd_tile_tiles(int B, int T, int V) {
@@ -301,7 +320,7 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
     FGCN_REQUIRE(x && a_hat && w3 && y, FGCN_E_BADARG, "spatial_fwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, FGCN_E_BADARG, "spatial_fwd_tile: bad sizes B=%d T=%d Cin=%d Cout=%d", B, T, Cin, Cout);
     FGCN_REQUIRE(fgcn_spatial_fwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
-                 "spatial_fwd_tile: needs math mode bf16x3 (bf16x3 products), 16 <= V <= %d, Cin %% 64 == 0, Cout %% 4 == 0 (V=%d Cin=%d Cout=%d)",
+                 "spatial_fwd_tile: needs math mode bf16x3 (bf16x3 products) or bf16, 16 <= V <= %d, Cin %% 64 == 0, Cout %% 4 == 0 (V=%d Cin=%d Cout=%d)",
                  FGCN_MAX_V, V, Cin, Cout);
     FGCN_REQUIRE(ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= Cin && ld_y >= Cout, FGCN_E_ALIGN, "spatial_fwd_tile: row strides");
     FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(y), FGCN_E_ALIGN, "spatial_fwd_tile: 16-byte alignment");
@@ -326,15 +345,21 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
     hipStream_t s = (hipStream_t)stream;
     const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
     const bool str = fgcn::stream_out(y_bytes);
-#define FGCN_ST_GO3(NT_, MU_, STR_)                                                                                 \
+#define FGCN_ST_GO4(NT_, MU_, STR_, NP_)                                                                            \
     do {                                                                                                            \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_, NP_>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             opted = true;                                                                                           \
         }                                                                                                           \
-        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_>), grid, dim3(256), lds, s, p);                   \
+        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_, NP_>), grid, dim3(256), lds, s, p);              \
+    } while (0)
+    const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
+#define FGCN_ST_GO3(NT_, MU_, STR_)                     \
+    do {                                                \
+        if (one_part) FGCN_ST_GO4(NT_, MU_, STR_, 1);   \
+        else FGCN_ST_GO4(NT_, MU_, STR_, 3);            \
     } while (0)
 #define FGCN_ST_GO(NT_, MU_)                                                                                        \
     do {                                                                                                            \
@@ -350,5 +375,6 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
     }
 #undef FGCN_ST_GO
 #undef FGCN_ST_GO3
+#undef FGCN_ST_GO4
     return launch_status("spatial_fwd_tile");
 }

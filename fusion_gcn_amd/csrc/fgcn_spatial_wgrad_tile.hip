@@ -72,9 +72,12 @@ __device__ __forceinline__ void swt_for_slots(Fn&& fn, std::integer_sequence<int
 // accumulators are added at the end); NT: 16-channel output tiles (4 or 8); NSLOT: frame slots of a wave per tile (ceil(F / FP) rounded up to
 // even -- compile time: the slots of a tile are straight-line code, so that the compiler counts the outstanding requests exactly (a run-time
 // slot loop put an s_waitcnt vmcnt(0) and register copies on its back edge: every request made ahead was waited for one slot later))
-template <int CT, int NT, int NSLOT>
+// NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3), 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout
+// keeps room for three parts, the first is used)
+template <int CT, int NT, int NSLOT, int NP = 3>
 __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p) {
-    constexpr int NP = 3, FP = 8 / CT;
+    constexpr int LP = 3, FP = 8 / CT;
+    static_assert(NP == 1 || NP == 3, "parts");
     constexpr int RS = swt_rs<NT>(), PL = SWT_ROWS * RS;
     constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = SWT_ROWS / RPP;    // 16-byte groups per row, rows per pass, passes
     static_assert(SWT_ROWS % RPP == 0 && NSLOT % 2 == 0, "staging passes / slot pairs");
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_lds[];
     unsigned char* Im = sw_lds;
-    unsigned char* Ah = sw_lds + NP * PL;
+    unsigned char* Ah = sw_lds + LP * PL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g4 = lane >> 4, q4 = l15 >> 2, c4 = lane & 3;
@@ -141,22 +144,23 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
             const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
             unsigned ph, pm, pl;
             split_bf16_pair(a, 0.f, ph, pm, pl);
-            unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + w) * SWT_AHB) + v;
+            unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * LP) * 32 + w) * SWT_AHB) + v;
             d[0] = (unsigned short)ph;
-            d[32 * SWT_AHB / 2] = (unsigned short)pm;
-            d[2 * 32 * SWT_AHB / 2] = (unsigned short)pl;
+            if constexpr (NP == 3) {
+                d[32 * SWT_AHB / 2] = (unsigned short)pm;
+                d[2 * 32 * SWT_AHB / 2] = (unsigned short)pl;
+            }
         }
     };
     auto deposit = [&]() {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int r = srow + RPP * i;
-            u32x2 ph, pm, pl;
-            split3_x4(stg[i], ph, pm, pl);
+            u32x2 parts[NP];
+            splitn_x4<NP>(stg[i], parts);
             unsigned char* dst = Im + r * RS + sg * 8;
-            *reinterpret_cast<u32x2*>(dst) = ph;
-            *reinterpret_cast<u32x2*>(dst + PL) = pm;
-            *reinterpret_cast<u32x2*>(dst + 2 * PL) = pl;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PL) = parts[pl];
         }
     };
 #pragma unroll
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
             float (&xr)[8] = xr2[PF == 2 ? (s & 1) : 0];
             const int f = fp + FP * s;
             u32x4v xs[NP];
-            split3_x8(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
+            splitn_x8<NP>(xr[0], xr[1], xr[2], xr[3], xr[4], xr[5], xr[6], xr[7], xs);
             if (!(FGCN_PROBE_SW & 4)) {
                 if constexpr (s + PF < NSLOT) xfetch(xr, g, s + PF);  // a later slot of this tile, or of the next tile
                 else xfetch(xr, g + 1, s + PF - NSLOT);
@@ -195,16 +199,15 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
                     u32x4v af[NP];
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
-                        af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * wt + l15) * SWT_AHB + 16 * g4);
-                    if constexpr ((FGCN_PROBE_SW & 2) != 0) m[wt] = __builtin_bit_cast(f32x4, af[0] ^ xs[0] ^ af[1] ^ xs[1] ^ af[2] ^ xs[2]);
-                    else m[wt] = mfma_x3_k32(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
+                        af[pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * LP + pl) * 32 + 16 * wt + l15) * SWT_AHB + 16 * g4);
+                    if constexpr ((FGCN_PROBE_SW & 2) != 0) m[wt] = __builtin_bit_cast(f32x4, af[0] ^ xs[0] ^ af[NP - 1] ^ xs[NP - 1]);
+                    else m[wt] = mfma_np_k32<NP>(af, xs, f32x4{0.f, 0.f, 0.f, 0.f});
                 }
                 if constexpr ((FGCN_PROBE_SW & 64) != 0) {
                     a3[k][0] = __builtin_bit_cast(u32x4v, m[0]);
-                    a3[k][1] = __builtin_bit_cast(u32x4v, m[1]);
-                    a3[k][2] = a3[k][0] ^ a3[k][1];
+                    a3[k][NP - 1] = __builtin_bit_cast(u32x4v, m[1]);
                 } else
-                    split3_x8(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3[k]);
+                    splitn_x8<NP>(m[0][0], m[0][1], m[0][2], m[0][3], m[1][0], m[1][1], m[1][2], m[1][3], a3[k]);
             }
             const int r_lo = f * V + 4 * g4 + q4, r_hi = r_lo + 16;
             u32x4v df[NP];
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    if constexpr ((FGCN_PROBE_SW & 1) != 0) acc[k][nt][0] += __builtin_bit_cast(float, a3[k][0][0] ^ a3[k][1][1] ^ a3[k][2][2] ^ df[0][0] ^ df[1][1] ^ df[2][2]);
-                    else acc[k][nt] = mfma_x3_k32(a3[k], df, acc[k][nt]);
+                    if constexpr ((FGCN_PROBE_SW & 1) != 0) acc[k][nt][0] += __builtin_bit_cast(float, a3[k][0][0] ^ a3[k][NP - 1][1] ^ df[0][0] ^ df[NP - 1][1]);
+                    else acc[k][nt] = mfma_np_k32<NP>(a3[k], df, acc[k][nt]);
                 }
             }
         };
@@ -281,6 +284,17 @@ static SwtGeom swt_geom(int B, int T, int V, int Cin, int Cout) {
     g.F = swt_frames(V);
     g.tiles_t = (int)cdiv(T, g.F);
     g.gtiles = B * g.tiles_t;
+    // Small batches: with 128-wide tiles a 256 -> 256 layer has 4 tile combinations, i.e. 64 row segments -- at 8 clips each workgroup
+    // would walk 3 of the 208 (sample, frame tile) pairs and write a 196 KB slab (50 MB of slabs for 64 MB of operands, and the block's
+    // reduction reads them back: reduce_multi took the same 0.34 ms per step at 8 clips as at 64).  Below 8 pairs per segment the tiles
+    // are 64 x 64: four times the combinations, a quarter of the segments and of the slab bytes; the operands are re-read from a cache they
+    // fit in at that size.  Tuning key 21: 1 = 128-wide tiles whenever the channels allow, 2 = 64-wide always.
+    {
+        const int combos = (Cin / (16 * g.CT)) * (Cout / (16 * g.NT));
+        const int segs = std::max(1, (fgcn::tuning(16) > 0 ? fgcn::tuning(16) : 256) / combos);
+        const bool few = g.gtiles < 8 * segs;
+        if (fgcn::tuning(21) == 2 || (fgcn::tuning(21) == 0 && few)) g.CT = 4, g.NT = 4;
+    }
     g.n_cg = Cin / (16 * g.CT);
     g.n_og = Cout / (16 * g.NT);
     // one workgroup per CU (tuning key 16 overrides the target)
@@ -297,7 +311,8 @@ using namespace fgcn;
 // 1 when fgcn_spatial_wgrad_tile runs these sizes in the current math mode (FGCN_MATH_BF16X3 with either product form: the kernel always
 // multiplies three-way bf16 splits; whole 64-channel groups on both sides; 16..32 joints)
 extern "C" int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout) {
-    return (fgcn::math_mode() == FGCN_MATH_BF16X3 && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 && Cout % 64 == 0 && Cout > 0) ? 1 : 0;
+    return ((fgcn::math_mode() == FGCN_MATH_BF16X3 || fgcn::math_mode() == FGCN_MATH_BF16) && V >= 16 && V <= FGCN_MAX_V && Cin % 64 == 0 && Cin > 0 &&
+            Cout % 64 == 0 && Cout > 0) ? 1 : 0;
 }
 
 // slabs of `partial` (0: sizes the kernel does not take)
@@ -329,15 +344,21 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
     p.p_bytes = (unsigned)((long long)g.nseg * 3 * Cin * Cout * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
-#define FGCN_SWT(CT_, NT_, NS_)                                                                                                  \
+#define FGCN_SWT4(CT_, NT_, NS_, NP_)                                                                                            \
     do {                                                                                                                          \
         static bool attr = false;                                                                                                 \
         if (!attr) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_>),              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, swt_lds<NT_>());                                \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_>), grid, dim3(512), swt_lds<NT_>(), s, p);                \
+        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_>), grid, dim3(512), swt_lds<NT_>(), s, p);           \
+    } while (0)
+    const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
+#define FGCN_SWT(CT_, NT_, NS_)                    \
+    do {                                           \
+        if (one_part) FGCN_SWT4(CT_, NT_, NS_, 1); \
+        else FGCN_SWT4(CT_, NT_, NS_, 3);          \
     } while (0)
     // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
     const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;
@@ -356,5 +377,6 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
     }
 #undef FGCN_SWT_NT
 #undef FGCN_SWT
+#undef FGCN_SWT4
     return launch_status("spatial_wgrad_tile");
 }

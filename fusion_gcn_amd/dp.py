@@ -32,6 +32,7 @@ class FlatGradients:
             offsets.append(total)
             total += (p.numel() + 3) // 4 * 4          # keeps every view 16-byte aligned
         self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.unused: List[bool] = [False] * len(self.params)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offsets)]
 
     def zero(self) -> None:
@@ -49,6 +50,7 @@ class FlatGradients:
     def gather(self) -> None:
         """Copy this step's gradients into the flat buffer (one multi-tensor copy) and re-point p.grad at it."""
         src, dst = [], []
+        self.unused = [p.grad is None for p in self.params]     # (allow_unused: all_reduce_mean(restore_unused=True) reads it)
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 # torch.optim skips parameters without a gradient; the flat update cannot, so an unused parameter is an
@@ -65,18 +67,36 @@ class FlatGradients:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, always: bool = False) -> None:
+    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, always: bool = False, restore_unused: bool = False) -> None:
         """Average gradients across replicas: one collective on the flat buffer.  ``always``: issue the collective for a
-        single-rank group too (what a 1-GPU box can prove about the RCCL path: tests/test_rccl_gpu.py)."""
+        single-rank group too (what a 1-GPU box can prove about the RCCL path: tests/test_rccl_gpu.py).  ``restore_unused`` (with
+        ``allow_unused``): a parameter that received no gradient on ANY rank gets ``p.grad = None`` back after the exchange, so a
+        torch.optim optimizer skips it exactly as in the single-rank run (no weight decay / momentum on it); one that some rank
+        did use keeps the averaged gradient on every rank.  Costs one small second all-reduce (a used-mask), only when something
+        was unused on this rank or any other."""
         self.gather()
         if not (dist.is_available() and dist.is_initialized()):
+            self._restore_unused(restore_unused, self.unused)
             return
         world = dist.get_world_size(group)
         if world == 1 and not always:
+            self._restore_unused(restore_unused, self.unused)
             return
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if world > 1:
             self.flat.mul_(1.0 / world)
+        if restore_unused and self.allow_unused:
+            # every rank must take part in the mask exchange whenever ANY rank has an unused parameter: first agree on that
+            mask = torch.tensor([0.0 if u else 1.0 for u in self.unused] + [float(any(self.unused))], device=self.flat.device)
+            dist.all_reduce(mask, op=dist.ReduceOp.SUM, group=group)
+            if float(mask[-1]) > 0:
+                self._restore_unused(True, [float(m) == 0.0 for m in mask[:-1]])
+
+    def _restore_unused(self, enabled: bool, unused) -> None:
+        if enabled and self.allow_unused:
+            for p, u in zip(self.params, unused):
+                if u:
+                    p.grad = None
 
 
 def shard_batch(n_total: int, rank: int, world: int) -> slice:

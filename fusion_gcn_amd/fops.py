@@ -776,3 +776,6 @@ class _JoinedVector(torch.autograd.Function):
 def joined_vector(forms: ParamForms, name: str, params: Sequence[torch.Tensor]) -> torch.Tensor:
     packed = forms.get(name, lambda: bias_form(list(params)), params[0].device)
     return _JoinedVector.apply(packed, *params)
+
+
+ops.bind_all_functions(globals())     # every Function's backward runs in its forward's library context (ops.Context)

@@ -405,3 +405,6 @@ class AGCNGraphConvolution(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         params = dict(self.named_parameters())
         return _AgcnConv1dFunction.apply(x, self, self.training, self.adj_b, *[params[n] for n in self._param_names()])
+
+
+ops.bind_all_functions(globals())     # every Function's backward runs in its forward's library context (ops.Context)

@@ -7,7 +7,9 @@ here computes anything in torch: a missing library or a non-gfx950 device raises
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
+import threading
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -22,27 +24,114 @@ MATH_MODES = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 2}     # FGCN_MATH_F32 
 # "f16x2" = FGCN_MATH_BF16X3 with FGCN_PRODUCTS_F16X2 in the convolution / 1x1 kernels: the weight forms built in this mode are
 # FGCN_PACK_SPLIT2H (``ScaledWeights``) and a kernel call takes the product form of the weights it is handed
 X3_MODES = ("bf16x3", "f16x2")        # float32-accurate split modes (every kernel outside the conv / 1x1 family is bf16x3 in both)
-_f16x2 = False
+
+
+class Context:
+    """A set of library settings (math mode, product form, kernel-variant table: ``fgcn_ctx``, include/fgcn.h) that is current PER
+    THREAD: ``with ops.context() as ctx:`` creates one from the thread's present settings, makes it current for this thread and
+    restores the previous one on exit; ``ops.set_math_mode`` / ``fgcn_set_tuning`` inside change it and nothing else.  Two threads
+    in two contexts (two models in two math modes on two streams) do not see each other's settings.  The autograd Functions of this
+    package remember the context of their forward and make it current on the autograd thread for their backward (``context_bound``).
+    Without any context a thread reads and writes the process-wide defaults (math mode bf16x3)."""
+
+    def __init__(self, handle: Optional[int]):
+        self.handle = handle            # None: the process-wide defaults
+        self.f16x2 = False              # the math mode's product form ("f16x2" = FGCN_MATH_BF16X3 + two-way f16 products)
+
+    def __del__(self):                  # the library object goes with the last reference (a Function's ctx may outlive the `with` block)
+        try:
+            if self.handle is not None and _lib is not None:
+                _lib.load().fgcn_ctx_destroy(self.handle)
+        except Exception:               # noqa: BLE001 - interpreter shutdown
+            pass
+        self.handle = None
+
+
+_DEFAULT_CONTEXT = Context(None)
+_tls = threading.local()
+
+
+def current_context() -> Context:
+    return getattr(_tls, "ctx", None) or _DEFAULT_CONTEXT
+
+
+@contextlib.contextmanager
+def use_context(ctx: Optional[Context]):
+    """Make ``ctx`` (None: the process-wide defaults) current on the calling thread for the duration."""
+    ctx = ctx or _DEFAULT_CONTEXT
+    prev = current_context()
+    if ctx is prev:
+        yield ctx
+        return
+    lib = _lib.load()
+    check(lib.fgcn_ctx_set_current(ctx.handle), "fgcn_ctx_set_current")
+    _tls.ctx = ctx
+    try:
+        yield ctx
+    finally:
+        check(lib.fgcn_ctx_set_current(prev.handle), "fgcn_ctx_set_current")
+        _tls.ctx = prev
+
+
+@contextlib.contextmanager
+def context(mode: Optional[str] = None):
+    """A fresh context (a copy of the thread's present settings, optionally with another math mode), current inside the block.  The
+    object lives as long as anything refers to it: a forward recorded inside the block runs its backward in this context even after
+    the block was left (``context_bound``)."""
+    handle = ctypes.c_void_p()
+    check(_lib.load().fgcn_ctx_create(ctypes.byref(handle)), "fgcn_ctx_create")
+    ctx = Context(handle.value)
+    ctx.f16x2 = current_context().f16x2
+    with use_context(ctx):
+        if mode is not None:
+            set_math_mode(mode)
+        yield ctx
+
+
+def context_bound(fn_cls):
+    """Class decorator for the package's torch.autograd.Function classes: the backward runs on an autograd worker thread, whose
+    current context is not the forward's -- remember the forward's and make it current around the backward."""
+    fwd, bwd = fn_cls.forward, fn_cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        ctx._fgcn_context = current_context()
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        with use_context(ctx._fgcn_context):
+            return bwd(ctx, *grads)
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    fn_cls.forward, fn_cls.backward = staticmethod(forward), staticmethod(backward)
+    return fn_cls
+
+
+def bind_all_functions(namespace: dict) -> None:
+    """``context_bound`` for every autograd Function class defined in a module (call at the end of the module with ``globals()``)."""
+    for obj in list(namespace.values()):
+        if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function \
+                and obj.__module__ == namespace.get("__name__") and not getattr(obj, "_fgcn_bound", False):
+            context_bound(obj)
+            obj._fgcn_bound = True
 
 
 def set_math_mode(mode: str) -> None:
-    """Arithmetic of the convolution / GEMM kernels, process-wide: "f32" (default, the parity path) or "bf16" (BASELINE
-    config 5: operands rounded to bfloat16 as the MFMA fragments are formed, float32 accumulation; everything in HBM,
-    BatchNorm statistics, softmax and the joint mixing stay float32) or "bf16x3" (float32-accurate: operands split into
-    three bfloat16 terms, six partial products per MFMA step, float32 accumulation -- same tolerances as "f32") or "f16x2"
-    (float32-accurate as well: bf16x3 whose temporal / 1x1 convolutions form every product from block-scaled two-way f16
-    splits, three MFMAs instead of six; include/fgcn.h FGCN_PRODUCTS_F16X2)."""
-    global _f16x2
+    """Arithmetic of the convolution / GEMM kernels in the calling thread's current context (the process-wide defaults when the
+    thread has none): "bf16x3" (the default: float32-accurate -- operands split into three bfloat16 terms, six partial products per
+    MFMA step, float32 accumulation; same tolerances as "f32") or "f32" (exact float32 MFMAs, the parity path) or "bf16" (BASELINE
+    config 5: operands rounded to bfloat16 as the MFMA fragments are formed, float32 accumulation; everything in HBM, BatchNorm
+    statistics, softmax and the joint mixing stay float32) or "f16x2" (float32-accurate as well: bf16x3 whose temporal / 1x1
+    convolutions form every product from block-scaled two-way f16 splits, three MFMAs instead of six; include/fgcn.h
+    FGCN_PRODUCTS_F16X2)."""
     if mode not in MATH_MODES:
         raise _lib.FgcnError(f"unknown math mode {mode!r} (f32 | bf16 | bf16x3 | f16x2)")
     check(_lib.load().fgcn_set_math_mode(MATH_MODES[mode]), "fgcn_set_math_mode")
-    _f16x2 = mode == "f16x2"
-    check(_lib.load().fgcn_set_products(int(_f16x2)), "fgcn_set_products")
+    current_context().f16x2 = mode == "f16x2"
+    check(_lib.load().fgcn_set_products(int(mode == "f16x2")), "fgcn_set_products")
 
 
 def get_math_mode() -> str:
     m = _lib.load().fgcn_get_math_mode()
-    return "f16x2" if (m == 2 and _f16x2) else {0: "f32", 1: "bf16", 2: "bf16x3"}[m]
+    return "f16x2" if (m == 2 and current_context().f16x2) else {0: "f32", 1: "bf16", 2: "bf16x3"}[m]
 
 
 class ScaledWeights:
@@ -71,7 +160,7 @@ def _mode_products() -> None:
     """The product form of the current math mode (f16x2: two-way f16 splits) -- for entry points that take no weight form of their
     own to read it from, and after a wrapper that switched the form for one call (the library's product form is process-global)."""
     if _lib.load().fgcn_get_math_mode() == 2:
-        check(_lib.load().fgcn_set_products(int(_f16x2)), "fgcn_set_products")
+        check(_lib.load().fgcn_set_products(int(current_context().f16x2)), "fgcn_set_products")
 
 
 def _use_products_of(w) -> None:
@@ -345,20 +434,20 @@ class ReduceBatch:
         self.keep = []
 
 
-_reduce_batch: Optional[ReduceBatch] = None
+def _batch() -> Optional[ReduceBatch]:
+    return getattr(_tls, "reduce_batch", None)
 
 
 @contextlib.contextmanager
 def deferred_reductions():
-    """Collect leaf reductions instead of launching them one by one (see ReduceBatch); not re-entrant."""
-    global _reduce_batch
-    if _reduce_batch is not None:
+    """Collect leaf reductions instead of launching them one by one (see ReduceBatch); per thread, not re-entrant."""
+    if _batch() is not None:
         raise _lib.FgcnError("deferred_reductions is not re-entrant")
-    batch = _reduce_batch = ReduceBatch()
+    batch = _tls.reduce_batch = ReduceBatch()
     try:
         yield batch
     finally:
-        _reduce_batch = None
+        _tls.reduce_batch = None
         if batch.items:          # an exception skipped the caller's flush: nothing may stay unreduced silently
             batch.flush()
         batch.release()
@@ -379,9 +468,10 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
     if conv_param is None:
         if out is None:
             out = torch.empty((taps, K, N), device=partial.device, dtype=torch.float32)
-        batch = _reduce_batch if _reduce_batch is not None else ReduceBatch()
+        cur = _batch()
+        batch = cur if cur is not None else ReduceBatch()
         batch.add(out, partial, slabs, taps, K, N, K, K * N, N, 1, accumulate)       # same kernel form as the parameter layout
-        if batch is not _reduce_batch:
+        if batch is not cur:
             batch.flush()
         return out
     groups, k_true = conv_param
@@ -397,8 +487,8 @@ def _reduce_slabs(partial: torch.Tensor, taps: int, K: int, N: int, out: Optiona
         out = torch.empty(shape, device=partial.device, dtype=torch.float32)
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise _lib.FgcnError(f"weight-gradient output must be contiguous {shape}, got {tuple(out.shape)}")
-    if _reduce_batch is not None:
-        _reduce_batch.add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
+    if _batch() is not None:
+        _batch().add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
         return out
     one = ReduceBatch()          # on its own: the same kernel (its few-slabs form), one item
     one.add(out, partial, slabs, g_taps, g_k, N, k_true, st_tap, st_k, st_n, accumulate)
@@ -508,8 +598,8 @@ def reduce_sum(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False, l
     S, count = src.shape[0], src[0].numel()
     if dst.numel() != count:
         raise _lib.FgcnError("reduce_sum: size mismatch")
-    if leaf and _reduce_batch is not None and count < (1 << 31):
-        _reduce_batch.add(dst, src, S, 1, 1, count, 1, 0, 0, 1, accumulate)
+    if leaf and _batch() is not None and count < (1 << 31):
+        _batch().add(dst, src, S, 1, 1, count, 1, 0, 0, 1, accumulate)
         return dst
     check(_lib.load().fgcn_reduce_sum(_p(dst), _p(src), S, count, int(accumulate), _stream()), "fgcn_reduce_sum")
     return dst
@@ -956,9 +1046,11 @@ def spatial_fwd(x: torch.Tensor, a_hat: torch.Tensor, wd: torch.Tensor, bias_sum
 
 
 def spatial_fwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
-    """Whether ``spatial_fwd_tile`` runs these sizes in the current math mode (bf16x3 products, Cin % 64 == 0, 16 <= V <= 32)."""
-    _mode_products()
-    return bool(_lib.load().fgcn_spatial_fwd_tile_available(V, Cin, Cout))
+    """Whether ``spatial_fwd_tile`` runs these sizes in the current math mode (bf16x3 products or bf16, Cin % 64 == 0, 16 <= V <= 32).  A pure
+    query: the answer is formed from the MODE's product form, whatever form the last kernel call of this context left selected."""
+    if current_context().f16x2:
+        return False
+    return _lib.load().fgcn_get_math_mode() in (1, 2) and 16 <= V <= 32 and Cin % 64 == 0 and Cout % 4 == 0 and Cin > 0
 
 
 def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,

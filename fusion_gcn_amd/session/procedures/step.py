@@ -52,10 +52,13 @@ class Step(abc.ABC):
                 params = [p for g in optimizer.param_groups for p in g["params"]]
                 key = (id(optimizer),) + tuple((id(p), p.device) for p in params)
                 if self._dp_grads is None or self._dp_key != key:   # another optimizer / model on this Step object, or moved parameters
-                    # (torch.optim skips parameters without a gradient; so does the exchange: they travel as zeros)
+                    # (torch.optim skips parameters without a gradient: they travel as zeros, and one that NO rank used gets
+                    # p.grad = None back after the exchange -- the optimizer then skips it as in the single-rank run)
                     self._dp_grads, self._dp_key = FlatGradients(params, allow_unused=True), key
                 grads = self._dp_grads
-            grads.all_reduce_mean()
+                grads.all_reduce_mean(restore_unused=True)
+            else:
+                grads.all_reduce_mean()
         return optimizer.step()
 
     def reset(self) -> None:
@@ -102,6 +105,7 @@ class MixedPrecisionStep(Step):
             self._inner.backward(loss)
 
     def reset(self):
+        super().reset()
         self._inner = DefaultStep()
 
     def get_state_dict_objects(self, object_container: dict):
@@ -209,6 +213,7 @@ class GraphStep(Step):
         return optimizer.step()
 
     def reset(self):
+        super().reset()
         self._recorded.clear()
         self._done = None
 

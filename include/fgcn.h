@@ -38,8 +38,23 @@ const char* fgcn_last_error(void);
 /* 0 if the current HIP device is gfx950, FGCN_E_ARCH otherwise (message names the arch found). */
 int fgcn_check_device(void);
 
-/* Select a kernel variant (process-wide; for tuning tools and same-box A/B runs -- value 0 of every key is the measured-best
- * default, every other form computes the same result in another summation order at most).  Keys 0..31 (others: FGCN_E_BADARG):
+/* Contexts: where the settings live that the launchers read on the host at call time -- the math mode, the product form and the
+ * kernel-variant table below.  Every thread has a CURRENT context; a thread that never made one current reads (and, through the
+ * setters below, writes) the process-wide defaults.  fgcn_ctx_create copies the calling thread's current settings into a new
+ * context; fgcn_ctx_set_current(ctx) makes it current for the CALLING THREAD ONLY (NULL: back to the process-wide defaults);
+ * fgcn_set_math_mode / fgcn_set_products / fgcn_set_tuning then change that context and nothing else.  Two threads with two contexts
+ * -- two models in two math modes on two streams -- therefore never see each other's settings (tests/test_context_gpu.py).  A caller
+ * whose work continues on another thread (an autograd backward) makes the same context current there for the duration of its calls:
+ * fusion_gcn_amd.ops.context_bound does that for every autograd Function of the host.  A context must not be destroyed while it is
+ * current on the destroying thread, and not while another thread still uses it. */
+typedef struct fgcn_ctx fgcn_ctx;
+int fgcn_ctx_create(fgcn_ctx** out);
+int fgcn_ctx_destroy(fgcn_ctx* ctx);
+int fgcn_ctx_set_current(fgcn_ctx* ctx);
+fgcn_ctx* fgcn_ctx_get_current(void);
+
+/* Select a kernel variant in the calling thread's current context (for tuning tools and same-box A/B runs -- value 0 of every key is the
+ * measured-best default, every other form computes the same result in another summation order at most).  Keys 0..31 (others: FGCN_E_BADARG):
  *   0  row-GEMM tile when N <= 64: 0 = 128x(32*nt) rows per workgroup, 1 = 256-row tile (default), 2 = 256-row, double-buffered LDS
  *   1  row GEMM, wider N: 0 = two barriers per K chunk, 1 = double-buffered LDS
  *   4  f32 halo conv: 0 = three workgroups per CU, 1 = two
@@ -57,19 +72,24 @@ int fgcn_check_device(void);
  *      over 192-row tiles from 1536 tiles on); 16: the 4 x 1 form with a 128-column tile for every N > 64 (default: 64 < N <= 128 only); 32: never; 64: the 4 x 1 form at <= 64 columns whatever the tile count (tests)
  *   10 output stores of the activation-writing kernels: 0 = non-temporal (streamed past L2) when the call writes 96 MiB or more, plain below;
  *      1 = always plain; 2 = always non-temporal (same results in every setting: tests/test_block_model_gpu.py)
- *   11 fgcn_spatial_bwd_tile: 2 = two four-wave workgroups per CU (8-22 % slower; parity-tested)
+ *   11 fgcn_spatial_bwd_tile: 2 = two four-wave workgroups per CU (8-22 % slower; parity-tested); calls with gated addends always run the
+ *      eight-wave form
  *   12 joint gram of three equal-width items: 1 = the generic kernel (default: joint_gram3_kernel)
  *   13 fgcn_spatial_wgrad: workgroups to aim for (0 = 512 up to 32 samples, 1024 above)
  *   15 fgcn_spatial_bwd_tile: workgroups to aim for (0 = 256, one per CU; sets the segment count, i.e. the shape of `partial`)
  *   16 fgcn_spatial_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
  *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
  *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
- *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two) */
+ *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two)
+ *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 0 = 64 x 64 tiles when a row segment would hold fewer than 8 (sample, frame tile)
+ *      pairs (small batches: fewer, smaller slabs), 1 = the widest tiles the channels allow, 2 = 64 x 64 always */
 int fgcn_set_tuning(int key, int value);
+int fgcn_get_tuning(int key);
 
-/* Arithmetic of the convolution / GEMM kernels (process-wide; the reference's counterpart is its mixed-precision step,
- * session/procedures/step.py:55-78, which wraps model(x) in autocast):
- *   FGCN_MATH_F32  (default) v_mfma_f32_32x32x2_f32 on float32 operands -- the parity path (<= 1e-3 rel);
+/* Arithmetic of the convolution / GEMM kernels, a setting of the calling thread's current context (the reference's counterpart is its
+ * mixed-precision step, session/procedures/step.py:55-78, which wraps model(x) in autocast).  The process-wide default is
+ * FGCN_MATH_BF16X3: the arithmetic bench.py reports (float32-accurate, 1.57x the step rate of FGCN_MATH_F32 on MI355X).
+ *   FGCN_MATH_F32  v_mfma_f32_32x32x2_f32 on float32 operands -- the exact-f32 parity path (<= 1e-3 rel);
  *   FGCN_MATH_BF16 (BASELINE config 5) operands rounded to bfloat16 (round-to-nearest-even) once -- as a tile is staged,
  *                  as a fragment is formed, or (weights of fgcn_tconv_halo) by fgcn_pack_split3 -- bf16 MFMAs with float32
  *                  accumulation; tensors in HBM, BatchNorm statistics, softmax, the joint mixing and every reduction
@@ -79,7 +99,7 @@ int fgcn_set_tuning(int key, int value);
  *                  three bfloat16 terms (x = x_h + x_m + x_l, 24 significand bits) and the six partial products down
  *                  to 2^-16 of the leading one are accumulated in float32 (the dropped ones are below 2^-23 |a.b|, the
  *                  rounding of a float32 product).  Six bf16 MFMAs replace four f32 MFMAs (2.67x the f32 matrix
- *                  rate); same tolerance contract as FGCN_MATH_F32 (the parity tests run in both). */
+ *                  rate); same tolerance contract as FGCN_MATH_F32 (the parity tests run in both).  The default. */
 #define FGCN_MATH_F32 0
 #define FGCN_MATH_BF16 1
 #define FGCN_MATH_BF16X3 2
@@ -450,7 +470,7 @@ int fgcn_spatial_tiles(int B, int T);
  *   aggregation x . A^_k of a (32-channel tile, subset) pair is formed once per workgroup on the matrix pipe and written to an LDS
  *   image, from which the feature contraction runs like one tap of fgcn_tconv_halo.
  *   w3: fgcn_pack_split3 form (acc_order 0) of the (3 Cin) x Cout matrix [k * Cin + c][o] = Wd_k[o][c] (one tap, K = 3 Cin); three
- *   subsets; Cin %% 64 == 0; 16 <= V <= 32.  stat_partials: float[fgcn_spatial_fwd_tile_tiles(B, T, V)][2][Cout] or NULL.
+ *   subsets; Cin % 64 == 0; 16 <= V <= 32.  stat_partials: float[fgcn_spatial_fwd_tile_tiles(B, T, V)][2][Cout] or NULL.
  *   fgcn_spatial_fwd_tile_available: 1 when the current math mode / products and these sizes run on this kernel. */
 int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
                           float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
@@ -465,7 +485,7 @@ int fgcn_spatial_fwd_tile_available(int V, int Cin, int Cout);
  *   dy (B,T,V,>=Cout), x (B,T,V,>=Cin), a_hat (B or 1, 3, V, V), dx (B,T,V,>=Cin);
  *   w3: fgcn_pack_split3 form (acc_order 0) of the Cout x (3 Cin) matrix [o][k * Cin + c] = Wd_k[o][c] (one tap, K = Cout);
  *   partial: float[B][fgcn_spatial_bwd_tile_segments(B, T, V)][3][32][32] (rows v, columns w; entries beyond V are zero) -- the layout
- *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin %% 64 == 0, Cout %% 64 == 0; 16 <= V <= 32; math mode bf16x3 with either product form (the
+ *   fgcn_adj_softmax_bwd sums.  Three subsets; Cin % 64 == 0, Cout % 64 == 0; 16 <= V <= 32; math mode bf16x3 with either product form (the
  *   kernel always multiplies three-way bf16 splits: fgcn_spatial_bwd_tile_available).  accumulate != 0: dx += (load, add, store); every sum has a fixed order.
  *   extra1 / mask1, extra2 / mask2 (all four or none; not with accumulate; ld_x == Cin): dx = ... + extra_i * [bit of mask_i] -- contiguous
  *   (B, T, V, Cin) tensors with fgcn_bn_act's one-bit sign images: the ReLU-gated gradients of the block's two identity shortcuts

@@ -43,7 +43,7 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
 
 
-# The kernel / block / model parity modules run three times on the GPU: in the default math mode (exact f32 MFMA), in "bf16x3"
+# The kernel / block / model parity modules run three times on the GPU: in "f32" (exact f32 MFMA), in "bf16x3"
 # (f32-accurate split-bf16 products, include/fgcn.h) and in "f16x2" (bf16x3 whose temporal / 1x1 convolutions form their products
 # from block-scaled two-way f16 splits, FGCN_PRODUCTS_F16X2) -- the same oracle, the same tolerances.
 BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu", "test_train_e2e_gpu", "test_imu_gcn", "test_grad_parity_gpu", "test_msg3d", "test_session_gpu"}
@@ -56,8 +56,11 @@ def pytest_generate_tests(metafunc):
 
 @pytest.fixture(autouse=True)
 def fgcn_math(request):
+    """Every test runs in an explicitly selected math mode: "f32" (exact-f32 MFMAs, the kernel tests' tight tolerances) unless the
+    module is parametrised over the three float32-class modes.  (The LIBRARY's own default is bf16x3 -- tests/test_abi.py checks it.)"""
     mode = getattr(request, "param", "f32")
-    if mode == "f32":
+    from fusion_gcn_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):           # no library built: only tests that never touch it can pass anyway
         yield mode
         return
     from fusion_gcn_amd import ops

@@ -132,3 +132,15 @@ def test_fresh_build_from_sources(tmp_path):
     exported = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True, check=True).stdout
     for n in _declared_symbols():
         assert re.search(rf"\bT {n}\b", exported), f"fresh build does not export {n}"
+
+
+def test_library_default_is_the_benchmarked_arithmetic(lib):
+    """A drop-in that follows INTEGRATION.md section 2 alone (no set_math_mode call) computes in bf16x3 -- the float32-accurate
+    arithmetic bench.py reports -- not in the 1.57x slower exact-f32 mode: checked in a fresh process, where no test
+    fixture has selected a mode."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "from fusion_gcn_amd import ops, _lib; print(ops.get_math_mode(), _lib.load().fgcn_get_products(), "
+                        "_lib.load().fgcn_get_tuning(0), _lib.load().fgcn_get_tuning(1))"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["bf16x3", "0", "1", "0"], r.stdout

@@ -43,6 +43,20 @@ def test_bench_starts_its_own_ranks_and_reports_strong_scaling():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dry_run"] is True
     assert out["config"]["global_batch"] == 64 and out["config"]["per_gpu_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    # the N > 1 line proves which collective ran where: backend, world, every rank's device, the all-reduce timed alone, and it carries
+    # the CPU baseline too (rank 0; the dry run does not time it)
+    coll = out["collective"]
+    assert coll["backend"] == "gloo" and coll["world"] == 2 and [d["rank"] for d in coll["devices"]] == [0, 1]
+    assert all(set(d) >= {"rank", "local_device", "name"} for d in coll["devices"])
+    assert coll["allreduce_bytes"] == 4 * 3_469_510 and coll["allreduce_ms"] > 0 and coll["allreduce_reps"] >= 1 and "rccl_version" in coll
+    assert out["cpu_baseline"]["kind"] == "port"
+    assert out["metric"].startswith("clips/sec (N,C,T,V,M)=(64,3,300,25,2)")
+    # the clip count in `metric` follows the batch that ran
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    out8 = json.loads([ln for ln in r8.stdout.splitlines() if ln.startswith("{")][0])
+    assert out8["metric"].startswith("clips/sec (N,C,T,V,M)=(8,3,300,25,2)") and out8["config"]["per_gpu_batch"] == 4
     # a batch that does not divide over the ranks is refused before any work
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "7", "--dry-run"],
                        env=env, capture_output=True, text=True, timeout=300)

@@ -238,3 +238,47 @@ def test_embedding_backward_tile_form_bf16(V, T, ic, cx, B):
     dx2 = gpu(base)
     ops.emb_dx_tile(gpu(emb), gpu(ds), w3, dx2, ic=ic, accumulate=True)
     assert torch.equal(dx, dx2)
+
+
+TILE_SHAPES = [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2), (22, 31, 256, 256, 1)]
+
+
+@pytest.mark.parametrize("V,T,cin,cout,B", TILE_SHAPES)
+def test_spatial_tile_kernels_with_one_bf16_part(V, T, cin, cout, B):
+    """The three tile kernels of the spatial stage (fgcn_spatial_fwd_tile, fgcn_spatial_bwd_tile, fgcn_spatial_wgrad_tile; reference
+    agcn.py:103-111 and its backward) instantiated with ONE bf16 part (FGCN_MATH_BF16, BASELINE config 5): every operand -- x, A^, the
+    on-chip aggregation / dagg, dy, the weights -- is rounded to bfloat16 once, products accumulate in float32.  Against the float64
+    formulas on operands rounded the same way (the kernel rounds a float32 intermediate, the formula a float64 one: a few last-bit
+    differences, 2e-4 in relative L2); bitwise reproducible."""
+    from fusion_gcn_amd import ops
+    assert ops.spatial_fwd_tile_available(V, cin, cout) and ops.spatial_bwd_tile_available(V, cin, cout) and ops.spatial_wgrad_tile_available(V, cin, cout)
+    x, a = rnd(B, T, V, cin, seed=400), rnd(B, 3, V, V, seed=401, scale=0.3)
+    wd, bias = rnd(3, cin, cout, seed=402, scale=(3 * cin) ** -0.5), rnd(cout, seed=403)
+    dy, base = rnd(B, T, V, cout, seed=404), rnd(B, T, V, cin, seed=405)
+    agg = torch.einsum("btvc,bkvw->btwkc", bf(x), bf(a))
+    # forward
+    want_y = torch.einsum("btwkc,kco->btwo", bf(agg), bf(wd)) + bias
+    w3 = ops.pack_split3(gpu(wd.reshape(1, 3 * cin, cout)))
+    y, part = ops.spatial_fwd_tile(gpu(x), gpu(a), w3, gpu(bias), Cin=cin, Cout=cout, stats=True)
+    assert rel_l2(y.cpu().numpy(), want_y.numpy()) < 2e-4
+    assert rel_l2(part.double().sum(0)[0].cpu().numpy(), y.double().sum((0, 1, 2)).cpu().numpy()) < TOL
+    y2, _ = ops.spatial_fwd_tile(gpu(x), gpu(a), w3, gpu(bias), Cin=cin, Cout=cout, stats=True)
+    assert torch.equal(y, y2)
+    # conv_d's weight gradient
+    want_w = torch.einsum("btwkc,btwo->kco", bf(agg), bf(dy)).reshape(1, 3 * cin, cout)
+    gw = ops.spatial_wgrad_tile(gpu(x), gpu(dy), gpu(a))
+    assert rel_l2(gw.cpu().numpy(), want_w.numpy()) < 2e-4
+    assert torch.equal(gw, ops.spatial_wgrad_tile(gpu(x), gpu(dy), gpu(a)))
+    # backward: dx and the partial grams
+    wt = wd.permute(2, 0, 1).reshape(1, cout, 3 * cin)                       # [o][k cin + c]
+    dagg = torch.einsum("btwo,okc->btwkc", bf(dy), bf(wt).reshape(cout, 3, cin))
+    want_dx = base + torch.einsum("btwkc,bkvw->btvc", bf(dagg), bf(a))
+    want_g = torch.einsum("btvc,btwkc->bkvw", bf(x), bf(dagg))
+    w3t = ops.pack_split3(gpu(wt))
+    dx = gpu(base)
+    part_g = ops.spatial_bwd_tile(gpu(dy), gpu(x), gpu(a), w3t, dx, accumulate=True)
+    assert rel_l2(dx.cpu().numpy(), want_dx.numpy()) < 2e-4
+    assert rel_l2(part_g.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_g.numpy()) < 2e-4
+    dx2 = gpu(base)
+    part_g2 = ops.spatial_bwd_tile(gpu(dy), gpu(x), gpu(a), w3t, dx2, accumulate=True)
+    assert torch.equal(dx, dx2) and torch.equal(part_g, part_g2)

@@ -112,6 +112,67 @@ def test_eager_steps_exchange_gradients_too():
         torch.testing.assert_close(torch.from_numpy(mine), want.detach(), rtol=1e-5, atol=1e-6)
 
 
+class _PartlyUsed(nn.Module):
+    """`a` is used by every rank, `b` by rank 1 only, `c` by no rank."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a, self.b, self.c = nn.Linear(4, 3), nn.Linear(4, 3), nn.Linear(4, 3)
+
+    def forward(self, x, use_b):
+        return self.a(x) + (self.b(x) if use_b else 0)
+
+
+def _unused_worker(rank, world, port, out_q):
+    from fusion_gcn_amd.session.procedures.step import DefaultStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _PartlyUsed()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=0.5)
+        step = DefaultStep()
+        g = torch.Generator().manual_seed(3 + rank)
+        for _ in range(2):
+            opt.zero_grad()
+            x, y = torch.randn(6, 4, generator=g), torch.randint(0, 3, (6,), generator=g)
+            loss = F.cross_entropy(model(x, use_b=rank == 1), y)
+            step.backward(loss)
+            step.run_optimizer_step(opt)
+        out_q.put((rank, {k: v.detach().clone().numpy() for k, v in model.state_dict().items()},
+                   [p.grad is None for p in model.c.parameters()], [p.grad is None for p in model.b.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unused_parameters_keep_the_single_rank_semantics():
+    """A parameter that received no gradient on ANY rank must come back from the exchange with p.grad = None, so that torch.optim
+    skips it (no weight decay, no momentum) as in the single-rank run (the reference's behaviour); one that some rank
+    used travels as zeros from the others and is updated identically everywhere."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unused_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, sd, c_none, b_none = q.get(timeout=120)
+        got[rank] = sd
+        assert all(c_none) and not any(b_none), (rank, c_none, b_none)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fresh = _PartlyUsed().state_dict()
+    for k in fresh:
+        assert (got[0][k] == got[1][k]).all(), k                      # replicas in lock step
+        if k.startswith("c."):
+            assert (got[0][k] == fresh[k].numpy()).all(), k           # untouched: no decay was applied
+        else:
+            assert not (got[0][k] == fresh[k].numpy()).all(), k
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -695,6 +695,13 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs                  # the setting really changed the segmentation
     frames = min(8, 128 // V + 1)                                                          # frames per tile: (F - 1) V + 32 <= 160 rows
     assert slabs[100000] == B * ((T + frames - 1) // frames), slabs
+    for tiles in (1, 2):                        # the widest tiles the channels allow / 64 x 64 tiles (the small-batch rule picks by size)
+        try:
+            assert lib.fgcn_set_tuning(21, tiles) == 0
+            gt = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a))
+        finally:
+            assert lib.fgcn_set_tuning(21, 0) == 0
+        assert rel_l2(gt.cpu().numpy(), want.numpy()) < RED_TOL, tiles
     shared = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a[:1]))                    # static (shared) adjacency
     want_s = torch.einsum("btvc,kvw,btwo->kco", x.double(), a[0].double(), dy.double()).reshape(1, 3 * cin, cout)
     assert rel_l2(shared.cpu().numpy(), want_s.numpy()) < RED_TOL
@@ -766,6 +773,13 @@ def test_embedding_backward_tile_form(V, T, ic, cx, B):
         assert rel_l2(g2.cpu().numpy(), want_w.numpy()) < RED_TOL, target
         assert rel_l2(b2.cpu().numpy(), want_b.numpy()) < RED_TOL, target
     assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs
+    for tiles in (1, 2):                        # the widest tiles the channels allow / 64 x 64 tiles
+        try:
+            assert lib.fgcn_set_tuning(21, tiles) == 0
+            gt, bt = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds), ic=ic)
+        finally:
+            assert lib.fgcn_set_tuning(21, 0) == 0
+        assert rel_l2(gt.cpu().numpy(), want_w.numpy()) < RED_TOL and rel_l2(bt.cpu().numpy(), want_b.numpy()) < RED_TOL, tiles
     # shared dS (one matrix set for every sample)
     _, sh_dx, sh_w, sh_b = emb_backward_reference(emb, ds[:1].expand(B, 3, V, V), x, w, ic)
     dx = torch.empty(B, T, V, cx, device=dev())

@@ -50,7 +50,7 @@ def _long_way(P, cfg, mode):
     d_list = [_pad_last(P[f"gcn1.conv_d.{k}.weight"].view(cout, cin), cx) for k in range(3)]
     R["d"] = torch.cat([w.t() for w in d_list], 0).contiguous()
     R["d4"] = ops.pack_spatial(R["d"], cx)
-    if mode == "bf16x3" and cx % 64 == 0:          # the tile form of the fused spatial kernel takes the plain split form
+    if mode in ("bf16x3", "bf16") and cx % 64 == 0:   # the tile form of the fused spatial kernel takes the plain split form (bf16: its part 0)
         R["d_s3"] = ops.pack_split3(R["d"].unsqueeze(0))
     R["d_t"] = torch.cat(d_list, 1).contiguous().unsqueeze(0)
     R["d_b"] = P["gcn1.conv_d.0.bias"] + P["gcn1.conv_d.1.bias"] + P["gcn1.conv_d.2.bias"]
@@ -73,8 +73,10 @@ def _long_way(P, cfg, mode):
         for key in ("emb", "emb_t", "d_t", "down", "down_t"):
             if key in R and R[key].shape[1] % 32 == 0:
                 R[key + "_s3"] = ops.pack_split3(R[key])
-    if mode in ("bf16x3", "f16x2") and cx % 64 == 0 and cout % 64 == 0:     # the fused spatial backward's weights: three-way bf16 splits in both modes
+    if mode in ("bf16x3", "f16x2", "bf16") and cx % 64 == 0 and cout % 64 == 0:   # the fused spatial backward's weights: three-way bf16 splits in every split mode
         R["d_t_b3"] = ops.pack_split3(R["d_t"])
+    if mode in ops.SPLIT_MODES and cx % 64 == 0:   # the embedding backward in tile form (fgcn_emb_dx_tile)
+        R["emb_t_b3"] = ops.pack_split3(R["emb_t"])
     return R
 
 
