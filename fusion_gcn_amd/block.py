@@ -280,6 +280,10 @@ SPATIAL_WGRAD_TILE = os.environ.get("FGCN_SPATIAL_WGRAD_TILE", "1") != "0"
 # frame on the matrix pipe inside the two kernels that consume it (dx += demb . Wemb; dWemb = demb^T . x, dbemb) and never exists in HBM --
 # replaces joint_mix_vec(demb) + the 1x1 data-gradient GEMM + the 1x1 weight-gradient GEMM.  FGCN_EMB_TILE=0: that chain.
 EMB_TILE = os.environ.get("FGCN_EMB_TILE", "1") != "0"
+# ... up to this many input channels.  Same-call A/B of the replayed 64-clip step (profiles/r05_ab_emb_tile.txt): every block 53.79 / 53.90 ms,
+# up to 128 channels 53.63 / 53.56, up to 64 channels 53.79 / 53.75, none (FGCN_EMB_TILE=0) 54.09 / 54.22 -- at 256 channels (l8, l9) both
+# kernels are bound by the matrix pipe (47 GFLOP each at 110-125 TFLOP/s of mixing-padded work) and the unfused chain's plain GEMMs win.
+EMB_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_TILE_MAX_CIN", "128"))
 SPATIAL_WGRAD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_WGRAD_TILE_F16X2", "1") != "0"
 FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
 # ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
@@ -726,7 +730,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        if (EMB_TILE and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
+        if (EMB_TILE and cin <= EMB_TILE_MAX_CIN and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
                 and small(max(6 * ic, cx))):
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)

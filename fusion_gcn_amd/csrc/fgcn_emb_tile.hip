@@ -578,11 +578,7 @@ static EwGeom ew_geom(int B, int T, int V, int ic, int Cx) {
     g.F = ew_frames(V);
     g.tiles_t = (int)cdiv(T, g.F);
     g.gtiles = B * g.tiles_t;
-    if (ic >= 32) {                                                  // small batches: 64 x 64 tiles, fewer and smaller slabs (fgcn_spatial_wgrad_tile.hip, swt_geom)
-        const int combos = (int)cdiv(Ce, 16 * g.CT) * (Cx / (16 * g.NT));
-        const int segs = std::max(1, (fgcn::tuning(17) > 0 ? fgcn::tuning(17) : 256) / combos);
-        if (fgcn::tuning(21) == 2 || (fgcn::tuning(21) == 0 && g.gtiles < 8 * segs)) g.CT = 4, g.NT = 4;
-    }
+    if (ic >= 32 && fgcn::tuning(21) == 2) g.CT = 4, g.NT = 4;        // (tuning key 21 = 2: 64 x 64 tiles; see fgcn_spatial_wgrad_tile.hip, swt_geom)
     g.n_cg = (int)cdiv(Ce, 16 * g.CT);
     g.n_og = Cx / (16 * g.NT);
     // every workgroup's channels must touch at most NM (subset, side) groups

@@ -284,17 +284,11 @@ static SwtGeom swt_geom(int B, int T, int V, int Cin, int Cout) {
     g.F = swt_frames(V);
     g.tiles_t = (int)cdiv(T, g.F);
     g.gtiles = B * g.tiles_t;
-    // Small batches: with 128-wide tiles a 256 -> 256 layer has 4 tile combinations, i.e. 64 row segments -- at 8 clips each workgroup
-    // would walk 3 of the 208 (sample, frame tile) pairs and write a 196 KB slab (50 MB of slabs for 64 MB of operands, and the block's
-    // reduction reads them back: reduce_multi took the same 0.34 ms per step at 8 clips as at 64).  Below 8 pairs per segment the tiles
-    // are 64 x 64: four times the combinations, a quarter of the segments and of the slab bytes; the operands are re-read from a cache they
-    // fit in at that size.  Tuning key 21: 1 = 128-wide tiles whenever the channels allow, 2 = 64-wide always.
-    {
-        const int combos = (Cin / (16 * g.CT)) * (Cout / (16 * g.NT));
-        const int segs = std::max(1, (fgcn::tuning(16) > 0 ? fgcn::tuning(16) : 256) / combos);
-        const bool few = g.gtiles < 8 * segs;
-        if (fgcn::tuning(21) == 2 || (fgcn::tuning(21) == 0 && few)) g.CT = 4, g.NT = 4;
-    }
+    // Tuning key 21 = 2: 64 x 64 tiles whatever the channels allow.  (Tried as the rule for small batches -- with 128-wide tiles a 256 -> 256
+    // layer has 64 row segments, at 8 clips each walks 3 (sample, frame tile) pairs and writes a 196 KB slab, 50 MB of slabs per launch,
+    // which the block's reduction reads back; 64 x 64 tiles quarter the slab bytes -- and measured SLOWER in the replayed step: 8 clips
+    // 9.16 -> 9.34 ms, 16 clips 16.11 -> 16.18, profiles/r05_ab_small_batch.txt: each operand is then read four times instead of twice.)
+    if (fgcn::tuning(21) == 2) g.CT = 4, g.NT = 4;
     g.n_cg = Cin / (16 * g.CT);
     g.n_og = Cout / (16 * g.NT);
     // one workgroup per CU (tuning key 16 overrides the target)

@@ -81,8 +81,7 @@ fgcn_ctx* fgcn_ctx_get_current(void);
  *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
  *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
  *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two)
- *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 0 = 64 x 64 tiles when a row segment would hold fewer than 8 (sample, frame tile)
- *      pairs (small batches: fewer, smaller slabs), 1 = the widest tiles the channels allow, 2 = 64 x 64 always */
+ *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 2 = 64 x 64 tiles (default: the widest tiles the channels allow) */
 int fgcn_set_tuning(int key, int value);
 int fgcn_get_tuning(int key);
 

@@ -695,7 +695,7 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs                  # the setting really changed the segmentation
     frames = min(8, 128 // V + 1)                                                          # frames per tile: (F - 1) V + 32 <= 160 rows
     assert slabs[100000] == B * ((T + frames - 1) // frames), slabs
-    for tiles in (1, 2):                        # the widest tiles the channels allow / 64 x 64 tiles (the small-batch rule picks by size)
+    for tiles in (0, 2):                        # the widest tiles the channels allow (default) / 64 x 64 tiles
         try:
             assert lib.fgcn_set_tuning(21, tiles) == 0
             gt = ops.spatial_wgrad_tile(to_gpu(x), to_gpu(dy), to_gpu(a))
@@ -773,7 +773,7 @@ def test_embedding_backward_tile_form(V, T, ic, cx, B):
         assert rel_l2(g2.cpu().numpy(), want_w.numpy()) < RED_TOL, target
         assert rel_l2(b2.cpu().numpy(), want_b.numpy()) < RED_TOL, target
     assert slabs[2] <= 2 and slabs[2] <= slabs[0] <= slabs[100000], slabs
-    for tiles in (1, 2):                        # the widest tiles the channels allow / 64 x 64 tiles
+    for tiles in (0, 2):                        # the widest tiles the channels allow (default) / 64 x 64 tiles
         try:
             assert lib.fgcn_set_tuning(21, tiles) == 0
             gt, bt = ops.emb_wgrad_tile(to_gpu(emb), to_gpu(x), to_gpu(ds), ic=ic)
