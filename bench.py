@@ -222,7 +222,7 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-TRAFFIC_RECORDS = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")      # newest first
+TRAFFIC_RECORDS = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")      # newest first
 
 
 def measured_traffic(dom, samples, math="f32"):
@@ -243,6 +243,48 @@ def measured_traffic(dom, samples, math="f32"):
     if rec["channels"] != dom["channels"] or rec["frames"] != dom["frames"] or rec["samples"] != samples:
         return None
     return rec["traffic_bytes"]
+
+
+def live_traffic(math: str, batch: int, timeout_s: int = 150):
+    """HBM-side bytes per launch of the dominant kernel MEASURED in this run: two child processes, `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; nothing but --kernel-trace beside --pmc), each around
+    `python3 bench.py --kernel-only` (the same launches `time_dominant_kernel` times).  traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's
+    gfx950 correction: 16-byte-per-lane reads are tallied at half their bytes), KiB -> bytes, averaged over the kernel's launches.
+    -> (bytes or None, how it went).  Any failure (no rocprofv3, a timeout, an unreadable file) returns None: the caller then reports the
+    stored record and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="fgcn_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--kernel-only", "--math", math, "--batch", str(batch)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("WORLD_SIZE", None)
+        try:
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s, start_new_session=True)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out after {timeout_s} s"
+        files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+        vals = []
+        for f in files:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get("Counter_Name") == counter and "conv_halo" in row.get("Kernel_Name", ""):
+                        vals.append(float(row["Counter_Value"]))
+        shutil.rmtree(out_dir, ignore_errors=True)
+        if r.returncode != 0 or not vals:
+            return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(vals)} launches read"
+        got[counter] = (sum(vals) / len(vals), len(vals))
+    byts = int(round((2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024))
+    return byts, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes of `bench.py --kernel-only`, "
+                  f"{got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of the kernel), 2*FETCH_SIZE + WRITE_SIZE per launch")
 
 
 def metric_name(n_global: int) -> str:
@@ -392,6 +434,8 @@ def main():
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs for A/B runs, e.g. 6=21505")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1 only: report the stored PMC record as roofline.traffic instead of measuring it in two rocprofv3 child passes")
     ap.add_argument("--kernel-only", action="store_true",
                     help="only the live timing of the dominant kernel at its dominant shape (256 channels): the command "
                          "profiles/*_dominant_kernel_stats.csv is the rocprofv3 --kernel-trace --stats summary of")
@@ -698,6 +742,15 @@ def main():
                                          f"{dom['channels']} channels, {dom['frames']} frames)"}
             notes["roofline.traffic"] = ("stored rocprofv3 PMC record of this kernel at this shape (profiles/r0*_traffic.json: "
                                          "2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run")
+            if world == 1 and not args.no_live_traffic and not args.no_kernel_timing:
+                log("measuring the dominant kernel's HBM-side traffic (two rocprofv3 --pmc child passes)")
+                live, how = live_traffic(args.math, args.batch)
+                if live is not None:
+                    out["roofline"]["traffic_stored_record"] = out["roofline"]["traffic"]
+                    out["roofline"]["traffic"] = live
+                    notes["roofline.traffic"] = how
+                else:
+                    notes["roofline.traffic"] += f" (live measurement failed: {how})"
             notes["roofline.practical_ceiling"] = ("MI355X_MICROARCH.md: tuned bf16 MFMA loops reach 1.25-1.48 PFLOP/s on random data "
                                                    "(the chip lowers its clock to ~1.9 GHz under MFMA load); this kernel issues "
                                                    "6 x achieved of bf16 MFMA work")

@@ -83,5 +83,9 @@ def test_round2_traffic_record_shows_the_fetch_reduction():
     r4 = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))["conv_halo_x3_fwd"]
     assert r4["traffic_bytes"] == int(round((2 * r4["fetch_size_kib_raw"] + r4["write_size_kib"]) * 1024))
     assert abs(r4["traffic_bytes"] - r3["conv_halo_x3_fwd"]["traffic_bytes"]) < 0.005 * r4["traffic_bytes"]
-    assert bench.measured_traffic(dict(channels=256, frames=75), 128, "bf16x3") == r4["traffic_bytes"]
+    # round 5: re-collected once more (within 0.5 % again); it is the stored fallback now -- bench.py measures the figure live in its default run
+    r5 = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))["conv_halo_x3_fwd"]
+    assert r5["traffic_bytes"] == int(round((2 * r5["fetch_size_kib_raw"] + r5["write_size_kib"]) * 1024))
+    assert abs(r5["traffic_bytes"] - r4["traffic_bytes"]) < 0.005 * r5["traffic_bytes"]
+    assert bench.measured_traffic(dict(channels=256, frames=75), 128, "bf16x3") == r5["traffic_bytes"]
     assert bench.measured_traffic(dict(channels=256, frames=75), 128, "f16x2") == r3["conv_halo_f16x2_fwd"]["traffic_bytes"]
