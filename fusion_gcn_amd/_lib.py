@@ -116,6 +116,9 @@ SIGNATURES = {
     "fgcn_spatial_wgrad_tile": (_I, [_P] * 4 + [_I] * 8 + [_P]),
     "fgcn_spatial_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_spatial_wgrad_tile_available": (_I, [_I] * 3),
+    "fgcn_emb_fwd_tile": (_I, [_P] * 5 + [_I] * 7 + [_P]),
+    "fgcn_emb_fwd_tile_segments": (_I, [_I] * 4),
+    "fgcn_emb_fwd_tile_available": (_I, [_I] * 3),
     "fgcn_emb_dx_tile": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "fgcn_emb_dx_tile_workspace": (_LL, [_I, _I]),
     "fgcn_emb_wgrad_tile": (_I, [_P] * 5 + [_I] * 8 + [_P]),

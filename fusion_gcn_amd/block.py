@@ -8,7 +8,8 @@ needs padding).  Every arithmetic step is a libfgcn kernel (fusion_gcn_amd/ops.p
 the stream and trivial weight re-layout (cat / permute of the small parameter tensors, cached per parameter version).
 
 Kernel schedule of one block, train mode (B = N*M samples):
-  forward   rows_gemm(theta|phi 1x1)  -> joint_gram (V x V affinity) -> adj_softmax (A^ = A + B + C)
+  forward   emb_fwd_tile [split modes: theta|phi 1x1 with the V x V affinity gram formed from the tile on chip]
+               (else: rows_gemm / pw_gemm(theta|phi 1x1) -> joint_gram) -> adj_softmax (A^ = A + B + C)
             spatial_fwd  [fused x.A^_k + conv_d, BN partial sums]   (or joint_mix + rows_gemm when fused_spatial=False)
             bn_finalize -> [rows_gemm(down) -> bn_finalize] -> bn_act (BN + down/identity + ReLU = G)
             tconv_halo (9x1 temporal conv, stride 1; rows_gemm for stride 2) with BN partial sums -> bn_finalize
@@ -178,6 +179,9 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     # every split mode (bf16: its part 0)
     if "emb_t" in F and mode in ops.SPLIT_MODES and cx % 64 == 0:
         F["emb_t_b3"] = Form("split3", 1, 6 * ic, cx, F["emb_t"].segs)
+    # ... and the embedding forward with the gram on chip (ops.emb_fwd_tile) the split of emb
+    if "emb" in F and mode in ops.SPLIT_MODES and cx % 32 == 0:
+        F["emb_b3"] = Form("split3", 1, cx, 6 * ic, F["emb"].segs)
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
@@ -280,6 +284,10 @@ SPATIAL_WGRAD_TILE = os.environ.get("FGCN_SPATIAL_WGRAD_TILE", "1") != "0"
 # frame on the matrix pipe inside the two kernels that consume it (dx += demb . Wemb; dWemb = demb^T . x, dbemb) and never exists in HBM --
 # replaces joint_mix_vec(demb) + the 1x1 data-gradient GEMM + the 1x1 weight-gradient GEMM.  FGCN_EMB_TILE=0: that chain.
 EMB_TILE = os.environ.get("FGCN_EMB_TILE", "1") != "0"
+# the forward of the attention embeddings with the affinity gram on chip (fgcn_emb_fwd_tile.hip: emb = x . Wemb + b written once, theta_k^T phi_k
+# formed from the tile while it is in LDS -- replaces the 1x1 product + joint_gram and the gram's read of emb).  FGCN_EMB_FWD_TILE=0: that pair.
+EMB_FWD_TILE = os.environ.get("FGCN_EMB_FWD_TILE", "1") != "0"
+EMB_FWD_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_FWD_TILE_MAX_CIN", "4096"))
 # ... up to this many input channels.  Same-call A/B of the replayed 64-clip step (profiles/r05_ab_emb_tile.txt): every block 53.79 / 53.90 ms,
 # up to 128 channels 53.63 / 53.56, up to 64 channels 53.79 / 53.75, none (FGCN_EMB_TILE=0) 54.09 / 54.22 -- at 256 channels (l8, l9) both
 # kernels are bound by the matrix pipe (47 GFLOP each at 110-125 TFLOP/s of mixing-padded work) and the unfused chain's plain GEMMs win.
@@ -455,10 +463,14 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         emb, c_mat = None, None
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
-        emb = new(B, T, V, 6 * ic)
-        S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
-        pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
-        part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
+        if (EMB_FWD_TILE and cin <= EMB_FWD_TILE_MAX_CIN and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
+                and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
+            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic)             # emb written once, the gram from the tile on chip
+        else:
+            emb = new(B, T, V, 6 * ic)
+            S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
+            pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
+            part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
         c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_a, B, adj_b=adj_b)
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 

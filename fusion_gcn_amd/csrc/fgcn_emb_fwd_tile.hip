@@ -1,0 +1,307 @@
+// Forward of the attention embeddings with the affinity gram on chip (split-bf16 math modes):
+//
+//     emb[(n,t,v), j]   = sum_c x[(n,t,v), c] Wemb[c][j] + bemb[j],     j over [th0 ph0 th1 ph1 th2 ph2], each ic wide
+//     S_k[n][v][w]      = sum_{t,e} emb[(n,t,v), th_k + e] emb[(n,t,w), ph_k + e]        (partial sums per row segment)
+//
+// reference: A1 = conv_a[k](x), A2 = conv_b[k](x), torch.matmul(A1, A2) of SpatialGraphConv.forward, torch_src/models/mmargcn/agcn.py:104-106
+// (the 1 / (ic T) scale and the softmax stay in fgcn_adj_softmax_fwd).  Until round 5 the stacked 1x1 product wrote emb and fgcn_joint_gram
+// read all 1.5 activations of it back for ten V x V matrices per sample; emb has to be written for the backward, but the gram can be formed
+// from the tile while it is on chip.
+//
+// A workgroup (4 waves; 2 x 2 over channels x rows) owns a contiguous range of frame tiles (F = 128 / V whole frames) of ONE sample and CW
+// embedding channels: all 6 ic of them for ic = 16 / 32, one subset's th_k | ph_k (2 ic = 128) for ic = 64 (three workgroups per row range).
+//   * The product is formed TRANSPOSED: emb^T (CW x 128 rows) = Wemb^T . x^T with the pre-split weights (fgcn_pack_split3 of the Cin x 6 ic
+//     matrix; streamed from L2 through a two-slot ring) as the A operand and the x tile -- staged in 32-channel chunks as bf16 planes, split once,
+//     the next chunk parked in registers during the MFMAs -- as the B operand.  An accumulator lane then holds four consecutive CHANNELS of one
+//     row: 16-byte stores of emb, 8-byte pieces of the gram's image.
+//   * Per subset the tile's th_k | ph_k channels (bias included: what the reference multiplies) are split into an LDS image [row][2 ic]; wave
+//     (vt, wt) owns the 16 x 16 tile (v in 16 vt .., w in 16 wt ..) of S_k and adds, frame by frame, th_kf (A operand: image rows of the frame,
+//     8 channels per lane) . ph_kf^T (B operand: the same rows, the phi half) on 16x16x32 MFMAs; joints >= V are masked to zero.  The gram
+//     accumulators live across the workgroup's tiles: one (3, 32, 32) partial per row segment (fgcn_adj_softmax_fwd sums them).
+// NP = 3: exact three-way bf16 splits (FGCN_MATH_BF16X3, either product form); NP = 1: operands rounded to bfloat16 once (FGCN_MATH_BF16).
+// Every sum has a fixed order (bitwise reproducible).
+#include <algorithm>
+
+#include "fgcn_common.hpp"
+
+namespace fgcn {
+
+struct EmbFwP {
+    const float* x;
+    const void* w3;                     // fgcn_pack_split3 form of the Cin x (6 ic) matrix: [part][c / 8][j][8] bf16
+    const float* bias;                  // float[6 ic]
+    float* emb;
+    float* partial;                     // float[B][nseg][3][32][32]
+    int B, T, V, Cin, ic, Ce, ld_x, ld_e;
+    int F, tiles_t, tps, nseg, ncol;    // frames per tile, tiles per sample, tiles per segment, segments per sample, column workgroups
+    unsigned x_bytes, e_bytes, w_plane_bytes, p_bytes;
+};
+
+constexpr unsigned EF_OOB = 0x80000000u;
+constexpr int EF_XS = 64;               // bytes per row and part of the x image (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
+constexpr int EF_XPLANE = 128 * EF_XS;
+// gram image of one subset: [part][128 rows][2 ic channels x bf16 + 16 pad bytes]
+constexpr int ef_gs(int ic) { return 4 * ic + 16; }
+template <int NP> constexpr int ef_lds(int ic) { return std::max(NP * EF_XPLANE, NP * 128 * ef_gs(ic)); }
+
+// MU: 16-channel units per wave (CW = 32 MU channels per workgroup); IC: channels per group (16, 32, 64); NSUB: subsets of the workgroup
+// (3 when it holds all 6 ic channels, 1 when it holds th_k | ph_k of one subset)
+template <int NP, int MU, int IC, int NSUB>
+__global__ __launch_bounds__(256, IC == 64 ? 1 : 2) void emb_fwd_tile_kernel(EmbFwP p) {
+    constexpr int CW = 32 * MU, NR = 4, GS = ef_gs(IC), GPLANE = 128 * GS, KS = IC >= 32 ? IC / 32 : 1;
+    static_assert(CW == (NSUB == 3 ? 6 * IC : 2 * IC), "workgroup channels");
+    auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char ef_lds_raw[];
+    unsigned char* Xh = ef_lds_raw;                                  // x image [NP][128 rows][64 B] / gram image [NP][128 rows][GS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wc = wave & 1, wr = wave >> 1;
+    const int col_wg = blockIdx.x % p.ncol;
+    const int rs = blockIdx.x / p.ncol;
+    const int n = rs / p.nseg, seg = rs - n * p.nseg;
+    const int V = p.V, F = p.F;
+    const int tile_lo = seg * p.tps, tile_hi = min(tile_lo + p.tps, p.tiles_t);
+    const int cbase = col_wg * CW;                                   // first embedding channel of the workgroup
+    const int ch0 = cbase + wc * 16 * MU;                            // ... of this wave (+ 16 mu)
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)p.emb, 0, p.e_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (unsigned)p.Ce * 4u, 0x00020000);
+
+    // bias of this lane's channels: unit mu, channels ch0 + 16 mu + 4 g4 .. + 3
+    f32x4 bv[MU];
+#pragma unroll
+    for (int mu = 0; mu < MU; ++mu) bv[mu] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(ch0 + 16 * mu + 4 * g4) * 4u, 0, 0));
+
+    // weight fragment of (unit mu, 32-channel chunk kc): lane (channel l15, g4) <- Wemb[kc + 8 g4 .. + 7][ch0 + 16 mu + l15]
+    const int nchunks = p.Cin >> 5;
+    unsigned wvoff[MU];
+#pragma unroll
+    for (int mu = 0; mu < MU; ++mu) wvoff[mu] = (unsigned)(((long long)g4 * p.Ce + ch0 + 16 * mu + l15) * 16);
+    auto load_w = [&](u32x4v (&dst)[NP], int mu, int c) {
+        if (c >= nchunks) c = 0;                                     // past the last chunk: the first one of the next tile
+        const unsigned so = (unsigned)(((long long)(4 * c) * p.Ce) * 16);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff[mu], so + pl * p.w_plane_bytes, 0);
+    };
+    // x rows of a chunk: thread (row tid / 8 + 32 i, channels 4 (tid % 8) .. + 3)
+    const int srow = tid >> 3, sg = tid & 7;
+    f32x4 stg[4];
+    auto fetch = [&](int tile, int c) {
+        const int t0_ = tile * F;
+        const int nrows_ = tile < tile_hi ? min(F, p.T - t0_) * V : 0;
+        const unsigned row0_ = (unsigned)((n * p.T + t0_) * V);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            const unsigned off = r < nrows_ ? ((row0_ + (unsigned)r) * (unsigned)p.ld_x + (unsigned)(32 * c + 4 * sg)) * 4u : EF_OOB;
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            u32x2 parts[NP];
+            splitn_x4<NP>(stg[i], parts);
+            unsigned char* dst = Xh + r * EF_XS + ((unsigned)(sg * 8) ^ swz(r));
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * EF_XPLANE) = parts[pl];
+        }
+    };
+    const int xrow = wr * 64 + l15;                                  // + 16 nt
+    auto load_x = [&](u32x4v (&dst)[NP], int nt) {
+        const int r = xrow + 16 * nt;
+        const unsigned char* src = Xh + r * EF_XS + ((unsigned)(16 * g4) ^ swz(r));
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const u32x4v*>(src + pl * EF_XPLANE);
+    };
+
+    // gram accumulators: this wave's 16 x 16 tile (v tile vt, w tile wt) of every subset the workgroup holds
+    const int vt = wave >> 1, wt = wave & 1;
+    f32x4 gacc[NSUB];
+#pragma unroll
+    for (int k = 0; k < NSUB; ++k) gacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int RS = MU % 2 == 0 ? 2 : 3;                          // weight ring slots: a divisor of MU, so that unit 0 of the next chunk lands in slot 0
+    static_assert(MU % RS == 0, "ring");
+    u32x4v wq[RS][NP];
+    load_w(wq[0], 0, 0);
+    fetch(tile_lo, 0);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+        const int t0 = tile * F;
+        const int nf = min(F, p.T - t0);
+        const int nrows = nf * V;
+        const unsigned m0 = (unsigned)((n * p.T + t0) * V);
+        f32x4 acc[MU][NR];
+#pragma unroll
+        for (int mu = 0; mu < MU; ++mu)
+#pragma unroll
+            for (int nt = 0; nt < NR; ++nt) acc[mu][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- emb^T tile = Wemb^T . x^T ----------------------------------------------------------------------------------------------
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();                                         // the image (x chunk / gram image) is free
+            deposit();
+            __syncthreads();
+            if (c + 1 < nchunks) fetch(tile, c + 1);                 // lands during the MFMAs below
+            else fetch(tile + 1, 0);                                 // (past the segment: nothing is read)
+            u32x4v xf[NR][NP];
+#pragma unroll
+            for (int nt = 0; nt < NR; ++nt) load_x(xf[nt], nt);
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) {
+                if (mu + 1 < MU) load_w(wq[(mu + 1) % RS], mu + 1, c);
+                else load_w(wq[0], 0, c + 1);
+#pragma unroll
+                for (int nt = 0; nt < NR; ++nt) acc[mu][nt] = mfma_np_k32<NP>(wq[mu % RS], xf[nt], acc[mu][nt]);
+            }
+        }
+        // ---- bias, 16-byte stores of emb (lane = row, four consecutive channels per unit) ----------------------------------------------
+#pragma unroll
+        for (int mu = 0; mu < MU; ++mu)
+#pragma unroll
+            for (int nt = 0; nt < NR; ++nt) {
+                acc[mu][nt] += bv[mu];
+                const int R = wr * 64 + 16 * nt + l15;
+                const unsigned off = R < nrows ? ((m0 + (unsigned)R) * (unsigned)p.ld_e + (unsigned)(ch0 + 16 * mu + 4 * g4)) * 4u : EF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[mu][nt]), re, off, 0, 0);
+            }
+        // ---- the gram of every subset from the tile -----------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < NSUB; ++ks) {
+            __syncthreads();                                         // the previous image's reads are done
+#pragma unroll
+            for (int mu = 0; mu < MU; ++mu) {
+                const int cw = wc * 16 * MU + 16 * mu;               // unit's first channel inside the workgroup
+                const int grp = cw / IC;                             // (compile-time per mu for a given wc: wave-uniform)
+                if ((NSUB == 3 ? (grp >> 1) : 0) != ks) continue;
+                const int cg = cw - (NSUB == 3 ? 2 * ks * IC : 0);   // channel inside the subset's th | ph image
+#pragma unroll
+                for (int nt = 0; nt < NR; ++nt) {
+                    const int R = wr * 64 + 16 * nt + l15;
+                    u32x2 parts[NP];
+                    splitn_x4<NP>(acc[mu][nt], parts);
+                    unsigned char* dst = Xh + R * GS + (cg + 4 * g4) * 2;
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * GPLANE) = parts[pl];
+                }
+            }
+            __syncthreads();
+            for (int f = 0; f < nf; ++f) {
+                const bool a_ok = 16 * vt + l15 < V && (IC >= 32 || g4 < 2), b_ok = 16 * wt + l15 < V && (IC >= 32 || g4 < 2);
+                const int ra = a_ok ? f * V + 16 * vt + l15 : 0, rbw = b_ok ? f * V + 16 * wt + l15 : 0;   // (absent joints / channels: row 0, then zeroed)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    u32x4v af[NP], bf[NP];
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) {
+                        const u32x4v a = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + ra * GS + (32 * s + 8 * g4) * 2);
+                        const u32x4v b = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + rbw * GS + (IC + 32 * s + 8 * g4) * 2);
+                        af[pl] = a_ok ? a : u32x4v{0u, 0u, 0u, 0u};
+                        bf[pl] = b_ok ? b : u32x4v{0u, 0u, 0u, 0u};
+                    }
+                    gacc[ks] = mfma_np_k32<NP>(af, bf, gacc[ks]);
+                }
+            }
+        }
+    }
+
+    // ---- the segment's partial matrices: lane (w = 16 wt + l15, g4), register r -> v = 16 vt + 4 g4 + r ----------------------------------
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, p.p_bytes, 0x00020000);
+#pragma unroll
+    for (int ks = 0; ks < NSUB; ++ks) {
+        const int k = NSUB == 3 ? ks : col_wg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned off = ((((unsigned)(n * p.nseg + seg) * 3u + (unsigned)k) * 32u + (unsigned)(16 * vt + 4 * g4 + r)) * 32u + (unsigned)(16 * wt + l15)) * 4u;
+            const float val = gacc[ks][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rp, off, 0, 0);
+        }
+    }
+}
+
+struct EfGeom {
+    int F, tiles_t, tps, nseg, ncol;
+};
+static EfGeom ef_geom(int B, int T, int V, int ic) {
+    EfGeom g;
+    g.F = 128 / V;
+    g.tiles_t = (int)cdiv(T, g.F);
+    g.ncol = ic == 64 ? 3 : 1;
+    // resident workgroups: two per CU (one at ic = 64); tuning key 22 overrides the target
+    const int slots = fgcn::tuning(22) > 0 ? fgcn::tuning(22) : (ic == 64 ? 256 : 512);
+    const int want = std::max(1, slots / (B * g.ncol));              // segments per sample
+    g.tps = (int)cdiv(g.tiles_t, std::min(g.tiles_t, want));
+    g.nseg = (int)cdiv(g.tiles_t, g.tps);
+    return g;
+}
+
+static bool emb_fwd_mode_ok() { return fgcn::math_mode() == FGCN_MATH_BF16X3 || fgcn::math_mode() == FGCN_MATH_BF16; }
+static bool emb_fwd_sizes_ok(int V, int ic, int Cin) {
+    return V >= 16 && V <= FGCN_MAX_V && (ic == 16 || ic == 32 || ic == 64) && Cin >= 32 && Cin % 32 == 0;
+}
+
+}  // namespace fgcn
+
+using namespace fgcn;
+
+// 1 when fgcn_emb_fwd_tile runs these sizes in the current math mode (FGCN_MATH_BF16X3 with either product form -- the kernel always multiplies
+// three-way bf16 splits there -- or FGCN_MATH_BF16; 16 .. 32 joints; ic 16, 32 or 64; Cin a multiple of 32)
+extern "C" int fgcn_emb_fwd_tile_available(int V, int ic, int Cin) { return (emb_fwd_mode_ok() && emb_fwd_sizes_ok(V, ic, Cin)) ? 1 : 0; }
+
+// row segments per sample = partial matrices per sample (0: sizes the kernel does not take)
+extern "C" int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic) {
+    if (B <= 0 || T <= 0 || V < 16 || V > FGCN_MAX_V || !(ic == 16 || ic == 32 || ic == 64)) return 0;
+    return ef_geom(B, T, V, ic).nseg;
+}
+
+extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
+                                 int ic, int ld_x, int ld_e, void* stream) {
+    FGCN_REQUIRE(x && w3 && bias && emb && partial, FGCN_E_BADARG, "emb_fwd_tile: null pointer");
+    FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_fwd_tile: bad sizes B=%d T=%d", B, T);
+    FGCN_REQUIRE(fgcn_emb_fwd_tile_available(V, ic, Cin), FGCN_E_BADARG,
+                 "emb_fwd_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic 16 / 32 / 64, Cin %% 32 == 0 (V=%d ic=%d Cin=%d, mode %d)", FGCN_MAX_V,
+                 V, ic, Cin, fgcn::math_mode());
+    const int Ce = 6 * ic;
+    FGCN_REQUIRE(ld_x % 4 == 0 && ld_e % 4 == 0 && ld_x >= Cin && ld_e >= Ce, FGCN_E_ALIGN, "emb_fwd_tile: row strides");
+    FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(emb) && aligned16(bias) && (reinterpret_cast<uintptr_t>(partial) & 3u) == 0, FGCN_E_ALIGN,
+                 "emb_fwd_tile: 16-byte alignment");
+    const long long x_bytes = (long long)B * T * V * ld_x * 4, e_bytes = (long long)B * T * V * ld_e * 4;
+    const long long plane = (long long)Cin * Ce * 2;
+    FGCN_REQUIRE(x_bytes < 0x7FFF0000ll && e_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
+                 "emb_fwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    const EfGeom g = ef_geom(B, T, V, ic);
+    EmbFwP p;
+    p.x = x; p.w3 = w3; p.bias = bias; p.emb = emb; p.partial = partial;
+    p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.ic = ic; p.Ce = Ce; p.ld_x = ld_x; p.ld_e = ld_e;
+    p.F = g.F; p.tiles_t = g.tiles_t; p.tps = g.tps; p.nseg = g.nseg; p.ncol = g.ncol;
+    p.x_bytes = (unsigned)x_bytes; p.e_bytes = (unsigned)e_bytes; p.w_plane_bytes = (unsigned)plane;
+    p.p_bytes = (unsigned)((long long)B * g.nseg * 3 * 1024 * 4);
+    const dim3 grid((unsigned)(B * g.nseg * g.ncol));
+    hipStream_t s = (hipStream_t)stream;
+    const int np = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3;
+#define FGCN_EF(NP_, MU_, IC_, NSUB_)                                                                                       \
+    do {                                                                                                                    \
+        static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */    \
+        constexpr int lds_ = ef_lds<NP_>(IC_);                                                                              \
+        if (!opted) {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_fwd_tile_kernel<NP_, MU_, IC_, NSUB_>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                    \
+            opted = true;                                                                                                   \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((emb_fwd_tile_kernel<NP_, MU_, IC_, NSUB_>), grid, dim3(256), lds_, s, p);                       \
+    } while (0)
+#define FGCN_EF_NP(MU_, IC_, NSUB_)                    \
+    do {                                               \
+        if (np == 3) FGCN_EF(3, MU_, IC_, NSUB_);      \
+        else FGCN_EF(1, MU_, IC_, NSUB_);              \
+    } while (0)
+    if (ic == 16) FGCN_EF_NP(3, 16, 3);
+    else if (ic == 32) FGCN_EF_NP(6, 32, 3);
+    else FGCN_EF_NP(4, 64, 1);
+#undef FGCN_EF_NP
+#undef FGCN_EF
+    return launch_status("emb_fwd_tile");
+}

@@ -1111,6 +1111,33 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     return partial
 
 
+def emb_fwd_tile_available(V: int, ic: int, cin: int) -> bool:
+    """Whether ``emb_fwd_tile`` runs these sizes in the current math mode (bf16x3, f16x2 or bf16; 16 <= V <= 32, ic 16 / 32 / 64, cin % 32 == 0)."""
+    return bool(_lib.load().fgcn_emb_fwd_tile_available(int(V), int(ic), int(cin)))
+
+
+def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: int, cin: Optional[int] = None):
+    """-> (emb (B,T,V,6 ic) = x . Wemb + bias, partial (B, segments, 3, 32, 32) of the affinity grams theta_k^T phi_k) in one launch
+    (fgcn_emb_fwd_tile.hip; agcn.py:104-106).  w3 = ``pack_split3`` of the (1, cin, 6 ic) matrix; ``partial`` goes to ``adj_softmax_fwd``."""
+    ensure_device()
+    _chk(x, "emb_fwd_tile.x"), _chk(bias, "emb_fwd_tile.bias")
+    B, T, V, ld_x = x.shape
+    cin = ld_x if cin is None else int(cin)
+    if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, cin // 8, 6 * ic, 8) or not w3.is_contiguous() or bias.numel() != 6 * ic
+            or cin > ld_x):
+        raise _lib.FgcnError(f"emb_fwd_tile: shape mismatch x={tuple(x.shape)} w3={tuple(w3.shape)} bias={tuple(bias.shape)} ic={ic} "
+                             f"(weights: pack_split3 of the (1, cin, 6 ic) matrix)")
+    lib = _lib.load()
+    nseg = lib.fgcn_emb_fwd_tile_segments(B, T, V, ic)
+    if nseg <= 0:
+        raise _lib.FgcnError(f"emb_fwd_tile: sizes not supported: V={V} ic={ic}")
+    emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.float32)
+    partial = torch.empty((B, nseg, 3, 32, 32), device=x.device, dtype=torch.float32)
+    check(lib.fgcn_emb_fwd_tile(_p(x), w3.data_ptr(), _p(bias), _p(emb), _p(partial), B, T, V, cin, ic, ld_x, 6 * ic, _stream()),
+          "fgcn_emb_fwd_tile")
+    return emb, partial
+
+
 def emb_tile_available(V: int, ic: int, cx: int) -> bool:
     """Whether ``emb_dx_tile`` / ``emb_wgrad_tile`` run these sizes in the current math mode (bf16x3, f16x2 -- the kernels multiply
     three-way bf16 splits in both -- or bf16; 16 <= V <= 32, ic % 16 == 0, cx % 64 == 0)."""

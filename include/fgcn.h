@@ -81,7 +81,8 @@ fgcn_ctx* fgcn_ctx_get_current(void);
  *   17 fgcn_emb_wgrad_tile: workgroups to aim for (0 = 256; sets the slab count)
  *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
  *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two)
- *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 2 = 64 x 64 tiles (default: the widest tiles the channels allow) */
+ *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 2 = 64 x 64 tiles (default: the widest tiles the channels allow)
+ *   22 fgcn_emb_fwd_tile: resident workgroups to aim for (0 = 512, 256 at ic = 64; sets the segment count) */
 int fgcn_set_tuning(int key, int value);
 int fgcn_get_tuning(int key);
 
@@ -510,6 +511,20 @@ int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat,
                             int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream);
 int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int Cout);
 int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
+
+/* Forward of the attention embeddings with the affinity gram on chip (fgcn_emb_fwd_tile.hip; reference: A1 = conv_a[k](x), A2 = conv_b[k](x),
+ * torch.matmul(A1, A2) of SpatialGraphConv.forward, torch_src/models/mmargcn/agcn.py:104-106):
+ *     emb[(n,t,v), j] = sum_c x[(n,t,v), c] Wemb[c][j] + bias[j]     (B, T, V, ld_e) rows [th0 ph0 th1 ph1 th2 ph2], each `ic` wide: written
+ *     partial[n][s][k][v][w] = sum over the frames t of row segment s and the channels e of emb[(n,t,v), th_k + e] emb[(n,t,w), ph_k + e]
+ * w3 = fgcn_pack_split3 of the (1, Cin, 6 ic) matrix, bias: float[6 ic].  partial: float[B][fgcn_emb_fwd_tile_segments(B, T, V, ic)][3][32][32]
+ * (rows / columns >= V are zeros), the input format of fgcn_adj_softmax_fwd (nchunk = segments), which applies the 1 / (ic T) scale.
+ * Replaces fgcn_pw_gemm / fgcn_rows_gemm (emb) + fgcn_joint_gram and the gram's read of the 1.5-activation-wide emb.  Sizes: 16 <= V <=
+ * FGCN_MAX_V, ic 16 / 32 / 64, Cin a multiple of 32; math modes FGCN_MATH_BF16X3 (either product form: exact three-way bf16 splits) and
+ * FGCN_MATH_BF16: fgcn_emb_fwd_tile_available.  Tuning key 22: resident workgroups to aim for (0 = 512, 256 at ic = 64; sets the segment count). */
+int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin, int ic,
+                      int ld_x, int ld_e, void* stream);
+int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic);
+int fgcn_emb_fwd_tile_available(int V, int ic, int Cin);
 
 /* Backward of the attention embeddings with the embedding gradient on chip (fgcn_emb_tile.hip; reference: the autograd backward of
  * SpatialGraphConv.forward through A1 = conv_a[k](x), A2 = conv_b[k](x), softmax(A1^T A2 / (ic T)), torch_src/models/mmargcn/agcn.py:104-106).

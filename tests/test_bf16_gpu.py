@@ -282,3 +282,18 @@ def test_spatial_tile_kernels_with_one_bf16_part(V, T, cin, cout, B):
     dx2 = gpu(base)
     part_g2 = ops.spatial_bwd_tile(gpu(dy), gpu(x), gpu(a), w3t, dx2, accumulate=True)
     assert torch.equal(dx, dx2) and torch.equal(part_g, part_g2)
+
+
+@pytest.mark.parametrize("V,T,cin,ic,B", [(25, 13, 64, 16, 2), (25, 7, 256, 64, 2), (18, 10, 128, 32, 2)])
+def test_embedding_forward_tile_form_bf16(V, T, cin, ic, B):
+    """fgcn_emb_fwd_tile with ONE bf16 part (FGCN_MATH_BF16; agcn.py:104-106 under the mixed-precision step): x and the weights rounded to
+    bfloat16 once, the embedding tile rounded once more for the gram; float32 accumulation."""
+    from fusion_gcn_amd import ops
+    assert ops.emb_fwd_tile_available(V, ic, cin)
+    x, w, bias = rnd(B, T, V, cin, seed=360), rnd(cin, 6 * ic, seed=361, scale=cin ** -0.5), rnd(6 * ic, seed=362)
+    want = bf(x) @ bf(w) + bias
+    e6 = bf(want).reshape(B, T, V, 3, 2, ic)
+    want_s = torch.einsum("btvke,btwke->bkvw", e6[..., 0, :], e6[..., 1, :])
+    emb, part = ops.emb_fwd_tile(gpu(x), ops.pack_split3(gpu(w.reshape(1, cin, 6 * ic))), gpu(bias), ic=ic)
+    assert rel_l2(emb.cpu().numpy(), want.numpy()) < TOL
+    assert rel_l2(part.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_s.numpy()) < 2e-4

@@ -715,6 +715,60 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert rel_l2(par.cpu().numpy().reshape(3, cout, cin - 3), want_p.numpy()) < RED_TOL
 
 
+@pytest.mark.parametrize("V,T,cin,ic,B", [(25, 13, 64, 16, 2), (25, 7, 256, 64, 2), (27, 9, 64, 32, 1), (18, 10, 128, 32, 2), (16, 8, 128, 64, 1),
+                                          (32, 5, 64, 16, 1), (22, 31, 256, 64, 1), (25, 300, 64, 16, 1), (17, 23, 32, 16, 2), (21, 12, 96, 32, 3)])
+def test_embedding_forward_tile_form(V, T, cin, ic, B):
+    """The forward of the attention embeddings with the affinity gram on chip (fgcn_emb_fwd_tile.hip; reference agcn.py:104-106): emb = x . Wemb
+    + b and the partial grams theta_k^T phi_k against the float64 formulas -- ic = 16 / 32 (all six groups in one workgroup) and 64 (one subset
+    per workgroup), 1 .. 8 chunks of input channels, ragged last frame groups, 4 .. 8 frames per tile, other segmentations (tuning key 22), rows
+    wider than the channels; zero padding of the 32 x 32 partial matrices; bitwise reproducible; agrees with the 1x1 product + joint_gram."""
+    from fusion_gcn_amd import _lib, ops
+    if not ops.emb_fwd_tile_available(V, ic, cin):
+        pytest.skip("the tile form runs in the split-bf16 math modes")
+    x, w, bias = rnd(B, T, V, cin, seed=360), rnd(cin, 6 * ic, seed=361, scale=cin ** -0.5), rnd(6 * ic, seed=362)
+    want = x @ w + bias
+    e6 = want.reshape(B, T, V, 3, 2, ic)
+    want_s = torch.einsum("btvke,btwke->bkvw", e6[..., 0, :], e6[..., 1, :])
+    w3 = ops.pack_split3(to_gpu(w.reshape(1, cin, 6 * ic)))
+    emb, part = ops.emb_fwd_tile(to_gpu(x), w3, to_gpu(bias), ic=ic)
+    assert tuple(emb.shape) == (B, T, V, 6 * ic) and tuple(part.shape[2:]) == (3, 32, 32)
+    assert rel_l2(emb.cpu().numpy(), want.numpy()) < FWD_TOL
+    got_s = part.double().sum(1)[:, :, :V, :V].cpu()
+    assert rel_l2(got_s.numpy(), want_s.numpy()) < RED_TOL
+    if V < 32:
+        assert float(part[:, :, :, V:, :].abs().max()) == 0.0 and float(part[:, :, :, :, V:].abs().max()) == 0.0     # padding stays zero
+    emb2, part2 = ops.emb_fwd_tile(to_gpu(x), w3, to_gpu(bias), ic=ic)
+    assert torch.equal(emb, emb2) and torch.equal(part, part2)
+    lib = _lib.load()
+    segs = {0: part.shape[1]}
+    for target in (1, 100000):                  # one long segment per sample / one frame tile per workgroup
+        try:
+            assert lib.fgcn_set_tuning(22, target) == 0
+            e_t, p_t = ops.emb_fwd_tile(to_gpu(x), w3, to_gpu(bias), ic=ic)
+        finally:
+            assert lib.fgcn_set_tuning(22, 0) == 0
+        segs[target] = p_t.shape[1]
+        assert torch.equal(e_t, emb)
+        assert rel_l2(p_t.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_s.numpy()) < RED_TOL, target
+    assert segs[1] == 1 and segs[100000] == (T + 128 // V - 1) // (128 // V), segs
+    # the unfused pair on the same data
+    emb_old = torch.empty(B, T, V, 6 * ic, device=dev())
+    ops.rows_gemm(to_gpu(x), to_gpu(w.reshape(1, cin, 6 * ic)), emb_old, K=cin, N=6 * ic, bias=to_gpu(bias))
+    part_old = ops.joint_gram(emb_old, emb_old, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(3)])
+    assert rel_l2(emb.cpu().numpy(), emb_old.cpu().numpy()) < FWD_TOL
+    assert rel_l2(part.sum(1).cpu().numpy(), part_old.sum(1).cpu().numpy()) < RED_TOL
+    # ... and through the adjacency softmax
+    adj = to_gpu(rnd(3, V, V, seed=363, scale=0.1))
+    c_new, a_new = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj, B)
+    c_old, a_old = ops.adj_softmax_fwd(part_old, 1.0 / (ic * T), adj, B)
+    assert rel_l2(c_new.cpu().numpy(), c_old.cpu().numpy()) < FWD_TOL and rel_l2(a_new.cpu().numpy(), a_old.cpu().numpy()) < FWD_TOL
+    # rows wider than the channels that take part
+    wide = torch.zeros(B, T, V, cin + 8, device=dev())
+    wide[..., :cin] = to_gpu(x)
+    e_w, p_w = ops.emb_fwd_tile(wide, w3, to_gpu(bias), ic=ic, cin=cin)
+    assert torch.equal(e_w, emb) and torch.equal(p_w, part)
+
+
 def emb_backward_reference(emb, ds, x, w, ic):
     """float64 backward of the attention embeddings (agcn.py:104-106): -> demb, demb . W, demb^T . x, column sums of demb."""
     B, T, V, _ = emb.shape

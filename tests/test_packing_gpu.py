@@ -77,6 +77,8 @@ def _long_way(P, cfg, mode):
         R["d_t_b3"] = ops.pack_split3(R["d_t"])
     if mode in ops.SPLIT_MODES and cx % 64 == 0:   # the embedding backward in tile form (fgcn_emb_dx_tile)
         R["emb_t_b3"] = ops.pack_split3(R["emb_t"])
+    if mode in ops.SPLIT_MODES and cx % 32 == 0:   # the embedding forward with the gram on chip (fgcn_emb_fwd_tile)
+        R["emb_b3"] = ops.pack_split3(R["emb"])
     return R
 
 

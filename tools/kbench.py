@@ -232,6 +232,30 @@ def bench_spatial_bwd(B, reps):
                4.0 * rows * (9 * cin + cout))
 
 
+def bench_emb_fwd(B, reps):
+    """Forward of the attention embeddings: the tile kernel (gram on chip) vs the 1x1 product + joint_gram, at the headline model's
+    (T, cin, ic) of blocks l1-l3, l4, l5-l6, l7, l8-l9."""
+    for T, cin, ic in ((300, 64, 16), (300, 64, 32), (150, 128, 32), (150, 128, 64), (75, 256, 64)):
+        ce = 6 * ic
+        x, bias = rnd(B, T, V, cin), rnd(ce)
+        wt = rnd(1, cin, ce) * cin ** -0.5
+        rows = B * T * V
+        fl = rows * (2.0 * cin * ce + 2.0 * V * 3 * ic)
+        tag = f"T{T} cin {cin} ic {ic}"
+        if ops.emb_fwd_tile_available(V, ic, cin):
+            w3 = ops.pack_split3(wt)
+            ms = timeit(lambda: ops.emb_fwd_tile(x, w3, bias, ic=ic), reps)
+            report(f"emb_fwd_tile             {tag}", ms, fl, 4.0 * rows * (cin + ce))
+        emb = torch.empty(B, T, V, ce, device=DEV)
+        if ops.pw_gemm_available() and cin >= 128:
+            w3 = ops.pack_split3(wt)
+            ms1 = timeit(lambda: ops.pw_gemm(x, w3, emb, bias=bias), reps)
+        else:
+            ms1 = timeit(lambda: ops.rows_gemm(x, wt, emb, K=cin, N=ce, bias=bias), reps)
+        ms2 = timeit(lambda: ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(3)]), reps)
+        report(f"  1x1 product {ms1:.3f} + joint_gram {ms2:.3f}  {tag}", ms1 + ms2, fl, 4.0 * rows * (cin + 2 * ce))
+
+
 def bench_emb_bwd(B, reps):
     """Backward of the attention embeddings: the two tile kernels (demb on chip) vs joint_mix_vec(demb) + the 1x1 data gradient + the 1x1
     weight gradient, at the headline model's (T, cin, ic) of blocks l1-l3, l4, l5-l6, l7, l8-l9."""
@@ -329,7 +353,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=128)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,emb_bwd,joint,elem")
+    ap.add_argument("--only", default="gemm,pw,tconv,wgrad,spatial,spatial_wgrad,spatial_bwd,emb_fwd,emb_bwd,joint,elem")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs, e.g. 5=1,4=1")
     ap.add_argument("--math", default="f32", choices=("f32", "bf16", "bf16x3", "f16x2"), help="fgcn_set_math_mode")
     args = ap.parse_args()
@@ -340,7 +364,7 @@ def main():
         print(f"-- tuning {k} = {v}")
     ops.set_math_mode(args.math)
     print(f"-- math mode {args.math}")
-    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, spatial_bwd=bench_spatial_bwd, emb_bwd=bench_emb_bwd, joint=bench_joint, elem=bench_elem)
+    fns = dict(gemm=bench_gemm, pw=bench_pw, tconv=bench_tconv, wgrad=bench_wgrad, spatial=bench_spatial, spatial_wgrad=bench_spatial_wgrad, spatial_bwd=bench_spatial_bwd, emb_fwd=bench_emb_fwd, emb_bwd=bench_emb_bwd, joint=bench_joint, elem=bench_elem)
     for k in args.only.split(","):
         fns[k](args.b, args.reps)
 
