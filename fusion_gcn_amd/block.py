@@ -287,7 +287,10 @@ EMB_TILE = os.environ.get("FGCN_EMB_TILE", "1") != "0"
 # the forward of the attention embeddings with the affinity gram on chip (fgcn_emb_fwd_tile.hip: emb = x . Wemb + b written once, theta_k^T phi_k
 # formed from the tile while it is in LDS -- replaces the 1x1 product + joint_gram and the gram's read of emb).  FGCN_EMB_FWD_TILE=0: that pair.
 EMB_FWD_TILE = os.environ.get("FGCN_EMB_FWD_TILE", "1") != "0"
-EMB_FWD_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_FWD_TILE_MAX_CIN", "4096"))
+# ... up to this many input channels: same-call A/B of the replayed step, 40 timed steps (profiles/r05_ab_emb_fwd_tile.txt): off 54.98 / 54.93 ms, up
+# to 64 channels 54.81 / 54.72, up to 128: 54.73 / 54.87, every block 54.83 / 54.86; 8 clips 9.08 / 9.06 / 9.03 / 9.03.  At 64-channel groups (the
+# 256-output blocks) three workgroups per row range each stage the x tile: 0.46-0.59 ms against 0.33-0.44 for the unfused pair.
+EMB_FWD_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_FWD_TILE_MAX_CIN", "128"))
 # ... up to this many input channels.  Same-call A/B of the replayed 64-clip step (profiles/r05_ab_emb_tile.txt): every block 53.79 / 53.90 ms,
 # up to 128 channels 53.63 / 53.56, up to 64 channels 53.79 / 53.75, none (FGCN_EMB_TILE=0) 54.09 / 54.22 -- at 256 channels (l8, l9) both
 # kernels are bound by the matrix pipe (47 GFLOP each at 110-125 TFLOP/s of mixing-padded work) and the unfused chain's plain GEMMs win.

@@ -40,15 +40,18 @@ struct EmbFwP {
 constexpr unsigned EF_OOB = 0x80000000u;
 constexpr int EF_XS = 64;               // bytes per row and part of the x image (32 channels x bf16), 32-byte blocks XOR-swizzled by row bit 2
 constexpr int EF_XPLANE = 128 * EF_XS;
-// gram image of one subset: [part][128 rows][2 ic channels x bf16 + 16 pad bytes]
-constexpr int ef_gs(int ic) { return 4 * ic + 16; }
+// gram image of one pass: [part][128 rows][(W theta + W phi channels) x bf16 + 16 pad bytes], W = min(ic, 32) -- one 32-channel slice of a
+// subset's theta | phi at a time, so that the 64-channel groups of the 256-output blocks keep two workgroups per CU (all 128 channels at
+// once: 104 KB, one workgroup of four waves per CU, 0.83 against 0.46 ms for the unfused pair)
+constexpr int ef_gw(int ic) { return ic < 32 ? ic : 32; }
+constexpr int ef_gs(int ic) { return 4 * ef_gw(ic) + 16; }
 template <int NP> constexpr int ef_lds(int ic) { return std::max(NP * EF_XPLANE, NP * 128 * ef_gs(ic)); }
 
 // MU: 16-channel units per wave (CW = 32 MU channels per workgroup); IC: channels per group (16, 32, 64); NSUB: subsets of the workgroup
 // (3 when it holds all 6 ic channels, 1 when it holds th_k | ph_k of one subset)
 template <int NP, int MU, int IC, int NSUB>
-__global__ __launch_bounds__(256, IC == 64 ? 1 : 2) void emb_fwd_tile_kernel(EmbFwP p) {
-    constexpr int CW = 32 * MU, NR = 4, GS = ef_gs(IC), GPLANE = 128 * GS, KS = IC >= 32 ? IC / 32 : 1;
+__global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
+    constexpr int CW = 32 * MU, NR = 4, GW = ef_gw(IC), GS = ef_gs(IC), GPLANE = 128 * GS, KS = IC >= 32 ? IC / 32 : 1;
     static_assert(CW == (NSUB == 3 ? 6 * IC : 2 * IC), "workgroup channels");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) unsigned char ef_lds_raw[];
@@ -168,37 +171,38 @@ __global__ __launch_bounds__(256, IC == 64 ? 1 : 2) void emb_fwd_tile_kernel(Emb
                 const unsigned off = R < nrows ? ((m0 + (unsigned)R) * (unsigned)p.ld_e + (unsigned)(ch0 + 16 * mu + 4 * g4)) * 4u : EF_OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[mu][nt]), re, off, 0, 0);
             }
-        // ---- the gram of every subset from the tile -----------------------------------------------------------------------------------
+        // ---- the gram of every subset from the tile: per pass one GW-channel slice of theta_k | phi_k goes into the image -------------------
 #pragma unroll
         for (int ks = 0; ks < NSUB; ++ks) {
-            __syncthreads();                                         // the previous image's reads are done
 #pragma unroll
-            for (int mu = 0; mu < MU; ++mu) {
-                const int cw = wc * 16 * MU + 16 * mu;               // unit's first channel inside the workgroup
-                const int grp = cw / IC;                             // (compile-time per mu for a given wc: wave-uniform)
-                if ((NSUB == 3 ? (grp >> 1) : 0) != ks) continue;
-                const int cg = cw - (NSUB == 3 ? 2 * ks * IC : 0);   // channel inside the subset's th | ph image
+            for (int s = 0; s < KS; ++s) {
+                __syncthreads();                                     // the previous image's reads are done
 #pragma unroll
-                for (int nt = 0; nt < NR; ++nt) {
-                    const int R = wr * 64 + 16 * nt + l15;
-                    u32x2 parts[NP];
-                    splitn_x4<NP>(acc[mu][nt], parts);
-                    unsigned char* dst = Xh + R * GS + (cg + 4 * g4) * 2;
+                for (int mu = 0; mu < MU; ++mu) {
+                    const int cw = wc * 16 * MU + 16 * mu;           // unit's first channel inside the workgroup
+                    const int grp = cw / IC, sub = NSUB == 3 ? (grp >> 1) : 0, side = grp & 1;   // (wave-uniform)
+                    const int cg = cw - grp * IC;                    // channel inside its group
+                    if (sub != ks || cg / GW != s) continue;
+                    const int ci = side * GW + (cg - s * GW);        // channel inside the pass's theta | phi image
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * GPLANE) = parts[pl];
+                    for (int nt = 0; nt < NR; ++nt) {
+                        const int R = wr * 64 + 16 * nt + l15;
+                        u32x2 parts[NP];
+                        splitn_x4<NP>(acc[mu][nt], parts);
+                        unsigned char* dst = Xh + R * GS + (ci + 4 * g4) * 2;
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * GPLANE) = parts[pl];
+                    }
                 }
-            }
-            __syncthreads();
-            for (int f = 0; f < nf; ++f) {
-                const bool a_ok = 16 * vt + l15 < V && (IC >= 32 || g4 < 2), b_ok = 16 * wt + l15 < V && (IC >= 32 || g4 < 2);
-                const int ra = a_ok ? f * V + 16 * vt + l15 : 0, rbw = b_ok ? f * V + 16 * wt + l15 : 0;   // (absent joints / channels: row 0, then zeroed)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
+                __syncthreads();
+                for (int f = 0; f < nf; ++f) {
+                    const bool a_ok = 16 * vt + l15 < V && (IC >= 32 || g4 < 2), b_ok = 16 * wt + l15 < V && (IC >= 32 || g4 < 2);
+                    const int ra = a_ok ? f * V + 16 * vt + l15 : 0, rbw = b_ok ? f * V + 16 * wt + l15 : 0;   // (absent joints / channels: row 0, then zeroed)
                     u32x4v af[NP], bf[NP];
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) {
-                        const u32x4v a = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + ra * GS + (32 * s + 8 * g4) * 2);
-                        const u32x4v b = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + rbw * GS + (IC + 32 * s + 8 * g4) * 2);
+                        const u32x4v a = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + ra * GS + (8 * g4) * 2);
+                        const u32x4v b = *reinterpret_cast<const u32x4v*>(Xh + pl * GPLANE + rbw * GS + (GW + 8 * g4) * 2);
                         af[pl] = a_ok ? a : u32x4v{0u, 0u, 0u, 0u};
                         bf[pl] = b_ok ? b : u32x4v{0u, 0u, 0u, 0u};
                     }
@@ -230,8 +234,8 @@ static EfGeom ef_geom(int B, int T, int V, int ic) {
     g.F = 128 / V;
     g.tiles_t = (int)cdiv(T, g.F);
     g.ncol = ic == 64 ? 3 : 1;
-    // resident workgroups: two per CU (one at ic = 64); tuning key 22 overrides the target
-    const int slots = fgcn::tuning(22) > 0 ? fgcn::tuning(22) : (ic == 64 ? 256 : 512);
+    // resident workgroups: two per CU; tuning key 22 overrides the target
+    const int slots = fgcn::tuning(22) > 0 ? fgcn::tuning(22) : 512;
     const int want = std::max(1, slots / (B * g.ncol));              // segments per sample
     g.tps = (int)cdiv(g.tiles_t, std::min(g.tiles_t, want));
     g.nseg = (int)cdiv(g.tiles_t, g.tps);

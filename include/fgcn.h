@@ -82,7 +82,7 @@ fgcn_ctx* fgcn_ctx_get_current(void);
  *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
  *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two)
  *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 2 = 64 x 64 tiles (default: the widest tiles the channels allow)
- *   22 fgcn_emb_fwd_tile: resident workgroups to aim for (0 = 512, 256 at ic = 64; sets the segment count) */
+ *   22 fgcn_emb_fwd_tile: resident workgroups to aim for (0 = 512; sets the segment count) */
 int fgcn_set_tuning(int key, int value);
 int fgcn_get_tuning(int key);
 
@@ -520,7 +520,7 @@ int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
  * (rows / columns >= V are zeros), the input format of fgcn_adj_softmax_fwd (nchunk = segments), which applies the 1 / (ic T) scale.
  * Replaces fgcn_pw_gemm / fgcn_rows_gemm (emb) + fgcn_joint_gram and the gram's read of the 1.5-activation-wide emb.  Sizes: 16 <= V <=
  * FGCN_MAX_V, ic 16 / 32 / 64, Cin a multiple of 32; math modes FGCN_MATH_BF16X3 (either product form: exact three-way bf16 splits) and
- * FGCN_MATH_BF16: fgcn_emb_fwd_tile_available.  Tuning key 22: resident workgroups to aim for (0 = 512, 256 at ic = 64; sets the segment count). */
+ * FGCN_MATH_BF16: fgcn_emb_fwd_tile_available.  Tuning key 22: resident workgroups to aim for (0 = 512; sets the segment count). */
 int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin, int ic,
                       int ld_x, int ld_e, void* stream);
 int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic);
