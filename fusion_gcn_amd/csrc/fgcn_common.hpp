@@ -52,6 +52,30 @@ inline int launch_status(const char* what) {
 
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// Division of a row index by a run-time constant (joints per frame, rows per sample, frames) without the ~25-instruction sequence a
+// 32-bit integer division costs per lane: q = (n * m) >> p with m = ceil(2^p / d), p = 29 + ceil(log2 d) -- exact for every n < 2^29
+// (n * (m d - 2^p) < 2^29 d <= 2^p).  One 32 x 32 -> 64-bit multiply and a 64-bit shift.  The halo conv's index prologue had 32 such
+// divisions per thread and tile: 930 vector instructions in front of a 64-channel tile's 1296 MFMAs.
+struct FastDiv {
+    unsigned m;
+    int p;
+    unsigned d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    FastDiv f;
+    f.p = 29 + L;
+    f.m = (unsigned)(((1ull << f.p) + d - 1) / d);
+    f.d = d;
+    return f;
+}
+#ifdef FGCN_NO_FASTDIV   // (A/B builds, tools/build_probe.py: the plain integer division)
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) { return n / f.d; }
+#else
+__device__ __forceinline__ unsigned fastdiv(unsigned n, FastDiv f) { return (unsigned)(((unsigned long long)n * f.m) >> f.p); }
+#endif
+
 // Kernel-variant selectors (fgcn_set_tuning): defaults are the measured-best variants; tests and tools/kbench.py
 // flip them to compare.  key 0: row-GEMM tile for <= 64 output channels, key 1: for wider outputs (see fgcn_gemm.hip);
 // key 4: halo conv register budget (0: 3

@@ -34,6 +34,7 @@ struct HaloP {
     unsigned w_plane_bytes;             // FGCN_MATH_BF16X3: bytes of one part (high / middle / low) of the split weights
     int tiles_m, tiles_n, per_xcd;   // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
     int Tv, V, K, N, ld_in, ld_out;
+    FastDiv dV, dTvV, dTv;              // row index / V, / (Tv V), frame index / Tv without integer divisions (rows < 2^29)
     int T_in_full, in_s, in_o, Th_in;   // input frame of virtual frame th: th*in_s + in_o (valid while th < Th_in)
     int T_out_full, out_s, out_o, Th_out;  // output frame of virtual frame th: th*out_s + out_o (th < Th_out)
     int taps, tb, tc;                   // d_j = j*tb + tc
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         bm = vid / p.tiles_n;
         bn = vid - bm * p.tiles_n;
     }
-    const long long m0 = (long long)bm * BMR;
+    const int m0 = bm * BMR;                         // (32-bit row math: the launcher bounds the rows of the split kernels by 2^29)
+    const int Mv = (int)p.Mv;
     constexpr int BN = (4 / WR) * NT * 32;
     const int n0 = bn * BN;
     const int V = p.V, TvV = p.Tv * p.V;
@@ -402,9 +404,10 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     int th_lane[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-        const long long mrow = m0 + wr * (16 * MTW) + mt * 16 + l15;
-        row_ok[mt] = mrow < p.Mv;
-        th_lane[mt] = row_ok[mt] ? (int)(((unsigned)mrow / (unsigned)V) % (unsigned)p.Tv) : 0;
+        const int mrow = m0 + wr * (16 * MTW) + mt * 16 + l15;
+        row_ok[mt] = mrow < Mv;
+        const unsigned fr_all = fastdiv(row_ok[mt] ? (unsigned)mrow : 0u, p.dV);     // frame index over all samples
+        th_lane[mt] = (int)(fr_all - fastdiv(fr_all, p.dTv) * (unsigned)p.Tv);
     }
 
     unsigned src_off[NST];
@@ -413,16 +416,16 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     for (int i = 0; i < NST; ++i) {
         src_off[i] = OOB;
         const int r = tid / TPR + RPP * i;
-        const long long hv = m0 + (long long)p.dmin * V + r;
-        if (i < nstage && hv >= 0 && hv < p.Mv) {
+        const int hv = m0 + p.dmin * V + r;
+        if (i < nstage && hv >= 0 && hv < Mv) {
             const unsigned hu = (unsigned)hv;
-            const int n = (int)(hu / (unsigned)TvV);
+            const int n = (int)fastdiv(hu, p.dTvV);
             const int rem = (int)(hu - (unsigned)n * (unsigned)TvV);
-            const int th = (int)((unsigned)rem / (unsigned)V);
+            const int th = (int)fastdiv((unsigned)rem, p.dV);
             const int v = rem - th * V;
             const int fr = th * p.in_s + p.in_o;
             if (th < p.Th_in && fr < p.T_in_full)
-                src_off[i] = (unsigned)(((((long long)n * p.T_in_full + fr) * V + v) * p.ld_in) * 4) + k4b;
+                src_off[i] = (unsigned)(((n * p.T_in_full + fr) * V + v) * p.ld_in) * 4u + k4b;      // (the launcher bounds the tensors by 2 GiB)
         }
     }
 
@@ -664,13 +667,13 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
-            bool ok = m < p.Mv;
+            const int m = m0 + wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
+            bool ok = m < Mv;
             unsigned orow = (unsigned)(ok ? m : 0);
             if (!plain_out) {                              // wave-uniform
-                const int n = (int)(orow / (unsigned)TvV);
+                const int n = (int)fastdiv(orow, p.dTvV);
                 const int rem = (int)(orow - (unsigned)n * (unsigned)TvV);
-                const int th = (int)((unsigned)rem / (unsigned)V);
+                const int th = (int)fastdiv((unsigned)rem, p.dV);
                 const int v = rem - th * V;
                 ok = ok && th < p.Th_out;
                 orow = (unsigned)((n * p.T_out_full + th * p.out_s + p.out_o) * V + v);
@@ -832,6 +835,8 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     p.Tv = Th > Th_in ? Th : Th_in;
     p.Mv = (long long)B * p.Tv * V;
     p.V = V; p.K = K; p.N = N; p.ld_in = ld_in; p.ld_out = ld_out;
+    p.dV = make_fastdiv((unsigned)V); p.dTvV = make_fastdiv((unsigned)(p.Tv * V)); p.dTv = make_fastdiv((unsigned)p.Tv);
+    FGCN_REQUIRE(mm == FGCN_MATH_F32 || p.Mv < (1ll << 29), FGCN_E_BADARG, "tconv_halo: too many rows for the split kernels' index arithmetic (< 2^29)");
     p.T_in_full = T_in_full; p.in_s = in_s; p.in_o = in_o; p.Th_in = Th_in;
     p.T_out_full = T_out_full; p.out_s = out_s; p.out_o = out_o; p.Th_out = Th;
     p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
