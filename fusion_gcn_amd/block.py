@@ -443,9 +443,16 @@ def _bn_vec(part, count, P, bufs, name, train):
     return ops.bn_eval_coeffs(g, b, rm, rv)
 
 
+# The model's last block with the global average pooling behind it (agcn.py:196-197): its epilogue pass sums the output per clip instead
+# of writing it (ops.bn_act_pool; the backward gates on the sign image alone) -- one activation write and one read less per step.
+# FGCN_POOL_EPILOGUE=0: bn_act + group_mean (A/B control).
+POOL_EPILOGUE = os.environ.get("FGCN_POOL_EPILOGUE", "1") != "0"
+
+
 def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
-                  cfg: BlockConfig, train: bool):
-    """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict)."""
+                  cfg: BlockConfig, train: bool, pool_groups: int = 0):
+    """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict).  ``pool_groups`` > 0 (the model's last block): O is
+    not formed, the first result is its mean over the rows of every group of B / pool_groups consecutive samples, (pool_groups, cout)."""
     B, T, V, cx = x.shape
     cout, ic, s = cfg.cout, cfg.ic, cfg.stride
     assert cx == cfg.cx, (cx, cfg.cx)
@@ -514,17 +521,25 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
                         fuse_in=(vec_y, x, g, g_sign) if fuse_g else None, amax_out=amax[1:2] if S["g_amax"] else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
+    epilogue = (lambda a, va, b, vb: ops.bn_act_pool(a, va, b, vb, pool_groups)) if pool_groups else \
+               (lambda a, va, b, vb: ops.bn_act(a, va, b, vb, relu=True, sign_mask=True))
     if cfg.residual == "none":
-        o, o_sign = ops.bn_act(u, vec_u, None, None, relu=True, sign_mask=True)
+        o, o_sign = epilogue(u, vec_u, None, None)
     elif cfg.residual == "identity":
-        o, o_sign = ops.bn_act(u, vec_u, x, None, relu=True, sign_mask=True)
+        o, o_sign = epilogue(u, vec_u, x, None)
     else:
         r = new(B, Tp, V, cout)
         part = ops.rows_gemm(x, W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
         vec_r = _bn_vec(part, B * Tp * V, P, bufs, "residual.bn", train)
-        o, o_sign = ops.bn_act(u, vec_u, r, vec_r, relu=True, sign_mask=True)
-    S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=o, o_sign=o_sign)
+        o, o_sign = epilogue(u, vec_u, r, vec_r)
+    S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=None if pool_groups else o, o_sign=o_sign)
     return o, S
+
+
+def pool_epilogue_ok(cfg: BlockConfig, B: int, T: int, V: int, groups: int) -> bool:
+    """the last block's epilogue can carry the pooling: equal groups of whole samples, a sign image exists (element count and cout in 8s)"""
+    Tp = (T - 1) // cfg.stride + 1
+    return POOL_EPILOGUE and groups > 0 and B % groups == 0 and cfg.cout % 8 == 0 and (B * Tp * V * cfg.cout) % 8 == 0
 
 
 # ---- backward --------------------------------------------------------------------------------------------------------
@@ -777,7 +792,10 @@ class STBlockFunction(torch.autograd.Function):
                 holder: Optional[dict], *params):
         names = param_names(cfg)
         P = dict(zip(names, params))
-        o, S = block_forward(x, P, bufs, W, cfg, train)
+        pool_groups = holder.get("pool_groups", 0) if holder is not None else 0
+        o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups)
+        B, T, V, _ = x.shape
+        ctx.pool = (pool_groups, (B, (T - 1) // cfg.stride + 1, V, cfg.cout)) if pool_groups else None
         # the block's input and output go through save_for_backward (an output kept on ctx would be a reference cycle
         # o -> grad_fn -> ctx -> o that only the garbage collector frees); the other activations are private to the block
         # (the backward gates on the one-bit sign image of o, so o itself is only kept when that image does not exist;
@@ -800,6 +818,10 @@ class STBlockFunction(torch.autograd.Function):
         P = dict(zip(ctx.names, params))
         S = dict(ctx.S, x=x, o=o)
         ctx.S = None
+        if ctx.pool is not None:            # d_o of the pooled output: every row of a group receives the group's gradient / rows
+            groups, shape = ctx.pool
+            rows = shape[0] * shape[1] * shape[2] // groups
+            d_o = (d_o / rows).unsqueeze(1).expand(groups, rows, shape[3]).contiguous().view(shape)
         dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0])
         del S
         grads = []

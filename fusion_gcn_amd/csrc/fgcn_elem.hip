@@ -237,6 +237,68 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
     }
 }
 
+// ---- the last block's epilogue with the global average pooling behind it ---------------------------------------------------
+// out = relu(BN(a) + r) of the LAST block is read once, by the pooling in front of the classifier (agcn.py:196-197): here the pass
+// that would write it sums it per (group, channel) instead and writes only the sign image the backward's ReLU gate reads -- one
+// activation write and one activation read less per step.  grid = (splits, groups, channel windows of 4 blockDim.x), block =
+// (C/4 up to 64, ny): thread (x, y) owns channels 4x .. 4x+3 and rows y, y + ny, ... of its split; fixed-order sums.
+template <int RES>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* a, const float* va, const float* b, const float* vb,
+                                                         unsigned char* mask, float* partial, int grp_rows, int per, int C) {
+    extern __shared__ float red[];                       // [ny][Cw]
+    const int Cw = blockDim.x * 4, c = blockIdx.z * Cw + threadIdx.x * 4;
+    const bool cok = c < C;                              // (C % 8 == 0: a quad -- and its lane pair -- is all-in or all-out)
+    const int g = blockIdx.y, r0 = blockIdx.x * per, r1 = min(r0 + per, grp_rows);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, sc_b = sc, sh_b = sc, sum = sc;
+    if (cok) {
+        sc = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
+        sh = *reinterpret_cast<const f32x4*>(va + 3 * C + c);
+        if (RES == 2) {
+            sc_b = *reinterpret_cast<const f32x4*>(vb + 2 * C + c);
+            sh_b = *reinterpret_cast<const f32x4*>(vb + 3 * C + c);
+        }
+    }
+    auto one = [&](f32x4 x, f32x4 r, long long o) {
+        f32x4 y = x * sc + sh;
+        if (RES == 1) y += r;
+        else if (RES == 2) y += r * sc_b + sh_b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        sum += y;
+        const int nib = (y[0] > 0.f ? 1 : 0) | (y[1] > 0.f ? 2 : 0) | (y[2] > 0.f ? 4 : 0) | (y[3] > 0.f ? 8 : 0);
+        const int other = __shfl_xor(nib, 1);
+        if (!(threadIdx.x & 1)) mask[o >> 3] = (unsigned char)(nib | (other << 4));
+    };
+    if (cok) {                                           // (uniform per lane pair)
+        const long long base = (long long)g * grp_rows;
+        int r = r0 + threadIdx.y;
+        const int ny = blockDim.y;
+        for (; r + 3 * ny < r1; r += 4 * ny) {           // four rows (eight 16-byte loads) in flight
+            f32x4 x[4], q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (base + r + u * ny) * C + c;
+                x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + o));
+                q[u] = RES != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(x[u], q[u], (base + r + u * ny) * C + c);
+        }
+        for (; r < r1; r += ny) {
+            const long long o = (base + r) * C + c;
+            one(*reinterpret_cast<const f32x4*>(a + o), RES != 0 ? *reinterpret_cast<const f32x4*>(b + o) : f32x4{0.f, 0.f, 0.f, 0.f}, o);
+        }
+    }
+    *reinterpret_cast<f32x4*>(red + threadIdx.y * Cw + threadIdx.x * 4) = sum;
+    __syncthreads();
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < Cw; i += blockDim.x * blockDim.y) {
+        float s = 0.f;
+        for (int y = 0; y < (int)blockDim.y; ++y) s += red[y * Cw + i];
+        if (blockIdx.z * Cw + i < C) partial[((long long)g * gridDim.x + blockIdx.x) * C + blockIdx.z * Cw + i] = s;
+    }
+}
+
 // ---- column sums ------------------------------------------------------------------------------------------------
 __global__ void col_sum_kernel(const float* x, float* partials, long long rows, long long rows_per_tile, int C, int ld) {
     extern __shared__ float red[];  // [ny][C4*4]
@@ -586,6 +648,36 @@ extern "C" int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const 
                                      void* stream) {
     return bn_act_bwd_apply_impl(dout, out, sign_mask, a, vec_a, b, vec_b, sums, da, db, rows, C, res_mode, relu, train, db_accumulate, C,
                                  stream);
+}
+
+// fgcn_bn_act followed by fgcn_group_mean without the tensor between them (the last block of the model): see bn_act_pool_kernel
+extern "C" int fgcn_bn_act_pool_splits(int groups, int grp_rows) {
+    int splits = 1;
+    while (splits < 64 && (long long)groups * splits < 1024 && grp_rows / (splits * 2) >= 32) splits *= 2;
+    return splits;
+}
+
+extern "C" int fgcn_bn_act_pool(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned char* sign_mask,
+                                float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, void* stream) {
+    FGCN_REQUIRE(a && vec_a && sign_mask && partial && pooled, FGCN_E_BADARG, "bn_act_pool: null pointer");
+    FGCN_REQUIRE(groups > 0 && groups <= 65535 && grp_rows > 0 && C > 0 && C % 8 == 0, FGCN_E_BADARG,
+                 "bn_act_pool: groups=%d grp_rows=%d C=%d (C must be a multiple of 8)", groups, grp_rows, C);
+    if (int e = check_elem("bn_act_pool", (long long)groups * grp_rows, C, res_mode, b, vec_b)) return e;
+    FGCN_REQUIRE(aligned16(a) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN, "bn_act_pool: 16-byte alignment");
+    const int splits = fgcn_bn_act_pool_splits(groups, grp_rows);
+    const int per = (int)cdiv(grp_rows, splits);
+    int cx = C / 4;
+    if (cx > 64) cx = 64;
+    const int ny = 256 / cx > 16 ? 16 : 256 / cx;
+    const dim3 grid((unsigned)splits, (unsigned)groups, (unsigned)cdiv(C, cx * 4)), blk((unsigned)cx, (unsigned)ny);
+    const size_t lds = (size_t)ny * cx * 4 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (res_mode == 0) hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
+    else if (res_mode == 1) hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
+    else hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
+    hipLaunchKernelGGL(group_mean_finish_kernel, dim3((unsigned)cdiv((long long)groups * C, 256)), dim3(256), 0, s, partial, pooled, groups,
+                       C, splits, 1.f / (float)grp_rows);
+    return launch_status("bn_act_pool");
 }
 
 // The same three passes for a plain BatchNorm (no residual, no activation) whose RESULT is a channel window of a wider tensor -- one

@@ -33,6 +33,7 @@ struct RowsGemmP {
     int tiles_m, tiles_n, per_xcd;  // per_xcd > 0: 1-D grid in XCD-aware order (column tiles of a row tile share an L2)
     long long in_bs, out_bs, w_bs;  // fgcn_rows_gemm_batched: element strides of blockIdx.z's problem (0 otherwise)
     int stream;                     // non-temporal output stores (fgcn_common.hpp, stream_out)
+    FastDiv dTV, dV;                // row -> (sample, frame, joint) by multiply-shift (rows < 2^29: the launcher checks)
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     // every store of the epilogue: 64 serialised store round trips per tile).
     constexpr unsigned OOB = 0x80000000u;
     const int TV = p.T_out * p.V;
-    const int n_first = (int)((unsigned)m0 / (unsigned)TV);   // 32-bit decode: host guarantees M < 2^31
+    const int n_first = (int)fastdiv((unsigned)m0, p.dTV);    // 32-bit decode: host guarantees M < 2^29
     const long long in_base = (long long)n_first * p.T_in * p.V * p.ld_in;
     const long long in_left = (p.in_elems - in_base) * 4;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     for (int i = 0; i < AR; ++i) {
         const long long m = m0 + (tid >> 3) + 32 * i;
         const unsigned mu = (unsigned)(m < p.M ? m : m0);
-        const int n = (int)(mu / (unsigned)TV);
+        const int n = (int)fastdiv(mu, p.dTV);
         const int rem = (int)(mu - (unsigned)n * (unsigned)TV);
-        const int to = (int)((unsigned)rem / (unsigned)p.V);
+        const int to = (int)fastdiv((unsigned)rem, p.dV);
         const int v = rem - to * p.V;
         roff[i] = (unsigned)(((n - n_first) * p.T_in * p.V + v) * p.ld_in) * 4u;
         rto[i] = m < p.M ? to : -1;
@@ -659,7 +660,9 @@ static int rows_gemm_launch(const float* in, float* out, const float* w, const f
     const int mt = (nt <= 2 && tune_small != 0) ? 2 : 1;
     const bool db = nt <= 2 ? tune_small == 2 : tune_wide == 1;
     const long long tiles_m = cdiv(p.M, 128 * mt);
-    FGCN_REQUIRE(p.M < (1ll << 31) - 4096, FGCN_E_BADARG, "rows_gemm: too many rows (32-bit row indices)");
+    FGCN_REQUIRE(p.M < (1ll << 29) - 4096, FGCN_E_BADARG, "rows_gemm: too many rows (2^29: multiply-shift row decode)");
+    p.dTV = make_fastdiv((unsigned)(T_out * V));
+    p.dV = make_fastdiv((unsigned)V);
     p.tiles_m = (int)tiles_m;
     p.tiles_n = (int)cdiv(N, 32 * nt);
     const long long total = tiles_m * p.tiles_n;

@@ -21,7 +21,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...block import BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, data_bn, pack_weights, param_names
+from ...block import (BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, data_bn, pack_weights, param_names,
+                      pool_epilogue_ok)
 from ...util.partition_strategy import GraphPartitionStrategy
 
 
@@ -210,11 +211,13 @@ class SpatialTemporalConv(nn.Module):
         """GraphStep hook: the packed set a recording made now reads (kept alive by the recording)."""
         return [] if self._wcache is None else [self._wcache[1]]
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pool_groups: int = 0) -> torch.Tensor:
+        """``pool_groups`` > 0 (the model's last block, block.pool_epilogue_ok): returns the block's output averaged over the rows of
+        every group of consecutive samples, (pool_groups, out_channels), without forming the output."""
         names = param_names(self.cfg)
         params = [self._tensor(n) for n in names]
         W = self._packed(params)
-        holder = {}
+        holder = {"pool_groups": pool_groups} if pool_groups else {}
         out = STBlockFunction.apply(x, self.cfg, self.training, self._block_buffers(), W, holder, *params)
         if self.training and not self._defer_nbt:
             torch._foreach_add_(self.nbt_buffers(), 1)
@@ -335,11 +338,15 @@ class Model(nn.Module):
         h = self._blocks_input(x)
         self._bump_batch_counters()
         refresh_packed_weights(self)
-        for layer in self.layers:
+        for layer in self.layers[:-1]:
             h = layer(h)
-        # (N*M, T', V, C') -> mean over (T', V) then over persons
-        c_new = h.size(-1)
-        h = GroupMeanFunction.apply(h.view(N, -1, c_new))   # mean over persons, frames and joints (equal-sized groups)
+        # (N*M, T', V, C') -> mean over (T', V) then over persons = one mean over persons, frames and joints (equal-sized groups)
+        last = self.layers[-1]
+        if isinstance(last, SpatialTemporalConv) and pool_epilogue_ok(last.cfg, h.shape[0], h.shape[1], h.shape[2], N):
+            h = last(h, pool_groups=N)                       # the block's epilogue pass sums per clip instead of writing its output
+        else:
+            h = last(h)
+            h = GroupMeanFunction.apply(h.view(N, -1, h.size(-1)))
         if self.fc is not None:    # nn.Linear is the parameter container; the arithmetic is the row GEMM
             h = LinearFunction.apply(h.contiguous(), self.fc.weight, self.fc.bias)
         return h

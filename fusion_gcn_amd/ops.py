@@ -854,6 +854,29 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
     return (out, mask) if sign_mask else out
 
 
+def bn_act_pool(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], groups: int):
+    """mean over every group's rows of relu(a*scale_a + shift_a + [b | b*scale_b + shift_b]) -> (pooled (groups, C), sign mask):
+    ``bn_act`` + ``group_mean`` of the last block without the activation between them (fgcn_bn_act_pool).  a: (..., C) whose rows
+    form ``groups`` equal consecutive groups; C % 8 == 0."""
+    ensure_device()
+    _chk(a, "bn_act_pool.a")
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if rows % groups or C % 8:
+        raise _lib.FgcnError(f"bn_act_pool: {rows} rows in {groups} groups, C={C} (equal groups, C % 8 == 0)")
+    if b is not None and b.shape != a.shape:
+        raise _lib.FgcnError(f"bn_act_pool: residual shape {tuple(b.shape)} != {tuple(a.shape)}")
+    res_mode = 0 if b is None else (1 if vec_b is None else 2)
+    lib = _lib.load()
+    splits = lib.fgcn_bn_act_pool_splits(groups, rows // groups)
+    partial = torch.empty((groups * splits, C), device=a.device, dtype=torch.float32)
+    pooled = torch.empty((groups, C), device=a.device, dtype=torch.float32)
+    mask = torch.empty(a.numel() // 8, device=a.device, dtype=torch.uint8)
+    check(lib.fgcn_bn_act_pool(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(mask), _p(partial), _p(pooled), groups, rows // groups, C,
+                               res_mode, _stream()), "fgcn_bn_act_pool")
+    return pooled, mask
+
+
 def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor, vec_a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,

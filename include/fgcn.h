@@ -131,7 +131,8 @@ typedef struct {
  *   :77 (down), :125-132 (residual conv) and their autograd backward w.r.t. the input.
  *   w is packed [taps][K][N] (N contiguous, N % 4 == 0).  bias may be NULL.
  *   stat_partials (may be NULL): float[ceil(M/128)][2][N] receives per-row-tile sum and sum of squares of the
- *   values written (the BatchNorm batch statistics of agcn.py:44,78,83 come from these).  accumulate: out += . */
+ *   values written (the BatchNorm batch statistics of agcn.py:44,78,83 come from these).  accumulate: out += .
+ *   At most 2^29 rows (B * T_out * V) per call. */
 int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
                    int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
                    fgcn_tmap map, int accumulate, void* stream);
@@ -423,6 +424,15 @@ int fgcn_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
  *   backward passes can read instead of the whole of `out` (the ReLU gate of the reference's autograd). */
 int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
                 unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream);
+
+/* The last block's epilogue and the pooling behind it in one pass (agcn.py:135-136 then :196-197):
+ *     pooled[g][c] = mean over the grp_rows consecutive rows r of group g of relu( a*scale_a + shift_a + r-term )[(g*grp_rows + r), c]
+ *   -- fgcn_bn_act (relu = 1) followed by fgcn_group_mean, but `out` is never written: only its sign image (sign_mask, rows*C/8 bytes,
+ *   what the backward reads) and the sums.  C % 8 == 0; partial: float[groups * fgcn_bn_act_pool_splits(groups, grp_rows)][C].
+ *   Fixed summation order (another one than fgcn_group_mean's). */
+int fgcn_bn_act_pool_splits(int groups, int grp_rows);
+int fgcn_bn_act_pool(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned char* sign_mask,
+                     float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, void* stream);
 
 /* Backward of the above, pass 1 (reductions): with dP = dout .* [out > 0] (or dout when relu = 0)
  *   partials[tile][0][c] = sum dP, [1] = sum dP * a_hat, [2] = sum dP * b_hat   (a_hat = (a-mean_a)*rstd_a).

@@ -536,6 +536,64 @@ def test_pool_and_classifier_kernels_and_graph_replay():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G,R,C,res_mode", [(8, 3750, 256, 1), (3, 77, 64, 0), (64, 500, 128, 2), (2, 1, 8, 1), (5, 130, 320, 2)])
+def test_last_blocks_epilogue_with_the_pooling_behind_it(G, R, C, res_mode):
+    """fgcn_bn_act_pool = fgcn_bn_act (relu, sign image) + fgcn_group_mean without the activation between them: the pooled means to
+    rounding, the sign image bit for bit, twice the same bits."""
+    from fusion_gcn_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11 + C)
+    a = torch.randn(G * R, C, device=dev)
+    b = torch.randn(G * R, C, device=dev) if res_mode else None
+    mk = lambda: torch.stack([torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev), torch.randn(C, device=dev)])   # noqa: E731
+    va, vb = mk().contiguous(), (mk().contiguous() if res_mode == 2 else None)
+    out, mask = ops.bn_act(a, va, b, vb, relu=True, sign_mask=True)
+    pooled, pmask = ops.bn_act_pool(a, va, b, vb, G)
+    again, amask = ops.bn_act_pool(a, va, b, vb, G)
+    assert torch.equal(mask, pmask) and torch.equal(pooled, again) and torch.equal(pmask, amask)
+    want = out.double().view(G, R, C).mean(1)
+    assert float((pooled.double() - want).norm() / want.norm()) < 3e-6
+    assert float((pooled - ops.group_mean(out.view(G, R, C))).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_model_with_and_without_the_pooling_epilogue(fgcn_math):
+    """The model's last block with the pooling in its epilogue against bn_act + group_mean: logits, loss and every gradient agree to
+    rounding (the pooled sums run in another order); the backward is the same code on the same sign image."""
+    import torch.nn.functional as F
+    from fusion_gcn_amd import block
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    model = Model((2, 40, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev).train()
+    with torch.no_grad():
+        for m in model.modules():                       # (the reference's 1e-6 BatchNorm gain would silence the graph convolutions)
+            if hasattr(m, "gcn1"):
+                m.gcn1.bn.weight.fill_(1.0)
+    x = torch.randn(3, 2, 40, 25, 3, device=dev)
+    y = torch.randint(0, 60, (3,), device=dev)
+
+    def run(flag):
+        old, block.POOL_EPILOGUE = block.POOL_EPILOGUE, flag
+        try:
+            for p in model.parameters():
+                p.grad = None
+            logits = model(x)
+            loss = F.cross_entropy(logits, y)
+            loss.backward()
+            return logits.detach().clone(), float(loss), [p.grad.clone() for p in model.parameters()]
+        finally:
+            block.POOL_EPILOGUE = old
+    lg0, l0, g0 = run(False)
+    lg1, l1, g1 = run(True)
+    assert float((lg1 - lg0).norm() / lg0.norm()) < 2e-6 and abs(l1 - l0) < 1e-5
+    f0, f1 = torch.cat([g.flatten() for g in g0]).double(), torch.cat([g.flatten() for g in g1]).double()
+    assert float((f1 - f0).norm() / f0.norm()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_dropout_between_blocks_and_second_backward():
     """reference Model(dropout > 0) puts an in-place nn.Dropout after every block but the last (agcn.py:166-169): the block's output is
     overwritten in place after the block saved what its backward needs (the one-bit sign image, not the output itself), so a
