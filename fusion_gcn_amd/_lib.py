@@ -84,6 +84,7 @@ SIGNATURES = {
     "fgcn_get_products": (_I, []),
     "fgcn_rows_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _P]),
     "fgcn_rows_gemm_batched": (_I, [_P, _P, _P, _I, _LL, _LL, _LL, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_rows_gemm_batched2": (_I, [_P, _P, _P, _I, _LL, _LL, _LL, _I, _LL, _LL, _LL, _I, _I, _I, _I, _I, _I, _P]),
     "fgcn_rows_gemm_tiles": (_I, [_LL]),
     "fgcn_tconv_halo_tiles": (_I, [_I, _I, _I, _I]),
     "fgcn_tconv_halo": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P, _P, _P] + [_P, _P, _P, _P] + [_P, _P]),

@@ -34,6 +34,8 @@ struct RowsGemmP {
     long long in_bs, out_bs, w_bs;  // fgcn_rows_gemm_batched: element strides of blockIdx.z's problem (0 otherwise)
     int stream;                     // non-temporal output stores (fgcn_common.hpp, stream_out)
     FastDiv dTV, dV;                // row -> (sample, frame, joint) by multiply-shift (rows < 2^29: the launcher checks)
+    int inner;                      // fgcn_rows_gemm_batched2: blockIdx.z = outer * inner + i; problem i of an outer group adds the *_bs2 strides
+    long long in_bs2, out_bs2, w_bs2;
 };
 
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
@@ -42,9 +44,13 @@ struct RowsGemmP {
 template <int MT, int NT, bool DB, bool BF>
 __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kernel(RowsGemmP p) {
     constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
-    p.in += (long long)blockIdx.z * p.in_bs;           // batched form: one independent problem per blockIdx.z
-    p.out += (long long)blockIdx.z * p.out_bs;
-    p.w += (long long)blockIdx.z * p.w_bs;
+    {                                                  // batched forms: one independent problem per blockIdx.z
+        const int zo = p.inner > 1 ? (int)blockIdx.z / p.inner : (int)blockIdx.z;
+        const int zi = (int)blockIdx.z - zo * (p.inner > 1 ? p.inner : 1);
+        p.in += (long long)zo * p.in_bs + (long long)zi * p.in_bs2;
+        p.out += (long long)zo * p.out_bs + (long long)zi * p.out_bs2;
+        p.w += (long long)zo * p.w_bs + (long long)zi * p.w_bs2;
+    }
     constexpr int AR = 4 * MT;                         // A-tile rows staged per thread
     __shared__ __attribute__((aligned(16))) float As[NBUF * BM * AS];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF * BK * BN];
@@ -626,10 +632,11 @@ static int check_tmap(const fgcn_tmap& m) {
 static int rows_gemm_launch(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
                             int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
                             fgcn_tmap map, int accumulate, int batch, long long in_bs, long long out_bs, long long w_bs,
-                            void* stream) {
+                            void* stream, int inner = 1, long long in_bs2 = 0, long long out_bs2 = 0, long long w_bs2 = 0) {
     FGCN_REQUIRE(in && out && w, FGCN_E_BADARG, "rows_gemm: null pointer");
-    FGCN_REQUIRE(batch >= 1 && batch <= 65535 && in_bs % 4 == 0 && out_bs % 4 == 0 && w_bs % 4 == 0, FGCN_E_BADARG,
-                 "rows_gemm: batch=%d / batch strides must be multiples of 4 floats", batch);
+    FGCN_REQUIRE(batch >= 1 && inner >= 1 && (long long)batch * inner <= 65535 && in_bs % 4 == 0 && out_bs % 4 == 0 && w_bs % 4 == 0 &&
+                     in_bs2 % 4 == 0 && out_bs2 % 4 == 0 && w_bs2 % 4 == 0,
+                 FGCN_E_BADARG, "rows_gemm: batch=%d x %d / batch strides must be multiples of 4 floats", batch, inner);
     FGCN_REQUIRE(B > 0 && T_in > 0 && T_out > 0 && V > 0 && K > 0 && N > 0, FGCN_E_BADARG,
                  "rows_gemm: non-positive size B=%d T_in=%d T_out=%d V=%d K=%d N=%d", B, T_in, T_out, V, K, N);
     FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, FGCN_E_ALIGN,
@@ -657,7 +664,18 @@ static int rows_gemm_launch(const float* in, float* out, const float* w, const f
     }
     // narrow outputs (<= 64 channels per tile) take two row tiles per wave so every A/B fragment feeds 2 MFMAs
     const int tune_small = fgcn::tuning(0), tune_wide = fgcn::tuning(1);
-    const int mt = (nt <= 2 && tune_small != 0) ? 2 : 1;
+    int mt = (nt <= 2 && tune_small != 0) ? 2 : 1;
+    // small problems (the per-sample V x V products of the IMU graph convolutions: 8 x 652 rows per launch): 256-row x 64-column tiles
+    // left 24 workgroups for 256 CUs -- the smallest tiles that still pad no extra column, until the grid covers the chip
+    // (tuning key 24 = 1: the large-problem tiles everywhere)
+    batch *= inner;
+    if (fgcn::tuning(24) != 1) {
+        auto wgs = [&](int mt_, int nt_) { return cdiv(p.M, 128 * mt_) * cdiv(N, 32 * nt_) * batch; };
+        if (mt == 2 && wgs(mt, nt) < 256) mt = 1;
+        while (nt % 2 == 0 && wgs(mt, nt) < 256) nt /= 2;       // (32 nt/2 divides 32 nt: never more padded columns)
+        if (nt == 3 && wgs(mt, nt) < 256) nt = 1;
+    }
+    p.inner = inner; p.in_bs2 = in_bs2; p.out_bs2 = out_bs2; p.w_bs2 = w_bs2;
     const bool db = nt <= 2 ? tune_small == 2 : tune_wide == 1;
     const long long tiles_m = cdiv(p.M, 128 * mt);
     FGCN_REQUIRE(p.M < (1ll << 29) - 4096, FGCN_E_BADARG, "rows_gemm: too many rows (2^29: multiply-shift row decode)");
@@ -710,6 +728,16 @@ extern "C" int fgcn_rows_gemm_batched(const float* in, float* out, const float* 
     const fgcn_tmap pointwise{1, 1, 0, 0, 1};
     return rows_gemm_launch(in, out, w, nullptr, nullptr, 1, rows, rows, 1, K, N, ld_in, ld_out, pointwise, accumulate, batch,
                             in_bstride, out_bstride, w_bstride, stream);
+}
+
+extern "C" int fgcn_rows_gemm_batched2(const float* in, float* out, const float* w, int batch, long long in_bstride,
+                                       long long out_bstride, long long w_bstride, int inner, long long in_bstride2,
+                                       long long out_bstride2, long long w_bstride2, int rows, int K, int N, int ld_in, int ld_out,
+                                       int accumulate, void* stream) {
+    FGCN_REQUIRE(rows > 0, FGCN_E_BADARG, "rows_gemm_batched2: rows=%d", rows);
+    const fgcn_tmap pointwise{1, 1, 0, 0, 1};
+    return rows_gemm_launch(in, out, w, nullptr, nullptr, 1, rows, rows, 1, K, N, ld_in, ld_out, pointwise, accumulate, batch,
+                            in_bstride, out_bstride, w_bstride, stream, inner, in_bstride2, out_bstride2, w_bstride2);
 }
 
 extern "C" int fgcn_rows_wgrad(const float* a, const float* g, float* partial,

@@ -256,14 +256,14 @@ class _AgcnConv1dFunction(torch.autograd.Function):
         tp = emb.view(B, V, 6, ic).permute(2, 0, 1, 3).contiguous()                    # (6, B, V, ic): theta_k = tp[2k], phi_k = tp[2k+1]
         th_fm = ops.transpose(tp[0::2].reshape(3 * B, V, ic))                          # (3B, ic, V): theta_k[b]^T as a (K = c, N = v) weight
         st = new(B, 3, V, V)
-        for k in range(3):         # S^T_k[b] = phi_k[b] . theta_k[b]^T: B problems per launch
-            ops.rows_gemm_batched(tp, th_fm, st, batch=B, rows=V, K=ic, N=V, ld_in=ic, ld_out=V, in_bs=V * ic, w_bs=ic * V,
-                                  out_bs=3 * V * V, in_off=(2 * k + 1) * B * V * ic, w_off=k * B * ic * V, out_off=k * V * V)
+        # S^T_k[b] = phi_k[b] . theta_k[b]^T: the 3 B problems (b, k) in one launch
+        ops.rows_gemm_batched(tp, th_fm, st, batch=B, rows=V, K=ic, N=V, ld_in=ic, ld_out=V, in_bs=V * ic, w_bs=ic * V,
+                              out_bs=3 * V * V, in_off=B * V * ic, inner=3, in_bs2=2 * B * V * ic, w_bs2=B * ic * V, out_bs2=V * V)
         c_t, a_t = ops.row_softmax_fwd(st, adj_t, V, 1.0 / ic)
         agg = new(B, V, 3 * Fp)
-        for k in range(3):         # agg_k[b] = A^^T_k[b] . x[b]
-            ops.rows_gemm_batched(a_t, x, agg, batch=B, rows=V, K=V, N=Fp, ld_in=V, ld_out=3 * Fp, in_bs=3 * V * V, w_bs=V * Fp,
-                                  out_bs=V * 3 * Fp, in_off=k * V * V, out_off=k * Fp)
+        # agg_k[b] = A^^T_k[b] . x[b]
+        ops.rows_gemm_batched(a_t, x, agg, batch=B, rows=V, K=V, N=Fp, ld_in=V, ld_out=3 * Fp, in_bs=3 * V * V, w_bs=V * Fp,
+                              out_bs=V * 3 * Fp, inner=3, in_bs2=V * V, w_bs2=0, out_bs2=Fp)
         y = new(B, V, O)
         part = ops.rows_gemm(_rows4(agg), w_d, _rows4(y), K=3 * Fp, N=O, bias=b_d, stats=train)
         vec_y = (ops.bn_finalize(part, B * V, P["bn.weight"], P["bn.bias"], mod.bn.running_mean, mod.bn.running_var) if train
@@ -325,11 +325,11 @@ class _AgcnConv1dFunction(torch.autograd.Function):
         a_n = ops.transpose(a_t.view(B * 3, V, V))                                                # (3B, V(v), V(w)): A^_k[b]
         x_fm = ops.transpose(x)                                                                   # (B, Fp, V)
         da_t = new(B, 3, V, V)
-        for k in range(3):
+        for k in range(3):             # (the three subsets add into the same dx: one after the other)
             ops.rows_gemm_batched(a_n, dagg, dx, batch=B, rows=V, K=V, N=Fp, ld_in=V, ld_out=Fp, in_bs=3 * V * V, w_bs=V * Fp,
                                   out_bs=V * Fp, in_off=k * V * V, w_off=k * B * V * Fp, accumulate=True)
-            ops.rows_gemm_batched(dagg, x_fm, da_t, batch=B, rows=V, K=Fp, N=V, ld_in=Fp, ld_out=V, in_bs=V * Fp, w_bs=Fp * V,
-                                  out_bs=3 * V * V, in_off=k * B * V * Fp, out_off=k * V * V)
+        ops.rows_gemm_batched(dagg, x_fm, da_t, batch=B, rows=V, K=Fp, N=V, ld_in=Fp, ld_out=V, in_bs=V * Fp, w_bs=Fp * V,
+                              out_bs=3 * V * V, inner=3, in_bs2=B * V * Fp, w_bs2=0, out_bs2=V * V)
         g_adj_t = new(3, V, V)
         ops.reduce_sum(da_t.view(B, -1), g_adj_t.view(-1))
         G["adj_b"] = g_adj_t.transpose(1, 2).contiguous()
@@ -337,11 +337,11 @@ class _AgcnConv1dFunction(torch.autograd.Function):
         ds_t = ops.row_softmax_bwd(da_t, c_t, V, 1.0 / ic)
         ds_n = ops.transpose(ds_t.view(B * 3, V, V))                                              # (3B, V(v), V(w))
         dtp = new(6, B, V, ic)
-        for k in range(3):
-            ops.rows_gemm_batched(ds_t, tp, dtp, batch=B, rows=V, K=V, N=ic, ld_in=V, ld_out=ic, in_bs=3 * V * V, w_bs=V * ic,
-                                  out_bs=V * ic, in_off=k * V * V, w_off=2 * k * B * V * ic, out_off=(2 * k + 1) * B * V * ic)
-            ops.rows_gemm_batched(ds_n, tp, dtp, batch=B, rows=V, K=V, N=ic, ld_in=V, ld_out=ic, in_bs=3 * V * V, w_bs=V * ic,
-                                  out_bs=V * ic, in_off=k * V * V, w_off=(2 * k + 1) * B * V * ic, out_off=2 * k * B * V * ic)
+        # (the 3 B problems (b, k) of each in one launch: theta_k / phi_k are slabs 2k / 2k + 1 of tp and dtp)
+        ops.rows_gemm_batched(ds_t, tp, dtp, batch=B, rows=V, K=V, N=ic, ld_in=V, ld_out=ic, in_bs=3 * V * V, w_bs=V * ic,
+                              out_bs=V * ic, out_off=B * V * ic, inner=3, in_bs2=V * V, w_bs2=2 * B * V * ic, out_bs2=2 * B * V * ic)
+        ops.rows_gemm_batched(ds_n, tp, dtp, batch=B, rows=V, K=V, N=ic, ld_in=V, ld_out=ic, in_bs=3 * V * V, w_bs=V * ic,
+                              out_bs=V * ic, w_off=B * V * ic, inner=3, in_bs2=V * V, w_bs2=2 * B * V * ic, out_bs2=2 * B * V * ic)
         demb = dtp.permute(1, 2, 0, 3).reshape(B, V, 6 * ic).contiguous()
         ops.rows_gemm(_rows4(demb), w_emb[0].t().contiguous().unsqueeze(0), _rows4(dx), K=6 * ic, N=Fp, accumulate=True)
         gw = ops.rows_wgrad(_rows4(x), _rows4(demb), K=Fp, N=6 * ic, conv_param=(1, Fin))        # (6ic, Fin, 1, 1)

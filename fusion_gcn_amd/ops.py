@@ -1268,17 +1268,24 @@ def row_softmax_bwd(da: torch.Tensor, c: torch.Tensor, V: int, scale: float) -> 
 
 def rows_gemm_batched(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch: int, rows: int, K: int, N: int,
                       ld_in: int, ld_out: int, in_bs: int, w_bs: int, out_bs: int, in_off: int = 0, w_off: int = 0,
-                      out_off: int = 0, accumulate: bool = False) -> None:
-    """``batch`` independent products out_b (rows x N) (+)= in_b (rows x K) . w_b (K x N) in one launch; problem b starts at element
-    ``*_off + b * *_bs`` of the (contiguous float32) tensors ``inp`` / ``w`` / ``out``."""
+                      out_off: int = 0, accumulate: bool = False, inner: int = 1, in_bs2: int = 0, w_bs2: int = 0,
+                      out_bs2: int = 0) -> None:
+    """``batch * inner`` independent products out_p (rows x N) (+)= in_p (rows x K) . w_p (K x N) in one launch; problem (b, i) starts
+    at element ``*_off + b * *_bs + i * *_bs2`` of the (contiguous float32) tensors ``inp`` / ``w`` / ``out``."""
     ensure_device()
     _chk(inp, "rows_gemm_batched.in"), _chk(w, "rows_gemm_batched.w"), _chk(out, "rows_gemm_batched.out")
-    last = lambda off, bs, span: off + (batch - 1) * bs + span       # noqa: E731
-    if (last(in_off, in_bs, (rows - 1) * ld_in + K) > inp.numel() or last(w_off, w_bs, K * N) > w.numel()
-            or last(out_off, out_bs, (rows - 1) * ld_out + N) > out.numel()):
+    last = lambda off, bs, bs2, span: off + (batch - 1) * bs + (inner - 1) * bs2 + span       # noqa: E731
+    if (min(in_bs, w_bs, out_bs, in_bs2, w_bs2, out_bs2) < 0 or last(in_off, in_bs, in_bs2, (rows - 1) * ld_in + K) > inp.numel()
+            or last(w_off, w_bs, w_bs2, K * N) > w.numel() or last(out_off, out_bs, out_bs2, (rows - 1) * ld_out + N) > out.numel()):
         raise _lib.FgcnError("rows_gemm_batched: a problem reaches outside its tensor")
-    check(_lib.load().fgcn_rows_gemm_batched(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, rows,
-                                             K, N, ld_in, ld_out, int(accumulate), _stream()), "fgcn_rows_gemm_batched")
+    lib = _lib.load()
+    if inner == 1:
+        check(lib.fgcn_rows_gemm_batched(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, rows,
+                                         K, N, ld_in, ld_out, int(accumulate), _stream()), "fgcn_rows_gemm_batched")
+    else:
+        check(lib.fgcn_rows_gemm_batched2(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, inner, in_bs2,
+                                          out_bs2, w_bs2, rows, K, N, ld_in, ld_out, int(accumulate), _stream()),
+              "fgcn_rows_gemm_batched2")
 
 
 # ---- MS-G3D data movement -------------------------------------------------------------------------------------------------------

@@ -82,7 +82,9 @@ fgcn_ctx* fgcn_ctx_get_current(void);
  *   18 fgcn_emb_dx_tile: 1 = 128-column tiles with a two-slot weight ring (default four)
  *   19 fgcn_emb_wgrad_tile: 1 = emb values requested one frame slot ahead (default: two)
  *   21 fgcn_spatial_wgrad_tile / fgcn_emb_wgrad_tile: 2 = 64 x 64 tiles (default: the widest tiles the channels allow)
- *   22 fgcn_emb_fwd_tile: resident workgroups to aim for (0 = 512; sets the segment count) */
+ *   22 fgcn_emb_fwd_tile: resident workgroups to aim for (0 = 512; sets the segment count)
+ *   24 fgcn_rows_gemm*: 1 = the large-problem tiles (256 / 128 rows x the widest column tile) also where they leave fewer than 256
+ *      workgroups (small problems otherwise take the smallest tiles that pad no extra column) */
 int fgcn_set_tuning(int key, int value);
 int fgcn_get_tuning(int key);
 
@@ -143,6 +145,13 @@ int fgcn_rows_gemm(const float* in, float* out, const float* w, const float* bia
 int fgcn_rows_gemm_batched(const float* in, float* out, const float* w, int batch, long long in_bstride,
                            long long out_bstride, long long w_bstride, int rows, int K, int N, int ld_in, int ld_out,
                            int accumulate, void* stream);
+/* The same with two batch levels, batch * inner problems per launch: problem (o, i) reads in + o*in_bstride + i*in_bstride2 (w, out
+ * alike) -- the three subsets of one sample in one launch (o = sample, i = subset) where a tensor is laid out (sample, subset, ...)
+ * and another (subset, sample, ...). */
+int fgcn_rows_gemm_batched2(const float* in, float* out, const float* w, int batch, long long in_bstride,
+                            long long out_bstride, long long w_bstride, int inner, long long in_bstride2,
+                            long long out_bstride2, long long w_bstride2, int rows, int K, int N, int ld_in, int ld_out,
+                            int accumulate, void* stream);
 /* number of row tiles = leading dimension of stat_partials for M = B*T_out*V rows */
 int fgcn_rows_gemm_tiles(long long M);
 
