@@ -346,6 +346,45 @@ def test_weight_gradients_in_parameter_layout():
     assert rel_l2(acc.cpu().numpy(), 2 * got1.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("B,V,K,N", [(8, 652, 652, 64), (3, 100, 16, 100), (2, 300, 128, 128), (5, 36, 36, 8)])
+def test_batched_row_gemms_one_and_two_levels(B, V, K, N):
+    """fgcn_rows_gemm_batched / _batched2 (the per-sample products of the IMU AGCN convolution, graph_convolution.py:96-101): B x 3
+    problems out[b, :, k] = a[b, k] . w[k, b] with the operands laid out (sample, subset) and (subset, sample), one launch, against
+    float64; the small-problem tile rule against the large-problem tiles (tuning key 24) to rounding; accumulate."""
+    from fusion_gcn_amd import _lib, ops
+    lib = _lib.load()
+    a = rnd(B, 3, V, K, seed=30, scale=0.3)                                      # (sample, subset, rows, K)
+    w = rnd(3, B, K, N, seed=31, scale=0.3)                                      # (subset, sample, K, N)
+    want = torch.einsum("bkvc,kbcn->bvkn", a, w).reshape(B, V, 3 * N)            # (sample, rows, subset * N)
+    ag, wg = to_gpu(a), to_gpu(w)
+
+    def run():
+        out = torch.zeros(B, V, 3 * N, device=dev())
+        ops.rows_gemm_batched(ag, wg, out, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
+                              out_bs=V * 3 * N, inner=3, in_bs2=V * K, w_bs2=B * K * N, out_bs2=N)
+        return out
+    got = run()
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < FWD_TOL
+    assert torch.equal(got, run())
+    lib.fgcn_set_tuning(24, 1)
+    try:
+        big = run()
+    finally:
+        lib.fgcn_set_tuning(24, 0)
+    assert rel_l2(big.cpu().numpy(), got.cpu().numpy()) < 1e-6
+    one = torch.zeros_like(got)                                                  # the same, one launch per subset
+    for k in range(3):
+        ops.rows_gemm_batched(ag, wg, one, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
+                              out_bs=V * 3 * N, in_off=k * V * K, w_off=k * B * K * N, out_off=k * N)
+    assert torch.equal(one, got)
+    ops.rows_gemm_batched(ag, wg, got, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
+                          out_bs=V * 3 * N, inner=3, in_bs2=V * K, w_bs2=B * K * N, out_bs2=N, accumulate=True)
+    assert rel_l2(got.cpu().numpy(), 2 * want.numpy()) < FWD_TOL
+    with pytest.raises(_lib.FgcnError):
+        ops.rows_gemm_batched(ag, wg, got, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
+                              out_bs=V * 3 * N, inner=4, in_bs2=V * K, w_bs2=B * K * N, out_bs2=N)
+
+
 def test_reduce_sum_and_col_sum_and_pack():
     from fusion_gcn_amd import ops
     src = rnd(37, 1000, seed=12)

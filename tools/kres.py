@@ -45,7 +45,7 @@ def main():
         name = demangle(mangled)
         if flt and flt not in name:
             continue
-        ei = next(i for i in range(si, len(lines)) if "s_endpgm" in lines[i])
+        ei = next(i for i in range(si, len(lines)) if lines[i].startswith(".Lfunc_end"))    # (the first s_endpgm may be an early exit)
         body = [l for l in lines[si:ei] if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
         cnt = lambda p: sum(1 for l in body if re.search(p, l))
         v, a, scr, occ, lds = res.get(mangled, ("?",) * 5)
