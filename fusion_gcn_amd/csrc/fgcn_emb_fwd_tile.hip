@@ -162,10 +162,12 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
             }
         }
         // ---- bias, 16-byte stores of emb (lane = row, four consecutive channels per unit) ----------------------------------------------
+        // (row tiles outside, channel units inside: consecutive stores fill a row's 64-byte pieces in address order, so the halves of a 128-byte
+        // line reach the L2 back to back -- fgcn_spatial_tile.hip's epilogue has the measurement)
 #pragma unroll
-        for (int mu = 0; mu < MU; ++mu)
+        for (int nt = 0; nt < NR; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NR; ++nt) {
+            for (int mu = 0; mu < MU; ++mu) {
                 acc[mu][nt] += bv[mu];
                 const int R = wr * 64 + 16 * nt + l15;
                 const unsigned off = R < nrows ? ((m0 + (unsigned)R) * (unsigned)p.ld_e + (unsigned)(ch0 + 16 * mu + 4 * g4)) * 4u : EF_OOB;

@@ -286,10 +286,12 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
             if constexpr (ACC) {
                 if (mt + 1 < MTW) load_old(mt + 1, old[(mt + 1) & 1]);
             }
+            // (row loop outside the unit loop: the 64-byte halves of a 128-byte line leave back to back -- fgcn_spatial_tile.hip's epilogue has
+            // the measurement; each unit's sums keep their order)
 #pragma unroll
-            for (int nu = 0; nu < NU; ++nu) {
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int nu = 0; nu < NU; ++nu) {
                     float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
                     if constexpr (ACC) val += old[mt & 1][nu][r];
                     if ((FGCN_PROBE_PW & 1) && val != 123.456f) continue;

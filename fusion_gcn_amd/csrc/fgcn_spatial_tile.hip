@@ -258,12 +258,17 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
         coff[nu] = col + nu * 16 < p.Cout ? (unsigned)(col + nu * 16) * 4u : OOB;
         bv[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, coff[nu], 0, 0));
     }
+    // Store order: the column units of a row group back to back (a store instruction covers 16 columns = 64 bytes of four rows; units nu, nu + 1
+    // are the two halves of a 128-byte line).  With the unit loop outside the row loop the halves of a line were four stores apart and the
+    // streamed (non-temporal) form wrote 1.45-1.97x the output's bytes -- WRITE_SIZE 0.366 GB per launch for a 0.246 GB tensor, 0.250 GB with
+    // plain stores (profiles/r05_pmc_spatial_tile_writes.txt): half-lines left the L2 one by one.  Each unit's sums still run over (mt, r) in
+    // the same order: same bits.
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
-        for (int nu = 0; nu < NU; ++nu) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int nu = 0; nu < NU; ++nu) {
                 const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
                 const unsigned off = (row < nrows && coff[nu] != OOB) ? (unsigned)((m0 + row) * p.ld_y * 4) + coff[nu] : OOB;
                 const float val = acc[mt][nu][r] + bv[nu];

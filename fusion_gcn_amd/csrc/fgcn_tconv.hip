@@ -714,10 +714,12 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
         if constexpr (ldacc) {
             if (mt + 1 < MTW) load_old(mt + 1, oldv[(mt + 1) & 1]);
         }
+        // (row loop outside the unit loop: the 64-byte halves of a 128-byte line leave back to back -- fgcn_spatial_tile.hip's epilogue has
+        // the measurement; each unit's sums keep their order)
 #pragma unroll
-        for (int nu = 0; nu < NU; ++nu) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int nu = 0; nu < NU; ++nu) {
                 const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
                 float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
                 if constexpr (ldacc) val += oldv[mt & 1][nu][r];
