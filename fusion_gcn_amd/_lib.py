@@ -135,6 +135,8 @@ SIGNATURES = {
     "fgcn_bn_act_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
     "fgcn_bn_act_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_reduce_g": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_apply_g": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_elem_tiles": (_I, [_LL]),
     "fgcn_bn_apply_ld": (_I, [_P, _P, _P, _LL, _I, _I, _P]),
     "fgcn_bn_bwd_reduce_ld": (_I, [_P, _I, _P, _P, _P, _I, _LL, _I, _P]),
@@ -146,6 +148,7 @@ SIGNATURES = {
     "fgcn_spatial_fwd_tile_tiles": (_I, [_I, _I, _I]),
     "fgcn_spatial_fwd_tile_available": (_I, [_I, _I, _I]),
     "fgcn_spatial_bwd_tile": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "fgcn_spatial_bwd_tile_g": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
     "fgcn_spatial_bwd_tile_segments": (_I, [_I, _I, _I]),
     "fgcn_spatial_bwd_tile_available": (_I, [_I, _I, _I]),
     "fgcn_transpose": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

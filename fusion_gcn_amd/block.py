@@ -30,7 +30,7 @@ from __future__ import annotations
 import contextlib
 import os
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -447,6 +447,9 @@ def _bn_vec(part, count, P, bufs, name, train):
 # of writing it (ops.bn_act_pool; the backward gates on the sign image alone) -- one activation write and one read less per step.
 # FGCN_POOL_EPILOGUE=0: bn_act + group_mean (A/B control).
 POOL_EPILOGUE = os.environ.get("FGCN_POOL_EPILOGUE", "1") != "0"
+# ... and its backward reads the pooled gradient as one row per clip (fgcn_bn_act_bwd_*_g, fgcn_spatial_bwd_tile_g) instead of expanding it to the
+# output's shape: one activation write and three reads less.  FGCN_POOL_BACKWARD_ROWS=0: expand (A/B control).
+POOL_BACKWARD_ROWS = os.environ.get("FGCN_POOL_BACKWARD_ROWS", "1") != "0"
 
 
 def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
@@ -610,30 +613,36 @@ class _BiasGrads:
 
 
 def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
-                   W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True):
+                   W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True,
+                   pool: Optional[Tuple[int, tuple]] = None):
     """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape}).
     The leaf reductions of the block (weight-gradient slabs, adj_b, embedding-bias partials) are collected and issued as one
     launch at the end, on the weight-gradient stream, before it joins the main stream (ops.deferred_reductions)."""
     with ops.deferred_reductions() as batch:
-        side = d_o.numel() >= WGRAD_SIDE_MIN_WORK if WGRAD_SIDE_STREAM == "auto" else bool(WGRAD_SIDE_STREAM)
+        work = d_o.numel() if pool is None else pool[1][0] * pool[1][1] * pool[1][2] * pool[1][3]
+        side = work >= WGRAD_SIDE_MIN_WORK if WGRAD_SIDE_STREAM == "auto" else bool(WGRAD_SIDE_STREAM)
         wgrad = _WgradBranch(d_o.device, side)
-        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, wgrad)
+        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, wgrad, pool)
         with wgrad():                 # after everything both streams hold so far
             batch.flush()
         wgrad.join()
     return out
 
 
-def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, wgrad: "_WgradBranch"):
+def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, wgrad: "_WgradBranch", pool=None):
+    """``pool`` = (groups, shape of the block's output): the block's forward returned the per-group mean of its output (pool_groups) and
+    ``d_o`` is the gradient of that, (groups, cout); it is consumed as a per-group row (divided by the group's rows) where the kernels
+    take one (POOL_BACKWARD_ROWS) and expanded to the output's shape otherwise."""
     x = S["x"]
     B, T, V, cx = x.shape
     cout, ic, s = cfg.cout, cfg.ic, cfg.stride
     cin, cin_true = cx, cfg.cin  # kernels work on the padded channel count; gradients are cut back to cin_true
-    Tp = d_o.shape[1]
+    Tp = d_o.shape[1] if pool is None else pool[1][1]
     dev = x.device
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     G: Dict[str, torch.Tensor] = {}
     d_o = d_o.contiguous()
+    o_numel = B * Tp * V * cout
     kt = P["tcn1.conv.weight"].shape[2]
 
     dx = new(B, T, V, cx)
@@ -646,25 +655,34 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
                and (ops.get_math_mode() in ("bf16x3", "bf16") or SPATIAL_BWD_TILE_F16X2) and small(max(cin, cout)))
     gate_in_dagg = ((GATED_SHORTCUTS_TILE if tile_ok else GATED_SHORTCUTS) and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
-                    and d_o.numel() * 4 < 0x7FFF0000)
+                    and o_numel * 4 < 0x7FFF0000)
     gated: List[tuple] = []
+    grp_rows = grp_samples = 0
+    if pool is not None:
+        groups = pool[0]
+        rows = o_numel // cout // groups
+        d_o = d_o / rows                             # (groups, cout): every row of a group receives the group's gradient / rows
+        if POOL_BACKWARD_ROWS and (not gate_in_dagg or (tile_ok and x.shape[3] == cin)):
+            grp_rows, grp_samples = rows, B // groups        # the BatchNorm-backward passes and the gated addend read the group's row
+        else:
+            d_o = d_o.unsqueeze(1).expand(groups, rows, cout).contiguous().view(B, Tp, V, cout)
     bias_grad = _BiasGrads(cfg, dev, train)
 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
     if cfg.residual == "none":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train,
-                                     sign_mask=S["o_sign"])
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
     elif cfg.residual == "identity" and gate_in_dagg:
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, need_db=False,
-                                     sign_mask=S["o_sign"])
-        gated.append((d_o, S["o_sign"]))           # dx += d_o * [o > 0], added by joint_dagg below
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
+        gated.append((d_o, S["o_sign"], grp_samples) if grp_samples else (d_o, S["o_sign"]))   # dx += d_o * [o > 0], added by joint_dagg below
     elif cfg.residual == "identity":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
-                                     sign_mask=S["o_sign"])
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
         dx_live = True
     else:
         du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train,
-                                      sign_mask=S["o_sign"])
+                                      sign_mask=S["o_sign"], grp_rows=grp_rows)
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
@@ -818,11 +836,7 @@ class STBlockFunction(torch.autograd.Function):
         P = dict(zip(ctx.names, params))
         S = dict(ctx.S, x=x, o=o)
         ctx.S = None
-        if ctx.pool is not None:            # d_o of the pooled output: every row of a group receives the group's gradient / rows
-            groups, shape = ctx.pool
-            rows = shape[0] * shape[1] * shape[2] // groups
-            d_o = (d_o / rows).unsqueeze(1).expand(groups, rows, shape[3]).contiguous().view(shape)
-        dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0])
+        dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0], pool=ctx.pool)
         del S
         grads = []
         for i, n in enumerate(ctx.names):

@@ -154,7 +154,7 @@ __device__ __forceinline__ void relu_gate(f32x4& dp, const float* out, const uns
 template <int RES, bool MASKED>
 __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const unsigned char* mask, const float* a,
                                          const float* va, const float* b, const float* vb, float* partials,
-                                         long long rows, long long rows_per_tile, int C, int relu, int ld_dout) {
+                                         long long rows, long long rows_per_tile, int C, int relu, int ld_dout, int grp_rows) {
     extern __shared__ float red[];  // [ny][3][Cw], Cw = the channel window of this block: 4 * blockDim.x channels from c0
     const int Cw = blockDim.x * 4, c0 = blockIdx.y * Cw, cl = threadIdx.x * 4;
     const int c = c0 + cl;
@@ -174,7 +174,10 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
     if (cok)
         for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
             const long long o = r * C + c;
-            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + r * ld_dout + c);   // (ld_dout > C: a channel window of a wider gradient)
+            // (ld_dout > C: a channel window of a wider gradient; grp_rows > 0: dout is one row per GROUP of grp_rows consecutive rows -- the
+            // gradient of the pooled output of the model's last block, fgcn_bn_act_pool -- and every row of a group reads its group's row)
+            const long long dr = grp_rows ? (long long)((unsigned)r / (unsigned)grp_rows) : r;
+            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + dr * ld_dout + c);
             if (relu) relu_gate<MASKED>(dp, out, mask, o);
             const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
             s1 += dp;
@@ -203,11 +206,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                                                                const float* va, const float* b, const float* vb,
                                                                const float* sums, float* da, float* db, long long n4,
                                                                int C, int relu, int train, float inv_m,
-                                                               int db_accumulate, int stream, int ld_dout) {
+                                                               int db_accumulate, int stream, int ld_dout, int grp_rows) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
-        f32x4 dp = *reinterpret_cast<const f32x4*>(ld_dout == C ? dout + i * 4 : dout + (i * 4 / C) * ld_dout + c);
+        f32x4 dp;
+        if (grp_rows) dp = *reinterpret_cast<const f32x4*>(dout + (long long)(((unsigned)i * 4u / (unsigned)C) / (unsigned)grp_rows) * ld_dout + c);   // (one row per group)
+        else dp = *reinterpret_cast<const f32x4*>(ld_dout == C ? dout + i * 4 : dout + (i * 4 / C) * ld_dout + c);
         if (relu) relu_gate<MASKED>(dp, out, mask, i * 4);
         const f32x4 sc_a = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         f32x4 ga = dp;
@@ -440,7 +445,9 @@ static int reduce_block(int C, dim3* blk) {
 static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const unsigned char* sign_mask,
                                   const float* a, const float* vec_a, const float* b, const float* vec_b,
                                   float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
-                                  int ld_dout, void* stream) {
+                                  int ld_dout, void* stream, int grp_rows = 0) {
+    FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
+                 "bn_act_bwd_reduce: %lld rows are not whole groups of %d", rows, grp_rows);
     FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out || sign_mask), FGCN_E_BADARG,
                  "bn_act_bwd_reduce: null pointer");
     if (int e = check_elem("bn_act_bwd_reduce", rows, C, res_mode, b, vec_b)) return e;
@@ -455,7 +462,7 @@ static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const uns
     dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
 #define FGCN_BN_RED(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
-                       partials, rows, rpt, C, relu, ld_dout)
+                       partials, rows, rpt, C, relu, ld_dout, grp_rows)
     if (res_mode == 2) {
         if (sign_mask) FGCN_BN_RED(2, true); else FGCN_BN_RED(2, false);
     } else {
@@ -469,7 +476,9 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
                                  const float* a, const float* vec_a, const float* b, const float* vec_b,
                                  const float* sums, float* da, float* db,
                                  long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
-                                 int ld_dout, void* stream) {
+                                 int ld_dout, void* stream, int grp_rows = 0) {
+    FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
+                 "bn_act_bwd_apply: %lld rows are not whole groups of %d", rows, grp_rows);
     FGCN_REQUIRE(dout && vec_a && da && (!relu || out || sign_mask) && (!train || (a && sums)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: null pointer");
     FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG,
@@ -484,7 +493,7 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_APP(RES_, M_)                                                                                      \
     hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                       da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout)
+                       da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows)
     if (res_mode == 0 || !db) {
         if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
     } else if (res_mode == 1) {
@@ -678,6 +687,23 @@ extern "C" int fgcn_bn_act_pool(const float* a, const float* vec_a, const float*
     hipLaunchKernelGGL(group_mean_finish_kernel, dim3((unsigned)cdiv((long long)groups * C, 256)), dim3(256), 0, s, partial, pooled, groups,
                        C, splits, 1.f / (float)grp_rows);
     return launch_status("bn_act_pool");
+}
+
+// The two backward passes with the gradient of a POOLED output (fgcn_bn_act_pool): dout is float[rows / grp_rows][C], one row per group of
+// grp_rows consecutive rows (already divided by the group size), read in place of the rows x C broadcast of it
+extern "C" int fgcn_bn_act_bwd_reduce_g(const float* dout_g, int grp_rows, const float* out, const unsigned char* sign_mask,
+                                        const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                        float* partials, int n_tiles, long long rows, int C, int res_mode, int relu, void* stream) {
+    FGCN_REQUIRE(grp_rows > 0, FGCN_E_BADARG, "bn_act_bwd_reduce_g: grp_rows=%d", grp_rows);
+    return bn_act_bwd_reduce_impl(dout_g, out, sign_mask, a, vec_a, b, vec_b, partials, n_tiles, rows, C, res_mode, relu, C, stream, grp_rows);
+}
+extern "C" int fgcn_bn_act_bwd_apply_g(const float* dout_g, int grp_rows, const float* out, const unsigned char* sign_mask,
+                                       const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                       const float* sums, float* da, float* db,
+                                       long long rows, int C, int res_mode, int relu, int train, int db_accumulate, void* stream) {
+    FGCN_REQUIRE(grp_rows > 0, FGCN_E_BADARG, "bn_act_bwd_apply_g: grp_rows=%d", grp_rows);
+    return bn_act_bwd_apply_impl(dout_g, out, sign_mask, a, vec_a, b, vec_b, sums, da, db, rows, C, res_mode, relu, train, db_accumulate, C,
+                                 stream, grp_rows);
 }
 
 // The same three passes for a plain BatchNorm (no residual, no activation) whose RESULT is a channel window of a wider tensor -- one

@@ -57,6 +57,10 @@ struct SpBwdP {
     const float* e[2];
     const unsigned char* m[2];
     unsigned e_bytes;
+    // e0_grp > 0: e[0] is float[B / e0_grp][Cin], one row per GROUP of e0_grp consecutive samples, added to every row of the group's samples (the
+    // gradient of the pooled output of the model's last block, fgcn_bn_act_pool: a per-clip vector instead of its (B, T, V, Cin) broadcast)
+    int e0_grp;
+    unsigned e0_bytes;
     int mix_wave[16];                   // mix unit u = 2 f + (16-channel tile of the 32-channel half) -> wave (eight-wave form)
     int mix_wave4[16];                  // ... four-wave form
 };
@@ -103,9 +107,11 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rge[2], rgm[2];
+    const unsigned e0_row = p.e0_grp ? (unsigned)(n / p.e0_grp) * (unsigned)p.Cin : 0u;      // element offset of this sample's group row in e[0]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        rge[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.e[i] : (const void*)p.dx), 0, NE ? p.e_bytes : 0u, 0x00020000);
+        rge[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.e[i] : (const void*)p.dx), 0,
+                                                   NE ? ((i == 0 && p.e0_grp) ? p.e0_bytes : p.e_bytes) : 0u, 0x00020000);
         rgm[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.m[i] : (const void*)p.dx), 0, NE ? p.e_bytes >> 5 : 0u, 0x00020000);
     }
 
@@ -289,11 +295,14 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                         for (int vt = 0; vt < 2; ++vt) {
                             const int v = 16 * vt + l15;
-                            const unsigned el = (row0 + sf[s] * V + v) * (unsigned)Cin + cbase + sct[s] * 16 + 4 * g4;
+                            const unsigned chan = (unsigned)(cbase + sct[s] * 16 + 4 * g4);
+                            const unsigned el = (row0 + sf[s] * V + v) * (unsigned)Cin + chan;
                             const bool ok = sok[s] && sf[s] < nf && v < V;
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
-                                ge[s][vt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[i], ok ? el * 4u : OOB, 0, 0));
+                                // (a per-group addend: the group's row instead of the element's; n is the workgroup's sample)
+                                const unsigned ea = (i == 0 && p.e0_grp) ? e0_row + chan : el;
+                                ge[s][vt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[i], ok ? ea * 4u : OOB, 0, 0));
                                 gm[s][vt][i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rgm[i], ok ? el >> 3 : OOB, 0, 0) >> (el & 4u);
                             }
                         }
@@ -724,10 +733,34 @@ extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
     return (int)cdiv(tiles_t, tps);
 }
 
+static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                                   int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
+                                   int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
+                                   const unsigned char* mask2, int extra1_group, void* stream);
+
 extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                      int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                      int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
                                      const unsigned char* mask2, void* stream) {
+    return spatial_bwd_tile_launch(dy, x, a_hat, w3, dx, partial, B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, a_hat_batched, accumulate, extra1, mask1,
+                                   extra2, mask2, 0, stream);
+}
+
+// the same with the first gated addend given per GROUP of `extra1_group` consecutive samples: extra1 is float[B / extra1_group][Cin]
+extern "C" int fgcn_spatial_bwd_tile_g(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                                       int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
+                                       const float* extra1, int extra1_group, const unsigned char* mask1, const float* extra2,
+                                       const unsigned char* mask2, void* stream) {
+    FGCN_REQUIRE(extra1 && extra1_group > 0 && B % extra1_group == 0, FGCN_E_BADARG, "spatial_bwd_tile_g: %d samples are not whole groups of %d", B,
+                 extra1_group);
+    return spatial_bwd_tile_launch(dy, x, a_hat, w3, dx, partial, B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx, a_hat_batched, 0, extra1, mask1, extra2,
+                                   mask2, extra1_group, stream);
+}
+
+static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                                   int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
+                                   int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
+                                   const unsigned char* mask2, int extra1_group, void* stream) {
     const bool gated = extra1 != nullptr;
     FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0), FGCN_E_BADARG,
                  "spatial_bwd_tile: gated addends come in pairs with their sign images, without accumulation, on contiguous (B, T, V, Cin) tensors");
@@ -755,6 +788,8 @@ extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const floa
     FGCN_REQUIRE((long long)B * p.nseg < (1ll << 30), FGCN_E_BADARG, "spatial_bwd_tile: too many workgroups");
     p.dy_bytes = (unsigned)dy_bytes; p.x_bytes = (unsigned)x_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
     p.e[0] = extra1; p.e[1] = extra2; p.m[0] = mask1; p.m[1] = mask2; p.e_bytes = (unsigned)(rows * Cin * 4);
+    p.e0_grp = extra1_group;
+    p.e0_bytes = extra1_group ? (unsigned)((long long)(B / extra1_group) * Cin * 4) : 0u;
     // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave 2 (f mod 4) + vt already carries the gram units (f, vt) -- one or
     // two per half, 12 MFMA groups each like a mix unit; greedy on the lightest wave, the later wave on ties
     {

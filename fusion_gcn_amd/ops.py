@@ -881,14 +881,18 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
                sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True,
-               partials: Optional[torch.Tensor] = None):
+               partials: Optional[torch.Tensor] = None, grp_rows: int = 0):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
-    ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass."""
+    ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass.
+    ``grp_rows`` > 0: ``dout`` is (rows / grp_rows, C), one row per group of consecutive rows -- the gradient of ``bn_act_pool``'s
+    output, already divided by the group size -- instead of its rows x C broadcast."""
     ensure_device()
     _chk(dout, "bn_act_bwd.dout"), _chk(a, "bn_act_bwd.a")
     C = a.shape[-1]
     rows = a.numel() // C
+    if grp_rows and (rows % grp_rows or tuple(dout.shape) != (rows // grp_rows, C) or partials is not None):
+        raise _lib.FgcnError(f"bn_act_bwd: a per-group gradient for {rows} rows in groups of {grp_rows} is ({rows // max(grp_rows, 1)}, {C}), got {tuple(dout.shape)}")
     lib = _lib.load()
     if sign_mask is not None and (sign_mask.dtype != torch.uint8 or sign_mask.numel() * 8 != a.numel()):
         raise _lib.FgcnError("bn_act_bwd: sign_mask must be the uint8 bit image of bn_act (numel/8 bytes)")
@@ -901,16 +905,25 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     elif need_sums or train:
         tiles = lib.fgcn_elem_tiles(rows)
         partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
-        check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
-                                         tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
+        if grp_rows:
+            check(lib.fgcn_bn_act_bwd_reduce_g(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
+                                               tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce_g")
+        else:
+            check(lib.fgcn_bn_act_bwd_reduce(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
+                                             tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
         sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
         reduce_sum(partials.view(tiles, -1), sums.view(-1))
     da = torch.empty_like(a)
     if res_mode != 0 and db is None and need_db:   # need_db=False (identity residual): the caller adds the gated gradient itself
         db = torch.empty_like(a)
-    check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
-                                    _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
-          "fgcn_bn_act_bwd_apply")
+    if grp_rows:
+        check(lib.fgcn_bn_act_bwd_apply_g(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
+                                          _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
+              "fgcn_bn_act_bwd_apply_g")
+    else:
+        check(lib.fgcn_bn_act_bwd_apply(_p(dout), _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
+                                        _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
+              "fgcn_bn_act_bwd_apply")
     return da, db, sums
 
 
@@ -1107,15 +1120,19 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     """The fused backward of the spatial stage (fgcn_spatial_bwd_tile.hip): dagg = dy . Wd stays on chip,
     dx (+)= sum_k dagg_k . A^_k^T, and the partial grams dA^_k = x^T dagg_k come back as (B, nseg, 3, 32, 32) -- joint_dagg's output
     format.  w3 = ``pack_split3`` of the (1, Cout, 3 Cin) matrix [o][k Cin + c] = Wd_k[o][c].  ``gated``: none or exactly two
-    (tensor, sign image) pairs added to dx where the image's bit is set (as in ``joint_dagg``; not with ``accumulate``)."""
+    (tensor, sign image) pairs added to dx where the image's bit is set (as in ``joint_dagg``; not with ``accumulate``).  The FIRST pair
+    may carry a third member, the number of consecutive samples per group: its tensor is then (B / group, Cin), one row per group, added
+    to every row of the group's samples (the gradient of a pooled block output, ``bn_act_pool``)."""
     ensure_device()
     if len(gated) not in (0, 2) or (gated and accumulate):
         raise _lib.FgcnError("spatial_bwd_tile: gated addends come as the pair of identity shortcuts, without accumulation")
-    for e, m in gated:
+    group = gated[0][2] if gated and len(gated[0]) == 3 else 0
+    for i, (e, m, *_) in enumerate(gated):
         _chk(e, "spatial_bwd_tile.gated")
-        if tuple(e.shape) != tuple(x.shape) or m.dtype != torch.uint8 or m.numel() * 8 != e.numel() or not m.is_cuda:
+        want = (x.shape[0] // group, x.shape[3]) if (i == 0 and group) else tuple(x.shape)
+        if tuple(e.shape) != want or m.dtype != torch.uint8 or m.numel() * 8 != x.numel() or not m.is_cuda or (group and x.shape[0] % group):
             raise _lib.FgcnError(f"spatial_bwd_tile: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
-    ex = [(_p(e), m.data_ptr()) for e, m in gated] + [(None, None)] * (2 - len(gated))
+    ex = [(_p(e), m.data_ptr()) for e, m, *_ in gated] + [(None, None)] * (2 - len(gated))
     _chk(dy, "spatial_bwd_tile.dy"), _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
     B, T, V, Cin = x.shape
     Cout = dy.shape[3]
@@ -1128,6 +1145,11 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     _mode_products()
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
+    if group:
+        check(lib.fgcn_spatial_bwd_tile_g(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
+                                          dx.shape[3], int(a_hat.shape[0] == B), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1], _stream()),
+              "fgcn_spatial_bwd_tile_g")
+        return partial
     check(lib.fgcn_spatial_bwd_tile(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
                                     dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], ex[0][1], ex[1][0], ex[1][1], _stream()),
           "fgcn_spatial_bwd_tile")

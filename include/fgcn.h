@@ -456,6 +456,14 @@ int fgcn_bn_act_bwd_apply(const float* dout, const float* out, const unsigned ch
                           const float* vec_a, const float* b, const float* vec_b, const float* sums, float* da, float* db,
                           long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
                           void* stream);
+/* Both passes with the gradient of a POOLED output (fgcn_bn_act_pool): dout_g is float[rows / grp_rows][C], one row per group of grp_rows consecutive
+ * rows (the pooled gradient already divided by the group size); every row reads its group's row instead of a rows x C broadcast of it. */
+int fgcn_bn_act_bwd_reduce_g(const float* dout_g, int grp_rows, const float* out, const unsigned char* sign_mask, const float* a,
+                             const float* vec_a, const float* b, const float* vec_b, float* partials, int n_tiles,
+                             long long rows, int C, int res_mode, int relu, void* stream);
+int fgcn_bn_act_bwd_apply_g(const float* dout_g, int grp_rows, const float* out, const unsigned char* sign_mask, const float* a,
+                            const float* vec_a, const float* b, const float* vec_b, const float* sums, float* da, float* db,
+                            long long rows, int C, int res_mode, int relu, int train, int db_accumulate, void* stream);
 /* number of row tiles the reduce kernel uses for `rows` rows (leading dim of its partials) */
 int fgcn_elem_tiles(long long rows);
 /* The same three passes for a plain BatchNorm (no residual, no activation) whose result is a CHANNEL WINDOW of a wider tensor: one of the
@@ -513,6 +521,13 @@ int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, c
                           int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
                           const float* extra1, const unsigned char* mask1, const float* extra2, const unsigned char* mask2,
                           void* stream);
+/* ... with the first gated addend given per GROUP of extra1_group consecutive samples: extra1 = float[B / extra1_group][Cin], every row of a group's
+ * samples adds its group's row (gated by mask1's bits as before) -- the gradient of the pooled output of the model's last block (fgcn_bn_act_pool)
+ * without its (B, T, V, Cin) broadcast.  Not accumulating. */
+int fgcn_spatial_bwd_tile_g(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial, int B,
+                            int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
+                            const float* extra1, int extra1_group, const unsigned char* mask1, const float* extra2,
+                            const unsigned char* mask2, void* stream);
 int fgcn_spatial_bwd_tile_segments(int B, int T, int V);
 int fgcn_spatial_bwd_tile_available(int V, int Cin, int Cout);
 

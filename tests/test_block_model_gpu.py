@@ -557,6 +557,56 @@ def test_last_blocks_epilogue_with_the_pooling_behind_it(G, R, C, res_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G,R,C,res_mode", [(4, 500, 64, 1), (3, 77, 128, 0), (2, 130, 256, 2), (5, 8, 8, 1)])
+def test_batchnorm_backward_from_a_per_group_gradient(G, R, C, res_mode):
+    """fgcn_bn_act_bwd_{reduce,apply}_g: the gradient of a pooled output as one row per group equals the two passes on its rows x C
+    broadcast, bit for bit (the same values reach the same arithmetic)."""
+    from fusion_gcn_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3 + C)
+    rows = G * R
+    a = torch.randn(rows, C, device=dev)
+    b = torch.randn(rows, C, device=dev) if res_mode else None
+    mk = lambda: torch.stack([torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev), torch.randn(C, device=dev)]).contiguous()   # noqa: E731
+    va, vb = mk(), (mk() if res_mode == 2 else None)
+    out, mask = ops.bn_act(a, va, b, vb, relu=True, sign_mask=True)
+    dg = torch.randn(G, C, device=dev)
+    full = dg.unsqueeze(1).expand(G, R, C).contiguous().view(rows, C)
+    for train in (True, False):
+        want = ops.bn_act_bwd(full, out, a, va, b, vb, res_mode=res_mode, train=train, sign_mask=mask)
+        got = ops.bn_act_bwd(dg, out, a, va, b, vb, res_mode=res_mode, train=train, sign_mask=mask, grp_rows=R)
+        for w, g_ in zip(want, got):
+            assert (w is None) == (g_ is None) and (w is None or torch.equal(w, g_))
+    with pytest.raises(Exception):
+        ops.bn_act_bwd(dg, out, a, va, b, vb, res_mode=res_mode, train=True, sign_mask=mask, grp_rows=R + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,V,C,group", [(4, 11, 25, 64, 2), (6, 7, 20, 128, 3), (2, 40, 25, 256, 1)])
+def test_spatial_backward_tile_with_a_per_group_addend(B, T, V, C, group):
+    """fgcn_spatial_bwd_tile_g: the first gated addend as one row per group of samples = the launch with its (B, T, V, Cin) broadcast, bit for bit."""
+    from fusion_gcn_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7 + C)
+    with ops.math_mode("bf16x3"):
+        if not ops.spatial_bwd_tile_available(V, C, C):
+            pytest.skip("tile backward not available for this shape")
+        x, dy = torch.randn(B, T, V, C, device=dev), torch.randn(B, T, V, C, device=dev)
+        a_hat = torch.randn(B, 3, V, V, device=dev) * 0.2
+        w = torch.randn(1, C, 3 * C, device=dev) * 0.05
+        w3 = ops.pack_split3(w)
+        e2 = torch.randn(B, T, V, C, device=dev)
+        m1 = torch.randint(0, 256, (B * T * V * C // 8,), device=dev, dtype=torch.uint8)
+        m2 = torch.randint(0, 256, (B * T * V * C // 8,), device=dev, dtype=torch.uint8)
+        eg = torch.randn(B // group, C, device=dev)
+        full = eg.repeat_interleave(group, 0).view(B, 1, 1, C).expand(B, T, V, C).contiguous()
+        dx0, dx1 = torch.empty(B, T, V, C, device=dev), torch.empty(B, T, V, C, device=dev)
+        p0 = ops.spatial_bwd_tile(dy, x, a_hat, w3, dx0, accumulate=False, gated=[(full, m1), (e2, m2)])
+        p1 = ops.spatial_bwd_tile(dy, x, a_hat, w3, dx1, accumulate=False, gated=[(eg, m1, group), (e2, m2)])
+        assert torch.equal(dx0, dx1) and torch.equal(p0, p1)
+
+
+@pytest.mark.gpu
 def test_model_with_and_without_the_pooling_epilogue(fgcn_math):
     """The model's last block with the pooling in its epilogue against bn_act + group_mean: logits, loss and every gradient agree to
     rounding (the pooled sums run in another order); the backward is the same code on the same sign image."""
@@ -591,6 +641,15 @@ def test_model_with_and_without_the_pooling_epilogue(fgcn_math):
     assert float((lg1 - lg0).norm() / lg0.norm()) < 2e-6 and abs(l1 - l0) < 1e-5
     f0, f1 = torch.cat([g.flatten() for g in g0]).double(), torch.cat([g.flatten() for g in g1]).double()
     assert float((f1 - f0).norm() / f0.norm()) < 2e-5
+    # the backward from the pooled gradient as one row per clip against its expansion: the same values reach the same arithmetic
+    old_rows, block.POOL_BACKWARD_ROWS = block.POOL_BACKWARD_ROWS, False
+    try:
+        lg2, l2, g2 = run(True)
+    finally:
+        block.POOL_BACKWARD_ROWS = old_rows
+    assert torch.equal(lg1, lg2) and l1 == l2
+    for a_, b_ in zip(g1, g2):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.gpu
