@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     }
     // Store order: the column units of a row group back to back (a store instruction covers 16 columns = 64 bytes of four rows; units nu, nu + 1
     // are the two halves of a 128-byte line).  With the unit loop outside the row loop the halves of a line were four stores apart and the
-    // streamed (non-temporal) form wrote 1.45-1.97x the output's bytes -- WRITE_SIZE 0.366 GB per launch for a 0.246 GB tensor, 0.250 GB with
+    // streamed (non-temporal) form wrote 1.45-1.48x the output's bytes -- WRITE_SIZE 0.366 GB per launch for a 0.246 GB tensor, 0.250 GB with
     // plain stores (profiles/r05_pmc_spatial_tile_writes.txt): half-lines left the L2 one by one.  Each unit's sums still run over (mt, r) in
     // the same order: same bits.
 #pragma unroll
