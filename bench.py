@@ -245,7 +245,7 @@ def measured_traffic(dom, samples, math="f32"):
     return rec["traffic_bytes"]
 
 
-def live_traffic(math: str, batch: int, timeout_s: int = 150):
+def live_traffic(math: str, batch: int, timeout_s: int = 90):
     """HBM-side bytes per launch of the dominant kernel MEASURED in this run: two child processes, `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
     and `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; nothing but --kernel-trace beside --pmc), each around
     `python3 bench.py --kernel-only` (the same launches `time_dominant_kernel` times).  traffic = 2 x FETCH_SIZE + WRITE_SIZE (the guide's
@@ -255,6 +255,7 @@ def live_traffic(math: str, batch: int, timeout_s: int = 150):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -267,20 +268,30 @@ def live_traffic(math: str, batch: int, timeout_s: int = 150):
                sys.executable, os.path.abspath(__file__), "--kernel-only", "--math", math, "--batch", str(batch)]
         env = dict(os.environ, TMPDIR="/tmp")
         env.pop("WORLD_SIZE", None)
+        # the child is a process GROUP (rocprofv3 -> python -> the kernels): on a timeout the whole group is killed, so that no
+        # grandchild keeps the GPU busy under the timed runs that follow, and the scratch directory goes either way
+        proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
-            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s, start_new_session=True)
-        except subprocess.TimeoutExpired:
-            return None, f"rocprofv3 --pmc {counter} timed out after {timeout_s} s"
-        files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
-        vals = []
-        for f in files:
-            with open(f) as fh:
-                for row in csv.DictReader(fh):
-                    if row.get("Counter_Name") == counter and "conv_halo" in row.get("Kernel_Name", ""):
-                        vals.append(float(row["Counter_Value"]))
-        shutil.rmtree(out_dir, ignore_errors=True)
-        if r.returncode != 0 or not vals:
-            return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(vals)} launches read"
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter} timed out after {timeout_s} s (process group killed)"
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and "conv_halo" in row.get("Kernel_Name", ""):
+                            vals.append(float(row["Counter_Value"]))
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+        if rc != 0 or not vals:
+            return None, f"rocprofv3 --pmc {counter}: rc {rc}, {len(vals)} launches read"
         got[counter] = (sum(vals) / len(vals), len(vals))
     byts = int(round((2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024))
     return byts, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes of `bench.py --kernel-only`, "
@@ -381,6 +392,7 @@ def dry_run(args, world: int, rank: int) -> None:
             line["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": None, "kind": "port", "sample": "dry run: not timed"}
         print(json.dumps(line), flush=True)
     if world > 1:
+        wait_for_rank0(rank)      # the same hand-off as the measured run's (there rank 0 times the CPU oracle first)
         dist.barrier()
         dist.destroy_process_group()
 
@@ -465,10 +477,13 @@ def main():
     device = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (generous collective timeout: graph capture + warm-up of one rank may lag the others by minutes on a cold box; the wait for
+        # rank 0's CPU baseline at the end does NOT sit in a collective at all -- see wait_for_rank0 below)
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(minutes=60))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60))
 
     from fusion_gcn_amd import ops as _ops
     _ops.set_math_mode(args.math)
@@ -792,8 +807,21 @@ def main():
         out["notes"] = notes
         print(json.dumps(out), flush=True)
     if world > 1:
+        wait_for_rank0(rank)      # rank 0 has timed the CPU oracle meanwhile: the others poll the rendezvous store, not a collective
         dist.barrier()
         dist.destroy_process_group()
+
+
+def wait_for_rank0(rank: int, key: str = "fgcn_bench_rank0_done", timeout_s: int = 7200) -> None:
+    """After the timed regions rank 0 alone times the CPU oracle (tens of seconds to minutes on a slow host) and prints the line.  The other
+    ranks must not sit in a collective meanwhile (an NCCL barrier is a GPU operation under the process group's watchdog timeout): they
+    wait on a key of the rendezvous store, which rank 0 sets when it is done."""
+    import datetime
+    store = dist.distributed_c10d._get_default_store()
+    if rank == 0:
+        store.set(key, "1")
+    else:
+        store.wait([key], datetime.timedelta(seconds=timeout_s))
 
 
 if __name__ == "__main__":

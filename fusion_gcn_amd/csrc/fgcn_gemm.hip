@@ -650,7 +650,7 @@ static int rows_gemm_launch(const float* in, float* out, const float* w, const f
     RowsGemmP p{in, out, w, bias, stat_partials, (long long)B * T_out * V, T_in, T_out, V, K, N, ld_in, ld_out,
                 map.taps, map.ta, map.tb, map.tc, map.td, accumulate,
                 (long long)B * T_in * V * ld_in, (unsigned)((long long)map.taps * K * N * 4), 0, 0, 0, in_bs, out_bs, w_bs,
-                (!accumulate && fgcn::stream_out((long long)batch * B * T_out * V * N * 4)) ? 1 : 0};
+                (!accumulate && fgcn::stream_out((long long)batch * inner * B * T_out * V * N * 4)) ? 1 : 0};   // (all batch levels: `batch *= inner` below)
     hipStream_t s = (hipStream_t)stream;
     // tile width (32*nt channels) with the fewest padded columns; ties go to the wider tile
     int nt = 4;

@@ -31,7 +31,11 @@ class FlatGradients:
                 raise ValueError("all parameters must share one device and dtype")
             offsets.append(total)
             total += (p.numel() + 3) // 4 * 4          # keeps every view 16-byte aligned
-        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        # allow_unused: one "used" slot per parameter + one "anything unused?" slot ride behind the gradients in the SAME allocation,
+        # so that all_reduce_mean(restore_unused=True) exchanges gradients and mask in one collective (self.flat stays the gradients)
+        self._n_mask = (len(self.params) + 1 + 3) // 4 * 4 if allow_unused else 0
+        self._buf = torch.zeros(total + self._n_mask, device=dev, dtype=dt)
+        self.flat = self._buf[:total]
         self.unused: List[bool] = [False] * len(self.params)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, offsets)]
 
@@ -72,8 +76,9 @@ class FlatGradients:
         single-rank group too (what a 1-GPU box can prove about the RCCL path: tests/test_rccl_gpu.py).  ``restore_unused`` (with
         ``allow_unused``): a parameter that received no gradient on ANY rank gets ``p.grad = None`` back after the exchange, so a
         torch.optim optimizer skips it exactly as in the single-rank run (no weight decay / momentum on it); one that some rank
-        did use keeps the averaged gradient on every rank.  Costs one small second all-reduce (a used-mask), only when something
-        was unused on this rank or any other."""
+        did use keeps the averaged gradient on every rank.  The used-mask travels behind the gradients in the same collective (every
+        step, by design: the ranks cannot know beforehand whether another rank had an unused parameter) and is read back with ONE
+        device-to-host copy."""
         self.gather()
         if not (dist.is_available() and dist.is_initialized()):
             self._restore_unused(restore_unused, self.unused)
@@ -82,15 +87,18 @@ class FlatGradients:
         if world == 1 and not always:
             self._restore_unused(restore_unused, self.unused)
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        with_mask = restore_unused and self.allow_unused
+        if with_mask:
+            n = len(self.params)
+            host = torch.tensor([0.0 if u else 1.0 for u in self.unused] + [float(any(self.unused))], dtype=self.flat.dtype)
+            self._buf[self.flat.numel():self.flat.numel() + n + 1].copy_(host, non_blocking=True)
+        dist.all_reduce(self._buf if with_mask else self.flat, op=dist.ReduceOp.SUM, group=group)
         if world > 1:
             self.flat.mul_(1.0 / world)
-        if restore_unused and self.allow_unused:
-            # every rank must take part in the mask exchange whenever ANY rank has an unused parameter: first agree on that
-            mask = torch.tensor([0.0 if u else 1.0 for u in self.unused] + [float(any(self.unused))], device=self.flat.device)
-            dist.all_reduce(mask, op=dist.ReduceOp.SUM, group=group)
-            if float(mask[-1]) > 0:
-                self._restore_unused(True, [float(m) == 0.0 for m in mask[:-1]])
+        if with_mask:
+            mask = self._buf[self.flat.numel():self.flat.numel() + n + 1].tolist()      # the one host sync of this path
+            if mask[-1] > 0:
+                self._restore_unused(True, [m == 0.0 for m in mask[:-1]])
 
     def _restore_unused(self, enabled: bool, unused) -> None:
         if enabled and self.allow_unused:

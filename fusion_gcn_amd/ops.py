@@ -98,7 +98,9 @@ def context_bound(fn_cls):
         return fwd(ctx, *args, **kwargs)
 
     def backward(ctx, *grads):
-        with use_context(ctx._fgcn_context):
+        # (a forward that bypassed this wrapper -- a subclass overriding forward without re-binding -- leaves no context: the
+        # process-wide defaults then, rather than an AttributeError on the autograd thread)
+        with use_context(getattr(ctx, "_fgcn_context", None)):
             return bwd(ctx, *grads)
     forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
     fn_cls.forward, fn_cls.backward = staticmethod(forward), staticmethod(backward)
@@ -109,7 +111,8 @@ def bind_all_functions(namespace: dict) -> None:
     """``context_bound`` for every autograd Function class defined in a module (call at the end of the module with ``globals()``)."""
     for obj in list(namespace.values()):
         if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function \
-                and obj.__module__ == namespace.get("__name__") and not getattr(obj, "_fgcn_bound", False):
+                and obj.__module__ == namespace.get("__name__") and "_fgcn_bound" not in obj.__dict__:
+            # (the class's OWN attribute: a subclass of a bound Function that overrides forward / backward is bound again)
             context_bound(obj)
             obj._fgcn_bound = True
 
@@ -1288,6 +1291,9 @@ def row_softmax_bwd(da: torch.Tensor, c: torch.Tensor, V: int, scale: float) -> 
     return ds
 
 
+ROWS_GEMM_MAX_PROBLEMS = 65535      # grid.z of one fgcn_rows_gemm_batched / _batched2 launch
+
+
 def rows_gemm_batched(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch: int, rows: int, K: int, N: int,
                       ld_in: int, ld_out: int, in_bs: int, w_bs: int, out_bs: int, in_off: int = 0, w_off: int = 0,
                       out_off: int = 0, accumulate: bool = False, inner: int = 1, in_bs2: int = 0, w_bs2: int = 0,
@@ -1301,13 +1307,18 @@ def rows_gemm_batched(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, 
             or last(w_off, w_bs, w_bs2, K * N) > w.numel() or last(out_off, out_bs, out_bs2, (rows - 1) * ld_out + N) > out.numel()):
         raise _lib.FgcnError("rows_gemm_batched: a problem reaches outside its tensor")
     lib = _lib.load()
-    if inner == 1:
-        check(lib.fgcn_rows_gemm_batched(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, rows,
-                                         K, N, ld_in, ld_out, int(accumulate), _stream()), "fgcn_rows_gemm_batched")
-    else:
-        check(lib.fgcn_rows_gemm_batched2(_p(inp, in_off), _p(out, out_off), _p(w, w_off), batch, in_bs, out_bs, w_bs, inner, in_bs2,
-                                          out_bs2, w_bs2, rows, K, N, ld_in, ld_out, int(accumulate), _stream()),
-              "fgcn_rows_gemm_batched2")
+    # one launch carries batch * inner problems on grid.z (<= 65535): more outer problems go out in chunks
+    step = max(1, ROWS_GEMM_MAX_PROBLEMS // inner)
+    for b0 in range(0, batch, step):
+        nb = min(step, batch - b0)
+        i_off, o_off, k_off = in_off + b0 * in_bs, out_off + b0 * out_bs, w_off + b0 * w_bs
+        if inner == 1:
+            check(lib.fgcn_rows_gemm_batched(_p(inp, i_off), _p(out, o_off), _p(w, k_off), nb, in_bs, out_bs, w_bs, rows,
+                                             K, N, ld_in, ld_out, int(accumulate), _stream()), "fgcn_rows_gemm_batched")
+        else:
+            check(lib.fgcn_rows_gemm_batched2(_p(inp, i_off), _p(out, o_off), _p(w, k_off), nb, in_bs, out_bs, w_bs, inner, in_bs2,
+                                              out_bs2, w_bs2, rows, K, N, ld_in, ld_out, int(accumulate), _stream()),
+                  "fgcn_rows_gemm_batched2")
 
 
 # ---- MS-G3D data movement -------------------------------------------------------------------------------------------------------

@@ -29,6 +29,36 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Every skipped test with its reason, by test id, as a file: the driver's `-q` tail shows a count only.  Written to
+    $FGCN_SKIP_REPORT, or to gpurun_out/gpu_skips.txt when the run is on a GPU box (copied to profiles/rNN_gpu_skips.txt per round)."""
+    path = os.environ.get("FGCN_SKIP_REPORT")
+    if not path:
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return
+        except Exception:  # pragma: no cover
+            return
+        path = os.path.join(ROOT, "gpurun_out", "gpu_skips.txt")
+    skipped = terminalreporter.stats.get("skipped", [])
+    by_reason = {}
+    for rep in skipped:
+        reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) else str(rep.longrepr)
+        by_reason.setdefault(reason.replace("Skipped: ", ""), []).append(rep.nodeid)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            counts = {k: len(terminalreporter.stats.get(k, [])) for k in ("passed", "failed", "skipped", "error")}
+            f.write(f"# pytest {' '.join(config.invocation_params.args)}: {counts}\n")
+            for reason in sorted(by_reason, key=lambda r: -len(by_reason[r])):
+                f.write(f"\n## {len(by_reason[reason])} x {reason}\n")
+                for nid in by_reason[reason]:
+                    f.write(f"{nid}\n")
+    except OSError:  # pragma: no cover  (a read-only tree must not fail the run)
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

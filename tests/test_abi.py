@@ -144,3 +144,51 @@ def test_library_default_is_the_benchmarked_arithmetic(lib):
                         "_lib.load().fgcn_get_tuning(0), _lib.load().fgcn_get_tuning(1))"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split() == ["bf16x3", "0", "1", "0"], r.stdout
+
+
+def test_every_autograd_function_of_the_package_is_context_bound(lib):
+    """Every torch.autograd.Function the package defines runs its backward in its forward's library context (ops.context_bound);
+    a module that defines Functions and forgets ops.bind_all_functions(globals()) would silently run them in the autograd
+    thread's defaults.  A subclass of a bound Function is bound again (the marker is the class's OWN attribute)."""
+    import importlib
+    import pkgutil
+
+    import torch
+
+    import fusion_gcn_amd
+    from fusion_gcn_amd import ops
+    found = []
+    for info in pkgutil.walk_packages(fusion_gcn_amd.__path__, "fusion_gcn_amd."):
+        if info.name.endswith((".build", ".libfgcn")):        # (the build script; the C-ABI library is not a Python module)
+            continue
+        mod = importlib.import_module(info.name)
+        for obj in vars(mod).values():
+            if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function \
+                    and obj.__module__ == mod.__name__:
+                found.append(obj)
+                assert "_fgcn_bound" in obj.__dict__, f"{obj.__module__}.{obj.__name__} is not context-bound"
+    assert len(found) >= 10
+
+    class Base(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    ns = {"__name__": Base.__module__, "Base": Base}
+    ops.bind_all_functions(ns)
+
+    class Sub(Base):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 3
+    ns["Sub"] = Sub
+    assert "_fgcn_bound" not in Sub.__dict__
+    x = torch.ones(2, requires_grad=True)
+    Sub.apply(x).sum().backward()            # unbound subclass: the inherited backward finds no context and uses the defaults
+    assert x.grad.tolist() == [2.0, 2.0]
+    ops.bind_all_functions(ns)
+    assert "_fgcn_bound" in Sub.__dict__

@@ -377,6 +377,13 @@ def test_batched_row_gemms_one_and_two_levels(B, V, K, N):
         ops.rows_gemm_batched(ag, wg, one, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
                               out_bs=V * 3 * N, in_off=k * V * K, w_off=k * B * K * N, out_off=k * N)
     assert torch.equal(one, got)
+    # more problems than one launch's grid.z carries go out in chunks of the outer level (here: forced to 2 samples per launch)
+    limit = ops.ROWS_GEMM_MAX_PROBLEMS
+    ops.ROWS_GEMM_MAX_PROBLEMS = 6
+    try:
+        assert rel_l2(run().cpu().numpy(), got.cpu().numpy()) < 1e-6      # (the tile rule may pick other tiles for a smaller launch)
+    finally:
+        ops.ROWS_GEMM_MAX_PROBLEMS = limit
     ops.rows_gemm_batched(ag, wg, got, batch=B, rows=V, K=K, N=N, ld_in=K, ld_out=3 * N, in_bs=3 * V * K, w_bs=K * N,
                           out_bs=V * 3 * N, inner=3, in_bs2=V * K, w_bs2=B * K * N, out_bs2=N, accumulate=True)
     assert rel_l2(got.cpu().numpy(), 2 * want.numpy()) < FWD_TOL
