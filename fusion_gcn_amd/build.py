@@ -2,6 +2,7 @@
 
     python -m fusion_gcn_amd.build          # compile if sources are newer than the library
     python -m fusion_gcn_amd.build --force
+    python -m fusion_gcn_amd.build --host-asan   # the launchers' HOST code under AddressSanitizer + UBSan (CPU box; see build_host_asan)
 
 hipcc cross-compiles gfx950 code objects without a GPU.  Objects go to fusion_gcn_amd/_build/, the library to
 fusion_gcn_amd/libfgcn.so (git-ignored, shipped to the GPU box with the tree).
@@ -80,5 +81,58 @@ def build(force: bool = False, verbose: bool = False, out_dir: str = None) -> st
     return lib
 
 
+ASAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fsanitize=address,undefined",
+              "-fno-gpu-sanitize", "-Wno-unused-function", "-Wno-pass-failed"]
+
+
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime of ROCm's clang (to LD_PRELOAD into a Python that loads the instrumented library)."""
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[-1]
+
+
+def build_host_asan(verbose: bool = False) -> str:
+    """SURVEY.md section 5 (sanitizers), CPU side only: every csrc/*.hip compiled with -fsanitize=address,undefined on the HOST half
+    (-fno-gpu-sanitize: the gfx950 code objects are built as usual -- GPU sanitizers are not available on this pool) into
+    fusion_gcn_amd/_build/asan/libfgcn_asan.so.  What it instruments is everything a call executes before its first launch: argument
+    validation, tile geometry, FastDiv tables, workspace / slab sizes, descriptor packing, the per-thread contexts.  Load it with
+    FGCN_LIB=<path> and LD_PRELOAD=asan_runtime() (tests/test_abi.py::test_host_code_under_sanitizers does).  Incremental."""
+    obj_dir = os.path.join(OBJ, "asan")
+    lib = os.path.join(obj_dir, "libfgcn_asan.so")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    dep_m = max(os.path.getmtime(f) for f in _deps())
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), dep_m):
+            return obj, False
+        cmd = [hipcc, *ASAN_FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (host asan) failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        done = list(ex.map(compile_one, sources()))
+    if any(fresh for _, fresh in done) or not os.path.exists(lib):
+        tmp = lib + ".tmp"
+        r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fsanitize=address,undefined", "-shared-libsan",
+                            "-o", tmp, *[o for o, _ in done]], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (host asan) failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, lib)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--host-asan" in sys.argv:
+        print(build_host_asan(verbose=True))
+        print("LD_PRELOAD=" + asan_runtime())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -192,3 +192,63 @@ def test_every_autograd_function_of_the_package_is_context_bound(lib):
     assert x.grad.tolist() == [2.0, 2.0]
     ops.bind_all_functions(ns)
     assert "_fgcn_bound" in Sub.__dict__
+
+
+def test_host_geometry_queries_sweep(lib):
+    """Every host-only query of the header (tile / slab / segment counts, availability) over a sweep of shapes, ragged ones and the
+    limits included: non-negative, zero exactly where `*_available` says no, monotone in the sample count.  No launch is reached;
+    test_host_code_under_sanitizers runs this sweep against the AddressSanitizer + UBSan build of the launchers' host code."""
+    assert lib.fgcn_set_math_mode(2) == 0          # bf16x3: the mode the tile kernels exist in (availability is per mode, sizes are not)
+    try:
+        _geometry_sweep(lib)
+    finally:
+        assert lib.fgcn_set_math_mode(0) == 0
+
+
+def _geometry_sweep(lib):
+    for V in (15, 16, 18, 20, 22, 25, 27, 32, 33):
+        for cin, cout in ((4, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (96, 64), (192, 192), (320, 256)):
+            ic = cout // 4
+            ok_f = lib.fgcn_spatial_fwd_tile_available(V, cin, cout)
+            ok_b = lib.fgcn_spatial_bwd_tile_available(V, cin, cout)
+            ok_w = lib.fgcn_spatial_wgrad_tile_available(V, cin, cout)
+            ok_e = lib.fgcn_emb_tile_available(V, ic, cin)
+            ok_ef = lib.fgcn_emb_fwd_tile_available(V, ic, cin)
+            assert {ok_f, ok_b, ok_w, ok_e, ok_ef} <= {0, 1}
+            prev = None
+            for B, T in ((1, 1), (2, 13), (3, 75), (16, 150), (128, 300), (200, 301)):
+                slabs = lib.fgcn_spatial_wgrad_tile_slabs(B, T, V, cin, cout)
+                assert slabs >= 0 and (slabs > 0) == bool(ok_w), (B, T, V, cin, cout, slabs)
+                eslabs = lib.fgcn_emb_wgrad_tile_slabs(B, T, V, ic, cin)
+                assert eslabs >= 0 and (eslabs > 0) == bool(ok_e), (B, T, V, ic, cin, eslabs)
+                if 16 <= V <= 32:
+                    assert lib.fgcn_spatial_bwd_tile_segments(B, T, V) >= 1 and lib.fgcn_spatial_fwd_tile_tiles(B, T, V) >= B
+                    assert lib.fgcn_emb_fwd_tile_segments(B, T, V, ic) >= (1 if ok_ef else 0)
+                tiles = (lib.fgcn_tconv_halo_tiles(B, T, T, V), lib.fgcn_spatial_tiles(B, T), lib.fgcn_rows_gemm_tiles(B * T * V),
+                         lib.fgcn_pw_gemm_tiles(B * T * V), lib.fgcn_elem_tiles(B * T * V), lib.fgcn_data_bn_tiles(B, T))
+                assert all(t >= 1 for t in tiles), tiles
+                if prev is not None:
+                    assert all(a >= b for a, b in zip(tiles[:4], prev[:4])), (tiles, prev)      # more rows never need fewer tiles
+                prev = tiles
+    for n, nsplit in ((64, 1), (64, 8), (128, 4), (256, 16), (60, 3)):
+        assert lib.fgcn_tconv_wgrad_slabs(n, nsplit) >= 1 and lib.fgcn_pw_wgrad_slabs(n, nsplit) >= 1
+
+
+def test_host_code_under_sanitizers(lib):
+    """the launchers' HOST code (argument validation, tile geometry, FastDiv tables, slab / segment counts, the
+    per-thread contexts) built with -fsanitize=address,undefined (fusion_gcn_amd.build.build_host_asan; the gfx950 code objects are the
+    usual ones -- GPU sanitizers do not exist on this pool) and driven by the host-only tests of this file and tests/test_fastdiv.py in
+    a child interpreter that preloads the sanitizer runtime.  Clean = exit code 0 and no sanitizer report in the output."""
+    import subprocess
+    import sys
+    asan_lib = build.build_host_asan()
+    env = dict(os.environ, FGCN_LIB=asan_lib, LD_PRELOAD=build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    keep = ("test_version_and_error_text or test_host_side_validation or test_tile_kernel_geometry_and_tuning_keys or "
+            "test_host_geometry_queries_sweep or test_header_symbols_are_exported_and_bound or test_quotients or test_multiplier")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_abi.py"), os.path.join(ROOT, "tests", "test_fastdiv.py"),
+                        "-q", "-x", "-p", "no:cacheprovider", "-k", keep], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    text = r.stdout + r.stderr
+    assert r.returncode == 0, text[-4000:]
+    assert "AddressSanitizer" not in text and "runtime error:" not in text, text[-4000:]
+    assert "7 passed" in text or "passed" in text
