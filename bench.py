@@ -421,9 +421,6 @@ def main():
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1 only: skip the secondary (strong-scaling) measurement reported as other_scaling")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--wgrad-stream", choices=("auto", "side", "main", "side-high", "side-low"), default="main",
-                    help="weight-gradient kernels in line (main, the library default since the end of round 3), on a second HIP stream "
-                         "beside the HBM-bound chain (side), or by the size of the block's tensors (auto: side from ~24 clips per GPU upwards)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--allow-eager", action="store_true",
                     help="if the HIP-graph capture of the step fails, time the eagerly launched step instead of exiting non-zero")
@@ -438,10 +435,10 @@ def main():
                     help="also run the fused parameter update (fusion_gcn_amd.optim.FlatOptimizer: ADAM weight_decay 0.01 as "
                          "config/utd-mhad/skeleton/agcn.yaml, or SGD momentum 0.9 nesterov) inside every timed step; the "
                          "headline metric is fwd+bwd, so the default leaves it out")
-    ap.add_argument("--agg-wgrad-max-cout", type=int, default=None,
-                    help="A/B only: widest block whose conv_d weight gradient uses the fused aggregation kernel (block.FUSED_AGG_WGRAD_MAX_COUT)")
-    ap.add_argument("--no-bn-sums-in-dgrad", action="store_true",
-                    help="A/B only: BatchNorm-backward sums by the stand-alone reduction kernel instead of the data-gradient epilogue")
+    ap.add_argument("--paths", default="",
+                    help="A/B only: kernel-form options of this run's library context, 'name=value,name=value' (fusion_gcn_amd/paths.py: "
+                         "emb_tile=0, spatial_tile_min_cout=64, bn_sums_in_dgrad=0, fuse_g=1, ...); the same string as the FGCN_PATHS "
+                         "environment variable, which sets the process defaults")
     ap.add_argument("--keep-packed", action="store_true",
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
@@ -494,12 +491,9 @@ def main():
         kern = time_dominant_kernel(device, args.batch * SHAPE["M"], reps=20, widths=(256,))
         print(json.dumps({"kernel": MATH_KERNEL[args.math].format(nt=4, nt2=2) + " forward, 256 channels", **kern[0]}), flush=True)
         return
-    from fusion_gcn_amd import block as _block
-    if args.agg_wgrad_max_cout is not None:
-        _block.FUSED_AGG_WGRAD_MAX_COUT[args.math] = args.agg_wgrad_max_cout
-    _block.BN_SUMS_IN_DGRAD = not args.no_bn_sums_in_dgrad
-    _block.WGRAD_SIDE_STREAM = "auto" if args.wgrad_stream == "auto" else args.wgrad_stream != "main"
-    _block.WGRAD_STREAM_PRIORITY = {"side-high": -1, "side-low": 1}.get(args.wgrad_stream, 0)
+    if args.paths:
+        _ops.paths().update_from(args.paths)      # this thread's current context (the process defaults here): per context, not a module global
+        log(f"path options: {args.paths}")
     from fusion_gcn_amd.dp import FlatGradients, broadcast_parameters, shard_batch
     from fusion_gcn_amd.loss import cross_entropy      # nn.CrossEntropyLoss() of the reference's session, on libfgcn
     model = build_model(device)

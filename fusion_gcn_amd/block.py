@@ -27,8 +27,6 @@ Kernel schedule of one block, train mode (B = N*M samples):
 """
 from __future__ import annotations
 
-import contextlib
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -185,25 +183,16 @@ def pack_weights(P: Dict[str, torch.Tensor], cfg: BlockConfig) -> PackedWeights:
     return PackedWeights(F, P["tcn1.conv.weight"].device)
 
 
-# 1x1 convolutions with a split form go to the persistent split-bf16 row GEMM (ops.pw_gemm, fgcn_pw.hip) from this contraction depth
-# on; below it (and in math mode f32) the exact-f32 row GEMM runs.  Measured on MI355X (tools/kbench.py pw, B = 128,
-# profiles/r03_kbench_pw.log): at K = 64 / 96 the f32 row GEMM is 8-18 % faster (both latency-bound at 3.3-4.0 TB/s), from K = 128 on
-# pw_gemm wins by 2-29 % over it and by 3-22 % over the one-tap halo kernel round 2 used from K = 192; same-box step A/B
-# (profiles/r03_ab_pw_gemm.txt): threshold 128 -> 62.53 / 62.58 ms against 62.82 / 63.10 with round 2's routing, 63.32 with 64
-# Round 3, after the epilogue fix of pw_gemm (-4..-26 %, profiles/r03_ab_epilogues.txt): in bf16x3 K = 64 / 96 is now even (-6..+9 %
-# over the four shapes: threshold stays 128); with the f16x2 products pw_gemm wins there too (-5..-19 %): threshold 64.
-# End of round 3 (four-slot weight ring, streamed stores; profiles/r03_ab_pw_min_k_small.txt): at 64 clips K = 64 is still even in bf16x3
-# (58.0-58.4 vs 58.3-58.5 ms), but on the 8-clip shard pw_gemm wins there (9.65-9.67 -> 9.61-9.62 ms: the f32 row GEMM's one tile per
-# workgroup quantises worse on few rows): below PW_X3_SMALL_ROWS rows the threshold is 64 in bf16x3 too.
-PW_X3_MIN_K = int(os.environ.get("FGCN_PW_MIN_K", "128"))
-PW_X3_MIN_K_F16X2 = int(os.environ.get("FGCN_PW_MIN_K_F16X2", os.environ.get("FGCN_PW_MIN_K", "64")))
-PW_X3_SMALL_ROWS = int(os.environ.get("FGCN_PW_SMALL_ROWS", "300000"))
-
-
+# Which kernel form a stage takes (tile forms, fusions, thresholds) is a per-context option: fusion_gcn_amd/paths.py carries the fields,
+# their defaults and the measurement behind each; `ops.paths()` is the calling thread's current set (the backward of a block runs in
+# its forward's context, so both halves see the same options).
 def _pw_min_k(rows: int) -> int:
+    """contraction depth from which a 1x1 convolution with a split form goes to the persistent split-bf16 row GEMM (ops.pw_gemm,
+    fgcn_pw.hip); below it (and in math mode f32) the exact-f32 row GEMM runs (paths.PathOptions.pw_min_k)"""
+    o = ops.paths()
     if ops.get_math_mode() == "f16x2":
-        return PW_X3_MIN_K_F16X2
-    return min(PW_X3_MIN_K, 64) if rows < PW_X3_SMALL_ROWS else PW_X3_MIN_K
+        return o.pw_min_k_f16x2
+    return min(o.pw_min_k, 64) if rows < o.pw_small_rows else o.pw_min_k
 
 
 def pw_routed(W, key: str, x: torch.Tensor, K: int) -> bool:
@@ -218,9 +207,6 @@ def pw_gemm(x: torch.Tensor, W: Dict[str, torch.Tensor], key: str, out: torch.Te
     w3 = W.get(key + "_s3")
     if w3 is not None and K % 32 == 0 and x.shape[3] == K and K >= _pw_min_k(x.numel() // x.shape[3]):
         return ops.pw_gemm(x, w3, out, bias=bias, stats=stats, accumulate=accumulate, amax_out=amax_out)
-    if PW_X3_MIN_K > 4096 and w3 is not None and K % 64 == 0 and x.shape[3] == K and (K >= 192 or (K >= 128 and N >= 384)):
-        # (A/B control, FGCN_PW_MIN_K=100000: round 2's routing -- the one-tap halo kernel from K = 192 on, the f32 row GEMM below)
-        return ops.tconv_halo(x, w3, out, Th=x.shape[1], taps=1, tb=1, tc=0, bias=bias, stats=stats, accumulate=accumulate)
     return ops.rows_gemm(x, W[key], out, K=K, N=N, bias=bias, stats=stats, accumulate=accumulate)
 
 
@@ -241,76 +227,11 @@ def spec_dx(cin: int) -> List[dict]:
             for c0 in range(0, cin, 32)]
 
 
-# Identity blocks: BatchNorm + shortcut + ReLU of the graph convolution applied INSIDE the temporal conv while it stages its image
-# (ops.tconv_halo(fuse_in=...): the north star's "temporal 9x1 conv + BN + ReLU" kernel, consumer side; G and its sign image come
-# out as by-products and the bn_act pass disappears).  Built, bit-identical to the two-pass form (tests/test_kernels_gpu.py) and
-# MEASURED SLOWER on MI355X: same-box A/B of the step (two pairs) 63.10 / 63.16 -> 64.68 / 64.96 ms at 64 clips, 10.44 / 10.46 ->
-# 10.68 / 10.74 ms at 8 -- the conv's staging phase (two tensors per row, in two halves to fit the registers: 16-52 spilled
-# VGPRs at 64 / 128 output columns otherwise) stops hiding under the other workgroup's MFMAs, which costs 0.35 ms per launch
-# where the bn_act pass took 0.126.  Off by default; FGCN_FUSE_G=1 selects it (profiles/r03_ab_fused_input_stage.txt).
-FUSE_BN_INTO_TCONV = bool(os.environ.get("FGCN_FUSE_G"))
-# the fused spatial forward in its tile form (fgcn_spatial_tile.hip; bf16x3 products, Cin % 64 == 0, 16 <= V <= 32); FGCN_SPATIAL_TILE=0:
-# the two-frames-per-wave form everywhere (A/B control)
-SPATIAL_TILE = os.environ.get("FGCN_SPATIAL_TILE", "1") != "0"
-# ... from this many output channels on (tools/kbench.py spatial, B = 128, profiles/r03_kbench_spatial_tile.log: 64 -> 64 0.345 vs 0.387 ms for
-# the tile form, 64 -> 128 0.562 vs 0.500, 128 -> 128 0.475 vs 0.433, 128 -> 256 0.927 vs 0.841, 256 -> 256 0.895 vs 0.797)
-SPATIAL_TILE_MIN_COUT = int(os.environ.get("FGCN_SPATIAL_TILE_MIN_COUT", "128"))
-# the backward of the spatial stage in ONE launch (fgcn_spatial_bwd_tile.hip): dagg = dy . Wd never leaves the chip -- replaces
-# pw_gemm(dy . Wd) + joint_dagg and their three-activation-wide round trip through HBM; FGCN_SPATIAL_BWD_TILE=0: the unfused pair
-SPATIAL_BWD_TILE = os.environ.get("FGCN_SPATIAL_BWD_TILE", "1") != "0"
-SPATIAL_BWD_TILE_MIN_CIN = int(os.environ.get("FGCN_SPATIAL_BWD_TILE_MIN_CIN", "64"))
-# ... also with the f16x2 products (the kernel itself always multiplies three-way bf16 splits: at least as accurate); FGCN_SPATIAL_BWD_TILE_F16X2=0:
-# there, dagg = dy . Wd by pw_gemm on two-way f16 splits + joint_dagg
-SPATIAL_BWD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_BWD_TILE_F16X2", "1") != "0"
-FUSED_DAGG = True        # dx mix + dA^ gram in one kernel (one read of dagg instead of two)
-BN_SUMS_IN_DGRAD = True  # BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue (see block_backward)
-# ... up to this many channels (FGCN_BN_SUMS_MAX_C; see the measurement at its use in block_backward)
-BN_SUMS_MAX_C = int(os.environ.get("FGCN_BN_SUMS_MAX_C", "4096"))
-# identity-shortcut gradients added to dx by joint_dagg from the sign images instead of by the BatchNorm-backward kernels (see
-# block_backward).  Measured neutral on MI355X (tools/probes/gated_dagg_probe.py, B = 128: the two apply kernels save 0.16 ms per
-# block, the two extra tensor reads cost joint_dagg 0.15 ms; slower at 8 clips), so off; the kernel form stays tested.
-GATED_SHORTCUTS = False
-# ... the same in the fused spatial backward (fgcn_spatial_bwd_tile: the gated addends are requested ahead of the image barrier and are the
-# mix accumulators' start, so the two BatchNorm-backward apply kernels neither write nor read-modify-write dx and the fused kernel has no
-# old values to fetch): same-box step A/B 55.31 / 55.37 -> 55.20 / 55.20 ms at 64 clips, 9.45 / 9.44 -> 9.46 / 9.43 at 8
-# (profiles/r04_ab_gated_tile.txt); on.  FGCN_GATED_TILE=0: the BatchNorm-backward kernels carry the shortcut gradients.
-GATED_SHORTCUTS_TILE = bool(int(os.environ.get("FGCN_GATED_TILE", "1")))
-# conv_d's weight gradient in tile form (fgcn_spatial_wgrad_tile: a workgroup owns a 64/128 x 64/128 tile of all three subsets and walks
-# whole frame tiles; the aggregation is formed per frame on the matrix pipe and its accumulators are the contraction's operand) for every
-# channel count in 64s -- replaces fgcn_spatial_wgrad up to 128 outputs and joint_mix_vec(agg) + the row weight-gradient GEMM beyond.
-# FGCN_SPATIAL_WGRAD_TILE=0: the older forms.  Also with the f16x2 products (the kernel always multiplies three-way bf16 splits).
-SPATIAL_WGRAD_TILE = os.environ.get("FGCN_SPATIAL_WGRAD_TILE", "1") != "0"
-# the backward of the attention embeddings (agcn.py:104-106) in tile form (fgcn_emb_tile.hip): the embedding gradient demb is formed per
-# frame on the matrix pipe inside the two kernels that consume it (dx += demb . Wemb; dWemb = demb^T . x, dbemb) and never exists in HBM --
-# replaces joint_mix_vec(demb) + the 1x1 data-gradient GEMM + the 1x1 weight-gradient GEMM.  FGCN_EMB_TILE=0: that chain.
-EMB_TILE = os.environ.get("FGCN_EMB_TILE", "1") != "0"
-# the forward of the attention embeddings with the affinity gram on chip (fgcn_emb_fwd_tile.hip: emb = x . Wemb + b written once, theta_k^T phi_k
-# formed from the tile while it is in LDS -- replaces the 1x1 product + joint_gram and the gram's read of emb).  FGCN_EMB_FWD_TILE=0: that pair.
-EMB_FWD_TILE = os.environ.get("FGCN_EMB_FWD_TILE", "1") != "0"
-# ... up to this many input channels: same-call A/B of the replayed step, 40 timed steps (profiles/r05_ab_emb_fwd_tile.txt): off 54.98 / 54.93 ms, up
-# to 64 channels 54.81 / 54.72, up to 128: 54.73 / 54.87, every block 54.83 / 54.86; 8 clips 9.08 / 9.06 / 9.03 / 9.03.  At 64-channel groups (the
-# 256-output blocks) three workgroups per row range each stage the x tile: 0.46-0.59 ms against 0.33-0.44 for the unfused pair.
-EMB_FWD_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_FWD_TILE_MAX_CIN", "128"))
-# ... up to this many input channels.  Same-call A/B of the replayed 64-clip step (profiles/r05_ab_emb_tile.txt): every block 53.79 / 53.90 ms,
-# up to 128 channels 53.63 / 53.56, up to 64 channels 53.79 / 53.75, none (FGCN_EMB_TILE=0) 54.09 / 54.22 -- at 256 channels (l8, l9) both
-# kernels are bound by the matrix pipe (47 GFLOP each at 110-125 TFLOP/s of mixing-padded work) and the unfused chain's plain GEMMs win.
-EMB_TILE_MAX_CIN = int(os.environ.get("FGCN_EMB_TILE_MAX_CIN", "128"))
-SPATIAL_WGRAD_TILE_F16X2 = os.environ.get("FGCN_SPATIAL_WGRAD_TILE_F16X2", "1") != "0"
-FUSED_AGG_WGRAD = True   # conv_d weight gradient with the aggregation recomputed on chip (agg never written) ...
-# ... up to this many output channels (measured, tools/kbench.py spatial_wgrad: the aggregation is recomputed per 64-column
-# tile; f32 0.42 vs 0.53 ms at 64 -> 64, even at 128, slower at 256; bf16 0.21 vs 0.46 and 0.36 vs 0.46 at 128 -> 128)
-# Round 4, in-step (same-box A/B of the 64-clip step, bench.py --agg-wgrad-max-cout, profiles/r04_ab_agg_wgrad_max_cout.txt): bf16x3 64 -> 55.75 /
-# 55.80 ms, 128 -> 55.51 / 55.58, 256 -> 56.22 / 56.27 -- inside the step the three-activation-wide agg of the unfused pair is written and read
-# through HBM, which the loop of identical launches of tools/kbench.py (agg resident in the Infinity Cache) does not charge: 128 now.
-FUSED_AGG_WGRAD_MAX_COUT = {"f32": 64, "bf16": 128, "bf16x3": 128, "f16x2": 64}
-MIX_VW_ORDER = (2, 1)   # preference order of channels per lane for the channel-group mix kernel
-
-
 def _vec_width(c: int, order: Sequence[int] = None) -> int:
     """Channels per lane (1/2) for a group-of-``c``-channels mix: groups of 32*vw channels must tile ``c`` exactly
     (first such vw in preference order), or ``c`` is a single narrower group (smallest such vw: most lanes busy).
     0: no such tiling, use the dword kernel with 16-lane masks."""
-    order = order or MIX_VW_ORDER
+    order = order or ops.paths().mix_vw_order
     for vw in order:
         if c % (32 * vw) == 0:
             return vw
@@ -443,15 +364,6 @@ def _bn_vec(part, count, P, bufs, name, train):
     return ops.bn_eval_coeffs(g, b, rm, rv)
 
 
-# The model's last block with the global average pooling behind it (agcn.py:196-197): its epilogue pass sums the output per clip instead
-# of writing it (ops.bn_act_pool; the backward gates on the sign image alone) -- one activation write and one read less per step.
-# FGCN_POOL_EPILOGUE=0: bn_act + group_mean (A/B control).
-POOL_EPILOGUE = os.environ.get("FGCN_POOL_EPILOGUE", "1") != "0"
-# ... and its backward reads the pooled gradient as one row per clip (fgcn_bn_act_bwd_*_g, fgcn_spatial_bwd_tile_g) instead of expanding it to the
-# output's shape: one activation write and three reads less.  FGCN_POOL_BACKWARD_ROWS=0: expand (A/B control).
-POOL_BACKWARD_ROWS = os.environ.get("FGCN_POOL_BACKWARD_ROWS", "1") != "0"
-
-
 def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
                   cfg: BlockConfig, train: bool, pool_groups: int = 0):
     """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict).  ``pool_groups`` > 0 (the model's last block): O is
@@ -462,6 +374,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     cin = cx                     # kernels work on the padded channel count; the pad channel is identically zero
     Tp = (T - 1) // s + 1
     dev = x.device
+    o_ = ops.paths()             # this context's kernel-form options (fusion_gcn_amd/paths.py)
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     S: Dict[str, Optional[torch.Tensor]] = {"x": x}
     # math mode f16x2: the largest magnitudes of x and G, recorded by the kernels that stage them (pw_gemm / tconv_halo), scale the
@@ -476,7 +389,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         emb, c_mat = None, None
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
-        if (EMB_FWD_TILE and cin <= EMB_FWD_TILE_MAX_CIN and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
+        if (o_.emb_fwd_tile and cin <= o_.emb_fwd_tile_max_cin and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
             emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic)             # emb written once, the gram from the tile on chip
         else:
@@ -488,7 +401,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
-    if cfg.fused_spatial and SPATIAL_TILE and cout >= SPATIAL_TILE_MIN_COUT and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
+    if cfg.fused_spatial and o_.spatial_tile and cout >= o_.spatial_tile_min_cout and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
         y, part = ops.spatial_fwd_tile(x, a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     elif cfg.fused_spatial:
         y, part = ops.spatial_fwd(x, a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
@@ -508,7 +421,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     # identity blocks on the split-bf16 kernels: G = relu(BatchNorm(y) + x) is formed INSIDE the temporal conv while it stages its
     # image (north-star kernel 2: "temporal 9x1 conv + BN + ReLU"), G and its sign image come out as by-products -- no bn_act pass
     kt = P["tcn1.conv.weight"].shape[2]
-    fuse_g = (FUSE_BN_INTO_TCONV and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
+    fuse_g = (o_.fuse_g and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
               and cx == cout and V <= 32 and (B * T * V * cout) % 8 == 0)
     if fuse_g:
         g = new(B, T, V, cout)
@@ -542,56 +455,10 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
 def pool_epilogue_ok(cfg: BlockConfig, B: int, T: int, V: int, groups: int) -> bool:
     """the last block's epilogue can carry the pooling: equal groups of whole samples, a sign image exists (element count and cout in 8s)"""
     Tp = (T - 1) // cfg.stride + 1
-    return POOL_EPILOGUE and groups > 0 and B % groups == 0 and cfg.cout % 8 == 0 and (B * Tp * V * cfg.cout) % 8 == 0
+    return ops.paths().pool_epilogue and groups > 0 and B % groups == 0 and cfg.cout % 8 == 0 and (B * Tp * V * cfg.cout) % 8 == 0
 
 
 # ---- backward --------------------------------------------------------------------------------------------------------
-# Weight gradients are leaves of the backward graph: nothing downstream in the block reads them.  They are MFMA-bound
-# while the chain that continues on the main stream (BatchNorm backward, the joint kernels, the narrow 1x1 data
-# gradients) is HBM-bound, so they can be launched on a second HIP stream and share the CUs with that chain (fork after
-# the producer of their inputs, one join at the end of the block's backward; a HIP-graph capture records the same fork/join
-# as parallel branches).  What that buys depends on the size of the block's tensors (same-box A/B of the whole step, bf16x3,
-# side vs in line): 64 clips 64.5 vs 65.1 ms, 32 clips 33.6 vs 33.7, 16 clips 18.2 vs 18.0, 8 clips 10.69 vs 10.34 -- below
-# ~24 clips the ~65 cross-stream edges per step (6-16 us of idle GPU each in the replayed graph) cost more than the overlap
-# returns.  WGRAD_SIDE_STREAM: "auto" (side stream from WGRAD_SIDE_MIN_WORK output elements per block upwards -- B*T'*V*cout is
-# the same for all ten blocks of the model: 480,000 per sample), True, False.  WGRAD_STREAM_PRIORITY: 0 normal, -1 high (torch
-# convention; high priority measured 1.5x SLOWER at 8 clips).
-# Final state of round 3 (same-box A/B, profiles/r03_ab_wgrad_stream.txt): with the XCD-aware weight-gradient order and the shorter
-# epilogues the side stream no longer pays -- 64 clips 59.33 / 59.39 ms in line vs 59.37 / 59.51 (auto = side) / 59.61 / 59.43 (side), 32 clips
-# 31.14 / 31.15 vs 31.28 / 31.31 -- so the default is in line (one stream, no cross-stream edges in the recorded graph); "auto" keeps the old rule.
-WGRAD_SIDE_STREAM = False
-WGRAD_SIDE_MIN_WORK = 48 * 480_000
-WGRAD_STREAM_PRIORITY = 0
-_side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
-
-
-class _WgradBranch:
-    def __init__(self, device: torch.device, enabled: bool):
-        self.enabled = enabled and device.type == "cuda"
-        self.forked = False
-        if self.enabled:
-            key = (device.index, WGRAD_STREAM_PRIORITY)
-            if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream(device=device, priority=WGRAD_STREAM_PRIORITY)
-            self.main, self.side = torch.cuda.current_stream(device), _side_streams[key]
-
-    @contextlib.contextmanager
-    def __call__(self):
-        """Kernels launched (and tensors allocated) inside run on the side stream, after everything the main stream
-        holds so far.  Inputs must stay referenced until join(); outputs are only read on the main stream after it."""
-        if not self.enabled:
-            yield
-            return
-        self.side.wait_stream(self.main)
-        self.forked = True
-        with torch.cuda.stream(self.side):
-            yield
-
-    def join(self) -> None:
-        if self.enabled and self.forked:
-            self.main.wait_stream(self.side)
-
-
 class _BiasGrads:
     """Gradients of conv biases that feed a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
     block output does not depend on such a bias and its gradient is exactly zero (the reference's autograd produces
@@ -617,19 +484,17 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
                    pool: Optional[Tuple[int, tuple]] = None):
     """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape}).
     The leaf reductions of the block (weight-gradient slabs, adj_b, embedding-bias partials) are collected and issued as one
-    launch at the end, on the weight-gradient stream, before it joins the main stream (ops.deferred_reductions)."""
+    launch at the end (ops.deferred_reductions).  Weight gradients are leaves of the backward graph and run in line, on the one stream:
+    launching them on a second HIP stream beside the HBM-bound chain was built in round 2, lost its A/B in rounds 3 and 4 (the matrix
+    kernels fill every CU's registers and LDS, so nothing of the other stream is co-resident: DESIGN.md section 3.2 item 11) and was
+    removed in round 6."""
     with ops.deferred_reductions() as batch:
-        work = d_o.numel() if pool is None else pool[1][0] * pool[1][1] * pool[1][2] * pool[1][3]
-        side = work >= WGRAD_SIDE_MIN_WORK if WGRAD_SIDE_STREAM == "auto" else bool(WGRAD_SIDE_STREAM)
-        wgrad = _WgradBranch(d_o.device, side)
-        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, wgrad, pool)
-        with wgrad():                 # after everything both streams hold so far
-            batch.flush()
-        wgrad.join()
+        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, pool)
+        batch.flush()
     return out
 
 
-def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, wgrad: "_WgradBranch", pool=None):
+def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, pool=None):
     """``pool`` = (groups, shape of the block's output): the block's forward returned the per-group mean of its output (pool_groups) and
     ``d_o`` is the gradient of that, (groups, cout); it is consumed as a per-group row (divided by the group's rows) where the kernels
     take one (POOL_BACKWARD_ROWS) and expanded to the output's shape otherwise."""
@@ -639,6 +504,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     cin, cin_true = cx, cfg.cin  # kernels work on the padded channel count; gradients are cut back to cin_true
     Tp = d_o.shape[1] if pool is None else pool[1][1]
     dev = x.device
+    o_ = ops.paths()             # this context's kernel-form options (the forward's context: ops.context_bound)
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     G: Dict[str, torch.Tensor] = {}
     d_o = d_o.contiguous()
@@ -651,9 +517,9 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
     small = lambda width: B * max(T, Tp) * V * width * 4 < 0x7FFF0000      # noqa: E731  the tile kernels address with 32-bit byte offsets
-    tile_ok = (SPATIAL_BWD_TILE and cin >= SPATIAL_BWD_TILE_MIN_CIN and "d_t_b3" in W and ops.spatial_bwd_tile_available(V, cin, cout)
-               and (ops.get_math_mode() in ("bf16x3", "bf16") or SPATIAL_BWD_TILE_F16X2) and small(max(cin, cout)))
-    gate_in_dagg = ((GATED_SHORTCUTS_TILE if tile_ok else GATED_SHORTCUTS) and FUSED_DAGG and not cfg.has_down and cfg.residual == "identity"
+    tile_ok = (o_.spatial_bwd_tile and cin >= o_.spatial_bwd_tile_min_cin and "d_t_b3" in W and ops.spatial_bwd_tile_available(V, cin, cout)
+               and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_bwd_tile_f16x2) and small(max(cin, cout)))
+    gate_in_dagg = ((o_.gated_shortcuts_tile if tile_ok else o_.gated_shortcuts) and o_.fused_dagg and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and o_numel * 4 < 0x7FFF0000)
     gated: List[tuple] = []
@@ -662,7 +528,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         groups = pool[0]
         rows = o_numel // cout // groups
         d_o = d_o / rows                             # (groups, cout): every row of a group receives the group's gradient / rows
-        if POOL_BACKWARD_ROWS and (not gate_in_dagg or (tile_ok and x.shape[3] == cin)):
+        if o_.pool_backward_rows and (not gate_in_dagg or (tile_ok and x.shape[3] == cin)):
             grp_rows, grp_samples = rows, B // groups        # the BatchNorm-backward passes and the gated addend read the group's row
         else:
             d_o = d_o.unsqueeze(1).expand(groups, rows, cout).contiguous().view(B, Tp, V, cout)
@@ -686,9 +552,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
-        with wgrad():
-            G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
-                                                       conv_param=(1, cin_true))
+        G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
+                                                   conv_param=(1, cin_true))
         G["residual.conv.bias"] = bias_grad(dr, cout)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
@@ -696,7 +561,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     dg = new(B, T, V, cout)
     # identity blocks in the split-bf16 modes: the data-gradient kernel sums dg * [g > 0] and dg * [g > 0] * y_hat in its epilogue,
     # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
-    fuse_sums = (BN_SUMS_IN_DGRAD and cout <= BN_SUMS_MAX_C and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
+    fuse_sums = (o_.bn_sums_in_dgrad and cout <= o_.bn_sums_max_c and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
                  and "t_t4" in W and ops.tconv_halo_bn_sums())
     # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
     # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
@@ -708,9 +573,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     g_partials = temporal_dgrad(du, dg, W, kt, s, bn_bwd=(S["y"], S["g_sign"], S["vec_y"]) if fuse_sums else None,
                                 amax_out=bamax[0:1] if du_amax else None)
     # weight gradients are reduced straight into the parameter's (out, in, kt, 1) layout: autograd takes them as they are
-    with wgrad():
-        G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout),
-                                                amax=(S["amax"][1:2], bamax[0:1]) if du_amax and S.get("g_amax") else None)
+    G["tcn1.conv.weight"] = ops.tconv_wgrad(S["g"], du, taps=kt, stride=s, conv_param=(1, cout),
+                                            amax=(S["amax"][1:2], bamax[0:1]) if du_amax and S.get("g_amax") else None)
     G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
@@ -720,8 +584,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         pw_gemm(dd, W, "down_t", dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
-        with wgrad():
-            G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
+        G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
         G["gcn1.down.0.bias"] = bias_grad(dd, cout)
     elif gate_in_dagg:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
@@ -744,19 +607,18 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         dy_amax = f16x2 and pw_routed(W, "d_t", dy, cout)
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
-    with wgrad():
-        if (SPATIAL_WGRAD_TILE and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
-                and (ops.get_math_mode() in ("bf16x3", "bf16") or SPATIAL_WGRAD_TILE_F16X2)):
-            gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
-        elif FUSED_AGG_WGRAD and x.shape[3] == cin and cin >= 32 and cout <= FUSED_AGG_WGRAD_MAX_COUT[ops.get_math_mode()]:
-            # agg = x . A^ is formed in registers and contracted with dy at once: never written
-            gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
-        else:
-            agg = new(B, T, V, c3)
-            agg_amax = mix_agg(x, agg, a_hat, cin, amax_out=bamax[2:3] if dy_amax else None)
-            gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true),   # (3, cout, cin_true, 1, 1)
-                                amax=(bamax[2:3], bamax[3:4]) if agg_amax else None)
-            del agg
+    if (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
+            and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2)):
+        gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
+    elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.fused_agg_wgrad_max_cout[ops.get_math_mode()]:
+        # agg = x . A^ is formed in registers and contracted with dy at once: never written
+        gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
+    else:
+        agg = new(B, T, V, c3)
+        agg_amax = mix_agg(x, agg, a_hat, cin, amax_out=bamax[2:3] if dy_amax else None)
+        gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true),   # (3, cout, cin_true, 1, 1)
+                            amax=(bamax[2:3], bamax[3:4]) if agg_amax else None)
+        del agg
     dbias = None if train else ops.col_sum(dy, cout)
     for k in range(NUM_SUBSETS):
         G[f"gcn1.conv_d.{k}.weight"] = gw[k]
@@ -764,7 +626,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
     if bwd_tile:
         part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_b3"], dx, accumulate=dx_live, gated=gated)   # dagg on chip: dx and dA^ in one launch
-    elif FUSED_DAGG and x.shape[3] == cin:
+    elif o_.fused_dagg and x.shape[3] == cin:
         part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:
         mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
@@ -778,21 +640,19 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        if (EMB_TILE and cin <= EMB_TILE_MAX_CIN and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
+        if (o_.emb_tile and cin <= o_.emb_tile_max_cin and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
                 and small(max(6 * ic, cx))):
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
-            with wgrad():
-                gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
+            gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
             gw = gw.view(6 * ic, cin_true, 1, 1)
         else:
             demb = new(B, T, V, 6 * ic)
             gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
             demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)
             pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live, amax_out=bamax[1:2] if demb_amax else None)
-            with wgrad():
-                gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
-                                    amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
+            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
+                                amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):
                 lo = (2 * k + j) * ic

@@ -62,7 +62,6 @@ struct SpBwdP {
     int e0_grp;
     unsigned e0_bytes;
     int mix_wave[16];                   // mix unit u = 2 f + (16-channel tile of the 32-channel half) -> wave (eight-wave form)
-    int mix_wave4[16];                  // ... four-wave form
 };
 
 constexpr int SB_ROWS = 144;            // 128 tile rows + the rows a 32-joint fragment of the last frame reaches past them (V = 16: 143)
@@ -430,284 +429,8 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     }
 }
 
-// ---- the same computation as TWO four-wave workgroups per CU ---------------------------------------------------------------------
-// The eight-wave form above runs its waves in lockstep: the FGCN_PROBE_SB timing probes add its phases up (256 -> 256: 0.30 ms of MFMAs
-// + 0.43 ms of everything else = the 0.73 ms launch) -- nothing but the requests made a phase ahead overlaps.  Two independent workgroups
-// per CU overlap by themselves (one stages / splits / stores while the other multiplies: the halo conv's and pw_gemm's arrangement), which
-// needs <= 80 KB of LDS per workgroup: the group is ONE 32-channel half (96 dagg columns: 3 x 4 accumulator tiles per wave, 2 x 2 waves) and
-// the image holds ONE subset at a time -- three rounds per group, the mix accumulators (and the group's contraction accumulators) live
-// across them.  Gram units (frame f, v tile): wave (f % 2) * 2 + vt; mix units (frame, 16-channel tile): the host's table.
-// MEASURED (MI355X, B = 128, tools/kbench.py spatial_bwd, same call): 0.519 / 0.614 / 0.595 / 0.882 / 0.850 ms at 64->64 / 64->128 /
-// 128->128 / 128->256 / 256->256 against 0.473 / 0.535 / 0.508 / 0.744 / 0.694 for the eight-wave form with its requests made two steps
-// ahead: the dY tile is staged per 32 instead of per 64 input channels, x is split once per subset round, and a group has 2 nks + 6
-// barriers.  Kept selectable (tuning key 11 = 2) and parity-tested; not the default.
-constexpr int SB4_IM = 3 * 128 * SB_XS;             // staging planes [3][128 rows] first, then the image [3 parts][SB_ROWS]
-constexpr int SB4_AH = SB4_IM + 3 * SB_PL;
-constexpr int SB4_LDS = SB4_AH + 9 * 32 * SB_AHB;   // 75264 bytes
-
-template <bool ACC, int MX>                          // MX: gram units and mix units per wave (3: up to six frames per tile, 4: seven / eight)
-__global__ __launch_bounds__(256, 2) void spatial_bwd_tile4_x3_kernel(SpBwdP p) {
-    constexpr int NP = 3, SPL = 128 * SB_XS;
-    constexpr unsigned OOB = 0x80000000u;
-    auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
-    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
-    unsigned char* St = sb_lds;
-    unsigned char* Im = sb_lds + SB4_IM;
-    unsigned char* Ah = sb_lds + SB4_AH;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4, q4 = l15 >> 2, c4 = lane & 3;
-    const int wm = wave >> 1, wc = wave & 1;
-    const int n = blockIdx.x / p.nseg, seg = blockIdx.x - n * p.nseg;
-    const int V = p.V, F = p.F, Cin = p.Cin, N3 = 3 * p.Cin;
-    const int tile_lo = seg * p.tps, tile_hi = min(tile_lo + p.tps, p.tiles_t);
-    const int nc32 = Cin >> 5, nks = p.Cout >> 5;
-
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, p.w_plane_bytes * NP, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0, p.dx_bytes, 0x00020000);
-
-    const float* asrc = p.a_hat + (p.a_batched ? (long long)n * 3 * V * V : 0);
-    for (int i = tid; i < 3 * 32 * 32; i += 256) {
-        const int k = i >> 10, v = (i >> 5) & 31, w = i & 31;
-        const float a = (v < V && w < V) ? asrc[(k * V + v) * V + w] : 0.f;
-        unsigned ph, pm, pl;
-        split_bf16_pair(a, 0.f, ph, pm, pl);
-        unsigned short* d = reinterpret_cast<unsigned short*>(Ah + ((k * NP) * 32 + v) * SB_AHB) + w;
-        d[0] = (unsigned short)ph;
-        d[32 * SB_AHB / 2] = (unsigned short)pm;
-        d[2 * 32 * SB_AHB / 2] = (unsigned short)pl;
-    }
-    for (int i = tid; i < 3 * 256; i += 256) {                       // image rows 128 .. 143 stay zero
-        const int pl = i >> 8, o = i & 255;
-        *reinterpret_cast<unsigned*>(Im + pl * SB_PL + 128 * SB_XS + o * 4) = 0u;
-    }
-
-    int sf[MX], sct[MX];
-    bool sok[MX];
-#pragma unroll
-    for (int s = 0; s < MX; ++s) {
-        sf[s] = 0;
-        sct[s] = 0;
-        sok[s] = false;
-    }
-    {
-        int cnt = 0;
-        for (int u = 0; u < 2 * F; ++u) {
-            const bool mine = p.mix_wave4[u] == wave;
-#pragma unroll
-            for (int s = 0; s < MX; ++s)
-                if (mine && cnt == s) {
-                    sf[s] = u >> 1;
-                    sct[s] = u & 1;
-                    sok[s] = true;
-                }
-            cnt += mine ? 1 : 0;
-        }
-#pragma unroll
-        for (int s = 0; s < MX; ++s) {
-            sf[s] = __builtin_amdgcn_readfirstlane(sf[s]);
-            sct[s] = __builtin_amdgcn_readfirstlane(sct[s]);
-            sok[s] = __builtin_amdgcn_readfirstlane(sok[s] ? 1 : 0) != 0;
-        }
-    }
-
-    f32x4 gacc[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int wt = 0; wt < 2; ++wt) gacc[k][wt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int srow = tid >> 3, sg = tid & 7;                          // staging: rows srow + 32 i; 16-byte group sg
-    f32x4 stg[4];
-    u32x4v wq[2][NP];
-    auto fetch = [&](int tile_, int kc) {                            // kc >= Cout or no such tile: nothing (branch-free)
-        const int t0_ = tile_ * F;
-        const int nrows_ = (tile_ < tile_hi && kc < p.Cout) ? min(F, p.T - t0_) * V : 0;
-        const unsigned row0_ = (unsigned)((n * p.T + t0_) * V);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
-        }
-    };
-    // weight fragment of this wave's tile i (16 dagg channels: tile m = 3 wm + i = subset m / 2, 16-channel tile m % 2) of half c32
-    auto load_w = [&](u32x4v (&dst)[NP], int i, int kc, int c32_) {
-        const int m = 3 * wm + i;
-        const int col = (m >> 1) * Cin + c32_ * 32 + (m & 1) * 16 + l15;
-        const unsigned off = (unsigned)((((kc >> 3) + g4) * N3 + col) * 16);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) dst[pl] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, pl * p.w_plane_bytes, 0);
-    };
-    fetch(tile_lo, 0);
-    load_w(wq[0], 0, 0, 0);
-
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-        const int t0 = tile * F;
-        const int nf = min(F, p.T - t0);
-        const unsigned row0 = (unsigned)((n * p.T + t0) * V);
-        for (int c32 = 0; c32 < nc32; ++c32) {
-            const int c32_n = c32 + 1 < nc32 ? c32 + 1 : 0, tile_n = c32_n ? tile : tile + 1;      // the group after this one
-            const int cbase = c32 * 32;
-            f32x4 acc[3][4];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto step = [&](int ks, auto pb_tag) {
-                constexpr int PB = decltype(pb_tag)::value;
-                __syncthreads();                                     // the previous step's (or round's) LDS reads are done
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = srow + 32 * i;
-                    u32x2 ph, pm, pl;
-                    split3_x4(stg[i], ph, pm, pl);
-                    unsigned char* dst = St + r * SB_XS + ((unsigned)(sg * 8) ^ swz(r));
-                    *reinterpret_cast<u32x2*>(dst) = ph;
-                    *reinterpret_cast<u32x2*>(dst + SPL) = pm;
-                    *reinterpret_cast<u32x2*>(dst + 2 * SPL) = pl;
-                }
-                __syncthreads();
-                const bool last = ks + 1 == nks;
-                fetch(last ? tile_n : tile, last ? 0 : (ks + 1) * 32);   // the next step's rows -- or the next group's first -- land during the MFMAs
-                u32x4v a[4][NP];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = wc * 64 + j * 16 + l15;
-                    const unsigned char* src = St + r * SB_XS + ((unsigned)(16 * g4) ^ swz(r));
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) a[j][pl] = *reinterpret_cast<const u32x4v*>(src + pl * SPL);
-                }
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32, c32);
-                    else load_w(wq[(PB + i + 1) & 1], 0, last ? 0 : (ks + 1) * 32, last ? c32_n : c32);   // (selects, not branches)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_x3_k32(wq[(PB + i) & 1], a[j], acc[i][j]);
-                }
-            };
-            for (int ks = 0; ks < nks; ks += 2) {
-                step(ks, std::integral_constant<int, 0>{});
-                step(ks + 1, std::integral_constant<int, 1>{});
-            }
-
-            // dx's old values (or zeros) are the mix accumulators' start: rows (frame, joint v = 16 vt + l15), channels 16 ct + 4 g4 .. + 3
-            f32x4 dxa[MX][2];
-            auto dx_off = [&](int s, int vt) -> unsigned {
-                const int v = 16 * vt + l15;
-                return (sok[s] && sf[s] < nf && v < V) ? ((row0 + sf[s] * V + v) * (unsigned)p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * 4u : OOB;
-            };
-#pragma unroll
-            for (int s = 0; s < MX; ++s)
-#pragma unroll
-                for (int vt = 0; vt < 2; ++vt) {
-                    if constexpr (ACC) dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
-                    else dxa[s][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            // x rows of this wave's gram units (frame (wave >> 1) + 2 u, v tile wave & 1): requested once per group, split per round
-            f32x4 xr[MX][2];
-#pragma unroll
-            for (int u = 0; u < MX; ++u) {
-                const int f = (wave >> 1) + 2 * u, v = 16 * (wave & 1) + l15;
-                const unsigned off = (f < nf && v < V) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * 4u : OOB;
-                xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-                xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                // the owners of subset k's two tiles write the image: row R = 64 wc + 16 j + l15, channels 16 (m & 1) + 4 g4 .. + 3
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int m = 3 * wm + i;
-                    if ((m >> 1) != k) continue;                     // wave-uniform
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int R = wc * 64 + j * 16 + l15;
-                        u32x2 ph, pm, pl;
-                        split3_x4(acc[i][j], ph, pm, pl);
-                        unsigned char* dst = Im + R * SB_XS + ((unsigned)(((m & 1) * 16 + 4 * g4) * 2) ^ swz(R));
-                        *reinterpret_cast<u32x2*>(dst) = ph;
-                        *reinterpret_cast<u32x2*>(dst + SB_PL) = pm;
-                        *reinterpret_cast<u32x2*>(dst + 2 * SB_PL) = pl;
-                    }
-                }
-                __syncthreads();
-                // gram: dA^_k (v tile x w) += x_f . dagg_kf^T over the half's 32 channels
-#pragma unroll
-                for (int u = 0; u < MX; ++u) {
-                    const int f = (wave >> 1) + 2 * u;
-                    if (f >= nf) continue;                           // wave-uniform
-                    u32x4v xs[NP];
-                    split3_x8(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
-#pragma unroll
-                    for (int wt = 0; wt < 2; ++wt) {
-                        const int R = f * V + 16 * wt + l15;
-                        const unsigned char* src = Im + R * SB_XS + ((unsigned)(16 * g4) ^ swz(R));
-                        u32x4v bf[NP];
-#pragma unroll
-                        for (int pl = 0; pl < NP; ++pl) bf[pl] = *reinterpret_cast<const u32x4v*>(src + pl * SB_PL);
-                        gacc[k][wt] = mfma_x3_k32(xs, bf, gacc[k][wt]);
-                    }
-                }
-                // mix: dx^T (16 channels x 32 joints v) += dagg_kf^T (c x w) . A^_k^T (w x v)
-                u32x4v af[2][NP];
-#pragma unroll
-                for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        af[vt][pl] = *reinterpret_cast<const u32x4v*>(Ah + ((k * NP + pl) * 32 + 16 * vt + l15) * SB_AHB + 16 * g4);
-#pragma unroll
-                for (int s = 0; s < MX; ++s) {
-                    if (!(sok[s] && sf[s] < nf)) continue;           // wave-uniform
-                    const int r_lo = sf[s] * V + 8 * g4 + q4, r_hi = r_lo + 4;
-                    const unsigned cb = (unsigned)(sct[s] * 32 + 8 * c4);
-                    u32x4v df[NP];
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) {
-                        const unsigned char* base = Im + pl * SB_PL;
-                        const u32x2 lo = sb_read_tr16(base + r_lo * SB_XS + (cb ^ swz(r_lo)));
-                        const u32x2 hi = sb_read_tr16(base + r_hi * SB_XS + (cb ^ swz(r_hi)));
-                        df[pl] = u32x4v{lo[0], lo[1], hi[0], hi[1]};
-                    }
-#pragma unroll
-                    for (int vt = 0; vt < 2; ++vt) dxa[s][vt] = mfma_x3_k32(df, af[vt], dxa[s][vt]);
-                }
-                if (k == 2) {
-#pragma unroll
-                    for (int s = 0; s < MX; ++s)
-#pragma unroll
-                        for (int vt = 0; vt < 2; ++vt)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, dx_off(s, vt), 0, 0);
-                }
-                __syncthreads();                                     // the image is free for the next subset / the next group
-            }
-        }
-    }
-
-    // ---- the workgroup's dA^ partial: fixed-order sum of the four waves ----------------------------------------------------------------
-    float* red = reinterpret_cast<float*>(sb_lds);                   // [4 waves][3][32 v][32 w]
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt)
-#pragma unroll
-            for (int wt = 0; wt < 2; ++wt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[(wave * 3 + k) * 1024 + (16 * vt + 4 * g4 + r) * 32 + 16 * wt + l15] = vt == (wave & 1) ? gacc[k][wt][r] : 0.f;
-    __syncthreads();
-    float* dst = p.partial + ((long long)n * p.nseg + seg) * 3 * 1024;
-    for (int e = tid; e < 3 * 1024; e += 256) {
-        const int k = e >> 10, idx = e & 1023;
-        float s = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) s += red[(wv * 3 + k) * 1024 + idx];
-        dst[e] = ((idx >> 5) < V && (idx & 31) < V) ? s : 0.f;
-    }
-}
-
+// (A variant as TWO four-wave workgroups per CU -- one 32-channel half per group, one subset in the image at a time, 75 KB of LDS -- was built
+// in round 4, parity-tested and measured 8-22 % slower at every shape (DESIGN_HISTORY.md section 3.10); removed in round 6.)
 
 }  // namespace fgcn
 
@@ -809,52 +532,9 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
             cnt[best] += 1;
         }
     }
-    // the four-wave form: wave (par, vt) = (w >> 1, w & 1) carries the gram units of the frames f = par (mod 2) (12 MFMA groups each, as a mix unit)
-    int max_units4 = 0;
-    {
-        int load[4], cnt[4];
-        for (int w = 0; w < 4; ++w) {
-            load[w] = (p.F - (w >> 1) + 1) / 2;
-            cnt[w] = 0;
-            max_units4 = std::max(max_units4, load[w]);
-        }
-        for (int u = 0; u < 16; ++u) p.mix_wave4[u] = -1;
-        for (int u = 0; u < 2 * p.F; ++u) {
-            int best = -1;
-            for (int w = 3; w >= 0; --w)
-                if (cnt[w] < 4 && (best < 0 || load[w] < load[best])) best = w;
-            FGCN_REQUIRE(best >= 0, FGCN_E_BADARG, "spatial_bwd_tile: no wave left for mix unit %d", u);
-            p.mix_wave4[u] = best;
-            load[best] += 1;
-            cnt[best] += 1;
-            max_units4 = std::max(max_units4, cnt[best]);
-        }
-    }
     const dim3 grid((unsigned)(B * p.nseg));
     hipStream_t s = (hipStream_t)stream;
-    // tuning key 11 = 2: two four-wave workgroups per CU (measured 8-22 % slower than the eight-wave form: see the kernel's comment)
-    const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once (the eight-wave form only)
-    if (fgcn::tuning(11) == 2 && !gated && !one_part) {          // (the four-wave form takes no gated addends: such a call runs the eight-wave form)
-#define FGCN_SB4_GO(ACC_, MX_)                                                                                         \
-    do {                                                                                                                \
-        static bool opted = false;                                                                                      \
-        if (!opted) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile4_x3_kernel<ACC_, MX_>),           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB4_LDS);                        \
-            opted = true;                                                                                               \
-        }                                                                                                               \
-        hipLaunchKernelGGL((spatial_bwd_tile4_x3_kernel<ACC_, MX_>), grid, dim3(256), SB4_LDS, s, p);                   \
-    } while (0)
-        if (max_units4 <= 3) {
-            if (accumulate) FGCN_SB4_GO(true, 3);
-            else FGCN_SB4_GO(false, 3);
-        } else {
-            if (accumulate) FGCN_SB4_GO(true, 4);
-            else FGCN_SB4_GO(false, 4);
-        }
-#undef FGCN_SB4_GO
-        return launch_status("spatial_bwd_tile");
-    }
+    const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
 #define FGCN_SB_GO4(ACC_, MS_, NE_, NP_)                                                                               \
     do {                                                                                                                \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \

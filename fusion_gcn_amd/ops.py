@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import GramItem, MixItem, MixTerm, TMap, check
+from .paths import PathOptions, process_defaults
 
 TMAP_POINTWISE = (1, 1, 0, 0, 1)
 
@@ -32,11 +33,24 @@ class Context:
     restores the previous one on exit; ``ops.set_math_mode`` / ``fgcn_set_tuning`` inside change it and nothing else.  Two threads
     in two contexts (two models in two math modes on two streams) do not see each other's settings.  The autograd Functions of this
     package remember the context of their forward and make it current on the autograd thread for their backward (``context_bound``).
-    Without any context a thread reads and writes the process-wide defaults (math mode bf16x3)."""
+    Without any context a thread reads and writes the process-wide defaults (math mode bf16x3).
+    ``paths``: which kernel form the blocks take for each stage (fusion_gcn_amd/paths.py) -- per context like the rest, so two models
+    in one process may differ in them (tests/test_context_gpu.py runs two models with different PATH options on two threads)."""
 
-    def __init__(self, handle: Optional[int]):
+    def __init__(self, handle: Optional[int], paths: Optional[PathOptions] = None):
         self.handle = handle            # None: the process-wide defaults
         self.f16x2 = False              # the math mode's product form ("f16x2" = FGCN_MATH_BF16X3 + two-way f16 products)
+        self._paths = paths             # None: the process defaults (dataclass defaults + FGCN_PATHS), made on first use
+
+    @property
+    def paths(self) -> PathOptions:
+        if self._paths is None:
+            self._paths = process_defaults()
+        return self._paths
+
+    @paths.setter
+    def paths(self, value: PathOptions) -> None:
+        self._paths = value
 
     def __del__(self):                  # the library object goes with the last reference (a Function's ctx may outlive the `with` block)
         try:
@@ -80,7 +94,7 @@ def context(mode: Optional[str] = None):
     the block was left (``context_bound``)."""
     handle = ctypes.c_void_p()
     check(_lib.load().fgcn_ctx_create(ctypes.byref(handle)), "fgcn_ctx_create")
-    ctx = Context(handle.value)
+    ctx = Context(handle.value, current_context().paths.copy())
     ctx.f16x2 = current_context().f16x2
     with use_context(ctx):
         if mode is not None:
@@ -130,6 +144,11 @@ def set_math_mode(mode: str) -> None:
     check(_lib.load().fgcn_set_math_mode(MATH_MODES[mode]), "fgcn_set_math_mode")
     current_context().f16x2 = mode == "f16x2"
     check(_lib.load().fgcn_set_products(int(mode == "f16x2")), "fgcn_set_products")
+
+
+def paths() -> PathOptions:
+    """The calling thread's current path options (fusion_gcn_amd/paths.py)."""
+    return current_context().paths
 
 
 def get_math_mode() -> str:
@@ -197,7 +216,7 @@ def math_mode(mode: str):
 
 
 # weight-gradient kernels: stages (64 / 128 rows) a workgroup should at least walk before the rows are split further (small batches)
-WGRAD_MIN_STAGES = int(os.environ.get("FGCN_WGRAD_MIN_STAGES", "16"))
+WGRAD_MIN_STAGES = 16
 
 
 def conv_tmap(kt: int, stride: int) -> Tuple[int, int, int, int, int]:

@@ -1,0 +1,101 @@
+"""Which kernel form a block takes for each stage: per-CONTEXT options, not process globals.
+
+Until round 5 these were ~25 module attributes of block.py initialised from environment variables at import: per process, so two
+models in one process could not differ in them and the `fgcn_ctx` guarantee ("two models in two modes do not see each other's
+settings", include/fgcn.h) stopped at ops.py.  They now live in a ``PathOptions`` object carried by ``ops.Context``:
+
+    with ops.context("bf16x3") as ctx:          # a fresh context = a copy of the thread's present settings
+        ctx.paths.emb_tile = False                # this model's blocks run the unfused embedding chain
+        out = model(x); out.sum().backward()      # (the backward runs in the forward's context, wherever autograd runs it)
+
+``block.py`` reads ``ops.current_context().paths`` once per block call.  The process-wide default context takes its initial values
+from ONE environment variable, ``FGCN_PATHS="name=value,name=value"`` (the same-call A/B scripts under tools/ set it per child
+process); nothing else in the package reads the environment for a path decision.
+
+Every default below is a measured choice; the measurement is cited next to the field (records under profiles/, narrative in
+DESIGN.md / DESIGN_HISTORY.md).  Variants that lost their A/B twice were deleted in round 6 instead of carried as switches: the
+four-wave spatial backward (tuning key 11 = 2) and the weight-gradient side stream.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Tuple
+
+
+@dataclass
+class PathOptions:
+    # -- 1x1 convolutions: the persistent split-bf16 row GEMM (ops.pw_gemm) from this contraction depth on, the exact-f32 row GEMM below.
+    # MI355X, tools/kbench.py pw, B = 128 (profiles/r03_kbench_pw.log, r03_ab_pw_gemm.txt, r03_ab_pw_min_k_small.txt): at K = 64 / 96 the
+    # f32 row GEMM is even or ahead in bf16x3 at 64 clips (58.0-58.4 vs 58.3-58.5 ms), pw_gemm wins from K = 128 (62.53 vs 62.82 ms) and,
+    # with the f16x2 products or on few rows (the 8-clip shard: 9.65 -> 9.61 ms), from K = 64
+    pw_min_k: int = 128
+    pw_min_k_f16x2: int = 64
+    pw_small_rows: int = 300_000
+    # -- north-star kernel 2 in its stated form: BatchNorm + shortcut + ReLU of the graph convolution applied INSIDE the temporal conv
+    # while it stages its image (ops.tconv_halo(fuse_in=...)); bit-identical to the two-pass form and measured SLOWER (63.10 / 63.16 ->
+    # 64.68 / 64.96 ms at 64 clips, round 3; +2.0 ms re-measured in round 5: profiles/r03_ab_fused_input_stage.txt, r05_ab_fused_input_stage.txt)
+    fuse_g: bool = False
+    # -- fused spatial forward in its tile form from this many output channels on (profiles/r03_kbench_spatial_tile.log)
+    spatial_tile: bool = True
+    spatial_tile_min_cout: int = 128
+    # -- the backward of the spatial stage in one launch (fgcn_spatial_bwd_tile.hip): 57.65 -> 56.0-56.2 ms (profiles/r04_ab_spatial_bwd_tile.txt)
+    spatial_bwd_tile: bool = True
+    spatial_bwd_tile_min_cin: int = 64
+    spatial_bwd_tile_f16x2: bool = True          # ... also with the f16x2 products: 49.37 / 49.44 -> 48.75 / 48.78 ms
+    fused_dagg: bool = True                      # (unfused route) dx mix + dA^ gram in one kernel
+    # -- BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue, up to this many channels
+    bn_sums_in_dgrad: bool = True
+    bn_sums_max_c: int = 4096
+    # -- identity-shortcut gradients added by the kernel that forms the spatial term of dx: neutral in joint_dagg (off), 55.31 / 55.37 ->
+    # 55.20 / 55.20 ms in the fused backward (profiles/r04_ab_gated_tile.txt)
+    gated_shortcuts: bool = False
+    gated_shortcuts_tile: bool = True
+    # -- conv_d's weight gradient in tile form: 56.57 / 56.49 -> 55.71 / 55.53 ms (profiles/r04_ab_spatial_wgrad_tile.txt)
+    spatial_wgrad_tile: bool = True
+    spatial_wgrad_tile_f16x2: bool = True
+    fused_agg_wgrad: bool = True                 # (older form) aggregation recomputed on chip, up to this many outputs per math mode
+    fused_agg_wgrad_max_cout: Dict[str, int] = field(default_factory=lambda: {"f32": 64, "bf16": 128, "bf16x3": 128, "f16x2": 64})
+    # -- attention embeddings: backward with the embedding gradient on chip, forward with the gram on chip; up to this many input
+    # channels (profiles/r05_ab_emb_tile.txt: every block 53.79 / 53.90 ms, up to 128: 53.63 / 53.56, none: 54.09 / 54.22;
+    # profiles/r05_ab_emb_fwd_tile.txt: off 54.98 / 54.93, up to 128: 54.73 / 54.87)
+    emb_tile: bool = True
+    emb_tile_max_cin: int = 128
+    emb_fwd_tile: bool = True
+    emb_fwd_tile_max_cin: int = 128
+    # -- the model's last block: the epilogue pass carries the global average pooling, and its backward reads the pooled gradient as one
+    # row per clip (profiles/r05_ab_pool_epilogue_and_split_sums.txt, r05_ab_pool_backward_rows.txt: 53.74 / 53.74 -> 53.62 / 53.50 ms)
+    pool_epilogue: bool = True
+    pool_backward_rows: bool = True
+    mix_vw_order: Tuple[int, ...] = (2, 1)       # channels per lane preference of the channel-group mix kernel
+
+    def copy(self) -> "PathOptions":
+        return dataclasses.replace(self, fused_agg_wgrad_max_cout=dict(self.fused_agg_wgrad_max_cout))
+
+    def update_from(self, spec: str) -> "PathOptions":
+        """``"name=value,name=value"`` (the FGCN_PATHS form).  Unknown names are an error: an A/B run that silently tests nothing is
+        worse than one that stops.  ``fused_agg_wgrad_max_cout=128`` sets every math mode's entry."""
+        fields = {f.name: f for f in dataclasses.fields(self)}
+        for item in filter(None, (s.strip() for s in spec.split(","))):
+            name, _, val = item.partition("=")
+            name = name.strip().lower()
+            if name not in fields:
+                raise ValueError(f"FGCN_PATHS: unknown path option {name!r} (known: {', '.join(sorted(fields))})")
+            cur = getattr(self, name)
+            if isinstance(cur, bool):
+                setattr(self, name, val.strip().lower() not in ("0", "false", "off", "no", ""))
+            elif isinstance(cur, int):
+                setattr(self, name, int(val))
+            elif isinstance(cur, dict):
+                setattr(self, name, {k: int(val) for k in cur})
+            elif isinstance(cur, tuple):
+                setattr(self, name, tuple(int(v) for v in val.replace(":", " ").split()))
+            else:  # pragma: no cover
+                raise ValueError(f"FGCN_PATHS: cannot parse {name!r}")
+        return self
+
+
+def process_defaults() -> PathOptions:
+    """The default context's options: the dataclass defaults, overridden by FGCN_PATHS (read once, at first use)."""
+    return PathOptions().update_from(os.environ.get("FGCN_PATHS", ""))

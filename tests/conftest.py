@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "math_modes(*modes): the float32-class math modes this test's kernel exists in (a subset of f32 / bf16x3 / "
+                                       "f16x2): the module-wide parametrisation over the three modes is cut down to them, so a kernel that has no "
+                                       "form in a mode is not collected there instead of showing up as a skip")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -81,7 +84,9 @@ BOTH_MATH_MODES = {"test_kernels_gpu", "test_block_model_gpu", "test_train_e2e_g
 
 def pytest_generate_tests(metafunc):
     if metafunc.module.__name__.split(".")[-1] in BOTH_MATH_MODES and "fgcn_math" in metafunc.fixturenames:
-        metafunc.parametrize("fgcn_math", ["f32", "bf16x3", "f16x2"], indirect=True)
+        only = metafunc.definition.get_closest_marker("math_modes")
+        modes = [m for m in ("f32", "bf16x3", "f16x2") if only is None or m in only.args]
+        metafunc.parametrize("fgcn_math", modes, indirect=True)
 
 
 @pytest.fixture(autouse=True)

@@ -611,7 +611,7 @@ def test_model_with_and_without_the_pooling_epilogue(fgcn_math):
     """The model's last block with the pooling in its epilogue against bn_act + group_mean: logits, loss and every gradient agree to
     rounding (the pooled sums run in another order); the backward is the same code on the same sign image."""
     import torch.nn.functional as F
-    from fusion_gcn_amd import block
+    from fusion_gcn_amd import ops
     from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
     from fusion_gcn_amd.models.mmargcn.agcn import Model
     from fusion_gcn_amd.util import Graph
@@ -625,28 +625,22 @@ def test_model_with_and_without_the_pooling_epilogue(fgcn_math):
     x = torch.randn(3, 2, 40, 25, 3, device=dev)
     y = torch.randint(0, 60, (3,), device=dev)
 
-    def run(flag):
-        old, block.POOL_EPILOGUE = block.POOL_EPILOGUE, flag
-        try:
+    def run(flag, rows=True):
+        with ops.context() as c:            # the kernel-form options are per context (fusion_gcn_amd/paths.py)
+            c.paths.pool_epilogue, c.paths.pool_backward_rows = flag, rows
             for p in model.parameters():
                 p.grad = None
             logits = model(x)
             loss = F.cross_entropy(logits, y)
             loss.backward()
             return logits.detach().clone(), float(loss), [p.grad.clone() for p in model.parameters()]
-        finally:
-            block.POOL_EPILOGUE = old
     lg0, l0, g0 = run(False)
     lg1, l1, g1 = run(True)
     assert float((lg1 - lg0).norm() / lg0.norm()) < 2e-6 and abs(l1 - l0) < 1e-5
     f0, f1 = torch.cat([g.flatten() for g in g0]).double(), torch.cat([g.flatten() for g in g1]).double()
     assert float((f1 - f0).norm() / f0.norm()) < 2e-5
     # the backward from the pooled gradient as one row per clip against its expansion: the same values reach the same arithmetic
-    old_rows, block.POOL_BACKWARD_ROWS = block.POOL_BACKWARD_ROWS, False
-    try:
-        lg2, l2, g2 = run(True)
-    finally:
-        block.POOL_BACKWARD_ROWS = old_rows
+    lg2, l2, g2 = run(True, rows=False)
     assert torch.equal(lg1, lg2) and l1 == l2
     for a_, b_ in zip(g1, g2):
         assert torch.equal(a_, b_)

@@ -58,8 +58,38 @@ def _model_and_batch():
     return model, x, y
 
 
-def _run(mode, steps, stream, out, barrier=None):
-    """`steps` forward + backward passes of a fresh copy of the model in `mode`, inside a context of its own, on `stream`."""
+def test_path_options_are_per_context_without_a_gpu():
+    """The kernel-form options (fusion_gcn_amd/paths.py) travel with the context: a fresh context starts from a COPY of the thread's
+    present ones, changes stay inside it, another thread keeps the process defaults; FGCN_PATHS-style strings parse strictly."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.paths import PathOptions
+    base = ops.paths()
+    assert base is ops.current_context().paths and base.emb_tile and base.emb_tile_max_cin == 128 and not base.fuse_g
+    with ops.context() as ctx:
+        assert ctx.paths is not base and ctx.paths == base              # a copy, equal in value
+        ctx.paths.emb_tile = False
+        ctx.paths.fused_agg_wgrad_max_cout["bf16x3"] = 64
+        assert ops.paths() is ctx.paths and not ops.paths().emb_tile
+        seen = {}
+        t = threading.Thread(target=lambda: seen.update(emb=ops.paths().emb_tile, same=ops.paths() is base))
+        t.start()
+        t.join()
+        assert seen == {"emb": True, "same": True}                      # the other thread reads the process defaults
+        with ops.context() as inner:                                    # nested: a copy of the CURRENT (changed) options
+            assert not inner.paths.emb_tile and inner.paths.fused_agg_wgrad_max_cout["bf16x3"] == 64
+            inner.paths.emb_tile = True
+        assert not ops.paths().emb_tile
+    assert ops.paths() is base and base.emb_tile and base.fused_agg_wgrad_max_cout["bf16x3"] == 128
+    o = PathOptions().update_from("emb_tile=0, spatial_tile_min_cout=64,fused_agg_wgrad_max_cout=256,mix_vw_order=1:2,fuse_g=1")
+    assert (not o.emb_tile and o.spatial_tile_min_cout == 64 and o.fuse_g and o.mix_vw_order == (1, 2)
+            and set(o.fused_agg_wgrad_max_cout.values()) == {256})
+    with pytest.raises(ValueError, match="unknown path option"):
+        PathOptions().update_from("emb_tiles=0")
+
+
+def _run(mode, steps, stream, out, barrier=None, paths=None, key=None):
+    """`steps` forward + backward passes of a fresh copy of the model in `mode`, inside a context of its own, on `stream`; ``paths``:
+    kernel-form options set on that context (a dict of PathOptions fields)."""
     from fusion_gcn_amd import ops
     from fusion_gcn_amd.loss import cross_entropy
     dev = torch.device("cuda:0")
@@ -68,7 +98,10 @@ def _run(mode, steps, stream, out, barrier=None):
     x, y = x.to(dev), y.to(dev)
     res = []
     try:
-        with ops.context(mode), torch.cuda.stream(stream):
+        with ops.context(mode) as c, torch.cuda.stream(stream):
+            for name, value in (paths or {}).items():
+                assert hasattr(c.paths, name), name
+                setattr(c.paths, name, value)
             for _ in range(steps):
                 if barrier is not None:
                     barrier.wait(timeout=120)                           # both threads enter every step together
@@ -78,9 +111,9 @@ def _run(mode, steps, stream, out, barrier=None):
                 loss.backward()
                 stream.synchronize()
                 res.append((logits.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()))
-        out[mode] = res
+        out[key or mode] = res
     except BaseException as e:      # noqa: BLE001 - the other thread must not wait for a partner that is gone
-        out[mode] = e
+        out[key or mode] = e
         if barrier is not None:
             barrier.abort()
 
@@ -108,6 +141,40 @@ def test_two_threads_in_two_math_modes_match_the_single_mode_runs():
     for mode in ("f32", "bf16x3"):
         for (la, ga), (lb, gb) in zip(alone[mode], both[mode]):
             assert torch.equal(la, lb) and torch.equal(ga, gb), mode       # bit for bit what the mode produces alone
+
+
+@pytest.mark.gpu
+def test_two_threads_with_different_path_options_match_their_single_runs():
+    """Two models in ONE math mode but with different kernel-form options -- one on the fused tile kernels (the defaults), one on the
+    unfused chains of the embedding and spatial backward -- on two threads and two streams: each reproduces, bit for bit, what it
+    produces alone, and the two really took different kernels (their gradients differ in the last bits).  Before round 6 these
+    switches were module globals of block.py and the two models could not differ."""
+    from fusion_gcn_amd import ops
+    steps = 2
+    unfused = {"emb_tile": False, "emb_fwd_tile": False, "spatial_bwd_tile": False, "spatial_wgrad_tile": False, "bn_sums_in_dgrad": False}
+    alone = {}
+    _run("bf16x3", steps, torch.cuda.Stream(), alone, key="tile")
+    _run("bf16x3", steps, torch.cuda.Stream(), alone, paths=unfused, key="unfused")
+    for k in ("tile", "unfused"):
+        if isinstance(alone[k], BaseException):
+            raise alone[k]
+    assert not torch.equal(alone["tile"][0][1], alone["unfused"][0][1])          # other kernels: other rounding
+    err = float((alone["tile"][0][1] - alone["unfused"][0][1]).norm() / alone["tile"][0][1].norm())
+    assert err < 1e-4, err                                                     # ... of the same gradient
+    both, barrier = {}, threading.Barrier(2)
+    threads = [threading.Thread(target=_run, args=("bf16x3", steps, torch.cuda.Stream(), both, barrier, None, "tile")),
+               threading.Thread(target=_run, args=("bf16x3", steps, torch.cuda.Stream(), both, barrier, unfused, "unfused"))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for k in ("tile", "unfused"):
+        if isinstance(both.get(k), BaseException):
+            raise both[k]
+        for (la, ga), (lb, gb) in zip(alone[k], both[k]):
+            assert torch.equal(la, lb) and torch.equal(ga, gb), k
+    assert ops.paths().emb_tile and ops.paths().spatial_bwd_tile              # the process defaults were never touched
 
 
 @pytest.mark.gpu

@@ -190,6 +190,7 @@ def test_halo_temporal_conv_forward_and_data_gradient(B, T, V, C, O, s):
     assert rel_l2(dg.cpu().numpy(), dx_want.numpy()) < FWD_TOL
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("rows,K,N,ld_in,ld_out", [
     (3000, 64, 96, 64, 96), (2999, 96, 64, 96, 64), (1283, 128, 384, 128, 384), (517, 192, 128, 192, 128), (4097, 256, 768, 256, 768),
     (130, 384, 256, 384, 256), (1000, 64, 128, 64, 128), (127, 32, 4, 36, 8), (12000, 64, 192, 64, 192), (70000, 64, 64, 64, 64),
@@ -234,6 +235,7 @@ def test_persistent_pointwise_gemm(rows, K, N, ld_in, ld_out):
         assert rel_l2(outb.view(rows, ld_out)[:, :N].cpu().numpy(), want.numpy()) < 2e-2
 
 
+@pytest.mark.math_modes("bf16x3")
 @pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 21, 25, 128), (2, 9, 27, 256), (1, 50, 22, 64), (5, 3, 18, 128), (2, 40, 32, 64)])
 def test_halo_temporal_conv_with_the_input_stage_fused(B, T, V, C):
     """North-star kernel 2 as the north star states it: G = relu(BatchNorm(y) + x) (agcn.py:113-115) formed INSIDE the 9x1 temporal
@@ -551,6 +553,7 @@ def test_batchnorm_into_channel_windows(rows, C, n):
         assert rel_l2(sums[0].cpu().numpy(), b.grad.numpy()) < RED_TOL * 5
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("B,T,V,C", [(3, 37, 25, 64), (2, 20, 27, 64), (2, 9, 25, 128), (1, 5, 28, 64)])
 def test_halo_conv_wave_arrangements_agree(B, T, V, C):
     """The nine-tap halo conv as 4 x 1 waves over 192-row tiles (64 output columns: used from 1536 tiles on, forced here by tuning key 7
@@ -589,6 +592,7 @@ def test_halo_conv_wave_arrangements_agree(B, T, V, C):
         assert rel_l2(a[1].double().sum(0).cpu().numpy(), b[1].double().sum(0).cpu().numpy()) < 1e-6
 
 
+@pytest.mark.math_modes("bf16x3")
 @pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
                                              (16, 8, 128, 128, 1), (32, 5, 64, 96, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1)])
 def test_spatial_forward_tile_form(V, T, cin, cout, B):
@@ -642,6 +646,7 @@ def test_joint_dagg_fused_dx_and_gram(V, T, C, B):
     assert rel_l2(dx.cpu().numpy(), torch.einsum("btwkc,kvw->btvc", d4, a[0]).numpy()) < FWD_TOL
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
                                              (16, 8, 128, 128, 1), (32, 5, 64, 64, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1),
                                              (17, 23, 64, 128, 2), (21, 12, 128, 64, 3)])
@@ -661,15 +666,6 @@ def test_spatial_backward_tile_form(V, T, cin, cout, B):
     want_g = torch.einsum("btvc,btwkc->bkvw", x, dagg)
     wt = wd.permute(1, 0, 2).reshape(1, cout, 3 * cin)                         # [o][k cin + c]
     w3 = ops.pack_split3(to_gpu(wt))
-    from fusion_gcn_amd import _lib
-    try:                                        # the other arrangement of the same kernel (two four-wave workgroups per CU, tuning key 11 = 2)
-        _lib.load().fgcn_set_tuning(11, 2)
-        dx4 = to_gpu(base)
-        part4 = ops.spatial_bwd_tile(to_gpu(dy), to_gpu(x), to_gpu(a), w3, dx4, accumulate=True)
-    finally:
-        _lib.load().fgcn_set_tuning(11, 0)
-    assert rel_l2(dx4.cpu().numpy(), (want_dx + base).numpy()) < FWD_TOL
-    assert rel_l2(part4.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_g.numpy()) < RED_TOL
     parts = []
     for acc in (False, True):
         dx = to_gpu(base)
@@ -708,6 +704,7 @@ def test_spatial_backward_tile_form(V, T, cin, cout, B):
     assert torch.equal(part_g, parts[0][1])
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 64, 64, 2),
                                              (16, 8, 128, 128, 1), (32, 5, 64, 64, 1), (22, 31, 256, 256, 1), (25, 300, 64, 64, 1),
                                              (17, 23, 64, 128, 2), (21, 12, 128, 64, 3), (25, 20, 192, 64, 5), (19, 2, 64, 192, 3)])
@@ -761,6 +758,7 @@ def test_spatial_weight_gradient_tile_form(V, T, cin, cout, B):
     assert rel_l2(par.cpu().numpy().reshape(3, cout, cin - 3), want_p.numpy()) < RED_TOL
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("V,T,cin,ic,B", [(25, 13, 64, 16, 2), (25, 7, 256, 64, 2), (27, 9, 64, 32, 1), (18, 10, 128, 32, 2), (16, 8, 128, 64, 1),
                                           (32, 5, 64, 16, 1), (22, 31, 256, 64, 1), (25, 300, 64, 16, 1), (17, 23, 32, 16, 2), (21, 12, 96, 32, 3)])
 def test_embedding_forward_tile_form(V, T, cin, ic, B):
@@ -831,6 +829,7 @@ EMB_TILE_SHAPES = [(25, 13, 16, 64, 2), (25, 7, 64, 256, 2), (27, 9, 32, 64, 1),
                    (19, 2, 128, 64, 2)]
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("V,T,ic,cx,B", EMB_TILE_SHAPES)
 def test_embedding_backward_tile_form(V, T, ic, cx, B):
     """The backward of the attention embeddings with demb on chip (fgcn_emb_tile.hip; reference agcn.py:104-106): dx (+)= demb . Wemb and
@@ -907,6 +906,7 @@ def test_embedding_backward_tile_form(V, T, ic, cx, B):
     assert torch.equal(gww, gw) and torch.equal(gbw, gb)
 
 
+@pytest.mark.math_modes("bf16x3", "f16x2")
 @pytest.mark.parametrize("B,T,V,C", [(3, 20, 25, 64), (2, 13, 18, 128), (1, 40, 25, 256), (2, 9, 27, 64)])
 def test_halo_data_gradient_emits_the_batchnorm_backward_sums(B, T, V, C, fgcn_math):
     """fgcn_tconv_halo with bn_a / bn_mask / bn_vec: the data gradient dG and, from its epilogue, sum dP and sum dP * a_hat with
@@ -1175,6 +1175,7 @@ def test_cross_entropy_matches_torch(rows, classes):
     assert torch.isnan(lb) and torch.isnan(z2.grad[0, :classes]).all()
 
 
+@pytest.mark.math_modes("f16x2")
 @pytest.mark.parametrize("B,T,V,K,N,kt,stride", [(2, 40, 25, 64, 64, 9, 1), (3, 33, 25, 128, 128, 9, 1), (2, 21, 25, 128, 128, 9, 2),
                                                  (2, 16, 27, 256, 256, 9, 1), (2, 30, 25, 128, 192, 1, 1), (2, 24, 22, 256, 384, 1, 1)])
 def test_weight_gradient_from_two_way_f16_splits(B, T, V, K, N, kt, stride):

@@ -22,12 +22,12 @@ if [ "$part" = "a" ]; then
     cp gpurun_out/prof_${tag}_tmp/step8_warm_kernel_stats.csv $out/bf16x3_8clips_step_warm_kernel_stats.csv
     tail -2 $out/prof_step.log
 else
-    SER="--steps 2 --warmup 1 $Q --no-graph --wgrad-stream main"
+    SER="--steps 2 --warmup 1 $Q --no-graph"
     for m in bf16x3 bf16; do
         rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_$m -o step_fetch -- python3 bench.py $SER --math $m > $out/step_fetch_$m.log 2>&1
         rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_$m -o step_write -- python3 bench.py $SER --math $m > $out/step_write_$m.log 2>&1
         python3 tools/step_traffic.py $(find $out/pmc_$m -name "step_fetch_counter_collection.csv") $(find $out/pmc_$m -name "step_write_counter_collection.csv") 3 \
-            "HBM-side traffic per launch of every kernel of the 64-clip step ($tag, --math $m): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two runs) -- python3 bench.py --steps 2 --warmup 1 --no-graph --wgrad-stream main" > $out/${m}_step_traffic_by_kernel.txt
+            "HBM-side traffic per launch of every kernel of the 64-clip step ($tag, --math $m): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two runs) -- python3 bench.py --steps 2 --warmup 1 --no-graph" > $out/${m}_step_traffic_by_kernel.txt
         tail -3 $out/${m}_step_traffic_by_kernel.txt
         rm -rf $out/pmc_$m
     done

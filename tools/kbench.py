@@ -300,7 +300,7 @@ def bench_emb_bwd(B, reps):
 
 def bench_joint(B, reps):
     for order in ((1,), (2, 1)):
-        block.MIX_VW_ORDER = order
+        ops.paths().mix_vw_order = order
         print(f"-- channel-group mix kernels, channels per lane preference {order}")
         for T, c in ((300, 64), (150, 128), (75, 256)):
             ic = c // 4
@@ -316,7 +316,7 @@ def bench_joint(B, reps):
             emb, demb = rnd(B, T, V, 6 * ic), torch.empty(B, T, V, 6 * ic, device=DEV)
             ms = timeit(lambda: block.mix_demb(emb, demb, a, ic), reps)
             report(f"mix_demb T{T} ic{ic}", ms, 2.0 * rows * V * 6 * ic, 4.0 * rows * 12 * ic)
-    block.MIX_VW_ORDER = (2, 1)
+    ops.paths().mix_vw_order = (2, 1)
     for T, c in ((300, 64), (150, 128), (75, 256)):
         ic = c // 4
         rows = B * T * V
