@@ -459,6 +459,11 @@ def pool_epilogue_ok(cfg: BlockConfig, B: int, T: int, V: int, groups: int) -> b
 
 
 # ---- backward --------------------------------------------------------------------------------------------------------
+def zero_bias_floats(cfg: BlockConfig) -> int:
+    """floats of exactly-zero bias gradients a block hands out in train mode (conv_d x 3, the temporal conv, down, residual conv)"""
+    return (NUM_SUBSETS + 1 + int(cfg.has_down) + int(cfg.residual == "conv")) * cfg.cout
+
+
 class _BiasGrads:
     """Gradients of conv biases that feed a BatchNorm.  In train mode the BatchNorm subtracts the batch mean, so the
     block output does not depend on such a bias and its gradient is exactly zero (the reference's autograd produces
@@ -466,10 +471,14 @@ class _BiasGrads:
     allocation (one fill launch per block; every parameter still gets memory of its own).  Only eval-mode statistics make
     them real column sums."""
 
-    def __init__(self, cfg: BlockConfig, device, train: bool):
+    def __init__(self, cfg: BlockConfig, device, train: bool, zeros: Optional[torch.Tensor] = None):
         self.train = train
-        n = (NUM_SUBSETS + 1 + int(cfg.has_down) + int(cfg.residual == "conv")) * cfg.cout
-        self.pool = torch.zeros(n, device=device, dtype=torch.float32) if train else None
+        n = zero_bias_floats(cfg)
+        # ``zeros``: this block's slice of a pool the MODEL filled once per step (one launch for the ten blocks instead of ten)
+        if train and zeros is not None and zeros.numel() >= n:
+            self.pool = zeros
+        else:
+            self.pool = torch.zeros(n, device=device, dtype=torch.float32) if train else None
         self.used = 0
 
     def __call__(self, d: torch.Tensor, c: int) -> torch.Tensor:
@@ -481,7 +490,7 @@ class _BiasGrads:
 
 def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: Dict[str, torch.Tensor],
                    W: Dict[str, torch.Tensor], cfg: BlockConfig, train: bool = True, need_dx: bool = True,
-                   pool: Optional[Tuple[int, tuple]] = None):
+                   pool: Optional[Tuple[int, tuple]] = None, zeros: Optional[torch.Tensor] = None):
     """-> (dx (B, T, V, cx) or None, {param name: grad in the parameter's own shape}).
     The leaf reductions of the block (weight-gradient slabs, adj_b, embedding-bias partials) are collected and issued as one
     launch at the end (ops.deferred_reductions).  Weight gradients are leaves of the backward graph and run in line, on the one stream:
@@ -489,12 +498,12 @@ def block_backward(d_o: torch.Tensor, S: Dict[str, Optional[torch.Tensor]], P: D
     kernels fill every CU's registers and LDS, so nothing of the other stream is co-resident: DESIGN.md section 3.2 item 11) and was
     removed in round 6."""
     with ops.deferred_reductions() as batch:
-        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, pool)
+        out = _block_backward(d_o, S, P, W, cfg, train, need_dx, pool, zeros)
         batch.flush()
     return out
 
 
-def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, pool=None):
+def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, pool=None, zeros=None):
     """``pool`` = (groups, shape of the block's output): the block's forward returned the per-group mean of its output (pool_groups) and
     ``d_o`` is the gradient of that, (groups, cout); it is consumed as a per-group row (divided by the group's rows) where the kernels
     take one (POOL_BACKWARD_ROWS) and expanded to the output's shape otherwise."""
@@ -532,7 +541,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
             grp_rows, grp_samples = rows, B // groups        # the BatchNorm-backward passes and the gated addend read the group's row
         else:
             d_o = d_o.unsqueeze(1).expand(groups, rows, cout).contiguous().view(B, Tp, V, cout)
-    bias_grad = _BiasGrads(cfg, dev, train)
+    bias_grad = _BiasGrads(cfg, dev, train, zeros)
 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
     if cfg.residual == "none":
@@ -674,6 +683,7 @@ class STBlockFunction(torch.autograd.Function):
         o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups)
         B, T, V, _ = x.shape
         ctx.pool = (pool_groups, (B, (T - 1) // cfg.stride + 1, V, cfg.cout)) if pool_groups else None
+        ctx.zeros = holder.get("zeros") if holder is not None else None      # the block's slice of the model's zero pool (or None)
         # the block's input and output go through save_for_backward (an output kept on ctx would be a reference cycle
         # o -> grad_fn -> ctx -> o that only the garbage collector frees); the other activations are private to the block
         # (the backward gates on the one-bit sign image of o, so o itself is only kept when that image does not exist;
@@ -696,7 +706,7 @@ class STBlockFunction(torch.autograd.Function):
         P = dict(zip(ctx.names, params))
         S = dict(ctx.S, x=x, o=o)
         ctx.S = None
-        dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0], pool=ctx.pool)
+        dx, G = block_backward(d_o, S, P, ctx.W, ctx.cfg, ctx.train, need_dx=ctx.needs_input_grad[0], pool=ctx.pool, zeros=ctx.zeros)
         del S
         grads = []
         for i, n in enumerate(ctx.names):

@@ -36,6 +36,8 @@
 #include "fgcn_common.hpp"
 
 // Timing probes (wrong results; tools/build_probe.py only).  dx kernel: bit 0 = no contraction MFMAs, 1 = no mixing (the image stays unwritten),
+// 16 = the emb values' bytes in a quarter of the requests, 17 = no in-register split of the emb values (16 + 17: what pre-split transposed
+// planes written by the producer would leave of this kernel's input side -- VERDICT r05 item 1),
 // 2 = emb values requested for the first chunk only, 3 = no matrix planes, 4 = accumulators start from zero, 5 = no stores, 6 = no weight
 // requests past the prologue, 7 = no image fragment reads past the first.  Weight-gradient kernel: bit 8 = no contraction MFMAs, 9 = no mixing
 // MFMAs, 10 = emb values requested for the first slot only, 11 = x rows requested / deposited for the first tile only, 12 = one transposing
@@ -239,7 +241,14 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
 #pragma unroll
         for (int i = 0; i < MAXU; ++i) {
             g[i] = group_of(32 * c + 16 * uh[i]);                    // the unit's group = its matrix
-            splitn_x8<NP>(xr[i][0], xr[i][1], xr[i][2], xr[i][3], xr[i][4], xr[i][5], xr[i][6], xr[i][7], xs[i]);
+            if constexpr ((FGCN_PROBE_EMB & 131072) != 0) {         // probe: emb arrives pre-split (its bits stand in for the planes)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    xs[i][pl] = u32x4v{__builtin_bit_cast(unsigned, xr[i][pl]), __builtin_bit_cast(unsigned, xr[i][pl + 1]),
+                                       __builtin_bit_cast(unsigned, xr[i][pl + 2]), __builtin_bit_cast(unsigned, xr[i][pl + 3])};
+            } else {
+                splitn_x8<NP>(xr[i][0], xr[i][1], xr[i][2], xr[i][3], xr[i][4], xr[i][5], xr[i][6], xr[i][7], xs[i]);
+            }
         }
         f32x4 m[MAXU][2];
 #pragma unroll

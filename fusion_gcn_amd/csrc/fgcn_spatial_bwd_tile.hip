@@ -34,7 +34,9 @@
 // Timing probes (wrong results; tools/build_probe.py only): bit 0 = no gram MFMAs, bit 1 = no mix MFMAs, bit 2 = no MFMAs in the
 // contraction steps, bit 3 = x rows / old dx values not requested, bit 4 = the dY rows requested for the first step only,
 // bit 5 = no image writes (the compiler then drops the contraction too), bit 6 = no dx stores, bit 7 = weight fragments requested
-// once per workgroup
+// once per workgroup, bit 8 = the dY rows deposited WITHOUT the three-way split (the bits of the f32 values stand in for pre-split
+// planes: what the kernel would cost if its producer had written dY as bf16 planes -- VERDICT r05 item 1 -- minus the 1.5x bytes),
+// bit 9 = the same for the x rows of the gram (no in-register split)
 #ifndef FGCN_PROBE_SB
 #define FGCN_PROBE_SB 0
 #endif
@@ -227,7 +229,13 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
                     u32x2 parts[NP];
-                    splitn_x4<NP>(stg[i], parts);
+                    if constexpr ((FGCN_PROBE_SB & 256) != 0) {
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl)
+                            parts[pl] = u32x2{__builtin_bit_cast(unsigned, stg[i][(pl) & 3]), __builtin_bit_cast(unsigned, stg[i][(pl + 1) & 3])};
+                    } else {
+                        splitn_x4<NP>(stg[i], parts);
+                    }
                     unsigned char* dst = St + r * SB_XS + ((unsigned)(sg * 8) ^ swz(r));
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * SB_PL) = parts[pl];
@@ -342,7 +350,12 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     const int f = (wave >> 1) + 4 * u;
                     if (f >= nf) continue;                           // wave-uniform
                     u32x4v xs[NP];
-                    splitn_x8<NP>(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
+                    if constexpr ((FGCN_PROBE_SB & 512) != 0) {
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) xs[pl] = __builtin_bit_cast(u32x4v, xr[u][pl & 1]);
+                    } else {
+                        splitn_x8<NP>(xr[u][0][0], xr[u][0][1], xr[u][0][2], xr[u][0][3], xr[u][1][0], xr[u][1][1], xr[u][1][2], xr[u][1][3], xs);
+                    }
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
 #pragma unroll

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...block import (BlockConfig, GroupMeanFunction, LinearFunction, STBlockFunction, bn_names, data_bn, pack_weights, param_names,
-                      pool_epilogue_ok)
+                      pool_epilogue_ok, zero_bias_floats)
 from ...util.partition_strategy import GraphPartitionStrategy
 
 
@@ -177,6 +177,7 @@ class SpatialTemporalConv(nn.Module):
             bufs[f"{bn}.running_mean"], bufs[f"{bn}.running_var"] = mod.running_mean, mod.running_var
         return bufs
 
+    _zeros = None        # a Model fills the exactly-zero bias gradients of all its blocks with one launch per step (Model.forward)
     _defer_nbt = False   # a Model bumps the num_batches_tracked counters of all its blocks with one multi-tensor add
 
     def nbt_buffers(self):
@@ -218,6 +219,8 @@ class SpatialTemporalConv(nn.Module):
         params = [self._tensor(n) for n in names]
         W = self._packed(params)
         holder = {"pool_groups": pool_groups} if pool_groups else {}
+        if self._zeros is not None:                   # this step's slice of the model's zero pool (Model.forward), used once
+            holder["zeros"], self._zeros = self._zeros, None
         out = STBlockFunction.apply(x, self.cfg, self.training, self._block_buffers(), W, holder, *params)
         if self.training and not self._defer_nbt:
             torch._foreach_add_(self.nbt_buffers(), 1)
@@ -338,6 +341,15 @@ class Model(nn.Module):
         h = self._blocks_input(x)
         self._bump_batch_counters()
         refresh_packed_weights(self)
+        if self.training and torch.is_grad_enabled():
+            # the exactly-zero bias gradients of all blocks (block._BiasGrads): one zero-filled allocation and one fill launch per step
+            blocks = [m for m in self.layers if isinstance(m, SpatialTemporalConv)]
+            sizes = [zero_bias_floats(b.cfg) for b in blocks]
+            zeros = torch.zeros(sum(sizes), device=h.device, dtype=torch.float32)
+            off = 0
+            for b, n in zip(blocks, sizes):
+                b._zeros = zeros[off:off + n]
+                off += n
         for layer in self.layers[:-1]:
             h = layer(h)
         # (N*M, T', V, C') -> mean over (T', V) then over persons = one mean over persons, frames and joints (equal-sized groups)

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...block import GroupMeanFunction, LinearFunction
+from ...block import GroupMeanFunction, LinearFunction, data_bn
 from .graph_convolution import AGCNGraphConvolution, STGCNGraphConvolution
 
 _GRAPH_CONVS = {"stgcn": STGCNGraphConvolution, "agcn": AGCNGraphConvolution}
@@ -55,8 +55,11 @@ class GCN(nn.Module):
 
     def forward(self, x):
         batch_size, feature_dim, num_nodes = x.size()
-        x = self.bn(torch.flatten(x, start_dim=1))       # (input BatchNorm: a torch op, as data_bn of the skeleton model)
-        h = x.view(batch_size, feature_dim, num_nodes).permute(0, 2, 1)   # node-major (B, V, F), channels padded to 4
+        # input BatchNorm1d over the (feature, node) channels, statistics across the batch (gcn.py:59-61 of the reference): libfgcn's
+        # data_bn kernels with (N, M, T, V, C) = (batch, 1, 1, features, nodes) -- channel index f * nodes + node, as torch.flatten gives
+        # it; running statistics and the batch counter are updated like the module's own forward would
+        h = data_bn(x.reshape(batch_size, 1, 1, feature_dim, num_nodes), self.bn)       # (B, 1, F, nodes padded to 4)
+        h = h[:, 0, :, :num_nodes].permute(0, 2, 1)      # node-major (B, V, F), channels padded to 4
         pad = (-feature_dim) % 4
         h = (F.pad(h, (0, pad)) if pad else h).contiguous()
         for layer in self.layers:

@@ -442,8 +442,8 @@ def test_joint_mix_aggregation_and_its_transpose(V, cin):
 def test_joint_mix_channel_groups(V, cin, order, monkeypatch):
     """The channel-group kernel (1 or 2 channels per lane; every k-step template) gives the same agg / dx as the
     einsum, with and without accumulation, and never writes outside its rows (canary row stride)."""
-    from fusion_gcn_amd import block
-    monkeypatch.setattr(block, "MIX_VW_ORDER", order)
+    from fusion_gcn_amd import block, ops
+    monkeypatch.setattr(ops.paths(), "mix_vw_order", order)      # (a per-context path option: fusion_gcn_amd/paths.py)
     B, T = 3, 9
     x, a = rnd(B, T, V, cin, seed=70), rnd(B, 3, V, V, seed=71, scale=0.3)
     want = torch.einsum("btvc,bkvw->btwkc", x, a).reshape(B, T, V, 3 * cin)
@@ -481,7 +481,7 @@ def test_joint_mix_embedding_gradient(ic, order, monkeypatch):
             pytest.skip("dword-kernel spec needs 16-channel groups")
         ops.joint_mix(to_gpu(emb), out, to_gpu(ds), block.spec_demb(ic), in_channels=6 * ic, out_channels=6 * ic)
     else:
-        monkeypatch.setattr(block, "MIX_VW_ORDER", order)
+        monkeypatch.setattr(ops.paths(), "mix_vw_order", order)      # (a per-context path option: fusion_gcn_amd/paths.py)
         sums = block.mix_demb(to_gpu(emb), out, to_gpu(ds), ic)
         # the column sums (theta|phi bias gradient) come out of the same launch
         assert rel_l2(sums.cpu().numpy(), want.reshape(-1, 6 * ic).sum(0).numpy()) < RED_TOL
