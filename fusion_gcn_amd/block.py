@@ -389,7 +389,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         emb, c_mat = None, None
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
-        if (o_.emb_fwd_tile and cin <= o_.emb_fwd_tile_max_cin and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
+        if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
             emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic)             # emb written once, the gram from the tile on chip
         else:
@@ -401,7 +401,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
-    if cfg.fused_spatial and o_.spatial_tile and cout >= o_.spatial_tile_min_cout and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
+    if cfg.fused_spatial and o_.spatial_tile and cout >= o_.get("spatial_tile_min_cout", ops.get_math_mode()) and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
         y, part = ops.spatial_fwd_tile(x, a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     elif cfg.fused_spatial:
         y, part = ops.spatial_fwd(x, a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
@@ -570,7 +570,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     dg = new(B, T, V, cout)
     # identity blocks in the split-bf16 modes: the data-gradient kernel sums dg * [g > 0] and dg * [g > 0] * y_hat in its epilogue,
     # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
-    fuse_sums = (o_.bn_sums_in_dgrad and cout <= o_.bn_sums_max_c and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
+    fuse_sums = (o_.get("bn_sums_in_dgrad", ops.get_math_mode()) and cout <= o_.bn_sums_max_c and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
                  and "t_t4" in W and ops.tconv_halo_bn_sums())
     # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
     # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
@@ -619,7 +619,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     if (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
             and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2)):
         gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
-    elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.fused_agg_wgrad_max_cout[ops.get_math_mode()]:
+    elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.get("fused_agg_wgrad_max_cout", ops.get_math_mode()):
         # agg = x . A^ is formed in registers and contracted with dy at once: never written
         gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
     else:
@@ -649,7 +649,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        if (o_.emb_tile and cin <= o_.emb_tile_max_cin and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
+        if (o_.emb_tile and cin <= o_.get("emb_tile_max_cin", ops.get_math_mode()) and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
                 and small(max(6 * ic, cx))):
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)

@@ -38,15 +38,19 @@ class PathOptions:
     # 64.68 / 64.96 ms at 64 clips, round 3; +2.0 ms re-measured in round 5: profiles/r03_ab_fused_input_stage.txt, r05_ab_fused_input_stage.txt)
     fuse_g: bool = False
     # -- fused spatial forward in its tile form from this many output channels on (profiles/r03_kbench_spatial_tile.log)
+    # (per math mode: in `bf16` the matrix work is a sixth and the tile form's single pass over x wins from 64 outputs on --
+    # profiles/r06_ab_bf16_paths.txt: 36.46 / 36.06 -> 35.83 / 35.72 ms)
     spatial_tile: bool = True
-    spatial_tile_min_cout: int = 128
+    spatial_tile_min_cout: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 64, "bf16x3": 128, "f16x2": 128})
     # -- the backward of the spatial stage in one launch (fgcn_spatial_bwd_tile.hip): 57.65 -> 56.0-56.2 ms (profiles/r04_ab_spatial_bwd_tile.txt)
     spatial_bwd_tile: bool = True
     spatial_bwd_tile_min_cin: int = 64
     spatial_bwd_tile_f16x2: bool = True          # ... also with the f16x2 products: 49.37 / 49.44 -> 48.75 / 48.78 ms
     fused_dagg: bool = True                      # (unfused route) dx mix + dA^ gram in one kernel
     # -- BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue, up to this many channels
-    bn_sums_in_dgrad: bool = True
+    # (bf16x3: neutral, round 4; `bf16`: the epilogue's dword loads of y and the sign image cost the now six times shorter conv more than
+    # the stand-alone reduction pass takes -- profiles/r06_ab_bf16_paths.txt: 36.46 / 36.06 -> 35.01 / 35.05 ms with the pass)
+    bn_sums_in_dgrad: Dict[str, bool] = field(default_factory=lambda: {"f32": True, "bf16": False, "bf16x3": True, "f16x2": True})
     bn_sums_max_c: int = 4096
     # -- identity-shortcut gradients added by the kernel that forms the spatial term of dx: neutral in joint_dagg (off), 55.31 / 55.37 ->
     # 55.20 / 55.20 ms in the fused backward (profiles/r04_ab_gated_tile.txt)
@@ -60,10 +64,12 @@ class PathOptions:
     # -- attention embeddings: backward with the embedding gradient on chip, forward with the gram on chip; up to this many input
     # channels (profiles/r05_ab_emb_tile.txt: every block 53.79 / 53.90 ms, up to 128: 53.63 / 53.56, none: 54.09 / 54.22;
     # profiles/r05_ab_emb_fwd_tile.txt: off 54.98 / 54.93, up to 128: 54.73 / 54.87)
+    # `bf16`: at 256 channels the tile kernels are no longer matrix-bound and the fused path wins there too
+    # (profiles/r06_ab_bf16_paths.txt: 36.46 / 36.06 -> 36.10 / 35.89 ms)
     emb_tile: bool = True
-    emb_tile_max_cin: int = 128
+    emb_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
     emb_fwd_tile: bool = True
-    emb_fwd_tile_max_cin: int = 128
+    emb_fwd_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
     # -- the model's last block: the epilogue pass carries the global average pooling, and its backward reads the pooled gradient as one
     # row per clip (profiles/r05_ab_pool_epilogue_and_split_sums.txt, r05_ab_pool_backward_rows.txt: 53.74 / 53.74 -> 53.62 / 53.50 ms)
     pool_epilogue: bool = True
@@ -71,24 +77,35 @@ class PathOptions:
     mix_vw_order: Tuple[int, ...] = (2, 1)       # channels per lane preference of the channel-group mix kernel
 
     def copy(self) -> "PathOptions":
-        return dataclasses.replace(self, fused_agg_wgrad_max_cout=dict(self.fused_agg_wgrad_max_cout))
+        return dataclasses.replace(self, **{f.name: dict(getattr(self, f.name)) for f in dataclasses.fields(self)
+                                            if isinstance(getattr(self, f.name), dict)})
+
+    def get(self, name: str, mode: str):
+        """The value of option ``name`` in math mode ``mode`` (per-mode options are dicts keyed by the mode's name)."""
+        v = getattr(self, name)
+        return v[mode] if isinstance(v, dict) else v
 
     def update_from(self, spec: str) -> "PathOptions":
         """``"name=value,name=value"`` (the FGCN_PATHS form).  Unknown names are an error: an A/B run that silently tests nothing is
-        worse than one that stops.  ``fused_agg_wgrad_max_cout=128`` sets every math mode's entry."""
+        worse than one that stops.  Per-mode options: ``fused_agg_wgrad_max_cout=128`` sets every math mode's entry,
+        ``emb_tile_max_cin.bf16=128`` one."""
         fields = {f.name: f for f in dataclasses.fields(self)}
         for item in filter(None, (s.strip() for s in spec.split(","))):
             name, _, val = item.partition("=")
-            name = name.strip().lower()
+            name, _, only_mode = name.strip().lower().partition(".")
             if name not in fields:
                 raise ValueError(f"FGCN_PATHS: unknown path option {name!r} (known: {', '.join(sorted(fields))})")
             cur = getattr(self, name)
+            if only_mode and not (isinstance(cur, dict) and only_mode in cur):
+                raise ValueError(f"FGCN_PATHS: {name!r} has no entry for math mode {only_mode!r}")
             if isinstance(cur, bool):
                 setattr(self, name, val.strip().lower() not in ("0", "false", "off", "no", ""))
             elif isinstance(cur, int):
                 setattr(self, name, int(val))
             elif isinstance(cur, dict):
-                setattr(self, name, {k: int(val) for k in cur})
+                sample = next(iter(cur.values()))
+                new = (val.strip().lower() not in ("0", "false", "off", "no", "")) if isinstance(sample, bool) else int(val)
+                setattr(self, name, {k: (new if (not only_mode or k == only_mode) else old) for k, old in cur.items()})
             elif isinstance(cur, tuple):
                 setattr(self, name, tuple(int(v) for v in val.replace(":", " ").split()))
             else:  # pragma: no cover

@@ -64,7 +64,7 @@ def test_path_options_are_per_context_without_a_gpu():
     from fusion_gcn_amd import ops
     from fusion_gcn_amd.paths import PathOptions
     base = ops.paths()
-    assert base is ops.current_context().paths and base.emb_tile and base.emb_tile_max_cin == 128 and not base.fuse_g
+    assert base is ops.current_context().paths and base.emb_tile and base.emb_tile_max_cin["bf16x3"] == 128 and not base.fuse_g
     with ops.context() as ctx:
         assert ctx.paths is not base and ctx.paths == base              # a copy, equal in value
         ctx.paths.emb_tile = False
@@ -80,9 +80,14 @@ def test_path_options_are_per_context_without_a_gpu():
             inner.paths.emb_tile = True
         assert not ops.paths().emb_tile
     assert ops.paths() is base and base.emb_tile and base.fused_agg_wgrad_max_cout["bf16x3"] == 128
-    o = PathOptions().update_from("emb_tile=0, spatial_tile_min_cout=64,fused_agg_wgrad_max_cout=256,mix_vw_order=1:2,fuse_g=1")
-    assert (not o.emb_tile and o.spatial_tile_min_cout == 64 and o.fuse_g and o.mix_vw_order == (1, 2)
-            and set(o.fused_agg_wgrad_max_cout.values()) == {256})
+    o = PathOptions().update_from("emb_tile=0, spatial_tile_min_cout=64,fused_agg_wgrad_max_cout=256,mix_vw_order=1:2,fuse_g=1,"
+                                  "bn_sums_in_dgrad.bf16x3=0, emb_tile_max_cin.bf16=64")
+    assert (not o.emb_tile and set(o.spatial_tile_min_cout.values()) == {64} and o.fuse_g and o.mix_vw_order == (1, 2)
+            and set(o.fused_agg_wgrad_max_cout.values()) == {256} and o.get("bn_sums_in_dgrad", "bf16x3") is False
+            and o.get("bn_sums_in_dgrad", "f16x2") is True and o.emb_tile_max_cin == {"f32": 128, "bf16": 64, "bf16x3": 128, "f16x2": 128})
+    assert PathOptions().get("bn_sums_in_dgrad", "bf16") is False and PathOptions().get("spatial_tile_min_cout", "bf16") == 64
+    with pytest.raises(ValueError, match="no entry for math mode"):
+        PathOptions().update_from("emb_tile.bf16=0")
     with pytest.raises(ValueError, match="unknown path option"):
         PathOptions().update_from("emb_tiles=0")
 
