@@ -355,6 +355,18 @@ def spec_demb(ic: int) -> List[dict]:
     return out
 
 
+def half_conv_operands_ok(W, kt: int, s: int, T: int, train: bool, o_) -> bool:
+    """Whether this block keeps G and dU in bfloat16 (paths.half_conv_operands): math mode bf16, a training step (the eval-mode bias
+    gradient reads dU as f32), and the three consumers on their bfloat16-input kernels -- the halo conv forward and data gradient
+    (the routes temporal_fwd / temporal_dgrad take for these sizes) and the all-taps weight gradient (tap counts it is built for)."""
+    if not (train and ops.get_math_mode() == "bf16" and o_.get("half_conv_operands", "bf16")) or kt <= 1:
+        return False
+    pad = (kt - 1) // 2
+    per_pass = [kt] if s == 1 else [len([j for j in range(kt) if (j - pad) % s == par]) for par in range(s)]
+    return (temporal_fwd_records_amax(W, kt, s, T) and temporal_dgrad_records_amax(W, kt, s)
+            and all(n in ops.TWGRAD_TAPS_SPLIT for n in per_pass if n))
+
+
 # ---- forward ---------------------------------------------------------------------------------------------------------
 def _bn_vec(part, count, P, bufs, name, train):
     g, b = P[f"{name}.weight"], P[f"{name}.bias"]
@@ -411,24 +423,29 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         y = new(B, T, V, cout)
         part = ops.rows_gemm(agg, W["d"].unsqueeze(0), y, K=3 * cin, N=cout, bias=W["d_b"], stats=train)
     vec_y = _bn_vec(part, B * T * V, P, bufs, "gcn1.bn", train)
+    # math mode bf16, training: G (the temporal conv's input) is stored as bfloat16 -- only bf16 MFMA staging reads it (the conv and its
+    # weight gradient), so the values those kernels multiply are the same and they copy half the bytes (paths.half_conv_operands)
+    kt = P["tcn1.conv.weight"].shape[2]
+    half = half_conv_operands_ok(W, kt, s, T, train, o_)
     if cfg.has_down:
         d = new(B, T, V, cout)
         part = pw_gemm(x, W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
         vec_d = _bn_vec(part, B * T * V, P, bufs, "gcn1.down.1", train)
-        g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True)
+        g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True, out_bf16=half)
     else:
         d, vec_d = None, None
     # identity blocks on the split-bf16 kernels: G = relu(BatchNorm(y) + x) is formed INSIDE the temporal conv while it stages its
     # image (north-star kernel 2: "temporal 9x1 conv + BN + ReLU"), G and its sign image come out as by-products -- no bn_act pass
-    kt = P["tcn1.conv.weight"].shape[2]
-    fuse_g = (o_.fuse_g and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
+    fuse_g = (o_.fuse_g and not half and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
               and cx == cout and V <= 32 and (B * T * V * cout) % 8 == 0)
     if fuse_g:
         g = new(B, T, V, cout)
         g_sign = torch.empty((B * T * V * cout) // 8, device=dev, dtype=torch.uint8)
     elif not cfg.has_down:
-        g, g_sign = ops.bn_act(y, vec_y, x, None, relu=True, sign_mask=True)
-    S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign)   # *_sign: 1 bit per element, the backward's ReLU gate
+        g, g_sign = ops.bn_act(y, vec_y, x, None, relu=True, sign_mask=True, out_bf16=half)
+    if half and g_sign is None:      # (no sign image: the backward would gate on g itself, which it reads as f32 -- cout % 64 == 0 rules it out)
+        raise ops._lib.FgcnError("half-precision storage of G needs the sign image (element count a multiple of 8)")
+    S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign, half=half)   # *_sign: 1 bit per element, the backward's ReLU gate
 
     # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
     u = new(B, Tp, V, cout)
@@ -514,6 +531,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     Tp = d_o.shape[1] if pool is None else pool[1][1]
     dev = x.device
     o_ = ops.paths()             # this context's kernel-form options (the forward's context: ops.context_bound)
+    half = bool(S.get("half")) and train     # G was stored as bfloat16: dU (the gradient of the temporal conv's output) is too
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     G: Dict[str, torch.Tensor] = {}
     d_o = d_o.contiguous()
@@ -546,18 +564,18 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- O = relu(BN(u) + res) ---------------------------------------------------------------------------------------------
     if cfg.residual == "none":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train,
-                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
     elif cfg.residual == "identity" and gate_in_dagg:
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, need_db=False,
-                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
         gated.append((d_o, S["o_sign"], grp_samples) if grp_samples else (d_o, S["o_sign"]))   # dx += d_o * [o > 0], added by joint_dagg below
     elif cfg.residual == "identity":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
-                                     sign_mask=S["o_sign"], grp_rows=grp_rows)
+                                     sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
         dx_live = True
     else:
         du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train,
-                                      sign_mask=S["o_sign"], grp_rows=grp_rows)
+                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True

@@ -102,10 +102,20 @@ __device__ __forceinline__ void store4(float* ptr, f32x4 val, int stream) {
     if (stream) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(ptr));
     else *reinterpret_cast<f32x4*>(ptr) = val;
 }
+// four values -> four bfloat16 (round to nearest even: v_cvt_pk_bf16_f32, the same rounding the bf16 kernels apply when they stage an
+// f32 tensor), one 8-byte store.  HALF-PRECISION STORAGE of a tensor that only bf16 MFMA staging reads (math mode bf16: G, the temporal
+// conv's input, and dU, its output gradient): the consumer then copies the bytes instead of converting them, and moves half of them.
+__device__ __forceinline__ void store4_bf16(unsigned short* ptr, f32x4 val, int stream) {
+    const u32x2 h = __builtin_bit_cast(u32x2, pack_bf16(val));
+    if (stream) __builtin_nontemporal_store(h, reinterpret_cast<u32x2*>(ptr));
+    else *reinterpret_cast<u32x2*>(ptr) = h;
+}
 // ---- forward epilogue ----------------------------------------------------------------------------------------
 // MASK: also writes the sign bits of the result (bit e%8 of byte e/8 = [out[e] > 0]) for the backward passes, which then
 // read 1/32 of an activation instead of `out`; a lane pair shares a byte (n4 is even, host check).
-template <int RES, bool MASK>
+// O16: `out` is a bfloat16 tensor (store4_bf16; ld_out == C); the sign image is that of the f32 values (a value that rounds to zero
+// keeps its sign bit: the backward gates exactly as with f32 storage).
+template <int RES, bool MASK, bool O16 = false>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
                                                      float* out, unsigned char* mask, long long n4, int C, int relu, int stream, int ld_out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
@@ -126,7 +136,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float
             for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
         }
         // (ld_out != C: the result goes into a channel window of a wider tensor -- MS-G3D's branch concatenation)
-        store4(ld_out == C ? out + i * 4 : out + (i * 4 / C) * ld_out + c, y, stream);
+        if constexpr (O16) store4_bf16(reinterpret_cast<unsigned short*>(out) + i * 4, y, stream);
+        else store4(ld_out == C ? out + i * 4 : out + (i * 4 / C) * ld_out + c, y, stream);
         if (MASK) {
             const int nib = (y[0] > 0.f ? 1 : 0) | (y[1] > 0.f ? 2 : 0) | (y[2] > 0.f ? 4 : 0) | (y[3] > 0.f ? 8 : 0);
             const int other = __shfl_xor(nib, 1);
@@ -200,7 +211,8 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
 }
 
 // ---- backward pass 2: apply -----------------------------------------------------------------------------------
-template <int RES, bool MASKED>
+// O16: `da` is a bfloat16 tensor (the gradient of the temporal conv's output, read only by bf16 MFMA staging)
+template <int RES, bool MASKED, bool O16 = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* out,
                                                                const unsigned char* mask, const float* a,
                                                                const float* va, const float* b, const float* vb,
@@ -222,7 +234,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
             ga = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
                  ah * (*reinterpret_cast<const f32x4*>(sums + C + c) * inv_m);
         }
-        store4(da + i * 4, ga * sc_a, stream);
+        if constexpr (O16) store4_bf16(reinterpret_cast<unsigned short*>(da) + i * 4, ga * sc_a, stream);
+        else store4(da + i * 4, ga * sc_a, stream);
         if (RES != 0 && db) {
             f32x4 gb = dp;
             if (RES == 2) {
@@ -407,8 +420,9 @@ static int check_elem(const char* what, long long rows, int C, int res_mode, con
 }
 
 static int bn_act_impl(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
-                       unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, int ld_out, void* stream) {
+                       unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, int ld_out, void* stream, bool o16 = false) {
     FGCN_REQUIRE(a && vec_a && out, FGCN_E_BADARG, "bn_act: null pointer");
+    FGCN_REQUIRE(!o16 || ld_out == C, FGCN_E_BADARG, "bn_act: a bfloat16 output is contiguous (ld_out == C)");
     if (int e = check_elem("bn_act", rows, C, res_mode, b, vec_b)) return e;
     FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
                  "bn_act: 16-byte alignment");
@@ -420,7 +434,11 @@ static int bn_act_impl(const float* a, const float* vec_a, const float* b, const
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_ACT(RES_)                                                                                         \
     do {                                                                                                          \
-        if (sign_mask)                                                                                            \
+        if (o16 && sign_mask)                                                                                     \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, true, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
+        else if (o16)                                                                                             \
+            hipLaunchKernelGGL((bn_act_kernel<RES_, false, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
+        else if (sign_mask)                                                                                       \
             hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
         else                                                                                                      \
             hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
@@ -476,7 +494,7 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
                                  const float* a, const float* vec_a, const float* b, const float* vec_b,
                                  const float* sums, float* da, float* db,
                                  long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
-                                 int ld_dout, void* stream, int grp_rows = 0) {
+                                 int ld_dout, void* stream, int grp_rows = 0, bool o16 = false) {
     FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: %lld rows are not whole groups of %d", rows, grp_rows);
     FGCN_REQUIRE(dout && vec_a && da && (!relu || out || sign_mask) && (!train || (a && sums)), FGCN_E_BADARG,
@@ -492,8 +510,12 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
 #define FGCN_BN_APP(RES_, M_)                                                                                      \
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                       da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows)
+    do {                                                                                                           \
+        if (o16) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_, true>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
+                                    da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows);     \
+        else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
+                                da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows);         \
+    } while (0)
     if (res_mode == 0 || !db) {
         if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
     } else if (res_mode == 1) {
@@ -643,6 +665,18 @@ extern "C" int fgcn_row_softmax_bwd(const float* da, const float* c, float* ds, 
 extern "C" int fgcn_bn_act(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
                            unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream) {
     return bn_act_impl(a, vec_a, b, vec_b, out, sign_mask, rows, C, res_mode, relu, C, stream);
+}
+extern "C" int fgcn_bn_act_h(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned short* out_h,
+                             unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream) {
+    return bn_act_impl(a, vec_a, b, vec_b, reinterpret_cast<float*>(out_h), sign_mask, rows, C, res_mode, relu, C, stream, true);
+}
+extern "C" int fgcn_bn_act_bwd_apply_h(const float* dout, int grp_rows, const float* out, const unsigned char* sign_mask,
+                                       const float* a, const float* vec_a, const float* b, const float* vec_b,
+                                       const float* sums, unsigned short* da_h, float* db,
+                                       long long rows, int C, int res_mode, int relu, int train, int db_accumulate, void* stream) {
+    FGCN_REQUIRE(grp_rows >= 0, FGCN_E_BADARG, "bn_act_bwd_apply_h: grp_rows=%d", grp_rows);
+    return bn_act_bwd_apply_impl(dout, out, sign_mask, a, vec_a, b, vec_b, sums, reinterpret_cast<float*>(da_h), db, rows, C, res_mode, relu,
+                                 train, db_accumulate, C, stream, grp_rows, true);
 }
 extern "C" int fgcn_bn_act_bwd_reduce(const float* dout, const float* out, const unsigned char* sign_mask,
                                       const float* a, const float* vec_a, const float* b, const float* vec_b,

@@ -338,8 +338,13 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // WR = wave rows: 2 = waves 2 x 2 over (128 rows x 64 NT columns); 4 = waves 4 x 1 over (192 rows x 32 NT columns), the form for 64
 // output columns (NT = 2): every image fragment then feeds FOUR 16-column units instead of two (half the LDS fragment reads per MFMA --
 // the 2 x 2 form at 64 columns reads 12 KB of fragments per 48 MFMAs and wave) and the halo image is re-staged 2.04x instead of 2.56x.
-template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false>   // STR: non-temporal output stores (stream_out)
+// IN16 (NP = 1): `in` is a BFLOAT16 tensor (half-precision storage of the conv's input, written by its producer: fgcn_bn_act_h /
+// fgcn_bn_act_bwd_apply_h) -- the image rows are copied, 8 bytes per four channels, instead of fetched as f32 and rounded here.  The staged
+// bytes are the same either way (one round-to-nearest-even per value), so the results are bit-identical to the f32-input form; the row
+// traffic through L2 -- what bounds this kernel in math mode bf16, where the matrix work is a sixth -- halves.
+template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false, bool IN16 = false>   // STR: non-temporal output stores (stream_out)
 __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+    static_assert(!IN16 || (NP == 1 && !FIN), "bfloat16 input: the one-part kernel without the fused input stage");
     static_assert(!(STR && EPI == 3), "an accumulating epilogue stores plainly");
     static_assert(WR == 2 || (WR == 4 && KC == 32 && !FIN), "wave arrangement: 2 x 2, or 4 x 1 for the tap form");
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
@@ -487,6 +492,11 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
 #pragma unroll
         for (int i = 0; i < NST; ++i)
             if (i >= lo && i < hi && i < nstage) {
+                if constexpr (IN16) {     // four bfloat16 = 8 bytes (every byte offset of the f32 form halves; the descriptor is the bf16 tensor's)
+                    const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, src_off[i] == OOB ? OOB : src_off[i] >> 1, (unsigned)kc * 2, 0));
+                    stage[i] = f32x4{__builtin_bit_cast(float, h2[0]), __builtin_bit_cast(float, h2[1]), 0.f, 0.f};
+                    continue;
+                }
                 stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
                 if constexpr (FIN)
                     stage2[i] = buf_load4(__builtin_amdgcn_make_buffer_rsrc((void*)p.fin_res, 0, p.in_bytes, 0x00020000), src_off[i],
@@ -538,6 +548,10 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                     split2h_x4(stage[i] * a_scale, ph, pm);
                     *reinterpret_cast<u32x2*>(dst) = ph;
                     *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                    continue;
+                }
+                if constexpr (IN16) {                // already bfloat16: a copy
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, stage[i][0]), __builtin_bit_cast(unsigned, stage[i][1])};
                     continue;
                 }
                 split3_x4(stage[i], ph, pm, pl);
@@ -791,14 +805,42 @@ extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
     return (int)cdiv((long long)B * Tv * V, halo_tile_rows(V));
 }
 
-extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
-                               int B, int Th, int V, int K, int N, int ld_in, int ld_out,
-                               int T_in_full, int in_s, int in_o, int Th_in,
-                               int T_out_full, int out_s, int out_o,
-                               int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
-                               const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
-                               unsigned char* fin_mask, unsigned* in_amax, void* stream) {
+// one instantiation of the split kernel (LDS opt-in once per instantiation: not a stream operation, stays out of graph captures); the
+// bfloat16-input form exists for the one-part tap kernel only
+template <int NT, int KC, int NP, int EPI, bool FIN, int WR, bool STR>
+static void halo_k32_launch(bool in16, dim3 grid, size_t lds, hipStream_t s, const HaloP& p) {
+    constexpr int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
+    if constexpr (NP == 1 && !FIN && KC == 32) {
+        if (in16) {
+            static bool opted16 = false;
+            if (!opted16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+                opted16 = true;
+            }
+            hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, true>), grid, dim3(256), lds, s, p);
+            return;
+        }
+    }
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        opted = true;
+    }
+    hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR>), grid, dim3(256), lds, s, p);
+}
+
+static int tconv_halo_impl(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
+                           int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                           int T_in_full, int in_s, int in_o, int Th_in,
+                           int T_out_full, int out_s, int out_o,
+                           int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                           const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
+                           unsigned char* fin_mask, unsigned* in_amax, void* stream, bool in16) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
+    FGCN_REQUIRE(!in16 || (fgcn::math_mode() == FGCN_MATH_BF16 && !(fin_vec || fin_res || fin_out || fin_mask) && !(taps == 1 && K % 64 == 0)),
+                 FGCN_E_BADARG, "tconv_halo_h: a bfloat16 input needs math mode bf16, the tap form and no fused input stage");
     const bool fin = fin_vec || fin_res || fin_out || fin_mask;
     FGCN_REQUIRE(!fin || !fgcn::f16x2_products(), FGCN_E_BADARG, "tconv_halo: the fused input stage is not built for the f16x2 products");
     FGCN_REQUIRE(!fin || (fin_vec && fin_res && fin_out && fin_mask && fgcn_tconv_halo_bn_sums() && !bn_a && !accumulate && taps > 1 &&
@@ -824,7 +866,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     const int mm = fgcn::math_mode();
     // FGCN_MATH_BF16X3 / FGCN_MATH_BF16: w4 is the split form (fgcn_pack_split3: three bf16 parts of [tap][K/8][N][8]) = 6 bytes
     // per weight; the bf16 mode reads part 0 only (the round-to-nearest-even bf16 of the weight)
-    const long long in_bytes = (long long)B * T_in_full * V * ld_in * 4;
+    const long long in_bytes = (long long)B * T_in_full * V * ld_in * (in16 ? 2 : 4);
     const bool two = fgcn::f16x2_products();                                                // FGCN_PACK_SPLIT2H weights: two f16 parts
     const long long w_bytes = (long long)taps * K * N * (mm != FGCN_MATH_F32 ? (two ? 4 : 6) : 4);   // split form in both bf16 modes
     const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
@@ -900,17 +942,7 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
         const int epi = bn_a ? 2 : (accumulate ? 3 : 0);     // epilogue form (compile time, see the kernel)
         const bool stream_k = fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes
-        const int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;   // (opt-in beyond the default dynamic-LDS limit, once per instantiation)
-#define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_)                                                               \
-    do {                                                                                                                 \
-        static bool opted = false;                                                                                       \
-        if (!opted) {                                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);                            \
-            opted = true;                                                                                                \
-        }                                                                                                                \
-        hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>), grid, dim3(256), lds_k, s, p); \
-    } while (0)
+#define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_) halo_k32_launch<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>(in16, grid, lds_k, s, p)
 #define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
     do {                                                                                                                 \
         if (EPI_ != 3 && stream_k) FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, (EPI_ != 3));                            \
@@ -985,4 +1017,29 @@ extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, con
     }
 #undef FGCN_HALO_LAUNCH
     return launch_status("tconv_halo");
+}
+
+extern "C" int fgcn_tconv_halo(const float* in, float* out, const float* w4, const float* bias, float* stat_partials,
+                               int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                               int T_in_full, int in_s, int in_o, int Th_in,
+                               int T_out_full, int out_s, int out_o,
+                               int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                               const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
+                               unsigned char* fin_mask, unsigned* in_amax, void* stream) {
+    return tconv_halo_impl(in, out, w4, bias, stat_partials, B, Th, V, K, N, ld_in, ld_out, T_in_full, in_s, in_o, Th_in, T_out_full, out_s, out_o,
+                           taps, tb, tc, accumulate, bn_a, bn_mask, bn_vec, fin_vec, fin_res, fin_out, fin_mask, in_amax, stream, false);
+}
+
+// The same convolution with a BFLOAT16 input tensor (math mode bf16 only; ld_in in elements): half-precision storage of the conv's input,
+// written by fgcn_bn_act_h (G) / fgcn_bn_act_bwd_apply_h (dU).  Bit-identical to fgcn_tconv_halo on the f32 tensor those kernels would
+// have written (the bf16 kernel rounds its input to bfloat16, to nearest even, as it stages it).
+extern "C" int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const float* w4, const float* bias, float* stat_partials,
+                                 int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                                 int T_in_full, int in_s, int in_o, int Th_in,
+                                 int T_out_full, int out_s, int out_o,
+                                 int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                                 const float* bn_vec, void* stream) {
+    return tconv_halo_impl(reinterpret_cast<const float*>(in_h), out, w4, bias, stat_partials, B, Th, V, K, N, ld_in, ld_out, T_in_full, in_s, in_o,
+                           Th_in, T_out_full, out_s, out_o, taps, tb, tc, accumulate, bn_a, bn_mask, bn_vec, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, stream, true);
 }

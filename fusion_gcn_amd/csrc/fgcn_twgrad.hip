@@ -40,6 +40,7 @@ struct TWgradP {
     // (profiles/r03_bf16x3_step_traffic_by_kernel.txt).  Id b takes virtual id (b % 8) * per_xcd + b / 8, tile fastest: the tiles of
     // a row split run side by side on one XCD and share its L2.
     int per_xcd, tiles_xy, n_split;
+    int in16;                           // a and g are BFLOAT16 tensors (tconv_wgrad_x3_kernel<.., NP = 1, .., IN16 = true>; ld_a / ld_g in elements)
 };
 
 // TN = out-channel tile (64: waves = 2 column tiles x 2 row halves of the stage, 128: 4 column tiles).
@@ -216,9 +217,22 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 // 9 taps, V = 25) the a planes are a circular image: row q of the sample's frame view lives at slot q & (ring_rows - 1), a stage
 // adds its X3_R new rows (prefetched across the previous stage's MFMAs), and only the first stage of a sample (or of the
 // workgroup's share) fills the (NTAP-1) V older rows, synchronously.  Fragment addresses wrap per read.
-template <int NTAP, int TN, bool CH, int NP, int WV = 8, bool RING = false>
+// IN16 (NP = 1, tap mode): a and g are BFLOAT16 tensors (half-precision storage written by fgcn_bn_act_h / fgcn_bn_act_bwd_apply_h): the
+// stage is copied, 8 bytes per four values, instead of fetched as f32 and rounded here -- the same staged bytes, half the reads.
+template <int NTAP, int TN, bool CH, int NP, int WV = 8, bool RING = false, bool IN16 = false>
 __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kernel(TWgradP p) {
     static_assert(!(RING && CH), "the circular window is the tap mode's");
+    static_assert(!IN16 || (NP == 1 && !CH), "bfloat16 inputs: the one-part kernel, tap mode");
+    constexpr unsigned ES = IN16 ? 2u : 4u;                       // bytes per stored element
+    // four values of a row: 16 bytes of f32, or 8 bytes of bfloat16 parked in the first two components
+    auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
+        if constexpr (IN16) {
+            const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+            return f32x4{__builtin_bit_cast(float, h[0]), __builtin_bit_cast(float, h[1]), 0.f, 0.f};
+        } else {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+        }
+    };
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NT = 64 * WV;
     constexpr int X3_R = x3_rows(TN, WV), X3_SG = x3_sg(TN);
@@ -276,14 +290,14 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 const int f = (int)((unsigned)row / (unsigned)V);
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
-            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + chunk * 32 + a_c4 * 4) * 4u : OOB;
-            if (RING || i * RA < win) sa[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + chunk * 32 + a_c4 * 4) * ES : OOB;
+            if (RING || i * RA < win) sa[i] = ld4(ra, off);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + g_row + GRP * i;
-            const unsigned off = (g_cok && r < TVg) ? (unsigned)((n * TVg + r) * p.ld_g + n0 + g_c4 * 4) * 4u : OOB;
-            sg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+            const unsigned off = (g_cok && r < TVg) ? (unsigned)((n * TVg + r) * p.ld_g + n0 + g_c4 * 4) * ES : OOB;
+            sg[i] = ld4(rg, off);
         }
     };
     auto put_a = [&](int slot, f32x4 v) {
@@ -293,6 +307,10 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
             split2h_x4(v * sc_a, ph, pm);
             *reinterpret_cast<u32x2*>(d) = ph;
             *reinterpret_cast<u32x2*>(d + a_plane) = pm;
+            return;
+        }
+        if constexpr (IN16) {                                     // already bfloat16: a copy
+            *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])};
             return;
         }
         split3_x4(v, ph, pm, pl);
@@ -316,8 +334,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 const int f = (int)((unsigned)row / (unsigned)V);
                 row = (f * p.a_s + p.a_o) * V + (row - f * V);
             }
-            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + a_c4 * 4) * 4u : OOB;
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            const unsigned off = ok ? (unsigned)((n * p.T_a_full * V + row) * p.ld_a + k0 + a_c4 * 4) * ES : OOB;
+            const f32x4 v = ld4(ra, off);
             if (wr < cnt) put_a(q & rmask, v);
         }
     };
@@ -341,6 +359,10 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 split2h_x4(sg[i] * sc_g, ph, pm);
                 *reinterpret_cast<u32x2*>(d) = ph;
                 *reinterpret_cast<u32x2*>(d + g_plane) = pm;
+                continue;
+            }
+            if constexpr (IN16) {
+                *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])};
                 continue;
             }
             split3_x4(sg[i], ph, pm, pl);
@@ -509,6 +531,24 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 #undef FGCN_TW_LAUNCH
 }
 
+// one instantiation of the split kernel; the bfloat16-input form exists for the one-part kernel in tap mode
+template <int NTAP, int TN, bool CH, int NP, int WV, bool RING>
+static void twx_go(const TWgradP& p, dim3 grid, size_t lds, hipStream_t s) {
+    if constexpr (NP == 1 && !CH) {
+        if (p.in16) {
+            static bool opted16 = false;
+            if (!opted16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_wgrad_x3_kernel<NTAP, TN, CH, NP, WV, RING, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                opted16 = true;
+            }
+            hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN, CH, NP, WV, RING, true>), grid, dim3(64 * WV), lds, s, p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN, CH, NP, WV, RING>), grid, dim3(64 * WV), lds, s, p);
+}
+
 template <int NTAP, bool CH>
 static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hipStream_t s) {
     static_assert(!CH || NTAP <= 6, "chunk mode: at most 6 (128 columns) / 3 (64 columns) chunks fit the staging passes");
@@ -533,8 +573,7 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
     const bool two = !one && p.a_amax && p.g_amax;                // f16x2 products (twgrad_launch cleared the pointers otherwise)
     const bool half = twgrad_x3_waves(N, CH ? 1 : 0) == 4;
     const bool ring = RG && p.ring_rows > 0;
-#define FGCN_TWX_GO(TN_, NP_, WV_, RING_) \
-    hipLaunchKernelGGL((tconv_wgrad_x3_kernel<NTAP, TN_, CH, NP_, WV_, RING_>), grid, dim3(64 * WV_), lds, s, p)
+#define FGCN_TWX_GO(TN_, NP_, WV_, RING_) twx_go<NTAP, TN_, CH, NP_, WV_, RING_>(p, grid, lds, s)
 #define FGCN_TWX_LAUNCH(TN_)                                                                                    \
     do {                                                                                                        \
         if (ring) {                                                                                             \
@@ -557,8 +596,10 @@ static void launch_twgrad_x3(const TWgradP& p, int N, dim3 grid, size_t lds, hip
 static int twgrad_launch(const float* a, const float* g, float* partial, int B, int T_g, int V, int K, int N,
                          int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a, int nacc, int chunk_mode,
                          int shift0, int tap0, int tap_step, int taps_total, int nsplit, const unsigned* a_amax,
-                         const unsigned* g_amax, void* stream, const char* what) {
+                         const unsigned* g_amax, void* stream, const char* what, bool in16 = false) {
     FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "%s: null pointer", what);
+    FGCN_REQUIRE(!in16 || (fgcn::math_mode() == FGCN_MATH_BF16 && !chunk_mode), FGCN_E_BADARG,
+                 "%s: bfloat16 inputs need math mode bf16 and the tap form", what);
     FGCN_REQUIRE(B > 0 && T_g > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0 && nsplit > 0 && nsplit <= 65535,
                  FGCN_E_BADARG, "%s: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", what, B, T_g, V, K, N, nsplit);
     FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_a % 4 == 0 && ld_g % 4 == 0 && ld_a >= K && ld_g >= N, FGCN_E_ALIGN,
@@ -566,7 +607,7 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     FGCN_REQUIRE(aligned16(a) && aligned16(g), FGCN_E_ALIGN, "%s: 16-byte alignment", what);
     FGCN_REQUIRE(a_s >= 1 && a_o >= 0 && Th_a > 0 && (long long)(Th_a - 1) * a_s + a_o < T_a_full, FGCN_E_BADARG,
                  "%s: frame view exceeds the tensor", what);
-    const long long a_bytes = (long long)B * T_a_full * V * ld_a * 4, g_bytes = (long long)B * T_g * V * ld_g * 4;
+    const long long a_bytes = (long long)B * T_a_full * V * ld_a * (in16 ? 2 : 4), g_bytes = (long long)B * T_g * V * ld_g * (in16 ? 2 : 4);
     const int parts = twgrad_parts(N, chunk_mode);
     const bool x3 = twgrad_use_x3(N, chunk_mode);
     const long long p_bytes = (long long)nsplit * parts * taps_total * K * N * 4;
@@ -577,6 +618,8 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
     p.B = B; p.T_g = T_g; p.V = V; p.K = K; p.N = N; p.ld_a = ld_a; p.ld_g = ld_g;
     p.T_a_full = T_a_full; p.a_s = a_s; p.a_o = a_o; p.Th_a = Th_a;
     p.shift0 = shift0; p.tap0 = tap0; p.tap_step = tap_step; p.taps_total = taps_total;
+    p.in16 = in16 ? 1 : 0;
+    FGCN_REQUIRE(!in16 || x3, FGCN_E_BADARG, "%s: bfloat16 inputs need the split kernel", what);
     p.stage_rows = x3 ? x3_rows(N <= 64 ? 64 : 128, twgrad_x3_waves(N, chunk_mode)) : (N <= 64 ? 128 : 64);
     p.stages_per_sample = (int)cdiv((long long)T_g * V, p.stage_rows);
     p.total_stages = B * p.stages_per_sample;
@@ -656,6 +699,18 @@ extern "C" int fgcn_tconv_wgrad(const float* a, const float* g, float* partial, 
                  FGCN_E_BADARG, "tconv_wgrad: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
     return twgrad_launch(a, g, partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s, a_o, Th_a, ntaps, 0, shift0, tap0,
                          tap_step, taps_total, nsplit, a_amax, g_amax, stream, "tconv_wgrad");
+}
+
+// The same weight gradient from BFLOAT16 tensors a (the conv's input) and g (the gradient of its output), math mode bf16 only; ld_a / ld_g in
+// elements.  Bit-identical to fgcn_tconv_wgrad on the f32 tensors the producers would have written (operands are rounded to bfloat16, to
+// nearest even, when staged either way).
+extern "C" int fgcn_tconv_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
+                                  int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
+                                  int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream) {
+    FGCN_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_step >= 1 && tap0 >= 0 && tap0 + (ntaps - 1) * tap_step < taps_total,
+                 FGCN_E_BADARG, "tconv_wgrad_h: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
+    return twgrad_launch(reinterpret_cast<const float*>(a_h), reinterpret_cast<const float*>(g_h), partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full,
+                         a_s, a_o, Th_a, ntaps, 0, shift0, tap0, tap_step, taps_total, nsplit, nullptr, nullptr, stream, "tconv_wgrad_h", true);
 }
 
 /* in-channel chunks (32 channels each = one accumulator) per wave for a 1x1 weight gradient: a divisor of the chunk

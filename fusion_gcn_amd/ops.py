@@ -239,6 +239,12 @@ def _chk(t: torch.Tensor, name: str) -> None:
                              f"contiguous={t.is_contiguous()}")
 
 
+def _chk16(t: torch.Tensor, name: str) -> None:
+    """a half-precision-storage tensor (include/fgcn.h, the `_h` entry points): contiguous bfloat16 on the device"""
+    if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise _lib.FgcnError(f"{name}: expected a contiguous bfloat16 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
 def _p(t: Optional[torch.Tensor], coff: int = 0) -> Optional[int]:
     return None if t is None else t.data_ptr() + 4 * coff
 
@@ -349,7 +355,14 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     g = relu(inp * scale + shift + shortcut), formed while the image is staged; g and its sign image (``bn_act``'s layout) are
     written as by-products -- the block's ``bn_act`` pass in front of the conv folded into it (split-bf16 kernel, taps > 1)."""
     ensure_device()
-    _chk(inp, "tconv_halo.in"), _chk(out, "tconv_halo.out")
+    in16 = inp.dtype == torch.bfloat16           # half-precision storage of the conv's input (math mode bf16: fgcn_tconv_halo_h)
+    if in16:
+        _chk16(inp, "tconv_halo.in")
+        if get_math_mode() != "bf16" or fuse_in is not None or amax_out is not None:
+            raise _lib.FgcnError("tconv_halo: a bfloat16 input needs math mode bf16 and takes neither a fused input stage nor amax_out")
+    else:
+        _chk(inp, "tconv_halo.in")
+    _chk(out, "tconv_halo.out")
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
     split = get_math_mode() in SPLIT_MODES       # the weights then are the pack_split3 form
@@ -389,6 +402,11 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
             raise _lib.FgcnError("tconv_halo: fuse_in needs the (4, K) BatchNorm vector, a shortcut and an output like the input "
                                  "(contiguous, K channels) and the uint8 sign image of numel / 8 bytes")
         fin = (_p(vec), _p(res), _p(g), g_sign.data_ptr())
+    if in16:
+        check(lib.fgcn_tconv_halo_h(inp.data_ptr(), _p(out), w4.data_ptr(), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
+                                    T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, _stream()),
+              "fgcn_tconv_halo_h")
+        return part
     check(lib.fgcn_tconv_halo(_p(inp), _p(out), w4.data_ptr(), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
                               T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, *fin,
                               None if amax_out is None else amax_out.data_ptr(), _stream()),
@@ -575,7 +593,13 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     a: (B, T_a, V, K) conv input, g: (B, T_g, V, N) gradient of the conv output.  ``all_taps`` False forces the
     per-tap kernel (measured slower: 105-107 vs 107-126 TFLOP/s at 64-256 channels, 111-113 for the strided ones)."""
     ensure_device()
-    _chk(a, "tconv_wgrad.a"), _chk(g, "tconv_wgrad.g")
+    in16 = a.dtype == torch.bfloat16 or g.dtype == torch.bfloat16     # half-precision storage of both operands (fgcn_tconv_wgrad_h)
+    if in16:
+        _chk16(a, "tconv_wgrad.a"), _chk16(g, "tconv_wgrad.g")
+        if get_math_mode() != "bf16" or amax is not None or all_taps is False:
+            raise _lib.FgcnError("tconv_wgrad: bfloat16 operands need math mode bf16 and the all-taps kernel")
+    else:
+        _chk(a, "tconv_wgrad.a"), _chk(g, "tconv_wgrad.g")
     B, T_a, V, K = a.shape
     Bg, T_g, Vg, N = g.shape
     pad = (taps - 1) // 2
@@ -590,6 +614,8 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
         all_taps = True
     ok_taps = TWGRAD_TAPS if get_math_mode() == "f32" else TWGRAD_TAPS_SPLIT
     if not all_taps or any(n not in ok_taps for _, _, n, _ in calls):
+        if in16:
+            raise _lib.FgcnError(f"tconv_wgrad: bfloat16 operands with {taps} taps, stride {stride}: no all-taps kernel for this pass")
         return rows_wgrad(a, g, K=K, N=N, tmap=conv_tmap(taps, stride), out=out, accumulate=accumulate, wide=False,
                           conv_param=conv_param)
     lib = _lib.load()
@@ -603,6 +629,10 @@ def tconv_wgrad(a: torch.Tensor, g: torch.Tensor, *, taps: int, stride: int = 1,
     partial = torch.empty((slabs, taps, K, N), device=a.device, dtype=torch.float32)
     for par, tap0, ntaps, shift0 in calls:
         th_a = (T_a - par + stride - 1) // stride
+        if in16:
+            check(lib.fgcn_tconv_wgrad_h(a.data_ptr(), g.data_ptr(), _p(partial), B, T_g, V, K, N, K, N, T_a, stride, par, th_a,
+                                         ntaps, shift0, tap0, stride, taps, nsplit, _stream()), "fgcn_tconv_wgrad_h")
+            continue
         am = (None, None) if amax is None else (amax[0].data_ptr(), amax[1].data_ptr())
         if am[0] is not None and lib.fgcn_get_math_mode() == 2:
             check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
@@ -855,10 +885,11 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float = 1e-5) ->
 
 
 def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = None, vec_b: Optional[torch.Tensor] = None,
-           relu: bool = True, out: Optional[torch.Tensor] = None, sign_mask: bool = False):
+           relu: bool = True, out: Optional[torch.Tensor] = None, sign_mask: bool = False, out_bf16: bool = False):
     """act(a*scale_a + shift_a + [b | b*scale_b + shift_b]).  ``sign_mask``: -> (out, mask) where mask holds one bit per
     element, [out > 0] (uint8, numel/8; None when the element count is not a multiple of 8) -- what the backward's
-    ReLU gate reads instead of ``out``."""
+    ReLU gate reads instead of ``out``.  ``out_bf16``: the result is stored as bfloat16 (round to nearest even; fgcn_bn_act_h) -- for a
+    tensor that only the bf16 kernels' staging reads (math mode bf16: the temporal conv's input)."""
     ensure_device()
     _chk(a, "bn_act.a")
     C = a.shape[-1]
@@ -867,12 +898,17 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
     if b is not None and b.shape != a.shape:
         raise _lib.FgcnError(f"bn_act: residual shape {tuple(b.shape)} != {tuple(a.shape)}")
     if out is None:
-        out = torch.empty_like(a)
+        out = torch.empty_like(a, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(a)
     mask = None
     if sign_mask and relu and a.numel() % 8 == 0:
         mask = torch.empty(a.numel() // 8, device=a.device, dtype=torch.uint8)
-    check(_lib.load().fgcn_bn_act(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(out), _p(mask), rows, C, res_mode, int(relu),
-                                  _stream()), "fgcn_bn_act")
+    if out_bf16:
+        _chk16(out, "bn_act.out")
+        check(_lib.load().fgcn_bn_act_h(_p(a), _p(vec_a), _p(b), _p(vec_b), out.data_ptr(), _p(mask), rows, C, res_mode, int(relu),
+                                        _stream()), "fgcn_bn_act_h")
+    else:
+        check(_lib.load().fgcn_bn_act(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(out), _p(mask), rows, C, res_mode, int(relu),
+                                      _stream()), "fgcn_bn_act")
     return (out, mask) if sign_mask else out
 
 
@@ -903,8 +939,9 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
                sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True,
-               partials: Optional[torch.Tensor] = None, grp_rows: int = 0):
+               partials: Optional[torch.Tensor] = None, grp_rows: int = 0, da_bf16: bool = False):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
+    ``da_bf16``: da is stored as bfloat16 (fgcn_bn_act_bwd_apply_h: the gradient of the temporal conv's output in math mode bf16).
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
     ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass.
     ``grp_rows`` > 0: ``dout`` is (rows / grp_rows, C), one row per group of consecutive rows -- the gradient of ``bn_act_pool``'s
@@ -935,10 +972,14 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
                                              tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
         sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
         reduce_sum(partials.view(tiles, -1), sums.view(-1))
-    da = torch.empty_like(a)
+    da = torch.empty_like(a, dtype=torch.bfloat16) if da_bf16 else torch.empty_like(a)
     if res_mode != 0 and db is None and need_db:   # need_db=False (identity residual): the caller adds the gated gradient itself
         db = torch.empty_like(a)
-    if grp_rows:
+    if da_bf16:
+        check(lib.fgcn_bn_act_bwd_apply_h(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums),
+                                          da.data_ptr(), _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
+              "fgcn_bn_act_bwd_apply_h")
+    elif grp_rows:
         check(lib.fgcn_bn_act_bwd_apply_g(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums), _p(da),
                                           _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
               "fgcn_bn_act_bwd_apply_g")

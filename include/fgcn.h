@@ -166,6 +166,32 @@ int fgcn_rows_gemm_tiles(long long M);
  *   stat_partials: float[fgcn_tconv_halo_tiles(B, Th, Th_in, V)][2][N] or NULL (sums of the values written, after
  *   accumulation).  Tensors must be smaller than 2 GiB (32-bit buffer offsets). */
 int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
+
+/* ---- half-precision STORAGE of the temporal convolution's operands (math mode FGCN_MATH_BF16 only; round 6) -----------------------------
+ * The reference's MixedPrecisionStep (torch_src/session/procedures/step.py:55-78, autocast) keeps conv inputs in half precision.  In
+ * FGCN_MATH_BF16 the matrix kernels round their f32 inputs to bfloat16 (to nearest even) as they stage them; for the two tensors that
+ * ONLY such staging reads -- G, the temporal conv's input (fgcn_bn_act), and dU, the gradient of its output (fgcn_bn_act_bwd_apply) --
+ * the producer can write the bfloat16 values directly: the consumers copy instead of convert and move half the bytes, and every result
+ * is BIT-IDENTICAL to the f32-storage form (one rounding per value either way).  `_h` entry points take / write `unsigned short`
+ * (bfloat16 bit patterns), contiguous (rows, C); everything else is as in the entry point without the suffix. */
+int fgcn_bn_act_h(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned short* out_h,
+                  unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, void* stream);
+/* grp_rows >= 0 (0: dout is (rows, C); > 0: one row per group, as fgcn_bn_act_bwd_apply_g) */
+int fgcn_bn_act_bwd_apply_h(const float* dout, int grp_rows, const float* out, const unsigned char* sign_mask,
+                            const float* a, const float* vec_a, const float* b, const float* vec_b,
+                            const float* sums, unsigned short* da_h, float* db,
+                            long long rows, int C, int res_mode, int relu, int train, int db_accumulate, void* stream);
+/* fgcn_tconv_halo with a bfloat16 input tensor (ld_in in elements; the tap form, no fused input stage) */
+int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const float* w4, const float* bias, float* stat_partials,
+                      int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                      int T_in_full, int in_s, int in_o, int Th_in,
+                      int T_out_full, int out_s, int out_o,
+                      int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
+                      const float* bn_vec, void* stream);
+/* fgcn_tconv_wgrad with bfloat16 tensors a and g (ld_a / ld_g in elements) */
+int fgcn_tconv_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
+                       int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
+                       int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
 /* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
  * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
  * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel

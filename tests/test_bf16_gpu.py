@@ -297,3 +297,104 @@ def test_embedding_forward_tile_form_bf16(V, T, cin, ic, B):
     emb, part = ops.emb_fwd_tile(gpu(x), ops.pack_split3(gpu(w.reshape(1, cin, 6 * ic))), gpu(bias), ic=ic)
     assert rel_l2(emb.cpu().numpy(), want.numpy()) < TOL
     assert rel_l2(part.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_s.numpy()) < 2e-4
+
+
+# ---- half-precision STORAGE of the temporal conv's operands (include/fgcn.h, the `_h` entry points; paths.half_conv_operands) -------------
+@pytest.mark.parametrize("rows,C,res", [(1000, 64, 0), (777, 128, 1), (2048, 256, 2), (50, 8, 1)])
+def test_bn_act_and_its_backward_write_bfloat16(rows, C, res):
+    """fgcn_bn_act_h / fgcn_bn_act_bwd_apply_h: the bfloat16 tensor they write is the round-to-nearest-even of what the f32 entry
+    points write, bit for bit; the sign image and the sums are those of the f32 values."""
+    from fusion_gcn_amd import ops
+    a, b = gpu(rnd(rows, C, seed=1)), gpu(rnd(rows, C, seed=2))
+    mk = lambda seed: gpu(torch.stack([rnd(C, seed=seed), rnd(C, seed=seed + 1).abs() + 0.5, rnd(C, seed=seed + 2), rnd(C, seed=seed + 3)]))  # noqa: E731
+    va, vb = mk(10), mk(20)
+    args = (a, va, None if res == 0 else b, vb if res == 2 else None)
+    want, m0 = ops.bn_act(*args, relu=True, sign_mask=True)
+    got, m1 = ops.bn_act(*args, relu=True, sign_mask=True, out_bf16=True)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, want.to(torch.bfloat16))
+    assert (m0 is None and m1 is None) or torch.equal(m0, m1)
+    dout = gpu(rnd(rows, C, seed=3))
+    kw = dict(res_mode=res, sign_mask=m0, need_db=res != 0)
+    da0, db0, s0 = ops.bn_act_bwd(dout, want, a, va, args[2], args[3], **kw)
+    da1, db1, s1 = ops.bn_act_bwd(dout, want, a, va, args[2], args[3], da_bf16=True, **kw)
+    assert da1.dtype == torch.bfloat16 and torch.equal(da1, da0.to(torch.bfloat16)) and torch.equal(s0, s1)
+    assert (db0 is None and db1 is None) or torch.equal(db0, db1)
+
+
+@pytest.mark.parametrize("B,T,V,C,N,kt,s", [(2, 20, 25, 64, 64, 9, 1), (2, 21, 25, 128, 128, 9, 2), (3, 13, 18, 256, 256, 9, 1),
+                                            (2, 30, 27, 64, 128, 5, 1), (1, 9, 32, 128, 64, 3, 1), (2, 12, 22, 64, 64, 9, 2)])
+def test_halo_conv_and_weight_gradient_from_bfloat16_tensors(B, T, V, C, N, kt, s):
+    """fgcn_tconv_halo_h (forward, data gradient; strided passes) and fgcn_tconv_wgrad_h on bfloat16 tensors against the f32 entry
+    points on the f32 tensors holding the same (bfloat16-representable) values: bit for bit -- the kernels stage the same bytes."""
+    from fusion_gcn_amd import block, ops
+    from fusion_gcn_amd.packing import Form, Seg
+    pad = (kt - 1) // 2
+    Tp = (T - 1) // s + 1
+    g16 = gpu(rnd(B, T, V, C, seed=5)).to(torch.bfloat16)
+    du16 = gpu(rnd(B, Tp, V, N, seed=6)).to(torch.bfloat16)
+    g32, du32 = g16.float(), du16.float()
+    wt = gpu(rnd(N, C, kt, 1, seed=7, scale=(kt * C) ** -0.5))
+    # the block's own packed forms of the temporal weight (forward + data gradient), built as block.pack_weights does
+    t_seg = lambda **kw: [Seg(wt, st_tap=1, st_k=kt, st_n=C * kt, klen=C, nlen=N, **kw)]          # noqa: E731  (kt, c, o)
+    tt_seg = lambda **kw: [Seg(wt, st_tap=1, st_k=C * kt, st_n=kt, klen=N, nlen=C, **kw)]         # noqa: E731  (kt, o, c)
+    from fusion_gcn_amd.packing import PackedWeights
+    F = {}
+    if s == 1:
+        F["t4"] = Form("split3", kt, C, N, t_seg(tlen=kt))
+        F["t_t4"] = Form("split3", kt, N, C, tt_seg(tlen=kt))
+    else:
+        for par, tag in ((0, "e"), (1, "o")):
+            n_par = (kt - par + 1) // 2
+            F[f"t4_{tag}"] = Form("split3", n_par, C, N, t_seg(tlen=n_par, tap0=par, tap_step=2))
+            F[f"t_t4_{tag}"] = Form("split3", n_par, N, C, tt_seg(tlen=n_par, tap0=par, tap_step=2))
+    W = PackedWeights(F, wt.device)
+    bias = gpu(rnd(N, seed=8))
+    outs = []
+    for g, du in ((g32, du32), (g16, du16)):
+        u = torch.empty(B, Tp, V, N, device=dev())
+        part = block.temporal_fwd(g, u, W, bias, kt, s, stats=True)
+        dg = torch.zeros(B, T, V, C, device=dev())
+        block.temporal_dgrad(du, dg, W, kt, s)
+        gw = ops.tconv_wgrad(g, du, taps=kt, stride=s, conv_param=(1, C))
+        outs.append((u, part, dg, gw))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    # ... and the values are the convolution of the rounded operands (the f32 call is pinned to float64 by the tests above)
+    want = conv_ref(g32.double().cpu(), bf(wt[..., 0].permute(2, 1, 0).cpu()), kt, s, Tp, bias.double().cpu())
+    assert rel_l2(outs[1][0].cpu().numpy(), want.numpy()) < TOL
+
+
+def test_model_step_is_bit_identical_with_half_precision_conv_operands():
+    """The whole model in math mode bf16 with G and dU stored as bfloat16 (the default there) against f32 storage: logits, loss and
+    every gradient bit for bit -- the layout change moves bytes, not values.  All ten blocks: strided ones, down / residual convs."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.loss import cross_entropy
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    torch.manual_seed(11)
+    model = Model((2, 40, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev()).train()
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, "gcn1"):
+                m.gcn1.bn.weight.fill_(1.0)
+    x = torch.randn(3, 2, 40, 25, 3, device=dev())
+    y = torch.randint(0, 60, (3,), device=dev())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(half):
+        model.load_state_dict(sd)
+        with ops.context("bf16") as c:
+            c.paths.half_conv_operands["bf16"] = half
+            for p in model.parameters():
+                p.grad = None
+            logits = model(x)
+            loss = cross_entropy(logits, y)
+            loss.backward()
+            return logits.detach().clone(), loss.detach().clone(), [p.grad.clone() for p in model.parameters()]
+    l0, s0, g0 = run(False)
+    l1, s1, g1 = run(True)
+    assert ops.paths().half_conv_operands["bf16"] is True              # the default of the mode
+    assert torch.equal(l0, l1) and torch.equal(s0, s1)
+    for a_, b_ in zip(g0, g1):
+        assert torch.equal(a_, b_)
