@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             if (i >= lo && i < hi && i < nstage) {
                 if constexpr (IN16) {     // four bfloat16 = 8 bytes (every byte offset of the f32 form halves; the descriptor is the bf16 tensor's)
                     const u32x2 h2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, src_off[i] == OOB ? OOB : src_off[i] >> 1, (unsigned)kc * 2, 0));
-                    stage[i] = f32x4{__builtin_bit_cast(float, h2[0]), __builtin_bit_cast(float, h2[1]), 0.f, 0.f};
+                    const unsigned b0 = h2[0], b1 = h2[1];
+                    stage[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
                     continue;
                 }
                 stage[i] = buf_load4(rin, src_off[i], (unsigned)kc * 4);
@@ -551,7 +552,9 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                     continue;
                 }
                 if constexpr (IN16) {                // already bfloat16: a copy
-                    *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, stage[i][0]), __builtin_bit_cast(unsigned, stage[i][1])};
+                    // (element -> scalar first: __builtin_bit_cast on an ext-vector ELEMENT reads element 0 with hipcc 7.2)
+                    const float e0 = stage[i][0], e1 = stage[i][1];
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
                     continue;
                 }
                 split3_x4(stage[i], ph, pm, pl);

@@ -228,7 +228,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
     auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
         if constexpr (IN16) {
             const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
-            return f32x4{__builtin_bit_cast(float, h[0]), __builtin_bit_cast(float, h[1]), 0.f, 0.f};
+            const unsigned b0 = h[0], b1 = h[1];      // (element -> scalar first: bit casts of ext-vector ELEMENTS read element 0 with hipcc 7.2)
+            return f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
         } else {
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
         }
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
             return;
         }
         if constexpr (IN16) {                                     // already bfloat16: a copy
-            *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])};
+            const float e0 = v[0], e1 = v[1];
+            *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
             return;
         }
         split3_x4(v, ph, pm, pl);
@@ -362,7 +364,8 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kerne
                 continue;
             }
             if constexpr (IN16) {
-                *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])};
+                const float e0 = sg[i][0], e1 = sg[i][1];
+                *reinterpret_cast<u32x2*>(d) = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
                 continue;
             }
             split3_x4(sg[i], ph, pm, pl);
