@@ -355,11 +355,11 @@ def spec_demb(ic: int) -> List[dict]:
     return out
 
 
-def half_conv_operands_ok(W, kt: int, s: int, T: int, train: bool, o_) -> bool:
-    """Whether this block keeps G and dU in bfloat16 (paths.half_conv_operands): math mode bf16, a training step (the eval-mode bias
+def half_storage_ok(W, kt: int, s: int, T: int, train: bool, o_) -> bool:
+    """Whether this block keeps G and dU in bfloat16 (paths.half_storage): math mode bf16, a training step (the eval-mode bias
     gradient reads dU as f32), and the three consumers on their bfloat16-input kernels -- the halo conv forward and data gradient
     (the routes temporal_fwd / temporal_dgrad take for these sizes) and the all-taps weight gradient (tap counts it is built for)."""
-    if not (train and ops.get_math_mode() == "bf16" and o_.get("half_conv_operands", "bf16")) or kt <= 1:
+    if not (train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16")) or kt <= 1:
         return False
     pad = (kt - 1) // 2
     per_pass = [kt] if s == 1 else [len([j for j in range(kt) if (j - pad) % s == par]) for par in range(s)]
@@ -424,9 +424,9 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         part = ops.rows_gemm(agg, W["d"].unsqueeze(0), y, K=3 * cin, N=cout, bias=W["d_b"], stats=train)
     vec_y = _bn_vec(part, B * T * V, P, bufs, "gcn1.bn", train)
     # math mode bf16, training: G (the temporal conv's input) is stored as bfloat16 -- only bf16 MFMA staging reads it (the conv and its
-    # weight gradient), so the values those kernels multiply are the same and they copy half the bytes (paths.half_conv_operands)
+    # weight gradient), so the values those kernels multiply are the same and they copy half the bytes (paths.half_storage)
     kt = P["tcn1.conv.weight"].shape[2]
-    half = half_conv_operands_ok(W, kt, s, T, train, o_)
+    half = half_storage_ok(W, kt, s, T, train, o_)
     if cfg.has_down:
         d = new(B, T, V, cout)
         part = pw_gemm(x, W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
@@ -605,9 +605,14 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
+    # math mode bf16, training, both consumers of dy on their tile kernels: dy is stored as bfloat16 (only their staging reads it)
+    wgrad_tile = (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
+                  and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2))
+    half_dy = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and wgrad_tile and tile_ok and x.shape[3] == cin
+                   and S["g_sign"] is not None)
     if cfg.has_down:
         dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train,
-                                      sign_mask=S["g_sign"])
+                                      sign_mask=S["g_sign"], da_bf16=half_dy)
         G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         pw_gemm(dd, W, "down_t", dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
@@ -615,11 +620,11 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         G["gcn1.down.0.bias"] = bias_grad(dd, cout)
     elif gate_in_dagg:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
-                                     sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None)
+                                     sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
         gated.append((dg, S["g_sign"]))            # dx += dg * [g > 0]
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
-                                     db_accumulate=dx_live, sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None)
+                                     db_accumulate=dx_live, sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
         dx_live = True
     G["gcn1.bn.weight"], G["gcn1.bn.bias"] = sums[1], sums[0]
 
@@ -627,6 +632,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     a_hat = S["a_hat"]
     c3 = 3 * cin
     bwd_tile = tile_ok and x.shape[3] == cin and (not gated or len(gated) == 2)
+    if half_dy and not bwd_tile:     # (cannot happen: the gated list holds none or both shortcuts by construction)
+        raise ops._lib.FgcnError("block backward: dy was stored as bfloat16 but the fused spatial backward is not taken")
     dagg, dy_amax = None, False
     if not bwd_tile:
         # dagg = dy . Wd first: in math mode f16x2 the row GEMM records max |dy| (slot 3), the operand scale of conv_d's weight gradient
@@ -634,8 +641,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         dy_amax = f16x2 and pw_routed(W, "d_t", dy, cout)
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
-    if (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
-            and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2)):
+    if wgrad_tile:
         gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
     elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.get("fused_agg_wgrad_max_cout", ops.get_math_mode()):
         # agg = x . A^ is formed in registers and contracted with dy at once: never written

@@ -84,10 +84,13 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
 // NE: gated addends of dx (0 or 2; 2 only without accumulation)
 // NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3), 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS
 // layout keeps room for three parts, the first is used)
-template <bool ACC, int MAXS, int NE = 0, int NP = 3>
+// IN16 (NP = 1): dy is a BFLOAT16 tensor (half-precision storage written by fgcn_bn_act_bwd_apply_h; ld_dy in elements): its rows are
+// copied into the staging plane instead of fetched as f32 and rounded -- the same staged bytes, half the reads
+template <bool ACC, int MAXS, int NE = 0, int NP = 3, bool IN16 = false>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     static_assert(NE == 0 || (NE == 2 && !ACC), "gated addends: both identity shortcuts, dx not live before");
     static_assert(NP == 1 || NP == 3, "parts");
+    static_assert(!IN16 || NP == 1, "bfloat16 dy: the one-part kernel");
     constexpr int LP = 3;                                            // parts the LDS layout has room for
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -188,8 +191,14 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = srow + 64 * i;
-            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * 4u : OOB;
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+            const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(kc + 4 * sg)) * (IN16 ? 2u : 4u) : OOB;
+            if constexpr (IN16) {                                // four bfloat16 = 8 bytes, parked in the first two components
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rdy, off, 0, 0));
+                const unsigned b0 = h[0], b1 = h[1];             // (element -> scalar before a bit cast: hipcc 7.2 reads element 0 otherwise)
+                stg[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+            } else {
+                stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+            }
         }
     };
     // weight fragment of this wave's tile i (16 dagg channels) of group cg at contraction channel kc: lane (l15, g4) holds k = kc + 8 g4 + j
@@ -229,7 +238,10 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 for (int i = 0; i < 2; ++i) {
                     const int r = srow + 64 * i;
                     u32x2 parts[NP];
-                    if constexpr ((FGCN_PROBE_SB & 256) != 0) {
+                    if constexpr (IN16) {                        // already bfloat16: a copy
+                        const float e0 = stg[i][0], e1 = stg[i][1];
+                        parts[0] = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+                    } else if constexpr ((FGCN_PROBE_SB & 256) != 0) {
 #pragma unroll
                         for (int pl = 0; pl < NP; ++pl)
                             parts[pl] = u32x2{__builtin_bit_cast(unsigned, stg[i][(pl) & 3]), __builtin_bit_cast(unsigned, stg[i][(pl + 1) & 3])};
@@ -472,7 +484,19 @@ extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
 static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                    int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                    int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
-                                   const unsigned char* mask2, int extra1_group, void* stream);
+                                   const unsigned char* mask2, int extra1_group, void* stream, bool dy16 = false);
+
+// dy as a BFLOAT16 tensor (math mode bf16 only; ld_dy in elements): fgcn_spatial_bwd_tile (extra1_group = 0) / fgcn_spatial_bwd_tile_g
+// otherwise unchanged; bit-identical to the f32-dy call on the tensor fgcn_bn_act_bwd_apply would have written
+extern "C" int fgcn_spatial_bwd_tile_h(const unsigned short* dy_h, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                                       int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                                       const float* extra1, int extra1_group, const unsigned char* mask1, const float* extra2,
+                                       const unsigned char* mask2, void* stream) {
+    FGCN_REQUIRE(extra1_group >= 0 && (extra1_group == 0 || (extra1 && B % extra1_group == 0 && !accumulate)), FGCN_E_BADARG,
+                 "spatial_bwd_tile_h: %d samples are not whole groups of %d", B, extra1_group);
+    return spatial_bwd_tile_launch(reinterpret_cast<const float*>(dy_h), x, a_hat, w3, dx, partial, B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx,
+                                   a_hat_batched, accumulate, extra1, mask1, extra2, mask2, extra1_group, stream, true);
+}
 
 extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                      int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
@@ -496,8 +520,9 @@ extern "C" int fgcn_spatial_bwd_tile_g(const float* dy, const float* x, const fl
 static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                    int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                    int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
-                                   const unsigned char* mask2, int extra1_group, void* stream) {
+                                   const unsigned char* mask2, int extra1_group, void* stream, bool dy16) {
     const bool gated = extra1 != nullptr;
+    FGCN_REQUIRE(!dy16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "spatial_bwd_tile_h: a bfloat16 dy needs math mode bf16");
     FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0), FGCN_E_BADARG,
                  "spatial_bwd_tile: gated addends come in pairs with their sign images, without accumulation, on contiguous (B, T, V, Cin) tensors");
     FGCN_REQUIRE(!gated || (aligned16(extra1) && aligned16(extra2)), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte aligned addends");
@@ -510,7 +535,7 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
                  "spatial_bwd_tile: row strides");
     FGCN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w3) && aligned16(dx), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte alignment");
     const long long rows = (long long)B * T * V;
-    const long long dy_bytes = rows * ld_dy * 4, x_bytes = rows * ld_x * 4, dx_bytes = rows * ld_dx * 4;
+    const long long dy_bytes = rows * ld_dy * (dy16 ? 2 : 4), x_bytes = rows * ld_x * 4, dx_bytes = rows * ld_dx * 4;
     const long long plane = (long long)3 * Cin * Cout * 2;
     FGCN_REQUIRE(dy_bytes < 0x7FFF0000ll && x_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "spatial_bwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -548,20 +573,21 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
     const dim3 grid((unsigned)(B * p.nseg));
     hipStream_t s = (hipStream_t)stream;
     const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
-#define FGCN_SB_GO4(ACC_, MS_, NE_, NP_)                                                                               \
+#define FGCN_SB_GO4(ACC_, MS_, NE_, NP_, I16_)                                                                         \
     do {                                                                                                                \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_>),  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_, I16_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_LDS);                         \
             opted = true;                                                                                               \
         }                                                                                                               \
-        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_>), grid, dim3(512), SB_LDS, s, p);           \
+        hipLaunchKernelGGL((spatial_bwd_tile_x3_kernel<ACC_, MS_, NE_, NP_, I16_>), grid, dim3(512), SB_LDS, s, p);     \
     } while (0)
 #define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
     do {                                                                                                                \
-        if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1);                                                                   \
-        else FGCN_SB_GO4(ACC_, MS_, NE_, 3);                                                                            \
+        if (one_part && dy16) FGCN_SB_GO4(ACC_, MS_, NE_, 1, true);                                                     \
+        else if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1, false);                                                       \
+        else FGCN_SB_GO4(ACC_, MS_, NE_, 3, false);                                                                     \
     } while (0)
 #define FGCN_SB_GO(ACC_, MS_)                                                                                          \
     do {                                                                                                                \

@@ -74,10 +74,12 @@ __device__ __forceinline__ void swt_for_slots(Fn&& fn, std::integer_sequence<int
 // slot loop put an s_waitcnt vmcnt(0) and register copies on its back edge: every request made ahead was waited for one slot later))
 // NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3), 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout
 // keeps room for three parts, the first is used)
-template <int CT, int NT, int NSLOT, int NP = 3>
+// IN16 (NP = 1): dy is a BFLOAT16 tensor (fgcn_bn_act_bwd_apply_h; ld_dy in elements): its rows are copied into the plane, half the reads
+template <int CT, int NT, int NSLOT, int NP = 3, bool IN16 = false>
 __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p) {
     constexpr int LP = 3, FP = 8 / CT;
     static_assert(NP == 1 || NP == 3, "parts");
+    static_assert(!IN16 || NP == 1, "bfloat16 dy: the one-part kernel");
     constexpr int RS = swt_rs<NT>(), PL = SWT_ROWS * RS;
     constexpr int GPR = NT * 4, RPP = 512 / GPR, NPASS = SWT_ROWS / RPP;    // 16-byte groups per row, rows per pass, passes
     static_assert(SWT_ROWS % RPP == 0 && NSLOT % 2 == 0, "staging passes / slot pairs");
@@ -118,8 +120,14 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
         const int nrows_ = g < g_hi ? min(F, p.T - t0_) * V : 0;
         const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
         const int r = srow + RPP * i;
-        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(o0 + 4 * sg)) * 4u : OOB;
-        stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_dy + (unsigned)(o0 + 4 * sg)) * (IN16 ? 2u : 4u) : OOB;
+        if constexpr (IN16) {                                    // four bfloat16 = 8 bytes, parked in the first two components
+            const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rdy, off, 0, 0));
+            const unsigned b0 = h[0], b1 = h[1];                 // (element -> scalar before a bit cast: hipcc 7.2 reads element 0 otherwise)
+            stg[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+        } else {
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+        }
     };
     // x values of frame slot s of pair g for this wave: lane (c = l15, g4) <- x[(f, v = 8 g4 + j)][c0 + l15], j = 0 .. 7; requested PF slots
     // ahead (PF = 2: two register sets, by slot parity)
@@ -157,7 +165,12 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
         for (int i = 0; i < NPASS; ++i) {
             const int r = srow + RPP * i;
             u32x2 parts[NP];
-            splitn_x4<NP>(stg[i], parts);
+            if constexpr (IN16) {                                // already bfloat16: a copy
+                const float e0 = stg[i][0], e1 = stg[i][1];
+                parts[0] = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+            } else {
+                splitn_x4<NP>(stg[i], parts);
+            }
             unsigned char* dst = Im + r * RS + sg * 8;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PL) = parts[pl];
@@ -315,9 +328,26 @@ extern "C" int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int C
     return swt_geom(B, T, V, Cin, Cout).nseg;
 }
 
+static int spatial_wgrad_tile_launch(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, bool dy16);
+
 extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
                                        int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream) {
+    return spatial_wgrad_tile_launch(x, dy, a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy, a_hat_batched, stream, false);
+}
+
+// dy as a BFLOAT16 tensor (math mode bf16 only; ld_dy in elements); otherwise fgcn_spatial_wgrad_tile, bit-identical to its result on the
+// f32 tensor fgcn_bn_act_bwd_apply would have written
+extern "C" int fgcn_spatial_wgrad_tile_h(const float* x, const unsigned short* dy_h, const float* a_hat, float* partial, int B, int T, int V,
+                                         int Cin, int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream) {
+    return spatial_wgrad_tile_launch(x, reinterpret_cast<const float*>(dy_h), a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy, a_hat_batched, stream,
+                                     true);
+}
+
+static int spatial_wgrad_tile_launch(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, bool dy16) {
     FGCN_REQUIRE(x && dy && a_hat && partial, FGCN_E_BADARG, "spatial_wgrad_tile: null pointer");
+    FGCN_REQUIRE(!dy16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "spatial_wgrad_tile_h: a bfloat16 dy needs math mode bf16");
     FGCN_REQUIRE(fgcn_spatial_wgrad_tile_available(V, Cin, Cout), FGCN_E_BADARG,
                  "spatial_wgrad_tile: V=%d Cin=%d Cout=%d in math mode %d not supported (split-bf16 mode, 16 <= V <= %d, channels in 64s)", V,
                  Cin, Cout, fgcn::math_mode(), FGCN_MAX_V);
@@ -334,25 +364,26 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
     p.x = x, p.dy = dy, p.a_hat = a_hat, p.partial = partial;
     p.B = B, p.T = T, p.V = V, p.Cin = Cin, p.Cout = Cout, p.ld_x = ld_x, p.ld_dy = ld_dy, p.a_batched = a_hat_batched;
     p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
-    p.x_bytes = (unsigned)(rows * ld_x * 4), p.dy_bytes = (unsigned)(rows * ld_dy * 4);
+    p.x_bytes = (unsigned)(rows * ld_x * 4), p.dy_bytes = (unsigned)(rows * ld_dy * (dy16 ? 2 : 4));
     p.p_bytes = (unsigned)((long long)g.nseg * 3 * Cin * Cout * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
-#define FGCN_SWT4(CT_, NT_, NS_, NP_)                                                                                            \
+#define FGCN_SWT4(CT_, NT_, NS_, NP_, I16_)                                                                                      \
     do {                                                                                                                          \
         static bool attr = false;                                                                                                 \
         if (!attr) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_, I16_>),   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, swt_lds<NT_>());                                \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_>), grid, dim3(512), swt_lds<NT_>(), s, p);           \
+        hipLaunchKernelGGL((spatial_wgrad_tile_x3_kernel<CT_, NT_, NS_, NP_, I16_>), grid, dim3(512), swt_lds<NT_>(), s, p);     \
     } while (0)
     const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
-#define FGCN_SWT(CT_, NT_, NS_)                    \
-    do {                                           \
-        if (one_part) FGCN_SWT4(CT_, NT_, NS_, 1); \
-        else FGCN_SWT4(CT_, NT_, NS_, 3);          \
+#define FGCN_SWT(CT_, NT_, NS_)                                    \
+    do {                                                           \
+        if (one_part && dy16) FGCN_SWT4(CT_, NT_, NS_, 1, true);   \
+        else if (one_part) FGCN_SWT4(CT_, NT_, NS_, 1, false);     \
+        else FGCN_SWT4(CT_, NT_, NS_, 3, false);                   \
     } while (0)
     // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
     const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;

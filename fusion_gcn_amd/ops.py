@@ -788,7 +788,14 @@ def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *,
     result layout.  x (B,T,V,ld_x), dy (B,T,V,ld_dy), mats (B or 1, 3, V, V); ``cin`` / ``cout``: the leading channels of wider
     rows that take part (default: all)."""
     ensure_device()
-    _chk(x, "spatial_wgrad_tile.x"), _chk(dy, "spatial_wgrad_tile.dy"), _chk(mats, "spatial_wgrad_tile.mats")
+    dy16 = dy.dtype == torch.bfloat16            # half-precision storage of dy (math mode bf16: fgcn_spatial_wgrad_tile_h)
+    if dy16:
+        _chk16(dy, "spatial_wgrad_tile.dy")
+        if get_math_mode() != "bf16":
+            raise _lib.FgcnError("spatial_wgrad_tile: a bfloat16 dy needs math mode bf16")
+    else:
+        _chk(dy, "spatial_wgrad_tile.dy")
+    _chk(x, "spatial_wgrad_tile.x"), _chk(mats, "spatial_wgrad_tile.mats")
     B, T, V, ld_x = x.shape
     ld_dy = dy.shape[3]
     Cin, Cout = ld_x if cin is None else int(cin), ld_dy if cout is None else int(cout)
@@ -801,8 +808,12 @@ def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *,
     if slabs <= 0:
         raise _lib.FgcnError(f"spatial_wgrad_tile: sizes not supported: V={V} Cin={Cin} Cout={Cout}")
     partial = torch.empty((slabs, 1, 3 * Cin, Cout), device=x.device, dtype=torch.float32)
-    check(lib.fgcn_spatial_wgrad_tile(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
-                                      int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile")
+    if dy16:
+        check(lib.fgcn_spatial_wgrad_tile_h(_p(x), dy.data_ptr(), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
+                                            int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile_h")
+    else:
+        check(lib.fgcn_spatial_wgrad_tile(_p(x), _p(dy), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
+                                          int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile")
     return _reduce_slabs(partial, 1, 3 * Cin, Cout, out, accumulate, conv_param)
 
 
@@ -1196,7 +1207,14 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
         if tuple(e.shape) != want or m.dtype != torch.uint8 or m.numel() * 8 != x.numel() or not m.is_cuda or (group and x.shape[0] % group):
             raise _lib.FgcnError(f"spatial_bwd_tile: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
     ex = [(_p(e), m.data_ptr()) for e, m, *_ in gated] + [(None, None)] * (2 - len(gated))
-    _chk(dy, "spatial_bwd_tile.dy"), _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
+    dy16 = dy.dtype == torch.bfloat16            # half-precision storage of dy (math mode bf16: fgcn_spatial_bwd_tile_h)
+    if dy16:
+        _chk16(dy, "spatial_bwd_tile.dy")
+        if get_math_mode() != "bf16":
+            raise _lib.FgcnError("spatial_bwd_tile: a bfloat16 dy needs math mode bf16")
+    else:
+        _chk(dy, "spatial_bwd_tile.dy")
+    _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
     B, T, V, Cin = x.shape
     Cout = dy.shape[3]
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, Cout // 8, 3 * Cin, 8) or not w3.is_contiguous()
@@ -1208,6 +1226,11 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     _mode_products()
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
+    if dy16:
+        check(lib.fgcn_spatial_bwd_tile_h(dy.data_ptr(), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
+                                          dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1],
+                                          _stream()), "fgcn_spatial_bwd_tile_h")
+        return partial
     if group:
         check(lib.fgcn_spatial_bwd_tile_g(_p(dy), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
                                           dx.shape[3], int(a_hat.shape[0] == B), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1], _stream()),

@@ -70,12 +70,12 @@ class PathOptions:
     emb_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
     emb_fwd_tile: bool = True
     emb_fwd_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
-    # -- math mode bf16 (BASELINE config 5): half-precision STORAGE of the temporal conv's operands -- G (its input) and dU (the gradient of
-    # its output) are written as bfloat16 by the BatchNorm passes that produce them and copied by the conv / its data and weight
-    # gradients (include/fgcn.h, the `_h` entry points).  Bit-identical to f32 storage (the bf16 kernels round these tensors to bfloat16
+    # -- math mode bf16 (BASELINE config 5): half-precision STORAGE of the tensors that only bf16 MFMA staging reads -- G (the temporal conv's
+    # input), dU (the gradient of its output) and dY (the gradient of the spatial stage's output) are written as bfloat16 by the BatchNorm
+    # passes that produce them and copied by their consumers (include/fgcn.h, the `_h` entry points).  Bit-identical to f32 storage (the bf16 kernels round these tensors to bfloat16
     # when they stage them anyway); the halo conv, bound by its row traffic through L2 in this mode, moves half of it
     # (probe: 34.38 -> 32.9 ms from the conv's input alone, profiles/r06_ab_bf16_half_storage.txt).  Only the mode's own entry counts.
-    half_conv_operands: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
+    half_storage: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
     # -- the model's last block: the epilogue pass carries the global average pooling, and its backward reads the pooled gradient as one
     # row per clip (profiles/r05_ab_pool_epilogue_and_split_sums.txt, r05_ab_pool_backward_rows.txt: 53.74 / 53.74 -> 53.62 / 53.50 ms)
     pool_epilogue: bool = True

@@ -192,6 +192,15 @@ int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const float* w4, c
 int fgcn_tconv_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
                        int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                        int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
+/* ... and of dY, the gradient of the spatial stage's output (written by fgcn_bn_act_bwd_apply_h; read only by the staging of the two tile
+ * kernels of the spatial backward): fgcn_spatial_bwd_tile / _g (extra1_group = 0: the plain form) and fgcn_spatial_wgrad_tile with dy as
+ * bfloat16 (ld_dy in elements) */
+int fgcn_spatial_bwd_tile_h(const unsigned short* dy_h, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
+                            int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                            const float* extra1, int extra1_group, const unsigned char* mask1, const float* extra2,
+                            const unsigned char* mask2, void* stream);
+int fgcn_spatial_wgrad_tile_h(const float* x, const unsigned short* dy_h, const float* a_hat, float* partial, int B, int T, int V,
+                              int Cin, int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream);
 /* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
  * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
  * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel

@@ -299,7 +299,7 @@ def test_embedding_forward_tile_form_bf16(V, T, cin, ic, B):
     assert rel_l2(part.double().sum(1)[:, :, :V, :V].cpu().numpy(), want_s.numpy()) < 2e-4
 
 
-# ---- half-precision STORAGE of the temporal conv's operands (include/fgcn.h, the `_h` entry points; paths.half_conv_operands) -------------
+# ---- half-precision STORAGE of the temporal conv's operands (include/fgcn.h, the `_h` entry points; paths.half_storage) -------------
 @pytest.mark.parametrize("rows,C,res", [(1000, 64, 0), (777, 128, 1), (2048, 256, 2), (50, 8, 1)])
 def test_bn_act_and_its_backward_write_bfloat16(rows, C, res):
     """fgcn_bn_act_h / fgcn_bn_act_bwd_apply_h: the bfloat16 tensor they write is the round-to-nearest-even of what the f32 entry
@@ -385,7 +385,7 @@ def test_model_step_is_bit_identical_with_half_precision_conv_operands():
     def run(half):
         model.load_state_dict(sd)
         with ops.context("bf16") as c:
-            c.paths.half_conv_operands["bf16"] = half
+            c.paths.half_storage["bf16"] = half
             for p in model.parameters():
                 p.grad = None
             logits = model(x)
@@ -394,7 +394,36 @@ def test_model_step_is_bit_identical_with_half_precision_conv_operands():
             return logits.detach().clone(), loss.detach().clone(), [p.grad.clone() for p in model.parameters()]
     l0, s0, g0 = run(False)
     l1, s1, g1 = run(True)
-    assert ops.paths().half_conv_operands["bf16"] is True              # the default of the mode
+    assert ops.paths().half_storage["bf16"] is True              # the default of the mode
     assert torch.equal(l0, l1) and torch.equal(s0, s1)
     for a_, b_ in zip(g0, g1):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 256, 256, 2), (32, 5, 128, 64, 1)])
+def test_spatial_backward_tile_kernels_from_a_bfloat16_dy(V, T, cin, cout, B):
+    """fgcn_spatial_bwd_tile_h / fgcn_spatial_wgrad_tile_h on a bfloat16 dy against the f32 entry points on the f32 tensor holding the
+    same values: bit for bit (plain, accumulating, gated and per-group-gated forms of the fused backward)."""
+    from fusion_gcn_amd import ops
+    x, a = gpu(rnd(B, T, V, cin, seed=41)), gpu(rnd(B, 3, V, V, seed=42, scale=0.3))
+    dy16 = gpu(rnd(B, T, V, cout, seed=43)).to(torch.bfloat16)
+    dy32 = dy16.float()
+    w3 = ops.pack_split3(gpu(rnd(1, cout, 3 * cin, seed=44, scale=cout ** -0.5)))
+    base = gpu(rnd(B, T, V, cin, seed=45))
+    for acc in (False, True):
+        d0, d1 = base.clone(), base.clone()
+        p0 = ops.spatial_bwd_tile(dy32, x, a, w3, d0, accumulate=acc)
+        p1 = ops.spatial_bwd_tile(dy16, x, a, w3, d1, accumulate=acc)
+        assert torch.equal(d0, d1) and torch.equal(p0, p1), acc
+    if (B * T * V * cin) % 8 == 0:
+        e1, e2 = gpu(rnd(B, T, V, cin, seed=46)), gpu(rnd(B, T, V, cin, seed=47))
+        m1 = torch.randint(0, 256, (B * T * V * cin // 8,), device=dev(), dtype=torch.uint8)
+        m2 = torch.randint(0, 256, (B * T * V * cin // 8,), device=dev(), dtype=torch.uint8)
+        eg = gpu(rnd(B, cin, seed=48))
+        for gated in ([(e1, m1), (e2, m2)], [(eg, m1, 1), (e2, m2)]):
+            d0, d1 = torch.empty_like(base), torch.empty_like(base)
+            p0 = ops.spatial_bwd_tile(dy32, x, a, w3, d0, accumulate=False, gated=gated)
+            p1 = ops.spatial_bwd_tile(dy16, x, a, w3, d1, accumulate=False, gated=gated)
+            assert torch.equal(d0, d1) and torch.equal(p0, p1)
+    assert torch.equal(ops.spatial_wgrad_tile(x, dy32, a), ops.spatial_wgrad_tile(x, dy16, a))
+    assert torch.equal(ops.spatial_wgrad_tile(x, dy32, a[:1]), ops.spatial_wgrad_tile(x, dy16, a[:1]))
