@@ -131,6 +131,8 @@ SIGNATURES = {
     "fgcn_bn_finalize": (_I, [_P, _I, _LL, _P, _P, _P, _P, _F, _F, _P, _I, _P]),
     "fgcn_bn_eval_coeffs": (_I, [_P, _P, _P, _P, _F, _P, _I, _P]),
     "fgcn_bn_act": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
+    "fgcn_tconv_halo_bn_relu": (_I, [_P] * 7 + [_I] * 10 + [_P]),
+    "fgcn_spatial_fwd_tile_bn_relu": (_I, [_P] * 7 + [_I] + [_P] + [_I] * 8 + [_P]),
     "fgcn_bn_act_h": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
     "fgcn_bn_act_bwd_apply_h": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_tconv_halo_h": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P, _P, _P] + [_P]),

@@ -377,9 +377,11 @@ def _bn_vec(part, count, P, bufs, name, train):
 
 
 def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
-                  cfg: BlockConfig, train: bool, pool_groups: int = 0):
+                  cfg: BlockConfig, train: bool, pool_groups: int = 0, inference: bool = False):
     """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict).  ``pool_groups`` > 0 (the model's last block): O is
-    not formed, the first result is its mean over the rows of every group of B / pool_groups consecutive samples, (pool_groups, cout)."""
+    not formed, the first result is its mean over the rows of every group of B / pool_groups consecutive samples, (pool_groups, cout).
+    ``inference`` (eval mode, no autograd graph): BatchNorm + shortcut + ReLU run as the EPILOGUES of the two north-star kernels where
+    their inference forms exist (paths.fused_inference) -- no pre-BatchNorm tensors, no bn_act passes, nothing saved for a backward."""
     B, T, V, cx = x.shape
     cout, ic, s = cfg.cout, cfg.ic, cfg.stride
     assert cx == cfg.cx, (cx, cfg.cx)
@@ -413,6 +415,19 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
 
     # -- spatial aggregation + conv_d ------------------------------------------------------------------------------------
+    infer = bool(inference and not train and o_.fused_inference and ops.inference_kernels_available())
+    kt = P["tcn1.conv.weight"].shape[2]
+    if infer and cfg.fused_spatial and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout) and (cfg.has_down or x.shape[3] >= cout):
+        # north-star kernel 1, inference form: aggregation + feature contraction + BatchNorm + shortcut + ReLU in one kernel
+        vec_y = _bn_vec(None, B * T * V, P, bufs, "gcn1.bn", False)
+        d, vec_d = None, None
+        if cfg.has_down:
+            d = new(B, T, V, cout)
+            pw_gemm(x, W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"])
+            vec_d = _bn_vec(None, B * T * V, P, bufs, "gcn1.down.1", False)
+        g = ops.spatial_fwd_tile_bn_relu(x, a_hat, W["d_s3"], W["d_b"], vec_y, Cin=cin, Cout=cout, res=d if cfg.has_down else x, res_vec=vec_d)
+        S.update(y=None, vec_y=vec_y, d=None, vec_d=vec_d, g=g, g_sign=None, half=False)
+        return _temporal_stage(x, g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_)
     if cfg.fused_spatial and o_.spatial_tile and cout >= o_.get("spatial_tile_min_cout", ops.get_math_mode()) and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
         y, part = ops.spatial_fwd_tile(x, a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     elif cfg.fused_spatial:
@@ -447,11 +462,37 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         raise ops._lib.FgcnError("half-precision storage of G needs the sign image (element count a multiple of 8)")
     S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign, half=half)   # *_sign: 1 bit per element, the backward's ReLU gate
 
-    # -- temporal 9x1 conv + BN, residual, ReLU --------------------------------------------------------------------------
+    return _temporal_stage(x, y if fuse_g else g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_, fuse_in=(vec_y, x, g, g_sign) if fuse_g else None)
+
+
+def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_groups: int, infer: bool, kt: int, o_, fuse_in=None):
+    """The second half of block_forward: the temporal conv, its BatchNorm, the block's shortcut and ReLU (agcn.py:49-51,125-136)."""
+    B, T, V, cx = x.shape
+    cout, s = cfg.cout, cfg.stride
+    cin = cx
+    Tp = (T - 1) // s + 1
+    dev = x.device
+    new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+    f16x2 = ops.get_math_mode() == "f16x2"
+    amax = S["amax"]
+    if infer and s == 1 and kt > 1 and "t4" in W and not pool_groups and cfg.residual in ("none", "identity", "conv") and (cfg.residual != "identity" or x.shape[3] == cout):
+        # north-star kernel 2 as the north star states it, inference form: temporal conv + BatchNorm + shortcut + ReLU in one kernel
+        vec_u = _bn_vec(None, B * Tp * V, P, bufs, "tcn1.bn", False)
+        r, vec_r = None, None
+        if cfg.residual == "conv":
+            r = new(B, Tp, V, cout)
+            ops.rows_gemm(x, W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"])
+            vec_r = _bn_vec(None, B * Tp * V, P, bufs, "residual.bn", False)
+        o = new(B, Tp, V, cout)
+        pad = (kt - 1) // 2
+        ops.tconv_halo_bn_relu(g, W["t4"], o, taps=kt, tb=1, tc=-pad, vec=vec_u, bias=P["tcn1.conv.bias"],
+                               res=x if cfg.residual == "identity" else r, res_vec=vec_r)
+        S.update(u=None, vec_u=vec_u, r=None, vec_r=vec_r, o=o, o_sign=None)
+        return o, S
     u = new(B, Tp, V, cout)
     S["g_amax"] = f16x2 and temporal_fwd_records_amax(W, kt, s, T)
-    part = temporal_fwd(y if fuse_g else g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
-                        fuse_in=(vec_y, x, g, g_sign) if fuse_g else None, amax_out=amax[1:2] if S["g_amax"] else None)
+    part = temporal_fwd(g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
+                        fuse_in=fuse_in, amax_out=amax[1:2] if S["g_amax"] else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     epilogue = (lambda a, va, b, vb: ops.bn_act_pool(a, va, b, vb, pool_groups)) if pool_groups else \
@@ -704,7 +745,8 @@ class STBlockFunction(torch.autograd.Function):
         names = param_names(cfg)
         P = dict(zip(names, params))
         pool_groups = holder.get("pool_groups", 0) if holder is not None else 0
-        o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups)
+        inference = bool(holder.get("inference")) if holder is not None else False      # eval mode and no autograd graph (the module says)
+        o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups, inference=inference)
         B, T, V, _ = x.shape
         ctx.pool = (pool_groups, (B, (T - 1) // cfg.stride + 1, V, cfg.cout)) if pool_groups else None
         ctx.zeros = holder.get("zeros") if holder is not None else None      # the block's slice of the model's zero pool (or None)

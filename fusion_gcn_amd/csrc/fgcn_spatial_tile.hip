@@ -42,6 +42,14 @@ struct SpTileP {
     int B, T, V, Cin, Cout, ld_x, ld_y, a_batched;
     int F, tiles_t, tiles_m, tiles_n, per_xcd;
     unsigned x_bytes, y_bytes, w_plane_bytes;
+    // Inference epilogue (spatial_tile_x3_kernel<.., FEP = true>; fgcn_spatial_fwd_tile_bn_relu): with eval-mode BatchNorm the statistics are
+    // constants, so BatchNorm + shortcut + ReLU of the graph convolution (agcn.py:113-115) are the kernel's epilogue and `y` receives
+    // G = relu((acc + bias) * scale + shift + res * rscale + rshift) -- no pre-BatchNorm tensor, no bn_act pass.
+    const float* ep_vec;                // float[4][Cout] of fgcn_bn_eval_coeffs (scale at [2 Cout, 3 Cout), shift at [3 Cout, 4 Cout))
+    const float* ep_res;                // the shortcut operand, rows of ld_res floats (x for an identity block, the down conv's output), or NULL
+    const float* ep_rvec;               // float[4][Cout]: BatchNorm of the shortcut (the down branch), or NULL (identity)
+    int ld_res;
+    unsigned res_bytes;
 };
 
 constexpr int ST_AHB = 80;              // bytes per [w] row of a split A^ plane (32 joints x bf16 + 16 pad: conflict-free b128 reads)
@@ -50,7 +58,8 @@ constexpr int ST_PLANE = 256 * ST_XS;   // one part of the image: two pairs x 12
 
 // STR: non-temporal output stores (fgcn_common.hpp, stream_out); NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3),
 // 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout keeps room for three parts, the first is used)
-template <int NT, int MAXU, bool STR = false, int NP = 3>
+// FEP: the inference epilogue (SpTileP::ep_*) instead of bias + BatchNorm partial sums
+template <int NT, int MAXU, bool STR = false, int NP = 3, bool FEP = false>
 __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     constexpr int LP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     static_assert(NP == 1 || NP == 3, "parts");
@@ -263,6 +272,55 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     // streamed (non-temporal) form wrote 1.45-1.48x the output's bytes -- WRITE_SIZE 0.366 GB per launch for a 0.246 GB tensor, 0.250 GB with
     // plain stores (profiles/r05_pmc_spatial_tile_writes.txt): half-lines left the L2 one by one.  Each unit's sums still run over (mt, r) in
     // the same order: same bits.
+    if constexpr (FEP) {
+        // G = relu((acc + bias) * scale + shift + res * rscale + rshift): per-column constants first, the shortcut values of a row tile
+        // requested one row tile ahead of its stores (two register sets)
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_vec, 0, (unsigned)p.Cout * 16u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_rvec ? p.ep_rvec : p.ep_vec), 0,
+                                                                             p.ep_rvec ? (unsigned)p.Cout * 16u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_res ? (const void*)p.ep_res : (const void*)p.y), 0,
+                                                                              p.ep_res ? p.res_bytes : 0u, 0x00020000);
+        float esc[NU], esh[NU], rsc[NU], rsh[NU];
+        const float res_unit = p.ep_rvec ? 0.f : 1.f;
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            esc[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, coff[nu], (unsigned)p.Cout * 8u, 0));
+            esh[nu] = __builtin_fmaf(bv[nu], esc[nu], __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, coff[nu], (unsigned)p.Cout * 12u, 0)));
+            // (branch-free: without a shortcut BatchNorm the descriptor is empty, the load returns 0 and the scalar addend makes it 1)
+            rsc[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrv, coff[nu], (unsigned)p.Cout * 8u, 0)) + res_unit;
+            rsh[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrv, coff[nu], (unsigned)p.Cout * 12u, 0));   // (no BatchNorm: zero bytes -> 0)
+        }
+        float resv[2][NU][4];
+        auto load_res = [&](int mt, float (&dst)[NU][4]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
+                    const unsigned off = (row < nrows && coff[nu] != OOB) ? (unsigned)((m0 + row) * p.ld_res * 4) + coff[nu] : OOB;
+                    dst[nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, off, 0, 0));
+                }
+        };
+        load_res(0, resv[0]);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            if (mt + 1 < MTW) load_res(mt + 1, resv[(mt + 1) & 1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + r;
+                    const unsigned off = (row < nrows && coff[nu] != OOB) ? (unsigned)((m0 + row) * p.ld_y * 4) + coff[nu] : OOB;
+                    float val = __builtin_fmaf(acc[mt][nu][r], esc[nu], esh[nu]);
+                    val += __builtin_fmaf(resv[mt & 1][nu][r], rsc[nu], rsh[nu]);
+                    val = fmaxf(val, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ry, off, 0, STR ? FGCN_STORE_AUX : 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
@@ -319,9 +377,32 @@ extern "C" int fgcn_spatial_fwd_tile_tiles(int B, int T, int V) {
     return V >= 16 && V <= FGCN_MAX_V ? (int)(B * cdiv(T, sp_tile_frames(V))) : 0;
 }
 
+static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
+                                 float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec);
+
 extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
                                      float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
                                      int a_hat_batched, void* stream) {
+    return spatial_fwd_tile_impl(x, a_hat, w3, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, a_hat_batched, stream, nullptr, nullptr, 0,
+                                 nullptr);
+}
+
+// Inference form of north-star kernel 1: aggregation + 1x1 feature contraction + (eval-mode) BatchNorm + shortcut + ReLU in ONE kernel --
+// g = relu(BN(sum_k conv_d[k](x . A^_k)) + shortcut), agcn.py:103-115 with the BatchNorm's running statistics folded into a per-channel
+// scale / shift (bn_vec = fgcn_bn_eval_coeffs).  res: the shortcut operand (x for an identity block, the down conv's output with its own
+// res_vec) or NULL; rows of ld_res floats.  No pre-BatchNorm tensor is written and nothing is kept for a backward.
+extern "C" int fgcn_spatial_fwd_tile_bn_relu(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* g,
+                                             const float* bn_vec, const float* res, int ld_res, const float* res_vec,
+                                             int B, int T, int V, int Cin, int Cout, int ld_x, int ld_g, int a_hat_batched, void* stream) {
+    FGCN_REQUIRE(bn_vec && aligned16(bn_vec) && (!res || (ld_res >= Cout && ld_res % 4 == 0)) && (!res_vec || res), FGCN_E_BADARG,
+                 "spatial_fwd_tile_bn_relu: the BatchNorm vector is required; a shortcut needs ld_res >= Cout, its BatchNorm needs the shortcut");
+    return spatial_fwd_tile_impl(x, a_hat, w3, bias_sum, g, nullptr, B, T, V, Cin, Cout, ld_x, ld_g, a_hat_batched, stream, bn_vec, res, ld_res, res_vec);
+}
+
+static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
+                                 float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec) {
     FGCN_REQUIRE(x && a_hat && w3 && y, FGCN_E_BADARG, "spatial_fwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, FGCN_E_BADARG, "spatial_fwd_tile: bad sizes B=%d T=%d Cin=%d Cout=%d", B, T, Cin, Cout);
     FGCN_REQUIRE(fgcn_spatial_fwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
@@ -345,20 +426,29 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
     FGCN_REQUIRE(total < (1ll << 30), FGCN_E_BADARG, "spatial_fwd_tile: too many tiles");
     p.per_xcd = (int)cdiv(total, 8);
     p.x_bytes = (unsigned)x_bytes; p.y_bytes = (unsigned)y_bytes; p.w_plane_bytes = (unsigned)plane;
+    const bool fep = ep_vec != nullptr;
+    const long long res_bytes = ep_res ? (long long)B * T * V * ld_res * 4 : 0;
+    FGCN_REQUIRE(res_bytes < 0x7FFF0000ll, FGCN_E_BADARG, "spatial_fwd_tile: the shortcut tensor must be smaller than 2 GiB");
+    p.ep_vec = ep_vec; p.ep_res = ep_res; p.ep_rvec = ep_rvec; p.ld_res = ld_res; p.res_bytes = (unsigned)res_bytes;
     const size_t lds = (size_t)3 * ST_PLANE + 9 * 32 * ST_AHB;
     const dim3 grid((unsigned)(p.per_xcd * 8));
     hipStream_t s = (hipStream_t)stream;
     const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
     const bool str = fgcn::stream_out(y_bytes);
-#define FGCN_ST_GO4(NT_, MU_, STR_, NP_)                                                                            \
+#define FGCN_ST_GO5(NT_, MU_, STR_, NP_, FEP_)                                                                      \
     do {                                                                                                            \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_, NP_>),  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             opted = true;                                                                                           \
         }                                                                                                           \
-        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_, NP_>), grid, dim3(256), lds, s, p);              \
+        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_>), grid, dim3(256), lds, s, p);        \
+    } while (0)
+#define FGCN_ST_GO4(NT_, MU_, STR_, NP_)                \
+    do {                                                \
+        if (fep) FGCN_ST_GO5(NT_, MU_, STR_, NP_, true); \
+        else FGCN_ST_GO5(NT_, MU_, STR_, NP_, false);   \
     } while (0)
     const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
 #define FGCN_ST_GO3(NT_, MU_, STR_)                     \
@@ -381,5 +471,6 @@ extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const v
 #undef FGCN_ST_GO
 #undef FGCN_ST_GO3
 #undef FGCN_ST_GO4
+#undef FGCN_ST_GO5
     return launch_status("spatial_fwd_tile");
 }

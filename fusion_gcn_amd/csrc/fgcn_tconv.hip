@@ -54,6 +54,12 @@ struct HaloP {
     const float* fin_res;               // the shortcut operand, laid out like `in`
     float* fin_out;                     // G, laid out like `in`
     unsigned char* fin_mask;            // rows * K / 8 bytes
+    // Inference epilogue (conv_halo_x3k32_kernel<.., EPI = 4>; fgcn_tconv_halo_bn_relu): north-star kernel 2 as the north star states it --
+    // "temporal 9x1 conv + BN + ReLU" in one kernel.  With eval-mode BatchNorm the statistics are constants, so the block's output stage
+    // (agcn.py:49-51,134-136) is this kernel's epilogue: out = relu((acc + bias) * scale + shift + res * rscale + rshift).
+    const float* ep_vec;                // float[4][N] of fgcn_bn_eval_coeffs (scale at [2N, 3N), shift at [3N, 4N))
+    const float* ep_res;                // the block's shortcut operand, laid out like `out` (x, or the residual conv's output), or NULL
+    const float* ep_rvec;               // float[4][N]: BatchNorm of the shortcut (the residual conv), or NULL (identity)
     unsigned* in_amax;                  // NP == 2: receives max |in| over everything staged (integer atomic maximum of the float bits) or NULL
     int stats_rows;                     // rows of `stats` the caller allocated (fgcn_tconv_halo_tiles: 128-row tiles); a kernel form with larger
                                         // row tiles fills tiles_m of them and zeroes the rest
@@ -331,7 +337,9 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // group of four stores -- sixteen serialised write round trips per workgroup; found with the timing probes of fgcn_pw.hip):
 //   0  store;  2  store + the BatchNorm-backward sums (bn_a / bn_mask / bn_vec);  3  accumulate: load / add / store with the old
 //   values of a row tile requested one row tile AHEAD of the stores (the second pass of a strided forward convolution; statistics
-//   are those of the final values).  (1 was accumulation by one no-return float atomic per element -- deterministic, every element
+//   are those of the final values);  4  the INFERENCE output stage: BatchNorm (eval-mode coefficients) + shortcut + ReLU applied to the
+//   accumulators, the shortcut values of a row tile requested one row tile ahead like EPI 3's old values -- the block's output without a
+//   pre-BatchNorm tensor and without a bn_act pass (HaloP::ep_*).  (1 was accumulation by one no-return float atomic per element -- deterministic, every element
 //   has one contributor -- measured 5-40 % slower in fgcn_pw.hip: the L2 performs about one per clock and channel.)
 // (A 96-row tile for images that do not fit LDS twice is not needed: with the swizzled unpadded image the 128-row tile fits up to
 // 36 joints, FGCN_MAX_V is 32.)
@@ -343,12 +351,13 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // bytes are the same either way (one round-to-nearest-even per value), so the results are bit-identical to the f32-input form; the row
 // traffic through L2 -- what bounds this kernel in math mode bf16, where the matrix work is a sixth -- halves.
 template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false, bool IN16 = false>   // STR: non-temporal output stores (stream_out)
-__global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {
+__global__ __launch_bounds__(256, (NP == 1 && !FIN && EPI != 4) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {   // (EPI 4 at 168 registers spilled)
     static_assert(!IN16 || (NP == 1 && !FIN), "bfloat16 input: the one-part kernel without the fused input stage");
     static_assert(!(STR && EPI == 3), "an accumulating epilogue stores plainly");
     static_assert(WR == 2 || (WR == 4 && KC == 32 && !FIN), "wave arrangement: 2 x 2, or 4 x 1 for the tap form");
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
-    static_assert((EPI == 0 || EPI == 2 || EPI == 3) && !(FIN && EPI != 0), "epilogue: store / store + BatchNorm-backward sums / accumulate");
+    static_assert((EPI == 0 || EPI == 2 || EPI == 3 || EPI == 4) && !(FIN && EPI != 0),
+                  "epilogue: store / store + BatchNorm-backward sums / accumulate / inference output stage");
     constexpr int MTW = WR == 4 ? 3 : 4;             // 16-row tiles per wave
     constexpr int BMR = WR * 16 * MTW;               // output rows per workgroup: 128 (2 x 2 waves) or 192 (4 x 1)
     static_assert(NP == 1 || NP == 2 || NP == 3, "one or three bf16 parts per operand, or two f16 parts (FGCN_PRODUCTS_F16X2)");
@@ -711,7 +720,25 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
                 m_[nu][r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rbm, off == OOB ? OOB : off >> 5, 0, 0);
             }
     };
-    constexpr bool ldacc = EPI == 3;
+    constexpr bool fep = EPI == 4;                        // inference output stage (HaloP::ep_*)
+    constexpr bool ldacc = EPI == 3 || fep;               // per-element operand of the epilogue: out's old values / the shortcut values
+    const __amdgpu_buffer_rsrc_t rold = fep ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_res ? (const void*)p.ep_res : (const void*)p.out), 0,
+                                                                                p.ep_res ? p.out_bytes : 0u, 0x00020000)
+                                            : rout;
+    float esc[NU], esh[NU], rsc[NU], rsh[NU];
+    if constexpr (fep) {
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.ep_vec, 0, (unsigned)p.N * 16u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ep_rvec ? p.ep_rvec : p.ep_vec), 0,
+                                                                             p.ep_rvec ? (unsigned)p.N * 16u : 0u, 0x00020000);
+        const float res_unit = p.ep_rvec ? 0.f : 1.f;     // (branch-free: an empty descriptor returns 0, the scalar addend makes the scale 1)
+#pragma unroll
+        for (int nu = 0; nu < NU; ++nu) {
+            esc[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, coff[nu], (unsigned)p.N * 8u, 0));
+            esh[nu] = __builtin_fmaf(bv[nu], esc[nu], __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, coff[nu], (unsigned)p.N * 12u, 0)));
+            rsc[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrv, coff[nu], (unsigned)p.N * 8u, 0)) + res_unit;
+            rsh[nu] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrv, coff[nu], (unsigned)p.N * 12u, 0));
+        }
+    }
     float oldv[ldacc ? 2 : 1][NU][4];
     auto load_old = [&](int mt, float (&o_)[NU][4]) {
 #pragma unroll
@@ -719,7 +746,7 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 o_[nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rout, (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu], 0, 0));
+                    rold, (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu], 0, 0));
     };
     if constexpr (bnb) load_bn(0, av[0], mbits[0]);
     if constexpr (ldacc) load_old(0, oldv[0]);
@@ -739,7 +766,12 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN) ? 3 : 2) void conv_halo_x3k3
             for (int nu = 0; nu < NU; ++nu) {
                 const unsigned off = (rowoff[mt][r] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][r] + coff[nu];
                 float val = (NP == 2 ? acc[mt][nu][r] * un_a * un_w : acc[mt][nu][r]) + bv[nu];
-                if constexpr (ldacc) val += oldv[mt & 1][nu][r];
+                if constexpr (fep) {
+                    val = __builtin_fmaf(acc[mt][nu][r], esc[nu], esh[nu]) + __builtin_fmaf(oldv[mt & 1][nu][r], rsc[nu], rsh[nu]);
+                    val = fmaxf(val, 0.f);
+                } else if constexpr (ldacc) {
+                    val += oldv[mt & 1][nu][r];
+                }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rout, ((FGCN_PROBE_HALO & 1) && val != 123.456f) ? OOB : off, 0, STR ? FGCN_STORE_AUX : 0);
                 const float kept = off != OOB ? val : 0.f;
                 if constexpr (bnb) {
@@ -813,7 +845,7 @@ extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
 template <int NT, int KC, int NP, int EPI, bool FIN, int WR, bool STR>
 static void halo_k32_launch(bool in16, dim3 grid, size_t lds, hipStream_t s, const HaloP& p) {
     constexpr int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
-    if constexpr (NP == 1 && !FIN && KC == 32) {
+    if constexpr (NP == 1 && !FIN && KC == 32 && EPI != 4) {
         if (in16) {
             static bool opted16 = false;
             if (!opted16) {
@@ -840,8 +872,15 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
                            int T_out_full, int out_s, int out_o,
                            int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
                            const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
-                           unsigned char* fin_mask, unsigned* in_amax, void* stream, bool in16) {
+                           unsigned char* fin_mask, unsigned* in_amax, void* stream, bool in16, const float* ep_vec = nullptr,
+                           const float* ep_res = nullptr, const float* ep_rvec = nullptr) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
+    const bool fep = ep_vec != nullptr;
+    FGCN_REQUIRE(!fep || ((fgcn::math_mode() == FGCN_MATH_BF16X3 || fgcn::math_mode() == FGCN_MATH_BF16) && !fgcn::f16x2_products() && !in16 &&
+                          !accumulate && !bn_a && !stat_partials && !(fin_vec || fin_res || fin_out || fin_mask) && taps > 1 && out_s == 1 && out_o == 0 &&
+                          T_out_full == Th && aligned16(ep_vec) && (!ep_res || aligned16(ep_res)) && (!ep_rvec || ep_res)),
+                 FGCN_E_BADARG, "tconv_halo_bn_relu: the inference output stage needs the split kernel (bf16x3 products or bf16), the tap form, a "
+                 "plain output view, no statistics / accumulation / fused input stage");
     FGCN_REQUIRE(!in16 || (fgcn::math_mode() == FGCN_MATH_BF16 && !(fin_vec || fin_res || fin_out || fin_mask) && !(taps == 1 && K % 64 == 0)),
                  FGCN_E_BADARG, "tconv_halo_h: a bfloat16 input needs math mode bf16, the tap form and no fused input stage");
     const bool fin = fin_vec || fin_res || fin_out || fin_mask;
@@ -889,6 +928,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
     p.taps = taps; p.tb = tb; p.tc = tc; p.accumulate = accumulate;
     p.bn_a = bn_a; p.bn_mask = bn_mask; p.bn_vec = bn_vec;
     p.fin_vec = fin_vec; p.fin_res = fin_res; p.fin_out = fin_out; p.fin_mask = fin_mask;
+    p.ep_vec = ep_vec; p.ep_res = ep_res; p.ep_rvec = ep_rvec;
     p.in_amax = fgcn::f16x2_products() ? in_amax : nullptr;
     const int d0 = tc, d1 = (taps - 1) * tb + tc;
     p.dmin = d0 < d1 ? d0 : d1;
@@ -899,7 +939,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
     // the same arrangement for ONE 128-column tile (64 < N <= 128): a wave owns 48 rows x 128 columns, every image fragment feeds eight
     // units: -5 % (bf16x3) / -9 % (f16x2) at 128 channels, nothing at 256 (two column tiles; key 7 bit 4 forces it there, bit 5 switches it
     // off); epilogue forms 0 and 3 only -- the BatchNorm-sums epilogue would spill at 255 registers
-    const bool wide128 = ((fgcn::tuning(7) & 16) || (N <= 128 && !(fgcn::tuning(7) & 32))) && N > 64 && !bn_a;
+    const bool wide128 = ((fgcn::tuning(7) & 16) || (N <= 128 && !(fgcn::tuning(7) & 32))) && N > 64 && !bn_a && !fep;   // (EPI 4 spills in that form)
     const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && ((N <= 64 && N > 32) || wide128) && !(taps == 1 && K % 64 == 0) &&
                            !(fin_vec || fin_res || fin_out || fin_mask) && !(fgcn::tuning(7) & 8) &&
                            192 + (dmax - p.dmin) * V <= 32 * HALO_MAX_STAGE && (size_t)(192 + (dmax - p.dmin) * V) * 64 * 3 + 16 <= 80 * 1024 &&
@@ -943,7 +983,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
         const size_t lds_k = (pw ? (size_t)bmr * 128 * np : (size_t)p.halo_rows * 64 * np) + 16;
         FGCN_REQUIRE(bmr == 128 || wide_rows, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
-        const int epi = bn_a ? 2 : (accumulate ? 3 : 0);     // epilogue form (compile time, see the kernel)
+        const int epi = fep ? 4 : (bn_a ? 2 : (accumulate ? 3 : 0));     // epilogue form (compile time, see the kernel)
         const bool stream_k = fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes
 #define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_) halo_k32_launch<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>(in16, grid, lds_k, s, p)
 #define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
@@ -964,10 +1004,16 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
         else if (two) FGCN_K32_GO(NT_, KC_, 2, EPI_, false);                                                             \
         else FGCN_K32_GO(NT_, KC_, 3, EPI_, false);                                                                      \
     } while (0)
+#define FGCN_K32_NP13(NT_, KC_, EPI_)      /* (the inference stage: three bf16 parts or one -- not the f16x2 products) */ \
+    do {                                                                                                                 \
+        if (one) FGCN_K32_GO(NT_, KC_, 1, EPI_, false);                                                                  \
+        else FGCN_K32_GO(NT_, KC_, 3, EPI_, false);                                                                      \
+    } while (0)
 #define FGCN_K32_LAUNCH(NT_, KC_)                                                                                        \
     do {                                                                                                                 \
         if (epi == 0) FGCN_K32_NP(NT_, KC_, 0);                                                                          \
         else if (epi == 3) FGCN_K32_NP(NT_, KC_, 3);                                                                     \
+        else if (epi == 4 && KC_ == 32) FGCN_K32_NP13(NT_, 32, 4);                                                       \
         else if (epi == 2 && KC_ == 32) FGCN_K32_NP(NT_, 32, 2);                                                         \
         else return fgcn::fail(FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums are built for the tap kernel only"); \
     } while (0)
@@ -984,7 +1030,9 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
             if (N <= 64) FGCN_K32_LAUNCH(1, 64);
             else FGCN_K32_LAUNCH(2, 64);
         } else {
-            if (wide_rows && N > 64) {
+            if (wide_rows && epi == 4) {                 // (N <= 64: the 128-column 4 x 1 form is excluded for this epilogue above)
+                if (one) FGCN_K32_GO6(2, 32, 1, 4, false, 4); else FGCN_K32_GO6(2, 32, 3, 4, false, 4);
+            } else if (wide_rows && N > 64) {
                 if (epi == 0) { if (one) FGCN_K32_GO6(4, 32, 1, 0, false, 4); else if (two) FGCN_K32_GO6(4, 32, 2, 0, false, 4); else FGCN_K32_GO6(4, 32, 3, 0, false, 4); }
                 else { if (one) FGCN_K32_GO6(4, 32, 1, 3, false, 4); else if (two) FGCN_K32_GO6(4, 32, 2, 3, false, 4); else FGCN_K32_GO6(4, 32, 3, 3, false, 4); }
             } else if (wide_rows) {
@@ -995,6 +1043,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
             else FGCN_K32_LAUNCH(2, 32);
         }
 #undef FGCN_K32_LAUNCH
+#undef FGCN_K32_NP13
 #undef FGCN_K32_NP
 #undef FGCN_K32_GO
 #undef FGCN_K32_GO6
@@ -1045,4 +1094,18 @@ extern "C" int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const f
     return tconv_halo_impl(reinterpret_cast<const float*>(in_h), out, w4, bias, stat_partials, B, Th, V, K, N, ld_in, ld_out, T_in_full, in_s, in_o,
                            Th_in, T_out_full, out_s, out_o, taps, tb, tc, accumulate, bn_a, bn_mask, bn_vec, nullptr, nullptr, nullptr, nullptr,
                            nullptr, stream, true);
+}
+
+// North-star kernel 2 as the north star states it, for INFERENCE: the (taps x 1) temporal convolution (stride 1) with the block's output
+// stage in its epilogue -- out = relu(BN(conv(in) + bias) + shortcut), agcn.py:49-51,134-136 with the BatchNorm's running statistics folded
+// into a per-channel scale / shift (bn_vec = fgcn_bn_eval_coeffs).  res: the shortcut operand laid out like out (x of an identity block, the
+// residual conv's output with its own res_vec) or NULL (the first block).  Split kernel only (FGCN_MATH_BF16X3 with the bf16x3 products, or
+// FGCN_MATH_BF16).  Nothing is kept for a backward: a training step runs fgcn_tconv_halo (statistics in the epilogue) + fgcn_bn_act, because
+// train-mode BatchNorm needs the statistics of the WHOLE batch before it can be applied.
+extern "C" int fgcn_tconv_halo_bn_relu(const float* in, float* out, const float* w4, const float* bias, const float* bn_vec,
+                                       const float* res, const float* res_vec, int B, int T, int V, int K, int N, int ld_in, int ld_out,
+                                       int taps, int tb, int tc, void* stream) {
+    FGCN_REQUIRE(bn_vec, FGCN_E_BADARG, "tconv_halo_bn_relu: the BatchNorm vector is required");
+    return tconv_halo_impl(in, out, w4, bias, nullptr, B, T, V, K, N, ld_in, ld_out, T, 1, 0, T, T, 1, 0, taps, tb, tc, 0, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, stream, false, bn_vec, res, res_vec);
 }

@@ -219,6 +219,8 @@ class SpatialTemporalConv(nn.Module):
         params = [self._tensor(n) for n in names]
         W = self._packed(params)
         holder = {"pool_groups": pool_groups} if pool_groups else {}
+        if not self.training and not torch.is_grad_enabled():
+            holder["inference"] = True                # no backward can follow: the block may take its inference kernels (block_forward)
         if self._zeros is not None:                   # this step's slice of the model's zero pool (Model.forward), used once
             holder["zeros"], self._zeros = self._zeros, None
         out = STBlockFunction.apply(x, self.cfg, self.training, self._block_buffers(), W, holder, *params)

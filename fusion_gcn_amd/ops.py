@@ -414,6 +414,62 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
     return part
 
 
+def inference_kernels_available() -> bool:
+    """Whether the inference forms of the two north-star kernels exist in the current math mode (the split kernels: bf16x3 / bf16)."""
+    return get_math_mode() in ("bf16x3", "bf16")
+
+
+def tconv_halo_bn_relu(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, taps: int, tb: int, tc: int, vec: torch.Tensor,
+                       bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                       res_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """North-star kernel 2 as stated, for inference: out = relu(BN(conv(inp) + bias) + [res | BN_res(res)]) in ONE kernel
+    (fgcn_tconv_halo_bn_relu; stride 1; vec / res_vec = ``bn_eval_coeffs``; res laid out like out).  w4: the pack_split3 form."""
+    ensure_device()
+    _chk(inp, "tconv_halo_bn_relu.in"), _chk(out, "tconv_halo_bn_relu.out"), _chk(vec, "tconv_halo_bn_relu.vec")
+    B, T, V, ld_in = inp.shape
+    if w4.dtype != torch.bfloat16 or w4.dim() != 5 or w4.shape[0] != 3 or w4.shape[4] != 8 or not w4.is_contiguous():
+        raise _lib.FgcnError(f"tconv_halo_bn_relu: pack_split3 weights expected, got {w4.dtype} {tuple(w4.shape)}")
+    w_taps, K, N = w4.shape[1], w4.shape[2] * 8, w4.shape[3]
+    if tuple(out.shape[:3]) != (B, T, V) or w_taps != taps or K > ld_in or N > out.shape[3] or tuple(vec.shape) != (4, N):
+        raise _lib.FgcnError(f"tconv_halo_bn_relu: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} weights (taps, K, N) = {(w_taps, K, N)}")
+    if res is not None:
+        _chk(res, "tconv_halo_bn_relu.res")
+        if tuple(res.shape) != tuple(out.shape):
+            raise _lib.FgcnError(f"tconv_halo_bn_relu: the shortcut {tuple(res.shape)} must be laid out like the output {tuple(out.shape)}")
+    if res_vec is not None and (res is None or tuple(res_vec.shape) != (4, N)):
+        raise _lib.FgcnError("tconv_halo_bn_relu: res_vec is the (4, N) BatchNorm vector of a given shortcut")
+    _mode_products()
+    check(_lib.load().fgcn_tconv_halo_bn_relu(_p(inp), _p(out), w4.data_ptr(), _p(bias), _p(vec), _p(res), _p(res_vec), B, T, V, K, N, ld_in,
+                                              out.shape[3], taps, tb, tc, _stream()), "fgcn_tconv_halo_bn_relu")
+    return out
+
+
+def spatial_fwd_tile_bn_relu(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bias: Optional[torch.Tensor], vec: torch.Tensor, *,
+                             Cin: int, Cout: int, res: Optional[torch.Tensor] = None, res_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """North-star kernel 1 for inference: g = relu(BN(sum_k conv_d[k](x . A^_k) + bias) + [res | BN_res(res)]) in ONE kernel
+    (fgcn_spatial_fwd_tile_bn_relu; vec / res_vec = ``bn_eval_coeffs``; res (B, T, V, >= Cout))."""
+    ensure_device()
+    _chk(x, "spatial_fwd_tile_bn_relu.x"), _chk(a_hat, "spatial_fwd_tile_bn_relu.a_hat"), _chk(vec, "spatial_fwd_tile_bn_relu.vec")
+    B, T, V, ld_x = x.shape
+    if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, 3 * Cin // 8, Cout, 8) or not w3.is_contiguous() or Cin > ld_x
+            or a_hat.shape[0] not in (1, B) or tuple(a_hat.shape[1:]) != (3, V, V) or tuple(vec.shape) != (4, Cout)):
+        raise _lib.FgcnError(f"spatial_fwd_tile_bn_relu: shape mismatch x={tuple(x.shape)} a_hat={tuple(a_hat.shape)} w3={tuple(w3.shape)} vec={tuple(vec.shape)}")
+    ld_res = 0
+    if res is not None:
+        _chk(res, "spatial_fwd_tile_bn_relu.res")
+        if tuple(res.shape[:3]) != (B, T, V) or res.shape[3] < Cout:
+            raise _lib.FgcnError(f"spatial_fwd_tile_bn_relu: the shortcut {tuple(res.shape)} does not cover ({B}, {T}, {V}, {Cout})")
+        ld_res = res.shape[3]
+    if res_vec is not None and (res is None or tuple(res_vec.shape) != (4, Cout)):
+        raise _lib.FgcnError("spatial_fwd_tile_bn_relu: res_vec is the (4, Cout) BatchNorm vector of a given shortcut")
+    g = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
+    _mode_products()
+    check(_lib.load().fgcn_spatial_fwd_tile_bn_relu(_p(x), _p(a_hat), w3.data_ptr(), _p(bias), _p(g), _p(vec), _p(res), ld_res, _p(res_vec),
+                                                    B, T, V, Cin, Cout, ld_x, Cout, int(a_hat.shape[0] == B), _stream()),
+          "fgcn_spatial_fwd_tile_bn_relu")
+    return g
+
+
 def pw_gemm_available() -> bool:
     """Whether ``pw_gemm`` runs in the current math mode (the split-bf16 modes)."""
     return bool(_lib.load().fgcn_pw_gemm_available())

@@ -76,6 +76,9 @@ class PathOptions:
     # when they stage them anyway); the halo conv, bound by its row traffic through L2 in this mode, moves half of it
     # (probe: 34.38 -> 32.9 ms from the conv's input alone, profiles/r06_ab_bf16_half_storage.txt).  Only the mode's own entry counts.
     half_storage: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
+    # -- inference (module in eval mode, autograd off): BatchNorm + shortcut + ReLU in the epilogues of the two north-star kernels
+    # (fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- a block is two kernels + the attention; split modes bf16x3 / bf16
+    fused_inference: bool = True
     # -- the model's last block: the epilogue pass carries the global average pooling, and its backward reads the pooled gradient as one
     # row per clip (profiles/r05_ab_pool_epilogue_and_split_sums.txt, r05_ab_pool_backward_rows.txt: 53.74 / 53.74 -> 53.62 / 53.50 ms)
     pool_epilogue: bool = True

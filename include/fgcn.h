@@ -167,6 +167,23 @@ int fgcn_rows_gemm_tiles(long long M);
  *   accumulation).  Tensors must be smaller than 2 GiB (32-bit buffer offsets). */
 int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V);
 
+/* ---- INFERENCE forms of the two north-star kernels (round 6): with eval-mode BatchNorm the statistics are constants, so BatchNorm +
+ * shortcut + ReLU are the producing kernel's epilogue and a block is two kernels + the attention, as SURVEY.md Appendix A.3 states it.
+ * (A TRAINING step cannot do this: train-mode BatchNorm needs the statistics of the whole batch before it can be applied, so there the
+ * kernels emit the partial sums and fgcn_bn_act applies them.)  Split kernels only: FGCN_MATH_BF16X3 with the bf16x3 products, or
+ * FGCN_MATH_BF16.  bn_vec / res_vec: float[4][N] of fgcn_bn_eval_coeffs; res: the shortcut operand or NULL; nothing is kept for a backward.
+ *
+ * fgcn_tconv_halo_bn_relu -- "temporal 9x1 conv + BN + ReLU" (reference torch_src/models/mmargcn/agcn.py:49-51,134-136):
+ *   out = relu(BN(conv_{taps x 1, stride 1}(in) + bias) + [res | BN_res(res)]), res laid out like out.
+ * fgcn_spatial_fwd_tile_bn_relu -- aggregation + 1x1 feature contraction + BN + shortcut + ReLU (agcn.py:103-115):
+ *   g = relu(BN(sum_k conv_d[k](x . A^_k) + bias_sum) + [res | BN_res(res)]), res rows of ld_res floats (x, or the down conv's output). */
+int fgcn_tconv_halo_bn_relu(const float* in, float* out, const float* w4, const float* bias, const float* bn_vec,
+                            const float* res, const float* res_vec, int B, int T, int V, int K, int N, int ld_in, int ld_out,
+                            int taps, int tb, int tc, void* stream);
+int fgcn_spatial_fwd_tile_bn_relu(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* g,
+                                  const float* bn_vec, const float* res, int ld_res, const float* res_vec,
+                                  int B, int T, int V, int Cin, int Cout, int ld_x, int ld_g, int a_hat_batched, void* stream);
+
 /* ---- half-precision STORAGE of the temporal convolution's operands (math mode FGCN_MATH_BF16 only; round 6) -----------------------------
  * The reference's MixedPrecisionStep (torch_src/session/procedures/step.py:55-78, autocast) keeps conv inputs in half precision.  In
  * FGCN_MATH_BF16 the matrix kernels round their f32 inputs to bfloat16 (to nearest even) as they stage them; for the two tensors that

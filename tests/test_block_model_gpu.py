@@ -678,3 +678,53 @@ def test_dropout_between_blocks_and_second_backward():
     assert float(sum(p.grad.abs().sum() for p in drop.parameters())) > 0
     with pytest.raises(RuntimeError, match="backward ran twice"):
         loss.backward()
+
+
+@pytest.mark.gpu
+@pytest.mark.math_modes("bf16x3")
+def test_inference_runs_the_fused_output_stages(fgcn_math):
+    """Eval mode under torch.no_grad(): every block takes the inference forms of the two north-star kernels where they exist (BatchNorm
+    + shortcut + ReLU in the epilogues: fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- the logits equal those of the
+    unfused eval path to rounding; with autograd on (a backward may follow) the unfused path runs and is bit-identical to before."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    model = Model((2, 40, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev)
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, "gcn1"):
+                m.gcn1.bn.weight.fill_(1.0)
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):      # non-trivial running statistics
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    model.eval()
+    x = torch.randn(3, 2, 40, 25, 3, device=dev)
+    calls = {"conv": 0, "spatial": 0}
+    conv, spatial = ops.tconv_halo_bn_relu, ops.spatial_fwd_tile_bn_relu
+
+    def count(name, fn):
+        def wrapped(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return wrapped
+    ops.tconv_halo_bn_relu, ops.spatial_fwd_tile_bn_relu = count("conv", conv), count("spatial", spatial)
+    try:
+        with torch.no_grad():
+            with ops.context() as c:
+                c.paths.fused_inference = False
+                ref = model(x)
+            assert calls == {"conv": 0, "spatial": 0}
+            fused = model(x)
+        # the ten blocks: nine spatial stages (the first block has 3 input channels: no tile form), the seven stride-1 temporal stages
+        # that are not the pooled last block
+        assert calls == {"conv": 7, "spatial": 9}, calls
+        with_grad = model(x)                         # autograd on: a backward may follow -> the unfused path, nothing fused is called
+        assert calls == {"conv": 7, "spatial": 9}
+    finally:
+        ops.tconv_halo_bn_relu, ops.spatial_fwd_tile_bn_relu = conv, spatial
+    assert torch.equal(with_grad.detach(), ref)
+    err = float((fused - ref).norm() / ref.norm())
+    assert err < 1e-5, err

@@ -1220,3 +1220,77 @@ def test_weight_gradient_from_two_way_f16_splits(B, T, V, K, N, kt, stride):
                     continue
                 want[j] += torch.einsum("bvk,bvn->kn", a[:, num // td], g[:, to])
         assert rel_l2(got.cpu().numpy().reshape(kt, K, N), want.numpy()) < RED_TOL, (scale_a, scale_g)
+
+
+# ---- inference forms of the two north-star kernels (include/fgcn.h: fgcn_tconv_halo_bn_relu, fgcn_spatial_fwd_tile_bn_relu) ------------------
+def _eval_vec(C, seed):
+    """(4, C) vector of an eval-mode BatchNorm as fgcn_bn_eval_coeffs lays it out: mean, rstd, scale, shift"""
+    mean, var = rnd(C, seed=seed), rnd(C, seed=seed + 1).abs() + 0.5
+    gamma, beta = rnd(C, seed=seed + 2), rnd(C, seed=seed + 3)
+    rstd = (var + 1e-5).rsqrt()
+    return torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd]).float()
+
+
+@pytest.mark.math_modes("bf16x3")
+@pytest.mark.parametrize("B,T,V,C,kt,res", [(3, 37, 25, 64, 9, "identity"), (2, 21, 25, 128, 9, "identity"), (2, 9, 27, 256, 9, "conv"),
+                                            (1, 50, 22, 64, 9, "none"), (2, 40, 32, 128, 5, "identity"), (130, 5, 18, 64, 3, "conv")])
+def test_temporal_conv_with_batchnorm_shortcut_and_relu_in_one_kernel(B, T, V, C, kt, res):
+    """North-star kernel 2 as the north star states it, inference form (fgcn_tconv_halo_bn_relu): out = relu(BN(conv(g) + bias) +
+    [x | BN_r(r)]) against float64 and against the two-kernel form (fgcn_tconv_halo + fgcn_bn_act with the same eval-mode vectors),
+    bitwise repeatable; all three shortcut kinds, 64 / 128 / 256 channels (every tile form the launcher picks), ragged tiles."""
+    from fusion_gcn_amd import ops
+    g, w = rnd(B, T, V, C, seed=90), rnd(kt, C, C, seed=91, scale=(kt * C) ** -0.5)
+    bias, vec = rnd(C, seed=92), _eval_vec(C, 93)
+    r, rvec = rnd(B, T, V, C, seed=97), (_eval_vec(C, 98) if res == "conv" else None)
+    pad = (kt - 1) // 2
+    u = torch.zeros(B, T, V, C, dtype=torch.float64)
+    for j in range(kt):
+        for t in range(T):
+            ti = t + j - pad
+            if 0 <= ti < T:
+                u[:, t] += g[:, ti].double() @ w[j].double()
+    z = (u + bias.double()) * vec[2].double() + vec[3].double()
+    if res == "identity":
+        z = z + r.double()
+    elif res == "conv":
+        z = z + r.double() * rvec[2].double() + rvec[3].double()
+    want = z.clamp_min(0)
+    w4 = ops.pack_split3(to_gpu(w))
+    rg = None if res == "none" else to_gpu(r)
+    rv = None if rvec is None else to_gpu(rvec)
+    out = torch.empty(B, T, V, C, device=dev())
+    ops.tconv_halo_bn_relu(to_gpu(g), w4, out, taps=kt, tb=1, tc=-pad, vec=to_gpu(vec), bias=to_gpu(bias), res=rg, res_vec=rv)
+    assert rel_l2(out.cpu().numpy(), want.numpy()) < FWD_TOL
+    again = torch.empty_like(out)
+    ops.tconv_halo_bn_relu(to_gpu(g), w4, again, taps=kt, tb=1, tc=-pad, vec=to_gpu(vec), bias=to_gpu(bias), res=rg, res_vec=rv)
+    assert torch.equal(out, again)
+    ug = torch.empty(B, T, V, C, device=dev())
+    ops.tconv_halo(to_gpu(g), w4, ug, Th=T, taps=kt, tb=1, tc=-pad, bias=to_gpu(bias))
+    two = ops.bn_act(ug, to_gpu(vec), rg, rv, relu=True)
+    assert rel_l2(out.cpu().numpy(), two.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.math_modes("bf16x3")
+@pytest.mark.parametrize("V,T,cin,cout,B,down", [(25, 13, 64, 64, 2, False), (25, 7, 128, 256, 2, True), (27, 9, 64, 128, 1, True),
+                                                  (18, 10, 128, 128, 2, False), (22, 31, 256, 256, 1, False), (32, 5, 64, 64, 3, False)])
+def test_spatial_stage_with_batchnorm_shortcut_and_relu_in_one_kernel(V, T, cin, cout, B, down):
+    """North-star kernel 1, inference form (fgcn_spatial_fwd_tile_bn_relu): g = relu(BN(sum_k (x . A^_k) . Wd_k + bias) + [x | BN_d(d)])
+    against float64 and against fgcn_spatial_fwd_tile + fgcn_bn_act; identity shortcut (cin == cout) and the down branch."""
+    from fusion_gcn_amd import ops
+    x, a = rnd(B, T, V, cin, seed=300), rnd(B, 3, V, V, seed=301, scale=0.3)
+    wd, bias = rnd(3, cin, cout, seed=302, scale=(3 * cin) ** -0.5), rnd(cout, seed=303)
+    vec = _eval_vec(cout, 304)
+    d, dvec = (rnd(B, T, V, cout, seed=308), _eval_vec(cout, 309)) if down else (None, None)
+    y = torch.einsum("btwkc,kco->btwo", torch.einsum("btvc,bkvw->btwkc", x.double(), a.double()), wd.double()) + bias.double()
+    z = y * vec[2].double() + vec[3].double()
+    z = z + (d.double() * dvec[2].double() + dvec[3].double() if down else x.double())
+    want = z.clamp_min(0)
+    w3 = ops.pack_split3(to_gpu(wd.reshape(1, 3 * cin, cout)))
+    res = to_gpu(d) if down else to_gpu(x)
+    rv = to_gpu(dvec) if down else None
+    g = ops.spatial_fwd_tile_bn_relu(to_gpu(x), to_gpu(a), w3, to_gpu(bias), to_gpu(vec), Cin=cin, Cout=cout, res=res, res_vec=rv)
+    assert rel_l2(g.cpu().numpy(), want.numpy()) < FWD_TOL
+    assert torch.equal(g, ops.spatial_fwd_tile_bn_relu(to_gpu(x), to_gpu(a), w3, to_gpu(bias), to_gpu(vec), Cin=cin, Cout=cout, res=res, res_vec=rv))
+    yg, _ = ops.spatial_fwd_tile(to_gpu(x), to_gpu(a), w3, to_gpu(bias), Cin=cin, Cout=cout, stats=False)
+    two = ops.bn_act(yg, to_gpu(vec), res, rv, relu=True)
+    assert rel_l2(g.cpu().numpy(), two.cpu().numpy()) < 2e-6
