@@ -405,7 +405,8 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     else:
         if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
-            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic)             # emb written once, the gram from the tile on chip
+            # emb written once, the gram from the tile on chip (inference: not written at all -- only the backward reads it)
+            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic, write_emb=not (inference and not train and o_.fused_inference))
         else:
             emb = new(B, T, V, 6 * ic)
             S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)

@@ -265,7 +265,11 @@ extern "C" int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic) {
 
 extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
                                  int ic, int ld_x, int ld_e, void* stream) {
-    FGCN_REQUIRE(x && w3 && bias && emb && partial, FGCN_E_BADARG, "emb_fwd_tile: null pointer");
+    // emb == NULL (inference: nothing reads the embeddings after the gram): the kernel's stores of emb go to an empty buffer descriptor and are
+    // dropped by the hardware -- the 1.5-activation-wide tensor is never written
+    const bool write_emb = emb != nullptr;
+    if (!write_emb) emb = partial;
+    FGCN_REQUIRE(x && w3 && bias && partial, FGCN_E_BADARG, "emb_fwd_tile: null pointer");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_fwd_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_emb_fwd_tile_available(V, ic, Cin), FGCN_E_BADARG,
                  "emb_fwd_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic 16 / 32 / 64, Cin %% 32 == 0 (V=%d ic=%d Cin=%d, mode %d)", FGCN_MAX_V,
@@ -283,7 +287,7 @@ extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bi
     p.x = x; p.w3 = w3; p.bias = bias; p.emb = emb; p.partial = partial;
     p.B = B; p.T = T; p.V = V; p.Cin = Cin; p.ic = ic; p.Ce = Ce; p.ld_x = ld_x; p.ld_e = ld_e;
     p.F = g.F; p.tiles_t = g.tiles_t; p.tps = g.tps; p.nseg = g.nseg; p.ncol = g.ncol;
-    p.x_bytes = (unsigned)x_bytes; p.e_bytes = (unsigned)e_bytes; p.w_plane_bytes = (unsigned)plane;
+    p.x_bytes = (unsigned)x_bytes; p.e_bytes = write_emb ? (unsigned)e_bytes : 0u; p.w_plane_bytes = (unsigned)plane;
     p.p_bytes = (unsigned)((long long)B * g.nseg * 3 * 1024 * 4);
     const dim3 grid((unsigned)(B * g.nseg * g.ncol));
     hipStream_t s = (hipStream_t)stream;

@@ -1303,9 +1303,10 @@ def emb_fwd_tile_available(V: int, ic: int, cin: int) -> bool:
     return bool(_lib.load().fgcn_emb_fwd_tile_available(int(V), int(ic), int(cin)))
 
 
-def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: int, cin: Optional[int] = None):
+def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: int, cin: Optional[int] = None, write_emb: bool = True):
     """-> (emb (B,T,V,6 ic) = x . Wemb + bias, partial (B, segments, 3, 32, 32) of the affinity grams theta_k^T phi_k) in one launch
-    (fgcn_emb_fwd_tile.hip; agcn.py:104-106).  w3 = ``pack_split3`` of the (1, cin, 6 ic) matrix; ``partial`` goes to ``adj_softmax_fwd``."""
+    (fgcn_emb_fwd_tile.hip; agcn.py:104-106).  w3 = ``pack_split3`` of the (1, cin, 6 ic) matrix; ``partial`` goes to ``adj_softmax_fwd``.
+    ``write_emb=False`` (inference: only the backward reads the embeddings): emb is not written and None comes back in its place."""
     ensure_device()
     _chk(x, "emb_fwd_tile.x"), _chk(bias, "emb_fwd_tile.bias")
     B, T, V, ld_x = x.shape
@@ -1318,7 +1319,7 @@ def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: i
     nseg = lib.fgcn_emb_fwd_tile_segments(B, T, V, ic)
     if nseg <= 0:
         raise _lib.FgcnError(f"emb_fwd_tile: sizes not supported: V={V} ic={ic}")
-    emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.float32)
+    emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.float32) if write_emb else None
     partial = torch.empty((B, nseg, 3, 32, 32), device=x.device, dtype=torch.float32)
     check(lib.fgcn_emb_fwd_tile(_p(x), w3.data_ptr(), _p(bias), _p(emb), _p(partial), B, T, V, cin, ic, ld_x, 6 * ic, _stream()),
           "fgcn_emb_fwd_tile")

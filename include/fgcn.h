@@ -606,7 +606,8 @@ int fgcn_spatial_wgrad_tile_available(int V, int Cin, int Cout);
  * (rows / columns >= V are zeros), the input format of fgcn_adj_softmax_fwd (nchunk = segments), which applies the 1 / (ic T) scale.
  * Replaces fgcn_pw_gemm / fgcn_rows_gemm (emb) + fgcn_joint_gram and the gram's read of the 1.5-activation-wide emb.  Sizes: 16 <= V <=
  * FGCN_MAX_V, ic 16 / 32 / 64, Cin a multiple of 32; math modes FGCN_MATH_BF16X3 (either product form: exact three-way bf16 splits) and
- * FGCN_MATH_BF16: fgcn_emb_fwd_tile_available.  Tuning key 22: resident workgroups to aim for (0 = 512; sets the segment count). */
+ * FGCN_MATH_BF16: fgcn_emb_fwd_tile_available.  Tuning key 22: resident workgroups to aim for (0 = 512; sets the segment count).
+ * emb == NULL (inference: only the backward reads the embeddings): emb is not written, `partial` is all the call produces. */
 int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin, int ic,
                       int ld_x, int ld_e, void* stream);
 int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic);

@@ -427,3 +427,39 @@ def test_spatial_backward_tile_kernels_from_a_bfloat16_dy(V, T, cin, cout, B):
             assert torch.equal(d0, d1) and torch.equal(p0, p1)
     assert torch.equal(ops.spatial_wgrad_tile(x, dy32, a), ops.spatial_wgrad_tile(x, dy16, a))
     assert torch.equal(ops.spatial_wgrad_tile(x, dy32, a[:1]), ops.spatial_wgrad_tile(x, dy16, a[:1]))
+
+
+def test_inference_kernels_in_bf16_mode():
+    """The inference forms of the two north-star kernels (BatchNorm + shortcut + ReLU in the epilogue) with ONE bf16 part: the model's
+    eval logits under torch.no_grad() against the two-pass eval path of the same mode (bf16-level agreement: the epilogue's f32
+    arithmetic differs in its last bits and every later staging rounds to bfloat16 again)."""
+    from fusion_gcn_amd import ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    torch.manual_seed(13)
+    model = Model((2, 40, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev())
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, "gcn1"):
+                m.gcn1.bn.weight.fill_(1.0)
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    model.eval()
+    x = torch.randn(3, 2, 40, 25, 3, device=dev())
+    seen = []
+    conv = ops.tconv_halo_bn_relu
+    ops.tconv_halo_bn_relu = lambda *a, **k: (seen.append(1), conv(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            with ops.context() as c:
+                c.paths.fused_inference = False
+                ref = model(x)
+            assert not seen
+            fused = model(x)
+        assert len(seen) == 7
+    finally:
+        ops.tconv_halo_bn_relu = conv
+    err = float((fused - ref).norm() / ref.norm())
+    assert err < 1e-2, err

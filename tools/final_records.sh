@@ -3,7 +3,7 @@
 #   tools/final_records.sh <tag> a   -> gpurun_out/final_<tag>/: the driver's bench line, other configs, shards, warm-step kernel tables (64 / 8 clips)
 #   tools/final_records.sh <tag> b   -> per-kernel HBM traffic of the step, dominant-kernel stats, the bf16 step's tables
 set -e
-tag=${1:-r05}; part=${2:-a}
+tag=${1:-r06}; part=${2:-a}
 out=gpurun_out/final_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -17,6 +17,11 @@ if [ "$part" = "a" ]; then
     python3 bench.py --steps 20 --warmup 5 --math bf16 $Q >> $out/bench_other_configs.jsonl 2>> $out/bench.err
     tools/shards.sh > $out/shards.log 2>> $out/bench.err
     cat $out/shards.log
+    : > $out/inference.jsonl
+    python3 tools/infer_bench.py >> $out/inference.jsonl 2>> $out/bench.err
+    python3 tools/infer_bench.py --math bf16 >> $out/inference.jsonl 2>> $out/bench.err
+    python3 tools/infer_bench.py --batch 8 >> $out/inference.jsonl 2>> $out/bench.err
+    cat $out/inference.jsonl
     tools/prof_step.sh ${tag}_tmp > $out/prof_step.log 2>&1
     cp gpurun_out/prof_${tag}_tmp/step_warm_kernel_stats.csv $out/bf16x3_step_warm_kernel_stats.csv
     cp gpurun_out/prof_${tag}_tmp/step8_warm_kernel_stats.csv $out/bf16x3_8clips_step_warm_kernel_stats.csv
