@@ -443,6 +443,8 @@ def main():
                     help="A/B only (not the headline): keep the packed / split weight forms across steps instead of "
                          "rebuilding them from the parameters inside every timed step")
     ap.add_argument("--tune", default="", help="fgcn_set_tuning pairs for A/B runs, e.g. 6=21505")
+    ap.add_argument("--no-inference", action="store_true",
+                    help="N = 1 only: skip the secondary timing of the inference forward (eval mode, no autograd: the fused output stages)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1 only: report the stored PMC record as roofline.traffic instead of measuring it in two rocprofv3 child passes")
     ap.add_argument("--kernel-only", action="store_true",
@@ -708,6 +710,34 @@ def main():
                                              "frac": round(kern_h[0]["tflops"] / PEAK_SPLIT2H_TFLOPS, 4)}
         _ops.set_math_mode(args.math)
         del step_h
+    inference = None
+    if world == 1 and not args.no_inference and args.math in ("bf16x3", "bf16") and args.loader == "none":
+        # the same model's INFERENCE forward (eval-mode BatchNorm, no autograd graph): BatchNorm + shortcut + ReLU are then the epilogues of
+        # the two north-star kernels (fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- reported beside the training step
+        try:
+            model.eval()
+            with torch.no_grad():
+                for _ in range(2):
+                    model(x)
+                torch.cuda.synchronize()
+                ig = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ig):
+                    model(x)
+                ig.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ig.replay()
+                torch.cuda.synchronize()
+                dt_i = (time.perf_counter() - t0) / args.steps
+            inference = {"value": round(n_global / dt_i, 1), "unit": "clips/s", "ms_per_batch": round(1e3 * dt_i, 3),
+                         "what": "forward only, eval-mode BatchNorm, torch.no_grad(), HIP-graph replay; BatchNorm + shortcut + ReLU in the "
+                                 "epilogues of the spatial and temporal kernels (paths.fused_inference)"}
+            del ig
+        except Exception as e:  # noqa: BLE001 - a side number must not cost the headline line
+            log(f"inference timing failed ({type(e).__name__}: {e})")
+        finally:
+            model.train()
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         clips_per_s = n_global * args.steps / elapsed
@@ -727,6 +757,8 @@ def main():
             modes["f16x2"] = {"clips_s": f16x2_mode["value"], "ms": f16x2_mode["ms_per_step"]}
         if modes:
             out["modes"] = modes
+        if inference:
+            out["inference"] = inference
         if coll:
             out["collective"] = coll
         out["step_fractions"] = {
