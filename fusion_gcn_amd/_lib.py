@@ -118,11 +118,14 @@ SIGNATURES = {
     "fgcn_spatial_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_spatial_wgrad_tile_available": (_I, [_I] * 3),
     "fgcn_emb_fwd_tile": (_I, [_P] * 5 + [_I] * 7 + [_P]),
+    "fgcn_emb_fwd_tile_h": (_I, [_P] * 5 + [_I] * 7 + [_P]),
     "fgcn_emb_fwd_tile_segments": (_I, [_I] * 4),
     "fgcn_emb_fwd_tile_available": (_I, [_I] * 3),
     "fgcn_emb_dx_tile": (_I, [_P] * 5 + [_I] * 9 + [_P]),
+    "fgcn_emb_dx_tile_h": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "fgcn_emb_dx_tile_workspace": (_LL, [_I, _I]),
     "fgcn_emb_wgrad_tile": (_I, [_P] * 5 + [_I] * 8 + [_P]),
+    "fgcn_emb_wgrad_tile_h": (_I, [_P] * 5 + [_I] * 8 + [_P]),
     "fgcn_emb_wgrad_tile_slabs": (_I, [_I] * 5),
     "fgcn_emb_tile_available": (_I, [_I] * 3),
     "fgcn_joint_dagg": (_I, [_P] * 5 + [_I] * 11 + [_P] * 5),

@@ -355,6 +355,15 @@ def spec_demb(ic: int) -> List[dict]:
     return out
 
 
+def emb_bwd_tile_ok(W, cfg: BlockConfig, B: int, T: int, V: int, cx: int, o_) -> bool:
+    """Whether block_backward takes the tile form of the embedding backward (ops.emb_dx_tile + ops.emb_wgrad_tile) for this block -- one
+    predicate for the backward and for the forward, which stores emb as bfloat16 in math mode bf16 only if its readers are those two."""
+    cin, ic = cx, cfg.ic
+    small = B * T * V * max(6 * ic, cx) * 4 < 0x7FFF0000
+    return bool(o_.emb_tile and cin <= o_.get("emb_tile_max_cin", ops.get_math_mode()) and "emb_t_b3" in W and cx == cfg.cin
+                and ops.emb_tile_available(V, ic, cin) and small)
+
+
 def half_storage_ok(W, kt: int, s: int, T: int, train: bool, o_) -> bool:
     """Whether this block keeps G and dU in bfloat16 (paths.half_storage): math mode bf16, a training step (the eval-mode bias
     gradient reads dU as f32), and the three consumers on their bfloat16-input kernels -- the halo conv forward and data gradient
@@ -406,7 +415,9 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
             # emb written once, the gram from the tile on chip (inference: not written at all -- only the backward reads it)
-            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic, write_emb=not (inference and not train and o_.fused_inference))
+            half_emb = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_))
+            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic, write_emb=not (inference and not train and o_.fused_inference),
+                                         emb_bf16=half_emb)
         else:
             emb = new(B, T, V, 6 * ic)
             S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
@@ -715,13 +726,14 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        if (o_.emb_tile and cin <= o_.get("emb_tile_max_cin", ops.get_math_mode()) and "emb_t_b3" in W and cx == cin_true and x.shape[3] == cin and ops.emb_tile_available(V, ic, cin)
-                and small(max(6 * ic, cx))):
+        if emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_) and x.shape[3] == cin:
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
             gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
             gw = gw.view(6 * ic, cin_true, 1, 1)
         else:
+            if emb.dtype != torch.float32:       # (cannot happen: the forward asked the same predicate before it chose the storage)
+                raise ops._lib.FgcnError("block backward: emb was stored as bfloat16 but the tile form of its backward is not taken")
             demb = new(B, T, V, 6 * ic)
             gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
             demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)

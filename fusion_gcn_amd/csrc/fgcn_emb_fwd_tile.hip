@@ -49,8 +49,11 @@ template <int NP> constexpr int ef_lds(int ic) { return std::max(NP * EF_XPLANE,
 
 // MU: 16-channel units per wave (CW = 32 MU channels per workgroup); IC: channels per group (16, 32, 64); NSUB: subsets of the workgroup
 // (3 when it holds all 6 ic channels, 1 when it holds th_k | ph_k of one subset)
-template <int NP, int MU, int IC, int NSUB>
+// E16 (NP = 1): emb is written as BFLOAT16 (half-precision storage: only the bf16 staging of fgcn_emb_dx_tile_h / fgcn_emb_wgrad_tile_h reads
+// it, and that staging rounds to bfloat16 anyway -- the same values, half the bytes; ld_e in elements)
+template <int NP, int MU, int IC, int NSUB, bool E16 = false>
 __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
+    static_assert(!E16 || NP == 1, "bfloat16 emb: the one-part kernel");
     constexpr int CW = 32 * MU, NR = 4, GW = ef_gw(IC), GS = ef_gs(IC), GPLANE = 128 * GS, KS = IC >= 32 ? IC / 32 : 1;
     static_assert(CW == (NSUB == 3 ? 6 * IC : 2 * IC), "workgroup channels");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -171,7 +174,12 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
                 acc[mu][nt] += bv[mu];
                 const int R = wr * 64 + 16 * nt + l15;
                 const unsigned off = R < nrows ? ((m0 + (unsigned)R) * (unsigned)p.ld_e + (unsigned)(ch0 + 16 * mu + 4 * g4)) * 4u : EF_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[mu][nt]), re, off, 0, 0);
+                if constexpr (E16) {
+                    const u32x2 h = __builtin_bit_cast(u32x2, pack_bf16(acc[mu][nt]));
+                    __builtin_amdgcn_raw_buffer_store_b64(h, re, off == EF_OOB ? EF_OOB : off >> 1, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[mu][nt]), re, off, 0, 0);
+                }
             }
         // ---- the gram of every subset from the tile: per pass one GW-channel slice of theta_k | phi_k goes into the image -------------------
 #pragma unroll
@@ -263,8 +271,25 @@ extern "C" int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic) {
     return ef_geom(B, T, V, ic).nseg;
 }
 
+static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
+                             int ic, int ld_x, int ld_e, void* stream, bool e16);
+
 extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
                                  int ic, int ld_x, int ld_e, void* stream) {
+    return emb_fwd_tile_impl(x, w3, bias, emb, partial, B, T, V, Cin, ic, ld_x, ld_e, stream, false);
+}
+
+// emb written as BFLOAT16 (math mode bf16 only; ld_e in elements): its only readers, fgcn_emb_dx_tile_h / fgcn_emb_wgrad_tile_h, copy instead of
+// convert -- bit-identical results, half the bytes of the 1.5-activation-wide tensor
+extern "C" int fgcn_emb_fwd_tile_h(const float* x, const void* w3, const float* bias, unsigned short* emb_h, float* partial, int B, int T, int V,
+                                   int Cin, int ic, int ld_x, int ld_e, void* stream) {
+    FGCN_REQUIRE(emb_h, FGCN_E_BADARG, "emb_fwd_tile_h: null pointer");
+    return emb_fwd_tile_impl(x, w3, bias, reinterpret_cast<float*>(emb_h), partial, B, T, V, Cin, ic, ld_x, ld_e, stream, true);
+}
+
+static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
+                             int ic, int ld_x, int ld_e, void* stream, bool e16) {
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_fwd_tile_h: a bfloat16 emb needs math mode bf16");
     // emb == NULL (inference: nothing reads the embeddings after the gram): the kernel's stores of emb go to an empty buffer descriptor and are
     // dropped by the hardware -- the 1.5-activation-wide tensor is never written
     const bool write_emb = emb != nullptr;
@@ -278,7 +303,7 @@ extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bi
     FGCN_REQUIRE(ld_x % 4 == 0 && ld_e % 4 == 0 && ld_x >= Cin && ld_e >= Ce, FGCN_E_ALIGN, "emb_fwd_tile: row strides");
     FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(emb) && aligned16(bias) && (reinterpret_cast<uintptr_t>(partial) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_fwd_tile: 16-byte alignment");
-    const long long x_bytes = (long long)B * T * V * ld_x * 4, e_bytes = (long long)B * T * V * ld_e * 4;
+    const long long x_bytes = (long long)B * T * V * ld_x * 4, e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4);
     const long long plane = (long long)Cin * Ce * 2;
     FGCN_REQUIRE(x_bytes < 0x7FFF0000ll && e_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "emb_fwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -303,15 +328,28 @@ extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bi
         }                                                                                                                   \
         hipLaunchKernelGGL((emb_fwd_tile_kernel<NP_, MU_, IC_, NSUB_>), grid, dim3(256), lds_, s, p);                       \
     } while (0)
+#define FGCN_EF16(MU_, IC_, NSUB_)                                                                                          \
+    do {                                                                                                                    \
+        static bool opted16 = false;                                                                                        \
+        constexpr int lds_ = ef_lds<1>(IC_);                                                                                \
+        if (!opted16) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, true>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                    \
+            opted16 = true;                                                                                                 \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, true>), grid, dim3(256), lds_, s, p);                   \
+    } while (0)
 #define FGCN_EF_NP(MU_, IC_, NSUB_)                    \
     do {                                               \
         if (np == 3) FGCN_EF(3, MU_, IC_, NSUB_);      \
+        else if (e16) FGCN_EF16(MU_, IC_, NSUB_);      \
         else FGCN_EF(1, MU_, IC_, NSUB_);              \
     } while (0)
     if (ic == 16) FGCN_EF_NP(3, 16, 3);
     else if (ic == 32) FGCN_EF_NP(6, 32, 3);
     else FGCN_EF_NP(4, 64, 1);
 #undef FGCN_EF_NP
+#undef FGCN_EF16
 #undef FGCN_EF
     return launch_status("emb_fwd_tile");
 }

@@ -135,8 +135,12 @@ template <int NP> constexpr int ed_lds() { return NP * ED_PLANE + ED_NMAT * NP *
 // PD: chunks the emb values are requested ahead (the chunk loop is unrolled PD times; 6 ic / 32 is a multiple of 3); RSN: weight ring slots
 // (Measured and not kept, profiles/r05_kbench_emb_bwd_variants.txt: the emb values of all three chunks requested at once -- 215-244 registers,
 // 3-10 % slower; eight waves per workgroup, 4 x 2 over the tile, four waves per SIMD at 104-122 registers -- bit-identical, 6-14 % slower.)
-template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN>
+// E16 (NP = 1): emb is a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; ld_e in elements): the strided requests fetch two bytes per value and the value
+// is widened by a shift -- the fragment then holds the same bfloat16 the f32 form would have rounded to
+template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN, bool E16 = false>
 __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
+    static_assert(!E16 || NP == 1, "bfloat16 emb: the one-part kernel");
+    constexpr unsigned ES = E16 ? 2u : 4u;                           // bytes per stored emb value
     constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT, NW = 4;
     static_assert(PD == 1 || PD == 3, "the chunk count is a multiple of three");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
         uok[i] = u < u_hi && uf[i] < nf;                             // (wave-uniform)
     }
     const int nchunks = p.Ce >> 5;                                   // 32-channel pairs of demb
-    const unsigned row_b = (unsigned)p.ld_e * 4u;
+    const unsigned row_b = (unsigned)p.ld_e * ES;
     // emb values of a unit: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][partner channel + l15], j = 0 .. 7 (the A fragment of the mixing).
     // Per request: per-lane offset = the unit's row base | the joint's out-of-range bit (both fixed for the kernel), scalar offset = the
     // joint's rows + the chunk's partner channels; past the last chunk the requests go to an empty descriptor (zeros, no traffic).
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     unsigned ubase[MAXU], jinv[8];
 #pragma unroll
     for (int i = 0; i < MAXU; ++i)
-        ubase[i] = uok[i] ? (((unsigned)((n * p.T + t0 + uf[i]) * V) + 8u * g4) * (unsigned)p.ld_e + (unsigned)l15) * 4u : ET_OOB;
+        ubase[i] = uok[i] ? (((unsigned)((n * p.T + t0 + uf[i]) * V) + 8u * g4) * (unsigned)p.ld_e + (unsigned)l15) * ES : ET_OOB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) jinv[j] = 8 * g4 + j < V ? 0u : ET_OOB;
     auto group_of = [&](int d0) -> int { return (int)__umulhi((unsigned)d0, p.ic_inv); };
@@ -227,8 +231,14 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
                 continue;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, ubase[i] | jinv[j], (unsigned)j * row_b + (unsigned)csrc * 4u, 0));
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (E16) {
+                    const unsigned h = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rc, ubase[i] | jinv[j], (unsigned)j * row_b + (unsigned)csrc * 2u, 0);
+                    xr[i][j] = __builtin_bit_cast(float, h << 16);
+                } else {
+                    xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, ubase[i] | jinv[j], (unsigned)j * row_b + (unsigned)csrc * 4u, 0));
+                }
+            }
         }
     };
     // Branch-free over the wave's units: a unit that does not exist mixes the zeros its requests returned and writes nothing, so that the
@@ -388,7 +398,8 @@ __device__ __forceinline__ void ew_for_slots(Fn&& fn, std::integer_sequence<int,
 // end); NT: 16-channel tiles of x (4 or 8); NSLOT: frame slots of a wave per tile, compile time (straight-line code: exact request counts);
 // NM: matrix slots in LDS (the (subset, side) groups the workgroup's channels touch: 2, or 6 for ic = 16)
 // PF: frame slots the emb values are requested ahead (a ring of PF register sets, by slot index modulo PF: NSLOT % PF == 0)
-template <int NP, int CT, int NT, int NSLOT, int NM, int PF>
+// E16 (NP = 1): emb as BFLOAT16, as in the dx kernel
+template <int NP, int CT, int NT, int NSLOT, int NM, int PF, bool E16 = false>
 __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
     constexpr int FP = 8 / CT;
     static_assert(PF >= 1 && NSLOT % PF == 0, "the slot ring must close over a tile");
@@ -444,8 +455,13 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
         const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_e + (unsigned)((active ? csrc : 0) + l15);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_e)) * 4u : ET_OOB;
-            xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, off, 0, 0));
+            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_e)) * (E16 ? 2u : 4u) : ET_OOB;
+            if constexpr (E16) {
+                const unsigned h = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(re, off, 0, 0);
+                xr[j] = __builtin_bit_cast(float, h << 16);
+            } else {
+                xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, off, 0, 0));
+            }
         }
     };
     auto planes = [&](int n) { et_stage_planes<NP, 512>(Ah, p.d_s + (p.s_batched ? (long long)n * 3 * V * V : 0), V, g_lo, NM, tid); };
@@ -624,9 +640,50 @@ extern "C" long long fgcn_emb_dx_tile_workspace(int B, int d_s_batched) {
     return (d_s_batched ? (long long)B : 1ll) * per;
 }
 
+// one instantiation of the dx kernel (LDS opt-in once per instantiation; not a stream operation: stays out of graph captures); the bfloat16-emb
+// form exists for the one-part kernel
+template <int NP, int NT, int MU, bool ACC, int PD, int RS>
+static void ed_go(bool e16, dim3 grid, hipStream_t s, const EmbDxP& p) {
+    if constexpr (NP == 1) {
+        if (e16) {
+            static bool opted16 = false;
+            if (!opted16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP>());
+                opted16 = true;
+            }
+            hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, true>), grid, dim3(256), ed_lds<NP>(), s, p);
+            return;
+        }
+    }
+    static bool opted = false;
+    if (!opted) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP>());
+        opted = true;
+    }
+    hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS>), grid, dim3(256), ed_lds<NP>(), s, p);
+}
+
+static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, bool e16);
+
 extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
                                 int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
+    return emb_dx_tile_impl(emb, d_s, w3, dx, workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched, accumulate, stream, false);
+}
+
+// emb as a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; math mode bf16 only; ld_e in elements): bit-identical to the f32-emb call on the same values
+extern "C" int fgcn_emb_dx_tile_h(const unsigned short* emb_h, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V,
+                                  int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
+    return emb_dx_tile_impl(reinterpret_cast<const float*>(emb_h), d_s, w3, dx, workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched, accumulate, stream,
+                            true);
+}
+
+static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, bool e16) {
     FGCN_REQUIRE(emb && d_s && w3 && dx && workspace, FGCN_E_BADARG, "emb_dx_tile: null pointer");
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_dx_tile_h: a bfloat16 emb needs math mode bf16");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_dx_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(emb_tile_mode_ok() && emb_tile_sizes_ok(V, ic, Cx), FGCN_E_BADARG,
                  "emb_dx_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx %% 64 == 0 (V=%d ic=%d Cx=%d, mode %d)", FGCN_MAX_V, V,
@@ -635,7 +692,7 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
     FGCN_REQUIRE(ld_e % 4 == 0 && ld_dx % 4 == 0 && ld_e >= Ce && ld_dx >= Cx, FGCN_E_ALIGN, "emb_dx_tile: row strides");
     FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && aligned16(workspace) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_dx_tile: 16-byte alignment");
-    const long long e_bytes = (long long)B * T * V * ld_e * 4, dx_bytes = (long long)B * T * V * ld_dx * 4;
+    const long long e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4), dx_bytes = (long long)B * T * V * ld_dx * 4;
     const long long plane = (long long)Ce * Cx * 2;
     FGCN_REQUIRE(e_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "emb_dx_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -659,16 +716,7 @@ extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* 
     if (np == 3) hipLaunchKernelGGL((emb_planes_kernel<3>), dim3(d_s_batched ? B : 1), dim3(256), 0, s, d_s, static_cast<unsigned char*>(workspace), V);
     else hipLaunchKernelGGL((emb_planes_kernel<1>), dim3(d_s_batched ? B : 1), dim3(256), 0, s, d_s, static_cast<unsigned char*>(workspace), V);
     const bool big = 2 * p.F > 12;                                   // mixing units per wave and chunk: ceil(2 F / 4)
-#define FGCN_ED_GO6(NP_, NT_, MU_, ACC_, PD_, RS_)                                                                   \
-    do {                                                                                                             \
-        static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
-        if (!opted) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP_, NT_, MU_, ACC_, PD_, RS_>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP_>());                    \
-            opted = true;                                                                                            \
-        }                                                                                                            \
-        hipLaunchKernelGGL((emb_dx_tile_kernel<NP_, NT_, MU_, ACC_, PD_, RS_>), grid, dim3(256), ed_lds<NP_>(), s, p); \
-    } while (0)
+#define FGCN_ED_GO6(NP_, NT_, MU_, ACC_, PD_, RS_) ed_go<NP_, NT_, MU_, ACC_, PD_, RS_>(e16, grid, s, p)
     /* tuning key 18 = 1: 128-column tiles with a two-slot weight ring (default four; 64-column tiles always two) */
 #define FGCN_ED_GO4(NP_, NT_, MU_, ACC_)                                   \
     do {                                                                   \
@@ -709,9 +757,49 @@ extern "C" int fgcn_emb_wgrad_tile_slabs(int B, int T, int V, int ic, int Cx) {
     return g.ok ? g.nseg : 0;
 }
 
+template <int NP, int CT, int NT, int NS, int NM, int PF>
+static void ew_go(bool e16, dim3 grid, hipStream_t s, const EmbWgP& p) {
+    constexpr int lds_ = ew_lds<NP, NT, NM>();
+    if constexpr (NP == 1) {
+        if (e16) {
+            static bool attr16 = false;
+            if (!attr16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+                attr16 = true;
+            }
+            hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, true>), grid, dim3(512), lds_, s, p);
+            return;
+        }
+    }
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+        attr = true;
+    }
+    hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF>), grid, dim3(512), lds_, s, p);
+}
+
+static int emb_wgrad_tile_impl(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
+                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, bool e16);
+
 extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
                                    int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream) {
+    return emb_wgrad_tile_impl(emb, x, d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x, d_s_batched, stream, false);
+}
+
+// emb as a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; math mode bf16 only; ld_e in elements)
+extern "C" int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const float* d_s, float* partial, float* bias_partial, int B,
+                                     int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream) {
+    return emb_wgrad_tile_impl(reinterpret_cast<const float*>(emb_h), x, d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x, d_s_batched, stream,
+                               true);
+}
+
+static int emb_wgrad_tile_impl(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
+                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, bool e16) {
     FGCN_REQUIRE(emb && x && d_s && partial && bias_partial, FGCN_E_BADARG, "emb_wgrad_tile: null pointer");
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_wgrad_tile_h: a bfloat16 emb needs math mode bf16");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_wgrad_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_emb_tile_available(V, ic, Cx), FGCN_E_BADARG,
                  "emb_wgrad_tile: V=%d ic=%d Cx=%d in math mode %d not supported (bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx in 64s)", V, ic,
@@ -730,21 +818,11 @@ extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float
     p.emb = emb, p.x = x, p.d_s = d_s, p.partial = partial, p.bias_partial = bias_partial;
     p.B = B, p.T = T, p.V = V, p.ic = ic, p.Ce = Ce, p.Cx = Cx, p.ld_e = ld_e, p.ld_x = ld_x, p.s_batched = d_s_batched;
     p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
-    p.e_bytes = (unsigned)(rows * ld_e * 4), p.x_bytes = (unsigned)(rows * ld_x * 4);
+    p.e_bytes = (unsigned)(rows * ld_e * (e16 ? 2 : 4)), p.x_bytes = (unsigned)(rows * ld_x * 4);
     p.p_bytes = (unsigned)((long long)g.nseg * Ce * Cx * 4), p.b_bytes = (unsigned)((long long)g.nseg * Ce * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
-#define FGCN_EW6(NP_, CT_, NT_, NS_, NM_, PF_)                                                                                    \
-    do {                                                                                                                          \
-        static bool attr = false;                                                                                                 \
-        constexpr int lds_ = ew_lds<NP_, NT_, NM_>();                                                                             \
-        if (!attr) {                                                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_, PF_>),       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                          \
-            attr = true;                                                                                                          \
-        }                                                                                                                         \
-        hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP_, CT_, NT_, NS_, NM_, PF_>), grid, dim3(512), lds_, s, p);                   \
-    } while (0)
+#define FGCN_EW6(NP_, CT_, NT_, NS_, NM_, PF_) ew_go<NP_, CT_, NT_, NS_, NM_, PF_>(e16, grid, s, p)
     /* tuning key 19: slots the emb values are requested ahead (0 = two, 1 = one) */
 #define FGCN_EW(NP_, CT_, NT_, NS_, NM_)                           \
     do {                                                           \

@@ -1303,10 +1303,12 @@ def emb_fwd_tile_available(V: int, ic: int, cin: int) -> bool:
     return bool(_lib.load().fgcn_emb_fwd_tile_available(int(V), int(ic), int(cin)))
 
 
-def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: int, cin: Optional[int] = None, write_emb: bool = True):
+def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: int, cin: Optional[int] = None, write_emb: bool = True,
+                 emb_bf16: bool = False):
     """-> (emb (B,T,V,6 ic) = x . Wemb + bias, partial (B, segments, 3, 32, 32) of the affinity grams theta_k^T phi_k) in one launch
     (fgcn_emb_fwd_tile.hip; agcn.py:104-106).  w3 = ``pack_split3`` of the (1, cin, 6 ic) matrix; ``partial`` goes to ``adj_softmax_fwd``.
-    ``write_emb=False`` (inference: only the backward reads the embeddings): emb is not written and None comes back in its place."""
+    ``write_emb=False`` (inference: only the backward reads the embeddings): emb is not written and None comes back in its place.
+    ``emb_bf16`` (math mode bf16): emb is stored as bfloat16 (fgcn_emb_fwd_tile_h; its readers ``emb_dx_tile`` / ``emb_wgrad_tile`` take it)."""
     ensure_device()
     _chk(x, "emb_fwd_tile.x"), _chk(bias, "emb_fwd_tile.bias")
     B, T, V, ld_x = x.shape
@@ -1319,8 +1321,13 @@ def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: i
     nseg = lib.fgcn_emb_fwd_tile_segments(B, T, V, ic)
     if nseg <= 0:
         raise _lib.FgcnError(f"emb_fwd_tile: sizes not supported: V={V} ic={ic}")
-    emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.float32) if write_emb else None
     partial = torch.empty((B, nseg, 3, 32, 32), device=x.device, dtype=torch.float32)
+    if emb_bf16 and write_emb:
+        emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.bfloat16)
+        check(lib.fgcn_emb_fwd_tile_h(_p(x), w3.data_ptr(), _p(bias), emb.data_ptr(), _p(partial), B, T, V, cin, ic, ld_x, 6 * ic, _stream()),
+              "fgcn_emb_fwd_tile_h")
+        return emb, partial
+    emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.float32) if write_emb else None
     check(lib.fgcn_emb_fwd_tile(_p(x), w3.data_ptr(), _p(bias), _p(emb), _p(partial), B, T, V, cin, ic, ld_x, 6 * ic, _stream()),
           "fgcn_emb_fwd_tile")
     return emb, partial
@@ -1333,7 +1340,13 @@ def emb_tile_available(V: int, ic: int, cx: int) -> bool:
 
 
 def _chk_emb(name: str, emb: torch.Tensor, d_s: torch.Tensor, ic: int) -> None:
-    _chk(emb, f"{name}.emb"), _chk(d_s, f"{name}.d_s")
+    if emb.dtype == torch.bfloat16:       # half-precision storage (math mode bf16: the `_h` entry points)
+        _chk16(emb, f"{name}.emb")
+        if get_math_mode() != "bf16":
+            raise _lib.FgcnError(f"{name}: a bfloat16 emb needs math mode bf16")
+    else:
+        _chk(emb, f"{name}.emb")
+    _chk(d_s, f"{name}.d_s")
     B, T, V, ld_e = emb.shape
     if ld_e < 6 * ic or d_s.shape[0] not in (1, B) or tuple(d_s.shape[1:]) != (3, V, V):
         raise _lib.FgcnError(f"{name}: shape mismatch emb={tuple(emb.shape)} d_s={tuple(d_s.shape)} ic={ic}")
@@ -1356,6 +1369,10 @@ def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torc
     lib = _lib.load()
     batched = int(d_s.shape[0] != 1)
     ws = torch.empty(lib.fgcn_emb_dx_tile_workspace(B, batched), device=emb.device, dtype=torch.uint8)      # the split planes of dS, dS^T
+    if emb.dtype == torch.bfloat16:
+        check(lib.fgcn_emb_dx_tile_h(emb.data_ptr(), _p(d_s), w3.data_ptr(), _p(dx), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
+                                     int(accumulate), _stream()), "fgcn_emb_dx_tile_h")
+        return dx
     check(lib.fgcn_emb_dx_tile(_p(emb), _p(d_s), w3.data_ptr(), _p(dx), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
                                int(accumulate), _stream()), "fgcn_emb_dx_tile")
     return dx
@@ -1377,8 +1394,12 @@ def emb_wgrad_tile(emb: torch.Tensor, x: torch.Tensor, d_s: torch.Tensor, *, ic:
         raise _lib.FgcnError(f"emb_wgrad_tile: sizes not supported: V={V} ic={ic} cx={cx}")
     partial = torch.empty((slabs, 1, 6 * ic, cx), device=x.device, dtype=torch.float32)
     bpart = torch.empty((slabs, 6 * ic), device=x.device, dtype=torch.float32)
-    check(lib.fgcn_emb_wgrad_tile(_p(emb), _p(x), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
-                                  int(d_s.shape[0] != 1), _stream()), "fgcn_emb_wgrad_tile")
+    if emb.dtype == torch.bfloat16:
+        check(lib.fgcn_emb_wgrad_tile_h(emb.data_ptr(), _p(x), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
+                                        int(d_s.shape[0] != 1), _stream()), "fgcn_emb_wgrad_tile_h")
+    else:
+        check(lib.fgcn_emb_wgrad_tile(_p(emb), _p(x), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
+                                      int(d_s.shape[0] != 1), _stream()), "fgcn_emb_wgrad_tile")
     gw = _reduce_slabs(partial, 1, 6 * ic, cx, None, False, None)[0]
     gb = torch.empty((6 * ic,), device=x.device, dtype=torch.float32)
     reduce_sum(bpart, gb, leaf=True)

@@ -218,6 +218,14 @@ int fgcn_spatial_bwd_tile_h(const unsigned short* dy_h, const float* x, const fl
                             const unsigned char* mask2, void* stream);
 int fgcn_spatial_wgrad_tile_h(const float* x, const unsigned short* dy_h, const float* a_hat, float* partial, int B, int T, int V,
                               int Cin, int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream);
+/* ... and of emb, the attention embeddings (1.5 activations wide; written by fgcn_emb_fwd_tile, whose own gram reads the tile on chip; read
+ * only by the operand fetches of the two tile kernels of the embedding backward): ld_e in elements */
+int fgcn_emb_fwd_tile_h(const float* x, const void* w3, const float* bias, unsigned short* emb_h, float* partial, int B, int T, int V,
+                        int Cin, int ic, int ld_x, int ld_e, void* stream);
+int fgcn_emb_dx_tile_h(const unsigned short* emb_h, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V,
+                       int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream);
+int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const float* d_s, float* partial, float* bias_partial, int B,
+                          int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream);
 /* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
  * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
  * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel

@@ -466,3 +466,31 @@ def test_inference_kernels_in_bf16_mode():
         ops.tconv_halo_bn_relu = conv
     err = float((fused - ref).norm() / ref.norm())
     assert err < 5e-2, err      # (two realisations of ten blocks' bf16 roundings: see test_config5_model_against_the_reference)
+
+
+@pytest.mark.parametrize("V,T,cin,ic,B", [(25, 13, 64, 16, 2), (25, 7, 128, 32, 2), (27, 9, 64, 32, 1), (18, 10, 128, 64, 2), (22, 31, 256, 64, 1)])
+def test_embedding_kernels_with_a_bfloat16_emb(V, T, cin, ic, B):
+    """fgcn_emb_fwd_tile_h writes the bfloat16 rounding of what fgcn_emb_fwd_tile writes (same gram partials); fgcn_emb_dx_tile_h /
+    fgcn_emb_wgrad_tile_h on that tensor equal the f32 entry points on the f32 tensor holding the same values, bit for bit."""
+    from fusion_gcn_amd import ops
+    x = gpu(rnd(B, T, V, cin, seed=61))
+    w3 = ops.pack_split3(gpu(rnd(1, cin, 6 * ic, seed=62, scale=cin ** -0.5)))
+    bias = gpu(rnd(6 * ic, seed=63))
+    e32, p32 = ops.emb_fwd_tile(x, w3, bias, ic=ic)
+    e16, p16 = ops.emb_fwd_tile(x, w3, bias, ic=ic, emb_bf16=True)
+    assert e16.dtype == torch.bfloat16 and torch.equal(e16, e32.to(torch.bfloat16)) and torch.equal(p32, p16)
+    ef = e16.float()                                              # the f32 tensor holding the same (bfloat16-representable) values
+    ds = gpu(rnd(B, 3, V, V, seed=64, scale=0.2))
+    wt = ops.pack_split3(gpu(rnd(1, 6 * ic, cin, seed=65, scale=(6 * ic) ** -0.5)))
+    base = gpu(rnd(B, T, V, cin, seed=66))
+    for acc in (False, True):
+        d0, d1 = base.clone(), base.clone()
+        ops.emb_dx_tile(ef, ds, wt, d0, ic=ic, accumulate=acc)
+        ops.emb_dx_tile(e16, ds, wt, d1, ic=ic, accumulate=acc)
+        assert torch.equal(d0, d1), acc
+    gw0, gb0 = ops.emb_wgrad_tile(ef, x, ds, ic=ic)
+    gw1, gb1 = ops.emb_wgrad_tile(e16, x, ds, ic=ic)
+    assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+    gw2, gb2 = ops.emb_wgrad_tile(e16, x, ds[:1], ic=ic)          # shared dS
+    gw3, gb3 = ops.emb_wgrad_tile(ef, x, ds[:1], ic=ic)
+    assert torch.equal(gw2, gw3) and torch.equal(gb2, gb3)
