@@ -142,6 +142,18 @@ SIGNATURES = {
     "fgcn_tconv_wgrad_h": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
     "fgcn_spatial_bwd_tile_h": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P, _I, _P, _P, _P, _P]),
     "fgcn_spatial_wgrad_tile_h": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
+    # typed forms (half-precision activation storage, math mode bf16): `half_mask` before the stream
+    "fgcn_bn_act_t": (_I, [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
+    "fgcn_bn_act_pool_t": (_I, [_P] * 7 + [_I] * 5 + [_P]),
+    "fgcn_bn_act_bwd_reduce_t": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _I, _P]),
+    "fgcn_bn_act_bwd_apply_t": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),
+    "fgcn_tconv_halo_t": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P]),
+    "fgcn_spatial_fwd_tile_t": (_I, [_P] * 6 + [_I] * 9 + [_P]),
+    "fgcn_emb_fwd_tile_t": (_I, [_P] * 5 + [_I] * 8 + [_P]),
+    "fgcn_spatial_bwd_tile_t": (_I, [_P] * 6 + [_I] * 10 + [_P, _I, _P, _P, _P, _I, _P]),
+    "fgcn_spatial_wgrad_tile_t": (_I, [_P] * 4 + [_I] * 9 + [_P]),
+    "fgcn_emb_dx_tile_t": (_I, [_P] * 5 + [_I] * 10 + [_P]),
+    "fgcn_emb_wgrad_tile_t": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "fgcn_bn_act_pool_splits": (_I, [_I, _I]),
     "fgcn_bn_act_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fgcn_bn_act_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _I, _I, _P]),

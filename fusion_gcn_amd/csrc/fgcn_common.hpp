@@ -113,6 +113,22 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
     return __builtin_bit_cast(s16x4, r);
 }
 __device__ __forceinline__ s16x4 pack_bf16(f32x4 a) { return pack_bf16(a[0], a[1], a[2], a[3]); }
+// bfloat16 STORAGE helpers (math mode bf16, the `_t` entry points of include/fgcn.h): four bfloat16 (8 bytes) -> four floats (exact), two
+// floats -> two bfloat16 in one dword (round to nearest even, element 0 in the low half)
+__device__ __forceinline__ f32x4 unpack_bf16x4(__attribute__((ext_vector_type(2))) unsigned h) {
+    const unsigned a = h[0], b = h[1];       // (element -> scalar before the bit casts: hipcc 7.2 reads element 0 of a vector element otherwise)
+    return f32x4{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b << 16),
+                 __builtin_bit_cast(float, b & 0xffff0000u)};
+}
+// the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2]: no LDS traffic)
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a0, float a1) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, bf16x2));
+}
 __device__ __forceinline__ f32x16 mfma_bf16(s16x4 a, s16x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
 }

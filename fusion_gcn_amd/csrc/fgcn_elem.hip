@@ -110,25 +110,36 @@ __device__ __forceinline__ void store4_bf16(unsigned short* ptr, f32x4 val, int 
     if (stream) __builtin_nontemporal_store(h, reinterpret_cast<u32x2*>(ptr));
     else *reinterpret_cast<u32x2*>(ptr) = h;
 }
+// four elements at element offset e of a tensor that is float32 or (half) bfloat16 -- the typed forms of the BatchNorm passes (template
+// parameter TY, kernel argument hm: one bit per activation operand; math mode bf16 with half-precision activation storage, the `_t` entry
+// points).  The flag is a kernel argument: a uniform branch, eight bytes per lane instead of sixteen.
+__device__ __forceinline__ f32x4 ldx4(const float* p, long long e, bool half, int stream) {
+    if (half) {
+        const u32x2* q = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p) + e);
+        return unpack_bf16x4(stream ? __builtin_nontemporal_load(q) : *q);
+    }
+    return load4(p + e, stream);
+}
 // ---- forward epilogue ----------------------------------------------------------------------------------------
 // MASK: also writes the sign bits of the result (bit e%8 of byte e/8 = [out[e] > 0]) for the backward passes, which then
 // read 1/32 of an activation instead of `out`; a lane pair shares a byte (n4 is even, host check).
 // O16: `out` is a bfloat16 tensor (store4_bf16; ld_out == C); the sign image is that of the f32 values (a value that rounds to zero
 // keeps its sign bit: the backward gates exactly as with f32 storage).
-template <int RES, bool MASK, bool O16 = false>
+// TY: typed operands -- bit 0 of hm: `a` is bfloat16, bit 1: `b` is
+template <int RES, bool MASK, bool O16 = false, bool TY = false>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* a, const float* va, const float* b, const float* vb,
-                                                     float* out, unsigned char* mask, long long n4, int C, int relu, int stream, int ld_out) {
+                                                     float* out, unsigned char* mask, long long n4, int C, int relu, int stream, int ld_out, int hm) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
-        const f32x4 x = load4(a + i * 4, stream);
+        const f32x4 x = TY ? ldx4(a, i * 4, hm & 1, stream) : load4(a + i * 4, stream);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(va + 3 * C + c);
         f32x4 y = x * sc + sh;
         if (RES == 1) {
-            y += load4(b + i * 4, stream);
+            y += TY ? ldx4(b, i * 4, hm & 2, stream) : load4(b + i * 4, stream);
         } else if (RES == 2) {
-            const f32x4 r = load4(b + i * 4, stream);
+            const f32x4 r = TY ? ldx4(b, i * 4, hm & 2, stream) : load4(b + i * 4, stream);
             y += r * *reinterpret_cast<const f32x4*>(vb + 2 * C + c) + *reinterpret_cast<const f32x4*>(vb + 3 * C + c);
         }
         if (relu) {
@@ -162,10 +173,11 @@ __device__ __forceinline__ void relu_gate(f32x4& dp, const float* out, const uns
 
 // ---- backward pass 1: per-channel reductions ---------------------------------------------------------------
 // blockDim = (C/4, ny): thread (x, y) owns channels 4x..4x+3 and rows y, y+ny, ... of its tile.
-template <int RES, bool MASKED>
+// TY: typed operands -- bit 0 of hm: `dout` is bfloat16, bit 1: `a`, bit 2: `b`
+template <int RES, bool MASKED, bool TY = false>
 __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, const unsigned char* mask, const float* a,
                                          const float* va, const float* b, const float* vb, float* partials,
-                                         long long rows, long long rows_per_tile, int C, int relu, int ld_dout, int grp_rows) {
+                                         long long rows, long long rows_per_tile, int C, int relu, int ld_dout, int grp_rows, int hm) {
     extern __shared__ float red[];  // [ny][3][Cw], Cw = the channel window of this block: 4 * blockDim.x channels from c0
     const int Cw = blockDim.x * 4, c0 = blockIdx.y * Cw, cl = threadIdx.x * 4;
     const int c = c0 + cl;
@@ -188,12 +200,12 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
             // (ld_dout > C: a channel window of a wider gradient; grp_rows > 0: dout is one row per GROUP of grp_rows consecutive rows -- the
             // gradient of the pooled output of the model's last block, fgcn_bn_act_pool -- and every row of a group reads its group's row)
             const long long dr = grp_rows ? (long long)((unsigned)r / (unsigned)grp_rows) : r;
-            f32x4 dp = *reinterpret_cast<const f32x4*>(dout + dr * ld_dout + c);
+            f32x4 dp = TY ? ldx4(dout, dr * ld_dout + c, hm & 1, 0) : *reinterpret_cast<const f32x4*>(dout + dr * ld_dout + c);
             if (relu) relu_gate<MASKED>(dp, out, mask, o);
-            const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + o) - mean_a) * rstd_a;
+            const f32x4 ah = ((TY ? ldx4(a, o, hm & 2, 0) : *reinterpret_cast<const f32x4*>(a + o)) - mean_a) * rstd_a;
             s1 += dp;
             s2 += dp * ah;
-            if (RES == 2) s3 += dp * ((*reinterpret_cast<const f32x4*>(b + o) - mean_b) * rstd_b);
+            if (RES == 2) s3 += dp * (((TY ? ldx4(b, o, hm & 4, 0) : *reinterpret_cast<const f32x4*>(b + o)) - mean_b) * rstd_b);
         }
     float* mine = red + (long long)threadIdx.y * 3 * Cw;
     *reinterpret_cast<f32x4*>(mine + cl) = s1;
@@ -212,24 +224,26 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
 
 // ---- backward pass 2: apply -----------------------------------------------------------------------------------
 // O16: `da` is a bfloat16 tensor (the gradient of the temporal conv's output, read only by bf16 MFMA staging)
-template <int RES, bool MASKED, bool O16 = false>
+// TY: typed operands -- bit 0 of hm: `dout` is bfloat16, bit 1: `a`, bit 2: `b` (da: O16; db stays float32)
+template <int RES, bool MASKED, bool O16 = false, bool TY = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* out,
                                                                const unsigned char* mask, const float* a,
                                                                const float* va, const float* b, const float* vb,
                                                                const float* sums, float* da, float* db, long long n4,
                                                                int C, int relu, int train, float inv_m,
-                                                               int db_accumulate, int stream, int ld_dout, int grp_rows) {
+                                                               int db_accumulate, int stream, int ld_dout, int grp_rows, int hm) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 4u) % (unsigned)C);   // n4 < 2^30 (host check): 32-bit modulo
         f32x4 dp;
-        if (grp_rows) dp = *reinterpret_cast<const f32x4*>(dout + (long long)(((unsigned)i * 4u / (unsigned)C) / (unsigned)grp_rows) * ld_dout + c);   // (one row per group)
+        if (grp_rows) dp = *reinterpret_cast<const f32x4*>(dout + (long long)(((unsigned)i * 4u / (unsigned)C) / (unsigned)grp_rows) * ld_dout + c);   // (one row per group: float32)
+        else if (TY) dp = ldx4(dout, ld_dout == C ? i * 4 : (i * 4 / C) * ld_dout + c, hm & 1, 0);
         else dp = *reinterpret_cast<const f32x4*>(ld_dout == C ? dout + i * 4 : dout + (i * 4 / C) * ld_dout + c);
         if (relu) relu_gate<MASKED>(dp, out, mask, i * 4);
         const f32x4 sc_a = *reinterpret_cast<const f32x4*>(va + 2 * C + c);
         f32x4 ga = dp;
         if (train) {
-            const f32x4 ah = (*reinterpret_cast<const f32x4*>(a + i * 4) - *reinterpret_cast<const f32x4*>(va + c)) *
+            const f32x4 ah = ((TY ? ldx4(a, i * 4, hm & 2, 0) : *reinterpret_cast<const f32x4*>(a + i * 4)) - *reinterpret_cast<const f32x4*>(va + c)) *
                              *reinterpret_cast<const f32x4*>(va + C + c);
             ga = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
                  ah * (*reinterpret_cast<const f32x4*>(sums + C + c) * inv_m);
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                 const f32x4 sc_b = *reinterpret_cast<const f32x4*>(vb + 2 * C + c);
                 if (train) {
                     const f32x4 bh =
-                        (*reinterpret_cast<const f32x4*>(b + i * 4) - *reinterpret_cast<const f32x4*>(vb + c)) *
+                        ((TY ? ldx4(b, i * 4, hm & 4, 0) : *reinterpret_cast<const f32x4*>(b + i * 4)) - *reinterpret_cast<const f32x4*>(vb + c)) *
                         *reinterpret_cast<const f32x4*>(vb + C + c);
                     gb = dp - *reinterpret_cast<const f32x4*>(sums + c) * inv_m -
                          bh * (*reinterpret_cast<const f32x4*>(sums + 2 * C + c) * inv_m);
@@ -260,9 +274,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
 // that would write it sums it per (group, channel) instead and writes only the sign image the backward's ReLU gate reads -- one
 // activation write and one activation read less per step.  grid = (splits, groups, channel windows of 4 blockDim.x), block =
 // (C/4 up to 64, ny): thread (x, y) owns channels 4x .. 4x+3 and rows y, y + ny, ... of its split; fixed-order sums.
-template <int RES>
+// TY: typed operands -- bit 0 of hm: `a` is bfloat16, bit 1: `b`
+template <int RES, bool TY = false>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* a, const float* va, const float* b, const float* vb,
-                                                         unsigned char* mask, float* partial, int grp_rows, int per, int C) {
+                                                         unsigned char* mask, float* partial, int grp_rows, int per, int C, int hm) {
     extern __shared__ float red[];                       // [ny][Cw]
     const int Cw = blockDim.x * 4, c = blockIdx.z * Cw + threadIdx.x * 4;
     const bool cok = c < C;                              // (C % 8 == 0: a quad -- and its lane pair -- is all-in or all-out)
@@ -296,15 +311,16 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* a, const 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long o = (base + r + u * ny) * C + c;
-                x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + o));
-                q[u] = RES != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + o)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                x[u] = TY ? ldx4(a, o, hm & 1, 1) : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + o));
+                q[u] = RES != 0 ? (TY ? ldx4(b, o, hm & 2, 1) : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(b + o))) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) one(x[u], q[u], (base + r + u * ny) * C + c);
         }
         for (; r < r1; r += ny) {
             const long long o = (base + r) * C + c;
-            one(*reinterpret_cast<const f32x4*>(a + o), RES != 0 ? *reinterpret_cast<const f32x4*>(b + o) : f32x4{0.f, 0.f, 0.f, 0.f}, o);
+            one(TY ? ldx4(a, o, hm & 1, 0) : *reinterpret_cast<const f32x4*>(a + o),
+                RES != 0 ? (TY ? ldx4(b, o, hm & 2, 0) : *reinterpret_cast<const f32x4*>(b + o)) : f32x4{0.f, 0.f, 0.f, 0.f}, o);
         }
     }
     *reinterpret_cast<f32x4*>(red + threadIdx.y * Cw + threadIdx.x * 4) = sum;
@@ -420,8 +436,9 @@ static int check_elem(const char* what, long long rows, int C, int res_mode, con
 }
 
 static int bn_act_impl(const float* a, const float* vec_a, const float* b, const float* vec_b, float* out,
-                       unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, int ld_out, void* stream, bool o16 = false) {
+                       unsigned char* sign_mask, long long rows, int C, int res_mode, int relu, int ld_out, void* stream, bool o16 = false, int hm = 0) {
     FGCN_REQUIRE(a && vec_a && out, FGCN_E_BADARG, "bn_act: null pointer");
+    FGCN_REQUIRE((!o16 && !hm) || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "bn_act: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(!o16 || ld_out == C, FGCN_E_BADARG, "bn_act: a bfloat16 output is contiguous (ld_out == C)");
     if (int e = check_elem("bn_act", rows, C, res_mode, b, vec_b)) return e;
     FGCN_REQUIRE(aligned16(a) && aligned16(out) && aligned16(vec_a) && (!b || aligned16(b)), FGCN_E_ALIGN,
@@ -432,21 +449,26 @@ static int bn_act_impl(const float* a, const float* vec_a, const float* b, const
     FGCN_REQUIRE(!sign_mask || n4 % 2 == 0, FGCN_E_BADARG, "bn_act: a sign mask needs rows*C to be a multiple of 8");
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
+#define FGCN_BN_ACT4(RES_, M_, O_, TY_) \
+    hipLaunchKernelGGL((bn_act_kernel<RES_, M_, O_, TY_>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out, hm)
+#define FGCN_BN_ACT3(RES_, M_, O_)                                                                                \
+    do {                                                                                                          \
+        if (hm) FGCN_BN_ACT4(RES_, M_, O_, true);                                                                 \
+        else FGCN_BN_ACT4(RES_, M_, O_, false);                                                                   \
+    } while (0)
 #define FGCN_BN_ACT(RES_)                                                                                         \
     do {                                                                                                          \
-        if (o16 && sign_mask)                                                                                     \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, true, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
-        else if (o16)                                                                                             \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, false, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
-        else if (sign_mask)                                                                                       \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, true>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
-        else                                                                                                      \
-            hipLaunchKernelGGL((bn_act_kernel<RES_, false>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out); \
+        if (o16 && sign_mask) FGCN_BN_ACT3(RES_, true, true);                                                     \
+        else if (o16) FGCN_BN_ACT3(RES_, false, true);                                                            \
+        else if (sign_mask) FGCN_BN_ACT3(RES_, true, false);                                                      \
+        else FGCN_BN_ACT3(RES_, false, false);                                                                    \
     } while (0)
     if (res_mode == 0) FGCN_BN_ACT(0);
     else if (res_mode == 1) FGCN_BN_ACT(1);
     else FGCN_BN_ACT(2);
 #undef FGCN_BN_ACT
+#undef FGCN_BN_ACT3
+#undef FGCN_BN_ACT4
     return launch_status("bn_act");
 }
 
@@ -463,9 +485,11 @@ static int reduce_block(int C, dim3* blk) {
 static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const unsigned char* sign_mask,
                                   const float* a, const float* vec_a, const float* b, const float* vec_b,
                                   float* partials, int n_tiles, long long rows, int C, int res_mode, int relu,
-                                  int ld_dout, void* stream, int grp_rows = 0) {
+                                  int ld_dout, void* stream, int grp_rows = 0, int hm = 0) {
     FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
                  "bn_act_bwd_reduce: %lld rows are not whole groups of %d", rows, grp_rows);
+    FGCN_REQUIRE(!hm || (fgcn::math_mode() == FGCN_MATH_BF16 && !((hm & 1) && grp_rows) && (!relu || sign_mask)), FGCN_E_BADARG,
+                 "bn_act_bwd_reduce: bfloat16 tensors need math mode bf16, the sign image as the ReLU gate and a float32 per-group gradient");
     FGCN_REQUIRE(dout && a && vec_a && partials && (!relu || out || sign_mask), FGCN_E_BADARG,
                  "bn_act_bwd_reduce: null pointer");
     if (int e = check_elem("bn_act_bwd_reduce", rows, C, res_mode, b, vec_b)) return e;
@@ -478,15 +502,21 @@ static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const uns
     const long long rpt = rows_per_tile_for(rows);
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
+#define FGCN_BN_RED3(RES_, M_, TY_)                                                                                \
+    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_, TY_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
+                       partials, rows, rpt, C, relu, ld_dout, grp_rows, hm)
 #define FGCN_BN_RED(RES_, M_)                                                                                      \
-    hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
-                       partials, rows, rpt, C, relu, ld_dout, grp_rows)
+    do {                                                                                                           \
+        if (hm) FGCN_BN_RED3(RES_, M_, true);                                                                      \
+        else FGCN_BN_RED3(RES_, M_, false);                                                                        \
+    } while (0)
     if (res_mode == 2) {
         if (sign_mask) FGCN_BN_RED(2, true); else FGCN_BN_RED(2, false);
     } else {
         if (sign_mask) FGCN_BN_RED(0, true); else FGCN_BN_RED(0, false);
     }
 #undef FGCN_BN_RED
+#undef FGCN_BN_RED3
     return launch_status("bn_act_bwd_reduce");
 }
 
@@ -494,9 +524,11 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
                                  const float* a, const float* vec_a, const float* b, const float* vec_b,
                                  const float* sums, float* da, float* db,
                                  long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
-                                 int ld_dout, void* stream, int grp_rows = 0, bool o16 = false) {
+                                 int ld_dout, void* stream, int grp_rows = 0, bool o16 = false, int hm = 0) {
     FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: %lld rows are not whole groups of %d", rows, grp_rows);
+    FGCN_REQUIRE((!hm && !o16) || (fgcn::math_mode() == FGCN_MATH_BF16 && !((hm & 1) && grp_rows) && (!hm || !relu || sign_mask)), FGCN_E_BADARG,
+                 "bn_act_bwd_apply: bfloat16 tensors need math mode bf16, the sign image as the ReLU gate and a float32 per-group gradient");
     FGCN_REQUIRE(dout && vec_a && da && (!relu || out || sign_mask) && (!train || (a && sums)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: null pointer");
     FGCN_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && res_mode >= 0 && res_mode <= 2, FGCN_E_BADARG,
@@ -509,12 +541,15 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
+#define FGCN_BN_APP4(RES_, M_, O_, TY_)                                                                            \
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_, O_, TY_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
+                       da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows, hm)
 #define FGCN_BN_APP(RES_, M_)                                                                                      \
     do {                                                                                                           \
-        if (o16) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_, true>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                                    da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows);     \
-        else hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
-                                da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows);         \
+        if (o16 && hm) FGCN_BN_APP4(RES_, M_, true, true);                                                         \
+        else if (o16) FGCN_BN_APP4(RES_, M_, true, false);                                                         \
+        else if (hm) FGCN_BN_APP4(RES_, M_, false, true);                                                          \
+        else FGCN_BN_APP4(RES_, M_, false, false);                                                                 \
     } while (0)
     if (res_mode == 0 || !db) {
         if (sign_mask) FGCN_BN_APP(0, true); else FGCN_BN_APP(0, false);
@@ -524,6 +559,7 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
         if (sign_mask) FGCN_BN_APP(2, true); else FGCN_BN_APP(2, false);
     }
 #undef FGCN_BN_APP
+#undef FGCN_BN_APP4
     return launch_status("bn_act_bwd_apply");
 }
 
@@ -700,9 +736,10 @@ extern "C" int fgcn_bn_act_pool_splits(int groups, int grp_rows) {
     return splits;
 }
 
-extern "C" int fgcn_bn_act_pool(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned char* sign_mask,
-                                float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, void* stream) {
+static int bn_act_pool_impl(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned char* sign_mask,
+                            float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, void* stream, int hm) {
     FGCN_REQUIRE(a && vec_a && sign_mask && partial && pooled, FGCN_E_BADARG, "bn_act_pool: null pointer");
+    FGCN_REQUIRE(!hm || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "bn_act_pool: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(groups > 0 && groups <= 65535 && grp_rows > 0 && C > 0 && C % 8 == 0, FGCN_E_BADARG,
                  "bn_act_pool: groups=%d grp_rows=%d C=%d (C must be a multiple of 8)", groups, grp_rows, C);
     if (int e = check_elem("bn_act_pool", (long long)groups * grp_rows, C, res_mode, b, vec_b)) return e;
@@ -715,12 +752,53 @@ extern "C" int fgcn_bn_act_pool(const float* a, const float* vec_a, const float*
     const dim3 grid((unsigned)splits, (unsigned)groups, (unsigned)cdiv(C, cx * 4)), blk((unsigned)cx, (unsigned)ny);
     const size_t lds = (size_t)ny * cx * 4 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (res_mode == 0) hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
-    else if (res_mode == 1) hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
-    else hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C);
+#define FGCN_BN_POOL(RES_)                                                                                                          \
+    do {                                                                                                                            \
+        if (hm) hipLaunchKernelGGL((bn_act_pool_kernel<RES_, true>), grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C, hm); \
+        else hipLaunchKernelGGL((bn_act_pool_kernel<RES_, false>), grid, blk, lds, s, a, vec_a, b, vec_b, sign_mask, partial, grp_rows, per, C, 0);    \
+    } while (0)
+    if (res_mode == 0) FGCN_BN_POOL(0);
+    else if (res_mode == 1) FGCN_BN_POOL(1);
+    else FGCN_BN_POOL(2);
+#undef FGCN_BN_POOL
     hipLaunchKernelGGL(group_mean_finish_kernel, dim3((unsigned)cdiv((long long)groups * C, 256)), dim3(256), 0, s, partial, pooled, groups,
                        C, splits, 1.f / (float)grp_rows);
     return launch_status("bn_act_pool");
+}
+
+extern "C" int fgcn_bn_act_pool(const float* a, const float* vec_a, const float* b, const float* vec_b, unsigned char* sign_mask,
+                                float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, void* stream) {
+    return bn_act_pool_impl(a, vec_a, b, vec_b, sign_mask, partial, pooled, groups, grp_rows, C, res_mode, stream, 0);
+}
+
+// ---- typed forms (`_t`): `half_mask` says which activation operands are bfloat16 tensors (math mode bf16 with half-precision activation
+// storage: the reference's autocast semantics, session/procedures/step.py:55-78); bit order = argument order, see include/fgcn.h ------------
+extern "C" int fgcn_bn_act_t(const void* a, const float* vec_a, const void* b, const float* vec_b, void* out, unsigned char* sign_mask,
+                             long long rows, int C, int res_mode, int relu, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~7) == 0, FGCN_E_BADARG, "bn_act_t: half_mask=%d", half_mask);
+    return bn_act_impl(static_cast<const float*>(a), vec_a, static_cast<const float*>(b), vec_b, static_cast<float*>(out), sign_mask, rows, C,
+                       res_mode, relu, C, stream, (half_mask & 4) != 0, half_mask & 3);
+}
+extern "C" int fgcn_bn_act_pool_t(const void* a, const float* vec_a, const void* b, const float* vec_b, unsigned char* sign_mask,
+                                  float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~3) == 0, FGCN_E_BADARG, "bn_act_pool_t: half_mask=%d", half_mask);
+    return bn_act_pool_impl(static_cast<const float*>(a), vec_a, static_cast<const float*>(b), vec_b, sign_mask, partial, pooled, groups,
+                            grp_rows, C, res_mode, stream, half_mask);
+}
+extern "C" int fgcn_bn_act_bwd_reduce_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
+                                        const float* vec_a, const void* b, const float* vec_b, float* partials, int n_tiles, long long rows,
+                                        int C, int res_mode, int relu, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~7) == 0 && grp_rows >= 0, FGCN_E_BADARG, "bn_act_bwd_reduce_t: half_mask=%d grp_rows=%d", half_mask, grp_rows);
+    return bn_act_bwd_reduce_impl(static_cast<const float*>(dout), out, sign_mask, static_cast<const float*>(a), vec_a, static_cast<const float*>(b),
+                                  vec_b, partials, n_tiles, rows, C, res_mode, relu, C, stream, grp_rows, half_mask);
+}
+extern "C" int fgcn_bn_act_bwd_apply_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
+                                       const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, float* db,
+                                       long long rows, int C, int res_mode, int relu, int train, int db_accumulate, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~15) == 0 && grp_rows >= 0, FGCN_E_BADARG, "bn_act_bwd_apply_t: half_mask=%d grp_rows=%d", half_mask, grp_rows);
+    return bn_act_bwd_apply_impl(static_cast<const float*>(dout), out, sign_mask, static_cast<const float*>(a), vec_a, static_cast<const float*>(b),
+                                 vec_b, sums, static_cast<float*>(da), db, rows, C, res_mode, relu, train, db_accumulate, C, stream, grp_rows,
+                                 (half_mask & 8) != 0, half_mask & 7);
 }
 
 // The two backward passes with the gradient of a POOLED output (fgcn_bn_act_pool): dout is float[rows / grp_rows][C], one row per group of

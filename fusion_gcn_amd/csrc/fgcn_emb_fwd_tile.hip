@@ -51,9 +51,12 @@ template <int NP> constexpr int ef_lds(int ic) { return std::max(NP * EF_XPLANE,
 // (3 when it holds all 6 ic channels, 1 when it holds th_k | ph_k of one subset)
 // E16 (NP = 1): emb is written as BFLOAT16 (half-precision storage: only the bf16 staging of fgcn_emb_dx_tile_h / fgcn_emb_wgrad_tile_h reads
 // it, and that staging rounds to bfloat16 anyway -- the same values, half the bytes; ld_e in elements)
-template <int NP, int MU, int IC, int NSUB, bool E16 = false>
+// H16 bit 0 = that (emb bfloat16), bit 1 = x is a BFLOAT16 tensor too (half-precision activation storage, the `_t` entry point; ld_x in
+// elements): its rows are copied into the image, 8 bytes per four channels -- the staged bytes of the float32 tensor of the same values
+template <int NP, int MU, int IC, int NSUB, int H16 = 0>
 __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
-    static_assert(!E16 || NP == 1, "bfloat16 emb: the one-part kernel");
+    static_assert(!H16 || NP == 1, "bfloat16 tensors: the one-part kernel");
+    constexpr bool E16 = (H16 & 1) != 0, X16 = (H16 & 2) != 0;
     constexpr int CW = 32 * MU, NR = 4, GW = ef_gw(IC), GS = ef_gs(IC), GPLANE = 128 * GS, KS = IC >= 32 ? IC / 32 : 1;
     static_assert(CW == (NSUB == 3 ? 6 * IC : 2 * IC), "workgroup channels");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -102,8 +105,14 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = srow + 32 * i;
-            const unsigned off = r < nrows_ ? ((row0_ + (unsigned)r) * (unsigned)p.ld_x + (unsigned)(32 * c + 4 * sg)) * 4u : EF_OOB;
-            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            const unsigned off = r < nrows_ ? ((row0_ + (unsigned)r) * (unsigned)p.ld_x + (unsigned)(32 * c + 4 * sg)) * (X16 ? 2u : 4u) : EF_OOB;
+            if constexpr (X16) {                                     // four bfloat16 = 8 bytes, parked in the first two components
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0));
+                const unsigned b0 = h[0], b1 = h[1];                 // (element -> scalar before a bit cast: hipcc 7.2 reads element 0 otherwise)
+                stg[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+            } else {
+                stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            }
         }
     };
     auto deposit = [&]() {
@@ -111,7 +120,12 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
         for (int i = 0; i < 4; ++i) {
             const int r = srow + 32 * i;
             u32x2 parts[NP];
-            splitn_x4<NP>(stg[i], parts);
+            if constexpr (X16) {                                     // already bfloat16: a copy
+                const float e0 = stg[i][0], e1 = stg[i][1];
+                parts[0] = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+            } else {
+                splitn_x4<NP>(stg[i], parts);
+            }
             unsigned char* dst = Xh + r * EF_XS + ((unsigned)(sg * 8) ^ swz(r));
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * EF_XPLANE) = parts[pl];
@@ -272,11 +286,11 @@ extern "C" int fgcn_emb_fwd_tile_segments(int B, int T, int V, int ic) {
 }
 
 static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
-                             int ic, int ld_x, int ld_e, void* stream, bool e16);
+                             int ic, int ld_x, int ld_e, void* stream, int e16);
 
 extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
                                  int ic, int ld_x, int ld_e, void* stream) {
-    return emb_fwd_tile_impl(x, w3, bias, emb, partial, B, T, V, Cin, ic, ld_x, ld_e, stream, false);
+    return emb_fwd_tile_impl(x, w3, bias, emb, partial, B, T, V, Cin, ic, ld_x, ld_e, stream, 0);
 }
 
 // emb written as BFLOAT16 (math mode bf16 only; ld_e in elements): its only readers, fgcn_emb_dx_tile_h / fgcn_emb_wgrad_tile_h, copy instead of
@@ -284,12 +298,20 @@ extern "C" int fgcn_emb_fwd_tile(const float* x, const void* w3, const float* bi
 extern "C" int fgcn_emb_fwd_tile_h(const float* x, const void* w3, const float* bias, unsigned short* emb_h, float* partial, int B, int T, int V,
                                    int Cin, int ic, int ld_x, int ld_e, void* stream) {
     FGCN_REQUIRE(emb_h, FGCN_E_BADARG, "emb_fwd_tile_h: null pointer");
-    return emb_fwd_tile_impl(x, w3, bias, reinterpret_cast<float*>(emb_h), partial, B, T, V, Cin, ic, ld_x, ld_e, stream, true);
+    return emb_fwd_tile_impl(x, w3, bias, reinterpret_cast<float*>(emb_h), partial, B, T, V, Cin, ic, ld_x, ld_e, stream, 1);
+}
+
+// typed form (math mode bf16): half_mask bit 0 = x is a bfloat16 tensor, bit 1 = emb is written as bfloat16 (emb may be NULL)
+extern "C" int fgcn_emb_fwd_tile_t(const void* x, const void* w3, const float* bias, void* emb, float* partial, int B, int T, int V, int Cin,
+                                   int ic, int ld_x, int ld_e, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~3) == 0, FGCN_E_BADARG, "emb_fwd_tile_t: half_mask=%d", half_mask);
+    return emb_fwd_tile_impl(static_cast<const float*>(x), w3, bias, static_cast<float*>(emb), partial, B, T, V, Cin, ic, ld_x, ld_e, stream,
+                             ((half_mask & 2) ? 1 : 0) | ((half_mask & 1) ? 2 : 0));
 }
 
 static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, float* emb, float* partial, int B, int T, int V, int Cin,
-                             int ic, int ld_x, int ld_e, void* stream, bool e16) {
-    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_fwd_tile_h: a bfloat16 emb needs math mode bf16");
+                             int ic, int ld_x, int ld_e, void* stream, int e16) {      // e16: bit 0 = emb bfloat16, bit 1 = x bfloat16 (1 or 3)
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_fwd_tile_h: bfloat16 tensors need math mode bf16");
     // emb == NULL (inference: nothing reads the embeddings after the gram): the kernel's stores of emb go to an empty buffer descriptor and are
     // dropped by the hardware -- the 1.5-activation-wide tensor is never written
     const bool write_emb = emb != nullptr;
@@ -303,7 +325,7 @@ static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, 
     FGCN_REQUIRE(ld_x % 4 == 0 && ld_e % 4 == 0 && ld_x >= Cin && ld_e >= Ce, FGCN_E_ALIGN, "emb_fwd_tile: row strides");
     FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(emb) && aligned16(bias) && (reinterpret_cast<uintptr_t>(partial) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_fwd_tile: 16-byte alignment");
-    const long long x_bytes = (long long)B * T * V * ld_x * 4, e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4);
+    const long long x_bytes = (long long)B * T * V * ld_x * ((e16 & 2) ? 2 : 4), e_bytes = (long long)B * T * V * ld_e * ((e16 & 1) ? 2 : 4);
     const long long plane = (long long)Cin * Ce * 2;
     FGCN_REQUIRE(x_bytes < 0x7FFF0000ll && e_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "emb_fwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -328,21 +350,23 @@ static int emb_fwd_tile_impl(const float* x, const void* w3, const float* bias, 
         }                                                                                                                   \
         hipLaunchKernelGGL((emb_fwd_tile_kernel<NP_, MU_, IC_, NSUB_>), grid, dim3(256), lds_, s, p);                       \
     } while (0)
-#define FGCN_EF16(MU_, IC_, NSUB_)                                                                                          \
+#define FGCN_EF16(MU_, IC_, NSUB_, H_)                                                                                      \
     do {                                                                                                                    \
         static bool opted16 = false;                                                                                        \
         constexpr int lds_ = ef_lds<1>(IC_);                                                                                \
         if (!opted16) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, true>),        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, H_>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                                    \
             opted16 = true;                                                                                                 \
         }                                                                                                                   \
-        hipLaunchKernelGGL((emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, true>), grid, dim3(256), lds_, s, p);                   \
+        hipLaunchKernelGGL((emb_fwd_tile_kernel<1, MU_, IC_, NSUB_, H_>), grid, dim3(256), lds_, s, p);                     \
     } while (0)
 #define FGCN_EF_NP(MU_, IC_, NSUB_)                    \
     do {                                               \
         if (np == 3) FGCN_EF(3, MU_, IC_, NSUB_);      \
-        else if (e16) FGCN_EF16(MU_, IC_, NSUB_);      \
+        else if (e16 == 3) FGCN_EF16(MU_, IC_, NSUB_, 3); \
+        else if (e16 == 2) FGCN_EF16(MU_, IC_, NSUB_, 2); \
+        else if (e16 == 1) FGCN_EF16(MU_, IC_, NSUB_, 1); \
         else FGCN_EF(1, MU_, IC_, NSUB_);              \
     } while (0)
     if (ic == 16) FGCN_EF_NP(3, 16, 3);

@@ -137,10 +137,14 @@ template <int NP> constexpr int ed_lds() { return NP * ED_PLANE + ED_NMAT * NP *
 // 3-10 % slower; eight waves per workgroup, 4 x 2 over the tile, four waves per SIMD at 104-122 registers -- bit-identical, 6-14 % slower.)
 // E16 (NP = 1): emb is a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; ld_e in elements): the strided requests fetch two bytes per value and the value
 // is widened by a shift -- the fragment then holds the same bfloat16 the f32 form would have rounded to
-template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN, bool E16 = false>
+// H16 bit 0 = that, bit 1 = dx is a BFLOAT16 tensor too (half-precision activation storage, the `_t` entry point; ld_dx in elements): the old
+// values are 2-byte loads, the result is rounded once and adjacent lanes pair their columns into dword stores (fgcn_tconv.hip's bfloat16 epilogue)
+template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN, int H16 = 0>
 __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
-    static_assert(!E16 || NP == 1, "bfloat16 emb: the one-part kernel");
+    static_assert(!H16 || NP == 1, "bfloat16 tensors: the one-part kernel");
+    constexpr bool E16 = (H16 & 1) != 0, DX16 = (H16 & 2) != 0;
     constexpr unsigned ES = E16 ? 2u : 4u;                           // bytes per stored emb value
+    constexpr unsigned DS = DX16 ? 2u : 4u;                          // ... per dx value
     constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT, NW = 4;
     static_assert(PD == 1 || PD == 3, "the chunk count is a multiple of three");
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     // output element depends on its own image row and weight column only.
     const unsigned m0 = (unsigned)((n * p.T + t0) * V);              // (32-bit row math: the launcher bounds the tensors by 2 GiB)
     const int col = n0 + wc * NT * 32 + l15;                         // + nu * 16
-    const unsigned lane_base = ((m0 + (unsigned)(wr * (16 * MTW) + 4 * g4)) * (unsigned)p.ld_dx + (unsigned)col) * 4u;
-    const unsigned dx_row_b = (unsigned)p.ld_dx * 4u;
+    const unsigned lane_base = ((m0 + (unsigned)(wr * (16 * MTW) + 4 * g4)) * (unsigned)p.ld_dx + (unsigned)col) * DS;
+    const unsigned dx_row_b = (unsigned)p.ld_dx * DS;
     f32x4 acc[MTW][NU];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -183,7 +187,10 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                if constexpr (ACC && !(FGCN_PROBE_EMB & 16))
+                if constexpr (ACC && DX16)
+                    acc[mt][nu][r] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+                                                                   rdx, lane_base + nu * 32, (unsigned)(mt * 16 + r) * dx_row_b, 0) << 16);
+                else if constexpr (ACC && !(FGCN_PROBE_EMB & 16))
                     acc[mt][nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdx, lane_base + nu * 64, (unsigned)(mt * 16 + r) * dx_row_b, 0));
                 else
                     acc[mt][nu][r] = 0.f;
@@ -349,6 +356,25 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
 
     auto val_guard = [](float v) { return v != 1.2345e-30f; };      // (probe bit 5: the stores depend on the values, nothing is written)
     // ---- epilogue: branch-free buffer stores; rows beyond the tile's frames and columns beyond Cout carry the out-of-range offset
+    if constexpr (DX16) {
+        // two rows at a time: the even lane of a pair stores columns (c, c + 1) of row rp as one dword, the odd lane those of row rp + 1
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+                const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + rp + (odd ? 1 : 0);
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    const float v0 = acc[mt][nu][rp], v1 = acc[mt][nu][rp + 1];
+                    const float other = lane_xor1(odd ? v0 : v1);
+                    const unsigned pk = odd ? pack_bf16x2(other, v1) : pack_bf16x2(v0, other);
+                    const unsigned off = (row < nrows && col + nu * 16 < p.Cout) ? lane_base + nu * 32 + (odd ? dx_row_b - 2u : 0u) : ET_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, rdx, off, (unsigned)(mt * 16 + rp) * dx_row_b, 0);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -399,8 +425,11 @@ __device__ __forceinline__ void ew_for_slots(Fn&& fn, std::integer_sequence<int,
 // NM: matrix slots in LDS (the (subset, side) groups the workgroup's channels touch: 2, or 6 for ic = 16)
 // PF: frame slots the emb values are requested ahead (a ring of PF register sets, by slot index modulo PF: NSLOT % PF == 0)
 // E16 (NP = 1): emb as BFLOAT16, as in the dx kernel
-template <int NP, int CT, int NT, int NSLOT, int NM, int PF, bool E16 = false>
+// H16 bit 0 = that, bit 1 = x is a BFLOAT16 tensor too (the `_t` entry point; ld_x in elements): its rows are copied into the image
+template <int NP, int CT, int NT, int NSLOT, int NM, int PF, int H16 = 0>
 __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
+    static_assert(!H16 || NP == 1, "bfloat16 tensors: the one-part kernel");
+    constexpr bool E16 = (H16 & 1) != 0, X16 = (H16 & 2) != 0;
     constexpr int FP = 8 / CT;
     static_assert(PF >= 1 && NSLOT % PF == 0, "the slot ring must close over a tile");
     constexpr int RS = ew_rs<NT>(), PL = EW_ROWS * RS;
@@ -443,8 +472,14 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
         const int nrows_ = (g < t_hi && (!(FGCN_PROBE_EMB & 2048) || g == t_lo)) ? min(F, p.T - t0_) * V : 0;
         const unsigned row0_ = (unsigned)((n_ * p.T + t0_) * V);
         const int r = srow + RPP * i;
-        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_x + (unsigned)(o0 + 4 * sg)) * 4u : ET_OOB;
-        stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        const unsigned off = r < nrows_ ? ((row0_ + r) * (unsigned)p.ld_x + (unsigned)(o0 + 4 * sg)) * (X16 ? 2u : 4u) : ET_OOB;
+        if constexpr (X16) {                                         // four bfloat16 = 8 bytes, parked in the first two components
+            const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0));
+            const unsigned b0 = h[0], b1 = h[1];                     // (element -> scalar before a bit cast: hipcc 7.2 reads element 0 otherwise)
+            stg[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+        } else {
+            stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
     };
     // emb values of frame slot s of pair g for this wave: lane (c = l15, g4) <- emb[(f, v = 8 g4 + j)][csrc + l15], j = 0 .. 7
     float xr_ring[PF][8];
@@ -470,7 +505,12 @@ __global__ __launch_bounds__(512, 1) void emb_wgrad_tile_kernel(EmbWgP p) {
         for (int i = 0; i < NPASS; ++i) {
             const int r = srow + RPP * i;
             u32x2 parts[NP];
-            splitn_x4<NP>(stg[i], parts);
+            if constexpr (X16) {                                     // already bfloat16: a copy
+                const float e0 = stg[i][0], e1 = stg[i][1];
+                parts[0] = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+            } else {
+                splitn_x4<NP>(stg[i], parts);
+            }
             unsigned char* dst = Im + r * RS + sg * 8;
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PL) = parts[pl];
@@ -643,16 +683,26 @@ extern "C" long long fgcn_emb_dx_tile_workspace(int B, int d_s_batched) {
 // one instantiation of the dx kernel (LDS opt-in once per instantiation; not a stream operation: stays out of graph captures); the bfloat16-emb
 // form exists for the one-part kernel
 template <int NP, int NT, int MU, bool ACC, int PD, int RS>
-static void ed_go(bool e16, dim3 grid, hipStream_t s, const EmbDxP& p) {
+static void ed_go(int e16, dim3 grid, hipStream_t s, const EmbDxP& p) {      // e16: 1 = emb bfloat16, 3 = emb and dx
     if constexpr (NP == 1) {
+        if (e16 == 3) {
+            static bool opted163 = false;
+            if (!opted163) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP>());
+                opted163 = true;
+            }
+            hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 3>), grid, dim3(256), ed_lds<NP>(), s, p);
+            return;
+        }
         if (e16) {
             static bool opted16 = false;
             if (!opted16) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP>());
                 opted16 = true;
             }
-            hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, true>), grid, dim3(256), ed_lds<NP>(), s, p);
+            hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 1>), grid, dim3(256), ed_lds<NP>(), s, p);
             return;
         }
     }
@@ -666,24 +716,32 @@ static void ed_go(bool e16, dim3 grid, hipStream_t s, const EmbDxP& p) {
 }
 
 static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
-                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, bool e16);
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16);
 
 extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
                                 int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
-    return emb_dx_tile_impl(emb, d_s, w3, dx, workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched, accumulate, stream, false);
+    return emb_dx_tile_impl(emb, d_s, w3, dx, workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched, accumulate, stream, 0);
 }
 
 // emb as a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; math mode bf16 only; ld_e in elements): bit-identical to the f32-emb call on the same values
 extern "C" int fgcn_emb_dx_tile_h(const unsigned short* emb_h, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V,
                                   int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
     return emb_dx_tile_impl(reinterpret_cast<const float*>(emb_h), d_s, w3, dx, workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched, accumulate, stream,
-                            true);
+                            1);
+}
+
+// typed form (math mode bf16): half_mask bit 0 = emb is a bfloat16 tensor, bit 1 = dx is (masks 0, 1, 3); strides in elements
+extern "C" int fgcn_emb_dx_tile_t(const void* emb, const float* d_s, const void* w3, void* dx, void* workspace, int B, int T, int V,
+                                  int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "emb_dx_tile_t: half_mask=%d (0, 1 or 3)", half_mask);
+    return emb_dx_tile_impl(static_cast<const float*>(emb), d_s, w3, static_cast<float*>(dx), workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched,
+                            accumulate, stream, half_mask);
 }
 
 static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
-                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, bool e16) {
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16) {
     FGCN_REQUIRE(emb && d_s && w3 && dx && workspace, FGCN_E_BADARG, "emb_dx_tile: null pointer");
-    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_dx_tile_h: a bfloat16 emb needs math mode bf16");
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_dx_tile_h: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_dx_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(emb_tile_mode_ok() && emb_tile_sizes_ok(V, ic, Cx), FGCN_E_BADARG,
                  "emb_dx_tile: needs math mode bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx %% 64 == 0 (V=%d ic=%d Cx=%d, mode %d)", FGCN_MAX_V, V,
@@ -692,7 +750,7 @@ static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, 
     FGCN_REQUIRE(ld_e % 4 == 0 && ld_dx % 4 == 0 && ld_e >= Ce && ld_dx >= Cx, FGCN_E_ALIGN, "emb_dx_tile: row strides");
     FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && aligned16(workspace) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_dx_tile: 16-byte alignment");
-    const long long e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4), dx_bytes = (long long)B * T * V * ld_dx * 4;
+    const long long e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4), dx_bytes = (long long)B * T * V * ld_dx * (e16 == 3 ? 2 : 4);
     const long long plane = (long long)Ce * Cx * 2;
     FGCN_REQUIRE(e_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "emb_dx_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -758,17 +816,27 @@ extern "C" int fgcn_emb_wgrad_tile_slabs(int B, int T, int V, int ic, int Cx) {
 }
 
 template <int NP, int CT, int NT, int NS, int NM, int PF>
-static void ew_go(bool e16, dim3 grid, hipStream_t s, const EmbWgP& p) {
+static void ew_go(int e16, dim3 grid, hipStream_t s, const EmbWgP& p) {      // e16: 1 = emb bfloat16, 3 = emb and x
     constexpr int lds_ = ew_lds<NP, NT, NM>();
     if constexpr (NP == 1) {
+        if (e16 == 3) {
+            static bool attr163 = false;
+            if (!attr163) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, 3>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+                attr163 = true;
+            }
+            hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, 3>), grid, dim3(512), lds_, s, p);
+            return;
+        }
         if (e16) {
             static bool attr16 = false;
             if (!attr16) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
                 attr16 = true;
             }
-            hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, true>), grid, dim3(512), lds_, s, p);
+            hipLaunchKernelGGL((emb_wgrad_tile_kernel<NP, CT, NT, NS, NM, PF, 1>), grid, dim3(512), lds_, s, p);
             return;
         }
     }
@@ -782,24 +850,32 @@ static void ew_go(bool e16, dim3 grid, hipStream_t s, const EmbWgP& p) {
 }
 
 static int emb_wgrad_tile_impl(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
-                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, bool e16);
+                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, int e16);
 
 extern "C" int fgcn_emb_wgrad_tile(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
                                    int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream) {
-    return emb_wgrad_tile_impl(emb, x, d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x, d_s_batched, stream, false);
+    return emb_wgrad_tile_impl(emb, x, d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x, d_s_batched, stream, 0);
 }
 
 // emb as a BFLOAT16 tensor (fgcn_emb_fwd_tile_h; math mode bf16 only; ld_e in elements)
 extern "C" int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const float* d_s, float* partial, float* bias_partial, int B,
                                      int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream) {
     return emb_wgrad_tile_impl(reinterpret_cast<const float*>(emb_h), x, d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x, d_s_batched, stream,
-                               true);
+                               1);
+}
+
+// typed form (math mode bf16): half_mask bit 0 = emb is a bfloat16 tensor, bit 1 = x is (masks 0, 1, 3); strides in elements
+extern "C" int fgcn_emb_wgrad_tile_t(const void* emb, const void* x, const float* d_s, float* partial, float* bias_partial, int B,
+                                     int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "emb_wgrad_tile_t: half_mask=%d (0, 1 or 3)", half_mask);
+    return emb_wgrad_tile_impl(static_cast<const float*>(emb), static_cast<const float*>(x), d_s, partial, bias_partial, B, T, V, ic, Cx, ld_e, ld_x,
+                               d_s_batched, stream, half_mask);
 }
 
 static int emb_wgrad_tile_impl(const float* emb, const float* x, const float* d_s, float* partial, float* bias_partial, int B, int T,
-                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, bool e16) {
+                               int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream, int e16) {
     FGCN_REQUIRE(emb && x && d_s && partial && bias_partial, FGCN_E_BADARG, "emb_wgrad_tile: null pointer");
-    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_wgrad_tile_h: a bfloat16 emb needs math mode bf16");
+    FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_wgrad_tile_h: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_wgrad_tile: bad sizes B=%d T=%d", B, T);
     FGCN_REQUIRE(fgcn_emb_tile_available(V, ic, Cx), FGCN_E_BADARG,
                  "emb_wgrad_tile: V=%d ic=%d Cx=%d in math mode %d not supported (bf16x3 or bf16, 16 <= V <= %d, ic %% 16 == 0, Cx in 64s)", V, ic,
@@ -818,7 +894,7 @@ static int emb_wgrad_tile_impl(const float* emb, const float* x, const float* d_
     p.emb = emb, p.x = x, p.d_s = d_s, p.partial = partial, p.bias_partial = bias_partial;
     p.B = B, p.T = T, p.V = V, p.ic = ic, p.Ce = Ce, p.Cx = Cx, p.ld_e = ld_e, p.ld_x = ld_x, p.s_batched = d_s_batched;
     p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
-    p.e_bytes = (unsigned)(rows * ld_e * (e16 ? 2 : 4)), p.x_bytes = (unsigned)(rows * ld_x * 4);
+    p.e_bytes = (unsigned)(rows * ld_e * (e16 ? 2 : 4)), p.x_bytes = (unsigned)(rows * ld_x * (e16 == 3 ? 2 : 4));
     p.p_bytes = (unsigned)((long long)g.nseg * Ce * Cx * 4), p.b_bytes = (unsigned)((long long)g.nseg * Ce * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));

@@ -58,7 +58,7 @@ struct SpBwdP {
     // shortcuts (agcn.py:114,135), which the BatchNorm-backward kernels then neither write nor read-modify-write into dx
     const float* e[2];
     const unsigned char* m[2];
-    unsigned e_bytes;
+    unsigned e_bytes, m_bytes;          // bytes of a gated addend / of a sign image (one bit per element)
     // e0_grp > 0: e[0] is float[B / e0_grp][Cin], one row per GROUP of e0_grp consecutive samples, added to every row of the group's samples (the
     // gradient of the pooled output of the model's last block, fgcn_bn_act_pool: a per-clip vector instead of its (B, T, V, Cin) broadcast)
     int e0_grp;
@@ -86,8 +86,12 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
 // layout keeps room for three parts, the first is used)
 // IN16 (NP = 1): dy is a BFLOAT16 tensor (half-precision storage written by fgcn_bn_act_bwd_apply_h; ld_dy in elements): its rows are
 // copied into the staging plane instead of fetched as f32 and rounded -- the same staged bytes, half the reads
-template <bool ACC, int MAXS, int NE = 0, int NP = 3, bool IN16 = false>
+// IN16 = 3: x, dx and the gated addends are BFLOAT16 tensors as well (half-precision activation storage, the `_t` entry point; strides in
+// elements): x's gram fragment is one 16-byte load of eight bfloat16 and needs no split, the addends / old dx values are 8-byte loads
+// converted where they are consumed, dx is rounded once per store.  A per-group first addend (e0_grp) stays float32.
+template <bool ACC, int MAXS, int NE = 0, int NP = 3, int IN16 = 0>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
+    constexpr bool H16 = IN16 == 3;
     static_assert(NE == 0 || (NE == 2 && !ACC), "gated addends: both identity shortcuts, dx not live before");
     static_assert(NP == 1 || NP == 3, "parts");
     static_assert(!IN16 || NP == 1, "bfloat16 dy: the one-part kernel");
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     for (int i = 0; i < 2; ++i) {
         rge[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.e[i] : (const void*)p.dx), 0,
                                                    NE ? ((i == 0 && p.e0_grp) ? p.e0_bytes : p.e_bytes) : 0u, 0x00020000);
-        rgm[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.m[i] : (const void*)p.dx), 0, NE ? p.e_bytes >> 5 : 0u, 0x00020000);
+        rgm[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(NE ? (const void*)p.m[i] : (const void*)p.dx), 0, NE ? p.m_bytes : 0u, 0x00020000);
     }
 
     // A^_k of this sample, split once per workgroup: planes [subset][part][v][w] bf16 (one ds_read_b128 = 8 joints w of row v)
@@ -300,13 +304,14 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int f = (wave >> 1) + 4 * u, v = 16 * (wave & 1) + l15;
-                    const unsigned off = (f < nf && v < V && !(FGCN_PROBE_SB & 8)) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * 4u : OOB;
-                    xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-                    xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+                    const unsigned off = (f < nf && v < V && !(FGCN_PROBE_SB & 8)) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * (H16 ? 2u : 4u) : OOB;
+                    xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));      // (H16: the eight bfloat16 of the fragment)
+                    if constexpr (!H16) xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
                 }
                 // gated addends of this wave's mix units (element index of the lane's four channels; the sign image holds one bit per element:
                 // a nibble per lane), requested here as well
-                f32x4 ge[NE ? MAXS : 1][2][2];
+                f32x4 ge[NE ? MAXS : 1][2][2];                       // (H16: the raw bfloat16 quads in components 0 / 1, converted at their use)
+                f32x4 ge0f[(NE && H16) ? MAXS : 1][2];               // H16: the float32 per-group form of the first addend (requested beside the bfloat16 form, one of the two out of range)
                 unsigned gm[NE ? MAXS : 1][2][2];
                 if constexpr (NE == 2) {
 #pragma unroll
@@ -321,7 +326,15 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                             for (int i = 0; i < 2; ++i) {
                                 // (a per-group addend: the group's row instead of the element's; n is the workgroup's sample)
                                 const unsigned ea = (i == 0 && p.e0_grp) ? e0_row + chan : el;
-                                ge[s][vt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[i], ok ? ea * 4u : OOB, 0, 0));
+                                if constexpr (H16) {
+                                    const bool grp = i == 0 && p.e0_grp;
+                                    const u32x2 hq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rge[i], (ok && !grp) ? ea * 2u : OOB, 0, 0));
+                                    const unsigned b0 = hq[0], b1 = hq[1];
+                                    ge[s][vt][i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+                                    if (i == 0) ge0f[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[0], (ok && grp) ? ea * 4u : OOB, 0, 0));
+                                } else {
+                                    ge[s][vt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rge[i], ok ? ea * 4u : OOB, 0, 0));
+                                }
                                 gm[s][vt][i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rgm[i], ok ? el >> 3 : OOB, 0, 0) >> (el & 4u);
                             }
                         }
@@ -347,14 +360,21 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 f32x4 dxa[MAXS][2];
                 auto dx_off = [&](int s, int vt) -> unsigned {
                     const int v = 16 * vt + l15;
-                    return (sok[s] && sf[s] < nf && v < V) ? ((row0 + sf[s] * V + v) * (unsigned)p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * 4u : OOB;
+                    return (sok[s] && sf[s] < nf && v < V) ? ((row0 + sf[s] * V + v) * (unsigned)p.ld_dx + cbase + sct[s] * 16 + 4 * g4) * (H16 ? 2u : 4u) : OOB;
                 };
 #pragma unroll
                 for (int s = 0; s < MAXS; ++s)
 #pragma unroll
                     for (int vt = 0; vt < 2; ++vt) {
-                        if constexpr (ACC && !(FGCN_PROBE_SB & 8)) dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
-                        else dxa[s][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (ACC && H16) {                  // (raw bfloat16 quad in components 0 / 1; converted after the gram)
+                            const u32x2 hq = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rdx, dx_off(s, vt), 0, 0));
+                            const unsigned b0 = hq[0], b1 = hq[1];
+                            dxa[s][vt] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+                        } else if constexpr (ACC && !(FGCN_PROBE_SB & 8)) {
+                            dxa[s][vt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, dx_off(s, vt), 0, 0));
+                        } else {
+                            dxa[s][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                     }
                 // gram: dA^_k (v tile x w) += x_f . dagg_kf^T over the half's 32 channels
 #pragma unroll
@@ -362,7 +382,9 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     const int f = (wave >> 1) + 4 * u;
                     if (f >= nf) continue;                           // wave-uniform
                     u32x4v xs[NP];
-                    if constexpr ((FGCN_PROBE_SB & 512) != 0) {
+                    if constexpr (H16) {                             // already bfloat16: the fragment as loaded
+                        xs[0] = __builtin_bit_cast(u32x4v, xr[u][0]);
+                    } else if constexpr ((FGCN_PROBE_SB & 512) != 0) {
 #pragma unroll
                         for (int pl = 0; pl < NP; ++pl) xs[pl] = __builtin_bit_cast(u32x4v, xr[u][pl & 1]);
                     } else {
@@ -381,14 +403,29 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                             else gacc[k][wt] = mfma_np_k32<NP>(xs, bf, gacc[k][wt]);
                         }
                 }
+                auto from_bf16 = [](f32x4 raw) -> f32x4 {            // components 0 / 1 hold four bfloat16
+                    const float r0 = raw[0], r1 = raw[1];
+                    return unpack_bf16x4(u32x2{__builtin_bit_cast(unsigned, r0), __builtin_bit_cast(unsigned, r1)});
+                };
                 if constexpr (NE == 2) {                             // the gated addends are the mix accumulators' start
 #pragma unroll
                     for (int s = 0; s < MAXS; ++s)
 #pragma unroll
-                        for (int vt = 0; vt < 2; ++vt)
+                        for (int vt = 0; vt < 2; ++vt) {
+                            f32x4 a0 = ge[s][vt][0], a1 = ge[s][vt][1];
+                            if constexpr (H16) {
+                                a0 = p.e0_grp ? ge0f[s][vt] : from_bf16(a0);
+                                a1 = from_bf16(a1);
+                            }
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                dxa[s][vt][e] = (((gm[s][vt][0] >> e) & 1u) ? ge[s][vt][0][e] : 0.f) + (((gm[s][vt][1] >> e) & 1u) ? ge[s][vt][1][e] : 0.f);
+                                dxa[s][vt][e] = (((gm[s][vt][0] >> e) & 1u) ? a0[e] : 0.f) + (((gm[s][vt][1] >> e) & 1u) ? a1[e] : 0.f);
+                        }
+                } else if constexpr (ACC && H16) {
+#pragma unroll
+                    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+                        for (int vt = 0; vt < 2; ++vt) dxa[s][vt] = from_bf16(dxa[s][vt]);
                 }
                 // mix: dx^T (16 channels x 32 joints v) += sum_k dagg_kf^T (c x w) . A^_k^T (w x v)
 #pragma unroll
@@ -424,8 +461,10 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                 for (int s = 0; s < MAXS; ++s)
 #pragma unroll
-                    for (int vt = 0; vt < 2; ++vt)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, (FGCN_PROBE_SB & 64) ? OOB : dx_off(s, vt), 0, 0);
+                    for (int vt = 0; vt < 2; ++vt) {
+                        if constexpr (H16) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pack_bf16(dxa[s][vt])), rdx, dx_off(s, vt), 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, dxa[s][vt]), rdx, (FGCN_PROBE_SB & 64) ? OOB : dx_off(s, vt), 0, 0);
+                    }
                 __syncthreads();                                     // the image is free for the next half / the next group
             }
         }
@@ -484,7 +523,7 @@ extern "C" int fgcn_spatial_bwd_tile_segments(int B, int T, int V) {
 static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                    int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                    int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
-                                   const unsigned char* mask2, int extra1_group, void* stream, bool dy16 = false);
+                                   const unsigned char* mask2, int extra1_group, void* stream, int dy16 = 0);
 
 // dy as a BFLOAT16 tensor (math mode bf16 only; ld_dy in elements): fgcn_spatial_bwd_tile (extra1_group = 0) / fgcn_spatial_bwd_tile_g
 // otherwise unchanged; bit-identical to the f32-dy call on the tensor fgcn_bn_act_bwd_apply would have written
@@ -495,7 +534,21 @@ extern "C" int fgcn_spatial_bwd_tile_h(const unsigned short* dy_h, const float* 
     FGCN_REQUIRE(extra1_group >= 0 && (extra1_group == 0 || (extra1 && B % extra1_group == 0 && !accumulate)), FGCN_E_BADARG,
                  "spatial_bwd_tile_h: %d samples are not whole groups of %d", B, extra1_group);
     return spatial_bwd_tile_launch(reinterpret_cast<const float*>(dy_h), x, a_hat, w3, dx, partial, B, T, V, Cin, Cout, ld_dy, ld_x, ld_dx,
-                                   a_hat_batched, accumulate, extra1, mask1, extra2, mask2, extra1_group, stream, true);
+                                   a_hat_batched, accumulate, extra1, mask1, extra2, mask2, extra1_group, stream, 1);
+}
+
+// typed form (math mode bf16): half_mask bit 0 = dy is a bfloat16 tensor, bit 1 = x, dx AND the gated addends are (a per-group extra1 stays
+// float32); masks 0, 1, 3.  Strides in elements.
+extern "C" int fgcn_spatial_bwd_tile_t(const void* dy, const void* x, const float* a_hat, const void* w3, void* dx, float* partial,
+                                       int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                                       const void* extra1, int extra1_group, const unsigned char* mask1, const void* extra2,
+                                       const unsigned char* mask2, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "spatial_bwd_tile_t: half_mask=%d (0, 1 or 3)", half_mask);
+    FGCN_REQUIRE(extra1_group >= 0 && (extra1_group == 0 || (extra1 && B % extra1_group == 0 && !accumulate)), FGCN_E_BADARG,
+                 "spatial_bwd_tile_t: %d samples are not whole groups of %d", B, extra1_group);
+    return spatial_bwd_tile_launch(static_cast<const float*>(dy), static_cast<const float*>(x), a_hat, w3, static_cast<float*>(dx), partial, B, T, V,
+                                   Cin, Cout, ld_dy, ld_x, ld_dx, a_hat_batched, accumulate, static_cast<const float*>(extra1), mask1,
+                                   static_cast<const float*>(extra2), mask2, extra1_group, stream, half_mask);
 }
 
 extern "C" int fgcn_spatial_bwd_tile(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
@@ -520,7 +573,7 @@ extern "C" int fgcn_spatial_bwd_tile_g(const float* dy, const float* x, const fl
 static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                    int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                    int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
-                                   const unsigned char* mask2, int extra1_group, void* stream, bool dy16) {
+                                   const unsigned char* mask2, int extra1_group, void* stream, int dy16) {      // dy16: 1 = dy bfloat16; 3 = x, dx, addends too
     const bool gated = extra1 != nullptr;
     FGCN_REQUIRE(!dy16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "spatial_bwd_tile_h: a bfloat16 dy needs math mode bf16");
     FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0), FGCN_E_BADARG,
@@ -535,7 +588,8 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
                  "spatial_bwd_tile: row strides");
     FGCN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w3) && aligned16(dx), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte alignment");
     const long long rows = (long long)B * T * V;
-    const long long dy_bytes = rows * ld_dy * (dy16 ? 2 : 4), x_bytes = rows * ld_x * 4, dx_bytes = rows * ld_dx * 4;
+    const int abytes = dy16 == 3 ? 2 : 4;
+    const long long dy_bytes = rows * ld_dy * (dy16 ? 2 : 4), x_bytes = rows * ld_x * abytes, dx_bytes = rows * ld_dx * abytes;
     const long long plane = (long long)3 * Cin * Cout * 2;
     FGCN_REQUIRE(dy_bytes < 0x7FFF0000ll && x_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "spatial_bwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -548,7 +602,8 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
     p.tps = (int)cdiv(p.tiles_t, p.nseg);
     FGCN_REQUIRE((long long)B * p.nseg < (1ll << 30), FGCN_E_BADARG, "spatial_bwd_tile: too many workgroups");
     p.dy_bytes = (unsigned)dy_bytes; p.x_bytes = (unsigned)x_bytes; p.dx_bytes = (unsigned)dx_bytes; p.w_plane_bytes = (unsigned)plane;
-    p.e[0] = extra1; p.e[1] = extra2; p.m[0] = mask1; p.m[1] = mask2; p.e_bytes = (unsigned)(rows * Cin * 4);
+    p.e[0] = extra1; p.e[1] = extra2; p.m[0] = mask1; p.m[1] = mask2; p.e_bytes = (unsigned)(rows * Cin * abytes);
+    p.m_bytes = (unsigned)(rows * Cin / 8);
     p.e0_grp = extra1_group;
     p.e0_bytes = extra1_group ? (unsigned)((long long)(B / extra1_group) * Cin * 4) : 0u;
     // mix units (frame, 16-channel tile of a 32-channel half) -> waves: wave 2 (f mod 4) + vt already carries the gram units (f, vt) -- one or
@@ -585,9 +640,10 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
     } while (0)
 #define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
     do {                                                                                                                \
-        if (one_part && dy16) FGCN_SB_GO4(ACC_, MS_, NE_, 1, true);                                                     \
-        else if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1, false);                                                       \
-        else FGCN_SB_GO4(ACC_, MS_, NE_, 3, false);                                                                     \
+        if (one_part && dy16 == 3) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 3);                                                   \
+        else if (one_part && dy16) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 1);                                                   \
+        else if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 0);                                                           \
+        else FGCN_SB_GO4(ACC_, MS_, NE_, 3, 0);                                                                         \
     } while (0)
 #define FGCN_SB_GO(ACC_, MS_)                                                                                          \
     do {                                                                                                                \

@@ -59,10 +59,15 @@ constexpr int ST_PLANE = 256 * ST_XS;   // one part of the image: two pairs x 12
 // STR: non-temporal output stores (fgcn_common.hpp, stream_out); NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3),
 // 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout keeps room for three parts, the first is used)
 // FEP: the inference epilogue (SpTileP::ep_*) instead of bias + BatchNorm partial sums
-template <int NT, int MAXU, bool STR = false, int NP = 3, bool FEP = false>
+// IO (NP = 1, training epilogue): bit 0 = x is a BFLOAT16 tensor, bit 1 = y is (half-precision activation storage in math mode bf16, the `_t`
+// entry point; ld_x / ld_y in elements).  A bfloat16 x gives the same staged bytes as the float32 tensor of the same values (the one-part
+// kernel rounds x to bfloat16 anyway); a bfloat16 y is the rounded float32 result, the BatchNorm partial sums stay those of the accumulators.
+template <int NT, int MAXU, bool STR = false, int NP = 3, bool FEP = false, int IO = 0>
 __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     constexpr int LP = 3, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     static_assert(NP == 1 || NP == 3, "parts");
+    static_assert(IO == 0 || (NP == 1 && !FEP), "bfloat16 tensors: the one-part kernel's training form");
+    constexpr bool X16 = (IO & 1) != 0, O16 = (IO & 2) != 0;
     constexpr unsigned OOB = 0x80000000u;
     auto swz = [](int r) -> unsigned { return (unsigned)(r & 4) << 3; };
     extern __shared__ __attribute__((aligned(16))) float smem_st[];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     }
     const int npairs = 3 * (p.Cin >> 5);                             // (channel tile, subset) pairs; even (Cin % 64 == 0)
     const int nchunks = npairs >> 1;
-    const unsigned row_b = (unsigned)p.ld_x * 4u;
+    const unsigned row_b = (unsigned)p.ld_x * (X16 ? 2u : 4u);
     // the x rows of chunk c + 1 are requested at the start of chunk c's feature phase and parked in registers.  (A second register set,
     // requested a phase earlier so that the loads are not queued in front of the phase's weight fragments in the in-order vmcnt queue,
     // measured the same and cost 48 registers: FGCN_PROBE_ST puts the fetches at 0.12-0.17 ms of a 0.8 ms launch either way.)
@@ -145,12 +150,16 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
             if (ushare[i] && same_ci) continue;                      // (wave-uniform) the previous unit's rows serve this one too
             const int pq = 2 * c + uq[i];
             const int ci = pq / 3;
-            const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * h) * p.ld_x + ci * 32 + l31) * 4u;
+            const unsigned base = (unsigned)((((long long)n * p.T + t0 + (uok[i] ? uf[i] : 0)) * V + 8 * h) * p.ld_x + ci * 32 + l31) * (X16 ? 2u : 4u);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int vs = 16 * (r >> 3) + (r & 7);
-                xr[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (uok[i] && vs + 8 * h < V) ? base : OOB,
-                                                                                          (unsigned)vs * row_b, 0));
+                if constexpr (X16)       // one bfloat16 -> the float it stands for (the split below rounds it back to the same 16 bits)
+                    xr[i][r] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+                                                             rx, (uok[i] && vs + 8 * h < V) ? base : OOB, (unsigned)vs * row_b, 0) << 16);
+                else
+                    xr[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (uok[i] && vs + 8 * h < V) ? base : OOB,
+                                                                                              (unsigned)vs * row_b, 0));
             }
         }
     };
@@ -323,6 +332,30 @@ __global__ __launch_bounds__(256, 2) void spatial_tile_x3_kernel(SpTileP p) {
     }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
+        if constexpr (O16) {
+            // two rows at a time: the even lane of a pair stores columns (c, c + 1) of row rp as one dword, the odd lane those of row rp + 1
+            // (fgcn_tconv.hip's bfloat16 epilogue); each unit's sums run over (mt, r) in the float32 form's order
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    const int row = wr * (16 * MTW) + mt * 16 + 4 * g4 + rp;
+                    const bool ok0 = row < nrows && coff[nu] != OOB, ok1 = row + 1 < nrows && coff[nu] != OOB;
+                    const float v0 = acc[mt][nu][rp] + bv[nu], v1 = acc[mt][nu][rp + 1] + bv[nu];
+                    const float other = lane_xor1(odd ? v0 : v1);
+                    const unsigned pk = odd ? pack_bf16x2(other, v1) : pack_bf16x2(v0, other);
+                    const unsigned off = (odd ? ok1 : ok0) ? (unsigned)((m0 + row + (odd ? 1 : 0)) * p.ld_y * 2) + ((coff[nu] - (odd ? 4u : 0u)) >> 1) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, ry, off, 0, STR ? FGCN_STORE_AUX : 0);
+                    const float k0 = ok0 ? v0 : 0.f, k1 = ok1 ? v1 : 0.f;
+                    ssum[nu] += k0;
+                    ssq[nu] = __builtin_fmaf(k0, k0, ssq[nu]);
+                    ssum[nu] += k1;
+                    ssq[nu] = __builtin_fmaf(k1, k1, ssq[nu]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -379,13 +412,23 @@ extern "C" int fgcn_spatial_fwd_tile_tiles(int B, int T, int V) {
 
 static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
                                  float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
-                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec);
+                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec, int io = 0);
 
 extern "C" int fgcn_spatial_fwd_tile(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
                                      float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
                                      int a_hat_batched, void* stream) {
     return spatial_fwd_tile_impl(x, a_hat, w3, bias_sum, y, stat_partials, B, T, V, Cin, Cout, ld_x, ld_y, a_hat_batched, stream, nullptr, nullptr, 0,
                                  nullptr);
+}
+
+// typed form (math mode bf16, half-precision activation storage): half_mask bit 0 = x is a bfloat16 tensor, bit 1 = y is (masks 0, 2, 3);
+// ld_x / ld_y in elements; stat_partials: the moments of the float32 accumulators
+extern "C" int fgcn_spatial_fwd_tile_t(const void* x, const float* a_hat, const void* w3, const float* bias_sum, void* y,
+                                       float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                                       int a_hat_batched, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 2 || half_mask == 3, FGCN_E_BADARG, "spatial_fwd_tile_t: half_mask=%d (0, 2 or 3)", half_mask);
+    return spatial_fwd_tile_impl(static_cast<const float*>(x), a_hat, w3, bias_sum, static_cast<float*>(y), stat_partials, B, T, V, Cin, Cout, ld_x,
+                                 ld_y, a_hat_batched, stream, nullptr, nullptr, 0, nullptr, half_mask);
 }
 
 // Inference form of north-star kernel 1: aggregation + 1x1 feature contraction + (eval-mode) BatchNorm + shortcut + ReLU in ONE kernel --
@@ -402,15 +445,17 @@ extern "C" int fgcn_spatial_fwd_tile_bn_relu(const float* x, const float* a_hat,
 
 static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void* w3, const float* bias_sum, float* y,
                                  float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
-                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec) {
+                                 int a_hat_batched, void* stream, const float* ep_vec, const float* ep_res, int ld_res, const float* ep_rvec, int io) {
     FGCN_REQUIRE(x && a_hat && w3 && y, FGCN_E_BADARG, "spatial_fwd_tile: null pointer");
+    FGCN_REQUIRE(io == 0 || ((io == 2 || io == 3) && fgcn::math_mode() == FGCN_MATH_BF16 && !ep_vec), FGCN_E_BADARG,
+                 "spatial_fwd_tile_t: bfloat16 tensors (half_mask 2 or 3) need math mode bf16 and the training form");
     FGCN_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0, FGCN_E_BADARG, "spatial_fwd_tile: bad sizes B=%d T=%d Cin=%d Cout=%d", B, T, Cin, Cout);
     FGCN_REQUIRE(fgcn_spatial_fwd_tile_available(V, Cin, Cout), FGCN_E_BADARG,
                  "spatial_fwd_tile: needs math mode bf16x3 (bf16x3 products) or bf16, 16 <= V <= %d, Cin %% 64 == 0, Cout %% 4 == 0 (V=%d Cin=%d Cout=%d)",
                  FGCN_MAX_V, V, Cin, Cout);
     FGCN_REQUIRE(ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= Cin && ld_y >= Cout, FGCN_E_ALIGN, "spatial_fwd_tile: row strides");
     FGCN_REQUIRE(aligned16(x) && aligned16(w3) && aligned16(y), FGCN_E_ALIGN, "spatial_fwd_tile: 16-byte alignment");
-    const long long x_bytes = (long long)B * T * V * ld_x * 4, y_bytes = (long long)B * T * V * ld_y * 4;
+    const long long x_bytes = (long long)B * T * V * ld_x * ((io & 1) ? 2 : 4), y_bytes = (long long)B * T * V * ld_y * ((io & 2) ? 2 : 4);
     const long long plane = (long long)3 * Cin * Cout * 2;
     FGCN_REQUIRE(x_bytes < 0x7FFF0000ll && y_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "spatial_fwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -434,16 +479,24 @@ static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void*
     const dim3 grid((unsigned)(p.per_xcd * 8));
     hipStream_t s = (hipStream_t)stream;
     const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
-    const bool str = fgcn::stream_out(y_bytes);
-#define FGCN_ST_GO5(NT_, MU_, STR_, NP_, FEP_)                                                                      \
+    const bool str = !(io & 2) && fgcn::stream_out(y_bytes);        // (a bfloat16 y: 32-byte pieces, stored plainly)
+#define FGCN_ST_GO6(NT_, MU_, STR_, NP_, FEP_, IO_)                                                                 \
     do {                                                                                                            \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
         if (!opted) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_, IO_>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
             opted = true;                                                                                           \
         }                                                                                                           \
-        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_>), grid, dim3(256), lds, s, p);        \
+        hipLaunchKernelGGL((spatial_tile_x3_kernel<NT_, MU_, STR_, NP_, FEP_, IO_>), grid, dim3(256), lds, s, p);   \
+    } while (0)
+#define FGCN_ST_GO5(NT_, MU_, STR_, NP_, FEP_)                                                                      \
+    do {                                                                                                            \
+        if constexpr (NP_ == 1 && !FEP_ && !STR_) {                                                                 \
+            if (io == 3) { FGCN_ST_GO6(NT_, MU_, false, 1, false, 3); break; }                                      \
+            if (io == 2) { FGCN_ST_GO6(NT_, MU_, false, 1, false, 2); break; }                                      \
+        }                                                                                                           \
+        FGCN_ST_GO6(NT_, MU_, STR_, NP_, FEP_, 0);                                                                  \
     } while (0)
 #define FGCN_ST_GO4(NT_, MU_, STR_, NP_)                \
     do {                                                \
@@ -472,5 +525,6 @@ static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void*
 #undef FGCN_ST_GO3
 #undef FGCN_ST_GO4
 #undef FGCN_ST_GO5
+#undef FGCN_ST_GO6
     return launch_status("spatial_fwd_tile");
 }

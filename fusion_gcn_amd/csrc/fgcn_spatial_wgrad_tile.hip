@@ -75,7 +75,9 @@ __device__ __forceinline__ void swt_for_slots(Fn&& fn, std::integer_sequence<int
 // NP: bf16 parts per operand -- 3: exact three-way splits (FGCN_MATH_BF16X3), 1: operands rounded to bfloat16 once (FGCN_MATH_BF16; the LDS layout
 // keeps room for three parts, the first is used)
 // IN16 (NP = 1): dy is a BFLOAT16 tensor (fgcn_bn_act_bwd_apply_h; ld_dy in elements): its rows are copied into the plane, half the reads
-template <int CT, int NT, int NSLOT, int NP = 3, bool IN16 = false>
+// IN16 = 3: x is a BFLOAT16 tensor as well (half-precision activation storage, the `_t` entry point; ld_x in elements): 2-byte loads of the
+// values the float32 form would round to the same 16 bits
+template <int CT, int NT, int NSLOT, int NP = 3, int IN16 = 0>
 __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p) {
     constexpr int LP = 3, FP = 8 / CT;
     static_assert(NP == 1 || NP == 3, "parts");
@@ -139,8 +141,9 @@ __global__ __launch_bounds__(512, 1) void spatial_wgrad_tile_x3_kernel(SwTileP p
         const unsigned base = (unsigned)((n_ * p.T + t0_ + f) * V + 8 * g4) * (unsigned)p.ld_x + (unsigned)(c0 + l15);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_x)) * 4u : OOB;
-            xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+            const unsigned off = 8 * g4 + j < vlim ? (base + (unsigned)(j * p.ld_x)) * ((IN16 & 2) ? 2u : 4u) : OOB;
+            if constexpr ((IN16 & 2) != 0) xr[j] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, off, 0, 0) << 16);
+            else xr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
         }
     };
     // the A^ planes of sample n -> LDS (between two barriers): A^_k split once, planes [subset][part][w][v] bf16 (one ds_read_b128 = the 8
@@ -329,11 +332,11 @@ extern "C" int fgcn_spatial_wgrad_tile_slabs(int B, int T, int V, int Cin, int C
 }
 
 static int spatial_wgrad_tile_launch(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
-                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, bool dy16);
+                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, int dy16);
 
 extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
                                        int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream) {
-    return spatial_wgrad_tile_launch(x, dy, a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy, a_hat_batched, stream, false);
+    return spatial_wgrad_tile_launch(x, dy, a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy, a_hat_batched, stream, 0);
 }
 
 // dy as a BFLOAT16 tensor (math mode bf16 only; ld_dy in elements); otherwise fgcn_spatial_wgrad_tile, bit-identical to its result on the
@@ -341,11 +344,19 @@ extern "C" int fgcn_spatial_wgrad_tile(const float* x, const float* dy, const fl
 extern "C" int fgcn_spatial_wgrad_tile_h(const float* x, const unsigned short* dy_h, const float* a_hat, float* partial, int B, int T, int V,
                                          int Cin, int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream) {
     return spatial_wgrad_tile_launch(x, reinterpret_cast<const float*>(dy_h), a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy, a_hat_batched, stream,
-                                     true);
+                                     1);
+}
+
+// typed form (math mode bf16): half_mask bit 0 = x is a bfloat16 tensor, bit 1 = dy is (masks 0, 2, 3: a bfloat16 x comes with a bfloat16 dy)
+extern "C" int fgcn_spatial_wgrad_tile_t(const void* x, const void* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                                         int Cout, int ld_x, int ld_dy, int a_hat_batched, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 2 || half_mask == 3, FGCN_E_BADARG, "spatial_wgrad_tile_t: half_mask=%d (0, 2 or 3)", half_mask);
+    return spatial_wgrad_tile_launch(static_cast<const float*>(x), static_cast<const float*>(dy), a_hat, partial, B, T, V, Cin, Cout, ld_x, ld_dy,
+                                     a_hat_batched, stream, half_mask == 3 ? 3 : (half_mask == 2 ? 1 : 0));
 }
 
 static int spatial_wgrad_tile_launch(const float* x, const float* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
-                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, bool dy16) {
+                                     int Cout, int ld_x, int ld_dy, int a_hat_batched, void* stream, int dy16) {   // dy16: 1 = dy bfloat16, 3 = dy and x
     FGCN_REQUIRE(x && dy && a_hat && partial, FGCN_E_BADARG, "spatial_wgrad_tile: null pointer");
     FGCN_REQUIRE(!dy16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "spatial_wgrad_tile_h: a bfloat16 dy needs math mode bf16");
     FGCN_REQUIRE(fgcn_spatial_wgrad_tile_available(V, Cin, Cout), FGCN_E_BADARG,
@@ -364,7 +375,7 @@ static int spatial_wgrad_tile_launch(const float* x, const float* dy, const floa
     p.x = x, p.dy = dy, p.a_hat = a_hat, p.partial = partial;
     p.B = B, p.T = T, p.V = V, p.Cin = Cin, p.Cout = Cout, p.ld_x = ld_x, p.ld_dy = ld_dy, p.a_batched = a_hat_batched;
     p.F = g.F, p.tiles_t = g.tiles_t, p.gtiles = g.gtiles, p.tps = g.tps, p.nseg = g.nseg, p.n_cg = g.n_cg, p.n_og = g.n_og;
-    p.x_bytes = (unsigned)(rows * ld_x * 4), p.dy_bytes = (unsigned)(rows * ld_dy * (dy16 ? 2 : 4));
+    p.x_bytes = (unsigned)(rows * ld_x * ((dy16 & 2) ? 2 : 4)), p.dy_bytes = (unsigned)(rows * ld_dy * (dy16 ? 2 : 4));
     p.p_bytes = (unsigned)((long long)g.nseg * 3 * Cin * Cout * 4);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.nseg * g.n_cg * g.n_og));
@@ -381,9 +392,10 @@ static int spatial_wgrad_tile_launch(const float* x, const float* dy, const floa
     const bool one_part = fgcn::math_mode() == FGCN_MATH_BF16;     // operands rounded to bfloat16 once
 #define FGCN_SWT(CT_, NT_, NS_)                                    \
     do {                                                           \
-        if (one_part && dy16) FGCN_SWT4(CT_, NT_, NS_, 1, true);   \
-        else if (one_part) FGCN_SWT4(CT_, NT_, NS_, 1, false);     \
-        else FGCN_SWT4(CT_, NT_, NS_, 3, false);                   \
+        if (one_part && dy16 == 3) FGCN_SWT4(CT_, NT_, NS_, 1, 3); \
+        else if (one_part && dy16) FGCN_SWT4(CT_, NT_, NS_, 1, 1); \
+        else if (one_part) FGCN_SWT4(CT_, NT_, NS_, 1, 0);         \
+        else FGCN_SWT4(CT_, NT_, NS_, 3, 0);                       \
     } while (0)
     // frame slots of a wave per tile: F frames over 8 / CT waves per channel tile, rounded up to even
     const int nslot = ((g.F + 8 / g.CT - 1) / (8 / g.CT) + 1) & ~1;

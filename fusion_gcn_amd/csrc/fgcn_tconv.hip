@@ -350,9 +350,15 @@ __global__ __launch_bounds__(256, MINB) void conv_halo_kernel(HaloP p) {
 // fgcn_bn_act_bwd_apply_h) -- the image rows are copied, 8 bytes per four channels, instead of fetched as f32 and rounded here.  The staged
 // bytes are the same either way (one round-to-nearest-even per value), so the results are bit-identical to the f32-input form; the row
 // traffic through L2 -- what bounds this kernel in math mode bf16, where the matrix work is a sixth -- halves.
-template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false, bool IN16 = false>   // STR: non-temporal output stores (stream_out)
+// IN16 = 2: `out` is a bfloat16 tensor as well (half-precision ACTIVATION storage, the `_t` entry point: the pre-BatchNorm output U of the
+// forward, dG of the data gradient; ld_out in elements).  Epilogue form 0 only; the BatchNorm partial sums are those of the float32
+// accumulators (before the rounding).  A lane holds ONE column of four rows: adjacent lanes exchange a value (DPP) so that each stores
+// two adjacent columns of one row as a dword -- half the store instructions of the float32 form instead of twice as many 2-byte stores.
+template <int NT, int KC, int NP, int EPI = 0, bool FIN = false, int WR = 2, bool STR = false, int IN16 = 0>   // STR: non-temporal output stores (stream_out)
 __global__ __launch_bounds__(256, (NP == 1 && !FIN && EPI != 4) ? 3 : 2) void conv_halo_x3k32_kernel(HaloP p) {   // (EPI 4 at 168 registers spilled)
     static_assert(!IN16 || (NP == 1 && !FIN), "bfloat16 input: the one-part kernel without the fused input stage");
+    static_assert(IN16 != 2 || EPI == 0, "bfloat16 output: the plain store epilogue");
+    constexpr bool O16 = IN16 == 2;
     static_assert(!(STR && EPI == 3), "an accumulating epilogue stores plainly");
     static_assert(WR == 2 || (WR == 4 && KC == 32 && !FIN), "wave arrangement: 2 x 2, or 4 x 1 for the tap form");
     static_assert(!FIN || KC == 32, "the fused input stage is built for the tap form (32-channel chunks)");
@@ -758,6 +764,29 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN && EPI != 4) ? 3 : 2) void co
         if constexpr (ldacc) {
             if (mt + 1 < MTW) load_old(mt + 1, oldv[(mt + 1) & 1]);
         }
+        if constexpr (O16) {
+            // two rows at a time: the even lane of a pair stores columns (c, c + 1) of row rp, the odd lane those of row rp + 1
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+#pragma unroll
+                for (int nu = 0; nu < NU; ++nu) {
+                    const unsigned off0 = (rowoff[mt][rp] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][rp] + coff[nu];
+                    const unsigned off1 = (rowoff[mt][rp + 1] == OOB || coff[nu] == OOB) ? OOB : rowoff[mt][rp + 1] + coff[nu];
+                    const float v0 = acc[mt][nu][rp] + bv[nu], v1 = acc[mt][nu][rp + 1] + bv[nu];
+                    const float other = lane_xor1(odd ? v0 : v1);
+                    const unsigned pk = odd ? pack_bf16x2(other, v1) : pack_bf16x2(v0, other);
+                    const unsigned mine = odd ? off1 : off0;       // (float32-form byte offset of this lane's row and column: halves, minus the odd lane's column)
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, rout, mine == OOB ? OOB : (mine - (odd ? 4u : 0u)) >> 1, 0, STR ? FGCN_STORE_AUX : 0);
+                    const float k0 = off0 != OOB ? v0 : 0.f, k1 = off1 != OOB ? v1 : 0.f;
+                    ssum[nu] += k0;
+                    ssq[nu] = __builtin_fmaf(k0, k0, ssq[nu]);
+                    ssum[nu] += k1;
+                    ssq[nu] = __builtin_fmaf(k1, k1, ssq[nu]);
+                }
+            }
+            continue;
+        }
         // (row loop outside the unit loop: the 64-byte halves of a 128-byte line leave back to back -- fgcn_spatial_tile.hip's epilogue has
         // the measurement; each unit's sums keep their order)
 #pragma unroll
@@ -843,17 +872,29 @@ extern "C" int fgcn_tconv_halo_tiles(int B, int Th_out, int Th_in, int V) {
 // one instantiation of the split kernel (LDS opt-in once per instantiation: not a stream operation, stays out of graph captures); the
 // bfloat16-input form exists for the one-part tap kernel only
 template <int NT, int KC, int NP, int EPI, bool FIN, int WR, bool STR>
-static void halo_k32_launch(bool in16, dim3 grid, size_t lds, hipStream_t s, const HaloP& p) {
+static void halo_k32_launch(int in16, dim3 grid, size_t lds, hipStream_t s, const HaloP& p) {
     constexpr int max_lds = 32 * HALO_MAX_STAGE * XSB * 3;
+    if constexpr (NP == 1 && !FIN && KC == 32 && EPI == 0) {
+        if (in16 == 2) {             // bfloat16 in and out (the launcher has checked that this is the form it dispatches to)
+            static bool opted162 = false;
+            if (!opted162) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+                opted162 = true;
+            }
+            hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, 2>), grid, dim3(256), lds, s, p);
+            return;
+        }
+    }
     if constexpr (NP == 1 && !FIN && KC == 32 && EPI != 4) {
         if (in16) {
             static bool opted16 = false;
             if (!opted16) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
                 opted16 = true;
             }
-            hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, true>), grid, dim3(256), lds, s, p);
+            hipLaunchKernelGGL((conv_halo_x3k32_kernel<NT, KC, NP, EPI, FIN, WR, STR, 1>), grid, dim3(256), lds, s, p);
             return;
         }
     }
@@ -872,7 +913,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
                            int T_out_full, int out_s, int out_o,
                            int taps, int tb, int tc, int accumulate, const float* bn_a, const unsigned char* bn_mask,
                            const float* bn_vec, const float* fin_vec, const float* fin_res, float* fin_out,
-                           unsigned char* fin_mask, unsigned* in_amax, void* stream, bool in16, const float* ep_vec = nullptr,
+                           unsigned char* fin_mask, unsigned* in_amax, void* stream, int in16, const float* ep_vec = nullptr,
                            const float* ep_res = nullptr, const float* ep_rvec = nullptr) {
     FGCN_REQUIRE(in && out && w4, FGCN_E_BADARG, "tconv_halo: null pointer");
     const bool fep = ep_vec != nullptr;
@@ -883,6 +924,9 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
                  "plain output view, no statistics / accumulation / fused input stage");
     FGCN_REQUIRE(!in16 || (fgcn::math_mode() == FGCN_MATH_BF16 && !(fin_vec || fin_res || fin_out || fin_mask) && !(taps == 1 && K % 64 == 0)),
                  FGCN_E_BADARG, "tconv_halo_h: a bfloat16 input needs math mode bf16, the tap form and no fused input stage");
+    // (in16 == 2: the output is bfloat16 too -- the plain store epilogue, with or without the forward moments)
+    FGCN_REQUIRE(in16 != 2 || (!accumulate && !bn_a && !fep && ld_out % 2 == 0), FGCN_E_BADARG,
+                 "tconv_halo_t: a bfloat16 output is written by the plain store epilogue (no accumulation, no BatchNorm-backward sums)");
     const bool fin = fin_vec || fin_res || fin_out || fin_mask;
     FGCN_REQUIRE(!fin || !fgcn::f16x2_products(), FGCN_E_BADARG, "tconv_halo: the fused input stage is not built for the f16x2 products");
     FGCN_REQUIRE(!fin || (fin_vec && fin_res && fin_out && fin_mask && fgcn_tconv_halo_bn_sums() && !bn_a && !accumulate && taps > 1 &&
@@ -911,7 +955,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
     const long long in_bytes = (long long)B * T_in_full * V * ld_in * (in16 ? 2 : 4);
     const bool two = fgcn::f16x2_products();                                                // FGCN_PACK_SPLIT2H weights: two f16 parts
     const long long w_bytes = (long long)taps * K * N * (mm != FGCN_MATH_F32 ? (two ? 4 : 6) : 4);   // split form in both bf16 modes
-    const long long out_bytes = (long long)B * T_out_full * V * ld_out * 4;
+    const long long out_bytes = (long long)B * T_out_full * V * ld_out * (in16 == 2 ? 2 : 4);
     FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && w_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll, FGCN_E_BADARG,
                  "tconv_halo: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     HaloP p;
@@ -984,7 +1028,7 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
         FGCN_REQUIRE(bmr == 128 || wide_rows, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
         const int epi = fep ? 4 : (bn_a ? 2 : (accumulate ? 3 : 0));     // epilogue form (compile time, see the kernel)
-        const bool stream_k = fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes
+        const bool stream_k = in16 != 2 && fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes (a bfloat16 output: 32-byte pieces, stored plainly)
 #define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_) halo_k32_launch<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>(in16, grid, lds_k, s, p)
 #define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
     do {                                                                                                                 \
@@ -1093,7 +1137,20 @@ extern "C" int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const f
                                  const float* bn_vec, void* stream) {
     return tconv_halo_impl(reinterpret_cast<const float*>(in_h), out, w4, bias, stat_partials, B, Th, V, K, N, ld_in, ld_out, T_in_full, in_s, in_o,
                            Th_in, T_out_full, out_s, out_o, taps, tb, tc, accumulate, bn_a, bn_mask, bn_vec, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, stream, true);
+                           nullptr, stream, 1);
+}
+
+// typed form: half_mask bit 0 = `in` is bfloat16, bit 1 = `out` is (math mode bf16; a bfloat16 output needs a bfloat16 input: masks 0, 1, 3).
+// The plain store epilogue (no accumulation, no BatchNorm-backward sums); stat_partials: the forward moments of the float32 accumulators.
+extern "C" int fgcn_tconv_halo_t(const void* in, void* out, const float* w4, const float* bias, float* stat_partials,
+                                 int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                                 int T_in_full, int in_s, int in_o, int Th_in,
+                                 int T_out_full, int out_s, int out_o,
+                                 int taps, int tb, int tc, int half_mask, void* stream) {
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "tconv_halo_t: half_mask=%d (0, 1 or 3)", half_mask);
+    return tconv_halo_impl(static_cast<const float*>(in), static_cast<float*>(out), w4, bias, stat_partials, B, Th, V, K, N, ld_in, ld_out, T_in_full,
+                           in_s, in_o, Th_in, T_out_full, out_s, out_o, taps, tb, tc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, stream, half_mask == 3 ? 2 : half_mask);
 }
 
 // North-star kernel 2 as the north star states it, for INFERENCE: the (taps x 1) temporal convolution (stride 1) with the block's output

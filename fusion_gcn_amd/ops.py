@@ -245,6 +245,25 @@ def _chk16(t: torch.Tensor, name: str) -> None:
         raise _lib.FgcnError(f"{name}: expected a contiguous bfloat16 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+def _chka(t: Optional[torch.Tensor], name: str) -> bool:
+    """an activation tensor of a typed entry point (include/fgcn.h, `_t`): contiguous float32 or bfloat16 on the device -> whether it is
+    bfloat16 (half-precision activation storage, math mode bf16); None -> False"""
+    if t is None:
+        return False
+    if t.dtype == torch.bfloat16:
+        _chk16(t, name)
+        if get_math_mode() != "bf16":
+            raise _lib.FgcnError(f"{name}: a bfloat16 activation tensor needs math mode bf16 (the mode is {get_math_mode()})")
+        return True
+    _chk(t, name)
+    return False
+
+
+def _half_mask(*flags: bool) -> int:
+    """`half_mask` of a typed entry point: bit i = the i-th activation tensor (in the entry point's order) is bfloat16"""
+    return sum(1 << i for i, f in enumerate(flags) if f)
+
+
 def _p(t: Optional[torch.Tensor], coff: int = 0) -> Optional[int]:
     return None if t is None else t.data_ptr() + 4 * coff
 
@@ -362,7 +381,9 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
             raise _lib.FgcnError("tconv_halo: a bfloat16 input needs math mode bf16 and takes neither a fused input stage nor amax_out")
     else:
         _chk(inp, "tconv_halo.in")
-    _chk(out, "tconv_halo.out")
+    out16 = _chka(out, "tconv_halo.out")         # half-precision ACTIVATION storage: the output as bfloat16 too (fgcn_tconv_halo_t)
+    if out16 and (not in16 or accumulate or bn_bwd is not None):
+        raise _lib.FgcnError("tconv_halo: a bfloat16 output comes with a bfloat16 input, without accumulation or BatchNorm-backward sums")
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
     split = get_math_mode() in SPLIT_MODES       # the weights then are the pack_split3 form
@@ -402,6 +423,10 @@ def tconv_halo(inp: torch.Tensor, w4: torch.Tensor, out: torch.Tensor, *, Th: in
             raise _lib.FgcnError("tconv_halo: fuse_in needs the (4, K) BatchNorm vector, a shortcut and an output like the input "
                                  "(contiguous, K channels) and the uint8 sign image of numel / 8 bytes")
         fin = (_p(vec), _p(res), _p(g), g_sign.data_ptr())
+    if out16:
+        check(lib.fgcn_tconv_halo_t(inp.data_ptr(), out.data_ptr(), w4.data_ptr(), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
+                                    T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, 3, _stream()), "fgcn_tconv_halo_t")
+        return part
     if in16:
         check(lib.fgcn_tconv_halo_h(inp.data_ptr(), _p(out), w4.data_ptr(), _p(bias), _p(part), B, Th, V, K, N, ld_in, ld_out,
                                     T_in, in_s, in_o, Th_in, T_out, out_s, out_o, taps, tb, tc, int(accumulate), *bn, _stream()),
@@ -851,7 +876,10 @@ def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *,
             raise _lib.FgcnError("spatial_wgrad_tile: a bfloat16 dy needs math mode bf16")
     else:
         _chk(dy, "spatial_wgrad_tile.dy")
-    _chk(x, "spatial_wgrad_tile.x"), _chk(mats, "spatial_wgrad_tile.mats")
+    x16 = _chka(x, "spatial_wgrad_tile.x")        # half-precision activation storage (fgcn_spatial_wgrad_tile_t): with a bfloat16 dy
+    _chk(mats, "spatial_wgrad_tile.mats")
+    if x16 and not dy16:
+        raise _lib.FgcnError("spatial_wgrad_tile: a bfloat16 x comes with a bfloat16 dy")
     B, T, V, ld_x = x.shape
     ld_dy = dy.shape[3]
     Cin, Cout = ld_x if cin is None else int(cin), ld_dy if cout is None else int(cout)
@@ -864,7 +892,10 @@ def spatial_wgrad_tile(x: torch.Tensor, dy: torch.Tensor, mats: torch.Tensor, *,
     if slabs <= 0:
         raise _lib.FgcnError(f"spatial_wgrad_tile: sizes not supported: V={V} Cin={Cin} Cout={Cout}")
     partial = torch.empty((slabs, 1, 3 * Cin, Cout), device=x.device, dtype=torch.float32)
-    if dy16:
+    if x16:
+        check(lib.fgcn_spatial_wgrad_tile_t(x.data_ptr(), dy.data_ptr(), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
+                                            int(mats.shape[0] != 1), 3, _stream()), "fgcn_spatial_wgrad_tile_t")
+    elif dy16:
         check(lib.fgcn_spatial_wgrad_tile_h(_p(x), dy.data_ptr(), _p(mats), _p(partial), B, T, V, Cin, Cout, ld_x, ld_dy,
                                             int(mats.shape[0] != 1), _stream()), "fgcn_spatial_wgrad_tile_h")
     else:
@@ -956,20 +987,25 @@ def bn_act(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor] = Non
     """act(a*scale_a + shift_a + [b | b*scale_b + shift_b]).  ``sign_mask``: -> (out, mask) where mask holds one bit per
     element, [out > 0] (uint8, numel/8; None when the element count is not a multiple of 8) -- what the backward's
     ReLU gate reads instead of ``out``.  ``out_bf16``: the result is stored as bfloat16 (round to nearest even; fgcn_bn_act_h) -- for a
-    tensor that only the bf16 kernels' staging reads (math mode bf16: the temporal conv's input)."""
+    tensor that only the bf16 kernels' staging reads (math mode bf16: the temporal conv's input).  ``a`` / ``b`` may be bfloat16 tensors
+    themselves (half-precision activation storage, math mode bf16: fgcn_bn_act_t)."""
     ensure_device()
-    _chk(a, "bn_act.a")
+    a16, b16 = _chka(a, "bn_act.a"), _chka(b, "bn_act.b")
     C = a.shape[-1]
     rows = a.numel() // C
     res_mode = 0 if b is None else (1 if vec_b is None else 2)
     if b is not None and b.shape != a.shape:
         raise _lib.FgcnError(f"bn_act: residual shape {tuple(b.shape)} != {tuple(a.shape)}")
     if out is None:
-        out = torch.empty_like(a, dtype=torch.bfloat16) if out_bf16 else torch.empty_like(a)
+        out = torch.empty_like(a, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     mask = None
     if sign_mask and relu and a.numel() % 8 == 0:
         mask = torch.empty(a.numel() // 8, device=a.device, dtype=torch.uint8)
-    if out_bf16:
+    if a16 or b16:
+        (_chk16 if out_bf16 else _chk)(out, "bn_act.out")
+        check(_lib.load().fgcn_bn_act_t(a.data_ptr(), _p(vec_a), None if b is None else b.data_ptr(), _p(vec_b), out.data_ptr(), _p(mask), rows, C,
+                                        res_mode, int(relu), _half_mask(a16, b16, out_bf16), _stream()), "fgcn_bn_act_t")
+    elif out_bf16:
         _chk16(out, "bn_act.out")
         check(_lib.load().fgcn_bn_act_h(_p(a), _p(vec_a), _p(b), _p(vec_b), out.data_ptr(), _p(mask), rows, C, res_mode, int(relu),
                                         _stream()), "fgcn_bn_act_h")
@@ -984,7 +1020,7 @@ def bn_act_pool(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor],
     ``bn_act`` + ``group_mean`` of the last block without the activation between them (fgcn_bn_act_pool).  a: (..., C) whose rows
     form ``groups`` equal consecutive groups; C % 8 == 0."""
     ensure_device()
-    _chk(a, "bn_act_pool.a")
+    a16, b16 = _chka(a, "bn_act_pool.a"), _chka(b, "bn_act_pool.b")     # (bfloat16 operands: fgcn_bn_act_pool_t)
     C = a.shape[-1]
     rows = a.numel() // C
     if rows % groups or C % 8:
@@ -997,8 +1033,12 @@ def bn_act_pool(a: torch.Tensor, vec_a: torch.Tensor, b: Optional[torch.Tensor],
     partial = torch.empty((groups * splits, C), device=a.device, dtype=torch.float32)
     pooled = torch.empty((groups, C), device=a.device, dtype=torch.float32)
     mask = torch.empty(a.numel() // 8, device=a.device, dtype=torch.uint8)
-    check(lib.fgcn_bn_act_pool(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(mask), _p(partial), _p(pooled), groups, rows // groups, C,
-                               res_mode, _stream()), "fgcn_bn_act_pool")
+    if a16 or b16:
+        check(lib.fgcn_bn_act_pool_t(a.data_ptr(), _p(vec_a), None if b is None else b.data_ptr(), _p(vec_b), _p(mask), _p(partial), _p(pooled),
+                                     groups, rows // groups, C, res_mode, _half_mask(a16, b16), _stream()), "fgcn_bn_act_pool_t")
+    else:
+        check(lib.fgcn_bn_act_pool(_p(a), _p(vec_a), _p(b), _p(vec_b), _p(mask), _p(partial), _p(pooled), groups, rows // groups, C,
+                                   res_mode, _stream()), "fgcn_bn_act_pool")
     return pooled, mask
 
 
@@ -1012,9 +1052,15 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
     ``train=False`` (no BatchNorm statistics in the graph: only the gate and the scale) skips the reduction pass.
     ``grp_rows`` > 0: ``dout`` is (rows / grp_rows, C), one row per group of consecutive rows -- the gradient of ``bn_act_pool``'s
-    output, already divided by the group size -- instead of its rows x C broadcast."""
+    output, already divided by the group size -- instead of its rows x C broadcast.
+    ``dout`` / ``a`` / ``b`` may be bfloat16 tensors (half-precision activation storage, math mode bf16: the `_t` entry points; the gate
+    is then the sign image and a per-group ``dout`` stays float32); db is float32 always."""
     ensure_device()
-    _chk(dout, "bn_act_bwd.dout"), _chk(a, "bn_act_bwd.a")
+    d16, a16 = _chka(dout, "bn_act_bwd.dout"), _chka(a, "bn_act_bwd.a")
+    b16 = _chka(b, "bn_act_bwd.b") if (b is not None and res_mode == 2) else False      # (an identity shortcut is not read)
+    typed = d16 or a16 or b16
+    if typed and ((relu and sign_mask is None) or (d16 and grp_rows)):
+        raise _lib.FgcnError("bn_act_bwd: bfloat16 tensors need the sign image as the ReLU gate and a float32 per-group gradient")
     C = a.shape[-1]
     rows = a.numel() // C
     if grp_rows and (rows % grp_rows or tuple(dout.shape) != (rows // grp_rows, C) or partials is not None):
@@ -1031,7 +1077,11 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     elif need_sums or train:
         tiles = lib.fgcn_elem_tiles(rows)
         partials = torch.empty((tiles, 3, C), device=a.device, dtype=torch.float32)
-        if grp_rows:
+        if typed:
+            check(lib.fgcn_bn_act_bwd_reduce_t(dout.data_ptr(), grp_rows, None, _p(sign_mask), a.data_ptr(), _p(vec_a),
+                                               None if b is None else b.data_ptr(), _p(vec_b), _p(partials), tiles, rows, C, res_mode, int(relu),
+                                               _half_mask(d16, a16, b16), _stream()), "fgcn_bn_act_bwd_reduce_t")
+        elif grp_rows:
             check(lib.fgcn_bn_act_bwd_reduce_g(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(partials),
                                                tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce_g")
         else:
@@ -1039,10 +1089,17 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
                                              tiles, rows, C, res_mode, int(relu), _stream()), "fgcn_bn_act_bwd_reduce")
         sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
         reduce_sum(partials.view(tiles, -1), sums.view(-1))
-    da = torch.empty_like(a, dtype=torch.bfloat16) if da_bf16 else torch.empty_like(a)
+    da = torch.empty_like(a, dtype=torch.bfloat16 if da_bf16 else torch.float32)
     if res_mode != 0 and db is None and need_db:   # need_db=False (identity residual): the caller adds the gated gradient itself
-        db = torch.empty_like(a)
-    if da_bf16:
+        db = torch.empty_like(a, dtype=torch.float32)
+    if db is not None:
+        _chk(db, "bn_act_bwd.db")
+    if typed:
+        check(lib.fgcn_bn_act_bwd_apply_t(dout.data_ptr(), grp_rows, None, _p(sign_mask), a.data_ptr(), _p(vec_a),
+                                          None if b is None else b.data_ptr(), _p(vec_b), _p(sums), da.data_ptr(), _p(db), rows, C, res_mode,
+                                          int(relu), int(train), int(db_accumulate), _half_mask(d16, a16, b16, da_bf16), _stream()),
+              "fgcn_bn_act_bwd_apply_t")
+    elif da_bf16:
         check(lib.fgcn_bn_act_bwd_apply_h(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums),
                                           da.data_ptr(), _p(db), rows, C, res_mode, int(relu), int(train), int(db_accumulate), _stream()),
               "fgcn_bn_act_bwd_apply_h")
@@ -1220,11 +1277,15 @@ def spatial_fwd_tile_available(V: int, Cin: int, Cout: int) -> bool:
 
 
 def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bias_sum: Optional[torch.Tensor], *, Cin: int,
-                     Cout: int, stats: bool = True):
+                     Cout: int, stats: bool = True, y_bf16: bool = False):
     """y = sum_k conv_d[k](x . A^_k), the tile form of the fused kernel (fgcn_spatial_tile.hip): w3 = ``pack_split3`` of the stacked
-    (1, 3 Cin, Cout) matrix.  -> (y (B,T,V,Cout), stats partials or None)."""
+    (1, 3 Cin, Cout) matrix.  -> (y (B,T,V,Cout), stats partials or None).  Math mode bf16: ``x`` may be a bfloat16 tensor and ``y_bf16``
+    stores y as bfloat16 (half-precision activation storage, fgcn_spatial_fwd_tile_t; the statistics are those of the float32 accumulators)."""
     ensure_device()
-    _chk(x, "spatial_fwd_tile.x"), _chk(a_hat, "spatial_fwd_tile.a_hat")
+    x16 = _chka(x, "spatial_fwd_tile.x")
+    _chk(a_hat, "spatial_fwd_tile.a_hat")
+    if x16 and not y_bf16:
+        raise _lib.FgcnError("spatial_fwd_tile: a bfloat16 x comes with a bfloat16 y")
     B, T, V, ld_x = x.shape
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, 3 * Cin // 8, Cout, 8) or not w3.is_contiguous()
             or a_hat.shape[0] not in (1, B) or tuple(a_hat.shape[1:]) != (3, V, V)):
@@ -1232,8 +1293,12 @@ def spatial_fwd_tile(x: torch.Tensor, a_hat: torch.Tensor, w3: torch.Tensor, bia
                              "(weights: pack_split3 of the (1, 3 Cin, Cout) matrix)")
     lib = _lib.load()
     _mode_products()
-    y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.float32)
+    y = torch.empty((B, T, V, Cout), device=x.device, dtype=torch.bfloat16 if y_bf16 else torch.float32)
     part = torch.empty((lib.fgcn_spatial_fwd_tile_tiles(B, T, V), 2, Cout), device=x.device, dtype=torch.float32) if stats else None
+    if y_bf16:
+        check(lib.fgcn_spatial_fwd_tile_t(x.data_ptr(), _p(a_hat), w3.data_ptr(), _p(bias_sum), y.data_ptr(), _p(part), B, T, V, Cin, Cout, ld_x,
+                                          Cout, int(a_hat.shape[0] == B), _half_mask(x16, True), _stream()), "fgcn_spatial_fwd_tile_t")
+        return y, part
     check(lib.fgcn_spatial_fwd_tile(_p(x), _p(a_hat), w3.data_ptr(), _p(bias_sum), _p(y), _p(part), B, T, V, Cin, Cout, ld_x, Cout,
                                     int(a_hat.shape[0] == B), _stream()), "fgcn_spatial_fwd_tile")
     return y, part
@@ -1252,17 +1317,21 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     format.  w3 = ``pack_split3`` of the (1, Cout, 3 Cin) matrix [o][k Cin + c] = Wd_k[o][c].  ``gated``: none or exactly two
     (tensor, sign image) pairs added to dx where the image's bit is set (as in ``joint_dagg``; not with ``accumulate``).  The FIRST pair
     may carry a third member, the number of consecutive samples per group: its tensor is then (B / group, Cin), one row per group, added
-    to every row of the group's samples (the gradient of a pooled block output, ``bn_act_pool``)."""
+    to every row of the group's samples (the gradient of a pooled block output, ``bn_act_pool``).
+    Math mode bf16, half-precision activation storage (fgcn_spatial_bwd_tile_t): x, dx and the gated addends bfloat16 TOGETHER (with a
+    bfloat16 dy; a per-group first addend stays float32)."""
     ensure_device()
     if len(gated) not in (0, 2) or (gated and accumulate):
         raise _lib.FgcnError("spatial_bwd_tile: gated addends come as the pair of identity shortcuts, without accumulation")
     group = gated[0][2] if gated and len(gated[0]) == 3 else 0
+    all16 = _chka(x, "spatial_bwd_tile.x")
     for i, (e, m, *_) in enumerate(gated):
-        _chk(e, "spatial_bwd_tile.gated")
+        if _chka(e, "spatial_bwd_tile.gated") != (all16 and not (i == 0 and group)):
+            raise _lib.FgcnError("spatial_bwd_tile: the gated addends have x's storage type (a per-group first addend: float32)")
         want = (x.shape[0] // group, x.shape[3]) if (i == 0 and group) else tuple(x.shape)
         if tuple(e.shape) != want or m.dtype != torch.uint8 or m.numel() * 8 != x.numel() or not m.is_cuda or (group and x.shape[0] % group):
             raise _lib.FgcnError(f"spatial_bwd_tile: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
-    ex = [(_p(e), m.data_ptr()) for e, m, *_ in gated] + [(None, None)] * (2 - len(gated))
+    ex = [(e.data_ptr(), m.data_ptr()) for e, m, *_ in gated] + [(None, None)] * (2 - len(gated))
     dy16 = dy.dtype == torch.bfloat16            # half-precision storage of dy (math mode bf16: fgcn_spatial_bwd_tile_h)
     if dy16:
         _chk16(dy, "spatial_bwd_tile.dy")
@@ -1270,7 +1339,9 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
             raise _lib.FgcnError("spatial_bwd_tile: a bfloat16 dy needs math mode bf16")
     else:
         _chk(dy, "spatial_bwd_tile.dy")
-    _chk(x, "spatial_bwd_tile.x"), _chk(a_hat, "spatial_bwd_tile.a_hat"), _chk(dx, "spatial_bwd_tile.dx")
+    _chk(a_hat, "spatial_bwd_tile.a_hat")
+    if _chka(dx, "spatial_bwd_tile.dx") != all16 or (all16 and not dy16):
+        raise _lib.FgcnError("spatial_bwd_tile: x, dx and the gated addends are bfloat16 together, and then dy is too")
     B, T, V, Cin = x.shape
     Cout = dy.shape[3]
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, Cout // 8, 3 * Cin, 8) or not w3.is_contiguous()
@@ -1282,6 +1353,11 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     _mode_products()
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
+    if all16:
+        check(lib.fgcn_spatial_bwd_tile_t(dy.data_ptr(), x.data_ptr(), _p(a_hat), w3.data_ptr(), dx.data_ptr(), _p(partial), B, T, V, Cin, Cout, Cout,
+                                          Cin, dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1],
+                                          3, _stream()), "fgcn_spatial_bwd_tile_t")
+        return partial
     if dy16:
         check(lib.fgcn_spatial_bwd_tile_h(dy.data_ptr(), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,
                                           dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1],
@@ -1310,7 +1386,8 @@ def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: i
     ``write_emb=False`` (inference: only the backward reads the embeddings): emb is not written and None comes back in its place.
     ``emb_bf16`` (math mode bf16): emb is stored as bfloat16 (fgcn_emb_fwd_tile_h; its readers ``emb_dx_tile`` / ``emb_wgrad_tile`` take it)."""
     ensure_device()
-    _chk(x, "emb_fwd_tile.x"), _chk(bias, "emb_fwd_tile.bias")
+    x16 = _chka(x, "emb_fwd_tile.x")              # half-precision activation storage (math mode bf16: fgcn_emb_fwd_tile_t)
+    _chk(bias, "emb_fwd_tile.bias")
     B, T, V, ld_x = x.shape
     cin = ld_x if cin is None else int(cin)
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, cin // 8, 6 * ic, 8) or not w3.is_contiguous() or bias.numel() != 6 * ic
@@ -1322,6 +1399,12 @@ def emb_fwd_tile(x: torch.Tensor, w3: torch.Tensor, bias: torch.Tensor, *, ic: i
     if nseg <= 0:
         raise _lib.FgcnError(f"emb_fwd_tile: sizes not supported: V={V} ic={ic}")
     partial = torch.empty((B, nseg, 3, 32, 32), device=x.device, dtype=torch.float32)
+    if x16:
+        e16 = bool(emb_bf16 and write_emb)
+        emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.bfloat16 if e16 else torch.float32) if write_emb else None
+        check(lib.fgcn_emb_fwd_tile_t(x.data_ptr(), w3.data_ptr(), _p(bias), None if emb is None else emb.data_ptr(), _p(partial), B, T, V, cin, ic,
+                                      ld_x, 6 * ic, _half_mask(True, e16), _stream()), "fgcn_emb_fwd_tile_t")
+        return emb, partial
     if emb_bf16 and write_emb:
         emb = torch.empty((B, T, V, 6 * ic), device=x.device, dtype=torch.bfloat16)
         check(lib.fgcn_emb_fwd_tile_h(_p(x), w3.data_ptr(), _p(bias), emb.data_ptr(), _p(partial), B, T, V, cin, ic, ld_x, 6 * ic, _stream()),
@@ -1359,7 +1442,9 @@ def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torc
     w3 = ``pack_split3`` of the (1, 6 ic, cx) matrix [j][c] = Wemb[j][c], dx (B,T,V,>=cx)."""
     ensure_device()
     _chk_emb("emb_dx_tile", emb, d_s, ic)
-    _chk(dx, "emb_dx_tile.dx")
+    dx16 = _chka(dx, "emb_dx_tile.dx")            # half-precision activation storage (fgcn_emb_dx_tile_t): with a bfloat16 emb
+    if dx16 and emb.dtype != torch.bfloat16:
+        raise _lib.FgcnError("emb_dx_tile: a bfloat16 dx comes with a bfloat16 emb")
     B, T, V, ld_e = emb.shape
     cx = dx.shape[3] if cx is None else int(cx)
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, 6 * ic // 8, cx, 8) or not w3.is_contiguous()
@@ -1369,6 +1454,10 @@ def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torc
     lib = _lib.load()
     batched = int(d_s.shape[0] != 1)
     ws = torch.empty(lib.fgcn_emb_dx_tile_workspace(B, batched), device=emb.device, dtype=torch.uint8)      # the split planes of dS, dS^T
+    if dx16:
+        check(lib.fgcn_emb_dx_tile_t(emb.data_ptr(), _p(d_s), w3.data_ptr(), dx.data_ptr(), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
+                                     int(accumulate), 3, _stream()), "fgcn_emb_dx_tile_t")
+        return dx
     if emb.dtype == torch.bfloat16:
         check(lib.fgcn_emb_dx_tile_h(emb.data_ptr(), _p(d_s), w3.data_ptr(), _p(dx), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
                                      int(accumulate), _stream()), "fgcn_emb_dx_tile_h")
@@ -1383,7 +1472,9 @@ def emb_wgrad_tile(emb: torch.Tensor, x: torch.Tensor, d_s: torch.Tensor, *, ic:
     (see ``emb_dx_tile``).  x (B,T,V,>=cx): the embedding convolutions' input."""
     ensure_device()
     _chk_emb("emb_wgrad_tile", emb, d_s, ic)
-    _chk(x, "emb_wgrad_tile.x")
+    x16 = _chka(x, "emb_wgrad_tile.x")            # half-precision activation storage (fgcn_emb_wgrad_tile_t): with a bfloat16 emb
+    if x16 and emb.dtype != torch.bfloat16:
+        raise _lib.FgcnError("emb_wgrad_tile: a bfloat16 x comes with a bfloat16 emb")
     B, T, V, ld_e = emb.shape
     cx = x.shape[3] if cx is None else int(cx)
     if tuple(x.shape[:3]) != (B, T, V) or x.shape[3] < cx:
@@ -1394,7 +1485,10 @@ def emb_wgrad_tile(emb: torch.Tensor, x: torch.Tensor, d_s: torch.Tensor, *, ic:
         raise _lib.FgcnError(f"emb_wgrad_tile: sizes not supported: V={V} ic={ic} cx={cx}")
     partial = torch.empty((slabs, 1, 6 * ic, cx), device=x.device, dtype=torch.float32)
     bpart = torch.empty((slabs, 6 * ic), device=x.device, dtype=torch.float32)
-    if emb.dtype == torch.bfloat16:
+    if x16:
+        check(lib.fgcn_emb_wgrad_tile_t(emb.data_ptr(), x.data_ptr(), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
+                                        int(d_s.shape[0] != 1), 3, _stream()), "fgcn_emb_wgrad_tile_t")
+    elif emb.dtype == torch.bfloat16:
         check(lib.fgcn_emb_wgrad_tile_h(emb.data_ptr(), _p(x), _p(d_s), _p(partial), _p(bpart), B, T, V, ic, cx, ld_e, x.shape[3],
                                         int(d_s.shape[0] != 1), _stream()), "fgcn_emb_wgrad_tile_h")
     else:

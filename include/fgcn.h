@@ -226,6 +226,57 @@ int fgcn_emb_dx_tile_h(const unsigned short* emb_h, const float* d_s, const void
                        int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream);
 int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const float* d_s, float* partial, float* bias_partial, int B,
                           int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, void* stream);
+/* ---- half-precision ACTIVATION storage (math mode FGCN_MATH_BF16 only; round 6): the typed entry points `_t` ---------------------------
+ * The `_h` entry points above keep results bit-identical (only tensors that bf16 MFMA staging alone reads are bfloat16).  The reference's
+ * MixedPrecisionStep (torch_src/session/procedures/step.py:55-78: torch.cuda.amp.autocast around model(x)) goes further: under autocast every
+ * convolution / matmul OUTPUT is a half-precision tensor and BatchNorm / ReLU / the residual adds read and write half precision too; only
+ * statistics, softmax and accumulators are float32.  The `_t` entry points give the hot path that storage format: each takes `half_mask`,
+ * one bit per activation-sized tensor argument in argument order (set = the tensor is bfloat16, `unsigned short` bit patterns, strides in
+ * elements); accumulation, BatchNorm statistics (summed from the float32 accumulators, before the rounding of the stored value) and every
+ * small tensor stay float32.  A bfloat16 INPUT of a matrix kernel changes nothing (the FGCN_MATH_BF16 kernels round their operands to
+ * bfloat16 anyway: same staged bytes); a bfloat16 OUTPUT is the float32 result rounded to nearest even once.  Masks a kernel is not built for
+ * are refused with FGCN_E_BADARG.  Contract of the mode: SURVEY.md section 7 (logits <= 1e-2, loss <= 1e-3 abs ..., gradient cosine >= 0.98).
+ *   fgcn_bn_act_t             bit 0 a, 1 b (shortcut), 2 out
+ *   fgcn_bn_act_pool_t        bit 0 a, 1 b
+ *   fgcn_bn_act_bwd_reduce_t  bit 0 dout, 1 a, 2 b          (grp_rows > 0: dout is the float32 per-group form; the ReLU gate is the sign image)
+ *   fgcn_bn_act_bwd_apply_t   bit 0 dout, 1 a, 2 b, 3 da    (db stays float32)
+ *   fgcn_tconv_halo_t         bit 0 in, 1 out               masks 0, 1, 3; plain store epilogue (no accumulation / BatchNorm-backward sums)
+ *   fgcn_spatial_fwd_tile_t   bit 0 x, 1 y                  masks 0, 2, 3
+ *   fgcn_emb_fwd_tile_t       bit 0 x, 1 emb
+ *   fgcn_spatial_bwd_tile_t   bit 0 dy, 1 x + dx + gated addends (a per-group extra1 stays float32)      masks 0, 1, 3
+ *   fgcn_spatial_wgrad_tile_t bit 0 x, 1 dy                 masks 0, 2, 3
+ *   fgcn_emb_dx_tile_t        bit 0 emb, 1 dx               masks 0, 1, 3
+ *   fgcn_emb_wgrad_tile_t     bit 0 emb, 1 x                masks 0, 1, 3 */
+int fgcn_bn_act_t(const void* a, const float* vec_a, const void* b, const float* vec_b, void* out, unsigned char* sign_mask,
+                  long long rows, int C, int res_mode, int relu, int half_mask, void* stream);
+int fgcn_bn_act_pool_t(const void* a, const float* vec_a, const void* b, const float* vec_b, unsigned char* sign_mask,
+                       float* partial, float* pooled, int groups, int grp_rows, int C, int res_mode, int half_mask, void* stream);
+int fgcn_bn_act_bwd_reduce_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
+                             const float* vec_a, const void* b, const float* vec_b, float* partials, int n_tiles, long long rows,
+                             int C, int res_mode, int relu, int half_mask, void* stream);
+int fgcn_bn_act_bwd_apply_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
+                            const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, float* db,
+                            long long rows, int C, int res_mode, int relu, int train, int db_accumulate, int half_mask, void* stream);
+int fgcn_tconv_halo_t(const void* in, void* out, const float* w4, const float* bias, float* stat_partials,
+                      int B, int Th, int V, int K, int N, int ld_in, int ld_out,
+                      int T_in_full, int in_s, int in_o, int Th_in,
+                      int T_out_full, int out_s, int out_o,
+                      int taps, int tb, int tc, int half_mask, void* stream);
+int fgcn_spatial_fwd_tile_t(const void* x, const float* a_hat, const void* w3, const float* bias_sum, void* y,
+                            float* stat_partials, int B, int T, int V, int Cin, int Cout, int ld_x, int ld_y,
+                            int a_hat_batched, int half_mask, void* stream);
+int fgcn_emb_fwd_tile_t(const void* x, const void* w3, const float* bias, void* emb, float* partial, int B, int T, int V, int Cin,
+                        int ic, int ld_x, int ld_e, int half_mask, void* stream);
+int fgcn_spatial_bwd_tile_t(const void* dy, const void* x, const float* a_hat, const void* w3, void* dx, float* partial,
+                            int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
+                            const void* extra1, int extra1_group, const unsigned char* mask1, const void* extra2,
+                            const unsigned char* mask2, int half_mask, void* stream);
+int fgcn_spatial_wgrad_tile_t(const void* x, const void* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
+                              int Cout, int ld_x, int ld_dy, int a_hat_batched, int half_mask, void* stream);
+int fgcn_emb_dx_tile_t(const void* emb, const float* d_s, const void* w3, void* dx, void* workspace, int B, int T, int V,
+                       int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, int half_mask, void* stream);
+int fgcn_emb_wgrad_tile_t(const void* emb, const void* x, const float* d_s, float* partial, float* bias_partial, int B,
+                          int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, int half_mask, void* stream);
 /* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
  * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
  * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel

@@ -494,3 +494,137 @@ def test_embedding_kernels_with_a_bfloat16_emb(V, T, cin, ic, B):
     gw2, gb2 = ops.emb_wgrad_tile(e16, x, ds[:1], ic=ic)          # shared dS
     gw3, gb3 = ops.emb_wgrad_tile(ef, x, ds[:1], ic=ic)
     assert torch.equal(gw2, gw3) and torch.equal(gb2, gb3)
+
+
+# ---- half-precision ACTIVATION storage (include/fgcn.h, the typed `_t` entry points; paths.half_activations) ---------------------------
+# A bfloat16 INPUT of a kernel must give the bits of the float32 call on the same values; a bfloat16 OUTPUT must be the round-to-nearest-even
+# of the float32 call's output, with BatchNorm sums of the float32 values.
+def h16(*shape, seed=0, scale=1.0):
+    return gpu(rnd(*shape, seed=seed, scale=scale)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("rows,C,res", [(1000, 64, 0), (777, 128, 1), (2048, 256, 2), (50, 8, 1), (600, 64, 2)])
+def test_batchnorm_passes_with_bfloat16_operands(rows, C, res):
+    """fgcn_bn_act_t / fgcn_bn_act_pool_t / fgcn_bn_act_bwd_reduce_t / fgcn_bn_act_bwd_apply_t with a, the shortcut and the incoming
+    gradient as bfloat16 tensors, in every combination the block produces, against the float32 entry points on the same values."""
+    from fusion_gcn_amd import ops
+    a16, b16, d16 = h16(rows, C, seed=1), h16(rows, C, seed=2), h16(rows, C, seed=3)
+    mk = lambda seed: gpu(torch.stack([rnd(C, seed=seed), rnd(C, seed=seed + 1).abs() + 0.5, rnd(C, seed=seed + 2), rnd(C, seed=seed + 3)]))  # noqa: E731
+    va, vb = mk(10), mk(20)
+    for a_half, b_half, o_half in ((True, True, True), (True, False, False), (False, True, True), (True, True, False)):
+        a = a16 if a_half else a16.float()
+        b = None if res == 0 else (b16 if b_half else b16.float())
+        vec_b = vb if res == 2 else None
+        want, m0 = ops.bn_act(a16.float(), va, None if res == 0 else b16.float(), vec_b, relu=True, sign_mask=True)
+        got, m1 = ops.bn_act(a, va, b, vec_b, relu=True, sign_mask=True, out_bf16=o_half)
+        assert torch.equal(got, want.to(got.dtype)) and ((m0 is None and m1 is None) or torch.equal(m0, m1)), (a_half, b_half, o_half)
+        if m0 is None:
+            continue
+        for d_half in (True, False):
+            dout = d16 if d_half else d16.float()
+            kw = dict(res_mode=res, sign_mask=m0, need_db=res == 2)
+            da0, db0, s0 = ops.bn_act_bwd(d16.float(), None, a16.float(), va, None if res == 0 else b16.float(), vec_b, **kw)
+            da1, db1, s1 = ops.bn_act_bwd(dout, None, a, va, b, vec_b, da_bf16=o_half, **kw)
+            assert torch.equal(da1, da0.to(da1.dtype)) and torch.equal(s0, s1), (a_half, b_half, o_half, d_half)
+            assert (db0 is None and db1 is None) or torch.equal(db0, db1)
+    if C % 8 == 0 and rows % 4 == 0:
+        for a_half, b_half in ((True, True), (True, False), (False, True)):
+            args32 = (a16.float(), va, None if res == 0 else b16.float(), vb if res == 2 else None)
+            args = (a16 if a_half else a16.float(), va, None if res == 0 else (b16 if b_half else b16.float()), vb if res == 2 else None)
+            p0, m0 = ops.bn_act_pool(*args32, 4)
+            p1, m1 = ops.bn_act_pool(*args, 4)
+            assert torch.equal(p0, p1) and torch.equal(m0, m1)
+
+
+@pytest.mark.parametrize("B,T,V,C,N,kt,s", [(2, 20, 25, 64, 64, 9, 1), (3, 13, 18, 256, 256, 9, 1), (2, 30, 27, 64, 128, 5, 1), (1, 9, 32, 128, 64, 3, 1),
+                                            (2, 21, 25, 128, 128, 9, 2), (8, 40, 25, 128, 128, 9, 1), (16, 64, 25, 64, 64, 9, 1)])
+def test_halo_conv_writes_bfloat16(B, T, V, C, N, kt, s):
+    """fgcn_tconv_halo_t with mask 3: the output is the rounding of the float32 output of fgcn_tconv_halo_h, the BatchNorm moments are
+    those of the float32 values, bit for bit (forward with statistics; data gradient, also through the frame views of a strided conv)."""
+    from fusion_gcn_amd import ops
+    pad = (kt - 1) // 2
+    g16 = h16(B, T, V, C, seed=5)
+    w = ops.pack_split3(gpu(rnd(kt, C, N, seed=7, scale=(kt * C) ** -0.5)))
+    bias = gpu(rnd(N, seed=8))
+    if s == 1:
+        u32 = torch.empty(B, T, V, N, device=dev())
+        u16 = torch.empty(B, T, V, N, device=dev(), dtype=torch.bfloat16)
+        p32 = ops.tconv_halo(g16, w, u32, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=True)
+        p16 = ops.tconv_halo(g16, w, u16, Th=T, taps=kt, tb=1, tc=-pad, bias=bias, stats=True)
+        assert torch.equal(u16, u32.to(torch.bfloat16)) and torch.equal(p32, p16)
+        ops.tconv_halo(g16, w, u32, Th=T, taps=kt, tb=-1, tc=pad)
+        ops.tconv_halo(g16, w, u16, Th=T, taps=kt, tb=-1, tc=pad)
+        assert torch.equal(u16, u32.to(torch.bfloat16))
+    else:           # the data gradient of a stride-2 conv: even / odd output frames through out_view
+        Tp = (T - 1) // 2 + 1
+        du16 = h16(B, Tp, V, C, seed=6)
+        we = ops.pack_split3(gpu(rnd((kt + 1) // 2, C, N, seed=9, scale=(kt * C) ** -0.5)))
+        d32 = torch.zeros(B, T, V, N, device=dev())
+        d16 = torch.zeros(B, T, V, N, device=dev(), dtype=torch.bfloat16)
+        for out in (d32, d16):
+            ops.tconv_halo(du16, we, out, Th=(T + 1) // 2, taps=(kt + 1) // 2, tb=-1, tc=pad // 2, out_view=(2, 0))
+        assert torch.equal(d16, d32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 256, 256, 2), (32, 5, 128, 64, 1), (22, 40, 64, 64, 3)])
+def test_spatial_tile_kernels_on_bfloat16_activations(V, T, cin, cout, B):
+    """fgcn_spatial_fwd_tile_t (x in, y out), fgcn_spatial_wgrad_tile_t (x, dy), fgcn_spatial_bwd_tile_t (dy, x, dx, gated addends) against
+    the float32 / `_h` forms on the same values: equal inputs give equal bits, a bfloat16 output is the rounded float32 output."""
+    from fusion_gcn_amd import ops
+    x16, a = h16(B, T, V, cin, seed=41), gpu(rnd(B, 3, V, V, seed=42, scale=0.3))
+    x32 = x16.float()
+    wd = ops.pack_split3(gpu(rnd(1, 3 * cin, cout, seed=40, scale=(3 * cin) ** -0.5)))
+    bias = gpu(rnd(cout, seed=39))
+    y32, p32 = ops.spatial_fwd_tile(x32, a, wd, bias, Cin=cin, Cout=cout)
+    for xin in (x16, x32):
+        y16, p16 = ops.spatial_fwd_tile(xin, a, wd, bias, Cin=cin, Cout=cout, y_bf16=True)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16)) and torch.equal(p32, p16)
+    dy16 = h16(B, T, V, cout, seed=43)
+    assert torch.equal(ops.spatial_wgrad_tile(x32, dy16, a), ops.spatial_wgrad_tile(x16, dy16, a))
+    assert torch.equal(ops.spatial_wgrad_tile(x32, dy16, a[:1]), ops.spatial_wgrad_tile(x16, dy16, a[:1]))
+    w3 = ops.pack_split3(gpu(rnd(1, cout, 3 * cin, seed=44, scale=cout ** -0.5)))
+    base16 = h16(B, T, V, cin, seed=45)
+    for acc in (False, True):
+        d0, d1 = base16.float(), base16.clone()
+        p0 = ops.spatial_bwd_tile(dy16, x32, a, w3, d0, accumulate=acc)
+        p1 = ops.spatial_bwd_tile(dy16, x16, a, w3, d1, accumulate=acc)
+        assert torch.equal(d1, d0.to(torch.bfloat16)) and torch.equal(p0, p1), acc
+    if (B * T * V * cin) % 8 == 0:
+        e1, e2 = h16(B, T, V, cin, seed=46), h16(B, T, V, cin, seed=47)
+        m1 = torch.randint(0, 256, (B * T * V * cin // 8,), device=dev(), dtype=torch.uint8)
+        m2 = torch.randint(0, 256, (B * T * V * cin // 8,), device=dev(), dtype=torch.uint8)
+        eg = gpu(rnd(B, cin, seed=48))
+        for g32, g16 in (([(e1.float(), m1), (e2.float(), m2)], [(e1, m1), (e2, m2)]), ([(eg, m1, 1), (e2.float(), m2)], [(eg, m1, 1), (e2, m2)])):
+            d0, d1 = torch.empty_like(x32), torch.empty_like(x16)
+            p0 = ops.spatial_bwd_tile(dy16, x32, a, w3, d0, accumulate=False, gated=g32)
+            p1 = ops.spatial_bwd_tile(dy16, x16, a, w3, d1, accumulate=False, gated=g16)
+            assert torch.equal(d1, d0.to(torch.bfloat16)) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("V,T,cin,ic,B", [(25, 13, 64, 16, 2), (25, 7, 128, 32, 2), (27, 9, 64, 32, 1), (18, 10, 128, 64, 2), (22, 31, 256, 64, 1)])
+def test_embedding_kernels_on_bfloat16_activations(V, T, cin, ic, B):
+    """fgcn_emb_fwd_tile_t (x in), fgcn_emb_dx_tile_t (dx read-modify-written as bfloat16), fgcn_emb_wgrad_tile_t (x in) against the `_h`
+    forms on the same values."""
+    from fusion_gcn_amd import ops
+    x16 = h16(B, T, V, cin, seed=61)
+    x32 = x16.float()
+    w3 = ops.pack_split3(gpu(rnd(1, cin, 6 * ic, seed=62, scale=cin ** -0.5)))
+    bias = gpu(rnd(6 * ic, seed=63))
+    e0, p0 = ops.emb_fwd_tile(x32, w3, bias, ic=ic, emb_bf16=True)
+    e1, p1 = ops.emb_fwd_tile(x16, w3, bias, ic=ic, emb_bf16=True)
+    assert e1.dtype == torch.bfloat16 and torch.equal(e0, e1) and torch.equal(p0, p1)
+    e2, p2 = ops.emb_fwd_tile(x16, w3, bias, ic=ic)                 # a float32 emb from a bfloat16 x
+    e3, _ = ops.emb_fwd_tile(x32, w3, bias, ic=ic)
+    assert e2.dtype == torch.float32 and torch.equal(e2, e3) and torch.equal(p2, p0)
+    ds = gpu(rnd(B, 3, V, V, seed=64, scale=0.2))
+    wt = ops.pack_split3(gpu(rnd(1, 6 * ic, cin, seed=65, scale=(6 * ic) ** -0.5)))
+    base16 = h16(B, T, V, cin, seed=66)
+    for acc in (False, True):
+        d0, d1 = base16.float(), base16.clone()
+        ops.emb_dx_tile(e1, ds, wt, d0, ic=ic, accumulate=acc)
+        ops.emb_dx_tile(e1, ds, wt, d1, ic=ic, accumulate=acc)
+        assert torch.equal(d1, d0.to(torch.bfloat16)), acc
+    for d in (ds, ds[:1]):
+        gw0, gb0 = ops.emb_wgrad_tile(e1, x32, d, ic=ic)
+        gw1, gb1 = ops.emb_wgrad_tile(e1, x16, d, ic=ic)
+        assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
