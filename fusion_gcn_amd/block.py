@@ -385,12 +385,19 @@ def _bn_vec(part, count, P, bufs, name, train):
     return ops.bn_eval_coeffs(g, b, rm, rv)
 
 
+def half_activations_on(train: bool, o_) -> bool:
+    """Whether this block keeps its activation-sized tensors in bfloat16 (paths.half_activations): math mode bf16, a training step."""
+    return bool(train and ops.get_math_mode() == "bf16" and o_.get("half_activations", "bf16") and o_.get("half_storage", "bf16"))
+
+
 def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, torch.Tensor], W: Dict[str, torch.Tensor],
-                  cfg: BlockConfig, train: bool, pool_groups: int = 0, inference: bool = False):
+                  cfg: BlockConfig, train: bool, pool_groups: int = 0, inference: bool = False, out_half: bool = False):
     """x (B, T, V, cx) -> O (B, T', V, cout); returns (O, saved-for-backward dict).  ``pool_groups`` > 0 (the model's last block): O is
     not formed, the first result is its mean over the rows of every group of B / pool_groups consecutive samples, (pool_groups, cout).
     ``inference`` (eval mode, no autograd graph): BatchNorm + shortcut + ReLU run as the EPILOGUES of the two north-star kernels where
-    their inference forms exist (paths.fused_inference) -- no pre-BatchNorm tensors, no bn_act passes, nothing saved for a backward."""
+    their inference forms exist (paths.fused_inference) -- no pre-BatchNorm tensors, no bn_act passes, nothing saved for a backward.
+    Math mode bf16 (paths.half_activations): ``x`` may be a bfloat16 tensor (the previous block's output), Y / U are stored as bfloat16 where
+    their producers have the form, and ``out_half`` (the caller takes a bfloat16 output: the next block) makes O one too."""
     B, T, V, cx = x.shape
     cout, ic, s = cfg.cout, cfg.ic, cfg.stride
     assert cx == cfg.cx, (cx, cfg.cx)
@@ -400,6 +407,18 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     o_ = ops.paths()             # this context's kernel-form options (fusion_gcn_amd/paths.py)
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     S: Dict[str, Optional[torch.Tensor]] = {"x": x}
+    ha = half_activations_on(train, o_)
+    x16 = x.dtype == torch.bfloat16
+    _x32: List[torch.Tensor] = []
+
+    def x32() -> torch.Tensor:      # x for a kernel without a bfloat16-input form (converted once, on first use)
+        if not x16:
+            return x
+        if not _x32:
+            _x32.append(x.float())
+        return _x32[0]
+    if x16 and not ha:
+        raise ops._lib.FgcnError("block_forward: a bfloat16 input needs math mode bf16 with paths.half_activations (a training step)")
     # math mode f16x2: the largest magnitudes of x and G, recorded by the kernels that stage them (pw_gemm / tconv_halo), scale the
     # same tensors in the backward's weight gradients; slot 0 = x (only when the embedding runs on the split row GEMM), 1 = G
     f16x2 = ops.get_math_mode() == "f16x2"
@@ -421,7 +440,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         else:
             emb = new(B, T, V, 6 * ic)
             S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
-            pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
+            pw_gemm(x32(), W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
             part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
         c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_a, B, adj_b=adj_b)
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
@@ -435,18 +454,20 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         d, vec_d = None, None
         if cfg.has_down:
             d = new(B, T, V, cout)
-            pw_gemm(x, W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"])
+            pw_gemm(x32(), W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"])
             vec_d = _bn_vec(None, B * T * V, P, bufs, "gcn1.down.1", False)
         g = ops.spatial_fwd_tile_bn_relu(x, a_hat, W["d_s3"], W["d_b"], vec_y, Cin=cin, Cout=cout, res=d if cfg.has_down else x, res_vec=vec_d)
         S.update(y=None, vec_y=vec_y, d=None, vec_d=vec_d, g=g, g_sign=None, half=False)
         return _temporal_stage(x, g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_)
+    # (Y as bfloat16: not when the temporal data gradient is to carry the BatchNorm-backward sums -- that epilogue reads Y as float32)
+    y16 = ha and not o_.get("bn_sums_in_dgrad", ops.get_math_mode())
     if cfg.fused_spatial and o_.spatial_tile and cout >= o_.get("spatial_tile_min_cout", ops.get_math_mode()) and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
-        y, part = ops.spatial_fwd_tile(x, a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train)
+        y, part = ops.spatial_fwd_tile(x if y16 else x32(), a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train, y_bf16=y16)
     elif cfg.fused_spatial:
-        y, part = ops.spatial_fwd(x, a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
+        y, part = ops.spatial_fwd(x32(), a_hat, W["d4"], W["d_b"], Cin=cin, Cout=cout, stats=train)
     else:
         agg = new(B, T, V, 3 * cin)
-        mix_agg(x, agg, a_hat, cin)
+        mix_agg(x32(), agg, a_hat, cin)
         y = new(B, T, V, cout)
         part = ops.rows_gemm(agg, W["d"].unsqueeze(0), y, K=3 * cin, N=cout, bias=W["d_b"], stats=train)
     vec_y = _bn_vec(part, B * T * V, P, bufs, "gcn1.bn", train)
@@ -456,14 +477,14 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     half = half_storage_ok(W, kt, s, T, train, o_)
     if cfg.has_down:
         d = new(B, T, V, cout)
-        part = pw_gemm(x, W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
+        part = pw_gemm(x32(), W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
         vec_d = _bn_vec(part, B * T * V, P, bufs, "gcn1.down.1", train)
         g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True, out_bf16=half)
     else:
         d, vec_d = None, None
     # identity blocks on the split-bf16 kernels: G = relu(BatchNorm(y) + x) is formed INSIDE the temporal conv while it stages its
     # image (north-star kernel 2: "temporal 9x1 conv + BN + ReLU"), G and its sign image come out as by-products -- no bn_act pass
-    fuse_g = (o_.fuse_g and not half and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
+    fuse_g = (o_.fuse_g and not half and not ha and not cfg.has_down and s == 1 and kt > 1 and "t4" in W and ops.tconv_halo_bn_sums()
               and cx == cout and V <= 32 and (B * T * V * cout) % 8 == 0)
     if fuse_g:
         g = new(B, T, V, cout)
@@ -474,10 +495,12 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         raise ops._lib.FgcnError("half-precision storage of G needs the sign image (element count a multiple of 8)")
     S.update(y=y, vec_y=vec_y, d=d, vec_d=vec_d, g=g, g_sign=g_sign, half=half)   # *_sign: 1 bit per element, the backward's ReLU gate
 
-    return _temporal_stage(x, y if fuse_g else g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_, fuse_in=(vec_y, x, g, g_sign) if fuse_g else None)
+    return _temporal_stage(x, y if fuse_g else g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_, fuse_in=(vec_y, x, g, g_sign) if fuse_g else None,
+                           x32=x32, out_half=bool(ha and out_half))
 
 
-def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_groups: int, infer: bool, kt: int, o_, fuse_in=None):
+def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_groups: int, infer: bool, kt: int, o_, fuse_in=None, x32=None,
+                    out_half: bool = False):
     """The second half of block_forward: the temporal conv, its BatchNorm, the block's shortcut and ReLU (agcn.py:49-51,125-136)."""
     B, T, V, cx = x.shape
     cout, s = cfg.cout, cfg.stride
@@ -487,6 +510,8 @@ def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_gro
     new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
     f16x2 = ops.get_math_mode() == "f16x2"
     amax = S["amax"]
+    if x32 is None:
+        x32 = lambda: x          # noqa: E731
     if infer and s == 1 and kt > 1 and "t4" in W and not pool_groups and cfg.residual in ("none", "identity", "conv") and (cfg.residual != "identity" or x.shape[3] == cout):
         # north-star kernel 2 as the north star states it, inference form: temporal conv + BatchNorm + shortcut + ReLU in one kernel
         vec_u = _bn_vec(None, B * Tp * V, P, bufs, "tcn1.bn", False)
@@ -501,23 +526,28 @@ def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_gro
                                res=x if cfg.residual == "identity" else r, res_vec=vec_r)
         S.update(u=None, vec_u=vec_u, r=None, vec_r=vec_r, o=o, o_sign=None)
         return o, S
-    u = new(B, Tp, V, cout)
+    # paths.half_activations: U as bfloat16 where the conv that writes it has the form (the stride-1 halo kernel on a bfloat16 G; the strided
+    # conv's second pass accumulates into its output and keeps float32)
+    u16 = bool(half_activations_on(train, o_) and S.get("half") and s == 1 and kt > 1 and "t4" in W and fuse_in is None)
+    u = torch.empty((B, Tp, V, cout), device=dev, dtype=torch.bfloat16) if u16 else new(B, Tp, V, cout)
     S["g_amax"] = f16x2 and temporal_fwd_records_amax(W, kt, s, T)
     part = temporal_fwd(g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,
                         fuse_in=fuse_in, amax_out=amax[1:2] if S["g_amax"] else None)
     vec_u = _bn_vec(part, B * Tp * V, P, bufs, "tcn1.bn", train)
     r, vec_r = None, None
     epilogue = (lambda a, va, b, vb: ops.bn_act_pool(a, va, b, vb, pool_groups)) if pool_groups else \
-               (lambda a, va, b, vb: ops.bn_act(a, va, b, vb, relu=True, sign_mask=True))
+               (lambda a, va, b, vb: ops.bn_act(a, va, b, vb, relu=True, sign_mask=True, out_bf16=out_half))
     if cfg.residual == "none":
         o, o_sign = epilogue(u, vec_u, None, None)
     elif cfg.residual == "identity":
         o, o_sign = epilogue(u, vec_u, x, None)
     else:
         r = new(B, Tp, V, cout)
-        part = ops.rows_gemm(x, W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
+        part = ops.rows_gemm(x32(), W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
         vec_r = _bn_vec(part, B * Tp * V, P, bufs, "residual.bn", train)
         o, o_sign = epilogue(u, vec_u, r, vec_r)
+    if out_half and not pool_groups and o_sign is None:
+        raise ops._lib.FgcnError("half-precision storage of the block's output needs the sign image (element count a multiple of 8)")
     S.update(u=u, vec_u=vec_u, r=r, vec_r=vec_r, o=None if pool_groups else o, o_sign=o_sign)
     return o, S
 
@@ -590,9 +620,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     d_o = d_o.contiguous()
     o_numel = B * Tp * V * cout
     kt = P["tcn1.conv.weight"].shape[2]
-
-    dx = new(B, T, V, cx)
-    dx_live = False      # becomes True once dx holds a valid partial sum
+    ha = half_activations_on(train, o_)
+    x16 = x.dtype == torch.bfloat16          # the block's input arrived as bfloat16 (paths.half_activations): its gradient leaves as bfloat16
     # Identity shortcuts (cin == cout, stride 1: both the graph convolution's `y += x` and the block residual) send the ReLU-gated
     # incoming gradients straight to dx.  Instead of the BatchNorm-backward kernels writing / read-modify-writing dx, the kernel
     # that forms the spatial term of dx (joint_dagg) adds both from their sign images: two activation passes less per block.
@@ -602,6 +631,28 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     gate_in_dagg = ((o_.gated_shortcuts_tile if tile_ok else o_.gated_shortcuts) and o_.fused_dagg and not cfg.has_down and cfg.residual == "identity"
                     and cx == cfg.cin and cout % 8 == 0 and S["o_sign"] is not None and S["g_sign"] is not None
                     and o_numel * 4 < 0x7FFF0000)
+    # -- paths.half_activations: which gradients are bfloat16 tensors --------------------------------------------------------------------
+    # dG (written by the temporal data gradient's halo kernel from a bfloat16 dU; not when that kernel's epilogue carries the BatchNorm sums)
+    fuse_sums = (o_.get("bn_sums_in_dgrad", ops.get_math_mode()) and cout <= o_.bn_sums_max_c and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
+                 and "t_t4" in W and ops.tconv_halo_bn_sums())
+    dg16 = bool(ha and half and kt > 1 and temporal_dgrad_records_amax(W, kt, s) and not fuse_sums and S["g_sign"] is not None)     # (narrowed below)
+    wgrad_tile = (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
+                  and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2))
+    half_dy = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and wgrad_tile and tile_ok and x.shape[3] == cin
+                   and S["g_sign"] is not None)
+    emb_tile_bwd = (not cfg.static_adjacency) and emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_) and x.shape[3] == cin
+    # dx itself: every writer of dx must have the bfloat16 form -- the fused spatial backward first (with both gated shortcuts, or none to
+    # add), then the embedding tile kernel; a residual / down conv or an ungated shortcut writes float32, and the block converts at the end
+    dx16 = bool(x16 and ha and tile_ok and x.shape[3] == cin and half_dy and not cfg.has_down and cfg.residual != "conv"
+                and (cfg.residual == "none" or gate_in_dagg)
+                and (cfg.static_adjacency or (emb_tile_bwd and S["emb"] is not None and S["emb"].dtype == torch.bfloat16))
+                and (not gate_in_dagg or (dg16 and (d_o.dtype == torch.bfloat16 or (pool is not None and o_.pool_backward_rows)))))
+    dg16 = dg16 and (dx16 or not gate_in_dagg)       # (a gated addend has dx's storage type: the fused backward adds it)
+    if x16 and not dx16:
+        x = x.float()                        # (the kernels of this block's remaining paths read float32)
+    dx = torch.empty((B, T, V, cx), device=dev, dtype=torch.bfloat16) if dx16 else new(B, T, V, cx)
+    dx_live = False      # becomes True once dx holds a valid partial sum
+    as_extra = lambda t: t if (dx16 or t.dtype == torch.float32) else t.float()      # noqa: E731  a gated addend has dx's storage type
     gated: List[tuple] = []
     grp_rows = grp_samples = 0
     if pool is not None:
@@ -621,7 +672,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     elif cfg.residual == "identity" and gate_in_dagg:
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, need_db=False,
                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
-        gated.append((d_o, S["o_sign"], grp_samples) if grp_samples else (d_o, S["o_sign"]))   # dx += d_o * [o > 0], added by joint_dagg below
+        gated.append((d_o, S["o_sign"], grp_samples) if grp_samples else (as_extra(d_o), S["o_sign"]))   # dx += d_o * [o > 0], added by joint_dagg below
     elif cfg.residual == "identity":
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
@@ -638,11 +689,9 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
 
     # -- temporal conv -------------------------------------------------------------------------------------------------------
-    dg = new(B, T, V, cout)
+    dg = torch.empty((B, T, V, cout), device=dev, dtype=torch.bfloat16) if dg16 else new(B, T, V, cout)
     # identity blocks in the split-bf16 modes: the data-gradient kernel sums dg * [g > 0] and dg * [g > 0] * y_hat in its epilogue,
-    # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y
-    fuse_sums = (o_.get("bn_sums_in_dgrad", ops.get_math_mode()) and cout <= o_.bn_sums_max_c and train and s == 1 and not cfg.has_down and S["g_sign"] is not None
-                 and "t_t4" in W and ops.tconv_halo_bn_sums())
+    # so the BatchNorm backward of the graph convolution below needs no reduction pass of its own over dg and y (fuse_sums, above)
     # math mode f16x2: the data-gradient kernels record the largest magnitudes of the tensors they stage (slot 0 = du, 1 = demb);
     # with the forward's slots they are the operand scales of the weight gradients, which therefore follow those kernels
     f16x2 = S.get("amax") is not None and ops.get_math_mode() == "f16x2"
@@ -658,11 +707,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     G["tcn1.conv.bias"] = bias_grad(du, cout)
 
     # -- G = relu(BN(y) + down(x)) ---------------------------------------------------------------------------------------------
-    # math mode bf16, training, both consumers of dy on their tile kernels: dy is stored as bfloat16 (only their staging reads it)
-    wgrad_tile = (o_.spatial_wgrad_tile and x.shape[3] == cin and ops.spatial_wgrad_tile_available(V, cin, cout) and small(max(cin, cout))
-                  and (ops.get_math_mode() in ("bf16x3", "bf16") or o_.spatial_wgrad_tile_f16x2))
-    half_dy = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and wgrad_tile and tile_ok and x.shape[3] == cin
-                   and S["g_sign"] is not None)
+    # math mode bf16, training, both consumers of dy on their tile kernels: dy is stored as bfloat16 (only their staging reads it;
+    # wgrad_tile / half_dy: above)
     if cfg.has_down:
         dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train,
                                       sign_mask=S["g_sign"], da_bf16=half_dy)
@@ -674,7 +720,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     elif gate_in_dagg:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
                                      sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
-        gated.append((dg, S["g_sign"]))            # dx += dg * [g > 0]
+        gated.append((as_extra(dg), S["g_sign"]))  # dx += dg * [g > 0]
     else:
         dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
                                      db_accumulate=dx_live, sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
@@ -726,7 +772,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- attention embeddings -----------------------------------------------------------------------------------------------------
     if not cfg.static_adjacency:
         emb = S["emb"]
-        if emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_) and x.shape[3] == cin:
+        if emb_tile_bwd:
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
             gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
@@ -745,6 +791,8 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
                 lo = (2 * k + j) * ic
                 G[f"gcn1.{grp}.{k}.weight"] = gw[lo:lo + ic]
                 G[f"gcn1.{grp}.{k}.bias"] = gb[lo:lo + ic]
+    if x16 and dx.dtype != torch.bfloat16:
+        dx = dx.to(torch.bfloat16)           # the gradient of a bfloat16 input (one rounding, as the bfloat16-writing kernels apply it)
     return (dx if need_dx else None), G
 
 
@@ -759,7 +807,8 @@ class STBlockFunction(torch.autograd.Function):
         P = dict(zip(names, params))
         pool_groups = holder.get("pool_groups", 0) if holder is not None else 0
         inference = bool(holder.get("inference")) if holder is not None else False      # eval mode and no autograd graph (the module says)
-        o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups, inference=inference)
+        out_half = bool(holder.get("out_half")) if holder is not None else False        # the consumer takes a bfloat16 output (paths.half_activations)
+        o, S = block_forward(x, P, bufs, W, cfg, train, pool_groups, inference=inference, out_half=out_half)
         B, T, V, _ = x.shape
         ctx.pool = (pool_groups, (B, (T - 1) // cfg.stride + 1, V, cfg.cout)) if pool_groups else None
         ctx.zeros = holder.get("zeros") if holder is not None else None      # the block's slice of the model's zero pool (or None)

@@ -194,19 +194,61 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
         }
     }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
-    if (cok)
-        for (long long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
-            const long long o = r * C + c;
-            // (ld_dout > C: a channel window of a wider gradient; grp_rows > 0: dout is one row per GROUP of grp_rows consecutive rows -- the
-            // gradient of the pooled output of the model's last block, fgcn_bn_act_pool -- and every row of a group reads its group's row)
+    if (cok) {
+        // (ld_dout > C: a channel window of a wider gradient; grp_rows > 0: dout is one row per GROUP of grp_rows consecutive rows -- the
+        // gradient of the pooled output of the model's last block, fgcn_bn_act_pool -- and every row of a group reads its group's row)
+        auto ld_d = [&](long long r) {
             const long long dr = grp_rows ? (long long)((unsigned)r / (unsigned)grp_rows) : r;
-            f32x4 dp = TY ? ldx4(dout, dr * ld_dout + c, hm & 1, 0) : *reinterpret_cast<const f32x4*>(dout + dr * ld_dout + c);
-            if (relu) relu_gate<MASKED>(dp, out, mask, o);
-            const f32x4 ah = ((TY ? ldx4(a, o, hm & 2, 0) : *reinterpret_cast<const f32x4*>(a + o)) - mean_a) * rstd_a;
+            return TY ? ldx4(dout, dr * ld_dout + c, hm & 1, 0) : *reinterpret_cast<const f32x4*>(dout + dr * ld_dout + c);
+        };
+        auto ld_a = [&](long long o) { return TY ? ldx4(a, o, hm & 2, 0) : *reinterpret_cast<const f32x4*>(a + o); };
+        auto ld_b = [&](long long o) { return TY ? ldx4(b, o, hm & 4, 0) : *reinterpret_cast<const f32x4*>(b + o); };
+        // the gate of the four elements at offset o: the sign image's nibble, or the four values of `out` themselves
+        auto ld_g = [&](long long o) -> f32x4 {
+            if (MASKED) return f32x4{__builtin_bit_cast(float, (int)(mask[o >> 3] >> (int)(o & 4))), 0.f, 0.f, 0.f};
+            return *reinterpret_cast<const f32x4*>(out + o);
+        };
+        auto add = [&](f32x4 dp, f32x4 gv, f32x4 av, f32x4 bv) {
+            if (relu) {
+                if (MASKED) {
+                    const float g0 = gv[0];
+                    const int nib = __builtin_bit_cast(int, g0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dp[e] = (nib >> e) & 1 ? dp[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dp[e] = gv[e] > 0.f ? dp[e] : 0.f;
+                }
+            }
+            const f32x4 ah = (av - mean_a) * rstd_a;
             s1 += dp;
             s2 += dp * ah;
-            if (RES == 2) s3 += dp * (((TY ? ldx4(b, o, hm & 4, 0) : *reinterpret_cast<const f32x4*>(b + o)) - mean_b) * rstd_b);
+            if (RES == 2) s3 += dp * ((bv - mean_b) * rstd_b);
+        };
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        // four rows in flight (two with a second BatchNorm branch; all their loads first: the loop was one memory round trip per row); the sums
+        // still run over the thread's rows in ascending order -- same bits as one by one
+        constexpr int UNR = RES == 2 ? 2 : 4;                // (inside the 128 registers that four workgroups per CU leave a thread)
+        const long long ny = blockDim.y;
+        long long r = r0 + threadIdx.y;
+        for (; r + (UNR - 1) * ny < r1; r += UNR * ny) {
+            f32x4 dpv[UNR], gvv[UNR], avv[UNR], bvv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long long o = (r + u * ny) * C + c;
+                dpv[u] = ld_d(r + u * ny);
+                gvv[u] = relu ? ld_g(o) : z4;
+                avv[u] = ld_a(o);
+                bvv[u] = RES == 2 ? ld_b(o) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) add(dpv[u], gvv[u], avv[u], bvv[u]);
         }
+        for (; r < r1; r += ny) {
+            const long long o = r * C + c;
+            add(ld_d(r), relu ? ld_g(o) : z4, ld_a(o), RES == 2 ? ld_b(o) : z4);
+        }
+    }
     float* mine = red + (long long)threadIdx.y * 3 * Cw;
     *reinterpret_cast<f32x4*>(mine + cl) = s1;
     *reinterpret_cast<f32x4*>(mine + Cw + cl) = s2;
@@ -333,6 +375,202 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float* a, const 
     }
 }
 
+// ---- the typed passes, EIGHT elements per thread (C % 8 == 0) -----------------------------------------------------------------------------
+// With bfloat16 operands a four-element thread moves 8 bytes per operand and the passes stop following the bytes (measured in the bf16 step,
+// profiles/r06_ab_bf16_half_activations.txt: bn_act_bwd_apply 104.6 -> 95.5 us for 0.61 -> 0.37 GB): the thread count, not the traffic, bounds
+// them.  Here a thread owns eight consecutive channels: one 16-byte load per bfloat16 operand (two per float32 one), one 16-byte store of
+// eight bfloat16, one byte of the sign image.  Same arithmetic per element as the four-wide kernels: same bits.
+struct f32x8 {
+    f32x4 lo, hi;
+};
+__device__ __forceinline__ f32x8 ldx8(const float* p, long long e, bool half, int stream) {
+    f32x8 r;
+    if (half) {
+        const u32x4v* q = reinterpret_cast<const u32x4v*>(reinterpret_cast<const unsigned short*>(p) + e);
+        const u32x4v h = stream ? __builtin_nontemporal_load(q) : *q;
+        r.lo = unpack_bf16x4(u32x2{h[0], h[1]});
+        r.hi = unpack_bf16x4(u32x2{h[2], h[3]});
+    } else {
+        r.lo = load4(p + e, stream);
+        r.hi = load4(p + e + 4, stream);
+    }
+    return r;
+}
+__device__ __forceinline__ void stx8(float* p, long long e, f32x8 v, bool half, int stream) {
+    if (half) {
+        const u32x2 a = __builtin_bit_cast(u32x2, pack_bf16(v.lo)), b = __builtin_bit_cast(u32x2, pack_bf16(v.hi));
+        const u32x4v h = u32x4v{a[0], a[1], b[0], b[1]};
+        u32x4v* q = reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned short*>(p) + e);
+        if (stream) __builtin_nontemporal_store(h, q);
+        else *q = h;
+    } else {
+        store4(p + e, v.lo, stream);
+        store4(p + e + 4, v.hi, stream);
+    }
+}
+__device__ __forceinline__ f32x8 ldv8(const float* v, int c) { return f32x8{*reinterpret_cast<const f32x4*>(v + c), *reinterpret_cast<const f32x4*>(v + c + 4)}; }
+__device__ __forceinline__ int sign_byte(f32x8 y) {
+    return (y.lo[0] > 0.f ? 1 : 0) | (y.lo[1] > 0.f ? 2 : 0) | (y.lo[2] > 0.f ? 4 : 0) | (y.lo[3] > 0.f ? 8 : 0) | (y.hi[0] > 0.f ? 16 : 0) |
+           (y.hi[1] > 0.f ? 32 : 0) | (y.hi[2] > 0.f ? 64 : 0) | (y.hi[3] > 0.f ? 128 : 0);
+}
+__device__ __forceinline__ void gate8(f32x8& d, int bits) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        d.lo[e] = (bits >> e) & 1 ? d.lo[e] : 0.f;
+        d.hi[e] = (bits >> (4 + e)) & 1 ? d.hi[e] : 0.f;
+    }
+}
+
+// hm: bit 0 = `a` is bfloat16, bit 1 = `b`, bit 2 = `out`
+template <int RES, bool MASK>
+__global__ __launch_bounds__(256) void bn_act8_kernel(const float* a, const float* va, const float* b, const float* vb, float* out,
+                                                      unsigned char* mask, long long n8, int C, int relu, int stream, int hm) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(((unsigned)i * 8u) % (unsigned)C);       // n8 < 2^29 (host check)
+        const f32x8 x = ldx8(a, i * 8, hm & 1, stream), sc = ldv8(va + 2 * C, c), sh = ldv8(va + 3 * C, c);
+        f32x8 y{x.lo * sc.lo + sh.lo, x.hi * sc.hi + sh.hi};
+        if (RES == 1) {
+            const f32x8 r = ldx8(b, i * 8, hm & 2, stream);
+            y.lo += r.lo;
+            y.hi += r.hi;
+        } else if (RES == 2) {
+            const f32x8 r = ldx8(b, i * 8, hm & 2, stream), sb = ldv8(vb + 2 * C, c), hb = ldv8(vb + 3 * C, c);
+            y.lo += r.lo * sb.lo + hb.lo;
+            y.hi += r.hi * sb.hi + hb.hi;
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y.lo[e] = fmaxf(y.lo[e], 0.f);
+                y.hi[e] = fmaxf(y.hi[e], 0.f);
+            }
+        }
+        stx8(out, i * 8, y, hm & 4, stream);
+        if (MASK) mask[i] = (unsigned char)sign_byte(y);
+    }
+}
+
+// hm: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`; the ReLU gate is the sign image (or none); blockDim = (C/8 up to 128, ny)
+template <int RES>
+__global__ void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va, const float* b,
+                                          const float* vb, float* partials, long long rows, long long rows_per_tile, int C, int relu,
+                                          int grp_rows, int hm) {
+    extern __shared__ float red[];  // [ny][3][Cw]
+    const int Cw = blockDim.x * 8, c0 = blockIdx.y * Cw, cl = threadIdx.x * 8;
+    const int c = c0 + cl;
+    const bool cok = c < C;
+    const long long r0 = (long long)blockIdx.x * rows_per_tile;
+    const long long r1 = min(r0 + rows_per_tile, rows);
+    f32x8 zero{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x8 mean_a = zero, rstd_a = zero, mean_b = zero, rstd_b = zero, s1 = zero, s2 = zero, s3 = zero;
+    if (cok) {
+        mean_a = ldv8(va, c);
+        rstd_a = ldv8(va + C, c);
+        if (RES == 2) {
+            mean_b = ldv8(vb, c);
+            rstd_b = ldv8(vb + C, c);
+        }
+        // two rows in flight (all their loads first); the sums still run over the thread's rows in ascending order: same bits as one by one
+        auto add = [&](f32x8 dp, int bits, f32x8 av, f32x8 bv) {
+            if (relu) gate8(dp, bits);
+            const f32x4 ahl = (av.lo - mean_a.lo) * rstd_a.lo, ahh = (av.hi - mean_a.hi) * rstd_a.hi;
+            s1.lo += dp.lo;
+            s1.hi += dp.hi;
+            s2.lo += dp.lo * ahl;
+            s2.hi += dp.hi * ahh;
+            if (RES == 2) {
+                s3.lo += dp.lo * ((bv.lo - mean_b.lo) * rstd_b.lo);
+                s3.hi += dp.hi * ((bv.hi - mean_b.hi) * rstd_b.hi);
+            }
+        };
+        auto ld_d = [&](long long r, long long o) {
+            return grp_rows ? ldx8(dout, (long long)((unsigned)r / (unsigned)grp_rows) * C + c, false, 0)      // (one float32 row per group)
+                            : ldx8(dout, o, hm & 1, 0);
+        };
+        constexpr int UNR = RES == 2 ? 1 : 2;                // (sixteen-byte loads of eight values: what keeps the kernel inside 128 registers)
+        const long long ny = blockDim.y;
+        long long r = r0 + threadIdx.y;
+        for (; r + (UNR - 1) * ny < r1; r += UNR * ny) {
+            f32x8 dpv[UNR], avv[UNR], bvv[UNR];
+            int bits[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const long long o = (r + u * ny) * C + c;
+                dpv[u] = ld_d(r + u * ny, o);
+                bits[u] = relu ? mask[o >> 3] : 0;
+                avv[u] = ldx8(a, o, hm & 2, 0);
+                bvv[u] = RES == 2 ? ldx8(b, o, hm & 4, 0) : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) add(dpv[u], bits[u], avv[u], bvv[u]);
+        }
+        for (; r < r1; r += ny) {
+            const long long o = r * C + c;
+            add(ld_d(r, o), relu ? mask[o >> 3] : 0, ldx8(a, o, hm & 2, 0), RES == 2 ? ldx8(b, o, hm & 4, 0) : zero);
+        }
+    }
+    float* mine = red + (long long)threadIdx.y * 3 * Cw;
+    *reinterpret_cast<f32x4*>(mine + cl) = s1.lo;
+    *reinterpret_cast<f32x4*>(mine + cl + 4) = s1.hi;
+    *reinterpret_cast<f32x4*>(mine + Cw + cl) = s2.lo;
+    *reinterpret_cast<f32x4*>(mine + Cw + cl + 4) = s2.hi;
+    *reinterpret_cast<f32x4*>(mine + 2 * Cw + cl) = s3.lo;
+    *reinterpret_cast<f32x4*>(mine + 2 * Cw + cl + 4) = s3.hi;
+    __syncthreads();
+    const int nthreads = blockDim.x * blockDim.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < 3 * Cw; i += nthreads) {
+        const int which = i / Cw, ci = i - which * Cw;
+        float s = 0.f;
+        for (int y = 0; y < (int)blockDim.y; ++y) s += red[y * 3 * Cw + i];
+        if (c0 + ci < C) partials[(long long)blockIdx.x * 3 * C + which * C + c0 + ci] = s;
+    }
+}
+
+// hm: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da` (db: float32)
+template <int RES>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va,
+                                                                const float* b, const float* vb, const float* sums, float* da, float* db,
+                                                                long long n8, int C, int relu, int train, float inv_m, int db_accumulate,
+                                                                int stream, int grp_rows, int hm) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(((unsigned)i * 8u) % (unsigned)C);
+        f32x8 dp;
+        if (grp_rows) dp = ldx8(dout, (long long)(((unsigned)i * 8u / (unsigned)C) / (unsigned)grp_rows) * C + c, false, 0);
+        else dp = ldx8(dout, i * 8, hm & 1, 0);
+        if (relu) gate8(dp, mask[i]);
+        const f32x8 sc_a = ldv8(va + 2 * C, c);
+        f32x8 ga = dp;
+        f32x8 s0, s1;
+        if (train) {
+            const f32x8 av = ldx8(a, i * 8, hm & 2, 0), mean = ldv8(va, c), rstd = ldv8(va + C, c);
+            s0 = ldv8(sums, c);
+            s1 = ldv8(sums + C, c);
+            ga.lo = dp.lo - s0.lo * inv_m - ((av.lo - mean.lo) * rstd.lo) * (s1.lo * inv_m);
+            ga.hi = dp.hi - s0.hi * inv_m - ((av.hi - mean.hi) * rstd.hi) * (s1.hi * inv_m);
+        }
+        stx8(da, i * 8, f32x8{ga.lo * sc_a.lo, ga.hi * sc_a.hi}, hm & 8, stream);
+        if (RES != 0 && db) {
+            f32x8 gb = dp;
+            if (RES == 2) {
+                const f32x8 sc_b = ldv8(vb + 2 * C, c);
+                if (train) {
+                    const f32x8 bv = ldx8(b, i * 8, hm & 4, 0), mean = ldv8(vb, c), rstd = ldv8(vb + C, c), s2 = ldv8(sums + 2 * C, c);
+                    gb.lo = dp.lo - s0.lo * inv_m - ((bv.lo - mean.lo) * rstd.lo) * (s2.lo * inv_m);
+                    gb.hi = dp.hi - s0.hi * inv_m - ((bv.hi - mean.hi) * rstd.hi) * (s2.hi * inv_m);
+                }
+                gb.lo = gb.lo * sc_b.lo;
+                gb.hi = gb.hi * sc_b.hi;
+            }
+            if (db_accumulate) {
+                gb.lo += *reinterpret_cast<const f32x4*>(db + i * 8);
+                gb.hi += *reinterpret_cast<const f32x4*>(db + i * 8 + 4);
+            }
+            stx8(db, i * 8, gb, false, db_accumulate ? 0 : stream);
+        }
+    }
+}
+
 // ---- column sums ------------------------------------------------------------------------------------------------
 __global__ void col_sum_kernel(const float* x, float* partials, long long rows, long long rows_per_tile, int C, int ld) {
     extern __shared__ float red[];  // [ny][C4*4]
@@ -449,6 +687,21 @@ static int bn_act_impl(const float* a, const float* vec_a, const float* b, const
     FGCN_REQUIRE(!sign_mask || n4 % 2 == 0, FGCN_E_BADARG, "bn_act: a sign mask needs rows*C to be a multiple of 8");
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
+    if (hm && C % 8 == 0 && ld_out == C) {      // typed operands: eight elements per thread
+        const long long n8 = n4 / 2;
+        const int hm8 = hm | (o16 ? 4 : 0);
+        dim3 g8(stream_blocks(n8));
+#define FGCN_BN_ACT8(RES_)                                                                                                           \
+    do {                                                                                                                             \
+        if (sign_mask) hipLaunchKernelGGL((bn_act8_kernel<RES_, true>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str, hm8); \
+        else hipLaunchKernelGGL((bn_act8_kernel<RES_, false>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str, hm8);          \
+    } while (0)
+        if (res_mode == 0) FGCN_BN_ACT8(0);
+        else if (res_mode == 1) FGCN_BN_ACT8(1);
+        else FGCN_BN_ACT8(2);
+#undef FGCN_BN_ACT8
+        return launch_status("bn_act");
+    }
 #define FGCN_BN_ACT4(RES_, M_, O_, TY_) \
     hipLaunchKernelGGL((bn_act_kernel<RES_, M_, O_, TY_>), g, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n4, C, relu, str, ld_out, hm)
 #define FGCN_BN_ACT3(RES_, M_, O_)                                                                                \
@@ -502,6 +755,15 @@ static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const uns
     const long long rpt = rows_per_tile_for(rows);
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
+    if (hm && C % 8 == 0 && ld_dout == C && blk.x % 2 == 0) {
+        // typed operands: eight channels per thread, the same rows per thread as the four-wide kernel (same sums, bit for bit)
+        const dim3 blk8(blk.x / 2, blk.y);
+        if (res_mode == 2)
+            hipLaunchKernelGGL((bn_act_bwd_reduce8_kernel<2>), g, blk8, lds, s, dout, sign_mask, a, vec_a, b, vec_b, partials, rows, rpt, C, relu, grp_rows, hm);
+        else
+            hipLaunchKernelGGL((bn_act_bwd_reduce8_kernel<0>), g, blk8, lds, s, dout, sign_mask, a, vec_a, b, vec_b, partials, rows, rpt, C, relu, grp_rows, hm);
+        return launch_status("bn_act_bwd_reduce");
+    }
 #define FGCN_BN_RED3(RES_, M_, TY_)                                                                                \
     hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<RES_, M_, TY_>), g, blk, lds, s, dout, out, sign_mask, a, vec_a, b, vec_b, \
                        partials, rows, rpt, C, relu, ld_dout, grp_rows, hm)
@@ -541,6 +803,20 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
+    if (hm && C % 8 == 0 && ld_dout == C && (!relu || sign_mask)) {      // typed operands: eight elements per thread
+        const long long n8 = n4 / 2;
+        const int hm8 = hm | (o16 ? 8 : 0);
+        dim3 g8(stream_blocks(n8));
+        const int rm = (res_mode == 0 || !db) ? 0 : res_mode;
+#define FGCN_BN_APP8(RES_)                                                                                                                \
+    hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, relu, train, \
+                       inv_m, db_accumulate, str, grp_rows, hm8)
+        if (rm == 0) FGCN_BN_APP8(0);
+        else if (rm == 1) FGCN_BN_APP8(1);
+        else FGCN_BN_APP8(2);
+#undef FGCN_BN_APP8
+        return launch_status("bn_act_bwd_apply");
+    }
 #define FGCN_BN_APP4(RES_, M_, O_, TY_)                                                                            \
     hipLaunchKernelGGL((bn_act_bwd_apply_kernel<RES_, M_, O_, TY_>), g, blk, 0, s, dout, out, sign_mask, a, vec_a, b, vec_b, sums, \
                        da, db, n4, C, relu, train, inv_m, db_accumulate, str, ld_dout, grp_rows, hm)

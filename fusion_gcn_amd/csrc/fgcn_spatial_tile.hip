@@ -479,7 +479,7 @@ static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void*
     const dim3 grid((unsigned)(p.per_xcd * 8));
     hipStream_t s = (hipStream_t)stream;
     const bool four = 2 * p.F > 12;                                  // aggregation units per wave and chunk: ceil(2 F / 4)
-    const bool str = !(io & 2) && fgcn::stream_out(y_bytes);        // (a bfloat16 y: 32-byte pieces, stored plainly)
+    const bool str = !(io & 2) ? fgcn::stream_out(y_bytes) : ((fgcn::tuning(25) & 2) && fgcn::stream_out(y_bytes));   // (a bfloat16 y: 32-byte pieces, stored plainly; key 25 bit 1: streamed)
 #define FGCN_ST_GO6(NT_, MU_, STR_, NP_, FEP_, IO_)                                                                 \
     do {                                                                                                            \
         static bool opted = false;   /* once per instantiation; not a stream operation (stays out of graph captures) */ \
@@ -492,9 +492,9 @@ static int spatial_fwd_tile_impl(const float* x, const float* a_hat, const void*
     } while (0)
 #define FGCN_ST_GO5(NT_, MU_, STR_, NP_, FEP_)                                                                      \
     do {                                                                                                            \
-        if constexpr (NP_ == 1 && !FEP_ && !STR_) {                                                                 \
-            if (io == 3) { FGCN_ST_GO6(NT_, MU_, false, 1, false, 3); break; }                                      \
-            if (io == 2) { FGCN_ST_GO6(NT_, MU_, false, 1, false, 2); break; }                                      \
+        if constexpr (NP_ == 1 && !FEP_) {                                                                          \
+            if (io == 3) { FGCN_ST_GO6(NT_, MU_, STR_, 1, false, 3); break; }                                       \
+            if (io == 2) { FGCN_ST_GO6(NT_, MU_, STR_, 1, false, 2); break; }                                       \
         }                                                                                                           \
         FGCN_ST_GO6(NT_, MU_, STR_, NP_, FEP_, 0);                                                                  \
     } while (0)

@@ -1028,7 +1028,8 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
         FGCN_REQUIRE(bmr == 128 || wide_rows, FGCN_E_BADARG, "tconv_halo: the split kernels run the 128-row tile (V <= %d)", FGCN_MAX_V);
         FGCN_REQUIRE(!(bn_a && accumulate), FGCN_E_BADARG, "tconv_halo: BatchNorm-backward sums of an accumulating call are not built");
         const int epi = fep ? 4 : (bn_a ? 2 : (accumulate ? 3 : 0));     // epilogue form (compile time, see the kernel)
-        const bool stream_k = in16 != 2 && fgcn::stream_out((long long)B * Th * V * N * 4);   // the bytes this call writes (a bfloat16 output: 32-byte pieces, stored plainly)
+        // the bytes this call writes (a bfloat16 output: 32-byte pieces, stored plainly unless tuning key 25 bit 0 asks for streamed stores)
+        const bool stream_k = in16 != 2 ? fgcn::stream_out((long long)B * Th * V * N * 4) : ((fgcn::tuning(25) & 1) && fgcn::stream_out((long long)B * Th * V * N * 2));
 #define FGCN_K32_GO7(NT_, KC_, NP_, EPI_, FIN_, WR_, STR_) halo_k32_launch<NT_, KC_, NP_, EPI_, FIN_, WR_, STR_>(in16, grid, lds_k, s, p)
 #define FGCN_K32_GO6(NT_, KC_, NP_, EPI_, FIN_, WR_)                                                                     \
     do {                                                                                                                 \

@@ -212,13 +212,17 @@ class SpatialTemporalConv(nn.Module):
         """GraphStep hook: the packed set a recording made now reads (kept alive by the recording)."""
         return [] if self._wcache is None else [self._wcache[1]]
 
-    def forward(self, x: torch.Tensor, pool_groups: int = 0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pool_groups: int = 0, out_half: bool = False) -> torch.Tensor:
         """``pool_groups`` > 0 (the model's last block, block.pool_epilogue_ok): returns the block's output averaged over the rows of
-        every group of consecutive samples, (pool_groups, out_channels), without forming the output."""
+        every group of consecutive samples, (pool_groups, out_channels), without forming the output.
+        ``out_half``: the caller hands the output to another block of this kind, which takes a bfloat16 tensor -- in math mode bf16 with
+        paths.half_activations (a training step) the output then IS bfloat16 (and its gradient arrives as one); float32 otherwise."""
         names = param_names(self.cfg)
         params = [self._tensor(n) for n in names]
         W = self._packed(params)
         holder = {"pool_groups": pool_groups} if pool_groups else {}
+        if out_half and self.training and torch.is_grad_enabled():
+            holder["out_half"] = True
         if not self.training and not torch.is_grad_enabled():
             holder["inference"] = True                # no backward can follow: the block may take its inference kernels (block_forward)
         if self._zeros is not None:                   # this step's slice of the model's zero pool (Model.forward), used once
@@ -352,8 +356,10 @@ class Model(nn.Module):
             for b, n in zip(blocks, sizes):
                 b._zeros = zeros[off:off + n]
                 off += n
-        for layer in self.layers[:-1]:
-            h = layer(h)
+        for i, layer in enumerate(self.layers[:-1]):
+            # (a block that feeds another block may hand over a bfloat16 tensor: math mode bf16, paths.half_activations)
+            chain = isinstance(layer, SpatialTemporalConv) and isinstance(self.layers[i + 1], SpatialTemporalConv)
+            h = layer(h, out_half=True) if chain else layer(h)
         # (N*M, T', V, C') -> mean over (T', V) then over persons = one mean over persons, frames and joints (equal-sized groups)
         last = self.layers[-1]
         if isinstance(last, SpatialTemporalConv) and pool_epilogue_ok(last.cfg, h.shape[0], h.shape[1], h.shape[2], N):

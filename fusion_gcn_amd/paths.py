@@ -76,6 +76,12 @@ class PathOptions:
     # when they stage them anyway); the halo conv, bound by its row traffic through L2 in this mode, moves half of it
     # (probe: 34.38 -> 32.9 ms from the conv's input alone, profiles/r06_ab_bf16_half_storage.txt).  Only the mode's own entry counts.
     half_storage: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
+    # -- math mode bf16, one step further: half-precision storage of EVERY activation-sized tensor of a training step -- the pre-BatchNorm
+    # outputs Y / U, the block boundary x / O and its gradient, dG -- as the reference's autocast step keeps them (session/procedures/step.py:
+    # 55-78); BatchNorm statistics, softmax, accumulators stay float32.  Unlike half_storage this changes VALUES (one more rounding per
+    # stored tensor): SURVEY.md section 7's contract instead of bit-identity (tests/test_bf16_gpu.py; tools/probes/half_act_probe.py: logits
+    # 2.3e-3 -> 2.2e-3, gradient cosine 0.9977 -> 0.9972 against the float32 path).  The typed `_t` entry points of include/fgcn.h.
+    half_activations: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
     # -- inference (module in eval mode, autograd off): BatchNorm + shortcut + ReLU in the epilogues of the two north-star kernels
     # (fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- a block is two kernels + the attention; split modes bf16x3 / bf16
     fused_inference: bool = True

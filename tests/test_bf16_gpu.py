@@ -368,8 +368,9 @@ def test_halo_conv_and_weight_gradient_from_bfloat16_tensors(B, T, V, C, N, kt, 
 
 
 def test_model_step_is_bit_identical_with_half_precision_conv_operands():
-    """The whole model in math mode bf16 with G and dU stored as bfloat16 (the default there) against f32 storage: logits, loss and
-    every gradient bit for bit -- the layout change moves bytes, not values.  All ten blocks: strided ones, down / residual convs."""
+    """The whole model in math mode bf16 with G, dU, dY and emb stored as bfloat16 (paths.half_storage) against f32 storage: logits, loss and
+    every gradient bit for bit -- the layout change moves bytes, not values.  All ten blocks: strided ones, down / residual convs.
+    (paths.half_activations, the default of the mode, goes further and changes values: switched off on both sides here; its own test below.)"""
     from fusion_gcn_amd import ops
     from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
     from fusion_gcn_amd.loss import cross_entropy
@@ -389,6 +390,7 @@ def test_model_step_is_bit_identical_with_half_precision_conv_operands():
         model.load_state_dict(sd)
         with ops.context("bf16") as c:
             c.paths.half_storage["bf16"] = half
+            c.paths.half_activations["bf16"] = False
             for p in model.parameters():
                 p.grad = None
             logits = model(x)
@@ -401,6 +403,73 @@ def test_model_step_is_bit_identical_with_half_precision_conv_operands():
     assert torch.equal(l0, l1) and torch.equal(s0, s1)
     for a_, b_ in zip(g0, g1):
         assert torch.equal(a_, b_)
+
+
+def test_model_step_with_half_precision_activations():
+    """paths.half_activations (the default of math mode bf16): every activation-sized tensor of the training step is a bfloat16 tensor, as in
+    the reference's autocast step (session/procedures/step.py:55-78).  (1) The typed kernels really run: the blocks hand bfloat16 tensors
+    to each other, Y / U / dG / dx are bfloat16 where the path has the form.  (2) Against the same model with float32 activations: inside
+    SURVEY.md section 7's bf16 contract (this random-init model at T = 40, measured on MI355X: logits 2.8e-3, loss 3.7e-3, gradient cosine
+    0.992; on the reference's fixture, test_config5_model_against_the_reference: logits 2.2e-3, cosine 0.997 against the float64 oracle) --
+    the storage roundings are of the size of the operand roundings the mode already makes.  (3) Two runs agree bit for bit (fixed-order sums)."""
+    from fusion_gcn_amd import block, ops
+    from fusion_gcn_amd.datasets.ntu_rgb_d import constants as ntu
+    from fusion_gcn_amd.loss import cross_entropy
+    from fusion_gcn_amd.models.mmargcn.agcn import Model
+    from fusion_gcn_amd.util import Graph
+    torch.manual_seed(11)
+    model = Model((2, 40, 25, 3), 60, Graph(ntu.skeleton_edges, center_joint=ntu.center_joint)).to(dev()).train()
+    with torch.no_grad():
+        for m in model.modules():
+            if hasattr(m, "gcn1"):
+                m.gcn1.bn.weight.fill_(1.0)
+    x = torch.randn(3, 2, 40, 25, 3, device=dev())
+    y = torch.randint(0, 60, (3,), device=dev())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    seen = {"x16": 0, "dx16": 0, "y16": 0, "u16": 0, "dg16": 0}
+    fwd, bwd, conv = block.block_forward, block._block_backward, ops.tconv_halo
+
+    def spy_fwd(x_, *a, **k):
+        o, S = fwd(x_, *a, **k)
+        seen["x16"] += x_.dtype == torch.bfloat16
+        seen["y16"] += S["y"] is not None and S["y"].dtype == torch.bfloat16
+        seen["u16"] += S["u"] is not None and S["u"].dtype == torch.bfloat16
+        return o, S
+
+    def spy_bwd(d_o, S, *a, **k):
+        dx, G = bwd(d_o, S, *a, **k)
+        seen["dx16"] += dx is not None and dx.dtype == torch.bfloat16
+        return dx, G
+
+    def spy_conv(inp, w4, out, **k):
+        seen["dg16"] += k.get("tb") == -1 and out.dtype == torch.bfloat16
+        return conv(inp, w4, out, **k)
+
+    def run(half):
+        model.load_state_dict(sd)
+        with ops.context("bf16") as c:
+            c.paths.half_activations["bf16"] = half
+            for p in model.parameters():
+                p.grad = None
+            logits = model(x)
+            loss = cross_entropy(logits, y)
+            loss.backward()
+            return logits.detach().clone(), float(loss), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    l0, s0, g0 = run(False)
+    block.block_forward, block._block_backward, ops.tconv_halo = spy_fwd, spy_bwd, spy_conv
+    try:
+        l1, s1, g1 = run(True)
+    finally:
+        block.block_forward, block._block_backward, ops.tconv_halo = fwd, bwd, conv
+    l2, s2, g2 = run(True)
+    # ten blocks: nine receive a bfloat16 x (all but the first) and return a bfloat16 dx; Y is bfloat16 in the nine blocks on the tile kernel,
+    # U in the eight stride-1 blocks; dG in all ten (eight stride-1 calls + two per strided block)
+    assert seen == {"x16": 9, "dx16": 9, "y16": 9, "u16": 8, "dg16": 12}, seen
+    e = float((l1 - l0).norm() / l0.norm())
+    cos = float(torch.dot(g1, g0) / (g1.norm() * g0.norm()))
+    print(f"half-precision activations vs float32 activations (math mode bf16): logits {e:.2e}, |loss diff| {abs(s1 - s0):.2e}, gradient cosine {cos:.4f}")
+    assert 0 < e < 1e-2 and abs(s1 - s0) < 1e-2 and cos > 0.98, (e, s1 - s0, cos)
+    assert torch.equal(l1, l2) and s1 == s2 and torch.equal(g1, g2)
 
 
 @pytest.mark.parametrize("V,T,cin,cout,B", [(25, 13, 64, 64, 2), (25, 7, 128, 256, 2), (27, 9, 64, 128, 1), (18, 10, 256, 256, 2), (32, 5, 128, 64, 1)])
