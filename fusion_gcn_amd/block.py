@@ -460,7 +460,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         S.update(y=None, vec_y=vec_y, d=None, vec_d=vec_d, g=g, g_sign=None, half=False)
         return _temporal_stage(x, g, S, P, bufs, W, cfg, train, pool_groups, infer, kt, o_)
     # (Y as bfloat16: not when the temporal data gradient is to carry the BatchNorm-backward sums -- that epilogue reads Y as float32)
-    y16 = ha and not o_.get("bn_sums_in_dgrad", ops.get_math_mode())
+    y16 = ha and o_.half_spatial_out and not o_.get("bn_sums_in_dgrad", ops.get_math_mode())
     if cfg.fused_spatial and o_.spatial_tile and cout >= o_.get("spatial_tile_min_cout", ops.get_math_mode()) and "d_s3" in W and ops.spatial_fwd_tile_available(V, cin, cout):
         y, part = ops.spatial_fwd_tile(x if y16 else x32(), a_hat, W["d_s3"], W["d_b"], Cin=cin, Cout=cout, stats=train, y_bf16=y16)
     elif cfg.fused_spatial:
@@ -528,7 +528,7 @@ def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_gro
         return o, S
     # paths.half_activations: U as bfloat16 where the conv that writes it has the form (the stride-1 halo kernel on a bfloat16 G; the strided
     # conv's second pass accumulates into its output and keeps float32)
-    u16 = bool(half_activations_on(train, o_) and S.get("half") and s == 1 and kt > 1 and "t4" in W and fuse_in is None)
+    u16 = bool(half_activations_on(train, o_) and o_.half_conv_out and S.get("half") and s == 1 and kt > 1 and "t4" in W and fuse_in is None)
     u = torch.empty((B, Tp, V, cout), device=dev, dtype=torch.bfloat16) if u16 else new(B, Tp, V, cout)
     S["g_amax"] = f16x2 and temporal_fwd_records_amax(W, kt, s, T)
     part = temporal_fwd(g, u, W, P["tcn1.conv.bias"], kt, s, stats=train,

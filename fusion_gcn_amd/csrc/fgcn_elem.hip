@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void bn_act8_kernel(const float* a, const floa
 
 // hm: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`; the ReLU gate is the sign image (or none); blockDim = (C/8 up to 128, ny)
 template <int RES>
-__global__ void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va, const float* b,
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va, const float* b,
                                           const float* vb, float* partials, long long rows, long long rows_per_tile, int C, int relu,
                                           int grp_rows, int hm) {
     extern __shared__ float red[];  // [ny][3][Cw]
@@ -470,7 +470,7 @@ __global__ void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char
             mean_b = ldv8(vb, c);
             rstd_b = ldv8(vb + C, c);
         }
-        // two rows in flight (all their loads first); the sums still run over the thread's rows in ascending order: same bits as one by one
+        // several rows in flight (all their loads first); the sums still run over the thread's rows in ascending order: same bits as one by one
         auto add = [&](f32x8 dp, int bits, f32x8 av, f32x8 bv) {
             if (relu) gate8(dp, bits);
             const f32x4 ahl = (av.lo - mean_a.lo) * rstd_a.lo, ahh = (av.hi - mean_a.hi) * rstd_a.hi;
@@ -487,7 +487,9 @@ __global__ void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char
             return grp_rows ? ldx8(dout, (long long)((unsigned)r / (unsigned)grp_rows) * C + c, false, 0)      // (one float32 row per group)
                             : ldx8(dout, o, hm & 1, 0);
         };
-        constexpr int UNR = RES == 2 ? 1 : 2;                // (sixteen-byte loads of eight values: what keeps the kernel inside 128 registers)
+        // (at most 256 threads per block: the launch bound lets the compiler keep four rows of sixteen-byte loads in registers -- with 128-thread
+        // blocks, four per CU, the kernel had half the bytes in flight that the HBM latency asks for: 0.26 GB in 98.7 us)
+        constexpr int UNR = RES == 2 ? 2 : 4;
         const long long ny = blockDim.y;
         long long r = r0 + threadIdx.y;
         for (; r + (UNR - 1) * ny < r1; r += UNR * ny) {

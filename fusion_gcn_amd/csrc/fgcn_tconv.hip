@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256, (NP == 1 && !FIN && EPI != 4) ? 3 : 2) void co
     constexpr bool PF = KC == 64 || (NT == 1 && NP == 3 && !FIN && FGCN_HALO_PF64);
     constexpr int NST = KC == 64 ? 8 : HALO_MAX_STAGE;
     constexpr int NU = 2 * NT;                       // 16-column tiles (units) of a wave
-    constexpr int RS = (FGCN_HALO_RING == 4 && NU == 4 && NP >= 2 && (EPI != 2 || WR == 4) && !FIN) ? 4 : 2;   // weight ring slots (requested RS - 1 units ahead)
+#ifndef FGCN_HALO_RING_NP1
+#define FGCN_HALO_RING_NP1 4            // weight ring slots of the one-part (FGCN_MATH_BF16) kernel: with ONE MFMA per fragment and row tile the two-slot ring left the L2 latency of the weight stream exposed (28.40 -> 27.43 ms per bf16 step; A/B builds: 2)
+#endif
+    constexpr int RS = (FGCN_HALO_RING == 4 && NU == 4 && (NP >= 2 || FGCN_HALO_RING_NP1 == 4) && (EPI != 2 || WR == 4) && !FIN) ? 4 : 2;   // weight ring slots (requested RS - 1 units ahead)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float Ah[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -983,8 +986,11 @@ static int tconv_halo_impl(const float* in, float* out, const float* w4, const f
     // the same arrangement for ONE 128-column tile (64 < N <= 128): a wave owns 48 rows x 128 columns, every image fragment feeds eight
     // units: -5 % (bf16x3) / -9 % (f16x2) at 128 channels, nothing at 256 (two column tiles; key 7 bit 4 forces it there, bit 5 switches it
     // off); epilogue forms 0 and 3 only -- the BatchNorm-sums epilogue would spill at 255 registers
-    const bool wide128 = ((fgcn::tuning(7) & 16) || (N <= 128 && !(fgcn::tuning(7) & 32))) && N > 64 && !bn_a && !fep;   // (EPI 4 spills in that form)
-    const bool wide_rows = (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) && ((N <= 64 && N > 32) || wide128) && !(taps == 1 && K % 64 == 0) &&
+    // (FGCN_MATH_BF16: the one-part instantiation of this form runs with three workgroups per CU and spills -- 136 to 424 bytes of scratch -- and
+    // the matrix work it saves LDS reads for is a sixth: the 2 x 2 form measured 29.65 -> 28.47 ms per bf16 step, profiles/r06_ab_bf16_half_activations.txt)
+    const bool wide128 = ((fgcn::tuning(7) & 16) || (N <= 128 && !(fgcn::tuning(7) & 32) && mm != FGCN_MATH_BF16)) && N > 64 && !bn_a && !fep;   // (EPI 4 spills in that form)
+    // (FGCN_MATH_BF16: the 4 x 1 arrangements lose to the 2 x 2 form at every width -- 64 columns: 28.75 -> 28.55 ms per step -- key 7 bit 4 brings them back)
+    const bool wide_rows = (mm == FGCN_MATH_BF16X3 || (mm == FGCN_MATH_BF16 && (fgcn::tuning(7) & 16))) && ((N <= 64 && N > 32) || wide128) && !(taps == 1 && K % 64 == 0) &&
                            !(fin_vec || fin_res || fin_out || fin_mask) && !(fgcn::tuning(7) & 8) &&
                            192 + (dmax - p.dmin) * V <= 32 * HALO_MAX_STAGE && (size_t)(192 + (dmax - p.dmin) * V) * 64 * 3 + 16 <= 80 * 1024 &&
                            (cdiv(p.Mv, 192) >= 1536 || (fgcn::tuning(7) & 64));   // (three rounds of 512 workgroups: below, the coarser tiling quantises worse -- 8-clip step +0.07 ms)

@@ -82,6 +82,9 @@ class PathOptions:
     # stored tensor): SURVEY.md section 7's contract instead of bit-identity (tests/test_bf16_gpu.py; tools/probes/half_act_probe.py: logits
     # 2.3e-3 -> 2.2e-3, gradient cosine 0.9977 -> 0.9972 against the float32 path).  The typed `_t` entry points of include/fgcn.h.
     half_activations: Dict[str, bool] = field(default_factory=lambda: {"f32": False, "bf16": True, "bf16x3": False, "f16x2": False})
+    # ... per producer (A/B switches inside half_activations): the temporal conv's output U, the spatial tile kernel's output Y
+    half_conv_out: bool = True
+    half_spatial_out: bool = True
     # -- inference (module in eval mode, autograd off): BatchNorm + shortcut + ReLU in the epilogues of the two north-star kernels
     # (fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- a block is two kernels + the attention; split modes bf16x3 / bf16
     fused_inference: bool = True
