@@ -421,10 +421,13 @@ __device__ __forceinline__ void gate8(f32x8& d, int bits) {
     }
 }
 
-// hm: bit 0 = `a` is bfloat16, bit 1 = `b`, bit 2 = `out`
-template <int RES, bool MASK>
+// The storage types are TEMPLATE parameters here: behind a run-time flag every load sits in a branch of its own with its conversion, and the
+// compiler waits for each before it requests the next (the row-unrolled reduce below gained nothing until the flags were compile time).
+// HM: bit 0 = `a` is bfloat16, bit 1 = `b`, bit 2 = `out`
+template <int RES, bool MASK, int HM>
 __global__ __launch_bounds__(256) void bn_act8_kernel(const float* a, const float* va, const float* b, const float* vb, float* out,
-                                                      unsigned char* mask, long long n8, int C, int relu, int stream, int hm) {
+                                                      unsigned char* mask, long long n8, int C, int relu, int stream) {
+    constexpr int hm = HM;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 8u) % (unsigned)C);       // n8 < 2^29 (host check)
         const f32x8 x = ldx8(a, i * 8, hm & 1, stream), sc = ldv8(va + 2 * C, c), sh = ldv8(va + 3 * C, c);
@@ -450,11 +453,12 @@ __global__ __launch_bounds__(256) void bn_act8_kernel(const float* a, const floa
     }
 }
 
-// hm: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`; the ReLU gate is the sign image (or none); blockDim = (C/8 up to 128, ny)
-template <int RES>
+// HM: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`; the ReLU gate is the sign image (or none); blockDim = (C/8 up to 128, ny)
+template <int RES, int HM>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va, const float* b,
                                           const float* vb, float* partials, long long rows, long long rows_per_tile, int C, int relu,
-                                          int grp_rows, int hm) {
+                                          int grp_rows) {
+    constexpr int hm = HM;
     extern __shared__ float red[];  // [ny][3][Cw]
     const int Cw = blockDim.x * 8, c0 = blockIdx.y * Cw, cl = threadIdx.x * 8;
     const int c = c0 + cl;
@@ -484,8 +488,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
             }
         };
         auto ld_d = [&](long long r, long long o) {
-            return grp_rows ? ldx8(dout, (long long)((unsigned)r / (unsigned)grp_rows) * C + c, false, 0)      // (one float32 row per group)
-                            : ldx8(dout, o, hm & 1, 0);
+            // (one float32 row per group -- never together with a bfloat16 dout, host check: an offset select, not a branch around the load)
+            if constexpr ((HM & 1) != 0) return ldx8(dout, o, true, 0);
+            else return ldx8(dout, grp_rows ? (long long)((unsigned)r / (unsigned)grp_rows) * C + c : o, false, 0);
         };
         // (at most 256 threads per block: the launch bound lets the compiler keep four rows of sixteen-byte loads in registers -- with 128-thread
         // blocks, four per CU, the kernel had half the bytes in flight that the HBM latency asks for: 0.26 GB in 98.7 us)
@@ -529,17 +534,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
     }
 }
 
-// hm: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da` (db: float32)
-template <int RES>
+// HM: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da` (db: float32)
+template <int RES, int HM>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va,
                                                                 const float* b, const float* vb, const float* sums, float* da, float* db,
                                                                 long long n8, int C, int relu, int train, float inv_m, int db_accumulate,
-                                                                int stream, int grp_rows, int hm) {
+                                                                int stream, int grp_rows) {
+    constexpr int hm = HM;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 8u) % (unsigned)C);
         f32x8 dp;
-        if (grp_rows) dp = ldx8(dout, (long long)(((unsigned)i * 8u / (unsigned)C) / (unsigned)grp_rows) * C + c, false, 0);
-        else dp = ldx8(dout, i * 8, hm & 1, 0);
+        if constexpr ((HM & 1) != 0) dp = ldx8(dout, i * 8, true, 0);
+        else dp = ldx8(dout, grp_rows ? (long long)(((unsigned)i * 8u / (unsigned)C) / (unsigned)grp_rows) * C + c : i * 8, false, 0);   // (a select, not a branch)
         if (relu) gate8(dp, mask[i]);
         const f32x8 sc_a = ldv8(va + 2 * C, c);
         f32x8 ga = dp;
@@ -693,15 +699,26 @@ static int bn_act_impl(const float* a, const float* vec_a, const float* b, const
         const long long n8 = n4 / 2;
         const int hm8 = hm | (o16 ? 4 : 0);
         dim3 g8(stream_blocks(n8));
-#define FGCN_BN_ACT8(RES_)                                                                                                           \
+#define FGCN_BN_ACT8H(RES_, HM_)                                                                                                     \
     do {                                                                                                                             \
-        if (sign_mask) hipLaunchKernelGGL((bn_act8_kernel<RES_, true>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str, hm8); \
-        else hipLaunchKernelGGL((bn_act8_kernel<RES_, false>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str, hm8);          \
+        if (sign_mask) hipLaunchKernelGGL((bn_act8_kernel<RES_, true, HM_>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str); \
+        else hipLaunchKernelGGL((bn_act8_kernel<RES_, false, HM_>), g8, blk, 0, s, a, vec_a, b, vec_b, out, sign_mask, n8, C, relu, str);          \
+    } while (0)
+#define FGCN_BN_ACT8(RES_)                                                                                                           \
+    do switch (RES_ == 0 ? (hm8 & ~2) : hm8) {                                                                                       \
+        case 1: FGCN_BN_ACT8H(RES_, 1); break;                                                                                       \
+        case 2: FGCN_BN_ACT8H(RES_, 2); break;                                                                                       \
+        case 3: FGCN_BN_ACT8H(RES_, 3); break;                                                                                       \
+        case 4: FGCN_BN_ACT8H(RES_, 4); break;                                                                                       \
+        case 5: FGCN_BN_ACT8H(RES_, 5); break;                                                                                       \
+        case 6: FGCN_BN_ACT8H(RES_, 6); break;                                                                                       \
+        default: FGCN_BN_ACT8H(RES_, 7); break;                                                                                      \
     } while (0)
         if (res_mode == 0) FGCN_BN_ACT8(0);
         else if (res_mode == 1) FGCN_BN_ACT8(1);
         else FGCN_BN_ACT8(2);
 #undef FGCN_BN_ACT8
+#undef FGCN_BN_ACT8H
         return launch_status("bn_act");
     }
 #define FGCN_BN_ACT4(RES_, M_, O_, TY_) \
@@ -752,18 +769,34 @@ static int bn_act_bwd_reduce_impl(const float* dout, const float* out, const uns
                  fgcn_elem_tiles(rows));
     dim3 blk;
     FGCN_REQUIRE(reduce_block(C, &blk) == 0, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d unsupported", C);
-    const size_t lds = (size_t)blk.y * 3 * blk.x * 4 * sizeof(float);
+    const size_t lds = (size_t)blk.y * 3 * blk.x * 4 * sizeof(float) * ((hm && (fgcn::tuning(26) & 1)) ? 2 : 1);
     FGCN_REQUIRE(lds <= 64 * 1024, FGCN_E_BADARG, "bn_act_bwd_reduce: C=%d needs too much LDS", C);
     const long long rpt = rows_per_tile_for(rows);
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)n_tiles, (unsigned)cdiv(C, (int)blk.x * 4));
     if (hm && C % 8 == 0 && ld_dout == C && blk.x % 2 == 0) {
         // typed operands: eight channels per thread, the same rows per thread as the four-wide kernel (same sums, bit for bit)
-        const dim3 blk8(blk.x / 2, blk.y);
-        if (res_mode == 2)
-            hipLaunchKernelGGL((bn_act_bwd_reduce8_kernel<2>), g, blk8, lds, s, dout, sign_mask, a, vec_a, b, vec_b, partials, rows, rpt, C, relu, grp_rows, hm);
-        else
-            hipLaunchKernelGGL((bn_act_bwd_reduce8_kernel<0>), g, blk8, lds, s, dout, sign_mask, a, vec_a, b, vec_b, partials, rows, rpt, C, relu, grp_rows, hm);
+        const dim3 blk8(blk.x / 2, (fgcn::tuning(26) & 1) ? blk.y * 2 : blk.y);      // (key 26 bit 0, A/B: 256 threads -- other sums in the last bits)
+#define FGCN_BN_RED8(RES_, HM_) \
+    hipLaunchKernelGGL((bn_act_bwd_reduce8_kernel<RES_, HM_>), g, blk8, lds, s, dout, sign_mask, a, vec_a, b, vec_b, partials, rows, rpt, C, relu, grp_rows)
+        if (res_mode == 2) {
+            switch (hm) {
+                case 1: FGCN_BN_RED8(2, 1); break;
+                case 2: FGCN_BN_RED8(2, 2); break;
+                case 3: FGCN_BN_RED8(2, 3); break;
+                case 4: FGCN_BN_RED8(2, 4); break;
+                case 5: FGCN_BN_RED8(2, 5); break;
+                case 6: FGCN_BN_RED8(2, 6); break;
+                default: FGCN_BN_RED8(2, 7); break;
+            }
+        } else {
+            switch (hm & 3) {
+                case 1: FGCN_BN_RED8(0, 1); break;
+                case 2: FGCN_BN_RED8(0, 2); break;
+                default: FGCN_BN_RED8(0, 3); break;
+            }
+        }
+#undef FGCN_BN_RED8
         return launch_status("bn_act_bwd_reduce");
     }
 #define FGCN_BN_RED3(RES_, M_, TY_)                                                                                \
@@ -810,13 +843,32 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
         const int hm8 = hm | (o16 ? 8 : 0);
         dim3 g8(stream_blocks(n8));
         const int rm = (res_mode == 0 || !db) ? 0 : res_mode;
+#define FGCN_BN_APP8H(RES_, HM_)                                                                                                          \
+    hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, relu, train, \
+                       inv_m, db_accumulate, str, grp_rows)
 #define FGCN_BN_APP8(RES_)                                                                                                                \
-    hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, relu, train, \
-                       inv_m, db_accumulate, str, grp_rows, hm8)
+    do switch (RES_ == 2 ? hm8 : (hm8 & ~4)) {                                                                                            \
+        case 1: FGCN_BN_APP8H(RES_, 1); break;                                                                                            \
+        case 2: FGCN_BN_APP8H(RES_, 2); break;                                                                                            \
+        case 3: FGCN_BN_APP8H(RES_, 3); break;                                                                                            \
+        case 4: FGCN_BN_APP8H(RES_, 4); break;                                                                                            \
+        case 5: FGCN_BN_APP8H(RES_, 5); break;                                                                                            \
+        case 6: FGCN_BN_APP8H(RES_, 6); break;                                                                                            \
+        case 7: FGCN_BN_APP8H(RES_, 7); break;                                                                                            \
+        case 8: FGCN_BN_APP8H(RES_, 8); break;                                                                                            \
+        case 9: FGCN_BN_APP8H(RES_, 9); break;                                                                                            \
+        case 10: FGCN_BN_APP8H(RES_, 10); break;                                                                                          \
+        case 11: FGCN_BN_APP8H(RES_, 11); break;                                                                                          \
+        case 12: FGCN_BN_APP8H(RES_, 12); break;                                                                                          \
+        case 13: FGCN_BN_APP8H(RES_, 13); break;                                                                                          \
+        case 14: FGCN_BN_APP8H(RES_, 14); break;                                                                                          \
+        default: FGCN_BN_APP8H(RES_, 15); break;                                                                                          \
+    } while (0)
         if (rm == 0) FGCN_BN_APP8(0);
         else if (rm == 1) FGCN_BN_APP8(1);
         else FGCN_BN_APP8(2);
 #undef FGCN_BN_APP8
+#undef FGCN_BN_APP8H
         return launch_status("bn_act_bwd_apply");
     }
 #define FGCN_BN_APP4(RES_, M_, O_, TY_)                                                                            \
