@@ -648,6 +648,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
                 and (cfg.static_adjacency or (emb_tile_bwd and S["emb"] is not None and S["emb"].dtype == torch.bfloat16))
                 and (not gate_in_dagg or (dg16 and (d_o.dtype == torch.bfloat16 or (pool is not None and o_.pool_backward_rows)))))
     dg16 = dg16 and (dx16 or not gate_in_dagg)       # (a gated addend has dx's storage type: the fused backward adds it)
+    x_h = x                                  # the input as it arrived: the weight-gradient tile kernels take a bfloat16 x beside a bfloat16 dy / emb
     if x16 and not dx16:
         x = x.float()                        # (the kernels of this block's remaining paths read float32)
     dx = torch.empty((B, T, V, cx), device=dev, dtype=torch.bfloat16) if dx16 else new(B, T, V, cx)
@@ -741,7 +742,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     if wgrad_tile:
-        gw = ops.spatial_wgrad_tile(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))        # agg on chip, whole frame tiles
+        gw = ops.spatial_wgrad_tile(x_h if dy.dtype == torch.bfloat16 else x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))   # agg on chip, whole frame tiles
     elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.get("fused_agg_wgrad_max_cout", ops.get_math_mode()):
         # agg = x . A^ is formed in registers and contracted with dy at once: never written
         gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
@@ -775,7 +776,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         if emb_tile_bwd:
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
-            gw, gb = ops.emb_wgrad_tile(emb, x, d_s, ic=ic)
+            gw, gb = ops.emb_wgrad_tile(emb, x_h if emb.dtype == torch.bfloat16 else x, d_s, ic=ic)
             gw = gw.view(6 * ic, cin_true, 1, 1)
         else:
             if emb.dtype != torch.float32:       # (cannot happen: the forward asked the same predicate before it chose the storage)
