@@ -54,14 +54,16 @@ MATH_DTYPE = {
     "f32": "f32",
     "bf16x3": "f32 (products from exact 3-way bf16 splits of both operands: 6 bf16 MFMAs per product group, f32 accumulate; "
               "f32 storage / statistics; same parity tolerances as the f32 MFMA path)",
-    "bf16": "bf16 MFMA operands, f32 accumulate / storage / statistics",
+    "bf16": "bf16 MFMA operands and bf16 storage of the activation-sized tensors (the reference's autocast semantics; paths.half_activations), "
+            "f32 accumulate / BatchNorm statistics / softmax",
     "f16x2": "f32 (bf16x3, with the temporal and 1x1 convolutions' products from block-scaled 2-way f16 splits of both operands: 3 f16 "
              "MFMAs per product group, f32 accumulate; f32 storage / statistics; same parity tolerances as the f32 MFMA path)"}
-MATH_DTYPE_SHORT = {"f32": "f32", "bf16x3": "f32 (products from exact 3-way bf16 splits; see notes.dtype)", "bf16": "bf16 operands, f32 accumulate",
+MATH_DTYPE_SHORT = {"f32": "f32", "bf16x3": "f32 (products from exact 3-way bf16 splits; see notes.dtype)", "bf16": "bf16 operands and activation storage, f32 accumulate",
                     "f16x2": "f32 (products from block-scaled 2-way f16 splits; see notes.dtype)"}
-MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_kernel<{nt},3> (bf16 operands)",
+MATH_KERNEL = {"f32": "conv_halo_kernel<{nt},3>", "bf16": "conv_halo_x3k32_kernel<{nt2},32,1> (one bf16 part)",
                "bf16x3": "conv_halo_x3k32_kernel<{nt2},32>", "f16x2": "conv_halo_x3k32_kernel<{nt2},32,2> (f16x2 products)"}
 PEAK_HBM_GBPS = 8000.0            # spec; ~6300 achievable
+ACHIEVABLE_HBM_GBPS = 6300.0
 SHAPE = dict(N=64, M=2, T=300, V=25, C=3, classes=60)
 
 
@@ -765,8 +767,13 @@ def main():
             "mfma_f32": round(flops / (elapsed / args.steps) / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "mfma_of_this_math_mode": round(flops / (elapsed / args.steps) / world / (MATH_PEAK[args.math] * 1e12), 4),
             "hbm": round(byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4),
+            # ... against the rate a streaming kernel reaches on this part (MI355X_MICROARCH.md: ~6.3 TB/s of the 8.0 TB/s spec)
+            "hbm_of_achievable_6300": round(byts / (elapsed / args.steps) / world / (ACHIEVABLE_HBM_GBPS * 1e9), 4),
             "algorithmic_gflop_per_clip": round(flops / n_global / 1e9, 2),
             "algorithmic_mb_per_clip": round(byts / n_global / 1e6, 2)}
+        if args.math == "bf16":      # the activation-sized tensors of this mode are two bytes wide: SURVEY 8d's byte count halves
+            out["step_fractions"]["hbm_bf16_storage"] = round(0.5 * byts / (elapsed / args.steps) / world / (PEAK_HBM_GBPS * 1e9), 4)
+            out["step_fractions"]["algorithmic_mb_per_clip_bf16_storage"] = round(0.5 * byts / n_global / 1e6, 2)
         notes = {}
         roofline_detail = None
         if kern:
