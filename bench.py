@@ -416,6 +416,8 @@ def main():
                          "config 5 (bf16 MFMA operands, f32 accumulation)")
     ap.add_argument("--no-f32-mode", action="store_true",
                     help="N = 1 only: skip the secondary timing of the exact-f32-MFMA mode (f32_mfma_mode)")
+    ap.add_argument("--no-bf16-mode", action="store_true",
+                    help="N = 1 only: skip the secondary timing of BASELINE config 5 (math mode bf16: bf16 operands and activation storage; modes.bf16_config5)")
     ap.add_argument("--no-f16x2-mode", action="store_true",
                     help="N = 1 only: skip the secondary timing of the f16x2 products (f16x2_mode)")
     ap.add_argument("--verify-dp", action="store_true",
@@ -712,6 +714,17 @@ def main():
                                              "frac": round(kern_h[0]["tflops"] / PEAK_SPLIT2H_TFLOPS, 4)}
         _ops.set_math_mode(args.math)
         del step_h
+    bf16_mode = None
+    if world == 1 and args.math == "bf16x3" and not args.no_bf16_mode and SHAPE["V"] == 25:
+        # BASELINE config 5 on the same model and batch: bf16 MFMA operands AND bf16 storage of the activation-sized tensors (the reference's
+        # autocast semantics, DESIGN.md section 3.14 b / g) -- a different numerical contract, reported beside the headline
+        _ops.set_math_mode("bf16")
+        step_b, mode_b = make_step(x, y)
+        el_b, loss_b = timed(step_b, args.steps, args.warmup)
+        bf16_mode = {"value": round(n_global * args.steps / el_b, 2), "unit": "clips/s", "ms_per_step": round(1e3 * el_b / args.steps, 3),
+                     "loss": round(float(loss_b), 5), "launch": mode_b, "dtype": MATH_DTYPE["bf16"]}
+        _ops.set_math_mode(args.math)
+        del step_b
     inference = None
     if world == 1 and not args.no_inference and args.math in ("bf16x3", "bf16") and args.loader == "none":
         # the same model's INFERENCE forward (eval-mode BatchNorm, no autograd graph): BatchNorm + shortcut + ReLU are then the epilogues of
@@ -757,6 +770,8 @@ def main():
             modes["f32_mfma"] = {"clips_s": f32_mode["value"], "ms": f32_mode["ms_per_step"]}
         if f16x2_mode:
             modes["f16x2"] = {"clips_s": f16x2_mode["value"], "ms": f16x2_mode["ms_per_step"]}
+        if bf16_mode:
+            modes["bf16_config5"] = {"clips_s": bf16_mode["value"], "ms": bf16_mode["ms_per_step"]}
         if modes:
             out["modes"] = modes
         if inference:
@@ -832,6 +847,8 @@ def main():
             out["f32_mfma_mode"] = f32_mode
         if f16x2_mode:
             out["f16x2_mode"] = f16x2_mode
+        if bf16_mode:
+            out["bf16_mode"] = bf16_mode
         if roofline_detail:
             out["roofline_all_widths"] = roofline_detail
         notes["dtype"] = MATH_DTYPE[args.math]

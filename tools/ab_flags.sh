@@ -5,7 +5,7 @@
 FLAGS=""
 if [ "$1" = "-f" ]; then FLAGS="$2"; shift 2; fi
 mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/ab_flags.log
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference --no-live-traffic $FLAGS"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference --no-live-traffic $FLAGS"
 for rep in 1 2; do
 for t in "$@"; do
     echo "== [$t]" >> gpurun_out/ab/ab_flags.log

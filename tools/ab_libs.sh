@@ -3,7 +3,7 @@
 # ("-" = the tree's own build).  Every build runs the 64-clip and the 8-clip step, interleaved, <reps> times.
 out=$1; reps=$2; shift 2
 mkdir -p $(dirname $out); : > $out
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference"
 for rep in $(seq $reps); do
   for spec in "$@"; do
     name=${spec%%=*}; lib=${spec#*=}

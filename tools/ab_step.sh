@@ -2,7 +2,7 @@
 # Same-box A/B of the whole step between the baseline build (tools/probes/libfgcn_alt.so via FGCN_LIB) and the tree's build:
 #   tools/ab_step.sh "<bench args>" ...
 mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/abl.log
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference"
 for rep in 1 2; do
 for t in "$@"; do
   for which in base new; do

@@ -8,7 +8,7 @@ tag=${1:-r03}; shift || true
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-SER="--steps 3 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference --no-graph"
+SER="--steps 3 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference --no-graph"
 # 1. whole step, every kernel on one stream (true per-kernel durations), 64 clips and the 8-clip shard
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o step_serial -- python3 bench.py $SER "$@" > $out/step_serial.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o step8_serial -- python3 bench.py $SER --batch 8 "$@" > $out/step8_serial.log 2>&1
@@ -20,8 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out -o pmc_wri
 # 4. matrix-pipe occupancy
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out -o pmc_mfma -- python3 bench.py --kernel-only "$@" > $out/pmc_mfma.log 2>&1
 # 5. HBM-side traffic of the WHOLE step, per kernel (tools/step_traffic.py)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out -o step_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference --no-graph "$@" > $out/step_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out -o step_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference --no-graph "$@" > $out/step_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out -o step_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference --no-graph "$@" > $out/step_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out -o step_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference --no-graph "$@" > $out/step_write.log 2>&1
 python3 tools/step_traffic.py $(find $out -name "step_fetch_counter_collection.csv") $(find $out -name "step_write_counter_collection.csv") 3 \
     "HBM-side traffic per launch of every kernel of the 64-clip step ($tag $*): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two runs) -- python3 bench.py --steps 2 --warmup 1 --no-graph" > $out/step_traffic_by_kernel.txt
 find $out -name "*.csv" | head -40

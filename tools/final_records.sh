@@ -7,7 +7,7 @@ tag=${1:-r06}; part=${2:-a}
 out=gpurun_out/final_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-kernel-timing --no-inference --no-live-traffic"
+Q="--no-cpu-baseline --no-f32-mode --no-f16x2-mode --no-bf16-mode --no-kernel-timing --no-inference --no-live-traffic"
 if [ "$part" = "a" ]; then
     python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
     echo "bench: $(python3 -c "import json; d=json.load(open('$out/bench.json')); print(d['value'], d['ms_per_step'])")"
