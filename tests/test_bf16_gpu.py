@@ -572,7 +572,7 @@ def h16(*shape, seed=0, scale=1.0):
     return gpu(rnd(*shape, seed=seed, scale=scale)).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("rows,C,res", [(1000, 64, 0), (777, 128, 1), (2048, 256, 2), (50, 8, 1), (600, 64, 2)])
+@pytest.mark.parametrize("rows,C,res", [(1000, 64, 0), (777, 128, 1), (2048, 256, 2), (50, 8, 1), (600, 64, 2), (1000, 12, 1), (500, 20, 2)])   # (C % 8 != 0: the four-wide typed kernels)
 def test_batchnorm_passes_with_bfloat16_operands(rows, C, res):
     """fgcn_bn_act_t / fgcn_bn_act_pool_t / fgcn_bn_act_bwd_reduce_t / fgcn_bn_act_bwd_apply_t with a, the shortcut and the incoming
     gradient as bfloat16 tensors, in every combination the block produces, against the float32 entry points on the same values."""
