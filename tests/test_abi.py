@@ -62,6 +62,20 @@ def test_host_side_validation(lib):
     assert lib.fgcn_bn_act_bwd_reduce(p16, p16, None, p16, p16, None, None, p16, 7, 1000, 64, 0, 1, None) == -1   # needs 16 tiles
     assert lib.fgcn_elem_tiles(1000) == 16 and lib.fgcn_elem_tiles(10 ** 7) == 1024 and lib.fgcn_rows_gemm_tiles(129) == 2
     assert lib.fgcn_spatial_tiles(128, 300) == 128 * 10
+    # typed entry points (half-precision activation storage): a mask the kernel is not built for, and bfloat16 tensors outside math mode bf16
+    assert lib.fgcn_bn_act_t(p16, p16, None, None, p16, None, 16, 8, 0, 1, 8, None) == -1                  # bit 3 does not exist
+    assert b"half_mask" in lib.fgcn_last_error()
+    assert lib.fgcn_tconv_halo_t(p16, p16, p16, None, None, 1, 4, 25, 32, 32, 32, 32, 4, 1, 0, 4, 4, 1, 0, 9, 1, -4, 2, None) == -1   # out without in
+    assert lib.fgcn_spatial_bwd_tile_t(p16, p16, p16, p16, p16, p16, 1, 4, 25, 64, 64, 64, 64, 64, 1, 0, None, 0, None, None, None, 2, None) == -1
+    assert lib.fgcn_emb_dx_tile_t(p16, p16, p16, p16, p16, 1, 4, 25, 16, 64, 96, 64, 1, 0, 2, None) == -1
+    mode = lib.fgcn_get_math_mode()
+    lib.fgcn_set_math_mode(2)          # bf16x3: bfloat16 tensors are refused before anything is launched
+    try:
+        assert lib.fgcn_bn_act_t(p16, p16, None, None, p16, None, 16, 8, 0, 1, 1, None) == -1
+        assert b"math mode bf16" in lib.fgcn_last_error()
+        assert lib.fgcn_bn_act_bwd_apply_t(p16, 0, None, p16, p16, p16, None, None, p16, p16, None, 16, 8, 0, 1, 1, 0, 3, None) == -1
+    finally:
+        lib.fgcn_set_math_mode(mode)
 
 
 def test_tile_kernel_geometry_and_tuning_keys(lib):
