@@ -431,7 +431,8 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         emb, c_mat = None, None
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
-        if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
+        if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and ic <= o_.get("emb_fwd_tile_max_ic", ops.get_math_mode())
+                and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
             # emb written once, the gram from the tile on chip (inference: not written at all -- only the backward reads it)
             half_emb = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_))

@@ -70,6 +70,11 @@ class PathOptions:
     emb_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
     emb_fwd_tile: bool = True
     emb_fwd_tile_max_cin: Dict[str, int] = field(default_factory=lambda: {"f32": 128, "bf16": 256, "bf16x3": 128, "f16x2": 128})
+    # ... and up to this many embedding channels per group (ic = out_channels / 4): at ic = 64 a workgroup holds theta_k | phi_k of ONE subset and x
+    # is read three times -- the 128 -> 256 block's forward measures 0.587 ms in tile form against 0.431 ms for the 1x1 product + gram
+    # (tools/kbench.py emb_fwd, bf16x3); in the step 53.13 / 52.97 -> 52.92 / 52.89 ms (bf16x3), 46.34 -> 46.15 / 46.25 (f16x2); in `bf16` the tile form
+    # wins there by 1 ms (26.45 -> 27.5 ms without it): profiles/r06_ab_emb_fwd_tile_max_ic.txt
+    emb_fwd_tile_max_ic: Dict[str, int] = field(default_factory=lambda: {"f32": 32, "bf16": 64, "bf16x3": 32, "f16x2": 32})
     # -- math mode bf16 (BASELINE config 5): half-precision STORAGE of the tensors that only bf16 MFMA staging reads -- G (the temporal conv's
     # input), dU (the gradient of its output) and dY (the gradient of the spatial stage's output) are written as bfloat16 by the BatchNorm
     # passes that produce them and copied by their consumers (include/fgcn.h, the `_h` entry points).  Bit-identical to f32 storage (the bf16 kernels round these tensors to bfloat16
