@@ -431,13 +431,13 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         emb, c_mat = None, None
         _, a_hat = ops.adj_softmax_fwd(None, 1.0, adj_a, 1, use_softmax=False, adj_b=adj_b)
     else:
-        if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and ic <= o_.get("emb_fwd_tile_max_ic", ops.get_math_mode())
+        no_emb = bool(inference and not train and o_.fused_inference)      # inference: the tile form writes no embeddings at all -- it stays at every ic
+        if (o_.emb_fwd_tile and cin <= o_.get("emb_fwd_tile_max_cin", ops.get_math_mode()) and (no_emb or ic <= o_.get("emb_fwd_tile_max_ic", ops.get_math_mode()))
                 and "emb_b3" in W and ops.emb_fwd_tile_available(V, ic, cin)
                 and B * T * V * max(cin, 6 * ic) * 4 < 0x7FFF0000):
             # emb written once, the gram from the tile on chip (inference: not written at all -- only the backward reads it)
             half_emb = bool(train and ops.get_math_mode() == "bf16" and o_.get("half_storage", "bf16") and emb_bwd_tile_ok(W, cfg, B, T, V, cx, o_))
-            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic, write_emb=not (inference and not train and o_.fused_inference),
-                                         emb_bf16=half_emb)
+            emb, part = ops.emb_fwd_tile(x, W["emb_b3"], W["emb_b"], ic=ic, write_emb=not no_emb, emb_bf16=half_emb)
         else:
             emb = new(B, T, V, 6 * ic)
             S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
