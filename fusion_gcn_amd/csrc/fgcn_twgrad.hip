@@ -495,7 +495,9 @@ static bool twgrad_use_x3(int N, int chunk_mode) {
 // bit 7 = no circular window.  In the step the wave counts of the tap kernels are within the run-to-run noise of each other.)
 static int twgrad_x3_waves(int N, int chunk_mode) {
     if (chunk_mode) return (fgcn::tuning(6) & 32) ? 8 : 4;
-    if (N > 64) return (fgcn::tuning(6) & 64) ? 8 : 4;
+    // (FGCN_MATH_BF16: with a sixth of the matrix work per staged row the tap kernels above 64 columns are faster on 8 waves -- 26.67 -> 26.50 ms per
+    // step, profiles/r06_ab_bf16_half_activations.txt; bit 6 flips the choice in either mode)
+    if (N > 64) return (((fgcn::tuning(6) & 64) != 0) != (fgcn::math_mode() == FGCN_MATH_BF16)) ? 8 : 4;
     return (fgcn::tuning(6) & 256) ? 4 : 8;
 }
 static int twgrad_parts(int N, int chunk_mode) {
