@@ -258,8 +258,9 @@ static EfGeom ef_geom(int B, int T, int V, int ic) {
     g.F = 128 / V;
     g.tiles_t = (int)cdiv(T, g.F);
     g.ncol = ic == 64 ? 3 : 1;
-    // resident workgroups: two per CU; tuning key 22 overrides the target
-    const int slots = fgcn::tuning(22) > 0 ? fgcn::tuning(22) : 512;
+    // resident workgroups: two per CU (FGCN_MATH_BF16: twice as many, shorter segments -- the one-part kernel's tiles are too short to cover a
+    // workgroup's prologue: 26.47 -> 26.34 ms per bf16 step); tuning key 22 overrides the target
+    const int slots = fgcn::tuning(22) > 0 ? fgcn::tuning(22) : (fgcn::math_mode() == FGCN_MATH_BF16 ? 1024 : 512);
     const int want = std::max(1, slots / (B * g.ncol));              // segments per sample
     g.tps = (int)cdiv(g.tiles_t, std::min(g.tiles_t, want));
     g.nseg = (int)cdiv(g.tiles_t, g.tps);
