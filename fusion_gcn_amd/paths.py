@@ -50,7 +50,9 @@ class PathOptions:
     # -- BatchNorm-backward sums of the graph convolution in the temporal data gradient's epilogue, up to this many channels
     # (bf16x3: neutral, round 4; `bf16`: the epilogue's dword loads of y and the sign image cost the now six times shorter conv more than
     # the stand-alone reduction pass takes -- profiles/r06_ab_bf16_paths.txt: 36.46 / 36.06 -> 35.01 / 35.05 ms with the pass)
-    bn_sums_in_dgrad: Dict[str, bool] = field(default_factory=lambda: {"f32": True, "bf16": False, "bf16x3": True, "f16x2": True})
+    # (f16x2, re-measured with round 6's reduce kernel -- four rows of loads in flight: 46.46 / 46.54 -> 46.22 / 46.26 ms with the pass; bf16x3 still neutral,
+    # 53.02 / 53.07 vs 53.06 / 53.01: profiles/r06_ab_bf16x3_paths.txt)
+    bn_sums_in_dgrad: Dict[str, bool] = field(default_factory=lambda: {"f32": True, "bf16": False, "bf16x3": True, "f16x2": False})
     bn_sums_max_c: int = 4096
     # -- identity-shortcut gradients added by the kernel that forms the spatial term of dx: neutral in joint_dagg (off), 55.31 / 55.37 ->
     # 55.20 / 55.20 ms in the fused backward (profiles/r04_ab_gated_tile.txt)
