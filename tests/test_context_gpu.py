@@ -84,7 +84,7 @@ def test_path_options_are_per_context_without_a_gpu():
                                   "bn_sums_in_dgrad.bf16x3=0, emb_tile_max_cin.bf16=64")
     assert (not o.emb_tile and set(o.spatial_tile_min_cout.values()) == {64} and o.fuse_g and o.mix_vw_order == (1, 2)
             and set(o.fused_agg_wgrad_max_cout.values()) == {256} and o.get("bn_sums_in_dgrad", "bf16x3") is False
-            and o.get("bn_sums_in_dgrad", "f16x2") is True and o.emb_tile_max_cin == {"f32": 128, "bf16": 64, "bf16x3": 128, "f16x2": 128})
+            and o.get("bn_sums_in_dgrad", "f32") is True and o.emb_tile_max_cin == {"f32": 128, "bf16": 64, "bf16x3": 128, "f16x2": 128})
     assert PathOptions().get("bn_sums_in_dgrad", "bf16") is False and PathOptions().get("spatial_tile_min_cout", "bf16") == 64
     with pytest.raises(ValueError, match="no entry for math mode"):
         PathOptions().update_from("emb_tile.bf16=0")
