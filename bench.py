@@ -129,6 +129,8 @@ def time_dominant_kernel(device, b_local: int, reps: int = 10, widths=(64, 128, 
         x = torch.randn(b_local, t, SHAPE["V"], c, device=device)
         w4 = ops.pack_conv(torch.randn(9, c, c, device=device) * (9 * c) ** -0.5)   # the current math mode's form
         bias = torch.randn(c, device=device)
+        if ops.get_math_mode() == "bf16" and ops.paths().get("half_activations", "bf16"):
+            x = x.to(torch.bfloat16)        # the form the step launches in this mode: bfloat16 G in, bfloat16 U out (fgcn_tconv_halo_t)
         y = torch.empty_like(x)
 
         def launch():
@@ -143,7 +145,7 @@ def time_dominant_kernel(device, b_local: int, reps: int = 10, widths=(64, 128, 
         end.synchronize()
         ms = start.elapsed_time(end) / reps
         flops = 2.0 * b_local * t * SHAPE["V"] * 9 * c * c
-        byts = 4.0 * b_local * t * SHAPE["V"] * 2 * c
+        byts = float(x.element_size()) * b_local * t * SHAPE["V"] * 2 * c
         out.append(dict(channels=c, frames=t, ms=ms, flops=flops, bytes=byts, tflops=flops / ms / 1e9))
     return out
 
