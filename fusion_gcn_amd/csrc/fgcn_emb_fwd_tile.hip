@@ -145,10 +145,18 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
 #pragma unroll
     for (int k = 0; k < NSUB; ++k) gacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int RS = MU % 2 == 0 ? 2 : 3;                          // weight ring slots: a divisor of MU, so that unit 0 of the next chunk lands in slot 0
-    static_assert(MU % RS == 0, "ring");
+    // weight ring slots: a divisor of MU, so that unit 0 of the next chunk lands in slot 0; fragments are requested WD units ahead.  One part
+    // (FGCN_MATH_BF16): one MFMA per fragment and row tile instead of six -- one unit ahead leaves the L2 latency exposed (fgcn_tconv.hip,
+    // FGCN_HALO_RING_NP1): a deeper ring there
+#ifndef FGCN_EF_RING_NP1
+#define FGCN_EF_RING_NP1 1
+#endif
+    constexpr int RS = (NP == 1 && FGCN_EF_RING_NP1) ? (MU % 4 == 0 ? 4 : 3) : (MU % 2 == 0 ? 2 : 3);
+    constexpr int WD = (NP == 1 && FGCN_EF_RING_NP1) ? RS - 1 : 1;
+    static_assert(MU % RS == 0 && WD < RS && WD <= MU, "ring");
     u32x4v wq[RS][NP];
-    load_w(wq[0], 0, 0);
+#pragma unroll
+    for (int d = 0; d < WD; ++d) load_w(wq[d], d, 0);
     fetch(tile_lo, 0);
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
         const int t0 = tile * F;
@@ -172,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void emb_fwd_tile_kernel(EmbFwP p) {
             for (int nt = 0; nt < NR; ++nt) load_x(xf[nt], nt);
 #pragma unroll
             for (int mu = 0; mu < MU; ++mu) {
-                if (mu + 1 < MU) load_w(wq[(mu + 1) % RS], mu + 1, c);
-                else load_w(wq[0], 0, c + 1);
+                if (mu + WD < MU) load_w(wq[(mu + WD) % RS], mu + WD, c);
+                else load_w(wq[(mu + WD - MU) % RS], mu + WD - MU, c + 1);
 #pragma unroll
                 for (int nt = 0; nt < NR; ++nt) acc[mu][nt] = mfma_np_k32<NP>(wq[mu % RS], xf[nt], acc[mu][nt]);
             }

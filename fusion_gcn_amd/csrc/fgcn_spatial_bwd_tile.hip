@@ -186,7 +186,15 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     // under load -- the FGCN_PROBE_SB bit 4 probe put the exposed wait at 0.18 of 0.90 ms), across group and tile boundaries: the first
     // two steps of the NEXT group are requested before the current group's halves (gram / mix) run.
     f32x4 stg2[2][2];
-    u32x4v wq[2][NP];
+    // weight ring: three fragments per contraction step.  Three parts: two slots, requested one fragment ahead (slot = step parity + index).  One
+    // part (FGCN_MATH_BF16): four MFMAs per fragment instead of 24 leave the L2 latency exposed -- three slots (fragment i of a step always in slot
+    // i), requested two ahead (timing probe, weights free: -0.4 of the kernel's 2.8 ms per bf16 step)
+#ifndef FGCN_SB_RING_NP1
+#define FGCN_SB_RING_NP1 1
+#endif
+    constexpr bool WR3 = NP == 1 && FGCN_SB_RING_NP1 != 0;
+    constexpr int WD = WR3 ? 2 : 1;
+    u32x4v wq[WR3 ? 3 : 2][NP];
     bool probe_w_loaded = false;
     auto fetch = [&](f32x4 (&stg)[2], int tile_, int kc) {       // kc >= Cout or no such tile: nothing (branch-free)
         const int t0_ = tile_ * F;
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
     fetch(stg2[0], tile_lo, 0);
     fetch(stg2[1], tile_lo, 32);
     load_w(wq[0], 0, 0, 0);
+    if constexpr (WR3) load_w(wq[1], 1, 0, 0);
     if (FGCN_PROBE_SB & 128) {
         load_w(wq[1], 1, 0, 0);
         probe_w_loaded = true;
@@ -273,15 +282,16 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                 if (!(FGCN_PROBE_SB & 16)) fetch(stg2[PB], tile, (ks + 2) * 32);   // lands during this step's and the next one's MFMAs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) load_a(a[j], j, sb_lds);
+                auto slot = [](int t) { return WR3 ? t % 3 : (PB + t) & 1; };    // t: fragment index counted from this step's first
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    // the next fragment: a later tile of this step, or the first one of the next step (past the last step: step 0 again, unused)
-                    if (i + 1 < 3) load_w(wq[(PB + i + 1) & 1], i + 1, ks * 32, cg);
-                    else load_w(wq[(PB + i + 1) & 1], 0, ks + 1 < nks ? (ks + 1) * 32 : 0, ks + 1 < nks ? cg : cg_n);   // (selects, not branches)
+                    // the fragment WD ahead: a later tile of this step, or one of the next step (past the last step: the next group's first step)
+                    if (i + WD < 3) load_w(wq[slot(i + WD)], i + WD, ks * 32, cg);
+                    else load_w(wq[slot(i + WD)], i + WD - 3, ks + 1 < nks ? (ks + 1) * 32 : 0, ks + 1 < nks ? cg : cg_n);   // (selects, not branches)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr ((FGCN_PROBE_SB & 4) != 0) acc[i][j][0] += __builtin_bit_cast(float, wq[(PB + i) & 1][0][0] ^ a[j][0][0]);
-                        else acc[i][j] = mfma_np_k32<NP>(wq[(PB + i) & 1], a[j], acc[i][j]);
+                        if constexpr ((FGCN_PROBE_SB & 4) != 0) acc[i][j][0] += __builtin_bit_cast(float, wq[slot(i)][0][0] ^ a[j][0][0]);
+                        else acc[i][j] = mfma_np_k32<NP>(wq[slot(i)], a[j], acc[i][j]);
                     }
                 }
             };
