@@ -192,7 +192,10 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #ifndef FGCN_SB_RING_NP1
 #define FGCN_SB_RING_NP1 1
 #endif
-    constexpr bool WR3 = NP == 1 && FGCN_SB_RING_NP1 != 0;
+#ifndef FGCN_SB_RING_NP3
+#define FGCN_SB_RING_NP3 0              // (A/B builds: the three-part kernel two ahead as well -- 12 more registers at a 251-256 register kernel)
+#endif
+    constexpr bool WR3 = (NP == 1 && FGCN_SB_RING_NP1 != 0) || (NP == 3 && FGCN_SB_RING_NP3 != 0);
     constexpr int WD = WR3 ? 2 : 1;
     u32x4v wq[WR3 ? 3 : 2][NP];
     bool probe_w_loaded = false;
