@@ -261,6 +261,7 @@ __global__ void bn_act_bwd_reduce_kernel(const float* dout, const float* out, co
                 avv[u] = ld_a(o);
                 bvv[u] = RES == 2 ? ld_b(o) : z4;
             }
+            __builtin_amdgcn_sched_barrier(0);               // (the loads of all rows first: see the eight-wide kernel)
 #pragma unroll
             for (int u = 0; u < UNR; ++u) add(dpv[u], gvv[u], avv[u], bvv[u]);
         }
@@ -494,9 +495,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
             mean_b = ldv8(vb, c);
             rstd_b = ldv8(vb + C, c);
         }
+        // without a ReLU there is no sign image: the byte is then read from `a` (any valid memory) and ignored
+        const unsigned char* mp = relu ? mask : reinterpret_cast<const unsigned char*>(a);
         // several rows in flight (all their loads first); the sums still run over the thread's rows in ascending order: same bits as one by one
         auto add = [&](f32x8 dp, int bits, f32x8 av, f32x8 bv) {
-            if (relu) gate8(dp, bits);
+            gate8(dp, relu ? bits : 0xff);               // (a select, not a branch: the sign-byte loads stay with the others)
             const f32x4 ahl = (av.lo - mean_a.lo) * rstd_a.lo, ahh = (av.hi - mean_a.hi) * rstd_a.hi;
             s1.lo += dp.lo;
             s1.hi += dp.hi;
@@ -524,16 +527,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
             for (int u = 0; u < UNR; ++u) {
                 const long long o = (r + u * ny) * C + c;
                 dpv[u] = ld_d(r + u * ny, o);
-                bits[u] = relu ? mask[o >> 3] : 0;
+                bits[u] = mp[o >> 3];                    // (unconditional: a load behind `if (relu)` would sit in a branch of its own)
                 avv[u] = ldx8(a, o, hm & 2, 0);
                 bvv[u] = RES == 2 ? ldx8(b, o, hm & 4, 0) : zero;
             }
+            __builtin_amdgcn_sched_barrier(0);               // (left alone the scheduler interleaves the rows' loads with the sums: one row in flight)
 #pragma unroll
             for (int u = 0; u < UNR; ++u) add(dpv[u], bits[u], avv[u], bvv[u]);
         }
         for (; r < r1; r += ny) {
             const long long o = r * C + c;
-            add(ld_d(r, o), relu ? mask[o >> 3] : 0, ldx8(a, o, hm & 2, 0), RES == 2 ? ldx8(b, o, hm & 4, 0) : zero);
+            add(ld_d(r, o), mp[o >> 3], ldx8(a, o, hm & 2, 0), RES == 2 ? ldx8(b, o, hm & 4, 0) : zero);
         }
     }
     float* mine = red + (long long)threadIdx.y * 3 * Cw;
@@ -555,23 +559,30 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
 }
 
 // HM: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da` (db: float32)
-template <int RES, int HM>
+// TRAIN (compile time) and the unconditional sign-image load keep every load of a thread in ONE basic block: with `if (relu)` / `if (train)`
+// around them the kernel made three memory round trips per thread, one after the other (dout; the sign byte; a and the vectors)
+template <int RES, int HM, bool TRAIN>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va,
                                                                 const float* b, const float* vb, const float* sums, float* da, float* db,
-                                                                long long n8, int C, int relu, int train, float inv_m, int db_accumulate,
+                                                                long long n8, int C, int relu, float inv_m, int db_accumulate,
                                                                 int stream, int grp_rows) {
     constexpr int hm = HM;
+    constexpr bool train = TRAIN;
+    const unsigned char* mp = relu ? mask : reinterpret_cast<const unsigned char*>(dout);     // (no ReLU: any valid byte, ignored)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(((unsigned)i * 8u) % (unsigned)C);
         f32x8 dp;
         if constexpr ((HM & 1) != 0) dp = ldx8(dout, i * 8, true, 0);
         else dp = ldx8(dout, grp_rows ? (long long)(((unsigned)i * 8u / (unsigned)C) / (unsigned)grp_rows) * C + c : i * 8, false, 0);   // (a select, not a branch)
-        if (relu) gate8(dp, mask[i]);
+        const int bits = mp[i];
+        f32x8 av{dp.lo, dp.hi};
+        if constexpr (TRAIN) av = ldx8(a, i * 8, hm & 2, 0);
+        gate8(dp, relu ? bits : 0xff);                   // (a select: behind `if (relu)` the compiler sinks the sign-byte load into the branch)
         const f32x8 sc_a = ldv8(va + 2 * C, c);
         f32x8 ga = dp;
         f32x8 s0, s1;
-        if (train) {
-            const f32x8 av = ldx8(a, i * 8, hm & 2, 0), mean = ldv8(va, c), rstd = ldv8(va + C, c);
+        if constexpr (TRAIN) {
+            const f32x8 mean = ldv8(va, c), rstd = ldv8(va + C, c);
             s0 = ldv8(sums, c);
             s1 = ldv8(sums + C, c);
             ga.lo = dp.lo - s0.lo * inv_m - ((av.lo - mean.lo) * rstd.lo) * (s1.lo * inv_m);
@@ -864,8 +875,12 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
         dim3 g8(stream_blocks(n8));
         const int rm = (res_mode == 0 || !db) ? 0 : res_mode;
 #define FGCN_BN_APP8H(RES_, HM_)                                                                                                          \
-    hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, relu, train, \
-                       inv_m, db_accumulate, str, grp_rows)
+    do {                                                                                                                                  \
+        if (train) hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_, true>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, \
+                                      relu, inv_m, db_accumulate, str, grp_rows);                                                         \
+        else hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_, false>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C,      \
+                                relu, inv_m, db_accumulate, str, grp_rows);                                                               \
+    } while (0)
 #define FGCN_BN_APP8(RES_)                                                                                                                \
     do switch (RES_ == 2 ? hm8 : (hm8 & ~4)) {                                                                                            \
         case 1: FGCN_BN_APP8H(RES_, 1); break;                                                                                            \
