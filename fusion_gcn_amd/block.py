@@ -441,7 +441,7 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
         else:
             emb = new(B, T, V, 6 * ic)
             S["x_amax"] = f16x2 and pw_routed(W, "emb", x, cin)
-            pw_gemm(x32(), W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
+            pw_gemm(x, W, "emb", emb, K=cin, N=6 * ic, bias=W["emb_b"], amax_out=amax[0:1] if S["x_amax"] else None)
             part = ops.joint_gram(emb, emb, [(2 * k * ic, (2 * k + 1) * ic, ic) for k in range(NUM_SUBSETS)])
         c_mat, a_hat = ops.adj_softmax_fwd(part, 1.0 / (ic * T), adj_a, B, adj_b=adj_b)
     S.update(emb=emb, c_mat=c_mat, a_hat=a_hat)
@@ -477,8 +477,9 @@ def block_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], bufs: Dict[str, t
     kt = P["tcn1.conv.weight"].shape[2]
     half = half_storage_ok(W, kt, s, T, train, o_)
     if cfg.has_down:
-        d = new(B, T, V, cout)
-        part = pw_gemm(x32(), W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
+        # (paths.half_activations: the shortcut conv reads the bfloat16 x and writes a bfloat16 d -- the typed row GEMMs)
+        d = torch.empty((B, T, V, cout), device=dev, dtype=torch.bfloat16) if (ha and o_.half_shortcuts) else new(B, T, V, cout)
+        part = pw_gemm(x if (ha and o_.half_shortcuts) else x32(), W, "down", d, K=cin, N=cout, bias=P["gcn1.down.0.bias"], stats=train)
         vec_d = _bn_vec(part, B * T * V, P, bufs, "gcn1.down.1", train)
         g, g_sign = ops.bn_act(y, vec_y, d, vec_d, relu=True, sign_mask=True, out_bf16=half)
     else:
@@ -543,8 +544,9 @@ def _temporal_stage(x, g, S, P, bufs, W, cfg: BlockConfig, train: bool, pool_gro
     elif cfg.residual == "identity":
         o, o_sign = epilogue(u, vec_u, x, None)
     else:
-        r = new(B, Tp, V, cout)
-        part = ops.rows_gemm(x32(), W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
+        hs = bool(half_activations_on(train, o_) and o_.half_shortcuts)
+        r = torch.empty((B, Tp, V, cout), device=dev, dtype=torch.bfloat16) if hs else new(B, Tp, V, cout)
+        part = ops.rows_gemm(x if hs else x32(), W["res"], r, K=cin, N=cout, tmap=(1, s, 0, 0, 1), bias=P["residual.conv.bias"], stats=train)
         vec_r = _bn_vec(part, B * Tp * V, P, bufs, "residual.bn", train)
         o, o_sign = epilogue(u, vec_u, r, vec_r)
     if out_half and not pool_groups and o_sign is None:

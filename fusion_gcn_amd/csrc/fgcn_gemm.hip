@@ -41,9 +41,15 @@ struct RowsGemmP {
 // MT x NT 32x32 accumulators per wave; the four waves stack along the rows: tile = (128*MT) rows x (32*NT) channels.
 // DB = double-buffered LDS (one barrier per K chunk instead of two, at twice the LDS footprint).
 // BF: FGCN_MATH_BF16 (one bf16 MFMA per four f32 MFMAs, operands rounded as the fragments are read)
-template <int MT, int NT, bool DB, bool BF>
+// IO (BF only; the typed entry point fgcn_rows_gemm_t, half-precision activation storage): bit 0 = `in` is a BFLOAT16 tensor (its values are
+// widened into the same float32 LDS image: the fragments round them back to the same 16 bits), bit 1 = `out` is (the float32 result rounded
+// once; BatchNorm sums of the float32 values; not with accumulation; adjacent lanes pair their columns into dword stores)
+template <int MT, int NT, bool DB, bool BF, int IO = 0>
 __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kernel(RowsGemmP p) {
     constexpr int BM = 128 * MT, BK = 32, BN = 32 * NT, AS = BK + 4, NBUF = DB ? 2 : 1;
+    static_assert(IO == 0 || BF, "bfloat16 tensors: math mode bf16");
+    constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+    constexpr unsigned IS = IN16 ? 2u : 4u;            // bytes per input element
     {                                                  // batched forms: one independent problem per blockIdx.z
         const int zo = p.inner > 1 ? (int)blockIdx.z / p.inner : (int)blockIdx.z;
         const int zi = (int)blockIdx.z - zo * (p.inner > 1 ? p.inner : 1);
@@ -83,9 +89,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     const int TV = p.T_out * p.V;
     const int n_first = (int)fastdiv((unsigned)m0, p.dTV);    // 32-bit decode: host guarantees M < 2^29
     const long long in_base = (long long)n_first * p.T_in * p.V * p.ld_in;
-    const long long in_left = (p.in_elems - in_base) * 4;
+    const long long in_left = (p.in_elems - in_base) * IS;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.in + in_base), 0, (unsigned)(in_left < 0x7FFFFFFFll ? in_left : 0x7FFFFFFFll), 0x00020000);
+        (void*)(reinterpret_cast<const char*>(p.in) + in_base * IS), 0, (unsigned)(in_left < 0x7FFFFFFFll ? in_left : 0x7FFFFFFFll), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
     // the A-tile rows this thread stages: r = (tid >> 3) + 32*i
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
         const int rem = (int)(mu - (unsigned)n * (unsigned)TV);
         const int to = (int)fastdiv((unsigned)rem, p.dV);
         const int v = rem - to * p.V;
-        roff[i] = (unsigned)(((n - n_first) * p.T_in * p.V + v) * p.ld_in) * 4u;
+        roff[i] = (unsigned)(((n - n_first) * p.T_in * p.V + v) * p.ld_in) * IS;
         rto[i] = m < p.M ? to : -1;
     }
 
@@ -119,8 +125,9 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
         for (int i = 0; i < AR; ++i) {
             const int ti = rto[i] >= 0 ? tmap_src(rto[i], tap, p.ta, p.tb, p.tc, p.td, p.T_in) : -1;
             const int k = kc + k4;   // K % 4 == 0: a 16-byte group is either whole or absent
-            const unsigned off = (ti >= 0 && k < p.K) ? roff[i] + (unsigned)(ti * p.V * p.ld_in + k) * 4u : OOB;
-            areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+            const unsigned off = (ti >= 0 && k < p.K) ? roff[i] + (unsigned)(ti * p.V * p.ld_in + k) * IS : OOB;
+            if constexpr (IN16) areg[i] = unpack_bf16x4(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, off, 0, 0)));
+            else areg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
     const long long rows_left = p.M - m0;
     const unsigned tile_rows = (unsigned)(rows_left < BM ? rows_left : BM);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.out + m0 * p.ld_out), 0, tile_rows * (unsigned)p.ld_out * 4u, 0x00020000);
+        (void*)(reinterpret_cast<char*>(p.out) + m0 * p.ld_out * (OUT16 ? 2 : 4)), 0, tile_rows * (unsigned)p.ld_out * (OUT16 ? 2u : 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rbias = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.bias ? p.bias : p.w), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
     float ssum[NT], ssq[NT];
@@ -233,6 +240,26 @@ __global__ __launch_bounds__(256, (MT == 1 && !DB) ? 3 : 2) void rows_gemm_kerne
                 if (g + 1 < NG) load_old(g + 1, old[(g + 1) & 1]);
             }
             const unsigned rel0 = (unsigned)(wave * 32 * MT + mt * 32 + 4 * (lane >> 5));
+            if constexpr (OUT16 && !ACC) {
+                // two rows at a time: the even lane of a pair stores columns (c, c + 1) of row dr(r) as one dword, the odd lane those of row dr(r + 1)
+                const bool odd = lane & 1;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned dr0 = (unsigned)((r & 3) + 8 * (r >> 2));
+                    const float v0 = acc[mt][nt][r] + bvs[nt], v1 = acc[mt][nt][r + 1] + bvs[nt];
+                    const float other = lane_xor1(odd ? v0 : v1);
+                    const unsigned pk = odd ? pack_bf16x2(other, v1) : pack_bf16x2(v0, other);
+                    // (off0: the float32-form byte offset of (row rel0, this lane's column): halves, minus the odd lane's column, plus its row)
+                    const unsigned off = off0[g] == OOB ? OOB : ((off0[g] - (odd ? 4u : 0u)) >> 1) + (dr0 + (odd ? 1u : 0u)) * (rstep >> 1);
+                    __builtin_amdgcn_raw_buffer_store_b32(pk, rout, off, 0, AUX);
+                    const float k0 = (off0[g] != OOB && rel0 + dr0 < tile_rows) ? v0 : 0.f, k1 = (off0[g] != OOB && rel0 + dr0 + 1 < tile_rows) ? v1 : 0.f;
+                    ssum[nt] += k0;
+                    ssq[nt] += k0 * k0;
+                    ssum[nt] += k1;
+                    ssq[nt] += k1 * k1;
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned dr = (unsigned)((r & 3) + 8 * (r >> 2));
@@ -632,8 +659,10 @@ static int check_tmap(const fgcn_tmap& m) {
 static int rows_gemm_launch(const float* in, float* out, const float* w, const float* bias, float* stat_partials,
                             int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
                             fgcn_tmap map, int accumulate, int batch, long long in_bs, long long out_bs, long long w_bs,
-                            void* stream, int inner = 1, long long in_bs2 = 0, long long out_bs2 = 0, long long w_bs2 = 0) {
+                            void* stream, int inner = 1, long long in_bs2 = 0, long long out_bs2 = 0, long long w_bs2 = 0, int io = 0) {
     FGCN_REQUIRE(in && out && w, FGCN_E_BADARG, "rows_gemm: null pointer");
+    FGCN_REQUIRE(io == 0 || (fgcn::math_mode() == FGCN_MATH_BF16 && batch == 1 && inner == 1 && !((io & 2) && accumulate)), FGCN_E_BADARG,
+                 "rows_gemm_t: bfloat16 tensors need math mode bf16, a single problem and (for a bfloat16 output) no accumulation");
     FGCN_REQUIRE(batch >= 1 && inner >= 1 && (long long)batch * inner <= 65535 && in_bs % 4 == 0 && out_bs % 4 == 0 && w_bs % 4 == 0 &&
                      in_bs2 % 4 == 0 && out_bs2 % 4 == 0 && w_bs2 % 4 == 0,
                  FGCN_E_BADARG, "rows_gemm: batch=%d x %d / batch strides must be multiples of 4 floats", batch, inner);
@@ -696,7 +725,10 @@ static int rows_gemm_launch(const float* in, float* out, const float* w, const f
     const bool bf = fgcn::math_mode() == FGCN_MATH_BF16;
 #define FGCN_LAUNCH(MT_, NT_, DB_)                                                                         \
     do {                                                                                                   \
-        if (bf) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true>), grid, dim3(256), 0, s, p);     \
+        if (bf && io == 3) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true, 3>), grid, dim3(256), 0, s, p);      \
+        else if (bf && io == 2) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true, 2>), grid, dim3(256), 0, s, p); \
+        else if (bf && io == 1) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true, 1>), grid, dim3(256), 0, s, p); \
+        else if (bf) hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, true>), grid, dim3(256), 0, s, p); \
         else hipLaunchKernelGGL((rows_gemm_kernel<MT_, NT_, DB_, false>), grid, dim3(256), 0, s, p);       \
     } while (0)
     if (mt == 2) {
@@ -719,6 +751,16 @@ extern "C" int fgcn_rows_gemm(const float* in, float* out, const float* w, const
                               fgcn_tmap map, int accumulate, void* stream) {
     return rows_gemm_launch(in, out, w, bias, stat_partials, B, T_in, T_out, V, K, N, ld_in, ld_out, map, accumulate, 1, 0, 0, 0,
                             stream);
+}
+
+// typed form (math mode bf16, half-precision activation storage): half_mask bit 0 = `in` is a bfloat16 tensor, bit 1 = `out` is (not with accumulation);
+// strides in elements, stat_partials: the moments of the float32 results
+extern "C" int fgcn_rows_gemm_t(const void* in, void* out, const float* w, const float* bias, float* stat_partials,
+                                int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                                fgcn_tmap map, int accumulate, int half_mask, void* stream) {
+    FGCN_REQUIRE((half_mask & ~3) == 0, FGCN_E_BADARG, "rows_gemm_t: half_mask=%d", half_mask);
+    return rows_gemm_launch(static_cast<const float*>(in), static_cast<float*>(out), w, bias, stat_partials, B, T_in, T_out, V, K, N, ld_in, ld_out,
+                            map, accumulate, 1, 0, 0, 0, stream, 1, 0, 0, 0, half_mask);
 }
 
 extern "C" int fgcn_rows_gemm_batched(const float* in, float* out, const float* w, int batch, long long in_bstride,

@@ -49,9 +49,14 @@ using u32x4p = __attribute__((ext_vector_type(4))) unsigned int;
 // drained vmcnt(0) in front of EVERY group of four stores, i.e. sixteen full write round trips per tile and wave (found with the
 // FGCN_PROBE_PW timing probes: the stores cost 22 % of the kernel, the time the written bytes take at the HBM rate, with nothing
 // overlapping them).
-template <int NT, int NP, bool ACC, bool STR = false>          // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
+// IO (NP = 1; the typed entry point fgcn_pw_gemm_t, half-precision activation storage): bit 0 = `in` is a BFLOAT16 tensor (its rows are copied into
+// the image: the staged bytes of the float32 tensor of the same values), bit 1 = `out` is (not with ACC; the float32 result rounded once, BatchNorm
+// sums of the float32 values, adjacent lanes pair their columns into dword stores)
+template <int NT, int NP, bool ACC, bool STR = false, int IO = 0>          // STR: non-temporal output stores (fgcn_common.hpp, stream_out)
 __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
     static_assert(!(ACC && STR), "an accumulating epilogue stores plainly");
+    static_assert(IO == 0 || (NP == 1 && !((IO & 2) && ACC)), "bfloat16 tensors: the one-part kernel; a bfloat16 output without accumulation");
+    constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
     static_assert((NT == 1 || NT == 2) && (NP == 1 || NP == 2 || NP == 3), "64 / 128 columns; one or three bf16 parts, or two f16 parts");
     constexpr int KC = 64, XS = 2 * KC, BMR = 128, MTW = 4, NU = 2 * NT, BN = 64 * NT;
     // Weight ring: fragments are requested RS - 1 units (of 24 MFMAs) ahead.  One unit is 384 matrix cycles, less than an L2 round trip
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const long long m = (long long)bm * BMR + tid / TPR + RPP * i;
-            src_off[i] = m < p.M ? (unsigned)(m * p.ld_in * 4) + k4b : OOB;
+            src_off[i] = m < p.M ? (unsigned)(m * p.ld_in * (IN16 ? 2 : 4)) + (IN16 ? k4b >> 1 : k4b) : OOB;
         }
     };
     bool probe_first = true;
@@ -107,8 +112,15 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
         if ((FGCN_PROBE_PW & 8) && !probe_first) return;
         const bool kok = kc + k4 < p.K;                              // K % 4 == 0: a 16-byte group is whole or absent
 #pragma unroll
-        for (int i = 0; i < NST; ++i) stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                          rin, kok ? src_off[i] : OOB, (unsigned)kc * 4u, 0));
+        for (int i = 0; i < NST; ++i) {
+            if constexpr (IN16) {                                    // four bfloat16 = 8 bytes, parked in the first two components
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, kok ? src_off[i] : OOB, (unsigned)kc * 2u, 0));
+                const unsigned b0 = h[0], b1 = h[1];                 // (element -> scalar before a bit cast: hipcc 7.2 reads element 0 otherwise)
+                stage[i] = f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), 0.f, 0.f};
+            } else {
+                stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, kok ? src_off[i] : OOB, (unsigned)kc * 4u, 0));
+            }
+        }
     };
     auto deposit = [&]() {
         const float a_scale = ea == EA_NONE ? 1.f : exp2i(ea);
@@ -121,6 +133,11 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
                 split2h_x4(stage[i] * a_scale, ph, pm);
                 *reinterpret_cast<u32x2*>(dst) = ph;
                 *reinterpret_cast<u32x2*>(dst + plane) = pm;
+                continue;
+            }
+            if constexpr (IN16) {                                    // already bfloat16: a copy
+                const float e0 = stage[i][0], e1 = stage[i][1];
+                *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
                 continue;
             }
             split3_x4(stage[i], ph, pm, pl);
@@ -286,6 +303,29 @@ __global__ __launch_bounds__(256, 2) void pw_x3_kernel(PwP p) {
             if constexpr (ACC) {
                 if (mt + 1 < MTW) load_old(mt + 1, old[(mt + 1) & 1]);
             }
+            if constexpr (OUT16) {
+                // two rows at a time: the even lane of a pair stores columns (c, c + 1) of row rp as one dword, the odd lane those of row rp + 1
+                const bool odd = lane & 1;
+#pragma unroll
+                for (int rp = 0; rp < 4; rp += 2) {
+#pragma unroll
+                    for (int nu = 0; nu < NU; ++nu) {
+                        const float v0 = acc[mt][nu][rp] + bv[nu], v1 = acc[mt][nu][rp + 1] + bv[nu];
+                        const bool ok0 = cbase[nu] != OOB && (whole || ((rmask >> (4 * mt + rp)) & 1u));
+                        const bool ok1 = cbase[nu] != OOB && (whole || ((rmask >> (4 * mt + rp + 1)) & 1u));
+                        const float other = lane_xor1(odd ? v0 : v1);
+                        const unsigned pk = odd ? pack_bf16x2(other, v1) : pack_bf16x2(v0, other);
+                        const unsigned vo = (odd ? ok1 : ok0) ? ((cbase[nu] - (odd ? 4u : 0u)) >> 1) + (odd ? ld_b >> 1 : 0u) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(pk, rout, vo, (unsigned)(mt * 16 + rp) * (ld_b >> 1), STR ? FGCN_STORE_AUX : 0);
+                        const float k0 = ok0 ? v0 : 0.f, k1 = ok1 ? v1 : 0.f;
+                        ssum[nu] += k0;
+                        ssq[nu] += k0 * k0;
+                        ssum[nu] += k1;
+                        ssq[nu] += k1 * k1;
+                    }
+                }
+                continue;
+            }
             // (row loop outside the unit loop: the 64-byte halves of a 128-byte line leave back to back -- fgcn_spatial_tile.hip's epilogue has
             // the measurement; each unit's sums keep their order)
 #pragma unroll
@@ -344,15 +384,34 @@ extern "C" int fgcn_pw_gemm_available(void) {
     return (mm == FGCN_MATH_BF16X3 || mm == FGCN_MATH_BF16) ? 1 : 0;
 }
 
+static int pw_gemm_impl(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                        int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream_, int io);
+
 extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
                             int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream_) {
+    return pw_gemm_impl(in, out, w3, bias, stat_partials, rows, K, N, ld_in, ld_out, accumulate, in_amax, stream_, 0);
+}
+
+// typed form (math mode bf16, half-precision activation storage): half_mask bit 0 = `in` is a bfloat16 tensor, bit 1 = `out` is (not with
+// accumulation); strides in elements; stat_partials: the moments of the float32 results
+extern "C" int fgcn_pw_gemm_t(const void* in, void* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                              int K, int N, int ld_in, int ld_out, int accumulate, int half_mask, void* stream_) {
+    FGCN_REQUIRE((half_mask & ~3) == 0 && !((half_mask & 2) && accumulate), FGCN_E_BADARG, "pw_gemm_t: half_mask=%d (a bfloat16 output: no accumulation)",
+                 half_mask);
+    return pw_gemm_impl(static_cast<const float*>(in), static_cast<float*>(out), w3, bias, stat_partials, rows, K, N, ld_in, ld_out, accumulate,
+                        nullptr, stream_, half_mask);
+}
+
+static int pw_gemm_impl(const float* in, float* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                        int K, int N, int ld_in, int ld_out, int accumulate, unsigned* in_amax, void* stream_, int io) {
     FGCN_REQUIRE(in && out && w3 && rows > 0, FGCN_E_BADARG, "pw_gemm: null pointer or no rows");
+    FGCN_REQUIRE(io == 0 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "pw_gemm_t: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(fgcn_pw_gemm_available(), FGCN_E_BADARG, "pw_gemm: a split-bf16 math mode (bf16x3 / bf16) only");
     FGCN_REQUIRE(K > 0 && K % 32 == 0 && N > 0 && N % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= K && ld_out >= N,
                  FGCN_E_ALIGN, "pw_gemm: K must be a multiple of 32, N and the row strides multiples of 4 (K=%d N=%d ld_in=%d ld_out=%d)", K,
                  N, ld_in, ld_out);
     FGCN_REQUIRE(aligned16(in) && aligned16(w3) && aligned16(out), FGCN_E_ALIGN, "pw_gemm: 16-byte alignment");
-    const long long in_bytes = rows * ld_in * 4, out_bytes = rows * ld_out * 4, plane = (long long)K * N * 2;
+    const long long in_bytes = rows * ld_in * ((io & 1) ? 2 : 4), out_bytes = rows * ld_out * ((io & 2) ? 2 : 4), plane = (long long)K * N * 2;
     FGCN_REQUIRE(in_bytes < 0x7FFF0000ll && out_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "pw_gemm: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     PwP p;
@@ -376,13 +435,27 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
     const bool one = fgcn::math_mode() == FGCN_MATH_BF16, two = fgcn::f16x2_products();
     const size_t lds = (size_t)128 * 128 * (one ? 1 : (two ? 2 : 3)) + 16;
     hipStream_t s = (hipStream_t)stream_;
-    const bool stream = fgcn::stream_out(rows * (long long)N * 4);
+    const bool stream = !(io & 2) && fgcn::stream_out(rows * (long long)N * 4);
 #define FGCN_PW_LAUNCH(NT_, NP_)                                                                                         \
     do {                                                                                                                 \
         if (accumulate) hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, true>), grid, dim3(256), lds, s, p);                  \
         else if (stream) hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, false, true>), grid, dim3(256), lds, s, p);         \
         else hipLaunchKernelGGL((pw_x3_kernel<NT_, NP_, false>), grid, dim3(256), lds, s, p);                            \
     } while (0)
+#define FGCN_PW_LAUNCH_T(NT_)       /* one part, typed tensors */                                                        \
+    do {                                                                                                                 \
+        if (accumulate) hipLaunchKernelGGL((pw_x3_kernel<NT_, 1, true, false, 1>), grid, dim3(256), lds, s, p);          \
+        else if (io == 1 && stream) hipLaunchKernelGGL((pw_x3_kernel<NT_, 1, false, true, 1>), grid, dim3(256), lds, s, p); \
+        else if (io == 1) hipLaunchKernelGGL((pw_x3_kernel<NT_, 1, false, false, 1>), grid, dim3(256), lds, s, p);       \
+        else if (io == 2) hipLaunchKernelGGL((pw_x3_kernel<NT_, 1, false, false, 2>), grid, dim3(256), lds, s, p);       \
+        else hipLaunchKernelGGL((pw_x3_kernel<NT_, 1, false, false, 3>), grid, dim3(256), lds, s, p);                    \
+    } while (0)
+    if (io) {
+        FGCN_REQUIRE(one && !(accumulate && io != 1), FGCN_E_BADARG, "pw_gemm_t: an accumulating call takes a bfloat16 input only");
+        if (narrow) FGCN_PW_LAUNCH_T(1);
+        else FGCN_PW_LAUNCH_T(2);
+        return launch_status("pw_gemm");
+    }
     if (narrow) {
         if (one) FGCN_PW_LAUNCH(1, 1);
         else if (two) FGCN_PW_LAUNCH(1, 2);
@@ -393,5 +466,6 @@ extern "C" int fgcn_pw_gemm(const float* in, float* out, const void* w3, const f
         else FGCN_PW_LAUNCH(2, 3);
     }
 #undef FGCN_PW_LAUNCH
+#undef FGCN_PW_LAUNCH_T
     return launch_status("pw_gemm");
 }

@@ -283,9 +283,13 @@ def rows_gemm(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, K: int, 
               bias: Optional[torch.Tensor] = None, stats: bool = False, accumulate: bool = False,
               in_coff: int = 0, out_coff: int = 0) -> Optional[torch.Tensor]:
     """out[..., out_coff:out_coff+N] (+)= conv(inp[..., in_coff:in_coff+K]); w packed (taps, K, N).
-    Returns the (tiles, 2, N) statistics partials when ``stats``."""
+    Returns the (tiles, 2, N) statistics partials when ``stats``.  Math mode bf16: ``inp`` / ``out`` may be bfloat16 tensors
+    (half-precision activation storage, fgcn_rows_gemm_t; whole tensors, a bfloat16 ``out`` without accumulation)."""
     ensure_device()
-    _chk(inp, "rows_gemm.in"), _chk(out, "rows_gemm.out"), _chk(w, "rows_gemm.w")
+    in16, out16 = _chka(inp, "rows_gemm.in"), _chka(out, "rows_gemm.out")
+    _chk(w, "rows_gemm.w")
+    if (in16 or out16) and (in_coff or out_coff or (out16 and accumulate)):
+        raise _lib.FgcnError("rows_gemm: bfloat16 tensors are taken whole, a bfloat16 output without accumulation")
     B, T_in, V, ld_in = inp.shape
     Bo, T_out, Vo, ld_out = out.shape
     taps = tmap[0]
@@ -302,6 +306,10 @@ def rows_gemm(inp: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, K: int, 
     part = None
     if stats:
         part = torch.empty((lib.fgcn_rows_gemm_tiles(B * T_out * V), 2, N), device=inp.device, dtype=torch.float32)
+    if in16 or out16:
+        check(lib.fgcn_rows_gemm_t(inp.data_ptr(), out.data_ptr(), _p(w), _p(bias), _p(part), B, T_in, T_out, V, K, N, ld_in, ld_out, TMap(*tmap),
+                                   int(accumulate), _half_mask(in16, out16), _stream()), "fgcn_rows_gemm_t")
+        return part
     check(lib.fgcn_rows_gemm(_p(inp, in_coff), _p(out, out_coff), _p(w), _p(bias), _p(part), B, T_in, T_out, V, K, N,
                              ld_in, ld_out, TMap(*tmap), int(accumulate), _stream()), "fgcn_rows_gemm")
     return part
@@ -503,9 +511,12 @@ def pw_gemm_available() -> bool:
 def pw_gemm(inp: torch.Tensor, w3, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None, stats: bool = False,
             accumulate: bool = False, amax_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """1x1 convolution over all rows on the persistent split-bf16 row GEMM: inp (..., ld_in) and out (..., ld_out) contiguous with the
-    same number of rows, w3 = pack_split3 of the (1, K, N) matrix.  Returns the BatchNorm partial sums (tiles, 2, N) when asked."""
+    same number of rows, w3 = pack_split3 of the (1, K, N) matrix.  Returns the BatchNorm partial sums (tiles, 2, N) when asked.
+    Math mode bf16: ``inp`` / ``out`` may be bfloat16 tensors (fgcn_pw_gemm_t; a bfloat16 ``out`` without accumulation)."""
     ensure_device()
-    _chk(inp, "pw_gemm.in"), _chk(out, "pw_gemm.out")
+    in16, out16 = _chka(inp, "pw_gemm.in"), _chka(out, "pw_gemm.out")
+    if out16 and accumulate:
+        raise _lib.FgcnError("pw_gemm: a bfloat16 output is not accumulated into")
     if isinstance(w3, ScaledWeights):
         if w3.taps != 1:
             raise _lib.FgcnError("pw_gemm: a one-tap FGCN_PACK_SPLIT2H form expected")
@@ -521,6 +532,10 @@ def pw_gemm(inp: torch.Tensor, w3, out: torch.Tensor, *, bias: Optional[torch.Te
         raise _lib.FgcnError(f"pw_gemm: shape mismatch in={tuple(inp.shape)} out={tuple(out.shape)} weights (K, N) = {(K, N)}")
     lib = _lib.load()
     part = torch.empty((lib.fgcn_pw_gemm_tiles(rows), 2, N), device=inp.device, dtype=torch.float32) if stats else None
+    if in16 or out16:
+        check(lib.fgcn_pw_gemm_t(inp.data_ptr(), out.data_ptr(), w3.data_ptr(), _p(bias), _p(part), rows, K, N, ld_in, ld_out, int(accumulate),
+                                 _half_mask(in16, out16), _stream()), "fgcn_pw_gemm_t")
+        return part
     check(lib.fgcn_pw_gemm(_p(inp), _p(out), w3.data_ptr(), _p(bias), _p(part), rows, K, N, ld_in, ld_out, int(accumulate),
                            None if amax_out is None else amax_out.data_ptr(), _stream()), "fgcn_pw_gemm")
     return part

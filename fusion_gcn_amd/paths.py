@@ -92,6 +92,7 @@ class PathOptions:
     # ... per producer (A/B switches inside half_activations): the temporal conv's output U, the spatial tile kernel's output Y
     half_conv_out: bool = True
     half_spatial_out: bool = True
+    half_shortcuts: bool = True                  # the shortcut convolutions (down / residual) of the blocks that change width or stride: typed row GEMMs
     # -- inference (module in eval mode, autograd off): BatchNorm + shortcut + ReLU in the epilogues of the two north-star kernels
     # (fgcn_spatial_fwd_tile_bn_relu, fgcn_tconv_halo_bn_relu) -- a block is two kernels + the attention; split modes bf16x3 / bf16
     fused_inference: bool = True

@@ -246,7 +246,9 @@ int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const flo
  *   fgcn_spatial_bwd_tile_t   bit 0 dy, 1 x + dx + gated addends (a per-group extra1 stays float32)      masks 0, 1, 3
  *   fgcn_spatial_wgrad_tile_t bit 0 x, 1 dy                 masks 0, 2, 3
  *   fgcn_emb_dx_tile_t        bit 0 emb, 1 dx               masks 0, 1, 3
- *   fgcn_emb_wgrad_tile_t     bit 0 emb, 1 x                masks 0, 1, 3 */
+ *   fgcn_emb_wgrad_tile_t     bit 0 emb, 1 x                masks 0, 1, 3
+ *   fgcn_rows_gemm_t          bit 0 in, 1 out               (a bfloat16 out: no accumulation; a single problem)
+ *   fgcn_pw_gemm_t            bit 0 in, 1 out               (a bfloat16 out: no accumulation) */
 int fgcn_bn_act_t(const void* a, const float* vec_a, const void* b, const float* vec_b, void* out, unsigned char* sign_mask,
                   long long rows, int C, int res_mode, int relu, int half_mask, void* stream);
 int fgcn_bn_act_pool_t(const void* a, const float* vec_a, const void* b, const float* vec_b, unsigned char* sign_mask,
@@ -277,6 +279,11 @@ int fgcn_emb_dx_tile_t(const void* emb, const float* d_s, const void* w3, void* 
                        int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, int half_mask, void* stream);
 int fgcn_emb_wgrad_tile_t(const void* emb, const void* x, const float* d_s, float* partial, float* bias_partial, int B,
                           int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, int half_mask, void* stream);
+int fgcn_rows_gemm_t(const void* in, void* out, const float* w, const float* bias, float* stat_partials,
+                     int B, int T_in, int T_out, int V, int K, int N, int ld_in, int ld_out,
+                     fgcn_tmap map, int accumulate, int half_mask, void* stream);
+int fgcn_pw_gemm_t(const void* in, void* out, const void* w3, const float* bias, float* stat_partials, long long rows,
+                   int K, int N, int ld_in, int ld_out, int accumulate, int half_mask, void* stream);
 /* bn_a / bn_mask / bn_vec (all NULL, or all given where fgcn_tconv_halo_bn_sums() == 1: the split-bf16 kernel of the bf16 math
  * modes): the call is the data gradient that produces dG, the gradient of G = relu(BatchNorm(a) + shortcut) (agcn.py:113-115), and
  * stat_partials receives the BatchNorm-backward sums instead of the forward moments -- per row tile and channel

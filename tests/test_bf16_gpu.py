@@ -697,3 +697,46 @@ def test_embedding_kernels_on_bfloat16_activations(V, T, cin, ic, B):
         gw0, gb0 = ops.emb_wgrad_tile(e1, x32, d, ic=ic)
         gw1, gb1 = ops.emb_wgrad_tile(e1, x16, d, ic=ic)
         assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1)
+
+
+@pytest.mark.parametrize("B,T,V,K,N,s", [(2, 20, 25, 64, 128, 1), (2, 21, 25, 64, 128, 2), (3, 10, 18, 128, 256, 2), (2, 9, 27, 4, 64, 1), (2, 40, 25, 128, 64, 1),
+                                         (1, 300, 25, 256, 128, 1)])
+def test_row_gemms_on_bfloat16_activations(B, T, V, K, N, s):
+    """fgcn_rows_gemm_t / fgcn_pw_gemm_t (the shortcut convolutions of the blocks that change width or stride): a bfloat16 input gives the bits
+    of the float32 call on the same values, a bfloat16 output is the rounded float32 output with the float32 BatchNorm sums; also the
+    accumulating data-gradient form from a bfloat16 gradient."""
+    from fusion_gcn_amd import ops
+    Tp = (T - 1) // s + 1
+    x16 = h16(B, T, V, K, seed=71)
+    x32 = x16.float()
+    w = gpu(rnd(1, K, N, seed=72, scale=K ** -0.5))
+    bias = gpu(rnd(N, seed=73))
+    tmap = (1, s, 0, 0, 1)
+    o32 = torch.empty(B, Tp, V, N, device=dev())
+    p32 = ops.rows_gemm(x32, w, o32, K=K, N=N, tmap=tmap, bias=bias, stats=True)
+    for xin, half_out in ((x16, False), (x16, True), (x32, True)):
+        o = torch.empty(B, Tp, V, N, device=dev(), dtype=torch.bfloat16 if half_out else torch.float32)
+        p = ops.rows_gemm(xin, w, o, K=K, N=N, tmap=tmap, bias=bias, stats=True)
+        assert torch.equal(o, o32.to(o.dtype)) and torch.equal(p, p32), (xin.dtype, half_out)
+    # the data gradient of that convolution, accumulated into a float32 dx from a bfloat16 gradient
+    g16 = h16(B, Tp, V, N, seed=74)
+    wt = gpu(rnd(1, N, K, seed=75, scale=N ** -0.5))
+    base = gpu(rnd(B, T, V, K, seed=76))
+    d0, d1 = base.clone(), base.clone()
+    ops.rows_gemm(g16.float(), wt, d0, K=N, N=K, tmap=(1, 1, 0, 0, s), accumulate=True)
+    ops.rows_gemm(g16, wt, d1, K=N, N=K, tmap=(1, 1, 0, 0, s), accumulate=True)
+    assert torch.equal(d0, d1)
+    if s == 1 and K % 32 == 0:
+        w3 = ops.pack_split3(w)
+        o32 = torch.empty(B, T, V, N, device=dev())
+        p32 = ops.pw_gemm(x32, w3, o32, bias=bias, stats=True)
+        for xin, half_out in ((x16, False), (x16, True), (x32, True)):
+            o = torch.empty(B, T, V, N, device=dev(), dtype=torch.bfloat16 if half_out else torch.float32)
+            p = ops.pw_gemm(xin, w3, o, bias=bias, stats=True)
+            # (the sums of squares: the compiler contracts `s += v * v` to an fma in one instantiation and not in the other -- last-bit differences)
+            assert torch.equal(o, o32.to(o.dtype)) and torch.allclose(p, p32, rtol=2e-6, atol=0), (xin.dtype, half_out)
+        w3t = ops.pack_split3(wt)
+        d0, d1 = base.clone(), base.clone()
+        ops.pw_gemm(g16.float(), w3t, d0, accumulate=True)
+        ops.pw_gemm(g16, w3t, d1, accumulate=True)
+        assert torch.equal(d0, d1)
