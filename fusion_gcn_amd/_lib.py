@@ -140,6 +140,7 @@ SIGNATURES = {
     "fgcn_bn_act_bwd_apply_h": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
     "fgcn_tconv_halo_h": (_I, [_P, _P, _P, _P, _P] + [_I] * 18 + [_P, _P, _P] + [_P]),
     "fgcn_tconv_wgrad_h": (_I, [_P, _P, _P] + [_I] * 17 + [_P]),
+    "fgcn_pw_wgrad_h": (_I, [_P, _P, _P] + [_I] * 11 + [_P]),
     "fgcn_spatial_bwd_tile_h": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P, _I, _P, _P, _P, _P]),
     "fgcn_spatial_wgrad_tile_h": (_I, [_P, _P, _P, _P] + [_I] * 8 + [_P]),
     # typed forms (half-precision activation storage, math mode bf16): `half_mask` before the stream

@@ -651,9 +651,18 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
                 and (cfg.static_adjacency or (emb_tile_bwd and S["emb"] is not None and S["emb"].dtype == torch.bfloat16))
                 and (not gate_in_dagg or (dg16 and (d_o.dtype == torch.bfloat16 or (pool is not None and o_.pool_backward_rows)))))
     dg16 = dg16 and (dx16 or not gate_in_dagg)       # (a gated addend has dx's storage type: the fused backward adds it)
-    x_h = x                                  # the input as it arrived: the weight-gradient tile kernels take a bfloat16 x beside a bfloat16 dy / emb
-    if x16 and not dx16:
-        x = x.float()                        # (the kernels of this block's remaining paths read float32)
+    x_h = x                                  # the input as it arrived: the kernels with a typed form take the bfloat16 x beside a bfloat16 dy / emb / gradient
+    # the shortcut branches' gradients (dd / dr) as bfloat16 and their kernels on the bfloat16 x: the typed row GEMMs / 1x1 weight gradient
+    hs = bool(x16 and ha and o_.half_shortcuts and cin % 32 == 0 and cout % 8 == 0)
+    _xf: List[torch.Tensor] = []
+
+    def xf() -> torch.Tensor:                # x for a kernel without a bfloat16-input form (converted once, on first use)
+        if not x16:
+            return x_h
+        if not _xf:
+            _xf.append(x_h.float())
+        return _xf[0]
+    del x                                    # (every use below names the form it needs: x_h, or xf())
     dx = torch.empty((B, T, V, cx), device=dev, dtype=torch.bfloat16) if dx16 else new(B, T, V, cx)
     dx_live = False      # becomes True once dx holds a valid partial sum
     as_extra = lambda t: t if (dx16 or t.dtype == torch.float32) else t.float()      # noqa: E731  a gated addend has dx's storage type
@@ -663,7 +672,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         groups = pool[0]
         rows = o_numel // cout // groups
         d_o = d_o / rows                             # (groups, cout): every row of a group receives the group's gradient / rows
-        if o_.pool_backward_rows and (not gate_in_dagg or (tile_ok and x.shape[3] == cin)):
+        if o_.pool_backward_rows and (not gate_in_dagg or (tile_ok and x_h.shape[3] == cin)):
             grp_rows, grp_samples = rows, B // groups        # the BatchNorm-backward passes and the gated addend read the group's row
         else:
             d_o = d_o.unsqueeze(1).expand(groups, rows, cout).contiguous().view(B, Tp, V, cout)
@@ -674,20 +683,20 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], None, None, res_mode=0, train=train,
                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
     elif cfg.residual == "identity" and gate_in_dagg:
-        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, need_db=False,
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x_h, None, res_mode=1, train=train, need_db=False,
                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
         gated.append((d_o, S["o_sign"], grp_samples) if grp_samples else (as_extra(d_o), S["o_sign"]))   # dx += d_o * [o > 0], added by joint_dagg below
     elif cfg.residual == "identity":
-        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x, None, res_mode=1, train=train, db=dx,
+        du, _, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], x_h, None, res_mode=1, train=train, db=dx,
                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
         dx_live = True
     else:
         du, dr, sums = ops.bn_act_bwd(d_o, S["o"], S["u"], S["vec_u"], S["r"], S["vec_r"], res_mode=2, train=train,
-                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half)
+                                      sign_mask=S["o_sign"], grp_rows=grp_rows, da_bf16=half, db_bf16=hs)
         G["residual.bn.weight"], G["residual.bn.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is tcn1.bn.bias too
         ops.rows_gemm(dr, W["res_t"], dx, K=cout, N=cx, tmap=(1, 1, 0, 0, s))   # frames t % s != 0 receive zeros
         dx_live = True
-        G["residual.conv.weight"] = ops.rows_wgrad(x, dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
+        G["residual.conv.weight"] = ops.rows_wgrad(x_h if dr.dtype == torch.bfloat16 else xf(), dr, K=cin, N=cout, tmap=(1, s, 0, 0, 1),
                                                    conv_param=(1, cin_true))
         G["residual.conv.bias"] = bias_grad(dr, cout)
     G["tcn1.bn.weight"], G["tcn1.bn.bias"] = sums[1], sums[0]
@@ -715,18 +724,18 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # wgrad_tile / half_dy: above)
     if cfg.has_down:
         dy, dd, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], S["d"], S["vec_d"], res_mode=2, train=train,
-                                      sign_mask=S["g_sign"], da_bf16=half_dy)
+                                      sign_mask=S["g_sign"], da_bf16=half_dy, db_bf16=hs)
         G["gcn1.down.1.weight"], G["gcn1.down.1.bias"] = sums[2], sums[0].clone()   # own memory: sums[0] is gcn1.bn.bias too
         pw_gemm(dd, W, "down_t", dx, K=cout, N=cx, accumulate=dx_live)
         dx_live = True
-        G["gcn1.down.0.weight"] = ops.rows_wgrad(x, dd, K=cin, N=cout, conv_param=(1, cin_true))
+        G["gcn1.down.0.weight"] = ops.rows_wgrad(x_h if dd.dtype == torch.bfloat16 else xf(), dd, K=cin, N=cout, conv_param=(1, cin_true))
         G["gcn1.down.0.bias"] = bias_grad(dd, cout)
     elif gate_in_dagg:
-        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, need_db=False,
+        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x_h, None, res_mode=1, train=train, need_db=False,
                                      sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
         gated.append((as_extra(dg), S["g_sign"]))  # dx += dg * [g > 0]
     else:
-        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x, None, res_mode=1, train=train, db=dx,
+        dy, _, sums = ops.bn_act_bwd(dg, S["g"], S["y"], S["vec_y"], x_h, None, res_mode=1, train=train, db=dx,
                                      db_accumulate=dx_live, sign_mask=S["g_sign"], partials=g_partials if fuse_sums else None, da_bf16=half_dy)
         dx_live = True
     G["gcn1.bn.weight"], G["gcn1.bn.bias"] = sums[1], sums[0]
@@ -734,7 +743,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
     # -- conv_d and the joint aggregation ------------------------------------------------------------------------------------------
     a_hat = S["a_hat"]
     c3 = 3 * cin
-    bwd_tile = tile_ok and x.shape[3] == cin and (not gated or len(gated) == 2)
+    bwd_tile = tile_ok and x_h.shape[3] == cin and (not gated or len(gated) == 2)
     if half_dy and not bwd_tile:     # (cannot happen: the gated list holds none or both shortcuts by construction)
         raise ops._lib.FgcnError("block backward: dy was stored as bfloat16 but the fused spatial backward is not taken")
     dagg, dy_amax = None, False
@@ -745,13 +754,13 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         pw_gemm(dy, W, "d_t", dagg, K=cout, N=c3, amax_out=bamax[3:4] if dy_amax else None)
     # weight gradient of conv_d: agg is recomputed (cheaper than keeping 3 activations per block) and contracted with dy
     if wgrad_tile:
-        gw = ops.spatial_wgrad_tile(x_h if dy.dtype == torch.bfloat16 else x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))   # agg on chip, whole frame tiles
-    elif o_.fused_agg_wgrad and x.shape[3] == cin and cin >= 32 and cout <= o_.get("fused_agg_wgrad_max_cout", ops.get_math_mode()):
+        gw = ops.spatial_wgrad_tile(x_h if dy.dtype == torch.bfloat16 else xf(), dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))   # agg on chip, whole frame tiles
+    elif o_.fused_agg_wgrad and x_h.shape[3] == cin and cin >= 32 and cout <= o_.get("fused_agg_wgrad_max_cout", ops.get_math_mode()):
         # agg = x . A^ is formed in registers and contracted with dy at once: never written
-        gw = ops.spatial_wgrad(x, dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
+        gw = ops.spatial_wgrad(xf(), dy, a_hat, conv_param=(NUM_SUBSETS, cin_true))
     else:
         agg = new(B, T, V, c3)
-        agg_amax = mix_agg(x, agg, a_hat, cin, amax_out=bamax[2:3] if dy_amax else None)
+        agg_amax = mix_agg(xf(), agg, a_hat, cin, amax_out=bamax[2:3] if dy_amax else None)
         gw = ops.rows_wgrad(agg, dy, K=3 * cin, N=cout, conv_param=(NUM_SUBSETS, cin_true),   # (3, cout, cin_true, 1, 1)
                             amax=(bamax[2:3], bamax[3:4]) if agg_amax else None)
         del agg
@@ -761,12 +770,13 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         # three parameters, three buffers (the sum of the three biases is what the kernel adds: equal gradients)
         G[f"gcn1.conv_d.{k}.bias"] = bias_grad(dy, cout) if train else (dbias if k == 0 else dbias.clone())
     if bwd_tile:
-        part = ops.spatial_bwd_tile(dy, x, a_hat, W["d_t_b3"], dx, accumulate=dx_live, gated=gated)   # dagg on chip: dx and dA^ in one launch
-    elif o_.fused_dagg and x.shape[3] == cin:
-        part = ops.joint_dagg(x, dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
+        # dagg on chip: dx and dA^ in one launch (the bfloat16 x beside a bfloat16 dy, whatever dx is)
+        part = ops.spatial_bwd_tile(dy, x_h if dy.dtype == torch.bfloat16 else xf(), a_hat, W["d_t_b3"], dx, accumulate=dx_live, gated=gated)
+    elif o_.fused_dagg and x_h.shape[3] == cin:
+        part = ops.joint_dagg(xf(), dagg, a_hat, dx, accumulate=dx_live, gated=gated)   # dx and dA^ from one pass over dagg
     else:
         mix_dx(dagg, dx, a_hat, cin, accumulate=dx_live)
-        part = ops.joint_gram(x, dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
+        part = ops.joint_gram(xf(), dagg, [(0, k * cin, cin) for k in range(NUM_SUBSETS)])
     dx_live = True
     d_a_hat, d_s = ops.adj_softmax_bwd(part, 1.0 / (ic * T), S["c_mat"], V)
     db = torch.empty_like(P["gcn1.adj_b"])
@@ -779,7 +789,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         if emb_tile_bwd:
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
             ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
-            gw, gb = ops.emb_wgrad_tile(emb, x_h if emb.dtype == torch.bfloat16 else x, d_s, ic=ic)
+            gw, gb = ops.emb_wgrad_tile(emb, x_h if emb.dtype == torch.bfloat16 else xf(), d_s, ic=ic)
             gw = gw.view(6 * ic, cin_true, 1, 1)
         else:
             if emb.dtype != torch.float32:       # (cannot happen: the forward asked the same predicate before it chose the storage)
@@ -788,7 +798,7 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
             gb = mix_demb(emb, demb, d_s, ic)                                             # + column sums = bias gradient
             demb_amax = f16x2 and S["x_amax"] and pw_routed(W, "emb_t", demb, 6 * ic)
             pw_gemm(demb, W, "emb_t", dx, K=6 * ic, N=cx, accumulate=dx_live, amax_out=bamax[1:2] if demb_amax else None)
-            gw = ops.rows_wgrad(x, demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
+            gw = ops.rows_wgrad(xf(), demb, K=cin, N=6 * ic, conv_param=(1, cin_true),     # (6ic, cin_true, 1, 1)
                                 amax=(S["amax"][0:1], bamax[1:2]) if demb_amax else None)
         for k in range(NUM_SUBSETS):
             for j, grp in enumerate(("conv_a", "conv_b")):

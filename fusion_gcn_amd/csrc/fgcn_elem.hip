@@ -558,14 +558,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce8_kernel(const float* do
     }
 }
 
-// HM: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da` (db: float32)
+// HM: bit 0 = `dout` is bfloat16, bit 1 = `a`, bit 2 = `b`, bit 3 = `da`; db follows `da` when db_half (a kernel argument: it selects a store, no load)
 // TRAIN (compile time) and the unconditional sign-image load keep every load of a thread in ONE basic block: with `if (relu)` / `if (train)`
 // around them the kernel made three memory round trips per thread, one after the other (dout; the sign byte; a and the vectors)
 template <int RES, int HM, bool TRAIN>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply8_kernel(const float* dout, const unsigned char* mask, const float* a, const float* va,
                                                                 const float* b, const float* vb, const float* sums, float* da, float* db,
                                                                 long long n8, int C, int relu, float inv_m, int db_accumulate,
-                                                                int stream, int grp_rows) {
+                                                                int stream, int grp_rows, int db_half) {
     constexpr int hm = HM;
     constexpr bool train = TRAIN;
     const unsigned char* mp = relu ? mask : reinterpret_cast<const unsigned char*>(dout);     // (no ReLU: any valid byte, ignored)
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply8_kernel(const float* dou
                 gb.lo += *reinterpret_cast<const f32x4*>(db + i * 8);
                 gb.hi += *reinterpret_cast<const f32x4*>(db + i * 8 + 4);
             }
-            stx8(db, i * 8, gb, false, db_accumulate ? 0 : stream);
+            stx8(db, i * 8, gb, db_half != 0, db_accumulate ? 0 : stream);       // (db_half: never with db_accumulate, host check)
         }
     }
 }
@@ -852,7 +852,7 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
                                  const float* a, const float* vec_a, const float* b, const float* vec_b,
                                  const float* sums, float* da, float* db,
                                  long long rows, int C, int res_mode, int relu, int train, int db_accumulate,
-                                 int ld_dout, void* stream, int grp_rows = 0, bool o16 = false, int hm = 0) {
+                                 int ld_dout, void* stream, int grp_rows = 0, bool o16 = false, int hm = 0, int db16 = 0) {
     FGCN_REQUIRE(grp_rows >= 0 && (grp_rows == 0 || (rows % grp_rows == 0 && ld_dout == C)), FGCN_E_BADARG,
                  "bn_act_bwd_apply: %lld rows are not whole groups of %d", rows, grp_rows);
     FGCN_REQUIRE((!hm && !o16) || (fgcn::math_mode() == FGCN_MATH_BF16 && !((hm & 1) && grp_rows) && (!hm || !relu || sign_mask)), FGCN_E_BADARG,
@@ -869,6 +869,8 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
     hipStream_t s = (hipStream_t)stream;
     dim3 g(stream_blocks(n4)), blk(256);
     const int str = fgcn::stream_out(n4 * 16) ? 1 : 0;
+    FGCN_REQUIRE(!db16 || (hm && C % 8 == 0 && ld_dout == C && !db_accumulate && db && (!relu || sign_mask)), FGCN_E_BADARG,
+                 "bn_act_bwd_apply_t: a bfloat16 db needs the eight-wide typed kernel (C %% 8 == 0) and no accumulation");
     if (hm && C % 8 == 0 && ld_dout == C && (!relu || sign_mask)) {      // typed operands: eight elements per thread
         const long long n8 = n4 / 2;
         const int hm8 = hm | (o16 ? 8 : 0);
@@ -877,9 +879,9 @@ static int bn_act_bwd_apply_impl(const float* dout, const float* out, const unsi
 #define FGCN_BN_APP8H(RES_, HM_)                                                                                                          \
     do {                                                                                                                                  \
         if (train) hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_, true>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C, \
-                                      relu, inv_m, db_accumulate, str, grp_rows);                                                         \
+                                      relu, inv_m, db_accumulate, str, grp_rows, db16);                                                   \
         else hipLaunchKernelGGL((bn_act_bwd_apply8_kernel<RES_, HM_, false>), g8, blk, 0, s, dout, sign_mask, a, vec_a, b, vec_b, sums, da, db, n8, C,      \
-                                relu, inv_m, db_accumulate, str, grp_rows);                                                               \
+                                relu, inv_m, db_accumulate, str, grp_rows, db16);                                                         \
     } while (0)
 #define FGCN_BN_APP8(RES_)                                                                                                                \
     do switch (RES_ == 2 ? hm8 : (hm8 & ~4)) {                                                                                            \
@@ -1158,12 +1160,12 @@ extern "C" int fgcn_bn_act_bwd_reduce_t(const void* dout, int grp_rows, const fl
                                   vec_b, partials, n_tiles, rows, C, res_mode, relu, C, stream, grp_rows, half_mask);
 }
 extern "C" int fgcn_bn_act_bwd_apply_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
-                                       const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, float* db,
+                                       const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, void* db,
                                        long long rows, int C, int res_mode, int relu, int train, int db_accumulate, int half_mask, void* stream) {
-    FGCN_REQUIRE((half_mask & ~15) == 0 && grp_rows >= 0, FGCN_E_BADARG, "bn_act_bwd_apply_t: half_mask=%d grp_rows=%d", half_mask, grp_rows);
+    FGCN_REQUIRE((half_mask & ~31) == 0 && grp_rows >= 0, FGCN_E_BADARG, "bn_act_bwd_apply_t: half_mask=%d grp_rows=%d", half_mask, grp_rows);
     return bn_act_bwd_apply_impl(static_cast<const float*>(dout), out, sign_mask, static_cast<const float*>(a), vec_a, static_cast<const float*>(b),
-                                 vec_b, sums, static_cast<float*>(da), db, rows, C, res_mode, relu, train, db_accumulate, C, stream, grp_rows,
-                                 (half_mask & 8) != 0, half_mask & 7);
+                                 vec_b, sums, static_cast<float*>(da), static_cast<float*>(db), rows, C, res_mode, relu, train, db_accumulate, C, stream,
+                                 grp_rows, (half_mask & 8) != 0, half_mask & 7, (half_mask & 16) ? 1 : 0);
 }
 
 // The two backward passes with the gradient of a POOLED output (fgcn_bn_act_pool): dout is float[rows / grp_rows][C], one row per group of

@@ -86,12 +86,12 @@ __device__ __forceinline__ u32x2 sb_read_tr16(const unsigned char* p) {
 // layout keeps room for three parts, the first is used)
 // IN16 (NP = 1): dy is a BFLOAT16 tensor (half-precision storage written by fgcn_bn_act_bwd_apply_h; ld_dy in elements): its rows are
 // copied into the staging plane instead of fetched as f32 and rounded -- the same staged bytes, half the reads
-// IN16 = 3: x, dx and the gated addends are BFLOAT16 tensors as well (half-precision activation storage, the `_t` entry point; strides in
-// elements): x's gram fragment is one 16-byte load of eight bfloat16 and needs no split, the addends / old dx values are 8-byte loads
-// converted where they are consumed, dx is rounded once per store.  A per-group first addend (e0_grp) stays float32.
+// IN16 bit 1: x is a BFLOAT16 tensor as well, bit 2: dx and the gated addends are (half-precision activation storage, the `_t` entry point; strides
+// in elements; forms 0, 1, 3, 7): x's gram fragment is one 16-byte load of eight bfloat16 and needs no split, the addends / old dx values are
+// 8-byte loads converted where they are consumed, dx is rounded once per store.  A per-group first addend (e0_grp) stays float32.
 template <bool ACC, int MAXS, int NE = 0, int NP = 3, int IN16 = 0>
 __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
-    constexpr bool H16 = IN16 == 3;
+    constexpr bool X16 = (IN16 & 2) != 0, H16 = (IN16 & 4) != 0;
     static_assert(NE == 0 || (NE == 2 && !ACC), "gated addends: both identity shortcuts, dx not live before");
     static_assert(NP == 1 || NP == 3, "parts");
     static_assert(!IN16 || NP == 1, "bfloat16 dy: the one-part kernel");
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int f = (wave >> 1) + 4 * u, v = 16 * (wave & 1) + l15;
-                    const unsigned off = (f < nf && v < V && !(FGCN_PROBE_SB & 8)) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * (H16 ? 2u : 4u) : OOB;
-                    xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));      // (H16: the eight bfloat16 of the fragment)
-                    if constexpr (!H16) xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
+                    const unsigned off = (f < nf && v < V && !(FGCN_PROBE_SB & 8)) ? ((row0 + f * V + v) * (unsigned)p.ld_x + cbase + 8 * g4) * (X16 ? 2u : 4u) : OOB;
+                    xr[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));      // (X16: the eight bfloat16 of the fragment)
+                    if constexpr (!X16) xr[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 16, 0));
                 }
                 // gated addends of this wave's mix units (element index of the lane's four channels; the sign image holds one bit per element:
                 // a nibble per lane), requested here as well
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void spatial_bwd_tile_x3_kernel(SpBwdP p) {
                     const int f = (wave >> 1) + 4 * u;
                     if (f >= nf) continue;                           // wave-uniform
                     u32x4v xs[NP];
-                    if constexpr (H16) {                             // already bfloat16: the fragment as loaded
+                    if constexpr (X16) {                             // already bfloat16: the fragment as loaded
                         xs[0] = __builtin_bit_cast(u32x4v, xr[u][0]);
                     } else if constexpr ((FGCN_PROBE_SB & 512) != 0) {
 #pragma unroll
@@ -550,13 +550,14 @@ extern "C" int fgcn_spatial_bwd_tile_h(const unsigned short* dy_h, const float* 
                                    a_hat_batched, accumulate, extra1, mask1, extra2, mask2, extra1_group, stream, 1);
 }
 
-// typed form (math mode bf16): half_mask bit 0 = dy is a bfloat16 tensor, bit 1 = x, dx AND the gated addends are (a per-group extra1 stays
-// float32); masks 0, 1, 3.  Strides in elements.
+// typed form (math mode bf16): half_mask bit 0 = dy is a bfloat16 tensor, bit 1 = x is, bit 2 = dx AND the gated addends are (a per-group extra1
+// stays float32); masks 0, 1, 3, 7.  Strides in elements.
 extern "C" int fgcn_spatial_bwd_tile_t(const void* dy, const void* x, const float* a_hat, const void* w3, void* dx, float* partial,
                                        int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched, int accumulate,
                                        const void* extra1, int extra1_group, const unsigned char* mask1, const void* extra2,
                                        const unsigned char* mask2, int half_mask, void* stream) {
-    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "spatial_bwd_tile_t: half_mask=%d (0, 1 or 3)", half_mask);
+    FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3 || half_mask == 7, FGCN_E_BADARG, "spatial_bwd_tile_t: half_mask=%d (0, 1, 3 or 7)",
+                 half_mask);
     FGCN_REQUIRE(extra1_group >= 0 && (extra1_group == 0 || (extra1 && B % extra1_group == 0 && !accumulate)), FGCN_E_BADARG,
                  "spatial_bwd_tile_t: %d samples are not whole groups of %d", B, extra1_group);
     return spatial_bwd_tile_launch(static_cast<const float*>(dy), static_cast<const float*>(x), a_hat, w3, static_cast<float*>(dx), partial, B, T, V,
@@ -586,7 +587,7 @@ extern "C" int fgcn_spatial_bwd_tile_g(const float* dy, const float* x, const fl
 static int spatial_bwd_tile_launch(const float* dy, const float* x, const float* a_hat, const void* w3, float* dx, float* partial,
                                    int B, int T, int V, int Cin, int Cout, int ld_dy, int ld_x, int ld_dx, int a_hat_batched,
                                    int accumulate, const float* extra1, const unsigned char* mask1, const float* extra2,
-                                   const unsigned char* mask2, int extra1_group, void* stream, int dy16) {      // dy16: 1 = dy bfloat16; 3 = x, dx, addends too
+                                   const unsigned char* mask2, int extra1_group, void* stream, int dy16) {      // dy16: the typed entry's half_mask (0, 1, 3, 7)
     const bool gated = extra1 != nullptr;
     FGCN_REQUIRE(!dy16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "spatial_bwd_tile_h: a bfloat16 dy needs math mode bf16");
     FGCN_REQUIRE(!gated || (mask1 && extra2 && mask2 && !accumulate && ld_x == Cin && Cin % 8 == 0), FGCN_E_BADARG,
@@ -601,8 +602,8 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
                  "spatial_bwd_tile: row strides");
     FGCN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w3) && aligned16(dx), FGCN_E_ALIGN, "spatial_bwd_tile: 16-byte alignment");
     const long long rows = (long long)B * T * V;
-    const int abytes = dy16 == 3 ? 2 : 4;
-    const long long dy_bytes = rows * ld_dy * (dy16 ? 2 : 4), x_bytes = rows * ld_x * abytes, dx_bytes = rows * ld_dx * abytes;
+    const int abytes = (dy16 & 4) ? 2 : 4;
+    const long long dy_bytes = rows * ld_dy * (dy16 ? 2 : 4), x_bytes = rows * ld_x * ((dy16 & 2) ? 2 : 4), dx_bytes = rows * ld_dx * abytes;
     const long long plane = (long long)3 * Cin * Cout * 2;
     FGCN_REQUIRE(dy_bytes < 0x7FFF0000ll && x_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "spatial_bwd_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
@@ -653,7 +654,8 @@ static int spatial_bwd_tile_launch(const float* dy, const float* x, const float*
     } while (0)
 #define FGCN_SB_GO3(ACC_, MS_, NE_)                                                                                    \
     do {                                                                                                                \
-        if (one_part && dy16 == 3) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 3);                                                   \
+        if (one_part && dy16 == 7) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 7);                                                   \
+        else if (one_part && dy16 == 3) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 3);                                              \
         else if (one_part && dy16) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 1);                                                   \
         else if (one_part) FGCN_SB_GO4(ACC_, MS_, NE_, 1, 0);                                                           \
         else FGCN_SB_GO4(ACC_, MS_, NE_, 3, 0);                                                                         \

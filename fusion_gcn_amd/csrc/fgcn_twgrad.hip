@@ -222,7 +222,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 template <int NTAP, int TN, bool CH, int NP, int WV = 8, bool RING = false, bool IN16 = false>
 __global__ __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) void tconv_wgrad_x3_kernel(TWgradP p) {
     static_assert(!(RING && CH), "the circular window is the tap mode's");
-    static_assert(!IN16 || (NP == 1 && !CH), "bfloat16 inputs: the one-part kernel, tap mode");
+    static_assert(!IN16 || NP == 1, "bfloat16 inputs: the one-part kernel (tap mode, and the chunk mode of the 1x1 weight gradients)");
     constexpr unsigned ES = IN16 ? 2u : 4u;                       // bytes per stored element
     // four values of a row: 16 bytes of f32, or 8 bytes of bfloat16 parked in the first two components
     auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
@@ -539,7 +539,7 @@ static void launch_twgrad(const TWgradP& p, int N, dim3 grid, size_t lds, hipStr
 // one instantiation of the split kernel; the bfloat16-input form exists for the one-part kernel in tap mode
 template <int NTAP, int TN, bool CH, int NP, int WV, bool RING>
 static void twx_go(const TWgradP& p, dim3 grid, size_t lds, hipStream_t s) {
-    if constexpr (NP == 1 && !CH) {
+    if constexpr (NP == 1) {
         if (p.in16) {
             static bool opted16 = false;
             if (!opted16) {
@@ -603,8 +603,7 @@ static int twgrad_launch(const float* a, const float* g, float* partial, int B, 
                          int shift0, int tap0, int tap_step, int taps_total, int nsplit, const unsigned* a_amax,
                          const unsigned* g_amax, void* stream, const char* what, bool in16 = false) {
     FGCN_REQUIRE(a && g && partial, FGCN_E_BADARG, "%s: null pointer", what);
-    FGCN_REQUIRE(!in16 || (fgcn::math_mode() == FGCN_MATH_BF16 && !chunk_mode), FGCN_E_BADARG,
-                 "%s: bfloat16 inputs need math mode bf16 and the tap form", what);
+    FGCN_REQUIRE(!in16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "%s: bfloat16 inputs need math mode bf16", what);
     FGCN_REQUIRE(B > 0 && T_g > 0 && V > 0 && V <= FGCN_MAX_V && K > 0 && N > 0 && nsplit > 0 && nsplit <= 65535,
                  FGCN_E_BADARG, "%s: bad sizes B=%d T_g=%d V=%d K=%d N=%d nsplit=%d", what, B, T_g, V, K, N, nsplit);
     FGCN_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_a % 4 == 0 && ld_g % 4 == 0 && ld_a >= K && ld_g >= N, FGCN_E_ALIGN,
@@ -716,6 +715,15 @@ extern "C" int fgcn_tconv_wgrad_h(const unsigned short* a_h, const unsigned shor
                  FGCN_E_BADARG, "tconv_wgrad_h: taps (%d from %d step %d of %d)", ntaps, tap0, tap_step, taps_total);
     return twgrad_launch(reinterpret_cast<const float*>(a_h), reinterpret_cast<const float*>(g_h), partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full,
                          a_s, a_o, Th_a, ntaps, 0, shift0, tap0, tap_step, taps_total, nsplit, nullptr, nullptr, stream, "tconv_wgrad_h", true);
+}
+
+// fgcn_pw_wgrad with bfloat16 tensors a and g (math mode bf16; ld_a / ld_g in elements): the shortcut convolutions' weight gradients under
+// half-precision activation storage -- bit-identical to the float32 call on the same values
+extern "C" int fgcn_pw_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
+                               int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream) {
+    FGCN_REQUIRE(a_s >= 1 && T_g > 0, FGCN_E_BADARG, "pw_wgrad_h: bad frame view");
+    return twgrad_launch(reinterpret_cast<const float*>(a_h), reinterpret_cast<const float*>(g_h), partial, B, T_g, V, K, N, ld_a, ld_g, T_a_full, a_s,
+                         a_o, T_g, fgcn_pw_wgrad_chunks(K, N), 1, 0, 0, 1, 1, nsplit, nullptr, nullptr, stream, "pw_wgrad_h", true);
 }
 
 /* in-channel chunks (32 channels each = one accumulator) per wave for a 1x1 weight gradient: a divisor of the chunk

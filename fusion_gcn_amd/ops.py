@@ -642,7 +642,9 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
     one-element int32 tensors in which ``tconv_halo`` / ``pw_gemm`` left the operands' largest magnitudes (math mode f16x2: the
     split kernel then forms its products from two-way f16 splits; without them it runs bf16x3)."""
     ensure_device()
-    _chk(a, "rows_wgrad.a"), _chk(g, "rows_wgrad.g")
+    a16, g16 = _chka(a, "rows_wgrad.a"), _chka(g, "rows_wgrad.g")      # math mode bf16: both bfloat16 (fgcn_pw_wgrad_h: the 1x1 form, K % 32 == 0)
+    if a16 != g16 or (a16 and (a_coff or g_coff or amax is not None)):
+        raise _lib.FgcnError("rows_wgrad: bfloat16 operands come as a pair, whole tensors")
     B, T_a, V, ld_a = a.shape
     Bg, T_g, Vg, ld_g = g.shape
     if (Bg, Vg) != (B, V) or a_coff + K > ld_a + 3 or g_coff + N > ld_g + 3 or a_coff % 4 or g_coff % 4:
@@ -665,10 +667,16 @@ def rows_wgrad(a: torch.Tensor, g: torch.Tensor, *, K: int, N: int, tmap=TMAP_PO
         am = (None, None) if amax is None or a_coff or g_coff else (amax[0].data_ptr(), amax[1].data_ptr())
         if am[0] is not None and lib.fgcn_get_math_mode() == 2:
             check(lib.fgcn_set_products(1), "fgcn_set_products")   # (operand scales given: the f16x2 form of the split kernel)
+        if a16:
+            check(lib.fgcn_pw_wgrad_h(a.data_ptr(), g.data_ptr(), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0, nsplit, _stream()),
+                  "fgcn_pw_wgrad_h")
+            return _reduce_slabs(partial.view(slabs, 1, K, N), 1, K, N, out, accumulate, conv_param)
         check(lib.fgcn_pw_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_g, V, K, N, ld_a, ld_g, T_a, ta, 0,
                                 nsplit, *am, _stream()), "fgcn_pw_wgrad")
         _mode_products()
         return _reduce_slabs(partial.view(slabs, 1, K, N), 1, K, N, out, accumulate, conv_param)
+    if a16:
+        raise _lib.FgcnError("rows_wgrad: bfloat16 operands take the 1x1 multi-accumulator form only (K % 32 == 0, one tap)")
     nsplit = _pick_nsplit(B * T_g * V, K, N, taps)
     partial = torch.empty((nsplit, taps, K, N), device=a.device, dtype=torch.float32)
     check(lib.fgcn_rows_wgrad(_p(a, a_coff), _p(g, g_coff), _p(partial), B, T_a, T_g, V, K, N, ld_a, ld_g,
@@ -1061,7 +1069,7 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
                b: Optional[torch.Tensor], vec_b: Optional[torch.Tensor], *, relu: bool = True, train: bool = True,
                res_mode: int, db: Optional[torch.Tensor] = None, db_accumulate: bool = False,
                sign_mask: Optional[torch.Tensor] = None, need_sums: bool = True, need_db: bool = True,
-               partials: Optional[torch.Tensor] = None, grp_rows: int = 0, da_bf16: bool = False):
+               partials: Optional[torch.Tensor] = None, grp_rows: int = 0, da_bf16: bool = False, db_bf16: bool = False):
     """Backward of bn_act.  Returns (da, db, sums (3, C)): sums[0] = d beta, sums[1] = d gamma_a, sums[2] = d gamma_b.
     ``da_bf16``: da is stored as bfloat16 (fgcn_bn_act_bwd_apply_h: the gradient of the temporal conv's output in math mode bf16).
     The ReLU gate is read from ``sign_mask`` (bn_act's bit image) when given, else from ``out``.  ``need_sums=False`` with
@@ -1069,7 +1077,8 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
     ``grp_rows`` > 0: ``dout`` is (rows / grp_rows, C), one row per group of consecutive rows -- the gradient of ``bn_act_pool``'s
     output, already divided by the group size -- instead of its rows x C broadcast.
     ``dout`` / ``a`` / ``b`` may be bfloat16 tensors (half-precision activation storage, math mode bf16: the `_t` entry points; the gate
-    is then the sign image and a per-group ``dout`` stays float32); db is float32 always."""
+    is then the sign image and a per-group ``dout`` stays float32); ``db_bf16``: a freshly allocated db (the shortcut branch's gradient) is
+    bfloat16 too (typed operands, C % 8 == 0, no accumulation)."""
     ensure_device()
     d16, a16 = _chka(dout, "bn_act_bwd.dout"), _chka(a, "bn_act_bwd.a")
     b16 = _chka(b, "bn_act_bwd.b") if (b is not None and res_mode == 2) else False      # (an identity shortcut is not read)
@@ -1105,14 +1114,16 @@ def bn_act_bwd(dout: torch.Tensor, out: Optional[torch.Tensor], a: torch.Tensor,
         sums = torch.empty((3, C), device=a.device, dtype=torch.float32)
         reduce_sum(partials.view(tiles, -1), sums.view(-1))
     da = torch.empty_like(a, dtype=torch.bfloat16 if da_bf16 else torch.float32)
+    db16 = False
     if res_mode != 0 and db is None and need_db:   # need_db=False (identity residual): the caller adds the gated gradient itself
-        db = torch.empty_like(a, dtype=torch.float32)
-    if db is not None:
+        db16 = bool(db_bf16 and typed and C % 8 == 0)
+        db = torch.empty_like(a, dtype=torch.bfloat16 if db16 else torch.float32)
+    elif db is not None:
         _chk(db, "bn_act_bwd.db")
     if typed:
         check(lib.fgcn_bn_act_bwd_apply_t(dout.data_ptr(), grp_rows, None, _p(sign_mask), a.data_ptr(), _p(vec_a),
-                                          None if b is None else b.data_ptr(), _p(vec_b), _p(sums), da.data_ptr(), _p(db), rows, C, res_mode,
-                                          int(relu), int(train), int(db_accumulate), _half_mask(d16, a16, b16, da_bf16), _stream()),
+                                          None if b is None else b.data_ptr(), _p(vec_b), _p(sums), da.data_ptr(), None if db is None else db.data_ptr(), rows, C, res_mode,
+                                          int(relu), int(train), int(db_accumulate), _half_mask(d16, a16, b16, da_bf16, db16), _stream()),
               "fgcn_bn_act_bwd_apply_t")
     elif da_bf16:
         check(lib.fgcn_bn_act_bwd_apply_h(_p(dout), grp_rows, _p(out), _p(sign_mask), _p(a), _p(vec_a), _p(b), _p(vec_b), _p(sums),
@@ -1339,10 +1350,11 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     if len(gated) not in (0, 2) or (gated and accumulate):
         raise _lib.FgcnError("spatial_bwd_tile: gated addends come as the pair of identity shortcuts, without accumulation")
     group = gated[0][2] if gated and len(gated[0]) == 3 else 0
-    all16 = _chka(x, "spatial_bwd_tile.x")
+    x16 = _chka(x, "spatial_bwd_tile.x")
+    all16 = _chka(dx, "spatial_bwd_tile.dx")      # dx and the gated addends share a storage type; a bfloat16 dx comes with a bfloat16 x and dy
     for i, (e, m, *_) in enumerate(gated):
         if _chka(e, "spatial_bwd_tile.gated") != (all16 and not (i == 0 and group)):
-            raise _lib.FgcnError("spatial_bwd_tile: the gated addends have x's storage type (a per-group first addend: float32)")
+            raise _lib.FgcnError("spatial_bwd_tile: the gated addends have dx's storage type (a per-group first addend: float32)")
         want = (x.shape[0] // group, x.shape[3]) if (i == 0 and group) else tuple(x.shape)
         if tuple(e.shape) != want or m.dtype != torch.uint8 or m.numel() * 8 != x.numel() or not m.is_cuda or (group and x.shape[0] % group):
             raise _lib.FgcnError(f"spatial_bwd_tile: gated addend {tuple(e.shape)} / image {m.numel()} bytes do not match x {tuple(x.shape)}")
@@ -1355,8 +1367,8 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     else:
         _chk(dy, "spatial_bwd_tile.dy")
     _chk(a_hat, "spatial_bwd_tile.a_hat")
-    if _chka(dx, "spatial_bwd_tile.dx") != all16 or (all16 and not dy16):
-        raise _lib.FgcnError("spatial_bwd_tile: x, dx and the gated addends are bfloat16 together, and then dy is too")
+    if (all16 and not x16) or (x16 and not dy16):
+        raise _lib.FgcnError("spatial_bwd_tile: a bfloat16 dx comes with a bfloat16 x, a bfloat16 x with a bfloat16 dy")
     B, T, V, Cin = x.shape
     Cout = dy.shape[3]
     if (w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, 1, Cout // 8, 3 * Cin, 8) or not w3.is_contiguous()
@@ -1368,10 +1380,10 @@ def spatial_bwd_tile(dy: torch.Tensor, x: torch.Tensor, a_hat: torch.Tensor, w3:
     _mode_products()
     nseg = lib.fgcn_spatial_bwd_tile_segments(B, T, V)
     partial = torch.empty((B, max(nseg, 1), 3, 32, 32), device=x.device, dtype=torch.float32)
-    if all16:
+    if x16:
         check(lib.fgcn_spatial_bwd_tile_t(dy.data_ptr(), x.data_ptr(), _p(a_hat), w3.data_ptr(), dx.data_ptr(), _p(partial), B, T, V, Cin, Cout, Cout,
                                           Cin, dx.shape[3], int(a_hat.shape[0] == B), int(accumulate), ex[0][0], group, ex[0][1], ex[1][0], ex[1][1],
-                                          3, _stream()), "fgcn_spatial_bwd_tile_t")
+                                          7 if all16 else 3, _stream()), "fgcn_spatial_bwd_tile_t")
         return partial
     if dy16:
         check(lib.fgcn_spatial_bwd_tile_h(dy.data_ptr(), _p(x), _p(a_hat), w3.data_ptr(), _p(dx), _p(partial), B, T, V, Cin, Cout, Cout, Cin,

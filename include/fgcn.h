@@ -209,6 +209,9 @@ int fgcn_tconv_halo_h(const unsigned short* in_h, float* out, const float* w4, c
 int fgcn_tconv_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
                        int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int Th_a,
                        int ntaps, int shift0, int tap0, int tap_step, int taps_total, int nsplit, void* stream);
+/* fgcn_pw_wgrad (the 1x1 weight gradient, channel chunks) with bfloat16 tensors a and g */
+int fgcn_pw_wgrad_h(const unsigned short* a_h, const unsigned short* g_h, float* partial, int B, int T_g, int V, int K, int N,
+                    int ld_a, int ld_g, int T_a_full, int a_s, int a_o, int nsplit, void* stream);
 /* ... and of dY, the gradient of the spatial stage's output (written by fgcn_bn_act_bwd_apply_h; read only by the staging of the two tile
  * kernels of the spatial backward): fgcn_spatial_bwd_tile / _g (extra1_group = 0: the plain form) and fgcn_spatial_wgrad_tile with dy as
  * bfloat16 (ld_dy in elements) */
@@ -239,11 +242,11 @@ int fgcn_emb_wgrad_tile_h(const unsigned short* emb_h, const float* x, const flo
  *   fgcn_bn_act_t             bit 0 a, 1 b (shortcut), 2 out
  *   fgcn_bn_act_pool_t        bit 0 a, 1 b
  *   fgcn_bn_act_bwd_reduce_t  bit 0 dout, 1 a, 2 b          (grp_rows > 0: dout is the float32 per-group form; the ReLU gate is the sign image)
- *   fgcn_bn_act_bwd_apply_t   bit 0 dout, 1 a, 2 b, 3 da    (db stays float32)
+ *   fgcn_bn_act_bwd_apply_t   bit 0 dout, 1 a, 2 b, 3 da, 4 db  (a bfloat16 db: C % 8 == 0, not accumulating)
  *   fgcn_tconv_halo_t         bit 0 in, 1 out               masks 0, 1, 3; plain store epilogue (no accumulation / BatchNorm-backward sums)
  *   fgcn_spatial_fwd_tile_t   bit 0 x, 1 y                  masks 0, 2, 3
  *   fgcn_emb_fwd_tile_t       bit 0 x, 1 emb
- *   fgcn_spatial_bwd_tile_t   bit 0 dy, 1 x + dx + gated addends (a per-group extra1 stays float32)      masks 0, 1, 3
+ *   fgcn_spatial_bwd_tile_t   bit 0 dy, 1 x, 2 dx + gated addends (a per-group extra1 stays float32)     masks 0, 1, 3, 7
  *   fgcn_spatial_wgrad_tile_t bit 0 x, 1 dy                 masks 0, 2, 3
  *   fgcn_emb_dx_tile_t        bit 0 emb, 1 dx               masks 0, 1, 3
  *   fgcn_emb_wgrad_tile_t     bit 0 emb, 1 x                masks 0, 1, 3
@@ -257,7 +260,7 @@ int fgcn_bn_act_bwd_reduce_t(const void* dout, int grp_rows, const float* out, c
                              const float* vec_a, const void* b, const float* vec_b, float* partials, int n_tiles, long long rows,
                              int C, int res_mode, int relu, int half_mask, void* stream);
 int fgcn_bn_act_bwd_apply_t(const void* dout, int grp_rows, const float* out, const unsigned char* sign_mask, const void* a,
-                            const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, float* db,
+                            const float* vec_a, const void* b, const float* vec_b, const float* sums, void* da, void* db,
                             long long rows, int C, int res_mode, int relu, int train, int db_accumulate, int half_mask, void* stream);
 int fgcn_tconv_halo_t(const void* in, void* out, const float* w4, const float* bias, float* stat_partials,
                       int B, int Th, int V, int K, int N, int ld_in, int ld_out,

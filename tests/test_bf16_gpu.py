@@ -740,3 +740,36 @@ def test_row_gemms_on_bfloat16_activations(B, T, V, K, N, s):
         ops.pw_gemm(g16.float(), w3t, d0, accumulate=True)
         ops.pw_gemm(g16, w3t, d1, accumulate=True)
         assert torch.equal(d0, d1)
+
+
+@pytest.mark.parametrize("B,T,V,cin,cout,s", [(2, 20, 25, 64, 128, 1), (2, 21, 25, 64, 128, 2), (2, 12, 18, 128, 256, 2), (1, 30, 27, 128, 64, 1)])
+def test_shortcut_branch_backward_on_bfloat16_tensors(B, T, V, cin, cout, s):
+    """The backward of the blocks that change width or stride under half-precision activation storage: the shortcut BatchNorm's gradient as a
+    bfloat16 tensor (fgcn_bn_act_bwd_apply_t, bit 4), the 1x1 weight gradient from bfloat16 operands (fgcn_pw_wgrad_h), and the fused spatial
+    backward reading a bfloat16 x while it accumulates into a float32 dx (fgcn_spatial_bwd_tile_t, mask 3) -- against the float32 forms."""
+    from fusion_gcn_amd import ops
+    Tp = (T - 1) // s + 1
+    rows, C = B * Tp * V, cout
+    a16, b16, d16 = h16(rows, C, seed=81), h16(rows, C, seed=82), h16(rows, C, seed=83)
+    mk = lambda seed: gpu(torch.stack([rnd(C, seed=seed), rnd(C, seed=seed + 1).abs() + 0.5, rnd(C, seed=seed + 2), rnd(C, seed=seed + 3)]))  # noqa: E731
+    va, vb = mk(10), mk(20)
+    _, m0 = ops.bn_act(a16.float(), va, b16.float(), vb, relu=True, sign_mask=True)
+    kw = dict(res_mode=2, sign_mask=m0)
+    da0, db0, s0 = ops.bn_act_bwd(d16.float(), None, a16.float(), va, b16.float(), vb, **kw)
+    da1, db1, s1 = ops.bn_act_bwd(d16, None, a16, va, b16, vb, da_bf16=True, db_bf16=True, **kw)
+    assert db1.dtype == torch.bfloat16 and torch.equal(db1, db0.to(torch.bfloat16)) and torch.equal(da1, da0.to(torch.bfloat16)) and torch.equal(s0, s1)
+    # the 1x1 (strided) weight gradient
+    x16, g16 = h16(B, T, V, cin, seed=84), h16(B, Tp, V, cout, seed=85)
+    gw0 = ops.rows_wgrad(x16.float(), g16.float(), K=cin, N=cout, tmap=(1, s, 0, 0, 1), conv_param=(1, cin))
+    gw1 = ops.rows_wgrad(x16, g16, K=cin, N=cout, tmap=(1, s, 0, 0, 1), conv_param=(1, cin))
+    assert torch.equal(gw0, gw1)
+    # the fused spatial backward: bfloat16 dy and x, float32 dx (plain and accumulating)
+    a = gpu(rnd(B, 3, V, V, seed=86, scale=0.3))
+    dy16 = h16(B, T, V, cout, seed=87)
+    w3 = ops.pack_split3(gpu(rnd(1, cout, 3 * cin, seed=88, scale=cout ** -0.5)))
+    base = gpu(rnd(B, T, V, cin, seed=89))
+    for acc in (False, True):
+        e0, e1 = base.clone(), base.clone()
+        p0 = ops.spatial_bwd_tile(dy16, x16.float(), a, w3, e0, accumulate=acc)
+        p1 = ops.spatial_bwd_tile(dy16, x16, a, w3, e1, accumulate=acc)
+        assert torch.equal(e0, e1) and torch.equal(p0, p1), acc
