@@ -153,7 +153,7 @@ SIGNATURES = {
     "fgcn_emb_fwd_tile_t": (_I, [_P] * 5 + [_I] * 8 + [_P]),
     "fgcn_spatial_bwd_tile_t": (_I, [_P] * 6 + [_I] * 10 + [_P, _I, _P, _P, _P, _I, _P]),
     "fgcn_spatial_wgrad_tile_t": (_I, [_P] * 4 + [_I] * 9 + [_P]),
-    "fgcn_emb_dx_tile_t": (_I, [_P] * 5 + [_I] * 10 + [_P]),
+    "fgcn_emb_dx_tile_t": (_I, [_P] * 5 + [_I] * 9 + [_P, _I, _P]),
     "fgcn_emb_wgrad_tile_t": (_I, [_P] * 5 + [_I] * 9 + [_P]),
     "fgcn_rows_gemm_t": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, TMap, _I, _I, _P]),
     "fgcn_pw_gemm_t": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _I, _I, _P]),

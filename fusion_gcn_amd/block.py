@@ -788,7 +788,13 @@ def _block_backward(d_o, S, P, W, cfg: BlockConfig, train: bool, need_dx: bool, 
         emb = S["emb"]
         if emb_tile_bwd:
             # demb on chip: dx += demb . Wemb, then (a leaf) dWemb = demb^T . x and the bias gradient
-            ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
+            if x16 and dx.dtype == torch.float32 and emb.dtype == torch.bfloat16 and dx_live:
+                # the last writer of this block's float32-accumulated dx hands it over as the bfloat16 tensor the bfloat16 input asks for
+                dx16_out = torch.empty(dx.shape, device=dev, dtype=torch.bfloat16)
+                ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx16_out, ic=ic, accumulate=True, dx_old=dx)
+                dx = dx16_out
+            else:
+                ops.emb_dx_tile(emb, d_s, W["emb_t_b3"], dx, ic=ic, accumulate=dx_live)
             gw, gb = ops.emb_wgrad_tile(emb, x_h if emb.dtype == torch.bfloat16 else xf(), d_s, ic=ic)
             gw = gw.view(6 * ic, cin_true, 1, 1)
         else:

@@ -118,6 +118,8 @@ struct EmbDxP {
     const unsigned char* planes;        // the split matrix planes of every sample (emb_planes_kernel)
     const void* w3;                     // fgcn_pack_split3 form of the (6 ic) x Cout matrix: [part][j / 8][c][8] bf16
     float* dx;
+    const float* dx_old;                // H16 bit 2: the accumulating form reads its old values from THIS float32 tensor (ld_dx floats per row) and
+    unsigned old_bytes;                 // writes the sums to the bfloat16 dx -- the block's last writer of dx converts on the way (no torch pass)
     int B, T, V, ic, Ce, Cout, ld_e, ld_dx, s_batched;
     unsigned ic_inv;                    // ceil(2^32 / ic): d / ic = the high word of d * ic_inv for d < 6 ic
     int F, tiles_t, tiles_m, tiles_n, per_xcd;
@@ -142,7 +144,8 @@ template <int NP> constexpr int ed_lds() { return NP * ED_PLANE + ED_NMAT * NP *
 template <int NP, int NT, int MAXU, bool ACC, int PD, int RSN, int H16 = 0>
 __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
     static_assert(!H16 || NP == 1, "bfloat16 tensors: the one-part kernel");
-    constexpr bool E16 = (H16 & 1) != 0, DX16 = (H16 & 2) != 0;
+    constexpr bool E16 = (H16 & 1) != 0, DX16 = (H16 & 2) != 0, OLD32 = (H16 & 4) != 0;
+    static_assert(!OLD32 || (DX16 && ACC), "float32 old values: the accumulating form with a bfloat16 dx");
     constexpr unsigned ES = E16 ? 2u : 4u;                           // bytes per stored emb value
     constexpr unsigned DS = DX16 ? 2u : 4u;                          // ... per dx value
     constexpr int MTW = 4, NU = 2 * NT, BN = 64 * NT, NW = 4;
@@ -187,7 +190,11 @@ __global__ __launch_bounds__(256, 2) void emb_dx_tile_kernel(EmbDxP p) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int nu = 0; nu < NU; ++nu) {
-                if constexpr (ACC && DX16)
+                if constexpr (OLD32)
+                    acc[mt][nu][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                   __builtin_amdgcn_make_buffer_rsrc((void*)p.dx_old, 0, p.old_bytes, 0x00020000),
+                                                                   lane_base * 2u + nu * 64, (unsigned)(mt * 16 + r) * dx_row_b * 2u, 0));
+                else if constexpr (ACC && DX16)
                     acc[mt][nu][r] = __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
                                                                    rdx, lane_base + nu * 32, (unsigned)(mt * 16 + r) * dx_row_b, 0) << 16);
                 else if constexpr (ACC && !(FGCN_PROBE_EMB & 16))
@@ -684,6 +691,18 @@ extern "C" long long fgcn_emb_dx_tile_workspace(int B, int d_s_batched) {
 // form exists for the one-part kernel
 template <int NP, int NT, int MU, bool ACC, int PD, int RS>
 static void ed_go(int e16, dim3 grid, hipStream_t s, const EmbDxP& p) {      // e16: 1 = emb bfloat16, 3 = emb and dx
+    if constexpr (NP == 1 && ACC) {
+        if (e16 == 7) {
+            static bool opted167 = false;
+            if (!opted167) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 7>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, ed_lds<NP>());
+                opted167 = true;
+            }
+            hipLaunchKernelGGL((emb_dx_tile_kernel<NP, NT, MU, ACC, PD, RS, 7>), grid, dim3(256), ed_lds<NP>(), s, p);
+            return;
+        }
+    }
     if constexpr (NP == 1) {
         if (e16 == 3) {
             static bool opted163 = false;
@@ -716,7 +735,7 @@ static void ed_go(int e16, dim3 grid, hipStream_t s, const EmbDxP& p) {      // 
 }
 
 static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
-                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16);
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16, const float* dx_old = nullptr);
 
 extern "C" int fgcn_emb_dx_tile(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
                                 int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream) {
@@ -730,16 +749,21 @@ extern "C" int fgcn_emb_dx_tile_h(const unsigned short* emb_h, const float* d_s,
                             1);
 }
 
-// typed form (math mode bf16): half_mask bit 0 = emb is a bfloat16 tensor, bit 1 = dx is (masks 0, 1, 3); strides in elements
+// typed form (math mode bf16): half_mask bit 0 = emb is a bfloat16 tensor, bit 1 = dx is (masks 0, 1, 3); strides in elements.
+// dx_old (mask 3, accumulate): a float32 tensor laid out like dx that holds the values to add to -- dx itself is then only written
+// (dx = bfloat16(dx_old + term): the last writer of a float32-accumulated gradient hands it over as bfloat16); NULL: dx is read and written.
 extern "C" int fgcn_emb_dx_tile_t(const void* emb, const float* d_s, const void* w3, void* dx, void* workspace, int B, int T, int V,
-                                  int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, int half_mask, void* stream) {
+                                  int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, const float* dx_old, int half_mask,
+                                  void* stream) {
     FGCN_REQUIRE(half_mask == 0 || half_mask == 1 || half_mask == 3, FGCN_E_BADARG, "emb_dx_tile_t: half_mask=%d (0, 1 or 3)", half_mask);
+    FGCN_REQUIRE(!dx_old || (half_mask == 3 && accumulate && aligned16(dx_old)), FGCN_E_BADARG,
+                 "emb_dx_tile_t: dx_old comes with a bfloat16 emb and dx and accumulation");
     return emb_dx_tile_impl(static_cast<const float*>(emb), d_s, w3, static_cast<float*>(dx), workspace, B, T, V, ic, Cx, ld_e, ld_dx, d_s_batched,
-                            accumulate, stream, half_mask);
+                            accumulate, stream, dx_old ? 7 : half_mask, dx_old);
 }
 
 static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, float* dx, void* workspace, int B, int T, int V, int ic, int Cx,
-                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16) {
+                            int ld_e, int ld_dx, int d_s_batched, int accumulate, void* stream, int e16, const float* dx_old) {
     FGCN_REQUIRE(emb && d_s && w3 && dx && workspace, FGCN_E_BADARG, "emb_dx_tile: null pointer");
     FGCN_REQUIRE(!e16 || fgcn::math_mode() == FGCN_MATH_BF16, FGCN_E_BADARG, "emb_dx_tile_h: bfloat16 tensors need math mode bf16");
     FGCN_REQUIRE(B > 0 && T > 0, FGCN_E_BADARG, "emb_dx_tile: bad sizes B=%d T=%d", B, T);
@@ -750,13 +774,14 @@ static int emb_dx_tile_impl(const float* emb, const float* d_s, const void* w3, 
     FGCN_REQUIRE(ld_e % 4 == 0 && ld_dx % 4 == 0 && ld_e >= Ce && ld_dx >= Cx, FGCN_E_ALIGN, "emb_dx_tile: row strides");
     FGCN_REQUIRE(aligned16(emb) && aligned16(w3) && aligned16(dx) && aligned16(workspace) && (reinterpret_cast<uintptr_t>(d_s) & 3u) == 0, FGCN_E_ALIGN,
                  "emb_dx_tile: 16-byte alignment");
-    const long long e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4), dx_bytes = (long long)B * T * V * ld_dx * (e16 == 3 ? 2 : 4);
+    const long long e_bytes = (long long)B * T * V * ld_e * (e16 ? 2 : 4), dx_bytes = (long long)B * T * V * ld_dx * ((e16 & 2) ? 2 : 4);
     const long long plane = (long long)Ce * Cx * 2;
     FGCN_REQUIRE(e_bytes < 0x7FFF0000ll && dx_bytes < 0x7FFF0000ll && plane * 3 < 0x7FFF0000ll, FGCN_E_BADARG,
                  "emb_dx_tile: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     const int np = fgcn::math_mode() == FGCN_MATH_BF16 ? 1 : 3;
     EmbDxP p;
     p.emb = emb; p.planes = static_cast<const unsigned char*>(workspace); p.w3 = w3; p.dx = dx;
+    p.dx_old = dx_old; p.old_bytes = dx_old ? (unsigned)(dx_bytes * 2) : 0u;
     p.B = B; p.T = T; p.V = V; p.ic = ic; p.Ce = Ce; p.Cout = Cx; p.ld_e = ld_e; p.ld_dx = ld_dx; p.s_batched = d_s_batched;
     p.ic_inv = (unsigned)(((1ull << 32) + (unsigned)ic - 1) / (unsigned)ic);
     p.F = 128 / V;

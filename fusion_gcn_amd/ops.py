@@ -1463,7 +1463,7 @@ def _chk_emb(name: str, emb: torch.Tensor, d_s: torch.Tensor, ic: int) -> None:
 
 
 def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torch.Tensor, *, ic: int, accumulate: bool,
-                cx: Optional[int] = None) -> torch.Tensor:
+                cx: Optional[int] = None, dx_old: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx (+)= demb . Wemb^T with the embedding gradient demb (d theta_k = dS_k . phi_k, d phi_k = dS_k^T . theta_k) formed on chip
     (fgcn_emb_tile.hip; backward of agcn.py:104-106).  emb (B,T,V,>=6 ic) = [th0 ph0 th1 ph1 th2 ph2], d_s (B or 1, 3, V, V),
     w3 = ``pack_split3`` of the (1, 6 ic, cx) matrix [j][c] = Wemb[j][c], dx (B,T,V,>=cx)."""
@@ -1481,9 +1481,13 @@ def emb_dx_tile(emb: torch.Tensor, d_s: torch.Tensor, w3: torch.Tensor, dx: torc
     lib = _lib.load()
     batched = int(d_s.shape[0] != 1)
     ws = torch.empty(lib.fgcn_emb_dx_tile_workspace(B, batched), device=emb.device, dtype=torch.uint8)      # the split planes of dS, dS^T
+    if dx_old is not None:      # dx = bfloat16(dx_old + term): the float32-accumulated gradient handed over as bfloat16 by its last writer
+        _chk(dx_old, "emb_dx_tile.dx_old")
+        if not (dx16 and accumulate) or tuple(dx_old.shape) != tuple(dx.shape):
+            raise _lib.FgcnError("emb_dx_tile: dx_old (float32, dx's shape) comes with a bfloat16 dx and accumulate=True")
     if dx16:
         check(lib.fgcn_emb_dx_tile_t(emb.data_ptr(), _p(d_s), w3.data_ptr(), dx.data_ptr(), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,
-                                     int(accumulate), 3, _stream()), "fgcn_emb_dx_tile_t")
+                                     int(accumulate), _p(dx_old), 3, _stream()), "fgcn_emb_dx_tile_t")
         return dx
     if emb.dtype == torch.bfloat16:
         check(lib.fgcn_emb_dx_tile_h(emb.data_ptr(), _p(d_s), w3.data_ptr(), _p(dx), ws.data_ptr(), B, T, V, ic, cx, ld_e, dx.shape[3], batched,

@@ -278,8 +278,10 @@ int fgcn_spatial_bwd_tile_t(const void* dy, const void* x, const float* a_hat, c
                             const unsigned char* mask2, int half_mask, void* stream);
 int fgcn_spatial_wgrad_tile_t(const void* x, const void* dy, const float* a_hat, float* partial, int B, int T, int V, int Cin,
                               int Cout, int ld_x, int ld_dy, int a_hat_batched, int half_mask, void* stream);
+/* dx_old (mask 3, accumulate; or NULL): the float32 tensor that holds the values to add to -- dx = bfloat16(dx_old + term) is then only written */
 int fgcn_emb_dx_tile_t(const void* emb, const float* d_s, const void* w3, void* dx, void* workspace, int B, int T, int V,
-                       int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, int half_mask, void* stream);
+                       int ic, int Cx, int ld_e, int ld_dx, int d_s_batched, int accumulate, const float* dx_old, int half_mask,
+                       void* stream);
 int fgcn_emb_wgrad_tile_t(const void* emb, const void* x, const float* d_s, float* partial, float* bias_partial, int B,
                           int T, int V, int ic, int Cx, int ld_e, int ld_x, int d_s_batched, int half_mask, void* stream);
 int fgcn_rows_gemm_t(const void* in, void* out, const float* w, const float* bias, float* stat_partials,

@@ -67,7 +67,7 @@ def test_host_side_validation(lib):
     assert b"half_mask" in lib.fgcn_last_error()
     assert lib.fgcn_tconv_halo_t(p16, p16, p16, None, None, 1, 4, 25, 32, 32, 32, 32, 4, 1, 0, 4, 4, 1, 0, 9, 1, -4, 2, None) == -1   # out without in
     assert lib.fgcn_spatial_bwd_tile_t(p16, p16, p16, p16, p16, p16, 1, 4, 25, 64, 64, 64, 64, 64, 1, 0, None, 0, None, None, None, 5, None) == -1
-    assert lib.fgcn_emb_dx_tile_t(p16, p16, p16, p16, p16, 1, 4, 25, 16, 64, 96, 64, 1, 0, 2, None) == -1
+    assert lib.fgcn_emb_dx_tile_t(p16, p16, p16, p16, p16, 1, 4, 25, 16, 64, 96, 64, 1, 0, None, 2, None) == -1
     mode = lib.fgcn_get_math_mode()
     lib.fgcn_set_math_mode(2)          # bf16x3: bfloat16 tensors are refused before anything is launched
     try:

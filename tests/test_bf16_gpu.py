@@ -693,6 +693,12 @@ def test_embedding_kernels_on_bfloat16_activations(V, T, cin, ic, B):
         ops.emb_dx_tile(e1, ds, wt, d0, ic=ic, accumulate=acc)
         ops.emb_dx_tile(e1, ds, wt, d1, ic=ic, accumulate=acc)
         assert torch.equal(d1, d0.to(torch.bfloat16)), acc
+    # dx = bfloat16(dx_old + term): float32 old values, bfloat16 result (the last writer of a float32-accumulated gradient converts on the way)
+    old = gpu(rnd(B, T, V, cin, seed=67))
+    d0, d1 = old.clone(), torch.empty(B, T, V, cin, device=dev(), dtype=torch.bfloat16)
+    ops.emb_dx_tile(e1, ds, wt, d0, ic=ic, accumulate=True)
+    ops.emb_dx_tile(e1, ds, wt, d1, ic=ic, accumulate=True, dx_old=old)
+    assert torch.equal(d1, d0.to(torch.bfloat16))
     for d in (ds, ds[:1]):
         gw0, gb0 = ops.emb_wgrad_tile(e1, x32, d, ic=ic)
         gw1, gb1 = ops.emb_wgrad_tile(e1, x16, d, ic=ic)
